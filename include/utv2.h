@@ -1,0 +1,119 @@
+/* utv2.h - C ABI of the MI355X (gfx950) kernels behind the Unbiased-Teacher-v2 training step.
+ *
+ * The reference (facebookresearch/unbiased-teacher-v2) is pure Python and has no FFI of its own;
+ * every entry point below replaces the native op the reference reaches through PyTorch /
+ * Detectron2 / fvcore / torchvision at the cited call site (paths relative to the reference
+ * root).  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller unless the name ends in _host;
+ *     tensors are contiguous fp32 / int32 / int64 / uint8 as declared;
+ *   - activations are NHWC ([N][H][W][C]); conv weights are [Cout][KH][KW][Cin];
+ *   - the last argument is the hipStream_t to launch on; nothing synchronises the stream,
+ *     nothing allocates; scratch memory is passed in (size from the *_workspace_* twin);
+ *   - return 0 on success, -(hipError_t) on a launch failure, -1000 on a bad argument.
+ *   - re-entrant; no global state.
+ */
+#ifndef UTV2_H
+#define UTV2_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* utv2_stream_t; /* == hipStream_t */
+
+/* ---- convolution (implicit GEMM on v_mfma_f32_32x32x2_f32) ------------------------------------
+ * Replaces ATen conv2d fwd / dgrad / wgrad reached from D2 ResNet/FPN, fcos/fcos.py:252-304
+ * (towers + prediction convs), backbone/fpn.py:21-22 (P6/P7) and the RCNN heads.
+ * y = relu?(conv(x,w) * scale[co] + bias[co] + residual) (+ y when accumulate).
+ * Kred = length of one weight row (KH*KW*C, or the 16-padded 208 for the C==4 stem image).
+ * in_dil > 1: transposed gather (dgrad of a strided conv) - see ubteacher/hip.py:conv2d_dgrad. */
+int utv2_conv2d_nhwc_fwd(const float* x, const float* w, float* y, const float* scale, const float* bias,
+                         const float* residual, int N, int H, int W, int C, int K, int KH, int KW, int stride, int pad,
+                         int in_dil, int OH, int OW, int relu, int accumulate, int Kred, utv2_stream_t stream);
+int utv2_conv2d_wgrad_splits(int N, int OH, int OW, int K, int Kred);
+int64_t utv2_conv2d_wgrad_workspace_floats(int N, int OH, int OW, int K, int Kred);
+/* dw[K][KH*KW*C] (+)= sum_m dy[m][k] * im2col(x)[m][:]; deterministic split reduction through ws. */
+int utv2_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw, float* ws, int N, int H, int W, int C, int K,
+                           int KH, int KW, int stride, int pad, int OH, int OW, int accumulate, utv2_stream_t stream);
+/* db[C] (+)= column sums of g[M][C] (conv bias gradient).  ws >= 64*C floats. */
+int utv2_colsum(const float* g, float* db, float* ws, int M, int C, int accumulate, utv2_stream_t stream);
+/* wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci]  (weight image consumed by dgrad) */
+int utv2_weight_flip_transpose(const float* w, float* wt, int K, int KH, int KW, int C, utv2_stream_t stream);
+
+/* ---- teacher EMA: engine/trainer.py:468-486 (FCOS), :950-968 (RCNN) --------------------------
+ * teacher = student*(1-keep) + teacher*keep, evaluated with the reference's three roundings. */
+int utv2_ema_axpby(float* teacher, const float* student, int64_t n, double keep_rate, utv2_stream_t stream);
+/* ---- SGD+momentum+weight-decay on a flat arena: torch.optim.SGD via D2 build_optimizer
+ * (engine/trainer.py:50,625; optimizer.step at :425-429,:912). */
+int utv2_sgd_momentum(float* param, float* grad, float* mom_buf, int64_t n, float lr, float momentum, float weight_decay,
+                      float grad_scale, int zero_grad, utv2_stream_t stream);
+
+/* ---- elementwise pieces of ResNet / FPN ([D2-recall]) ------------------ */
+int utv2_relu_bwd_scale(const float* dy, const float* y, const float* scale, float* out, int64_t M, int C,
+                        utv2_stream_t stream);
+int utv2_add(const float* a, const float* b, float* out, int64_t n, utv2_stream_t stream);
+int utv2_maxpool3x3s2_nhwc(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, utv2_stream_t stream);
+int utv2_upsample2x_add_nhwc(const float* lateral, const float* top, float* out, int N, int H, int W, int C,
+                             utv2_stream_t stream);
+int utv2_downsample2x_sum_nhwc(const float* g, float* dtop, int N, int TH, int TW, int C, int accumulate,
+                               utv2_stream_t stream);
+/* modeling/one_stage_detector.py:88-90 / meta_arch/rcnn.py:18 (preprocess_image + ImageList pad) */
+int utv2_preprocess_image(const void* src, int is_u8, float* dst, int H, int W, int Hp, int Wp,
+                          const float* mean3_host, const float* std3_host, utv2_stream_t stream);
+/* D2 FrozenBatchNorm2d.forward: scale = w*rsqrt(var+eps), shift = b - mean*scale, all layers at once */
+int utv2_frozenbn_fold(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift,
+                       int n, float eps, utv2_stream_t stream);
+/* GroupNorm(32)+ReLU of the FCOS towers: fcos/fcos.py:263-264,283 */
+int64_t utv2_groupnorm_workspace_floats(int N, int HW, int C);
+int utv2_groupnorm_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                            float* ws, int N, int HW, int C, int G, float eps, int relu, utv2_stream_t stream);
+int utv2_groupnorm_relu_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
+                            const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws, int N, int HW, int C,
+                            int G, int relu, utv2_stream_t stream);
+
+/* ---- FCOS targets / losses / decode: modeling/fcos/fcos_outputs.py --------------------------- */
+/* :649-698,:772-906 (CENTER_SAMPLE False).  H,W,strides,soi are HOST arrays. */
+int utv2_fcos_targets(int num_levels, const int* H_host, const int* W_host, const int* strides_host,
+                      const float* soi_host, int N, int MAXG, const float* gt_boxes, const int* gt_classes,
+                      const unsigned char* gt_valid, const float* gt_std, int num_classes, int drop_empty, int* labels,
+                      float* reg_targets, float* bvars, int* gt_inds, utv2_stream_t stream);
+/* fvcore sigmoid_focal_loss_jit at :329-338,:619-628 with on-the-fly one-hot.  ws >= 1024 floats */
+int utv2_sigmoid_focal_fwd(const float* logits, const int* labels, int64_t P, int C, float alpha, float gamma,
+                           float* loss_sum, float* ws, utv2_stream_t stream);
+int utv2_sigmoid_focal_bwd(const float* logits, const int* labels, int64_t P, int C, float alpha, float gamma,
+                           const float* coef, float* dlogits, utv2_stream_t stream);
+/* :340-416 / :514-590 fused over positive locations: Integral(:44-77), centerness target + BCE,
+ * GIoU (layers/iou_loss.py:26-76), NLL (layers/kl_loss.py:69-105), TS-better L1 (:552-569).
+ * sums[8] = {n_pos, sum ctr_t, sum bce, sum giou*ctr_t, sum nll*iou, n_sel, sum_sel|d-t|, 0}
+ * ws >= 4096 floats. */
+int utv2_fcos_loc_terms_fwd(const int* labels, const float* box, int box_stride, const float* reg_targets,
+                            const float* bvars, int64_t P, int num_classes, int reg_max, float ts_better, float ts_cert,
+                            float* sums, float* ws, utv2_stream_t stream);
+int utv2_fcos_loc_terms_bwd(const int* labels, const float* box, int box_stride, const float* reg_targets,
+                            const float* bvars, int64_t P, int num_classes, int reg_max, float ts_better, float ts_cert,
+                            const float* coef, float* dbox, utv2_stream_t stream);
+/* :1146-1195 ranking score -> sortable int64 key (method 0 cls, 1 cls_n_ctr, 2 ctr, 3 cls_n_loc) */
+int utv2_fcos_rank_keys(const float* logits, const float* box, int box_stride, int reg_max, int N, int HW, int C,
+                        float thr, int method, long long* keys, utv2_stream_t stream);
+/* :1093-1104,:1258-1296 decode of the selected candidates of one level into padded slots */
+int utv2_fcos_decode(const long long* topkeys, int K, const float* logits, const float* box, int box_stride, int reg_max,
+                     int N, int HW, int Wl, int C, int stride, int level, int method, int MAXC, int slot0, float* oboxes,
+                     float* oscores, int* ocls, float* oloc, float* octr, float* oconf, float* ostd, int* olevel,
+                     unsigned char* ovalid, utv2_stream_t stream);
+/* Scale layer fcos/fcos.py:22-28,356-357 on the first ncols columns of strided rows */
+int utv2_scale_cols(float* y, int64_t rows, int row_stride, int ncols, const float* s, utv2_stream_t stream);
+int utv2_scale_cols_bwd(float* g, const float* ypost, int64_t rows, int row_stride, int ncols, const float* s, float* dsum,
+                        float* ws, utv2_stream_t stream);
+
+/* ---- NMS / IoU: layers/ml_nms.py:27, D2 batched_nms / pairwise_iou ---------------------------- */
+int utv2_nms_mpad(int M);
+int64_t utv2_nms_workspace_bytes(int N, int M);
+int utv2_nms_batched(const float* boxes, const float* scores, const int* cls, const unsigned char* valid, int N, int M,
+                     float iou_thr, int class_aware, int post_topk, int max_out, int* keep, int* keep_count, void* ws,
+                     utv2_stream_t stream);
+int utv2_box_iou(const float* a, const float* b, int A, int B, float* out, utv2_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,560 @@
+"""CPU ORACLE for the Unbiased-Teacher-v2 hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch (CPU, fp32) restatement of the reference's algorithm for the
+training-step path, used ONLY by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+as the checker / the timed CPU port.  The product (unbiased-teacher-v2_amd/) never imports it.
+
+Pinning status
+  * reference-owned arithmetic (FCOS targets / losses / decode, IOULoss, NLLoss, Integral,
+    pseudo-label thresholding, EMA, loss weighting): PINNED against golden vectors produced by
+    executing the reference's own modules in the build container
+    (tests/golden/gen_golden.py -> tests/golden/*.npz, checked by tests/test_oracle_golden.py).
+  * Detectron2 / fvcore / torchvision primitives (ResNet-50, FPN, FrozenBN, batched_nms, focal
+    loss, SGD): those libraries are NOT in /root/reference nor installed (detectron2 >= 0.6
+    unpinned commit, fvcore unpinned, torchvision "matching torch" - reference README.md:26-27,44),
+    so they are restated here from their published behaviour and are
+    "parity unpinned" beyond textbook known-answer tests and stock torch.nn.functional.
+
+Every function cites the reference file:line it follows (paths relative to the reference root).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+INF = 100000000
+
+
+# =================================================================================================
+# Third-party primitives (restated)
+# =================================================================================================
+def sigmoid_focal_loss(inputs, targets, alpha=0.25, gamma=2.0):
+    """fvcore.nn.sigmoid_focal_loss (reduction none) - called at fcos_outputs.py:329-335,619-625."""
+    p = torch.sigmoid(inputs)
+    ce = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = p * targets + (1 - p) * (1 - targets)
+    loss = ce * ((1 - p_t) ** gamma)
+    if alpha >= 0:
+        loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    return loss
+
+
+def nms(boxes, scores, thr):
+    """torchvision.ops.nms semantics with the tie rule declared for this project:
+    order = (score desc, index asc); suppress when inter/(a_i+a_j-inter) > thr (strict).
+    Returns kept indices in descending-score order (int64)."""
+    b = boxes.detach().cpu().numpy().astype(np.float32)
+    s = scores.detach().cpu().numpy().astype(np.float32)
+    n = len(s)
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int64)
+    order = np.lexsort((np.arange(n), -s.astype(np.float64)))  # primary -s, secondary index
+    x1, y1, x2, y2 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    areas = (x2 - x1) * (y2 - y1)
+    suppressed = np.zeros(n, dtype=bool)
+    keep = []
+    for ii in range(n):
+        i = order[ii]
+        if suppressed[i]:
+            continue
+        keep.append(i)
+        rest = order[ii + 1:]
+        xx1 = np.maximum(x1[i], x1[rest]); yy1 = np.maximum(y1[i], y1[rest])
+        xx2 = np.minimum(x2[i], x2[rest]); yy2 = np.minimum(y2[i], y2[rest])
+        w = np.maximum(np.float32(0), xx2 - xx1); h = np.maximum(np.float32(0), yy2 - yy1)
+        inter = (w * h).astype(np.float32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ovr = inter / (areas[i] + areas[rest] - inter)
+        suppressed[rest[ovr > np.float32(thr)]] = True
+    return torch.as_tensor(np.array(keep, dtype=np.int64))
+
+
+def batched_nms(boxes, scores, idxs, thr):
+    """torchvision batched_nms, coordinate-trick form (D2 batched_nms -> ml_nms.py:27):
+    boxes + idxs * (max_coordinate + 1) in fp32, then plain nms."""
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64)
+    max_coordinate = boxes.max()
+    offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+    return nms(boxes + offsets[:, None], scores, thr)
+
+
+def pairwise_iou(a, b):
+    """D2 pairwise_iou [D2-recall]."""
+    area1 = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area2 = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    wh = (torch.min(a[:, None, 2:], b[:, 2:]) - torch.max(a[:, None, :2], b[:, :2])).clamp(min=0)
+    inter = wh.prod(dim=2)
+    return torch.where(inter > 0, inter / (area1[:, None] + area2 - inter), torch.zeros(1, dtype=inter.dtype))
+
+
+def frozen_bn(x, sd, prefix, eps=1e-5):
+    """D2 FrozenBatchNorm2d.forward [D2-recall]."""
+    scale = sd[prefix + ".weight"] * (sd[prefix + ".running_var"] + eps).rsqrt()
+    bias = sd[prefix + ".bias"] - sd[prefix + ".running_mean"] * scale
+    return x * scale.reshape(1, -1, 1, 1) + bias.reshape(1, -1, 1, 1)
+
+
+def resnet50(sd, x, prefix, out_features):
+    """D2 ResNet-50, STRIDE_IN_1X1 True, FrozenBN [D2-recall, SURVEY appendix C]."""
+    outs = {}
+    x = F.conv2d(x, sd[prefix + ".stem.conv1.weight"], None, 2, 3)
+    x = F.relu(frozen_bn(x, sd, prefix + ".stem.conv1.norm"))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for name, nblocks in (("res2", 3), ("res3", 4), ("res4", 6), ("res5", 3)):
+        for b in range(nblocks):
+            p = "%s.%s.%d" % (prefix, name, b)
+            stride = 2 if (b == 0 and name != "res2") else 1
+            if (p + ".shortcut.weight") in sd:
+                sc = frozen_bn(F.conv2d(x, sd[p + ".shortcut.weight"], None, stride), sd, p + ".shortcut.norm")
+            else:
+                sc = x
+            o = F.relu(frozen_bn(F.conv2d(x, sd[p + ".conv1.weight"], None, stride), sd, p + ".conv1.norm"))
+            o = F.relu(frozen_bn(F.conv2d(o, sd[p + ".conv2.weight"], None, 1, 1), sd, p + ".conv2.norm"))
+            o = frozen_bn(F.conv2d(o, sd[p + ".conv3.weight"], None, 1), sd, p + ".conv3.norm")
+            x = F.relu(o + sc)
+        if name in out_features:
+            outs[name] = x
+    return outs
+
+
+def fpn(sd, feats, in_features, top="p6p7", prefix="backbone"):
+    """D2 FPN (sum fuse, no norm) + LastLevelP6P7 from P5 (backbone/fpn.py:11-29,65) or LastLevelMaxPool."""
+    stage = {"res2": 2, "res3": 3, "res4": 4, "res5": 5}
+    res = {}
+    prev = None
+    for f in reversed(in_features):
+        s = stage[f]
+        lat = F.conv2d(feats[f], sd["%s.fpn_lateral%d.weight" % (prefix, s)], sd["%s.fpn_lateral%d.bias" % (prefix, s)])
+        if prev is not None:
+            lat = lat + F.interpolate(prev, scale_factor=2.0, mode="nearest")
+        prev = lat
+        res["p%d" % s] = F.conv2d(lat, sd["%s.fpn_output%d.weight" % (prefix, s)], sd["%s.fpn_output%d.bias" % (prefix, s)], 1, 1)
+    last = stage[in_features[-1]]
+    if top == "p6p7":
+        p6 = F.conv2d(res["p%d" % last], sd[prefix + ".top_block.p6.weight"], sd[prefix + ".top_block.p6.bias"], 2, 1)
+        p7 = F.conv2d(F.relu(p6), sd[prefix + ".top_block.p7.weight"], sd[prefix + ".top_block.p7.bias"], 2, 1)
+        res["p%d" % (last + 1)] = p6
+        res["p%d" % (last + 2)] = p7
+    elif top == "maxpool":
+        res["p%d" % (last + 1)] = F.max_pool2d(res["p%d" % last], kernel_size=1, stride=2, padding=0)
+    return res
+
+
+def preprocess(images, mean, std, div):
+    """one_stage_detector.py:88-90: normalise, ImageList.from_tensors(pad to divisibility)."""
+    ims = [(x.float() - mean) / std for x in images]
+    sizes = [(t.shape[-2], t.shape[-1]) for t in ims]
+    hm, wm = max(s[0] for s in sizes), max(s[1] for s in sizes)
+    hm, wm = (hm + div - 1) // div * div, (wm + div - 1) // div * div
+    out = ims[0].new_zeros((len(ims), 3, hm, wm))
+    for i, t in enumerate(ims):
+        out[i, :, : t.shape[-2], : t.shape[-1]] = t
+    return out, sizes
+
+
+# =================================================================================================
+# FCOS head (fcos/fcos.py:220-376)
+# =================================================================================================
+def fcos_head(sd, feats, num_levels=5, prefix="proposal_generator.fcos_head"):
+    logits, reg, std, ctr = [], [], [], []
+    for l, f in enumerate(feats):
+        def tower(name, x):
+            i = 0
+            while "%s.%s_tower.%d.weight" % (prefix, name, 3 * i) in sd:
+                x = F.conv2d(x, sd["%s.%s_tower.%d.weight" % (prefix, name, 3 * i)], sd["%s.%s_tower.%d.bias" % (prefix, name, 3 * i)], 1, 1)
+                x = F.group_norm(x, 32, sd["%s.%s_tower.%d.weight" % (prefix, name, 3 * i + 1)], sd["%s.%s_tower.%d.bias" % (prefix, name, 3 * i + 1)])
+                x = F.relu(x)
+                i += 1
+            return x
+        f = tower("share", f)
+        ct, bt = tower("cls", f), tower("bbox", f)
+        logits.append(F.conv2d(ct, sd[prefix + ".cls_logits.weight"], sd[prefix + ".cls_logits.bias"], 1, 1))
+        ctr.append(F.conv2d(bt, sd[prefix + ".ctrness.weight"], sd[prefix + ".ctrness.bias"], 1, 1))
+        r = F.conv2d(bt, sd[prefix + ".bbox_pred.weight"], sd[prefix + ".bbox_pred.bias"], 1, 1)
+        key = "%s.scales.%d.scale" % (prefix, l)
+        if key in sd:
+            r = r * sd[key]
+        reg.append(r)  # REG_DISCRETE: no relu (fcos.py:360-364)
+        std.append(F.conv2d(bt, sd[prefix + ".bbox_pred_std.weight"], sd[prefix + ".bbox_pred_std.bias"], 1, 1))
+    return logits, reg, std, ctr
+
+
+def compute_locations(h, w, stride):
+    """utils/comm.py:34-45."""
+    sx = torch.arange(0, w * stride, step=stride, dtype=torch.float32)
+    sy = torch.arange(0, h * stride, step=stride, dtype=torch.float32)
+    yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+    return torch.stack((xx.reshape(-1), yy.reshape(-1)), dim=1) + stride // 2
+
+
+# =================================================================================================
+# FCOSOutputs restatement (fcos/fcos_outputs.py)
+# =================================================================================================
+def integral(x, reg_max=16):
+    """fcos_outputs.py:44-77."""
+    p = F.softmax(x.reshape(-1, reg_max + 1), dim=1)
+    return F.linear(p, torch.linspace(0, reg_max, reg_max + 1)).reshape(-1, 4)
+
+
+def ctrness_targets(t):
+    """fcos_outputs.py:80-88."""
+    if len(t) == 0:
+        return t.new_zeros(len(t))
+    lr, tb = t[:, [0, 2]], t[:, [1, 3]]
+    return torch.sqrt((lr.min(dim=-1)[0] / lr.max(dim=-1)[0]) * (tb.min(dim=-1)[0] / tb.max(dim=-1)[0]))
+
+
+def iou_targets(pred, target):
+    """fcos_outputs.py:91-129."""
+    if len(target) == 0:
+        return target.new_zeros(len(target))
+    ta = (target[:, 0] + target[:, 2]) * (target[:, 1] + target[:, 3])
+    pa = (pred[:, 0] + pred[:, 2]) * (pred[:, 1] + pred[:, 3])
+    wi = torch.min(pred[:, 0], target[:, 0]) + torch.min(pred[:, 2], target[:, 2])
+    hi = torch.min(pred[:, 3], target[:, 3]) + torch.min(pred[:, 1], target[:, 1])
+    ai = wi * hi
+    return (ai + 1.0) / (ta + pa - ai + 1.0)
+
+
+def giou_loss_ltrb(pred, target, weight=None):
+    """layers/iou_loss.py:20-76 with loc_loss_type 'giou'."""
+    ta = (target[:, 0] + target[:, 2]) * (target[:, 1] + target[:, 3])
+    pa = (pred[:, 0] + pred[:, 2]) * (pred[:, 1] + pred[:, 3])
+    wi = torch.min(pred[:, 0], target[:, 0]) + torch.min(pred[:, 2], target[:, 2])
+    hi = torch.min(pred[:, 3], target[:, 3]) + torch.min(pred[:, 1], target[:, 1])
+    gw = torch.max(pred[:, 0], target[:, 0]) + torch.max(pred[:, 2], target[:, 2])
+    gh = torch.max(pred[:, 3], target[:, 3]) + torch.max(pred[:, 1], target[:, 1])
+    ac = gw * gh
+    ai = wi * hi
+    au = ta + pa - ai
+    ious = (ai + 1.0) / (au + 1.0)
+    gious = ious - (ac - au) / ac
+    losses = 1 - gious
+    return (losses * weight).sum() if weight is not None else losses.sum()
+
+
+def nl_loss(inp, inp_std, target, iou_weight):
+    """layers/kl_loss.py:69-105 (NLLoss)."""
+    sigma = inp_std.sigmoid()
+    sq = torch.square(sigma)
+    first = torch.square(target - inp) / (2 * sq)
+    second = 0.5 * torch.log(sq)
+    s = (first + second).sum(dim=1) + 2 * torch.log(2 * torch.Tensor([math.pi]))
+    return (s * iou_weight).mean()
+
+
+class FCOSCfg:
+    """The FCOSOutputs constructor state (fcos_outputs.py:133-208) for the shipped UTv2 FCOS configs."""
+
+    def __init__(self, **kw):
+        self.alpha, self.gamma = 0.25, 2.0
+        self.num_classes = 80
+        self.strides = [8, 16, 32, 64, 128]
+        self.soi_edges = [64, 128, 256, 512]
+        self.reg_max = 16
+        self.kl_weight = 0.05
+        self.ts_better, self.ts_better_cert = 0.1, 0.8
+        self.pre_nms_thresh, self.pre_nms_topk, self.post_nms_topk = 0.05, 1000, 100
+        self.nms_thresh = 0.6
+        self.unify_ctrcls = False
+        self.__dict__.update(kw)
+        soi, prev = [], -1
+        for s in self.soi_edges:
+            soi.append([prev, s])
+            prev = s
+        soi.append([prev, INF])
+        self.soi = soi
+
+
+def fcos_targets(cfg, locations, gts):
+    """fcos_outputs.py:649-698 + 772-906 (CENTER_SAMPLE False, ignore_near False).
+    gts: list of dict(boxes [G,4], classes [G] long, reg_pred_std [G,4] optional).
+    Returns level-first dict of lists (labels, reg_targets (stride-normalised), boundary_vars, target_inds,
+    keep_locations)."""
+    num_loc = [len(l) for l in locations]
+    size_ranges = torch.cat([torch.tensor(cfg.soi[i], dtype=torch.float32)[None].expand(n, -1) for i, n in enumerate(num_loc)])
+    locs = torch.cat(locations, dim=0)
+    xs, ys = locs[:, 0], locs[:, 1]
+    out = {k: [] for k in ("labels", "reg_targets", "target_inds", "keep_locations", "boundary_vars")}
+    num_targets = 0
+    for g in gts:
+        bboxes, labels_im = g["boxes"], g["classes"]
+        bvar_im = g["reg_pred_std"] if g.get("reg_pred_std") is not None else torch.zeros_like(bboxes)
+        L = locs.size(0)
+        if bboxes.numel() == 0:
+            out["labels"].append(labels_im.new_zeros(L) + cfg.num_classes)
+            out["reg_targets"].append(locs.new_zeros((L, 4)))
+            out["boundary_vars"].append(locs.new_zeros((L, 4)))
+            out["target_inds"].append(labels_im.new_zeros(L) - 1)
+            out["keep_locations"].append(torch.zeros(L, dtype=torch.bool))
+            continue
+        area = (bboxes[:, 2] - bboxes[:, 0]) * (bboxes[:, 3] - bboxes[:, 1])
+        l = xs[:, None] - bboxes[:, 0][None]
+        t = ys[:, None] - bboxes[:, 1][None]
+        r = bboxes[:, 2][None] - xs[:, None]
+        b = bboxes[:, 3][None] - ys[:, None]
+        reg = torch.stack([l, t, r, b], dim=2)
+        is_in = reg.min(dim=2)[0] > 0
+        mx = reg.max(dim=2)[0]
+        cared = (mx >= size_ranges[:, [0]]) & (mx <= size_ranges[:, [1]])
+        a = area[None].repeat(L, 1)
+        a[is_in == 0] = INF
+        a[cared == 0] = INF
+        amin, ginds = a.min(dim=1)
+        reg = reg[range(L), ginds]
+        tinds = ginds + num_targets
+        num_targets += len(bboxes)
+        lab = labels_im[ginds].clone()
+        lab[amin == INF] = cfg.num_classes
+        bv = bvar_im[ginds].clone()
+        bv[amin == INF] = 99999.0
+        out["labels"].append(lab)
+        out["reg_targets"].append(reg)
+        out["target_inds"].append(tinds)
+        out["keep_locations"].append(torch.ones(L, dtype=torch.bool))
+        out["boundary_vars"].append(bv)
+
+    def transpose(lst):
+        per_im = [torch.split(x, num_loc, dim=0) for x in lst]
+        return [torch.cat(lv, dim=0) for lv in zip(*per_im)]
+
+    out = {k: transpose(v) for k, v in out.items()}
+    for la in range(len(out["reg_targets"])):
+        out["reg_targets"][la] = out["reg_targets"][la] / float(cfg.strides[la])
+    return out
+
+
+def _flatten_preds(cfg, logits, reg, std, ctr):
+    """fcos_outputs.py:261-290: NCHW per level -> level-first [P, C]."""
+    R = 4 * (cfg.reg_max + 1)
+    lg = torch.cat([x.permute(0, 2, 3, 1).reshape(-1, cfg.num_classes) for x in logits])
+    rg = torch.cat([x.permute(0, 2, 3, 1).reshape(-1, R) for x in reg])
+    sd_ = torch.cat([x.permute(0, 2, 3, 1).reshape(-1, 4) for x in std])
+    ct = torch.cat([x.permute(0, 2, 3, 1).reshape(-1) for x in ctr])
+    return lg, rg, sd_, ct
+
+
+def fcos_losses(cfg, logits, reg, std, ctr, locations, gts, world_size=1):
+    """Supervised branch: fcos_outputs.py:212-444 (branch 'labeled')."""
+    tg = fcos_targets(cfg, locations, gts)
+    labels = torch.cat([x.reshape(-1) for x in tg["labels"]])
+    keep = torch.cat([x.reshape(-1) for x in tg["keep_locations"]])
+    regt = torch.cat([x.reshape(-1, 4) for x in tg["reg_targets"]])
+    lg, rg, sdv, ct = _flatten_preds(cfg, logits, reg, std, ctr)
+    any_keep = keep.sum() > 0
+    if any_keep:  # :310-311
+        labels, regt, lg, rg, sdv, ct = labels[keep], regt[keep], lg[keep], rg[keep], sdv[keep], ct[keep]
+    pos = torch.nonzero(labels != cfg.num_classes).squeeze(1)
+    num_pos_avg = max(pos.numel() / world_size, 1.0)
+    tgt = torch.zeros_like(lg)
+    tgt[pos, labels[pos]] = 1
+    class_loss = sigmoid_focal_loss(lg, tgt, cfg.alpha, cfg.gamma).sum(1).sum() / num_pos_avg
+    rg, sdv, ct, regt = rg[pos], sdv[pos], ct[pos], regt[pos]
+    reg_pred = integral(rg, cfg.reg_max) if pos.numel() > 0 else rg
+    ctr_t = ctrness_targets(regt)
+    loss_denorm = max(ctr_t.sum().item() / world_size, 1e-6)
+    if pos.numel() > 0:
+        iou_t = iou_targets(reg_pred.detach(), regt)
+        ctr_loss = F.binary_cross_entropy_with_logits(ct, ctr_t, reduction="sum") / num_pos_avg
+        nll = cfg.kl_weight * nl_loss(reg_pred, sdv, regt, iou_t)  # :400
+        iou_loss = giou_loss_ltrb(reg_pred, regt, ctr_t) / loss_denorm
+        reg_loss = cfg.kl_weight * nll + iou_loss  # :416 (weight applied twice)
+    else:
+        reg_loss = torch.tensor(0.0)
+        ctr_loss = torch.tensor(0.0)
+    if not any_keep:  # :430-434
+        class_loss, reg_loss, ctr_loss = class_loss * 0, reg_loss * 0, ctr_loss * 0
+    return {"loss_fcos_cls": class_loss, "loss_fcos_loc": reg_loss, "loss_fcos_ctr": ctr_loss}, tg
+
+
+def fcos_pseudo_losses(cfg, logits, reg, std, ctr, locations, gt_dict, world_size=1):
+    """Unsupervised branch: fcos_outputs.py:447-631 (cls set -> cls+ctr; reg set -> loc)."""
+    losses, extras = {}, {}
+    lg, rg, sdv, ct = _flatten_preds(cfg, logits, reg, std, ctr)
+    for labeltype, gts in gt_dict.items():
+        tg = fcos_targets(cfg, locations, gts)
+        extras[labeltype] = tg
+        labels = torch.cat([x.reshape(-1) for x in tg["labels"]])
+        regt = torch.cat([x.reshape(-1, 4) for x in tg["reg_targets"]])
+        bvar = torch.cat([x.reshape(-1, 4) for x in tg["boundary_vars"]])
+        pos = torch.nonzero(labels != cfg.num_classes).squeeze(1)
+        num_pos_avg = max(pos.numel() / world_size, 1.0)
+        if labeltype == "cls":
+            tgt = torch.zeros_like(lg)
+            tgt[pos, labels[pos]] = 1
+            losses["loss_fcos_cls"] = sigmoid_focal_loss(lg, tgt, cfg.alpha, cfg.gamma).sum(1).sum() / num_pos_avg
+        ctr_t = ctrness_targets(regt[pos])
+        if pos.numel() > 0:
+            if labeltype == "cls":
+                cl = F.binary_cross_entropy_with_logits(ct[pos], ctr_t, reduction="sum") / num_pos_avg
+                losses["loss_fcos_ctr"] = cl * 0 if cfg.unify_ctrcls else cl
+            else:
+                reg_pred = integral(rg[pos], cfg.reg_max)
+                conf_s = 1 - sdv[pos].sigmoid()
+                conf_t = 1 - bvar[pos].sigmoid()
+                select = (conf_t > cfg.ts_better_cert) * (conf_t > conf_s + cfg.ts_better)
+                losses["teacher_better_student"] = select.sum()
+                if select.sum() > 0:
+                    losses["loss_fcos_loc"] = F.smooth_l1_loss(reg_pred[select], regt[pos][select], beta=0.0)
+                else:
+                    losses["loss_fcos_loc"] = torch.tensor(0.0)
+        else:
+            if labeltype == "cls":
+                losses["loss_fcos_ctr"] = torch.tensor(0.0)
+            else:
+                losses["loss_fcos_loc"] = torch.tensor(0.0)
+                losses["teacher_better_student"] = torch.tensor(0.0)
+    return losses, extras
+
+
+def fcos_predict(cfg, logits, reg, std, ctr, locations, image_sizes, nms_method):
+    """fcos_outputs.py:1046-1320.  Returns per image a dict of tensors (post NMS, kthvalue top-k rule).
+    Pre-NMS top-k: (ranking score desc, flat (loc,class) index asc) - the order upstream leaves open."""
+    N = logits[0].shape[0]
+    per_im = [[] for _ in range(N)]
+    for lvl, (loc, o, r, c, sd_) in enumerate(zip(locations, logits, reg, ctr, std)):
+        n, C, H, W = o.shape
+        s = cfg.strides[lvl]
+        rs = integral(r.permute(0, 2, 3, 1).reshape(-1, 4 * (cfg.reg_max + 1)), cfg.reg_max).reshape(n, H * W, 4) * s
+        p = o.permute(0, 2, 3, 1).reshape(n, -1, C).sigmoid()
+        cs = c.permute(0, 2, 3, 1).reshape(n, -1).sigmoid()
+        st = sd_.permute(0, 2, 3, 1).reshape(n, -1, 4)
+        cand = p > cfg.pre_nms_thresh
+        if nms_method == "cls_n_ctr":
+            rank = p * cs[:, :, None]
+        elif nms_method == "cls":
+            rank = p
+        elif nms_method == "ctr":
+            rank = cs[:, :, None].expand_as(p)
+        elif nms_method == "cls_n_loc":
+            rank = p * (1 - st.sigmoid()).mean(2)[:, :, None]
+        else:
+            raise ValueError("Undefined nms criteria")
+        for i in range(n):
+            nz = cand[i].nonzero()
+            bl, cl = nz[:, 0], nz[:, 1]
+            rk = rank[i][cand[i]]
+            k = min(int(cand[i].sum()), cfg.pre_nms_topk)
+            if len(rk) > k:
+                flat = bl * C + cl
+                order = np.lexsort((flat.numpy(), -rk.numpy().astype(np.float64)))[:k]
+                order = torch.as_tensor(order)
+                bl, cl, rk = bl[order], cl[order], rk[order]
+            box = torch.stack([loc[bl, 0] - rs[i][bl, 0], loc[bl, 1] - rs[i][bl, 1],
+                               loc[bl, 0] + rs[i][bl, 2], loc[bl, 1] + rs[i][bl, 3]], dim=1)
+            sc = torch.sqrt(rk) if nms_method in ("cls_n_ctr", "cls_n_loc") else rk
+            per_im[i].append(dict(boxes=box, scores=sc, classes=cl, locations=loc[bl], centerness=cs[i][bl],
+                                  cls_confid=p[i][bl, cl], reg_pred_std=st[i][bl],
+                                  fpn_levels=torch.full((len(bl),), lvl, dtype=torch.long)))
+    results = []
+    for i in range(N):
+        d = {k: torch.cat([x[k] for x in per_im[i]]) for k in per_im[i][0]}
+        keep = batched_nms(d["boxes"], d["scores"], d["classes"], cfg.nms_thresh)
+        d = {k: v[keep] for k, v in d.items()}
+        nd = len(keep)
+        if nd > cfg.post_nms_topk > 0:
+            thr, _ = torch.kthvalue(d["scores"], nd - cfg.post_nms_topk + 1)
+            kk = torch.nonzero(d["scores"] >= thr.item()).squeeze(1)
+            d = {k: v[kk] for k, v in d.items()}
+        d["image_size"] = image_sizes[i]
+        results.append(d)
+    return results
+
+
+def threshold_bbox(det, thr):
+    """pseudo_generator.py:62-105 ('roih')."""
+    m = det["scores"] > thr
+    return dict(boxes=det["boxes"][m], classes=det["classes"][m], scores=det["scores"][m],
+                centerness=det["centerness"][m], cls_confid=det["cls_confid"][m], reg_pred_std=det["reg_pred_std"][m])
+
+
+# =================================================================================================
+# EMA / SGD / step
+# =================================================================================================
+def ema_update(student_sd, teacher_sd, keep_rate):
+    """engine/trainer.py:468-486."""
+    new = OrderedDict()
+    for k, v in teacher_sd.items():
+        if k not in student_sd:
+            raise Exception("{} is not found in student model".format(k))
+        new[k] = student_sd[k] * (1 - keep_rate) + v * keep_rate
+    return new
+
+
+def sgd_step(params, grads, bufs, lr, momentum, wd):
+    """torch.optim.SGD (momentum, dampening 0, no nesterov) on dicts of tensors; wd: dict name->float."""
+    for k, p in params.items():
+        g = grads[k] + wd[k] * p
+        b = momentum * bufs[k] + g if k in bufs else g.clone()
+        bufs[k] = b
+        params[k] = p - lr * b
+    return params, bufs
+
+
+def is_norm_param(key):
+    return ("_tower." in key and int(key.split(".")[-2]) % 3 == 1)
+
+
+def fcos_forward(sd, images, mean, std_pix, trainable_keys=None):
+    x, sizes = preprocess(images, mean, std_pix, 32)
+    c = resnet50(sd, x, "backbone.bottom_up", ("res3", "res4", "res5"))
+    p = fpn(sd, c, ["res3", "res4", "res5"], "p6p7")
+    feats = [p[k] for k in ("p3", "p4", "p5", "p6", "p7")]
+    logits, reg, sdv, ctr = fcos_head(sd, feats)
+    locations = [compute_locations(f.shape[2], f.shape[3], s) for f, s in zip(feats, [8, 16, 32, 64, 128])]
+    return logits, reg, sdv, ctr, locations, sizes
+
+
+def fcos_semisup_step(cfg, student_sd, teacher_sd, batch, keep_rate, lam_u=3.0, lam_r=0.2, thr_cls=0.5, thr_reg=0.5,
+                      lr=0.01, momentum=0.9, wd=1e-4, bufs=None, mean=None, pix_std=None, frozen_prefixes=("backbone.bottom_up.stem", "backbone.bottom_up.res2")):
+    """One post-burn-in iteration of UBTeacherTrainer.run_step_full_semisup (engine/trainer.py:212-429),
+    fp32 (no AMP).  batch = (label_q, label_k, unlabel_q, unlabel_k) lists of dicts with 'image' (+ 'gt')."""
+    mean = mean if mean is not None else torch.tensor([103.53, 116.28, 123.675]).view(3, 1, 1)
+    pix_std = pix_std if pix_std is not None else torch.ones(3, 1, 1)
+    lq, lk, uq, uk = batch
+    teacher_sd = ema_update(student_sd, teacher_sd, keep_rate)
+    rec = {"ema_rate_1000x": keep_rate * 1000}
+    with torch.no_grad():
+        tl = fcos_forward(teacher_sd, [d["image"] for d in uk], mean, pix_std)
+        det_cls = fcos_predict(cfg, *tl[:4], tl[4], tl[5], "cls")
+        det_loc = fcos_predict(cfg, *tl[:4], tl[4], tl[5], "cls_n_loc")
+    pseudo_cls = [threshold_bbox(d, thr_cls) for d in det_cls]
+    pseudo_reg = [threshold_bbox(d, thr_reg) for d in det_loc]
+    params = {k: v.clone().requires_grad_(True) for k, v in student_sd.items()
+              if v.dtype.is_floating_point and "norm." not in k and not k.startswith(frozen_prefixes)
+              and k not in ("pixel_mean", "pixel_std") and not k.endswith("integral.project")}
+    sd = dict(student_sd)
+    sd.update(params)
+    out = fcos_forward(sd, [d["image"] for d in lq + lk], mean, pix_std)
+    sup, _ = fcos_losses(cfg, *out[:4], out[4], [d["gt"] for d in lq + lk])
+    rec.update(sup)
+    out = fcos_forward(sd, [d["image"] for d in uq], mean, pix_std)
+    uns, _ = fcos_pseudo_losses(cfg, *out[:4], out[4], {"cls": pseudo_cls, "reg": pseudo_reg})
+    for k, v in uns.items():
+        rec[k + "_pseudo"] = v
+    total = 0.0
+    for k, v in rec.items():
+        if k[:4] != "loss":
+            continue
+        if k in ("loss_fcos_ctr", "loss_fcos_cls"):
+            total = total + v / (lam_u + 1.0)
+        elif k in ("loss_fcos_ctr_pseudo", "loss_fcos_cls_pseudo"):
+            total = total + v * lam_u / (lam_u + 1.0)
+        elif k == "loss_fcos_loc":
+            total = total + v / (lam_r + 1.0)
+        elif k == "loss_fcos_loc_pseudo":
+            total = total + v * lam_r / (lam_r + 1.0)
+        else:
+            total = total + v / (lam_u + 1.0)
+    grads_l = torch.autograd.grad(total, list(params.values()), allow_unused=True)
+    grads = {k: (g if g is not None else torch.zeros_like(params[k])) for k, g in zip(params.keys(), grads_l)}
+    wds = {k: (0.0 if is_norm_param(k) else wd) for k in params}
+    bufs = bufs if bufs is not None else {}
+    newp, bufs = sgd_step({k: v.detach() for k, v in params.items()}, grads, bufs, lr, momentum, wds)
+    new_student = OrderedDict(student_sd)
+    new_student.update(newp)
+    rec = {k: (float(v.detach()) if torch.is_tensor(v) else float(v)) for k, v in rec.items()}
+    return rec, new_student, teacher_sd, grads, bufs, (pseudo_cls, pseudo_reg)

@@ -1,0 +1,529 @@
+// HBM-bound elementwise / reduction kernels of the UTv2 step (gfx950).
+// All arithmetic fp32, one rounding per written operation (the library is built with
+// -ffp-contract=off) so results are comparable op-for-op with the reference's eager
+// PyTorch expressions.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// Teacher EMA  (ubteacher/engine/trainer.py:468-486 == :950-968)
+//   new_teacher = student * (1 - keep) + teacher * keep      evaluated exactly as written:
+//   two rounded products and one rounded sum; a = (float)(1 - keep), b = (float)keep.
+// One launch over the whole flat state arena: 12 B/element algorithmic traffic.
+__global__ __launch_bounds__(256) void ema_axpby_f32(float* __restrict__ teacher, const float* __restrict__ student,
+                                                   size_t n4, size_t n, float a, float b) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  f32x4* t4 = (f32x4*)teacher;
+  const f32x4* s4 = (const f32x4*)student;
+  for (size_t j = i; j < n4; j += stride) {
+    f32x4 t = t4[j], s = s4[j], r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = __fadd_rn(__fmul_rn(s[e], a), __fmul_rn(t[e], b));
+    t4[j] = r;
+  }
+  // tail
+  for (size_t j = n4 * 4 + i; j < n; j += stride) teacher[j] = __fadd_rn(__fmul_rn(student[j], a), __fmul_rn(teacher[j], b));
+}
+
+// ---------------------------------------------------------------------------------------------
+// SGD with momentum + weight decay on a flat arena (D2 build_optimizer: torch.optim.SGD,
+// momentum 0.9, nesterov off).  g = grad*gscale + wd*p ; buf = mom*buf + g ; p -= lr*buf.
+// `gscale_ptr` (optional, device) multiplies the gradient (1/world for DDP mean, loss-scale
+// inverse); grad is zeroed afterwards if zero_grad != 0 (saves the separate memset pass).
+__global__ __launch_bounds__(256) void sgd_momentum_f32(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                      size_t n, float lr, float mom, float wd, float gscale,
+                                                      int zero_grad) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float pv = p[i];
+    float gv = __fmul_rn(g[i], gscale);
+    gv = __fadd_rn(gv, __fmul_rn(wd, pv));
+    const float mv = __fadd_rn(__fmul_rn(mom, m[i]), gv);
+    m[i] = mv;
+    p[i] = __fsub_rn(pv, __fmul_rn(lr, mv));
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// out = (mask_y ? (y > 0 ? dy : 0) : dy) * (scale ? scale[c] : 1)     on [M][C]
+__global__ __launch_bounds__(256) void relu_bwd_scale_f32(const float* __restrict__ dy, const float* __restrict__ y,
+                                                        const float* __restrict__ scale, float* __restrict__ out,
+                                                        size_t n4, int C4) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    f32x4 g = ((const f32x4*)dy)[i];
+    if (y) {
+      const f32x4 yy = ((const f32x4*)y)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
+    }
+    if (scale) {
+      const f32x4 s = ((const f32x4*)scale)[i % C4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] *= s[e];
+    }
+    ((f32x4*)out)[i] = g;
+  }
+}
+
+// y = a + b (used for gradient fan-in)
+__global__ __launch_bounds__(256) void add_f32(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o,
+                                             size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) o[i] = a[i] + b[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 stride-2 pad-1 max pool, NHWC (ResNet stem; frozen => forward only)
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_f32(const float* __restrict__ x, float* __restrict__ y, int N, int H,
+                                                           int W, int C4, int OH, int OW) {
+  const size_t total = (size_t)N * OH * OW * C4;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    size_t t = i;
+    const int c = (int)(t % C4); t /= C4;
+    const int ow = (int)(t % OW); t /= OW;
+    const int oh = (int)(t % OH); t /= OH;
+    const int n = (int)t;
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int ih = oh * 2 - 1 + dh;
+      if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int iw = ow * 2 - 1 + dw;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const f32x4 v = ((const f32x4*)x)[((size_t)(n * H + ih) * W + iw) * C4 + c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+      }
+    }
+    ((f32x4*)y)[i] = m;
+  }
+}
+
+// FPN top-down: out[n,h,w,:] = lateral[n,h,w,:] + top[n,h/2,w/2,:]   (nearest x2)
+__global__ __launch_bounds__(256) void upsample2x_add_nhwc_f32(const float* __restrict__ lat, const float* __restrict__ top,
+                                                             float* __restrict__ out, int N, int H, int W, int C4) {
+  const size_t total = (size_t)N * H * W * C4;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const int TH = H >> 1, TW = W >> 1;
+  for (; i < total; i += stride) {
+    size_t t = i;
+    const int c = (int)(t % C4); t /= C4;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); t /= H;
+    const int n = (int)t;
+    const f32x4 a = ((const f32x4*)lat)[i];
+    const f32x4 b = ((const f32x4*)top)[((size_t)(n * TH + (h >> 1)) * TW + (w >> 1)) * C4 + c];
+    ((f32x4*)out)[i] = a + b;
+  }
+}
+
+// backward of the nearest x2 upsample: dtop[n,h,w,:] (+)= sum of the 2x2 block of g
+__global__ __launch_bounds__(256) void downsample2x_sum_nhwc_f32(const float* __restrict__ g, float* __restrict__ dtop, int N,
+                                                               int TH, int TW, int C4, int accumulate) {
+  const size_t total = (size_t)N * TH * TW * C4;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const int H = TH * 2, W = TW * 2;
+  for (; i < total; i += stride) {
+    size_t t = i;
+    const int c = (int)(t % C4); t /= C4;
+    const int w = (int)(t % TW); t /= TW;
+    const int h = (int)(t % TH); t /= TH;
+    const int n = (int)t;
+    const f32x4* gp = (const f32x4*)g;
+    const size_t b = ((size_t)(n * H + 2 * h) * W + 2 * w) * C4 + c;
+    f32x4 s = gp[b] + gp[b + C4] + gp[b + (size_t)W * C4] + gp[b + (size_t)W * C4 + C4];
+    if (accumulate) s += ((f32x4*)dtop)[i];
+    ((f32x4*)dtop)[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Image normalisation + CHW -> padded NHWC4 (one_stage_detector.py:88-90 / D2 preprocess_image +
+// ImageList.from_tensors): dst[n,h,w,c] = (src[c,h,w] - mean[c]) / std[c] for h<H,w<W, else 0.
+template <typename T>
+__global__ __launch_bounds__(256) void preprocess_chw_to_nhwc4(const T* __restrict__ src, float* __restrict__ dst, int H, int W,
+                                                             int Hp, int Wp, float m0, float m1, float m2, float s0,
+                                                             float s1, float s2) {
+  const size_t total = (size_t)Hp * Wp;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int h = (int)(i / Wp), w = (int)(i % Wp);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (h < H && w < W) {
+      const size_t o = (size_t)h * W + w, hw = (size_t)H * W;
+      v[0] = ((float)src[o] - m0) / s0;
+      v[1] = ((float)src[hw + o] - m1) / s1;
+      v[2] = ((float)src[2 * hw + o] - m2) / s2;
+    }
+    ((f32x4*)dst)[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FrozenBatchNorm fold for every BN layer at once (D2 FrozenBatchNorm2d.forward [D2-recall]):
+//   scale = w * rsqrt(var + eps);  shift = b - mean * scale
+__global__ void frozenbn_fold_f32(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ mean,
+                                  const float* __restrict__ var, float* __restrict__ scale, float* __restrict__ shift,
+                                  int n, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float s = w[i] * (1.0f / sqrtf(var[i] + eps));
+    scale[i] = s;
+    shift[i] = b[i] - mean[i] * s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm(G groups) + ReLU on NHWC [N][HW][C]  (fcos/fcos.py:263-264, 283)
+// stage 1: per (n, chunk) partial sum / sumsq per group -> part[n][chunk][G][2]
+// stage 2: mean / rstd per (n, g)                        (double combine)
+// stage 3: y = relu((x - mean) * rstd * gamma + beta)
+#define GN_ROWS 64
+__global__ __launch_bounds__(256) void gn_stats_partial(const float* __restrict__ x, float* __restrict__ part, int HW, int C,
+                                                      int G, int nchunks) {
+  // thread t owns channel quad c4 = t % C4 and row lane t / C4 (deterministic reduction order)
+  __shared__ float red[2][256];
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int C4 = C >> 2;
+  const int r0 = chunk * GN_ROWS;
+  int r1 = r0 + GN_ROWS;
+  if (r1 > HW) r1 = HW;
+  const int cpg4 = (C / G) >> 2;  // channel quads per group
+  const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, RL = blockDim.x / C4;
+  float s = 0.f, q = 0.f;
+  for (int row = r0 + rl; row < r1; row += RL) {
+    const f32x4 v = ((const f32x4*)x)[((size_t)n * HW + row) * C4 + c4];
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+    q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  float* out = part + ((size_t)(n * nchunks + chunk) * G) * 2;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < RL; ++k)
+      for (int j = 0; j < cpg4; ++j) {
+        a += red[0][k * C4 + g * cpg4 + j];
+        b += red[1][k * C4 + g * cpg4 + j];
+      }
+    out[g * 2] = a;
+    out[g * 2 + 1] = b;
+  }
+}
+
+__global__ void gn_stats_final(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd, int NG,
+                               int G, int nchunks, double cnt, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (n, g)
+  if (i >= NG) return;
+  const int n = i / G, g = i % G;
+  double s = 0.0, q = 0.0;
+  for (int c = 0; c < nchunks; ++c) {
+    const float* p = part + ((size_t)(n * nchunks + c) * G + g) * 2;
+    s += (double)p[0];
+    q += (double)p[1];
+  }
+  const double m = s / cnt;
+  double var = q / cnt - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[i] = (float)m;
+  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void gn_apply_relu(const float* __restrict__ x, const float* __restrict__ mean,
+                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float* __restrict__ y, int N, int HW,
+                                                   int C, int G, int relu) {
+  const int C4 = C >> 2, cpg = C / G;
+  const size_t total = (size_t)N * HW * C4;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int c4 = (int)(i % C4);
+    const int n = (int)(i / ((size_t)HW * C4));
+    const int g = (c4 * 4) / cpg;
+    const float m = mean[n * G + g], r = rstd[n * G + g];
+    const f32x4 v = ((const f32x4*)x)[i];
+    const f32x4 ga = ((const f32x4*)gamma)[c4], be = ((const f32x4*)beta)[c4];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = (v[e] - m) * r * ga[e] + be[e];
+      o[e] = relu ? fmaxf(t, 0.f) : t;
+    }
+    ((f32x4*)y)[i] = o;
+  }
+}
+
+// backward stage 1: per (n, chunk, c): A = sum g*xhat, B = sum g   with g = dy * (y > 0)
+__global__ __launch_bounds__(256) void gn_bwd_partial(const float* __restrict__ dy, const float* __restrict__ y,
+                                                    const float* __restrict__ x, const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd, float* __restrict__ part, int HW, int C,
+                                                    int G, int nchunks, int relu) {
+  // blockDim.x == 256 threads: thread t owns channel quad c4 = t % C4 (C4 <= 256, 256 % C4 == 0)
+  __shared__ float red[2][256 * 4];
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int C4 = C >> 2, cpg = C / G;
+  const int r0 = chunk * GN_ROWS;
+  int r1 = r0 + GN_ROWS;
+  if (r1 > HW) r1 = HW;
+  const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, RL = blockDim.x / C4;
+  const int g = (c4 * 4) / cpg;
+  const float m = mean[n * G + g], r = rstd[n * G + g];
+  f32x4 A = {0.f, 0.f, 0.f, 0.f}, B = {0.f, 0.f, 0.f, 0.f};
+  for (int row = r0 + rl; row < r1; row += RL) {
+    const size_t o = ((size_t)n * HW + row) * C4 + c4;
+    f32x4 gg = ((const f32x4*)dy)[o];
+    const f32x4 xx = ((const f32x4*)x)[o];
+    if (relu) {
+      const f32x4 yy = ((const f32x4*)y)[o];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      A[e] += gg[e] * ((xx[e] - m) * r);
+      B[e] += gg[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[0][threadIdx.x * 4 + e] = A[e];
+    red[1][threadIdx.x * 4 + e] = B[e];
+  }
+  __syncthreads();
+  if (rl == 0) {
+    for (int k = 1; k < RL; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        A[e] += red[0][(k * C4 + c4) * 4 + e];
+        B[e] += red[1][(k * C4 + c4) * 4 + e];
+      }
+    float* out = part + ((size_t)(n * nchunks + chunk) * C + c4 * 4) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      out[e * 2] = A[e];
+      out[e * 2 + 1] = B[e];
+    }
+  }
+}
+
+// backward stage 2: AB[n][c][2] = sum over chunks; then per (n,g): s1 = sum gamma*A, s2 = sum gamma*B;
+// dgamma[c] += sum_n A ; dbeta[c] += sum_n B.   One block per n handles s1/s2; block N.. handles dgamma.
+__global__ void gn_bwd_reduce(const float* __restrict__ part, const float* __restrict__ gamma, float* __restrict__ AB,
+                              float* __restrict__ s12, int N, int C, int G, int nchunks) {
+  const int n = blockIdx.x;
+  const int cpg = C / G;
+  extern __shared__ float sh[];  // [C][2]
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < nchunks; ++k) {
+      const float* p = part + ((size_t)(n * nchunks + k) * C + c) * 2;
+      a += p[0];
+      b += p[1];
+    }
+    AB[((size_t)n * C + c) * 2] = a;
+    AB[((size_t)n * C + c) * 2 + 1] = b;
+    sh[c * 2] = a * gamma[c];
+    sh[c * 2 + 1] = b * gamma[c];
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < cpg; ++k) {
+      s1 += sh[(g * cpg + k) * 2];
+      s2 += sh[(g * cpg + k) * 2 + 1];
+    }
+    s12[(n * G + g) * 2] = s1;
+    s12[(n * G + g) * 2 + 1] = s2;
+  }
+}
+
+__global__ void gn_bwd_param(const float* __restrict__ AB, float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int n = 0; n < N; ++n) {
+    a += AB[((size_t)n * C + c) * 2];
+    b += AB[((size_t)n * C + c) * 2 + 1];
+  }
+  dgamma[c] += a;
+  dbeta[c] += b;
+}
+
+// backward stage 3: dx = rstd * (g*gamma - (s2 + xhat*s1)/cnt)
+__global__ __launch_bounds__(256) void gn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ y,
+                                                  const float* __restrict__ x, const float* __restrict__ mean,
+                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                  const float* __restrict__ s12, float* __restrict__ dx, int N, int HW, int C,
+                                                  int G, float inv_cnt, int relu) {
+  const int C4 = C >> 2, cpg = C / G;
+  const size_t total = (size_t)N * HW * C4;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int c4 = (int)(i % C4);
+    const int n = (int)(i / ((size_t)HW * C4));
+    const int g = (c4 * 4) / cpg;
+    const float m = mean[n * G + g], r = rstd[n * G + g];
+    const float s1 = s12[(n * G + g) * 2], s2 = s12[(n * G + g) * 2 + 1];
+    f32x4 gg = ((const f32x4*)dy)[i];
+    const f32x4 xx = ((const f32x4*)x)[i];
+    const f32x4 ga = ((const f32x4*)gamma)[c4];
+    if (relu) {
+      const f32x4 yy = ((const f32x4*)y)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
+    }
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (xx[e] - m) * r;
+      o[e] = r * (gg[e] * ga[e] - (s2 + xh * s1) * inv_cnt);
+    }
+    ((f32x4*)dx)[i] = o;
+  }
+}
+
+static inline int grid_for(size_t n, int block = 256, int cap = 256 * 16) {
+  size_t b = (n + block - 1) / block;
+  if (b > (size_t)cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" {
+
+int utv2_ema_axpby(float* teacher, const float* student, int64_t n, double keep_rate, hipStream_t stream) {
+  if (!teacher || !student || n < 0) return UTV2_EARG;
+  if (n == 0) return UTV2_OK;
+  if (((uintptr_t)teacher | (uintptr_t)student) & 15) return UTV2_EARG;
+  const float a = (float)(1.0 - keep_rate), b = (float)keep_rate;
+  hipLaunchKernelGGL(ema_axpby_f32, dim3(grid_for((size_t)n / 4)), dim3(256), 0, stream, teacher, student, (size_t)n / 4,
+                     (size_t)n, a, b);
+  return utv2_launch_status();
+}
+
+int utv2_sgd_momentum(float* param, float* grad, float* mom_buf, int64_t n, float lr, float momentum, float weight_decay,
+                      float grad_scale, int zero_grad, hipStream_t stream) {
+  if (!param || !grad || !mom_buf || n < 0) return UTV2_EARG;
+  if (n == 0) return UTV2_OK;
+  hipLaunchKernelGGL(sgd_momentum_f32, dim3(grid_for((size_t)n)), dim3(256), 0, stream, param, grad, mom_buf, (size_t)n, lr,
+                     momentum, weight_decay, grad_scale, zero_grad);
+  return utv2_launch_status();
+}
+
+// out[M][C] = (y? relu-mask by y : 1) * dy * (scale? scale[c] : 1).  C % 4 == 0.
+int utv2_relu_bwd_scale(const float* dy, const float* y, const float* scale, float* out, int64_t M, int C,
+                        hipStream_t stream) {
+  if (!dy || !out || (C & 3)) return UTV2_EARG;
+  const size_t n4 = (size_t)M * C / 4;
+  if (n4 == 0) return UTV2_OK;
+  hipLaunchKernelGGL(relu_bwd_scale_f32, dim3(grid_for(n4)), dim3(256), 0, stream, dy, y, scale, out, n4, C / 4);
+  return utv2_launch_status();
+}
+
+int utv2_add(const float* a, const float* b, float* out, int64_t n, hipStream_t stream) {
+  if (!a || !b || !out) return UTV2_EARG;
+  if (n == 0) return UTV2_OK;
+  hipLaunchKernelGGL(add_f32, dim3(grid_for((size_t)n)), dim3(256), 0, stream, a, b, out, (size_t)n);
+  return utv2_launch_status();
+}
+
+int utv2_maxpool3x3s2_nhwc(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, hipStream_t stream) {
+  if (!x || !y || (C & 3)) return UTV2_EARG;
+  hipLaunchKernelGGL(maxpool3x3s2_nhwc_f32, dim3(grid_for((size_t)N * OH * OW * C / 4, 256, 1 << 16)), dim3(256), 0, stream,
+                     x, y, N, H, W, C / 4, OH, OW);
+  return utv2_launch_status();
+}
+
+int utv2_upsample2x_add_nhwc(const float* lateral, const float* top, float* out, int N, int H, int W, int C,
+                             hipStream_t stream) {
+  if (!lateral || !top || !out || (C & 3) || (H & 1) || (W & 1)) return UTV2_EARG;
+  hipLaunchKernelGGL(upsample2x_add_nhwc_f32, dim3(grid_for((size_t)N * H * W * C / 4, 256, 1 << 16)), dim3(256), 0, stream,
+                     lateral, top, out, N, H, W, C / 4);
+  return utv2_launch_status();
+}
+
+int utv2_downsample2x_sum_nhwc(const float* g, float* dtop, int N, int TH, int TW, int C, int accumulate,
+                               hipStream_t stream) {
+  if (!g || !dtop || (C & 3)) return UTV2_EARG;
+  hipLaunchKernelGGL(downsample2x_sum_nhwc_f32, dim3(grid_for((size_t)N * TH * TW * C / 4, 256, 1 << 16)), dim3(256), 0,
+                     stream, g, dtop, N, TH, TW, C / 4, accumulate);
+  return utv2_launch_status();
+}
+
+// src: one image [3][H][W], uint8 (is_u8) or fp32; dst: one padded NHWC4 image [Hp][Wp][4]
+int utv2_preprocess_image(const void* src, int is_u8, float* dst, int H, int W, int Hp, int Wp, const float* mean3_host,
+                          const float* std3_host, hipStream_t stream) {
+  if (!src || !dst || H > Hp || W > Wp) return UTV2_EARG;
+  const float m0 = mean3_host[0], m1 = mean3_host[1], m2 = mean3_host[2];
+  const float s0 = std3_host[0], s1 = std3_host[1], s2 = std3_host[2];
+  const int g = grid_for((size_t)Hp * Wp, 256, 1 << 16);
+  if (is_u8)
+    hipLaunchKernelGGL((preprocess_chw_to_nhwc4<unsigned char>), dim3(g), dim3(256), 0, stream, (const unsigned char*)src,
+                       dst, H, W, Hp, Wp, m0, m1, m2, s0, s1, s2);
+  else
+    hipLaunchKernelGGL((preprocess_chw_to_nhwc4<float>), dim3(g), dim3(256), 0, stream, (const float*)src, dst, H, W, Hp,
+                       Wp, m0, m1, m2, s0, s1, s2);
+  return utv2_launch_status();
+}
+
+int utv2_frozenbn_fold(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift,
+                       int n, float eps, hipStream_t stream) {
+  if (!w || !b || !mean || !var || !scale || !shift) return UTV2_EARG;
+  if (n == 0) return UTV2_OK;
+  hipLaunchKernelGGL(frozenbn_fold_f32, dim3(cdiv(n, 256)), dim3(256), 0, stream, w, b, mean, var, scale, shift, n, eps);
+  return utv2_launch_status();
+}
+
+int64_t utv2_groupnorm_workspace_floats(int N, int HW, int C) {
+  const int nchunks = cdiv(HW, GN_ROWS);
+  return (int64_t)N * nchunks * C * 2 + (int64_t)N * C * 2 + (int64_t)N * C;
+}
+
+// x,y: [N][HW][C]; mean,rstd: [N][G] (saved for backward).  C % 4 == 0, (C/G) % 4 == 0, 256 % (C/4) == 0.
+int utv2_groupnorm_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                            float* ws, int N, int HW, int C, int G, float eps, int relu, hipStream_t stream) {
+  if (!x || !y || !mean || !rstd || !ws || (C & 3) || ((C / G) & 3) || C / 4 > 256 || (256 % (C / 4))) return UTV2_EARG;
+  const int nchunks = cdiv(HW, GN_ROWS);
+  hipLaunchKernelGGL(gn_stats_partial, dim3(nchunks, N), dim3(256), 0, stream, x, ws, HW, C, G, nchunks);
+  hipLaunchKernelGGL(gn_stats_final, dim3(cdiv(N * G, 64)), dim3(64), 0, stream, (const float*)ws, mean, rstd, N * G, G,
+                     nchunks, (double)HW * (C / G), eps);
+  hipLaunchKernelGGL(gn_apply_relu, dim3(grid_for((size_t)N * HW * C / 4, 256, 1 << 16)), dim3(256), 0, stream, x,
+                     (const float*)mean, (const float*)rstd, gamma, beta, y, N, HW, C, G, relu);
+  return utv2_launch_status();
+}
+
+// dx written; dgamma/dbeta accumulated (+=).
+int utv2_groupnorm_relu_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
+                            const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws, int N, int HW, int C,
+                            int G, int relu, hipStream_t stream) {
+  if (!dy || !x || !dx || !ws || (C & 3) || ((C / G) & 3) || C / 4 > 256 || (256 % (C / 4))) return UTV2_EARG;
+  const int nchunks = cdiv(HW, GN_ROWS);
+  float* part = ws;
+  float* AB = ws + (size_t)N * nchunks * C * 2;
+  float* s12 = AB + (size_t)N * C * 2;
+  hipLaunchKernelGGL(gn_bwd_partial, dim3(nchunks, N), dim3(256), 0, stream, dy, y, x, mean, rstd, part, HW, C, G, nchunks,
+                     relu);
+  hipLaunchKernelGGL(gn_bwd_reduce, dim3(N), dim3(256), 2 * C * sizeof(float), stream, (const float*)part, gamma, AB, s12, N,
+                     C, G, nchunks);
+  hipLaunchKernelGGL(gn_bwd_param, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)AB, dgamma, dbeta, N, C);
+  hipLaunchKernelGGL(gn_bwd_apply, dim3(grid_for((size_t)N * HW * C / 4, 256, 1 << 16)), dim3(256), 0, stream, dy, y, x,
+                     mean, rstd, gamma, (const float*)s12, dx, N, HW, C, G, 1.0f / ((float)HW * (C / G)), relu);
+  return utv2_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,596 @@
+// FCOS-specific kernels of the UTv2 step (gfx950): target assignment, fused sigmoid-focal,
+// fused positive-location losses (Integral + centerness BCE + GIoU + NLL + pseudo "teacher better"
+// L1), ranking keys and box decode for the teacher's pseudo-label NMS.
+//
+// Dense layout used by every kernel here ("level-first", the ordering the reference builds with
+// _transpose / cat at ubteacher/modeling/fcos/fcos_outputs.py:634-647,227-290): row index
+//   p = N * level_off[l] + n * HW_l + hw,   level_off[l] = sum_{l'<l} HW_l'
+// so each level's NHWC head output [N][H_l][W_l][C] is one contiguous row range and no
+// permute/cat is ever materialised.
+#include "common.h"
+
+#define MAX_LEVELS 8
+
+struct LevelTable {
+  int num_levels;
+  int H[MAX_LEVELS], W[MAX_LEVELS], stride[MAX_LEVELS];
+  int off[MAX_LEVELS + 1];  // prefix sums of H*W
+  float soi_lo[MAX_LEVELS], soi_hi[MAX_LEVELS];
+};
+
+__device__ __forceinline__ int level_of(const LevelTable& t, int loc) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_LEVELS; ++i)
+    if (i < t.num_levels && loc >= t.off[i]) l = i;
+  return l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Target assignment  (fcos_outputs.py:649-698 _get_ground_truth, :772-906
+// compute_targets_for_locations with CENTER_SAMPLE False, ignore_near False).
+// gt arrays are padded to MAXG per image with a validity byte (the thresholded pseudo-label
+// mask, pseudo_generator.py:85, stays on the device; compaction order == index order).
+// One thread per (image, location); gts of the image staged in LDS.
+//   labels[p]      class id, num_classes for background, -1 for "location dropped" (image has
+//                  no gt and drop_empty != 0: the keep_locations filter of :310-311,804-815)
+//   reg_targets[p] ltrb / stride of the min-area matching gt (gt 0 when none, as the reference)
+//   bvars[p]       teacher reg_pred_std of the matched gt (99999 for background, 0 if no gt)
+//   gt_inds[p]     matched gt slot (or -1 when the image has no gt)
+#define TG_MAXG 256
+__global__ __launch_bounds__(256) void fcos_targets_kernel(LevelTable lt, int N, int MAXG, const float* __restrict__ gt_boxes,
+                                                         const int* __restrict__ gt_classes,
+                                                         const unsigned char* __restrict__ gt_valid,
+                                                         const float* __restrict__ gt_std, int num_classes, int drop_empty,
+                                                         int* __restrict__ labels, float* __restrict__ reg_targets,
+                                                         float* __restrict__ bvars, int* __restrict__ gt_inds) {
+  __shared__ float sb[TG_MAXG][4];
+  __shared__ float sarea[TG_MAXG];
+  __shared__ int sidx[TG_MAXG];
+  __shared__ int scount;
+  const int n = blockIdx.y;
+  const int L = lt.off[lt.num_levels];
+  if (threadIdx.x == 0) {
+    // ordered compaction of the valid gts (serial: MAXG <= 256)
+    int c = 0;
+    for (int g = 0; g < MAXG; ++g)
+      if (gt_valid[n * MAXG + g]) sidx[c++] = g;
+    scount = c;
+  }
+  __syncthreads();
+  const int G = scount;
+  for (int k = threadIdx.x; k < G; k += blockDim.x) {
+    const float* b = gt_boxes + ((size_t)n * MAXG + sidx[k]) * 4;
+    sb[k][0] = b[0]; sb[k][1] = b[1]; sb[k][2] = b[2]; sb[k][3] = b[3];
+    sarea[k] = (b[2] - b[0]) * (b[3] - b[1]);
+  }
+  __syncthreads();
+  const int loc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (loc >= L) return;
+  const int l = level_of(lt, loc);
+  const int hw = loc - lt.off[l];
+  const int HWl = lt.H[l] * lt.W[l];
+  const int y = hw / lt.W[l], x = hw - y * lt.W[l];
+  const float s = (float)lt.stride[l];
+  const float xs = (float)(x * lt.stride[l]) + (float)(lt.stride[l] / 2);
+  const float ys = (float)(y * lt.stride[l]) + (float)(lt.stride[l] / 2);
+  const size_t p = (size_t)N * lt.off[l] + (size_t)n * HWl + hw;
+  if (G == 0) {
+    labels[p] = drop_empty ? -1 : num_classes;
+    gt_inds[p] = -1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { reg_targets[p * 4 + e] = 0.f; bvars[p * 4 + e] = 0.f; }
+    return;
+  }
+  const float INF = 100000000.f;
+  float best = INF;
+  int bi = 0;
+  for (int k = 0; k < G; ++k) {
+    const float lft = xs - sb[k][0], top = ys - sb[k][1], rgt = sb[k][2] - xs, bot = sb[k][3] - ys;
+    const float mn = fminf(fminf(lft, top), fminf(rgt, bot));
+    const float mx = fmaxf(fmaxf(lft, top), fmaxf(rgt, bot));
+    float a = sarea[k];
+    if (!(mn > 0.f)) a = INF;
+    if (!(mx >= lt.soi_lo[l] && mx <= lt.soi_hi[l])) a = INF;
+    if (a < best) { best = a; bi = k; }
+  }
+  const bool bg = (best == INF);
+  const int g = sidx[bi];
+  labels[p] = bg ? num_classes : gt_classes[n * MAXG + g];
+  gt_inds[p] = g;
+  reg_targets[p * 4 + 0] = (xs - sb[bi][0]) / s;
+  reg_targets[p * 4 + 1] = (ys - sb[bi][1]) / s;
+  reg_targets[p * 4 + 2] = (sb[bi][2] - xs) / s;
+  reg_targets[p * 4 + 3] = (sb[bi][3] - ys) / s;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bvars[p * 4 + e] = bg ? 99999.0f : (gt_std ? gt_std[((size_t)n * MAXG + g) * 4 + e] : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sigmoid focal loss (fvcore sigmoid_focal_loss_jit [fvcore-recall], called at
+// fcos_outputs.py:329-335,619-625) with the one-hot target built on the fly from labels.
+//   p = sigmoid(x); ce = max(x,0) - x*t + log1p(exp(-|x|)); p_t = p*t + (1-p)(1-t)
+//   loss = ce * (1-p_t)^gamma * (alpha*t + (1-alpha)(1-t))
+// fwd: deterministic two-stage sum -> partial[gridDim.x];  rows with label < 0 are skipped.
+__device__ __forceinline__ float focal_term(float x, float t, float alpha, float gamma, float* dldx) {
+  const float p = 1.f / (1.f + expf(-x));
+  const float ce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+  const float pt = p * t + (1.f - p) * (1.f - t);
+  const float om = 1.f - pt;
+  const float mod = (gamma == 2.f) ? om * om : powf(om, gamma);
+  const float at = alpha * t + (1.f - alpha) * (1.f - t);
+  if (dldx) {
+    // dL/dx = a_t (2t-1) (1-pt)^g [ g*pt*log(pt) - (1-pt) ],  log(pt) = -ce
+    *dldx = at * (2.f * t - 1.f) * mod * (gamma * pt * (-ce) - om);
+  }
+  return ce * mod * at;
+}
+
+__global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict__ logits, const int* __restrict__ labels, size_t P,
+                                                      int C, float alpha, float gamma, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const size_t total = P * (size_t)C;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  float acc = 0.f;
+  for (; i < total; i += stride) {
+    const size_t row = i / C;
+    const int c = (int)(i - row * C);
+    const int lab = labels[row];
+    if (lab < 0) continue;
+    acc += focal_term(logits[i], lab == c ? 1.f : 0.f, alpha, gamma, nullptr);
+  }
+  const float s = block_reduce_sum(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// dlogits = coef[0] * dL/dx   (coef = upstream grad / num_pos_avg, a device scalar: no host sync)
+__global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict__ logits, const int* __restrict__ labels, size_t P,
+                                                      int C, float alpha, float gamma, const float* __restrict__ coef,
+                                                      float* __restrict__ dlogits) {
+  const size_t total = P * (size_t)C;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const float k = coef[0];
+  for (; i < total; i += stride) {
+    const size_t row = i / C;
+    const int c = (int)(i - row * C);
+    const int lab = labels[row];
+    float g = 0.f;
+    if (lab >= 0) {
+      focal_term(logits[i], lab == c ? 1.f : 0.f, alpha, gamma, &g);
+      g *= k;
+    }
+    dlogits[i] = g;
+  }
+}
+
+__global__ void sum_partials_kernel(const float* __restrict__ partial, int n, int ncols, float* __restrict__ out) {
+  // out[c] = sum_r partial[r*ncols + c]  (double accumulate, fixed order)
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  double s = 0.0;
+  for (int r = 0; r < n; ++r) s += (double)partial[(size_t)r * ncols + c];
+  out[c] = (float)s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused positive-location terms (fcos_outputs.py:340-416 supervised; :514-590 pseudo;
+// Integral :44-77; compute_ctrness_targets :80-88; compute_iou_targets :91-129;
+// IOULoss giou layers/iou_loss.py:26-76; NLLoss layers/kl_loss.py:69-105).
+// box rows: [reg logits 4*(R+1) | std 4 | ctr 1 | pad], row stride BS floats.
+// Sums produced (LT_NSUM columns):
+//   0 n_pos  1 sum ctr_t  2 sum bce(ctr)  3 sum (1-giou)*ctr_t  4 sum nll_i*iou_i
+//   5 n_sel  6 sum_sel |d - t|
+#define LT_NSUM 8
+struct LocTerms {
+  float d[4];      // Integral ltrb
+  float ctr_t, iou, giou_l, nll;
+};
+
+template <int R1>
+__device__ __forceinline__ void integral4(const float* __restrict__ z, float* d, float (*prob)[R1]) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < R1; ++j) m = fmaxf(m, z[b * R1 + j]);
+    float s = 0.f, e[R1];
+#pragma unroll
+    for (int j = 0; j < R1; ++j) { e[j] = expf(z[b * R1 + j] - m); s += e[j]; }
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < R1; ++j) {
+      const float pj = e[j] / s;
+      if (prob) prob[b][j] = pj;
+      acc += pj * (float)j;
+    }
+    d[b] = acc;
+  }
+}
+
+__device__ __forceinline__ float min_grad(float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); }  // d min(a,b)/da
+__device__ __forceinline__ float max_grad(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }
+
+// giou loss (1 - giou) on ltrb with +1 smoothing on the IoU only; optionally its gradient wrt d
+__device__ __forceinline__ float giou_ltrb(const float* d, const float* t, float* iou_out, float* grad) {
+  const float ta = (t[0] + t[2]) * (t[1] + t[3]);
+  const float pw = d[0] + d[2], ph = d[1] + d[3];
+  const float pa = pw * ph;
+  const float wi = fminf(d[0], t[0]) + fminf(d[2], t[2]);
+  const float hi = fminf(d[3], t[3]) + fminf(d[1], t[1]);
+  const float gw = fmaxf(d[0], t[0]) + fmaxf(d[2], t[2]);
+  const float gh = fmaxf(d[3], t[3]) + fmaxf(d[1], t[1]);
+  const float ac = gw * gh;
+  const float I = wi * hi;
+  const float U = ta + pa - I;
+  const float iou = (I + 1.f) / (U + 1.f);
+  const float giou = iou - (ac - U) / ac;
+  if (iou_out) *iou_out = iou;
+  if (grad) {
+    // index 0: left, 1: top, 2: right, 3: bottom
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const bool horiz = (b == 0 || b == 2);
+      const float dpa = horiz ? ph : pw;
+      const float dI = horiz ? min_grad(d[b], t[b]) * hi : min_grad(d[b], t[b]) * wi;
+      const float dac = horiz ? max_grad(d[b], t[b]) * gh : max_grad(d[b], t[b]) * gw;
+      const float dU = dpa - dI;
+      const float diou = (dI * (U + 1.f) - (I + 1.f) * dU) / ((U + 1.f) * (U + 1.f));
+      // giou = iou - 1 + U/ac
+      const float dgiou = diou + dU / ac - U * dac / (ac * ac);
+      grad[b] = -dgiou;
+    }
+  }
+  return 1.f - giou;
+}
+
+template <int R1>
+__global__ __launch_bounds__(128) void fcos_loc_fwd_kernel(const int* __restrict__ labels, const float* __restrict__ box, int BS,
+                                                         const float* __restrict__ reg_targets, const float* __restrict__ bvars,
+                                                         size_t P, int num_classes, float ts_better, float ts_cert,
+                                                         float* __restrict__ partial) {
+  __shared__ float red[2];
+  float acc[LT_NSUM];
+#pragma unroll
+  for (int k = 0; k < LT_NSUM; ++k) acc[k] = 0.f;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < P; i += stride) {
+    const int lab = labels[i];
+    if (lab < 0 || lab == num_classes) continue;
+    const float* row = box + i * BS;
+    float d[4], t[4];
+    integral4<R1>(row, d, (float(*)[R1]) nullptr);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) t[b] = reg_targets[i * 4 + b];
+    const float ctr_t = sqrtf((fminf(t[0], t[2]) / fmaxf(t[0], t[2])) * (fminf(t[1], t[3]) / fmaxf(t[1], t[3])));
+    float iou;
+    const float gl = giou_ltrb(d, t, &iou, nullptr);
+    float nll = 0.f;
+    const float* sp = row + 4 * R1;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float sg = 1.f / (1.f + expf(-sp[b]));
+      const float sq = sg * sg;
+      const float df = t[b] - d[b];
+      nll += (df * df) / (2.f * sq) + 0.5f * logf(sq);
+    }
+    nll += 2.f * logf(2.f * 3.14159265358979323846f);
+    const float c = row[4 * R1 + 4];
+    const float bce = fmaxf(c, 0.f) - c * ctr_t + log1pf(expf(-fabsf(c)));
+    acc[0] += 1.f;
+    acc[1] += ctr_t;
+    acc[2] += bce;
+    acc[3] += gl * ctr_t;
+    acc[4] += nll * iou;
+    if (bvars) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float cs = 1.f - 1.f / (1.f + expf(-sp[b]));
+        const float ct = 1.f - 1.f / (1.f + expf(-bvars[i * 4 + b]));
+        if (ct > ts_cert && ct > cs + ts_better) {
+          acc[5] += 1.f;
+          acc[6] += fabsf(d[b] - t[b]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < LT_NSUM; ++k) {
+    const float s = block_reduce_sum(acc[k], red);
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.x * LT_NSUM + k] = s;
+  }
+}
+
+// coef: device floats [c_bce, c_giou, c_nll, c_l1]: the fully normalised upstream factors
+//   d(total)/d(sum bce), d/d(sum giou*ctr), d/d(sum nll*iou), d/d(sum_sel |d-t|)
+// writes the whole gradient row (zeros for background / pad channels).
+template <int R1>
+__global__ __launch_bounds__(128) void fcos_loc_bwd_kernel(const int* __restrict__ labels, const float* __restrict__ box, int BS,
+                                                         const float* __restrict__ reg_targets, const float* __restrict__ bvars,
+                                                         size_t P, int num_classes, float ts_better, float ts_cert,
+                                                         const float* __restrict__ coef, float* __restrict__ dbox) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const float c_bce = coef[0], c_giou = coef[1], c_nll = coef[2], c_l1 = coef[3];
+  for (; i < P; i += stride) {
+    const int lab = labels[i];
+    float* grow = dbox + i * BS;
+    if (lab < 0 || lab == num_classes) {
+      for (int k = 0; k < BS; k += 4) *(f32x4*)(grow + k) = f32x4{0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
+    const float* row = box + i * BS;
+    float d[4], t[4], prob[4][R1];
+    integral4<R1>(row, d, prob);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) t[b] = reg_targets[i * 4 + b];
+    const float ctr_t = sqrtf((fminf(t[0], t[2]) / fmaxf(t[0], t[2])) * (fminf(t[1], t[3]) / fmaxf(t[1], t[3])));
+    float iou, gg[4];
+    giou_ltrb(d, t, &iou, gg);
+    const float* sp = row + 4 * R1;
+    float dd[4], ds[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float sg = 1.f / (1.f + expf(-sp[b]));
+      const float df = t[b] - d[b];
+      // nll_b = df^2/(2 sg^2) + log(sg);  d/dd = -df/sg^2 ; d/ds = (1-sg) * (1 - df^2/sg^2)
+      dd[b] = c_giou * ctr_t * gg[b] + c_nll * iou * (-df / (sg * sg));
+      ds[b] = c_nll * iou * (1.f - sg) * (1.f - (df * df) / (sg * sg));
+      if (bvars) {
+        const float cs = 1.f - sg;
+        const float ct = 1.f - 1.f / (1.f + expf(-bvars[i * 4 + b]));
+        if (ct > ts_cert && ct > cs + ts_better) {
+          const float e = d[b] - t[b];
+          dd[b] += c_l1 * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int j = 0; j < R1; ++j) grow[b * R1 + j] = dd[b] * prob[b][j] * ((float)j - d[b]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) grow[4 * R1 + b] = ds[b];
+    const float c = row[4 * R1 + 4];
+    grow[4 * R1 + 4] = c_bce * (1.f / (1.f + expf(-c)) - ctr_t);
+    for (int k = 4 * R1 + 5; k < BS; ++k) grow[k] = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ranking keys for the pre-NMS top-k (fcos_outputs.py:1146-1195,1238-1241).
+// key = (float bits of ranking score) << 32 | (0xFFFFFFFF - flat index) for candidates
+// (sigmoid(logit) > thr), else -1: descending int64 order == (score desc, index asc).
+// method: 0 cls, 1 cls_n_ctr, 2 ctr, 3 cls_n_loc
+__global__ __launch_bounds__(256) void fcos_rank_keys_kernel(const float* __restrict__ logits, const float* __restrict__ box, int BS,
+                                                           int R4, int HW, int C, float thr, int method,
+                                                           long long* __restrict__ keys) {
+  // grid.y = image; rows of this (level, image): [HW][C]
+  const int n = blockIdx.y;
+  const size_t total = (size_t)HW * C;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const size_t hw = i / C;
+    const size_t row = (size_t)n * HW + hw;
+    const float p = 1.f / (1.f + expf(-logits[row * C + (i - hw * C)]));
+    long long key = -1;
+    if (p > thr) {
+      float r = p;
+      const float* br = box + row * BS;
+      if (method == 1) r = p * (1.f / (1.f + expf(-br[R4 + 4])));
+      else if (method == 2) r = 1.f / (1.f + expf(-br[R4 + 4]));
+      else if (method == 3) {
+        float m = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) m += 1.f - 1.f / (1.f + expf(-br[R4 + b]));
+        r = p * (m / 4.f);
+      }
+      key = ((long long)__float_as_uint(r) << 32) | (long long)(0xFFFFFFFFu - (unsigned)i);
+    }
+    keys[(size_t)n * total + i] = key;
+  }
+}
+
+// Decode the selected candidates of one level (fcos_outputs.py:1093-1104,1258-1296):
+// in : topkeys [N][K] (from the keys above, sorted or not; -1 = empty slot)
+// out (slot s = level_slot0 + k of image n, MAXC slots per image):
+//   boxes[4] scores cls(int) loc[2] ctr cls_conf std[4] level valid
+template <int R1>
+__global__ __launch_bounds__(128) void fcos_decode_kernel(const long long* __restrict__ topkeys, int K, const float* __restrict__ logits,
+                                                        const float* __restrict__ box, int BS, int HW, int Wl, int C, int stride,
+                                                        int level, int method, int MAXC, int slot0, float* __restrict__ oboxes,
+                                                        float* __restrict__ oscores, int* __restrict__ ocls, float* __restrict__ oloc,
+                                                        float* __restrict__ octr, float* __restrict__ oconf, float* __restrict__ ostd,
+                                                        int* __restrict__ olevel, unsigned char* __restrict__ ovalid) {
+  const int n = blockIdx.y;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const size_t s = (size_t)n * MAXC + slot0 + k;
+  const long long key = topkeys[(size_t)n * K + k];
+  if (key < 0) {
+    ovalid[s] = 0;
+    oscores[s] = -1.f;
+    ocls[s] = 0;
+    olevel[s] = level;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { oboxes[s * 4 + e] = 0.f; ostd[s * 4 + e] = 0.f; }
+    oloc[s * 2] = 0.f; oloc[s * 2 + 1] = 0.f; octr[s] = 0.f; oconf[s] = 0.f;
+    return;
+  }
+  const unsigned flat = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFll);
+  const float rank = __uint_as_float((unsigned)(key >> 32));
+  const int hw = flat / C, c = flat - hw * C;
+  const size_t row = (size_t)n * HW + hw;
+  const float* br = box + row * BS;
+  float d[4];
+  integral4<R1>(br, d, (float(*)[R1]) nullptr);
+  const int y = hw / Wl, x = hw - y * Wl;
+  const float lx = (float)(x * stride) + (float)(stride / 2), ly = (float)(y * stride) + (float)(stride / 2);
+  const float fs = (float)stride;
+  oboxes[s * 4 + 0] = lx - d[0] * fs;
+  oboxes[s * 4 + 1] = ly - d[1] * fs;
+  oboxes[s * 4 + 2] = lx + d[2] * fs;
+  oboxes[s * 4 + 3] = ly + d[3] * fs;
+  oscores[s] = (method == 1 || method == 3) ? sqrtf(rank) : rank;
+  ocls[s] = c;
+  oloc[s * 2] = lx; oloc[s * 2 + 1] = ly;
+  octr[s] = 1.f / (1.f + expf(-br[4 * R1 + 4]));
+  oconf[s] = 1.f / (1.f + expf(-logits[row * C + c]));
+#pragma unroll
+  for (int e = 0; e < 4; ++e) ostd[s * 4 + e] = br[4 * R1 + e];
+  olevel[s] = level;
+  ovalid[s] = 1;
+}
+
+// in-place y[:, 0:ncols] *= s[0] on rows of stride BS (Scale layer, fcos/fcos.py:22-28,356-357)
+__global__ __launch_bounds__(256) void scale_cols_kernel(float* __restrict__ y, size_t rows, int BS, int ncols, const float* __restrict__ s) {
+  const size_t total = rows * (size_t)ncols;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const float k = s[0];
+  for (; i < total; i += stride) {
+    const size_t r = i / ncols;
+    const int c = (int)(i - r * ncols);
+    y[r * BS + c] *= k;
+  }
+}
+
+// backward of the above: g[:, 0:ncols] *= s ; partial[b] = sum g_in * y_post   (ds = sum / s)
+__global__ __launch_bounds__(256) void scale_cols_bwd_kernel(float* __restrict__ g, const float* __restrict__ ypost, size_t rows, int BS,
+                                                           int ncols, const float* __restrict__ s, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const size_t total = rows * (size_t)ncols;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const float k = s[0];
+  float acc = 0.f;
+  for (; i < total; i += stride) {
+    const size_t r = i / ncols;
+    const int c = (int)(i - r * ncols);
+    const float gv = g[r * BS + c];
+    acc += gv * ypost[r * BS + c];
+    g[r * BS + c] = gv * k;
+  }
+  const float t = block_reduce_sum(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+static LevelTable make_table(int num_levels, const int* H, const int* W, const int* strides, const float* soi) {
+  LevelTable t;
+  t.num_levels = num_levels;
+  int off = 0;
+  for (int l = 0; l < MAX_LEVELS; ++l) {
+    if (l < num_levels) {
+      t.H[l] = H[l]; t.W[l] = W[l]; t.stride[l] = strides[l];
+      t.soi_lo[l] = soi ? soi[2 * l] : 0.f; t.soi_hi[l] = soi ? soi[2 * l + 1] : 0.f;
+      t.off[l] = off;
+      off += H[l] * W[l];
+    } else {
+      t.H[l] = t.W[l] = t.stride[l] = 0; t.soi_lo[l] = t.soi_hi[l] = 0.f; t.off[l] = off;
+    }
+  }
+  t.off[num_levels] = off;
+  for (int l = num_levels + 1; l <= MAX_LEVELS; ++l) t.off[l] = off;
+  return t;
+}
+
+extern "C" {
+
+// H,W,strides: host int[num_levels]; soi: host float[2*num_levels] (lo,hi per level).
+int utv2_fcos_targets(int num_levels, const int* H, const int* W, const int* strides, const float* soi, int N, int MAXG,
+                      const float* gt_boxes, const int* gt_classes, const unsigned char* gt_valid, const float* gt_std,
+                      int num_classes, int drop_empty, int* labels, float* reg_targets, float* bvars, int* gt_inds,
+                      hipStream_t stream) {
+  if (num_levels < 1 || num_levels > MAX_LEVELS || MAXG > TG_MAXG || MAXG < 1 || !gt_boxes || !gt_classes || !gt_valid ||
+      !labels || !reg_targets || !bvars || !gt_inds)
+    return UTV2_EARG;
+  LevelTable t = make_table(num_levels, H, W, strides, soi);
+  const int L = t.off[num_levels];
+  hipLaunchKernelGGL(fcos_targets_kernel, dim3(cdiv(L, 256), N), dim3(256), 0, stream, t, N, MAXG, gt_boxes, gt_classes,
+                     gt_valid, gt_std, num_classes, drop_empty, labels, reg_targets, bvars, gt_inds);
+  return utv2_launch_status();
+}
+
+#define FOCAL_BLOCKS 1024
+// loss_sum[0] = sum over rows with label >= 0 and all C classes.  ws: >= FOCAL_BLOCKS floats.
+int utv2_sigmoid_focal_fwd(const float* logits, const int* labels, int64_t P, int C, float alpha, float gamma,
+                           float* loss_sum, float* ws, hipStream_t stream) {
+  if (!logits || !labels || !loss_sum || !ws) return UTV2_EARG;
+  hipLaunchKernelGGL(focal_fwd_kernel, dim3(FOCAL_BLOCKS), dim3(256), 0, stream, logits, labels, (size_t)P, C, alpha, gamma, ws);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws, FOCAL_BLOCKS, 1, loss_sum);
+  return utv2_launch_status();
+}
+
+int utv2_sigmoid_focal_bwd(const float* logits, const int* labels, int64_t P, int C, float alpha, float gamma,
+                           const float* coef, float* dlogits, hipStream_t stream) {
+  if (!logits || !labels || !coef || !dlogits) return UTV2_EARG;
+  hipLaunchKernelGGL(focal_bwd_kernel, dim3(2048), dim3(256), 0, stream, logits, labels, (size_t)P, C, alpha, gamma, coef, dlogits);
+  return utv2_launch_status();
+}
+
+#define LOC_BLOCKS 512
+// sums[8]: see LT_NSUM comment.  ws >= LOC_BLOCKS*8 floats.  reg_max+1 must be 17.
+int utv2_fcos_loc_terms_fwd(const int* labels, const float* box, int box_stride, const float* reg_targets,
+                            const float* bvars, int64_t P, int num_classes, int reg_max, float ts_better, float ts_cert,
+                            float* sums, float* ws, hipStream_t stream) {
+  if (!labels || !box || !reg_targets || !sums || !ws || reg_max != 16 || box_stride < 4 * 17 + 5 || (box_stride & 3)) return UTV2_EARG;
+  hipLaunchKernelGGL((fcos_loc_fwd_kernel<17>), dim3(LOC_BLOCKS), dim3(128), 0, stream, labels, box, box_stride, reg_targets,
+                     bvars, (size_t)P, num_classes, ts_better, ts_cert, ws);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws, LOC_BLOCKS, LT_NSUM, sums);
+  return utv2_launch_status();
+}
+
+int utv2_fcos_loc_terms_bwd(const int* labels, const float* box, int box_stride, const float* reg_targets,
+                            const float* bvars, int64_t P, int num_classes, int reg_max, float ts_better, float ts_cert,
+                            const float* coef, float* dbox, hipStream_t stream) {
+  if (!labels || !box || !reg_targets || !coef || !dbox || reg_max != 16 || box_stride < 4 * 17 + 5 || (box_stride & 3)) return UTV2_EARG;
+  hipLaunchKernelGGL((fcos_loc_bwd_kernel<17>), dim3(cdiv(P, 128)), dim3(128), 0, stream, labels, box, box_stride, reg_targets,
+                     bvars, (size_t)P, num_classes, ts_better, ts_cert, coef, dbox);
+  return utv2_launch_status();
+}
+
+// one level: logits [N][HW][C], box [N][HW][BS] -> keys [N][HW*C]
+int utv2_fcos_rank_keys(const float* logits, const float* box, int box_stride, int reg_max, int N, int HW, int C, float thr,
+                        int method, long long* keys, hipStream_t stream) {
+  if (!logits || !box || !keys || method < 0 || method > 3) return UTV2_EARG;
+  int gx = cdiv((int64_t)HW * C, 256);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(fcos_rank_keys_kernel, dim3(gx, N), dim3(256), 0, stream, logits, box, box_stride, 4 * (reg_max + 1), HW, C,
+                     thr, method, keys);
+  return utv2_launch_status();
+}
+
+int utv2_fcos_decode(const long long* topkeys, int K, const float* logits, const float* box, int box_stride, int reg_max,
+                     int N, int HW, int Wl, int C, int stride, int level, int method, int MAXC, int slot0, float* oboxes,
+                     float* oscores, int* ocls, float* oloc, float* octr, float* oconf, float* ostd, int* olevel,
+                     unsigned char* ovalid, hipStream_t stream) {
+  if (!topkeys || !logits || !box || reg_max != 16 || slot0 + K > MAXC) return UTV2_EARG;
+  hipLaunchKernelGGL((fcos_decode_kernel<17>), dim3(cdiv(K, 128), N), dim3(128), 0, stream, topkeys, K, logits, box, box_stride,
+                     HW, Wl, C, stride, level, method, MAXC, slot0, oboxes, oscores, ocls, oloc, octr, oconf, ostd, olevel,
+                     ovalid);
+  return utv2_launch_status();
+}
+
+int utv2_scale_cols(float* y, int64_t rows, int row_stride, int ncols, const float* s, hipStream_t stream) {
+  if (!y || !s) return UTV2_EARG;
+  int g = cdiv(rows * ncols, 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(scale_cols_kernel, dim3(g), dim3(256), 0, stream, y, (size_t)rows, row_stride, ncols, s);
+  return utv2_launch_status();
+}
+
+// g[:, :ncols] *= s in place; dsum[0] = sum(g_in * ypost) (caller divides by s).  ws >= 1024 floats.
+int utv2_scale_cols_bwd(float* g, const float* ypost, int64_t rows, int row_stride, int ncols, const float* s, float* dsum,
+                        float* ws, hipStream_t stream) {
+  if (!g || !ypost || !s || !dsum || !ws) return UTV2_EARG;
+  int nb = cdiv(rows * ncols, 256);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(scale_cols_bwd_kernel, dim3(nb), dim3(256), 0, stream, g, ypost, (size_t)rows, row_stride, ncols, s, ws);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws, nb, 1, dsum);
+  return utv2_launch_status();
+}
+
+}  // extern "C"

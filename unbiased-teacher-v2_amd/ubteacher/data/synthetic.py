@@ -1,0 +1,88 @@
+"""Synthetic COCO-shaped two-crop batches (SURVEY.md 8d "Synthetic inputs").
+
+Output contract = the reference loader's (ubteacher/data/common.py:158-163,
+dataset_mapper.py:139-157): each iteration yields
+    (label_strong, label_weak, unlabel_strong, unlabel_weak)
+four lists of dicts {image: uint8 [3,H,W] BGR, height, width, instances: Instances(gt_boxes, gt_classes)}.
+Images are generated once (seeded) and kept resident on the device; the strong view is the weak
+view with three noise-filled erase rectangles (area 2-20 %).
+"""
+import math
+
+import numpy as np
+import torch
+
+from ..d2.structures import Boxes, Instances
+from ..utils import comm
+
+
+def make_image(rng, h, w):
+    return torch.from_numpy(rng.integers(0, 256, size=(3, h, w), dtype=np.uint8))
+
+
+def strong_view(rng, img):
+    out = img.clone()
+    _, h, w = img.shape
+    for _ in range(3):
+        area = rng.uniform(0.02, 0.2) * h * w
+        ar = math.exp(rng.uniform(math.log(0.3), math.log(3.3)))
+        eh, ew = int(round(math.sqrt(area * ar))), int(round(math.sqrt(area / ar)))
+        eh, ew = min(eh, h), min(ew, w)
+        y0 = int(rng.integers(0, h - eh + 1))
+        x0 = int(rng.integers(0, w - ew + 1))
+        out[:, y0:y0 + eh, x0:x0 + ew] = torch.from_numpy(rng.integers(0, 256, size=(3, eh, ew), dtype=np.uint8))
+    return out
+
+
+def make_gt(rng, h, w, num_classes=80, max_boxes=15):
+    g = int(rng.integers(1, max_boxes + 1))
+    cx = rng.uniform(0, w, size=g)
+    cy = rng.uniform(0, h, size=g)
+    bw = np.exp(rng.uniform(math.log(16), math.log(600), size=g))
+    bh = np.exp(rng.uniform(math.log(16), math.log(600), size=g))
+    x1 = np.clip(cx - bw / 2, 0, w - 1)
+    y1 = np.clip(cy - bh / 2, 0, h - 1)
+    x2 = np.clip(cx + bw / 2, x1 + 2, w)
+    y2 = np.clip(cy + bh / 2, y1 + 2, h)
+    boxes = torch.tensor(np.stack([x1, y1, x2, y2], 1), dtype=torch.float32)
+    classes = torch.from_numpy(rng.integers(0, num_classes, size=g)).long()
+    inst = Instances((h, w))
+    inst.gt_boxes = Boxes(boxes)
+    inst.gt_classes = classes
+    return inst
+
+
+class SyntheticTwoCropLoader:
+    def __init__(self, cfg, height=800, width=1333, seed=0, device=None, num_batches=1):
+        ws = comm.get_world_size()
+        bl, bu = cfg.SOLVER.IMG_PER_BATCH_LABEL, cfg.SOLVER.IMG_PER_BATCH_UNLABEL
+        assert bl % ws == 0 and bu % ws == 0, "batch must be divisible by world size (data/build.py:228-238)"
+        self.bl, self.bu = bl // ws, bu // ws
+        dev = torch.device(device if device is not None else cfg.MODEL.DEVICE)
+        rng = np.random.default_rng(seed + 1000 * comm.get_rank())
+        nc = cfg.MODEL.FCOS.NUM_CLASSES if "FCOS" in cfg.MODEL else 80
+        self.batches = []
+        for _ in range(num_batches):
+            lq, lk, uq, uk = [], [], [], []
+            for _ in range(self.bl):
+                weak = make_image(rng, height, width)
+                strong = strong_view(rng, weak)
+                gt = make_gt(rng, height, width, nc)
+                lk.append({"image": weak.to(dev), "height": height, "width": width, "instances": gt})
+                lq.append({"image": strong.to(dev), "height": height, "width": width, "instances": gt})
+            for _ in range(self.bu):
+                weak = make_image(rng, height, width)
+                strong = strong_view(rng, weak)
+                uk.append({"image": weak.to(dev), "height": height, "width": width})
+                uq.append({"image": strong.to(dev), "height": height, "width": width})
+            self.batches.append((lq, lk, uq, uk))
+        self._i = 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        b = self.batches[self._i % len(self.batches)]
+        self._i += 1
+        # fresh dicts: the trainer deletes / adds keys in place (trainer.py:161-175)
+        return tuple([dict(d) for d in part] for part in b)

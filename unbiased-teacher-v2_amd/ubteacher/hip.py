@@ -20,15 +20,41 @@ c_i = ctypes.c_int
 c_i64 = ctypes.c_int64
 c_f = ctypes.c_float
 
-# name -> (restype, argtypes).  Must list every symbol declared in include/utv2.h.
-_SIGS = {
-    "utv2_conv2d_nhwc_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p] + [c_i] * 15 + [c_p]),
-    "utv2_conv2d_wgrad_splits": (c_i, [c_i] * 5),
-    "utv2_conv2d_wgrad_workspace_floats": (c_i64, [c_i] * 5),
-    "utv2_conv2d_nhwc_wgrad": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 12 + [c_p]),
-    "utv2_colsum": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
-    "utv2_weight_flip_transpose": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
-}
+HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "utv2.h")
+
+
+def _parse_header(path):
+    """Build ctypes signatures from the prototypes in include/utv2.h (single source of truth)."""
+    import re
+
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    sigs = {}
+    for m in re.finditer(r"\b(int64_t|int)\s+(utv2_\w+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        argt = []
+        for a in [x.strip() for x in args.replace("\n", " ").split(",") if x.strip()]:
+            if "*" in a or "utv2_stream_t" in a:
+                argt.append(c_p)
+            elif a.startswith("int64_t"):
+                argt.append(c_i64)
+            elif a.startswith("double"):
+                argt.append(ctypes.c_double)
+            elif a.startswith("float"):
+                argt.append(c_f)
+            elif a.startswith("int"):
+                argt.append(c_i)
+            elif a == "void":
+                pass
+            else:
+                raise RuntimeError("utv2.h: cannot map argument %r of %s" % (a, name))
+        sigs[name] = (c_i64 if ret == "int64_t" else c_i, argt)
+    return sigs
+
+
+_SIGS = _parse_header(HEADER_PATH)
+_PLAIN = {"utv2_conv2d_wgrad_splits", "utv2_conv2d_wgrad_workspace_floats", "utv2_groupnorm_workspace_floats",
+          "utv2_nms_mpad", "utv2_nms_workspace_bytes"}  # return a value, not a status
 
 
 def load():
@@ -143,3 +169,218 @@ def colsum(g2d, db, accumulate=True):
     ws = workspace(64 * C, g2d.device, "colsum")
     call("utv2_colsum", _p(g2d), _p(db), _p(ws), M, C, int(accumulate), _stream())
     return db
+
+
+# --------------------------------------------------------------------------------------------
+# elementwise / optimiser
+def ema_axpby(teacher_flat, student_flat, keep_rate):
+    assert teacher_flat.numel() == student_flat.numel()
+    call("utv2_ema_axpby", _p(teacher_flat), _p(student_flat), teacher_flat.numel(), float(keep_rate), _stream())
+
+
+def sgd_momentum(param, grad, mom, lr, momentum, weight_decay, grad_scale=1.0, zero_grad=True):
+    call("utv2_sgd_momentum", _p(param), _p(grad), _p(mom), param.numel(), float(lr), float(momentum),
+         float(weight_decay), float(grad_scale), int(zero_grad), _stream())
+
+
+def relu_bwd_scale(dy, y=None, scale=None, out=None):
+    C = dy.shape[-1]
+    M = dy.numel() // C
+    if out is None:
+        out = torch.empty_like(dy)
+    call("utv2_relu_bwd_scale", _p(dy), _p(y), _p(scale), _p(out), M, C, _stream())
+    return out
+
+
+def add(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    call("utv2_add", _p(a), _p(b), _p(out), a.numel(), _stream())
+    return out
+
+
+def maxpool3x3s2(x):
+    N, H, W, C = x.shape
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device)
+    call("utv2_maxpool3x3s2_nhwc", _p(x), _p(y), N, H, W, C, OH, OW, _stream())
+    return y
+
+
+def upsample2x_add(lateral, top):
+    N, H, W, C = lateral.shape
+    assert top.shape == (N, H // 2, W // 2, C), (lateral.shape, top.shape)
+    out = torch.empty_like(lateral)
+    call("utv2_upsample2x_add_nhwc", _p(lateral), _p(top), _p(out), N, H, W, C, _stream())
+    return out
+
+
+def downsample2x_sum(g, out=None, accumulate=False):
+    N, H, W, C = g.shape
+    if out is None:
+        out = torch.empty((N, H // 2, W // 2, C), dtype=torch.float32, device=g.device)
+    call("utv2_downsample2x_sum_nhwc", _p(g), _p(out), N, H // 2, W // 2, C, int(accumulate), _stream())
+    return out
+
+
+def preprocess_images(images, mean, std, size_divisibility):
+    """list of [3,H,W] uint8/float CUDA tensors -> ([N,Hp,Wp,4] fp32 NHWC4, image_sizes)."""
+    sizes = [(int(im.shape[1]), int(im.shape[2])) for im in images]
+    Hm, Wm = max(s[0] for s in sizes), max(s[1] for s in sizes)
+    d = size_divisibility
+    if d > 1:
+        Hm, Wm = (Hm + d - 1) // d * d, (Wm + d - 1) // d * d
+    out = torch.empty((len(images), Hm, Wm, 4), dtype=torch.float32, device=images[0].device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    for i, im in enumerate(images):
+        assert im.is_contiguous() and im.dtype in (torch.uint8, torch.float32)
+        call("utv2_preprocess_image", _p(im), int(im.dtype == torch.uint8), c_p(out[i].data_ptr()), sizes[i][0],
+             sizes[i][1], Hm, Wm, ctypes.cast(m, c_p), ctypes.cast(s, c_p), _stream())
+    return out, sizes
+
+
+def frozenbn_fold(w, b, mean, var, scale, shift, eps=1e-5):
+    call("utv2_frozenbn_fold", _p(w), _p(b), _p(mean), _p(var), _p(scale), _p(shift), w.numel(), float(eps), _stream())
+
+
+def groupnorm_relu_fwd(x, gamma, beta, G=32, eps=1e-5, relu=True):
+    N, H, W, C = x.shape
+    HW = H * W
+    y = torch.empty_like(x)
+    mean = torch.empty((N, G), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((N, G), dtype=torch.float32, device=x.device)
+    ws = workspace(load().utv2_groupnorm_workspace_floats(N, HW, C), x.device, "gn")
+    call("utv2_groupnorm_relu_fwd", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(ws), N, HW, C, G,
+         float(eps), int(relu), _stream())
+    return y, mean, rstd
+
+
+def groupnorm_relu_bwd(dy, y, x, mean, rstd, gamma, dgamma, dbeta, G=32, relu=True):
+    N, H, W, C = x.shape
+    HW = H * W
+    dx = torch.empty_like(x)
+    ws = workspace(load().utv2_groupnorm_workspace_floats(N, HW, C), x.device, "gn")
+    call("utv2_groupnorm_relu_bwd", _p(dy), _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta),
+         _p(ws), N, HW, C, G, int(relu), _stream())
+    return dx
+
+
+# --------------------------------------------------------------------------------------------
+# FCOS
+def _iarr(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def _farr(vals):
+    return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def fcos_targets(level_hw, strides, soi, gt_boxes, gt_classes, gt_valid, gt_std, num_classes, drop_empty):
+    """gt_* padded [N,MAXG,...]; returns labels[int32 P], reg_targets[P,4], bvars[P,4], gt_inds[P]."""
+    N, MAXG = gt_classes.shape
+    L = sum(h * w for h, w in level_hw)
+    P = N * L
+    dev = gt_boxes.device
+    labels = torch.empty(P, dtype=torch.int32, device=dev)
+    reg = torch.empty((P, 4), dtype=torch.float32, device=dev)
+    bv = torch.empty((P, 4), dtype=torch.float32, device=dev)
+    gi = torch.empty(P, dtype=torch.int32, device=dev)
+    H = _iarr([h for h, _ in level_hw])
+    W = _iarr([w for _, w in level_hw])
+    S = _iarr(strides)
+    flat = []
+    for lo, hi in soi:
+        flat += [lo, hi]
+    so = _farr(flat)
+    call("utv2_fcos_targets", len(level_hw), ctypes.cast(H, c_p), ctypes.cast(W, c_p), ctypes.cast(S, c_p),
+         ctypes.cast(so, c_p), N, MAXG, _p(gt_boxes), _p(gt_classes), _p(gt_valid), _p(gt_std), num_classes,
+         int(drop_empty), _p(labels), _p(reg), _p(bv), _p(gi), _stream())
+    return labels, reg, bv, gi
+
+
+def sigmoid_focal_fwd(logits, labels, alpha, gamma):
+    P, C = logits.shape
+    out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    ws = workspace(4096, logits.device, "loss")
+    call("utv2_sigmoid_focal_fwd", _p(logits), _p(labels), P, C, float(alpha), float(gamma), _p(out), _p(ws), _stream())
+    return out
+
+
+def sigmoid_focal_bwd(logits, labels, alpha, gamma, coef, out=None):
+    P, C = logits.shape
+    if out is None:
+        out = torch.empty_like(logits)
+    call("utv2_sigmoid_focal_bwd", _p(logits), _p(labels), P, C, float(alpha), float(gamma), _p(coef), _p(out), _stream())
+    return out
+
+
+def fcos_loc_terms_fwd(labels, box, reg_targets, bvars, num_classes, reg_max, ts_better, ts_cert):
+    P, BS = box.shape
+    sums = torch.empty(8, dtype=torch.float32, device=box.device)
+    ws = workspace(4096, box.device, "loss")
+    call("utv2_fcos_loc_terms_fwd", _p(labels), _p(box), BS, _p(reg_targets), _p(bvars), P, num_classes, reg_max,
+         float(ts_better), float(ts_cert), _p(sums), _p(ws), _stream())
+    return sums
+
+
+def fcos_loc_terms_bwd(labels, box, reg_targets, bvars, num_classes, reg_max, ts_better, ts_cert, coef, out=None):
+    P, BS = box.shape
+    if out is None:
+        out = torch.empty_like(box)
+    call("utv2_fcos_loc_terms_bwd", _p(labels), _p(box), BS, _p(reg_targets), _p(bvars), P, num_classes, reg_max,
+         float(ts_better), float(ts_cert), _p(coef), _p(out), _stream())
+    return out
+
+
+def fcos_rank_keys(logits, box, reg_max, N, HW, thr, method):
+    C = logits.shape[-1]
+    BS = box.shape[-1]
+    keys = torch.empty((N, HW * C), dtype=torch.int64, device=logits.device)
+    call("utv2_fcos_rank_keys", _p(logits), _p(box), BS, reg_max, N, HW, C, float(thr), method, _p(keys), _stream())
+    return keys
+
+
+def fcos_decode(topkeys, logits, box, reg_max, N, HW, Wl, stride, level, method, slot0, outs):
+    K = topkeys.shape[1]
+    C = logits.shape[-1]
+    BS = box.shape[-1]
+    MAXC = outs["scores"].shape[1]
+    call("utv2_fcos_decode", _p(topkeys), K, _p(logits), _p(box), BS, reg_max, N, HW, Wl, C, stride, level, method, MAXC,
+         slot0, _p(outs["boxes"]), _p(outs["scores"]), _p(outs["classes"]), _p(outs["locations"]), _p(outs["centerness"]),
+         _p(outs["cls_confid"]), _p(outs["reg_pred_std"]), _p(outs["fpn_levels"]), _p(outs["valid"]), _stream())
+
+
+def scale_cols(y2d, ncols, s):
+    rows, BS = y2d.shape
+    call("utv2_scale_cols", _p(y2d), rows, BS, ncols, _p(s), _stream())
+
+
+def scale_cols_bwd(g2d, ypost2d, ncols, s):
+    rows, BS = g2d.shape
+    dsum = torch.empty(1, dtype=torch.float32, device=g2d.device)
+    ws = workspace(4096, g2d.device, "loss")
+    call("utv2_scale_cols_bwd", _p(g2d), _p(ypost2d), rows, BS, ncols, _p(s), _p(dsum), _p(ws), _stream())
+    return dsum
+
+
+# --------------------------------------------------------------------------------------------
+# NMS / IoU
+def nms_batched(boxes, scores, classes, valid, iou_thr, class_aware=True, post_topk=-1, max_out=128):
+    """boxes [N,M,4], scores [N,M], classes [N,M] int32, valid [N,M] uint8 ->
+    keep [N,max_out] int32 (slot ids, -1 padded, descending score), count [N] int32."""
+    N, M = scores.shape
+    keep = torch.empty((N, max_out), dtype=torch.int32, device=boxes.device)
+    cnt = torch.empty(N, dtype=torch.int32, device=boxes.device)
+    nbytes = load().utv2_nms_workspace_bytes(N, M)
+    ws = workspace((nbytes + 3) // 4, boxes.device, "nms")
+    call("utv2_nms_batched", _p(boxes), _p(scores), _p(classes), _p(valid), N, M, float(iou_thr), int(class_aware),
+         int(post_topk), max_out, _p(keep), _p(cnt), _p(ws), _stream())
+    return keep, cnt
+
+
+def box_iou(a, b):
+    A, B = a.shape[0], b.shape[0]
+    out = torch.empty((A, B), dtype=torch.float32, device=a.device)
+    call("utv2_box_iou", _p(a), _p(b), A, B, _p(out), _stream())
+    return out

@@ -1,0 +1,221 @@
+"""ResNet-50 + FPN on the HIP conv path.
+
+Behavioural spec: Detectron2 v0.6 ResNet (STRIDE_IN_1X1, FrozenBN, FREEZE_AT=2) and FPN
+[D2-recall, SURVEY.md appendix C]; FCOS top block: reference ubteacher/modeling/backbone/fpn.py:11-78
+(P6 = conv3x3 s2 (P5), P7 = conv3x3 s2 (relu(P6))).  State-dict keys follow Detectron2's
+(`bottom_up.stem.conv1.weight`, `bottom_up.res3.0.conv1.norm.running_mean`, `fpn_lateral3.weight`,
+`top_block.p6.weight`, ...) so checkpoints stay interchangeable.
+
+MI355X mapping: every conv is one implicit-GEMM launch with FrozenBN/ReLU/residual fused in
+the epilogue; stem+res2 (frozen) run outside autograd; the image batch enters as NHWC4.
+"""
+import math
+
+import torch
+
+from .. import hip, ops
+from ..d2.registry import BACKBONE_REGISTRY
+
+
+def _nchw_view(cout, cin, k):
+    """[cout, k*k*cin] arena matrix -> [cout, cin, k, k]-shaped strided view (state_dict surface)."""
+    def fn(t):
+        return t.view(cout, k, k, cin).permute(0, 3, 1, 2)
+    return fn
+
+
+def _msra_init(cout, cin, k):
+    def fn(t):  # kaiming_normal_(mode="fan_out", nonlinearity="relu")
+        std = math.sqrt(2.0 / (cout * k * k))
+        t.normal_(0.0, std)
+    return fn
+
+
+def _xavier_init(cout, cin, k):
+    def fn(t):  # c2_xavier_fill: kaiming_uniform_(a=1)  -> bound = sqrt(3 / fan_in)
+        bound = math.sqrt(3.0 / (cin * k * k))
+        t.uniform_(-bound, bound)
+    return fn
+
+
+class FrozenBN:
+    """Four per-channel buffers; folded to scale/shift by one launch for all layers (utv2_frozenbn_fold)."""
+
+    def __init__(self, store, prefix, c):
+        self.w = store.new((c,), "bn_w", lambda t: t.fill_(1.0)).export(prefix + ".weight")
+        self.b = store.new((c,), "bn_b", lambda t: t.zero_()).export(prefix + ".bias")
+        self.m = store.new((c,), "bn_m", lambda t: t.zero_()).export(prefix + ".running_mean")
+        self.v = store.new((c,), "bn_v", lambda t: t.fill_(1.0)).export(prefix + ".running_var")
+        self.c = c
+        self.scale = None
+        self.shift = None
+
+
+class BNFolder:
+    def __init__(self, store):
+        self.store = store
+        self.layers = []
+        self.scale_all = None
+
+    def add(self, bn):
+        self.layers.append(bn)
+        return bn
+
+    def materialize(self):
+        st = self.store
+        s0, e0 = st.ranges["bn_w"]
+        n = e0 - s0
+        self.n = n
+        self.scale_all = torch.empty(n, dtype=torch.float32, device=st.flat.device)
+        self.shift_all = torch.empty(n, dtype=torch.float32, device=st.flat.device)
+        for bn in self.layers:
+            o = bn.w.offset - s0
+            bn.scale = self.scale_all[o: o + bn.c]
+            bn.shift = self.shift_all[o: o + bn.c]
+
+    def fold(self, eps=1e-5):
+        if self.n == 0:
+            return
+        st = self.store
+        hip.frozenbn_fold(st.region("bn_w"), st.region("bn_b"), st.region("bn_m"), st.region("bn_v"),
+                          self.scale_all, self.shift_all, eps)
+
+
+def _conv_bn(store, folder, prefix, cin, cout, k, stride, pad, relu, trainable):
+    kind = "decay" if trainable else "frozen"
+    w = store.new((cout, k * k * cin), kind, _msra_init(cout, cin, k)).export(prefix + ".weight", _nchw_view(cout, cin, k))
+    bn = folder.add(FrozenBN(store, prefix + ".norm", cout))
+    return ops.Conv(w, cin, cout, k, stride, pad, bias=None, bn=bn, relu=relu, trainable=trainable)
+
+
+class Bottleneck:
+    def __init__(self, store, folder, prefix, cin, cout, mid, stride, trainable):
+        # STRIDE_IN_1X1: the stride sits on conv1
+        self.conv1 = _conv_bn(store, folder, prefix + ".conv1", cin, mid, 1, stride, 0, True, trainable)
+        self.conv2 = _conv_bn(store, folder, prefix + ".conv2", mid, mid, 3, 1, 1, True, trainable)
+        self.conv3 = _conv_bn(store, folder, prefix + ".conv3", mid, cout, 1, 1, 0, True, trainable)  # relu after add
+        self.shortcut = None
+        if cin != cout:
+            self.shortcut = _conv_bn(store, folder, prefix + ".shortcut", cin, cout, 1, stride, 0, False, trainable)
+
+    def __call__(self, x):
+        sc = self.shortcut(x) if self.shortcut is not None else x
+        out = self.conv1(x)
+        out = self.conv2(out)
+        return self.conv3(out, residual=sc)
+
+
+class ResNet50:
+    def __init__(self, store, folder, prefix, out_features, freeze_at=2):
+        self.out_features = out_features
+        # stem on the NHWC4 image: [64][7*7*4 -> padded to 208]
+        def stem_init(t):
+            t.zero_()
+            w = torch.empty(64, 7, 7, 3, device=t.device).normal_(0.0, math.sqrt(2.0 / (64 * 49)))
+            t.view(64, 208)[:, :196].view(64, 7, 7, 4)[..., :3].copy_(w)
+        stem_train = freeze_at < 1
+        self.stem_w = store.new((64, 208), "decay" if stem_train else "frozen", stem_init).export(
+            prefix + ".stem.conv1.weight", lambda t: torch.as_strided(t, (64, 3, 7, 7), (208, 1, 28, 4), t.storage_offset()))
+        self.stem_bn = folder.add(FrozenBN(store, prefix + ".stem.conv1.norm", 64))
+        self.stem = ops.Conv(self.stem_w, 4, 64, 7, 2, 3, bn=self.stem_bn, relu=True, trainable=stem_train, kred=208)
+        self.stages = []
+        cin = 64
+        for si, (name, nblocks, mid, cout) in enumerate([("res2", 3, 64, 256), ("res3", 4, 128, 512),
+                                                          ("res4", 6, 256, 1024), ("res5", 3, 512, 2048)]):
+            trainable = freeze_at < si + 2
+            blocks = []
+            for b in range(nblocks):
+                stride = 2 if (b == 0 and name != "res2") else 1
+                blocks.append(Bottleneck(store, folder, "%s.%s.%d" % (prefix, name, b), cin, cout, mid, stride, trainable))
+                cin = cout
+            self.stages.append((name, blocks, trainable))
+        self.channels = {"res2": 256, "res3": 512, "res4": 1024, "res5": 2048}
+        self.strides = {"res2": 4, "res3": 8, "res4": 16, "res5": 32}
+
+    def __call__(self, x4):
+        outs = {}
+        with torch.no_grad():
+            x = self.stem(x4)
+            x = hip.maxpool3x3s2(x)
+        for name, blocks, trainable in self.stages:
+            if trainable:
+                for b in blocks:
+                    x = b(x)
+            else:
+                with torch.no_grad():
+                    for b in blocks:
+                        x = b(x)
+            if name in self.out_features:
+                outs[name] = x
+        return outs
+
+
+def _conv_bias(store, prefix, cin, cout, k, stride, pad, init, relu=False):
+    w = store.new((cout, k * k * cin), "decay", init(cout, cin, k)).export(prefix + ".weight", _nchw_view(cout, cin, k))
+    b = store.new((cout,), "decay", lambda t: t.zero_()).export(prefix + ".bias")
+    return ops.Conv(w, cin, cout, k, stride, pad, bias=b, relu=relu, trainable=True)
+
+
+class FPN:
+    """lateral 1x1 + top-down nearest x2 sum + output 3x3 (FUSE_TYPE sum, NORM '')."""
+
+    def __init__(self, store, folder, cfg, top_block_kind):
+        self.bottom_up = ResNet50(store, folder, "backbone.bottom_up", cfg.MODEL.RESNETS.OUT_FEATURES,
+                                  cfg.MODEL.BACKBONE.FREEZE_AT)
+        self.in_features = list(cfg.MODEL.FPN.IN_FEATURES)
+        oc = cfg.MODEL.FPN.OUT_CHANNELS
+        self.out_channels = oc
+        self.lateral, self.output = {}, {}
+        for f in self.in_features:
+            stage = int(math.log2(self.bottom_up.strides[f]))
+            self.lateral[f] = _conv_bias(store, "backbone.fpn_lateral%d" % stage, self.bottom_up.channels[f], oc, 1, 1, 0, _xavier_init)
+            self.output[f] = _conv_bias(store, "backbone.fpn_output%d" % stage, oc, oc, 3, 1, 1, _xavier_init)
+        self.top_block_kind = top_block_kind
+        self.top = []
+        if top_block_kind == "p6p7":
+            self.top = [_conv_bias(store, "backbone.top_block.p6", oc, oc, 3, 2, 1, _xavier_init),
+                        _conv_bias(store, "backbone.top_block.p7", oc, oc, 3, 2, 1, _xavier_init)]
+        elif top_block_kind == "p6":
+            self.top = [_conv_bias(store, "backbone.top_block.p6", oc, oc, 3, 2, 1, _xavier_init)]
+        stages = [int(math.log2(self.bottom_up.strides[f])) for f in self.in_features]
+        self.out_names = ["p%d" % s for s in stages]
+        last = stages[-1]
+        ntop = {"p6p7": 2, "p6": 1, "maxpool": 1, "none": 0}[top_block_kind]
+        self.out_names += ["p%d" % (last + 1 + i) for i in range(ntop)]
+        self.size_divisibility = self.bottom_up.strides[self.in_features[-1]]
+
+    def __call__(self, x4):
+        feats = self.bottom_up(x4)
+        results = {}
+        prev = None
+        for f in reversed(self.in_features):
+            lat = self.lateral[f](feats[f])
+            if prev is not None:
+                lat = ops.upsample2x_add(lat, prev)
+            prev = lat
+            stage = int(math.log2(self.bottom_up.strides[f]))
+            results["p%d" % stage] = self.output[f](lat)
+        last = "p%d" % int(math.log2(self.bottom_up.strides[self.in_features[-1]]))
+        if self.top_block_kind == "p6p7":
+            p6 = self.top[0](results[last])
+            p7 = self.top[1](ops.relu(p6))
+            n = int(last[1:])
+            results["p%d" % (n + 1)] = p6
+            results["p%d" % (n + 2)] = p7
+        elif self.top_block_kind == "p6":
+            results["p%d" % (int(last[1:]) + 1)] = self.top[0](results[last])
+        elif self.top_block_kind == "maxpool":
+            # LastLevelMaxPool: max_pool2d(kernel 1, stride 2) == strided subsample
+            results["p%d" % (int(last[1:]) + 1)] = results[last][:, ::2, ::2, :].contiguous()
+        return {k: results[k] for k in self.out_names}
+
+
+@BACKBONE_REGISTRY.register()
+def build_fcos_resnet_fpn_backbone(cfg, store, folder):
+    tl = cfg.MODEL.FCOS.TOP_LEVELS
+    return FPN(store, folder, cfg, {2: "p6p7", 1: "p6", 0: "none"}[tl])
+
+
+@BACKBONE_REGISTRY.register()
+def build_resnet_fpn_backbone(cfg, store, folder):
+    return FPN(store, folder, cfg, "maxpool")

@@ -1,0 +1,397 @@
+"""FCOS proposal generator (head + targets + losses + decode) on the HIP path.
+
+Mirrors the reference's `FCOS` / `FCOSHead` / `FCOSOutputs` (ubteacher/modeling/fcos/fcos.py:44-376,
+fcos_outputs.py:132-1320) behind the same registry name and the same branch / nms_method
+arguments, re-laid-out for MI355X:
+
+  * head outputs of all levels are written by the convs straight into two level-first
+    [P, 80] buffers (cls logits; box = 68 reg bins | 4 std | 1 ctr | 7 pad): the reference's
+    permute/reshape/cat (fcos_outputs.py:261-290) never exists;
+  * bbox_pred / bbox_pred_std / ctrness share one fused 256->80 conv (their weights are adjacent
+    rows of one arena matrix; state_dict still exposes the three reference tensors);
+  * targets, focal, and the positive-location losses are dense kernels over all locations with
+    device-side normalisers: no nonzero()/item() host syncs (the reference has ~10 per call);
+  * pseudo-labels stay on the device as padded slots + validity masks.
+"""
+import math
+
+import torch
+
+from .. import hip, ops
+from ..d2.registry import PROPOSAL_GENERATOR_REGISTRY
+from ..d2.structures import Boxes, Instances
+from ..utils import comm
+from .backbone import _nchw_view
+
+INF = 100000000
+METHODS = {"cls": 0, "cls_n_ctr": 1, "ctr": 2, "cls_n_loc": 3}
+BOX_STRIDE = 80  # 4*(REG_MAX+1) + 4 + 1 = 73 -> padded to 80 (multiple of 16 for the dgrad fast path)
+
+
+class PaddedBoxes:
+    """Per-image padded detections / ground truth living on the device."""
+
+    def __init__(self, image_sizes, **fields):
+        self.image_sizes = image_sizes
+        self.f = fields  # boxes [N,M,4], classes [N,M] int32, valid [N,M] uint8, scores, reg_pred_std, ...
+
+    def __getitem__(self, k):
+        return self.f[k]
+
+    def __contains__(self, k):
+        return k in self.f
+
+    @property
+    def n(self):
+        return self.f["valid"].shape[0]
+
+    def threshold(self, thr, ctr_thr=None):
+        """pseudo_generator.py:62-131: keep scores > thr (or cls_confid > thr0 & centerness > thr1)."""
+        if ctr_thr is None:
+            keep = self.f["scores"] > thr
+        else:
+            keep = (self.f["cls_confid"] > thr) & (self.f["centerness"] > ctr_thr)
+        out = dict(self.f)
+        out["valid"] = (self.f["valid"].bool() & keep).to(torch.uint8)
+        return PaddedBoxes(self.image_sizes, **out)
+
+    def to_instances(self, as_gt=False):
+        """Materialise reference-style Instances (forces a device sync; API compatibility only)."""
+        res = []
+        for i in range(self.n):
+            m = self.f["valid"][i].bool()
+            inst = Instances(self.image_sizes[i])
+            if as_gt:
+                inst.gt_boxes = Boxes(self.f["boxes"][i][m])
+                inst.gt_classes = self.f["classes"][i][m].long()
+            else:
+                inst.pred_boxes = Boxes(self.f["boxes"][i][m])
+                inst.pred_classes = self.f["classes"][i][m].long()
+            for k in ("scores", "centerness", "cls_confid", "reg_pred_std", "locations", "fpn_levels"):
+                if k in self.f:
+                    inst.set(k, self.f[k][i][m])
+            res.append(inst)
+        return res
+
+    @staticmethod
+    def from_instances(instances, device, min_slots=16):
+        """list[Instances] with gt_boxes/gt_classes (+ optional scores, reg_pred_std) -> padded device arrays."""
+        n = len(instances)
+        g = max([len(x) for x in instances] + [1])
+        M = max(min_slots, (g + 15) // 16 * 16)
+        assert M <= 256, "more than 256 ground-truth boxes per image is not supported by utv2_fcos_targets"
+        boxes = torch.zeros((n, M, 4), dtype=torch.float32)
+        classes = torch.zeros((n, M), dtype=torch.int32)
+        valid = torch.zeros((n, M), dtype=torch.uint8)
+        std = None
+        has_std = any(x.has("reg_pred_std") for x in instances if len(x))
+        if has_std:
+            std = torch.zeros((n, M, 4), dtype=torch.float32)
+        for i, x in enumerate(instances):
+            k = len(x)
+            if k == 0:
+                continue
+            boxes[i, :k] = x.gt_boxes.tensor.detach().float().cpu()
+            classes[i, :k] = x.gt_classes.detach().cpu().to(torch.int32)
+            valid[i, :k] = 1
+            if has_std and x.has("reg_pred_std"):
+                std[i, :k] = x.reg_pred_std.detach().float().cpu()
+        f = dict(boxes=boxes.to(device), classes=classes.to(device), valid=valid.to(device))
+        if std is not None:
+            f["reg_pred_std"] = std.to(device)
+        return PaddedBoxes([x.image_size for x in instances], **f)
+
+
+def compute_locations(h, w, stride, device):
+    """utils/comm.py:34-45 of the reference: (x*s + s//2, y*s + s//2), row-major."""
+    sx = torch.arange(0, w * stride, step=stride, dtype=torch.float32, device=device)
+    sy = torch.arange(0, h * stride, step=stride, dtype=torch.float32, device=device)
+    yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+    return torch.stack((xx.reshape(-1), yy.reshape(-1)), dim=1) + stride // 2
+
+
+class FCOSHead:
+    def __init__(self, cfg, store, in_channels, prefix):
+        fc = cfg.MODEL.FCOS
+        assert fc.NORM == "GN", "only the GN towers of the shipped configs are built"
+        assert fc.REG_DISCRETE and fc.KL_LOSS and fc.REG_MAX == 16, "UTv2 FCOS configs: REG_DISCRETE + KL_LOSS, REG_MAX 16"
+        assert not fc.USE_DEFORMABLE
+        self.num_classes = fc.NUM_CLASSES
+        self.reg_max = fc.REG_MAX
+        self.num_levels = len(fc.FPN_STRIDES)
+        C = in_channels
+        self.C = C
+        self.towers = {}
+        for name, nconv in (("cls", fc.NUM_CLS_CONVS), ("bbox", fc.NUM_BOX_CONVS), ("share", fc.NUM_SHARE_CONVS)):
+            layers = []
+            for i in range(nconv):
+                p = "%s.%s_tower.%d" % (prefix, name, 3 * i)
+                w = store.new((C, 9 * C), "decay", lambda t: t.normal_(0.0, 0.01)).export(p + ".weight", _nchw_view(C, C, 3))
+                b = store.new((C,), "decay", lambda t: t.zero_()).export(p + ".bias")
+                conv = ops.Conv(w, C, C, 3, 1, 1, bias=b)
+                pg = "%s.%s_tower.%d" % (prefix, name, 3 * i + 1)
+                ga = store.new((C,), "nodecay", lambda t: t.fill_(1.0)).export(pg + ".weight")
+                be = store.new((C,), "nodecay", lambda t: t.zero_()).export(pg + ".bias")
+                layers.append((conv, ops.GroupNormReLU(ga, be, 32, 1e-5, True)))
+            self.towers[name] = layers
+        nc = self.num_classes
+        prior = fc.PRIOR_PROB
+        bias_value = -math.log((1 - prior) / prior)
+        w = store.new((nc, 9 * C), "decay", lambda t: t.normal_(0.0, 0.01)).export(prefix + ".cls_logits.weight", _nchw_view(nc, C, 3))
+        b = store.new((nc,), "decay", lambda t: t.fill_(bias_value)).export(prefix + ".cls_logits.bias")
+        self.cls_logits = ops.Conv(w, C, nc, 3, 1, 1, bias=b)
+        # fused box head: rows [0:R4) bbox_pred, [R4:R4+4) bbox_pred_std, [R4+4] ctrness, rest zero padding
+        R4 = 4 * (self.reg_max + 1)
+        self.R4 = R4
+
+        def init_box(t):
+            t.zero_()
+            t[:R4].normal_(0.0, 0.01)
+            t[R4:R4 + 4].normal_(0.0, 0.0001)
+            t[R4 + 4:R4 + 5].normal_(0.0, 0.01)
+
+        def rows(r0, r1):
+            def fn(t):
+                return t[r0:r1].view(r1 - r0, 3, 3, C).permute(0, 3, 1, 2)
+            return fn
+
+        wb = store.new((BOX_STRIDE, 9 * C), "decay", init_box)
+        wb.export(prefix + ".bbox_pred.weight", rows(0, R4))
+        wb.export(prefix + ".bbox_pred_std.weight", rows(R4, R4 + 4))
+        wb.export(prefix + ".ctrness.weight", rows(R4 + 4, R4 + 5))
+        bb = store.new((BOX_STRIDE,), "decay", lambda t: t.zero_())
+        bb.export(prefix + ".bbox_pred.bias", lambda t: t[0:R4])
+        bb.export(prefix + ".bbox_pred_std.bias", lambda t: t[R4:R4 + 4])
+        bb.export(prefix + ".ctrness.bias", lambda t: t[R4 + 4:R4 + 5])
+        self.box_head = ops.Conv(wb, C, BOX_STRIDE, 3, 1, 1, bias=bb, colscale=R4)
+        self.scales = None
+        if fc.USE_SCALE:
+            self.scales = [store.new((1,), "decay", lambda t: t.fill_(1.0)).export("%s.scales.%d.scale" % (prefix, l))
+                           for l in range(self.num_levels)]
+
+    def __call__(self, feats):
+        """feats: list of NHWC level features. Returns (logits_levels, box_levels, logits_all, box_all, rows)."""
+        N = feats[0].shape[0]
+        hw = [f.shape[1] * f.shape[2] for f in feats]
+        P = N * sum(hw)
+        dev = feats[0].device
+        logits_all = torch.empty((P, self.num_classes), dtype=torch.float32, device=dev)
+        box_all = torch.empty((P, BOX_STRIDE), dtype=torch.float32, device=dev)
+        rows_l, rows_b, lo, bo = [], [], [], []
+        r = 0
+        for l, f in enumerate(feats):
+            n, h, w, _ = f.shape
+            t = f
+            for conv, gn in self.towers["share"]:
+                t = gn(conv(t))
+            tc = t
+            for conv, gn in self.towers["cls"]:
+                tc = gn(conv(tc))
+            tb = t
+            for conv, gn in self.towers["bbox"]:
+                tb = gn(conv(tb))
+            r1 = r + n * h * w
+            lo.append(self.cls_logits(tc, out=logits_all[r:r1].view(n, h, w, self.num_classes)))
+            bo.append(self.box_head(tb, out=box_all[r:r1].view(n, h, w, BOX_STRIDE),
+                                    colscale_handle=self.scales[l] if self.scales is not None else None))
+            rows_l.append((r, r1, (n, h, w, self.num_classes)))
+            rows_b.append((r, r1, (n, h, w, BOX_STRIDE)))
+            r = r1
+        return lo, bo, logits_all, box_all, rows_l, rows_b
+
+
+class FCOSOutputs:
+    """Targets, losses and proposal decode (reference fcos_outputs.py:132-1320) on dense kernels."""
+
+    def __init__(self, cfg):
+        fc = cfg.MODEL.FCOS
+        self.focal_loss_alpha = fc.LOSS_ALPHA
+        self.focal_loss_gamma = fc.LOSS_GAMMA
+        assert not fc.CENTER_SAMPLE, "CENTER_SAMPLE True is a SURVEY 8(f) 'next' row"
+        self.pre_nms_thresh_train = fc.INFERENCE_TH_TRAIN
+        self.pre_nms_topk_train = fc.PRE_NMS_TOPK_TRAIN
+        self.post_nms_topk_train = fc.POST_NMS_TOPK_TRAIN
+        self.pre_nms_thresh_test = fc.INFERENCE_TH_TEST
+        self.pre_nms_topk_test = fc.PRE_NMS_TOPK_TEST
+        self.post_nms_topk_test = fc.POST_NMS_TOPK_TEST
+        self.nms_thresh = fc.NMS_TH
+        assert not fc.THRESH_WITH_CTR
+        self.num_classes = fc.NUM_CLASSES
+        self.strides = list(fc.FPN_STRIDES)
+        assert not cfg.SEMISUPNET.SOFT_CLS_LABEL
+        assert cfg.SEMISUPNET.CLS_LOSS_METHOD == "focal"
+        self.reg_max = fc.REG_MAX
+        self.unify_ctrcls = fc.UNIFY_CTRCLS
+        assert fc.KL_LOSS and fc.KL_LOSS_TYPE == "nlloss" and fc.LOC_LOSS_TYPE == "giou" and fc.QUALITY_EST == "centerness"
+        self.kl_loss_weight = fc.KLLOSS_WEIGHT
+        self.reg_unsup_loss = cfg.SEMISUPNET.CONSIST_REG_LOSS
+        assert self.reg_unsup_loss == "ts_locvar_better_nms_nll_l1"
+        self.tsbetter_reg = cfg.SEMISUPNET.TS_BETTER
+        self.tsbetter_reg_cert = cfg.SEMISUPNET.TS_BETTER_CERT
+        soi, prev = [], -1
+        for s in fc.SIZES_OF_INTEREST:
+            soi.append([prev, s])
+            prev = s
+        soi.append([prev, INF])
+        self.sizes_of_interest = soi
+        self.training = True
+
+    # -- targets --------------------------------------------------------------------------------
+    def _targets(self, level_hw, gt, drop_empty):
+        std = gt["reg_pred_std"] if "reg_pred_std" in gt else None
+        return hip.fcos_targets(level_hw, self.strides, self.sizes_of_interest, gt["boxes"], gt["classes"],
+                                gt["valid"], std, self.num_classes, drop_empty)
+
+    @staticmethod
+    def _normalisers(sums):
+        """num_pos_avg = max(allreduce(n_pos)/world, 1), loss_denorm = max(allreduce(sum ctr)/world, 1e-6)
+        (fcos_outputs.py:317-321,361-362) as ONE fused 2-float all-reduce kept on the device."""
+        ws = comm.get_world_size()
+        pair = sums[0:2].detach().clone()
+        pair = comm.reduce_sum(pair)
+        npa = (pair[0] / ws).clamp(min=1.0)
+        den = (pair[1] / ws).clamp(min=1e-6)
+        return npa, den
+
+    # -- supervised branch (fcos_outputs.py:212-444) -------------------------------------------------
+    def losses(self, head_out, level_hw, gt, branch="labeled"):
+        if branch != "labeled":
+            raise ValueError("Incorrect branch name")
+        lo, bo, logits_all, box_all, rows_l, rows_b = head_out
+        labels, reg_t, bvars, gt_inds = self._targets(level_hw, gt, drop_empty=1)
+        focal = ops.focal_loss_sum(logits_all, labels, self.focal_loss_alpha, self.focal_loss_gamma, rows_l, lo)
+        sums = ops.fcos_loc_terms(box_all, labels, reg_t, None, (self.num_classes, self.reg_max, 0.0, 0.0), rows_b, bo)
+        npa, den = self._normalisers(sums)
+        w = self.kl_loss_weight
+        nll_mean = sums[4] / sums[0].detach().clamp(min=1.0)
+        losses = {
+            "loss_fcos_cls": focal[0] / npa,
+            "loss_fcos_loc": w * (w * nll_mean) + sums[3] / den,
+            "loss_fcos_ctr": sums[2] / npa,
+        }
+        extras = {"labels": labels, "reg_targets": reg_t, "gt_inds": gt_inds, "loss_denorm": den, "sums": sums}
+        return extras, losses
+
+    # -- pseudo branch (fcos_outputs.py:447-631) -----------------------------------------------------
+    def pseudo_losses(self, head_out, level_hw, gt_dict, branch="unlabeled"):
+        assert branch == "unlabeled"
+        lo, bo, logits_all, box_all, rows_l, rows_b = head_out
+        losses, extras = {}, {}
+        for labeltype, gt in gt_dict.items():
+            labels, reg_t, bvars, gt_inds = self._targets(level_hw, gt, drop_empty=0)
+            if labeltype == "cls":
+                focal = ops.focal_loss_sum(logits_all, labels, self.focal_loss_alpha, self.focal_loss_gamma, rows_l, lo)
+                sums = ops.fcos_loc_terms(box_all, labels, reg_t, None, (self.num_classes, self.reg_max, 0.0, 0.0), rows_b, bo)
+                npa, den = self._normalisers(sums)
+                losses["loss_fcos_cls"] = focal[0] / npa
+                ctr = sums[2] / npa
+                losses["loss_fcos_ctr"] = ctr * 0 if self.unify_ctrcls else ctr
+            elif labeltype == "reg":
+                sums = ops.fcos_loc_terms(box_all, labels, reg_t, bvars,
+                                          (self.num_classes, self.reg_max, self.tsbetter_reg, self.tsbetter_reg_cert), rows_b, bo)
+                self._normalisers(sums)  # the reference issues the same two reductions here (:504,:521)
+                losses["loss_fcos_loc"] = sums[6] / sums[5].detach().clamp(min=1.0)
+                losses["teacher_better_student"] = sums[5].detach()
+            else:
+                raise ValueError(labeltype)
+            extras["labels_" + labeltype] = labels
+            extras["sums_" + labeltype] = sums
+        return extras, losses
+
+    # -- decode + NMS (fcos_outputs.py:1046-1320) ---------------------------------------------------
+    def predict_proposals(self, head_out, level_hw, image_sizes, nms_method="cls_n_ctr", max_det=128):
+        if self.training:
+            th, pre, post = self.pre_nms_thresh_train, self.pre_nms_topk_train, self.post_nms_topk_train
+        else:
+            th, pre, post = self.pre_nms_thresh_test, self.pre_nms_topk_test, self.post_nms_topk_test
+        if nms_method not in METHODS:
+            raise ValueError("Undefined nms criteria")
+        method = METHODS[nms_method]
+        lo, bo, logits_all, box_all, rows_l, rows_b = head_out
+        N = lo[0].shape[0]
+        dev = logits_all.device
+        ks = [min(pre, h * w * self.num_classes) for (h, w) in level_hw]
+        MAXC = sum(ks)
+        outs = dict(
+            boxes=torch.empty((N, MAXC, 4), dtype=torch.float32, device=dev),
+            scores=torch.empty((N, MAXC), dtype=torch.float32, device=dev),
+            classes=torch.empty((N, MAXC), dtype=torch.int32, device=dev),
+            locations=torch.empty((N, MAXC, 2), dtype=torch.float32, device=dev),
+            centerness=torch.empty((N, MAXC), dtype=torch.float32, device=dev),
+            cls_confid=torch.empty((N, MAXC), dtype=torch.float32, device=dev),
+            reg_pred_std=torch.empty((N, MAXC, 4), dtype=torch.float32, device=dev),
+            fpn_levels=torch.empty((N, MAXC), dtype=torch.int32, device=dev),
+            valid=torch.empty((N, MAXC), dtype=torch.uint8, device=dev),
+        )
+        slot0 = 0
+        for l, (h, w) in enumerate(level_hw):
+            lg, bx = lo[l].detach(), bo[l].detach()
+            keys = hip.fcos_rank_keys(lg, bx, self.reg_max, N, h * w, th, method)
+            top = torch.topk(keys, ks[l], dim=1, sorted=True).values.contiguous()
+            hip.fcos_decode(top, lg, bx, self.reg_max, N, h * w, w, self.strides[l], l, method, slot0, outs)
+            slot0 += ks[l]
+        keep, cnt = hip.nms_batched(outs["boxes"], outs["scores"], outs["classes"], outs["valid"], self.nms_thresh,
+                                    class_aware=True, post_topk=post, max_out=max_det)
+        idx = keep.clamp(min=0).long()
+        valid = (torch.arange(max_det, device=dev)[None, :] < cnt[:, None]).to(torch.uint8)
+        f = {}
+        for k, v in outs.items():
+            if k == "valid":
+                continue
+            ix = idx if v.dim() == 2 else idx[:, :, None].expand(-1, -1, v.shape[2])
+            f[k] = torch.gather(v, 1, ix).contiguous()
+        f["valid"] = valid
+        f["count"] = cnt
+        return PaddedBoxes(image_sizes, **f)
+
+
+@PROPOSAL_GENERATOR_REGISTRY.register()
+class FCOS:
+    def __init__(self, cfg, store, in_channels, prefix="proposal_generator"):
+        fc = cfg.MODEL.FCOS
+        self.in_features = list(fc.IN_FEATURES)
+        self.fpn_strides = list(fc.FPN_STRIDES)
+        self.yield_proposal = fc.YIELD_PROPOSAL
+        self.fcos_head = FCOSHead(cfg, store, in_channels, prefix + ".fcos_head")
+        self.fcos_outputs = FCOSOutputs(cfg)
+        # Integral.project is a persistent buffer in the reference (fcos_outputs.py:61-63): keep the key.
+        self.project = store.new((fc.REG_MAX + 1,), "buffer",
+                                 lambda t: t.copy_(torch.linspace(0, fc.REG_MAX, fc.REG_MAX + 1))).export(
+            prefix + ".fcos_outputs.integral.project")
+        self.training = True
+
+    def train(self, mode=True):
+        self.training = mode
+        self.fcos_outputs.training = mode
+
+    def forward(self, image_sizes, features, gt_instances=None, output_raw=False, nms_method="cls_n_ctr",
+                ignore_near=False, branch="labeled"):
+        feats = [features[f] for f in self.in_features]
+        level_hw = [(f.shape[1], f.shape[2]) for f in feats]
+        head_out = self.fcos_head(feats)
+        raw_output = {"head_out": head_out, "level_hw": level_hw, "image_sizes": image_sizes,
+                      "logits_pred": head_out[0], "box_pred": head_out[1]}
+        results = {}
+        if self.training:
+            if ignore_near:
+                raise NotImplementedError("PSEUDO_CLS_IGNORE_NEAR is False in every shipped config")
+            if branch == "labeled":
+                results, losses = self.fcos_outputs.losses(head_out, level_hw, gt_instances, branch=branch)
+            elif branch == "unlabeled":
+                results, losses = self.fcos_outputs.pseudo_losses(head_out, level_hw, gt_instances, branch=branch)
+            elif branch == "raw":
+                results, losses = {}, {}
+            else:
+                raise ValueError("Unknown branch")
+            # B16: the reference also decodes + NMSes student proposals here when
+            # YIELD_PROPOSAL is set and never uses them; that wasted work is deliberately skipped.
+            if output_raw:
+                return results, losses, raw_output
+            return results, losses
+        with torch.no_grad():
+            results = self.fcos_outputs.predict_proposals(head_out, level_hw, image_sizes, nms_method)
+        if output_raw:
+            return results, {}, raw_output
+        return results, {}
+
+    __call__ = forward

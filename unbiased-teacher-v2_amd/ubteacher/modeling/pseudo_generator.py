@@ -1,0 +1,30 @@
+"""Pseudo-label generation for FCOS (reference ubteacher/modeling/pseudo_generator.py:7-131).
+
+Quirk kept: this object owns its own FCOSOutputs that is never put in eval mode, so
+`nms_from_dense` reads the *_TRAIN thresholds while the eval-mode teacher reads *_TEST.
+"""
+from .fcos import FCOSOutputs, METHODS
+
+
+class PseudoGenerator:
+    def __init__(self, cfg):
+        self.fcos_output = FCOSOutputs(cfg)
+
+    def nms_from_dense(self, raw_output, nms_method):
+        assert nms_method in METHODS
+        return self.fcos_output.predict_proposals(raw_output["head_out"], raw_output["level_hw"],
+                                                  raw_output["image_sizes"], nms_method)
+
+    def process_pseudo_label(self, proposals, cur_threshold, proposal_type, psedo_label_method=""):
+        """Returns (thresholded padded boxes, mean #boxes as a device scalar - no host sync)."""
+        if proposal_type != "roih":
+            raise ValueError("FCOS pseudo labels are 'roih' detections")
+        if psedo_label_method == "thresholding":
+            out = proposals.threshold(cur_threshold)
+        elif psedo_label_method == "thresholding_cls_ctr":
+            out = proposals.threshold(cur_threshold[0], cur_threshold[1])
+        else:
+            raise ValueError("Unkown pseudo label boxes methods")
+        num = out["valid"].float().sum() / max(out.n, 1)
+        # as ground truth for the student: rename to the gt_* convention expected by the targets kernel
+        return out, num

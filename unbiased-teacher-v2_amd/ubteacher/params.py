@@ -1,0 +1,123 @@
+"""Flat parameter arena: all model state lives in ONE contiguous fp32 buffer laid out for the
+MI355X step (288 GB HBM: no reason to scatter ~300 small tensors):
+
+    [ decay | nodecay | frozen | buffer ]
+      ^^^^^^^^^^^^^^^  trainable prefix: one SGD launch per sub-range, one flat RCCL all-reduce
+      ^^^^^^^^^^^^^^^^^^^^^^^^^^^^^^^^^^^  whole arena: one EMA launch (the reference EMAs params
+                                           AND buffers, engine/trainer.py:477-486)
+
+Modules declare `Handle`s while they are constructed; `finalize()` assigns offsets, allocates the
+arena (+ grad and momentum arenas for the trainable prefix) and materialises views.  Conv weights
+are stored [Cout][KH][KW][Cin]; state_dict() exposes them as [Cout,Cin,KH,KW]-shaped strided
+views so checkpoints keep the reference's key names and shapes (modelStudent.* / modelTeacher.*).
+"""
+from collections import OrderedDict
+
+import torch
+
+KINDS = ("decay", "nodecay", "frozen", "buffer")
+# sub-kinds that must each be contiguous across all BN layers (single-launch FrozenBN fold)
+BN_KINDS = ("bn_w", "bn_b", "bn_m", "bn_v")
+_ORDER = ("decay", "nodecay", "frozen", "bn_w", "bn_b", "buffer", "bn_m", "bn_v")
+
+
+class Handle:
+    __slots__ = ("shape", "kind", "init", "numel", "offset", "t", "g", "exports")
+
+    def __init__(self, shape, kind, init):
+        self.shape = tuple(int(s) for s in shape)
+        self.kind = kind
+        self.init = init
+        n = 1
+        for s in self.shape:
+            n *= s
+        self.numel = n
+        self.offset = -1
+        self.t = None  # view into the state arena
+        self.g = None  # view into the grad arena (trainable only)
+        self.exports = []  # (state_dict key, fn(view)->tensor view)
+
+    def export(self, key, fn=None):
+        self.exports.append((key, fn))
+        return self
+
+
+class ParamStore:
+    def __init__(self):
+        self.handles = []
+        self.finalized = False
+
+    def new(self, shape, kind, init=None):
+        assert not self.finalized
+        assert kind in _ORDER, kind
+        h = Handle(shape, kind, init)
+        self.handles.append(h)
+        return h
+
+    @staticmethod
+    def _align(n, a=4):
+        return (n + a - 1) // a * a
+
+    def finalize(self, device):
+        off = 0
+        self.ranges = {}
+        for kind in _ORDER:
+            start = off
+            for h in self.handles:
+                if h.kind == kind:
+                    h.offset = off
+                    off += self._align(h.numel)
+            self.ranges[kind] = (start, off)
+        self.total = off
+        self.n_train = self.ranges["nodecay"][1]
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.n_train, dtype=torch.float32, device=device)
+        self.mom = None  # allocated by the optimizer
+        for h in self.handles:
+            h.t = self.flat[h.offset: h.offset + h.numel].view(h.shape)
+            if h.kind in ("decay", "nodecay"):
+                h.g = self.grad[h.offset: h.offset + h.numel].view(h.shape)
+        self.finalized = True
+        for h in self.handles:
+            if h.init is not None:
+                h.init(h.t)
+        return self
+
+    def region(self, kind):
+        s, e = self.ranges[kind]
+        return self.flat[s:e]
+
+    def grad_region(self, kind):
+        s, e = self.ranges[kind]
+        return self.grad[s:e]
+
+    # ---- state_dict surface ------------------------------------------------------------
+    def state_dict(self):
+        sd = OrderedDict()
+        for h in self.handles:
+            for key, fn in h.exports:
+                sd[key] = h.t if fn is None else fn(h.t)
+        return sd
+
+    def trainable_named(self):
+        out = OrderedDict()
+        for h in self.handles:
+            if h.kind in ("decay", "nodecay"):
+                for key, fn in h.exports:
+                    out[key] = (h.t if fn is None else fn(h.t), h.g if fn is None else fn(h.g))
+        return out
+
+    def load_state_dict(self, sd, strict=True):
+        mine = self.state_dict()
+        missing = [k for k in mine if k not in sd]
+        unexpected = [k for k in sd if k not in mine]
+        if strict and (missing or unexpected):
+            raise RuntimeError("load_state_dict: missing %s unexpected %s" % (missing[:5], unexpected[:5]))
+        with torch.no_grad():
+            for k, v in mine.items():
+                if k in sd:
+                    src = sd[k]
+                    if tuple(src.shape) != tuple(v.shape):
+                        raise RuntimeError("size mismatch for %s: %s vs %s" % (k, tuple(src.shape), tuple(v.shape)))
+                    v.copy_(src.to(device=v.device, dtype=v.dtype))
+        return missing, unexpected
