@@ -1,0 +1,269 @@
+"""HIP FCOS kernels (targets, focal, fused location losses, decode, NMS, EMA, SGD, GroupNorm ...)
+vs the golden vectors generated from the reference and vs the CPU oracle, through the C-ABI.
+Tolerances: integer / index outputs exact; fp32 losses rtol 2e-5; gradients rtol 1e-4 (different
+summation order + device expf/logf)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import utv2_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda"
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.allclose(a, b, rtol=rtol, atol=atol), (float(np.abs(a - b).max()), float(np.abs(b).max()))
+
+
+@pytest.fixture(scope="module")
+def fc():
+    return dict(np.load(os.path.join(G, "fcos_outputs.npz")))
+
+
+def fcos_cfg():
+    from ubteacher import add_ubteacher_config
+    from ubteacher.d2 import get_cfg
+    cfg = get_cfg()
+    add_ubteacher_config(cfg)
+    f = cfg.MODEL.FCOS
+    f.CENTER_SAMPLE = False; f.REG_DISCRETE = True; f.KL_LOSS = True; f.KLLOSS_WEIGHT = 0.05; f.KL_LOSS_TYPE = "nlloss"
+    f.YIELD_PROPOSAL = True
+    cfg.SEMISUPNET.CONSIST_REG_LOSS = "ts_locvar_better_nms_nll_l1"
+    return cfg
+
+
+def build_head_out(fc, requires_grad=False):
+    """golden NCHW head tensors -> the product's level-first NHWC buffers + per-level views."""
+    N = int(fc["N"])
+    level_hw = [tuple(fc["logits%d" % l].shape[2:]) for l in range(5)]
+    P = N * sum(h * w for h, w in level_hw)
+    logits_all = torch.zeros((P, 80), device=DEV)
+    box_all = torch.zeros((P, 80), device=DEV)
+    lo, bo, rows_l, rows_b = [], [], [], []
+    r = 0
+    for l, (h, w) in enumerate(level_hw):
+        r1 = r + N * h * w
+        logits_all[r:r1] = T(fc["logits%d" % l]).permute(0, 2, 3, 1).reshape(-1, 80).to(DEV)
+        box_all[r:r1, :68] = T(fc["reg%d" % l]).permute(0, 2, 3, 1).reshape(-1, 68).to(DEV)
+        box_all[r:r1, 68:72] = T(fc["std%d" % l]).permute(0, 2, 3, 1).reshape(-1, 4).to(DEV)
+        box_all[r:r1, 72] = T(fc["ctr%d" % l]).permute(0, 2, 3, 1).reshape(-1).to(DEV)
+        r = r1
+    r = 0
+    for l, (h, w) in enumerate(level_hw):
+        r1 = r + N * h * w
+        a = logits_all[r:r1].view(N, h, w, 80)
+        b = box_all[r:r1].view(N, h, w, 80)
+        if requires_grad:
+            a = a.detach().requires_grad_(True)
+            b = b.detach().requires_grad_(True)
+        lo.append(a); bo.append(b)
+        rows_l.append((r, r1, (N, h, w, 80))); rows_b.append((r, r1, (N, h, w, 80)))
+        r = r1
+    return (lo, bo, logits_all, box_all, rows_l, rows_b), level_hw
+
+
+def padded_gt(fc, prefix, N):
+    from ubteacher.d2.structures import Boxes, Instances
+    from ubteacher.modeling.fcos import PaddedBoxes
+    insts = []
+    for i in range(N):
+        x = Instances((int(fc["H"]), int(fc["W"])))
+        x.gt_boxes = Boxes(T(fc["%s%d_boxes" % (prefix, i)]).float().reshape(-1, 4))
+        x.gt_classes = T(fc["%s%d_classes" % (prefix, i)]).long()
+        if "%s%d_std" % (prefix, i) in fc:
+            x.reg_pred_std = T(fc["%s%d_std" % (prefix, i)]).float().reshape(-1, 4)
+            x.scores = T(fc["%s%d_scores" % (prefix, i)])
+        insts.append(x)
+    return PaddedBoxes.from_instances(insts, DEV)
+
+
+def level_grads(fc, case, nm_list, lo, bo):
+    """compare d/d(head outputs) with the golden NCHW grads"""
+    for l in range(5):
+        gl = lo[l].grad
+        close(gl.permute(0, 3, 1, 2), fc["%s_glogits%d" % (case, l)], rtol=1e-4, atol=2e-7)
+        gb = bo[l].grad
+        close(gb[..., :68].permute(0, 3, 1, 2), fc["%s_greg%d" % (case, l)], rtol=1e-4, atol=2e-7)
+        close(gb[..., 68:72].permute(0, 3, 1, 2), fc["%s_gstd%d" % (case, l)], rtol=1e-4, atol=2e-7)
+        close(gb[..., 72:73].permute(0, 3, 1, 2), fc["%s_gctr%d" % (case, l)], rtol=1e-4, atol=2e-7)
+        assert float(gb[..., 73:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", ["sup", "supempty"])
+def test_supervised_losses(fc, case):
+    from ubteacher.modeling.fcos import FCOSOutputs
+    outm = FCOSOutputs(fcos_cfg())
+    head_out, level_hw = build_head_out(fc, True)
+    gt = padded_gt(fc, case + "_gt", int(fc["N"]))
+    extras, losses = outm.losses(head_out, level_hw, gt)
+    for k in ("loss_fcos_cls", "loss_fcos_loc", "loss_fcos_ctr"):
+        close(losses[k], fc["%s_%s" % (case, k)], rtol=2e-5)
+    # targets: exact labels (dropped locations of empty images compare as "not kept")
+    lab = extras["labels"].cpu().numpy()
+    N = int(fc["N"])
+    r = 0
+    for l, (h, w) in enumerate(level_hw):
+        gl = fc["%s_labels%d" % (case, l)]
+        mine = lab[r:r + N * h * w]
+        keep = mine >= 0
+        assert np.array_equal(mine[keep], gl[keep])
+        if case == "supempty":
+            assert (~keep).sum() == h * w  # exactly the empty image's locations
+        close(extras["reg_targets"][r:r + N * h * w][torch.from_numpy(keep).to(DEV)], fc["%s_regt%d" % (case, l)][keep])
+        r += N * h * w
+    tot = losses["loss_fcos_cls"] + 2.0 * losses["loss_fcos_loc"] + 3.0 * losses["loss_fcos_ctr"]
+    tot.backward()
+    level_grads(fc, case, None, head_out[0], head_out[1])
+
+
+def test_pseudo_losses(fc):
+    from ubteacher.modeling.fcos import FCOSOutputs
+    outm = FCOSOutputs(fcos_cfg())
+    head_out, level_hw = build_head_out(fc, True)
+    N = int(fc["N"])
+    gt = {"cls": padded_gt(fc, "pcls_gt", N), "reg": padded_gt(fc, "preg_gt", N)}
+    extras, losses = outm.pseudo_losses(head_out, level_hw, gt)
+    for k in ("loss_fcos_cls", "loss_fcos_loc", "loss_fcos_ctr", "teacher_better_student"):
+        close(losses[k], fc["pseudo_%s" % k], rtol=2e-5)
+    tot = losses["loss_fcos_cls"] + 2.0 * losses["loss_fcos_loc"] + 3.0 * losses["loss_fcos_ctr"]
+    tot.backward()
+    level_grads(fc, "pseudo", None, head_out[0], head_out[1])
+
+
+@pytest.mark.parametrize("method", ["cls", "cls_n_ctr", "cls_n_loc"])
+def test_decode_nms(fc, method):
+    from ubteacher.modeling.fcos import FCOSOutputs
+    outm = FCOSOutputs(fcos_cfg())
+    outm.training = False
+    head_out, level_hw = build_head_out(fc)
+    N, H, W = int(fc["N"]), int(fc["H"]), int(fc["W"])
+    det = outm.predict_proposals(head_out, level_hw, [(H, W)] * N, method)
+    insts = det.to_instances()
+    for i, r in enumerate(insts):
+        gcls = fc["det_%s_%d_classes" % (method, i)]
+        assert len(r) == len(gcls)
+        assert np.array_equal(r.pred_classes.cpu().numpy(), gcls)  # same detections, same (descending score) order
+        close(r.pred_boxes.tensor, fc["det_%s_%d_boxes" % (method, i)], rtol=1e-5, atol=2e-4)
+        close(r.scores, fc["det_%s_%d_scores" % (method, i)], rtol=2e-5)
+        close(r.centerness, fc["det_%s_%d_ctr" % (method, i)], rtol=2e-5)
+        close(r.cls_confid, fc["det_%s_%d_conf" % (method, i)], rtol=2e-5)
+        close(r.reg_pred_std, fc["det_%s_%d_std" % (method, i)])
+    th = det.threshold(0.3).to_instances(as_gt=True)
+    for i, r in enumerate(th):
+        close(r.gt_boxes.tensor, fc["thr_%s_%d_boxes" % (method, i)], rtol=1e-5, atol=2e-4)
+
+
+def test_nms_bit_exact_vs_oracle():
+    """NMS index selection must be bit-exact (north star): random overlapping boxes incl. score ties."""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(5)
+    for (N, M, thr, aware) in [(2, 700, 0.6, True), (1, 3000, 0.7, False), (3, 130, 0.5, True), (1, 64, 0.3, True)]:
+        ctr = torch.rand(N, M, 2, generator=g) * 300
+        wh = torch.rand(N, M, 2, generator=g) * 80 + 4
+        boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], dim=2)
+        scores = torch.rand(N, M, generator=g)
+        scores[:, ::7] = 0.5  # ties
+        cls = torch.randint(0, 5, (N, M), generator=g, dtype=torch.int32)
+        valid = (torch.rand(N, M, generator=g) > 0.1).to(torch.uint8)
+        keep, cnt = hip.nms_batched(boxes.to(DEV), scores.to(DEV), cls.to(DEV), valid.to(DEV), thr, class_aware=aware,
+                                    post_topk=-1, max_out=M)
+        keep, cnt = keep.cpu(), cnt.cpu()
+        for n in range(N):
+            vi = valid[n].bool().nonzero().squeeze(1)
+            if aware:
+                ref = O.batched_nms(boxes[n][vi], scores[n][vi], cls[n][vi].long(), thr)
+            else:
+                ref = O.nms(boxes[n][vi], scores[n][vi], thr)
+            ref = vi[ref]
+            assert int(cnt[n]) == len(ref)
+            assert torch.equal(keep[n, : len(ref)].long(), ref)
+
+
+def test_ema_bit_exact():
+    from ubteacher import hip
+    d = dict(np.load(os.path.join(G, "ema.npz")))
+    for keep in (0.0, 0.9996, 0.9999):
+        tag = str(keep).replace(".", "p")
+        keys = sorted(k[len(tag) + 3:] for k in d if k.startswith(tag + "_s_"))
+        s = torch.cat([T(d["%s_s_%s" % (tag, k)]) for k in keys]).to(DEV)
+        t = torch.cat([T(d["%s_t_%s" % (tag, k)]) for k in keys]).to(DEV)
+        want = np.concatenate([d["%s_out_%s" % (tag, k)] for k in keys])
+        hip.ema_axpby(t, s, keep)
+        assert np.array_equal(t.cpu().numpy(), want)  # bit exact vs the reference's own output
+
+
+def test_sgd_matches_torch():
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(2)
+    p = torch.randn(10007, generator=g); gr = torch.randn(10007, generator=g)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    pd, gd, md = p.to(DEV), gr.to(DEV), torch.zeros(10007, device=DEV)
+    for it in range(3):
+        pr.grad = gr.clone() * (it + 1)
+        opt.step()
+        gd.copy_((gr * (it + 1)).to(DEV))
+        hip.sgd_momentum(pd, gd, md, 0.01, 0.9, 1e-4, 1.0, zero_grad=True)
+    close(pd, pr.detach(), rtol=1e-6, atol=1e-7)
+    assert float(gd.abs().max()) == 0.0
+
+
+def test_groupnorm_relu_fwd_bwd():
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(4)
+    N, H, W, C = 2, 13, 21, 256
+    x = torch.randn(N, C, H, W, generator=g) * 2 + 0.5
+    ga = torch.rand(C, generator=g) + 0.5; be = torch.randn(C, generator=g) * 0.1
+    xr = x.clone().requires_grad_(True); gar = ga.clone().requires_grad_(True); ber = be.clone().requires_grad_(True)
+    y = F.relu(F.group_norm(xr, 32, gar, ber, 1e-5))
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    yh, mean, rstd = hip.groupnorm_relu_fwd(xh, ga.to(DEV), be.to(DEV))
+    close(yh.permute(0, 3, 1, 2), y.detach(), rtol=1e-4, atol=1e-5)
+    dga = torch.zeros(C, device=DEV); dbe = torch.zeros(C, device=DEV)
+    dx = hip.groupnorm_relu_bwd(dy.permute(0, 2, 3, 1).contiguous().to(DEV), yh, xh, mean, rstd, ga.to(DEV), dga, dbe)
+    close(dx.permute(0, 3, 1, 2), xr.grad, rtol=1e-3, atol=1e-5)
+    close(dga, gar.grad, rtol=1e-4, atol=1e-4)
+    close(dbe, ber.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_pool_upsample_preprocess_fold():
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 64, 18, 26, generator=g)
+    y = hip.maxpool3x3s2(x.permute(0, 2, 3, 1).contiguous().to(DEV))
+    close(y.permute(0, 3, 1, 2), F.max_pool2d(x, 3, 2, 1), rtol=0, atol=0)
+    lat = torch.randn(2, 32, 8, 12, generator=g); top = torch.randn(2, 32, 4, 6, generator=g)
+    o = hip.upsample2x_add(lat.permute(0, 2, 3, 1).contiguous().to(DEV), top.permute(0, 2, 3, 1).contiguous().to(DEV))
+    close(o.permute(0, 3, 1, 2), lat + F.interpolate(top, scale_factor=2.0, mode="nearest"), rtol=0, atol=0)
+    gg = torch.randn(2, 8, 12, 32, generator=g)
+    dt = hip.downsample2x_sum(gg.to(DEV))
+    ref = F.avg_pool2d(gg.permute(0, 3, 1, 2), 2) * 4
+    close(dt.permute(0, 3, 1, 2), ref, rtol=1e-6, atol=1e-6)
+    ims = [torch.randint(0, 256, (3, 37, 50), generator=g, dtype=torch.uint8), torch.randint(0, 256, (3, 40, 45), generator=g, dtype=torch.uint8)]
+    mean, std = [103.53, 116.28, 123.675], [1.0, 57.0, 2.0]
+    x4, sizes = hip.preprocess_images([i.to(DEV) for i in ims], mean, std, 32)
+    ref, rs = O.preprocess(ims, torch.tensor(mean).view(3, 1, 1), torch.tensor(std).view(3, 1, 1), 32)
+    assert sizes == rs and tuple(x4.shape) == (2, 64, 64, 4)
+    close(x4[..., :3].permute(0, 3, 1, 2), ref, rtol=1e-6, atol=1e-6)
+    assert float(x4[..., 3].abs().max()) == 0.0
+    n = 300
+    w, b, m, v = (torch.rand(n, generator=g) + 0.5 for _ in range(4))
+    sc, sh = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    hip.frozenbn_fold(w.to(DEV), b.to(DEV), m.to(DEV), v.to(DEV), sc, sh)
+    rsc = w * (v + 1e-5).rsqrt()
+    close(sc, rsc, rtol=1e-6); close(sh, b - m * rsc, rtol=1e-5, atol=1e-6)
