@@ -1,0 +1,95 @@
+"""End-to-end parity of the HIP UTv2 FCOS path against the CPU oracle on a small seeded problem:
+(1) backbone+head forward, (2) one full run_step_full_semisup (teacher EMA, teacher forward,
+two-criteria pseudo-labelling, both student forwards, weighted loss, backward, SGD).
+Tolerance: losses 1e-3 relative (north star), weights after the step 1e-4 of their scale."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import utv2_oracle as O
+from tests.utv2_testutil import FixedLoader, cpu_state, make_batch, small_fcos_cfg, tune_state_for_pseudo_labels
+
+pytestmark = pytest.mark.gpu
+H, W = 96, 128
+
+
+def relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def test_forward_parity():
+    from ubteacher.modeling import build_model
+    cfg = small_fcos_cfg()
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    prod, orac = make_batch(11, 2, 2, H, W, "cuda")
+    sd = cpu_state(model)
+    model.eval()
+    with torch.no_grad():
+        _, raw = model(prod[3], output_raw=True, nms_method="cls", branch="teacher_weak")
+        logits, reg, std, ctr, locs, sizes = O.fcos_forward(sd, [d["image"] for d in orac[3]],
+                                                            sd["pixel_mean"], sd["pixel_std"])
+    for l in range(5):
+        lo = raw["logits_pred"][l].permute(0, 3, 1, 2)
+        bo = raw["box_pred"][l].permute(0, 3, 1, 2)
+        assert relerr(lo, logits[l]) < 1e-4
+        assert relerr(bo[:, :68], reg[l]) < 1e-4
+        assert relerr(bo[:, 72:73], ctr[l]) < 1e-4
+        assert float((bo[:, 68:72].cpu() - std[l]).abs().max()) < 1e-6
+
+
+def test_full_semisup_step_parity():
+    from ubteacher.engine import UBTeacherTrainer
+    cfg = small_fcos_cfg()
+    torch.manual_seed(0)
+    prod, orac = make_batch(12, 2, 2, H, W, "cuda")
+    tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+    sd_s = tune_state_for_pseudo_labels(cpu_state(tr.model), [d["image"] for d in orac[3]])
+    sd_t = dict(sd_s)
+    sd_t["proposal_generator.fcos_head.bbox_pred_std.bias"] = torch.full((4,), -3.0)  # confident teacher boundaries
+    tr.model.load_state_dict(sd_s)
+    tr.model_teacher.load_state_dict(sd_t)
+    tr.iter = 1
+    tr.optimizer.param_groups[0]["lr"] = 0.01
+    tr.run_step_full_semisup()
+    rec = tr.flush_metrics()
+    torch.cuda.synchronize()
+
+    ocfg = O.FCOSCfg()
+    rec_o, new_s, new_t, grads, bufs, pseudo = O.fcos_semisup_step(
+        ocfg, sd_s, sd_t, orac, keep_rate=cfg.SEMISUPNET.EMA_KEEP_RATE, lam_u=cfg.SEMISUPNET.UNSUP_LOSS_WEIGHT,
+        lam_r=cfg.SEMISUPNET.UNSUP_REG_LOSS_WEIGHT, lr=0.01, momentum=0.9, wd=1e-4,
+        mean=sd_s["pixel_mean"], pix_std=sd_s["pixel_std"])
+    assert sum(len(p["boxes"]) for p in pseudo[0]) > 0 and sum(len(p["boxes"]) for p in pseudo[1]) > 0
+    assert rec_o["teacher_better_student_pseudo"] > 0
+    # the same pseudo labels were selected
+    pc, pr = tr._last_pseudo
+    for i, p in enumerate(pseudo[0]):
+        assert int(pc["valid"][i].sum()) == len(p["boxes"])
+    for i, p in enumerate(pseudo[1]):
+        assert int(pr["valid"][i].sum()) == len(p["boxes"])
+    for k, v in rec_o.items():
+        assert k in rec, k
+        assert abs(rec[k] - v) <= 1e-3 * max(abs(v), 1e-6), (k, rec[k], v)
+    # weights after SGD, teacher after EMA
+    s_after = cpu_state(tr.model)
+    t_after = cpu_state(tr.model_teacher)
+    worst = 0.0
+    for k in new_s:
+        # |dw| <= 1e-4 * |w| + 3e-3 * |lr * (momentum-free) update|  (zero-init biases ARE their update)
+        err = float((s_after[k].double() - new_s[k].double()).abs().max())
+        upd = float((new_s[k].double() - sd_s[k].double()).abs().max())
+        tol = 1e-4 * float(new_s[k].abs().max()) + 3e-3 * upd + 1e-12
+        assert err <= tol, (k, err, tol)
+    for k in new_t:
+        assert torch.equal(t_after[k], new_t[k]), k  # EMA is bit exact
+    # gradients themselves (arena) vs autograd of the oracle
+    named = tr.model.store.trainable_named()
+    checked = 0
+    for k, (p, gview) in named.items():
+        if k in grads and grads[k].abs().max() > 0:
+            # deep backbone grads see ReLU-gate flips from 1e-6-level forward differences
+            assert relerr(gview, grads[k]) < (1e-2 if k.startswith("backbone.bottom_up") else 3e-3), k
+            checked += 1
+    assert checked > 100
