@@ -1,0 +1,208 @@
+"""bench.py - images/sec of the UTv2 training step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" is one UBTeacherTrainer.run_step_full_semisup on one synthetic COCO-shaped batch
+(FCOS R50-FPN, 4 labeled + 4 unlabeled 1333x800 images per GPU, post-burn-in: teacher EMA,
+teacher forward + two-criteria pseudo-labelling, two student forwards, backward, SGD).
+Inputs are resident in HBM before the timed region.  One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "unbiased-teacher-v2_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def tune_for_pseudo_labels(trainer, batch, target_std=1.5, bias=-6.0):
+    """Random-init weights give no confident detections; rescale the student's cls_logits (on the
+    device, with the product's own forward) so the teacher emits some pseudo boxes per image."""
+    from ubteacher.modeling.fcos import PaddedBoxes  # noqa: F401
+    m = trainer.model
+    sd = m.state_dict()
+    w, b = sd["proposal_generator.fcos_head.cls_logits.weight"], sd["proposal_generator.fcos_head.cls_logits.bias"]
+    g = torch.Generator(device="cpu").manual_seed(0)
+    w.copy_((torch.randn(w.shape, generator=g) * 0.01).to(w.device))
+    b.zero_()
+    m.eval()
+    with torch.no_grad():
+        _, raw = m(batch[3], output_raw=True, nms_method="cls", branch="teacher_weak")
+        s = torch.cat([x.reshape(-1) for x in raw["logits_pred"]]).std()
+    m.train()
+    w.mul_(target_std / s.clamp(min=1e-12))
+    b.fill_(bias)
+    sd["proposal_generator.fcos_head.bbox_pred_std.bias"].fill_(-3.0)
+    trainer._update_teacher_model(keep_rate=0.0)  # teacher := student
+    sd["proposal_generator.fcos_head.bbox_pred_std.bias"].fill_(0.0)  # student less certain than teacher
+
+
+class ConvTimer:
+    """HIP-event timing of the dominant kernel (conv_igemm_f32<128,0>: every forward/dgrad conv with
+    Cout > 64 and Cin % 16 == 0) on the stream it is launched on, live inside the timed region."""
+
+    def __init__(self):
+        self.pairs = []
+        self.enabled = False
+
+    def install(self):
+        from ubteacher import hip
+        orig = hip.conv2d_fwd
+        timer = self
+
+        def wrapped(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, relu=False, kh=1, kw=1, out=None,
+                    in_dil=1, out_hw=None, accumulate=False):
+            N, H, W, C = x.shape
+            K = w.shape[0]
+            dominant = timer.enabled and K > 64 and C % 16 == 0 and w.shape[1] == kh * kw * C
+            if dominant:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            y = orig(x, w, scale, bias, residual, stride, pad, relu, kh, kw, out, in_dil, out_hw, accumulate)
+            if dominant:
+                e1.record()
+                if in_dil > 1:  # dgrad of a strided conv: algorithmic work is that of the forward conv
+                    macs = x.shape[0] * x.shape[1] * x.shape[2] * C * K * kh * kw
+                else:
+                    macs = y.shape[0] * y.shape[1] * y.shape[2] * K * kh * kw * C
+                timer.pairs.append((e0, e1, 2.0 * macs))
+            return y
+
+        hip.conv2d_fwd = wrapped
+
+    def summary(self):
+        if not self.pairs:
+            return None
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.pairs)
+        fl = sum(f for _, _, f in self.pairs)
+        return dict(launches=len(self.pairs), total_ms=ms, avg_us=1e3 * ms / len(self.pairs), tflops=fl / ms / 1e9)
+
+
+def cpu_baseline(cfg):
+    """The oracle (CPU port of the reference step) timed on the host cores on a bounded sample:
+    ONE step with 1 labeled + 1 unlabeled 1333x800 image."""
+    from oracle import utv2_oracle as O
+    from ubteacher.data.synthetic import make_gt, make_image, strong_view
+    from ubteacher.modeling import build_model
+    import numpy as np
+    ccfg = cfg.clone()
+    ccfg.defrost()
+    ccfg.MODEL.DEVICE = "cuda"
+    rng = np.random.default_rng(0)
+    model = build_model(ccfg)
+    sd = {k: v.detach().cpu().clone().contiguous() for k, v in model.state_dict().items()}
+    del model
+    torch.cuda.empty_cache()
+
+    def im():
+        return make_image(rng, 800, 1333)
+    gt = make_gt(rng, 800, 1333)
+    g = dict(boxes=gt.gt_boxes.tensor, classes=gt.gt_classes)
+    wk = im()
+    batch = ([{"image": strong_view(rng, wk), "gt": g}], [{"image": wk, "gt": g}], [{"image": im()}], [{"image": im()}])
+    cores = torch.get_num_threads()
+    t0 = time.perf_counter()
+    O.fcos_semisup_step(O.FCOSCfg(), sd, dict(sd), batch, keep_rate=0.9999)
+    dt = time.perf_counter() - t0
+    return {"value": 2.0 / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "1 step, 1 labeled (weak+strong views) + 1 unlabeled 1333x800 image, fp32, torch CPU kernels, %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--label", type=int, default=4, help="labeled images per GPU")
+    ap.add_argument("--unlabel", type=int, default=4, help="unlabeled images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # nccl == RCCL over xGMI on ROCm
+
+    from ubteacher.engine import UBTeacherTrainer
+    from ubteacher.presets import get_config
+    from ubteacher import hip
+    hip.load()
+    cfg = get_config("fcos", 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label * world, "SOLVER.IMG_PER_BATCH_UNLABEL",
+                                 args.unlabel * world, "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", False,
+                                 "MODEL.DEVICE", "cuda:%d" % local_rank])
+    torch.manual_seed(0)
+    timer = ConvTimer()
+    timer.install()
+    tr = UBTeacherTrainer(cfg)
+    batch = tr._data_loader.batches[0]
+    tune_for_pseudo_labels(tr, batch)
+    if world > 1:  # identical students on every rank (DDP broadcasts rank 0's parameters)
+        dist.broadcast(tr.model.flat_state(), 0)
+        dist.broadcast(tr.model_teacher.flat_state(), 0)
+    tr.iter = 1
+    tr.log_period = 10 ** 9
+    for _ in range(args.warmup):
+        tr.run_step_full_semisup(); tr.iter += 1
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sync()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.run_step_full_semisup(); tr.iter += 1
+    sync()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    metrics = tr.flush_metrics()
+    conv = timer.summary()
+
+    if rank == 0:
+        per_step_images = (args.label + args.unlabel) * world
+        out = {
+            "metric": "images/sec/node (labeled+unlabeled) UTv2 step, R50-FPN 1333x800",
+            "value": per_step_images * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "FCOS R50-FPN UTv2 sup1 (configs[1]): %d labeled + %d unlabeled 1333x800 images per GPU, "
+                                   "post-burn-in semi-supervised step" % (args.label, args.unlabel),
+                       "global_batch": per_step_images, "parallelism": "dp%d" % world, "precision": "fp32 MFMA"},
+            "losses": {k: v for k, v in metrics.items() if k.startswith("loss") or k.startswith("teacher")},
+        }
+        if conv:
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_f32<128,0> (all fwd+dgrad launches)",
+                               "achieved": conv["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": conv["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "launches": conv["launches"], "avg_us": conv["avg_us"],
+                               "time_share": conv["total_ms"] / (1e3 * dt)}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg)
+            except Exception as e:  # never lose the GPU measurement to a host-side problem
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
