@@ -113,6 +113,30 @@ int utv2_nms_batched(const float* boxes, const float* scores, const int* cls, co
                      utv2_stream_t stream);
 int utv2_box_iou(const float* a, const float* b, int A, int B, float* out, utv2_stream_t stream);
 
+/* ---- Faster-RCNN path ----------------------------------------------------------------------- */
+/* D2 pairwise_iou + Matcher (proposal_generator/rpn.py:112-148, roi_heads/roi_heads.py:213-231):
+ * per candidate box the max IoU over the image's valid gts and its (first) argmax; optionally the
+ * per-gt max over boxes (uint32 float bits, caller zero-fills) for the low-quality pass. */
+int utv2_match_boxes(const float* boxes, int64_t box_img_stride, int N, int P, const float* gt_boxes,
+                     const unsigned char* gt_valid, int G, float* max_iou, int* arg, unsigned* gt_max_bits,
+                     utv2_stream_t stream);
+int utv2_match_lowq(const float* boxes, int64_t box_img_stride, int N, int P, const float* gt_boxes,
+                    const unsigned char* gt_valid, int G, const unsigned* gt_max_bits, unsigned char* lowq,
+                    utv2_stream_t stream);
+/* torchvision roi_align(aligned=True, sampling_ratio=0) through D2 ROIPooler level assignment
+ * (roi_heads/roi_heads.py:28-45,118).  feats_host / dfeats_host: HOST arrays of device pointers. */
+int utv2_roi_align_fwd(int num_levels, int min_level, const float* const* feats_host, const int* H_host,
+                       const int* W_host, const float* scales_host, const float* rois, const int* roi_batch,
+                       const unsigned char* roi_valid, int R, int C, int PH, int PW, float* out, utv2_stream_t stream);
+int utv2_roi_align_bwd(int num_levels, int min_level, float* const* dfeats_host, const int* H_host, const int* W_host,
+                       const float* scales_host, const float* rois, const int* roi_batch, const unsigned char* roi_valid,
+                       int R, int C, int PH, int PW, const float* dy, utv2_stream_t stream);
+/* roi_heads/fast_rcnn.py:925-936 + FocalLoss :1405-1429 (softmax CE focal, gamma 1.5), summed */
+int utv2_softmax_focal_fwd(const float* logits, const int* target, int R, int C, float gamma, float* loss_sum, float* ws,
+                           utv2_stream_t stream);
+int utv2_softmax_focal_bwd(const float* logits, const int* target, int R, int C, float gamma, const float* coef,
+                           float* dlogits, utv2_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -558,3 +558,400 @@ def fcos_semisup_step(cfg, student_sd, teacher_sd, batch, keep_rate, lam_u=3.0, 
     new_student.update(newp)
     rec = {k: (float(v.detach()) if torch.is_tensor(v) else float(v)) for k, v in rec.items()}
     return rec, new_student, teacher_sd, grads, bufs, (pseudo_cls, pseudo_reg)
+
+
+# =================================================================================================
+# Faster-RCNN path
+# =================================================================================================
+SCALE_CLAMP = math.log(1000.0 / 16)
+
+
+def xyxy_get_deltas(src, tgt, weights=(10.0, 10.0, 5.0, 5.0)):
+    """modeling/box_regression.py:38-73 (order l, r, d, u; +1 on the source size; only weights[0:2])."""
+    sw = src[:, 2] - src[:, 0] + 1.0
+    sh = src[:, 3] - src[:, 1] + 1.0
+    wx, wy = weights[0], weights[1]
+    return torch.stack((wx * (tgt[:, 0] - src[:, 0]) / sw, wx * (tgt[:, 2] - src[:, 2]) / sw,
+                        wy * (tgt[:, 1] - src[:, 1]) / sh, wy * (tgt[:, 3] - src[:, 3]) / sh), dim=1)
+
+
+def xyxy_apply_deltas(deltas, boxes, weights=(10.0, 10.0, 5.0, 5.0), clamp=1000.0 / 16):
+    """modeling/box_regression.py:75-129 (no +1, clamp +-62.5, class-agnostic 4 columns)."""
+    w, h = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    wx, wy = weights[0], weights[1]
+    dl = torch.clamp(deltas[:, 0] / wx, max=clamp, min=-clamp)
+    dr = torch.clamp(deltas[:, 1] / wx, max=clamp, min=-clamp)
+    dd = torch.clamp(deltas[:, 2] / wy, max=clamp, min=-clamp)
+    du = torch.clamp(deltas[:, 3] / wy, max=clamp, min=-clamp)
+    return torch.stack((dl * w + boxes[:, 0], dd * h + boxes[:, 1], dr * w + boxes[:, 2], du * h + boxes[:, 3]), dim=1)
+
+
+def rpn_get_deltas(src, tgt):
+    """D2 Box2BoxTransform.get_deltas, weights (1,1,1,1) [D2-recall]."""
+    sw, sh = src[:, 2] - src[:, 0], src[:, 3] - src[:, 1]
+    sx, sy = src[:, 0] + 0.5 * sw, src[:, 1] + 0.5 * sh
+    tw, th = tgt[:, 2] - tgt[:, 0], tgt[:, 3] - tgt[:, 1]
+    tx, ty = tgt[:, 0] + 0.5 * tw, tgt[:, 1] + 0.5 * th
+    return torch.stack(((tx - sx) / sw, (ty - sy) / sh, torch.log(tw / sw), torch.log(th / sh)), dim=1)
+
+
+def rpn_apply_deltas(deltas, boxes):
+    w, h = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    cx, cy = boxes[:, 0] + 0.5 * w, boxes[:, 1] + 0.5 * h
+    dw, dh = torch.clamp(deltas[:, 2], max=SCALE_CLAMP), torch.clamp(deltas[:, 3], max=SCALE_CLAMP)
+    pcx, pcy = deltas[:, 0] * w + cx, deltas[:, 1] * h + cy
+    pw, ph = torch.exp(dw) * w, torch.exp(dh) * h
+    return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph), dim=1)
+
+
+def matcher(iou, thresholds, labels, allow_low_quality):
+    """D2 Matcher [D2-recall].  iou [G, P] -> (matched idx [P], labels [P])."""
+    if iou.numel() == 0:
+        P = iou.shape[1]
+        return torch.zeros(P, dtype=torch.int64), torch.full((P,), labels[0], dtype=torch.int8)
+    vals, idx = iou.max(dim=0)
+    out = torch.full(vals.shape, 1, dtype=torch.int8)
+    th = [-float("inf")] + list(thresholds) + [float("inf")]
+    for l, lo, hi in zip(labels, th[:-1], th[1:]):
+        out[(vals >= lo) & (vals < hi)] = l
+    if allow_low_quality:
+        best, _ = iou.max(dim=1)
+        out[(iou == best[:, None]).any(dim=0)] = 1
+    return idx, out
+
+
+def subsample_by_keys(labels, keys, num, frac, bg):
+    """D2 subsample_labels with randperm[:k] replaced by 'k smallest per-slot keys' (same distribution; lets
+    the product and the oracle draw the same sample).  Returns (pos idx, neg idx)."""
+    pos = torch.nonzero((labels != -1) & (labels != bg)).squeeze(1)
+    neg = torch.nonzero(labels == bg).squeeze(1)
+    npos = min(int(num * frac), pos.numel())
+    nneg = min(num - npos, neg.numel())
+    pos = pos[torch.argsort(keys[pos], stable=True)[:npos]]
+    neg = neg[torch.argsort(keys[neg], stable=True)[:nneg]]
+    return pos, neg
+
+
+def make_anchors(level_hw, strides, sizes=(32, 64, 128, 256, 512), ratios=(0.5, 1.0, 2.0)):
+    """D2 DefaultAnchorGenerator, offset 0, order (H, W, A) [D2-recall]."""
+    out = []
+    for (h, w), s, sz in zip(level_hw, strides, sizes):
+        cell = []
+        for r in ratios:
+            ww = math.sqrt(sz ** 2.0 / r)
+            hh = r * ww
+            cell.append([-ww / 2.0, -hh / 2.0, ww / 2.0, hh / 2.0])
+        cell = torch.tensor(cell, dtype=torch.float32)
+        sx = torch.arange(0, w * s, step=s, dtype=torch.float32)
+        sy = torch.arange(0, h * s, step=s, dtype=torch.float32)
+        yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+        shifts = torch.stack((xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)), dim=1)
+        out.append((shifts.view(-1, 1, 4) + cell.view(1, -1, 4)).reshape(-1, 4))
+    return out
+
+
+def rpn_head(sd, feats, prefix="proposal_generator.rpn_head"):
+    """D2 StandardRPNHead [D2-recall]; outputs flattened to the (H, W, A) anchor order of rpn.py:33-46."""
+    obj, dl = [], []
+    for f in feats:
+        t = F.relu(F.conv2d(f, sd[prefix + ".conv.weight"], sd[prefix + ".conv.bias"], 1, 1))
+        o = F.conv2d(t, sd[prefix + ".objectness_logits.weight"], sd[prefix + ".objectness_logits.bias"])
+        d = F.conv2d(t, sd[prefix + ".anchor_deltas.weight"], sd[prefix + ".anchor_deltas.bias"])
+        obj.append(o.permute(0, 2, 3, 1).flatten(1))
+        dl.append(d.view(d.shape[0], -1, 4, d.shape[-2], d.shape[-1]).permute(0, 3, 4, 1, 2).flatten(1, -2))
+    return obj, dl
+
+
+def find_top_rpn_proposals(anchors, obj, deltas, image_sizes, pre_topk, post_topk, nms_thresh=0.7):
+    """D2 find_top_rpn_proposals [D2-recall]; per-level order (logit desc, anchor index asc)."""
+    N = obj[0].shape[0]
+    res = []
+    for n in range(N):
+        bs, ss, ls = [], [], []
+        for l, (a, o, d) in enumerate(zip(anchors, obj, deltas)):
+            k = min(pre_topk, o.shape[1])
+            order = np.lexsort((np.arange(o.shape[1]), -o[n].detach().numpy().astype(np.float64)))[:k]
+            order = torch.as_tensor(order)
+            bs.append(rpn_apply_deltas(d[n][order].detach(), a[order])); ss.append(o[n][order].detach())
+            ls.append(torch.full((k,), l, dtype=torch.int64))
+        b, s, lv = torch.cat(bs), torch.cat(ss), torch.cat(ls)
+        ok = torch.isfinite(b).all(dim=1) & torch.isfinite(s)
+        b, s, lv = b[ok], s[ok], lv[ok]
+        h, w = image_sizes[n]
+        b = torch.stack((b[:, 0].clamp(0, w), b[:, 1].clamp(0, h), b[:, 2].clamp(0, w), b[:, 3].clamp(0, h)), dim=1)
+        keep = ((b[:, 2] - b[:, 0]) > 0) & ((b[:, 3] - b[:, 1]) > 0)
+        b, s, lv = b[keep], s[keep], lv[keep]
+        k = batched_nms(b, s, lv, nms_thresh)[:post_topk]
+        res.append(dict(boxes=b[k], logits=s[k]))
+    return res
+
+
+def rpn_losses(anchors_cat, obj_cat, deltas_cat, gts, keys, pseudo, batch=256, frac=0.25):
+    """rpn.py:78-225 + D2 label_and_sample_anchors.  gts: list of dict(boxes, scores?).  keys [N, R]."""
+    N = obj_cat.shape[0]
+    cls_sum, loc_sum = 0.0, 0.0
+    samples = []
+    for n in range(N):
+        gb = gts[n]["boxes"]
+        iou = pairwise_iou(gb, anchors_cat) if len(gb) else torch.zeros((0, anchors_cat.shape[0]))
+        midx, lab = matcher(iou, [0.3, 0.7], [0, -1, 1], True)
+        pos, neg = subsample_by_keys(lab, keys[n], batch, frac, 0)
+        samples.append((pos, neg))
+        idx = torch.cat((pos, neg))
+        tgt = torch.cat((torch.ones(len(pos)), torch.zeros(len(neg))))
+        if pseudo:
+            wgt = gts[n]["scores"][midx][idx] if len(gb) else torch.zeros(len(idx))  # rpn.py:135-144 (SURVEY B4)
+            cls_sum = cls_sum + F.binary_cross_entropy_with_logits(obj_cat[n][idx], tgt, weight=wgt, reduction="sum")
+        else:
+            cls_sum = cls_sum + F.binary_cross_entropy_with_logits(obj_cat[n][idx], tgt, reduction="sum")
+        if len(pos) and len(gb):
+            t = rpn_get_deltas(anchors_cat[pos], gb[midx[pos]])
+            loc_sum = loc_sum + (deltas_cat[n][pos] - t).abs().sum()
+    norm = batch * N
+    return {"loss_rpn_cls": cls_sum / norm, "loss_rpn_loc": loc_sum / norm}, samples
+
+
+def roi_align(feat, rois, scale, out=7):
+    """torchvision roi_align(aligned=True, sampling_ratio=0) on one NCHW level [D2/torchvision-recall].
+    feat [C,H,W] of ONE image; rois [R,4] -> [R,C,out,out]."""
+    C, H, W = feat.shape
+    R = rois.shape[0]
+    res = feat.new_zeros((R, C, out, out))
+    for r in range(R):
+        x1, y1, x2, y2 = [float(v) * scale - 0.5 for v in rois[r]]
+        rw, rh = x2 - x1, y2 - y1
+        bw, bh = rw / out, rh / out
+        gh, gw = int(math.ceil(rh / out)), int(math.ceil(rw / out))
+        if gh <= 0 or gw <= 0:
+            continue
+        ys = y1 + (torch.arange(out)[:, None] * bh + (torch.arange(gh)[None, :] + 0.5) * bh / gh).reshape(-1)
+        xs = x1 + (torch.arange(out)[:, None] * bw + (torch.arange(gw)[None, :] + 0.5) * bw / gw).reshape(-1)
+
+        def prep(v, L):
+            okk = (v >= -1.0) & (v <= L)
+            v = v.clamp(min=0)
+            lo = v.floor().long()
+            hi_edge = lo >= L - 1
+            lo = torch.where(hi_edge, torch.full_like(lo, L - 1), lo)
+            hi = torch.where(hi_edge, lo, lo + 1)
+            v = torch.where(hi_edge, lo.to(v.dtype), v)
+            frac = v - lo.to(v.dtype)
+            return okk, lo, hi, frac
+        oky, yl, yh, ly = prep(ys.float(), H)
+        okx, xl, xh, lx = prep(xs.float(), W)
+        hy, hx = 1 - ly, 1 - lx
+        v = (feat[:, yl][:, :, xl] * (hy[:, None] * hx[None, :]) + feat[:, yl][:, :, xh] * (hy[:, None] * lx[None, :]) +
+             feat[:, yh][:, :, xl] * (ly[:, None] * hx[None, :]) + feat[:, yh][:, :, xh] * (ly[:, None] * lx[None, :]))
+        v = v * (oky[:, None] & okx[None, :]).to(v.dtype)
+        res[r] = v.view(C, out, gh, out, gw).sum(dim=(2, 4)) / max(gh * gw, 1)
+    return res
+
+
+def roi_pool(feats, boxes_per_im, out=7):
+    """D2 ROIPooler (levels 2..5, canonical 224 @ level 4) [D2-recall]; feats NCHW list p2..p5."""
+    outs = []
+    for n, boxes in enumerate(boxes_per_im):
+        area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+        lv = torch.floor(4 + torch.log2(torch.sqrt(area) / 224 + 1e-8)).clamp(2, 5).long() - 2
+        o = feats[0].new_zeros((len(boxes), feats[0].shape[1], out, out))
+        for l in range(4):
+            m = torch.nonzero(lv == l).squeeze(1)
+            if len(m):
+                o[m] = roi_align(feats[l][n], boxes[m], 1.0 / (4 * 2 ** l), out)
+        outs.append(o)
+    return torch.cat(outs) if outs else feats[0].new_zeros((0, feats[0].shape[1], out, out))
+
+
+def box_head(sd, x, prefix="roi_heads"):
+    x = x.flatten(1)
+    x = F.relu(F.linear(x, sd[prefix + ".box_head.fc1.weight"], sd[prefix + ".box_head.fc1.bias"]))
+    x = F.relu(F.linear(x, sd[prefix + ".box_head.fc2.weight"], sd[prefix + ".box_head.fc2.bias"]))
+    p = prefix + ".box_predictor"
+    return (F.linear(x, sd[p + ".cls_score.weight"], sd[p + ".cls_score.bias"]),
+            F.linear(x, sd[p + ".bbox_pred.weight"], sd[p + ".bbox_pred.bias"]),
+            F.linear(x, sd[p + ".bbox_pred_std.weight"], sd[p + ".bbox_pred_std.bias"]))
+
+
+def softmax_focal(scores, gt_classes, gamma=1.5):
+    """roi_heads/fast_rcnn.py:925-936 + FocalLoss :1405-1429."""
+    if gt_classes.numel() == 0:
+        return 0.0 * scores.sum()
+    ce = F.cross_entropy(scores, gt_classes, reduction="none")
+    p = torch.exp(-ce)
+    return ((1 - p) ** gamma * ce).sum() / gt_classes.shape[0]
+
+
+def matched_iou(b1, b2):
+    """roi_heads/fast_rcnn.py:20-44."""
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    lt, rb = torch.max(b1[:, :2], b2[:, :2]), torch.min(b1[:, 2:], b2[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[:, 0] * wh[:, 1]
+    return inter / (a1 + a2 - inter)
+
+
+def roi_box_reg_loss(prop, gtb, deltas, std, gt_classes, num_classes=80):
+    """fast_rcnn.py:938-1016, type 'nlloss' + nl_loss :1228-1292 (reduction sum)."""
+    fg = torch.nonzero((gt_classes >= 0) & (gt_classes < num_classes)).squeeze(1)
+    d, s = deltas[fg], std[fg]
+    pred = xyxy_apply_deltas(d, prop[fg])
+    iou = matched_iou(gtb[fg], pred)
+    t = xyxy_get_deltas(prop[fg], gtb[fg])
+    sig = s.sigmoid()
+    sq = torch.square(sig)
+    nll = ((torch.square(t - d) / (2 * sq) + 0.5 * torch.log(sq)).sum(dim=1) + 2 * torch.log(2 * torch.Tensor([math.pi]))) * iou
+    l1 = (d - t).abs().sum()
+    return (l1 + 0.05 * nll.sum()) / max(gt_classes.numel(), 1.0)
+
+
+def roi_box_reg_pseudo_loss(prop, gtb, deltas, std, gt_loc_std, gt_classes, ts_better=0.1, t_cert=0.5, num_classes=80):
+    """fast_rcnn.py:1018-1092, type 'tsbetter'."""
+    fg = torch.nonzero((gt_classes >= 0) & (gt_classes < num_classes)).squeeze(1)
+    d, s = deltas[fg], std[fg]
+    t = xyxy_get_deltas(prop[fg], gtb[fg])
+    ct = 1 - gt_loc_std[fg].sigmoid()
+    cs = 1 - s.sigmoid()
+    sel = (ct > cs + ts_better) * (ct > t_cert)
+    return (d[sel] - t[sel]).abs().sum() / max(gt_classes.numel(), 1.0)
+
+
+def roi_label_and_sample(prop_boxes, gt, keys, pseudo, num_classes=80, batch=512, frac=0.25):
+    """roi_heads.py:141-270 for one image (+ D2 add_ground_truth_to_proposals, Matcher([0.5],[0,1]),
+    _sample_proposals); keys: one per (proposal ++ gt) slot."""
+    gb = gt["boxes"]
+    pb = torch.cat((prop_boxes, gb))
+    has_gt = len(gb) > 0
+    iou = pairwise_iou(gb, pb) if has_gt else torch.zeros((0, len(pb)))
+    midx, lab = matcher(iou, [0.5], [0, 1], False)
+    if has_gt:
+        cls = gt["classes"][midx].clone()
+        cls[lab == 0] = num_classes
+    else:
+        cls = torch.zeros_like(midx) + num_classes
+    fgi, bgi = subsample_by_keys(cls, keys, batch, frac, num_classes)
+    sidx = torch.cat((fgi, bgi))
+    out = dict(proposal_boxes=pb[sidx], gt_classes=cls[sidx])
+    if has_gt:
+        out["gt_boxes"] = gb[midx[sidx]]
+        if pseudo:
+            out["gt_confid"] = gt["scores"][midx[sidx]]
+            out["gt_loc_std"] = gt["pred_boxes_std"][midx[sidx]]
+    else:
+        out["gt_boxes"] = gb.new_zeros((len(sidx), 4))
+        if pseudo:
+            out["gt_confid"] = torch.zeros(len(sidx))
+            out["gt_loc_std"] = gb.new_zeros((len(sidx), 4))
+    return out
+
+
+def fast_rcnn_inference(boxes, probs, image_size, score_thresh=0.05, nms_thresh=0.5, topk=100):
+    """D2 fast_rcnn_inference_single_image [D2-recall] for class-agnostic boxes.  Returns (dets, kept proposal row)."""
+    ok = torch.isfinite(boxes).all(dim=1) & torch.isfinite(probs).all(dim=1)
+    rows = torch.nonzero(ok).squeeze(1)
+    boxes, probs = boxes[ok], probs[ok][:, :-1]
+    h, w = image_size
+    boxes = torch.stack((boxes[:, 0].clamp(0, w), boxes[:, 1].clamp(0, h), boxes[:, 2].clamp(0, w), boxes[:, 3].clamp(0, h)), dim=1)
+    m = probs > score_thresh
+    fi = m.nonzero()
+    b, s = boxes[fi[:, 0]], probs[m]
+    keep = batched_nms(b, s, fi[:, 1], nms_thresh)[:topk]
+    return dict(boxes=b[keep], scores=s[keep], classes=fi[keep, 1]), rows[fi[keep, 0]]
+
+
+def rcnn_backbone(sd, images, mean, pix_std):
+    x, sizes = preprocess(images, mean, pix_std, 32)
+    c = resnet50(sd, x, "backbone.bottom_up", ("res2", "res3", "res4", "res5"))
+    p = fpn(sd, c, ["res2", "res3", "res4", "res5"], "maxpool")
+    return p, sizes
+
+
+def rcnn_teacher(sd, images, mean, pix_std, pre_topk=2000, post_topk=1000, thr=0.7):
+    """meta_arch/rcnn.py:39-55 (branch unsup_data_weak, teacher left in train mode - SURVEY B13) +
+    trainer.py:727-751 thresholding."""
+    p, sizes = rcnn_backbone(sd, images, mean, pix_std)
+    feats = [p[k] for k in ("p2", "p3", "p4", "p5", "p6")]
+    hw = [(f.shape[2], f.shape[3]) for f in feats]
+    anchors = make_anchors(hw, [4, 8, 16, 32, 64])
+    obj, dl = rpn_head(sd, feats)
+    props = find_top_rpn_proposals(anchors, obj, dl, sizes, pre_topk, post_topk)
+    pooled = roi_pool(feats[:4], [q["boxes"] for q in props])
+    scores, deltas, std = box_head(sd, pooled)
+    out, r = [], 0
+    for n, q in enumerate(props):
+        k = len(q["boxes"])
+        boxes = xyxy_apply_deltas(deltas[r:r + k], q["boxes"])
+        dets, rows = fast_rcnn_inference(boxes, F.softmax(scores[r:r + k], dim=-1), sizes[n])
+        dets["pred_boxes_std"] = std[r:r + k][rows]
+        m = dets["scores"] > thr
+        out.append(dict(boxes=dets["boxes"][m], classes=dets["classes"][m], scores=dets["scores"][m], pred_boxes_std=dets["pred_boxes_std"][m]))
+        r += k
+    return out, props
+
+
+def rcnn_student_losses(sd, images, gts, rpn_keys, roi_keys, pseudo, mean, pix_std, pre_topk=2000, post_topk=1000):
+    """meta_arch/rcnn.py:23-37 / :57-72."""
+    p, sizes = rcnn_backbone(sd, images, mean, pix_std)
+    feats = [p[k] for k in ("p2", "p3", "p4", "p5", "p6")]
+    hw = [(f.shape[2], f.shape[3]) for f in feats]
+    anchors = make_anchors(hw, [4, 8, 16, 32, 64])
+    obj, dl = rpn_head(sd, feats)
+    rl, _ = rpn_losses(torch.cat(anchors), torch.cat(obj, 1), torch.cat(dl, 1), gts, rpn_keys, pseudo)
+    with torch.no_grad():
+        props = find_top_rpn_proposals(anchors, obj, dl, sizes, pre_topk, post_topk)
+    sampled = [roi_label_and_sample(q["boxes"], g, k, pseudo) for q, g, k in zip(props, gts, roi_keys)]
+    pooled = roi_pool(feats[:4], [s["proposal_boxes"] for s in sampled])
+    scores, deltas, std = box_head(sd, pooled)
+    cls = torch.cat([s["gt_classes"] for s in sampled])
+    pb = torch.cat([s["proposal_boxes"] for s in sampled])
+    gb = torch.cat([s["gt_boxes"] for s in sampled])
+    losses = {"loss_cls": softmax_focal(scores, cls)}
+    if pseudo:
+        gstd = torch.cat([s["gt_loc_std"] for s in sampled])
+        losses["loss_box_reg"] = roi_box_reg_pseudo_loss(pb, gb, deltas, std, gstd, cls)
+    else:
+        losses["loss_box_reg"] = roi_box_reg_loss(pb, gb, deltas, std, cls)
+    losses.update(rl)
+    return losses, props, sampled
+
+
+def rcnn_semisup_step(student_sd, teacher_sd, batch, keys, keep_rate=0.9996, lam_u=4.0, lam_r=1.0, thr=0.7, lr=0.01,
+                      momentum=0.9, wd=1e-4, mean=None, pix_std=None, pre_topk=2000, post_topk=1000,
+                      frozen_prefixes=("backbone.bottom_up.stem", "backbone.bottom_up.res2")):
+    """One post-burn-in UBRCNNTeacherTrainer.run_step_full_semisup (engine/trainer.py:814-912).
+    keys = dict(rpn_sup [N,R], roi_sup [list], rpn_unsup, roi_unsup): injected sampling keys."""
+    mean = mean if mean is not None else torch.tensor([103.53, 116.28, 123.675]).view(3, 1, 1)
+    pix_std = pix_std if pix_std is not None else torch.ones(3, 1, 1)
+    lq, lk, uq, uk = batch
+    teacher_sd = ema_update(student_sd, teacher_sd, keep_rate)
+    rec = {"EMA_rate": keep_rate}
+    with torch.no_grad():
+        pseudo, _ = rcnn_teacher(teacher_sd, [d["image"] for d in uk], mean, pix_std, pre_topk, post_topk, thr)
+    params = {k: v.clone().requires_grad_(True) for k, v in student_sd.items()
+              if v.dtype.is_floating_point and "norm." not in k and not k.startswith(frozen_prefixes)}
+    sd = dict(student_sd)
+    sd.update(params)
+    sup, _, _ = rcnn_student_losses(sd, [d["image"] for d in lq + lk], [d["gt"] for d in lq + lk], keys["rpn_sup"], keys["roi_sup"], False, mean, pix_std, pre_topk, post_topk)
+    rec.update(sup)
+    uns, _, _ = rcnn_student_losses(sd, [d["image"] for d in uq], pseudo, keys["rpn_unsup"], keys["roi_unsup"], True, mean, pix_std, pre_topk, post_topk)
+    for k, v in uns.items():
+        rec[k + "_pseudo"] = v
+    total = 0.0
+    for k, v in rec.items():
+        if k[:4] != "loss":
+            continue
+        if k == "loss_rpn_loc_pseudo":
+            total = total + v * 0
+        elif k == "loss_box_reg_pseudo":
+            total = total + v * lam_r
+        elif k[-6:] == "pseudo":
+            total = total + v * lam_u
+        else:
+            total = total + v
+    gl = torch.autograd.grad(total, list(params.values()), allow_unused=True)
+    grads = {k: (g if g is not None else torch.zeros_like(params[k])) for k, g in zip(params.keys(), gl)}
+    newp, bufs = sgd_step({k: v.detach() for k, v in params.items()}, grads, {}, lr, momentum, {k: wd for k in params})
+    new_student = OrderedDict(student_sd)
+    new_student.update(newp)
+    rec = {k: (float(v.detach()) if torch.is_tensor(v) else float(v)) for k, v in rec.items()}
+    return rec, new_student, teacher_sd, grads, pseudo

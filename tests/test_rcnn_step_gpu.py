@@ -1,0 +1,137 @@
+"""End-to-end parity of the HIP UTv2 Faster-RCNN path vs the CPU oracle on a small seeded problem
+(teacher RPN+ROI inference + thresholding, both student forwards with injected sampling keys, the
+weighted loss, backward, SGD, EMA).  Losses 1e-3 relative; NMS/top-k selections identical."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import utv2_oracle as O
+from tests.utv2_testutil import FixedLoader, cpu_state, make_batch
+
+pytestmark = pytest.mark.gpu
+H, W = 96, 128
+
+
+def rcnn_cfg():
+    from ubteacher.presets import get_config
+    return get_config("rcnn", 1, ["SOLVER.IMG_PER_BATCH_LABEL", 2, "SOLVER.IMG_PER_BATCH_UNLABEL", 2,
+                                  "SEMISUPNET.BURN_UP_STEP", 0, "MODEL.DEVICE", "cuda"])
+
+
+def relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def tune(sd, images, mean, pstd, seed=0):
+    """Random-init R50 features are not normalised (no pretrained BN statistics), so the head outputs
+    explode; rescale the prediction layers (data-driven, via the oracle forward) so the detector emits a
+    few confident, well separated, non-degenerate detections."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    sd = dict(sd)
+    q = "proposal_generator.rpn_head."
+    p = "roi_heads.box_predictor."
+    with torch.no_grad():
+        feats, sizes = O.rcnn_backbone(sd, images, mean, pstd)
+        fl = [feats[k] for k in ("p2", "p3", "p4", "p5", "p6")]
+        t = torch.cat([F.relu(F.conv2d(f, sd[q + "conv.weight"], sd[q + "conv.bias"], 1, 1)).permute(0, 2, 3, 1).reshape(-1, 256) for f in fl])
+        s_t = t.std().item()
+        sd[q + "objectness_logits.weight"] = torch.randn(3, 256, 1, 1, generator=g) * (1.0 / (s_t * 16))
+        sd[q + "anchor_deltas.weight"] = torch.randn(12, 256, 1, 1, generator=g) * (0.1 / (s_t * 16))
+        hw = [(f.shape[2], f.shape[3]) for f in fl]
+        anchors = O.make_anchors(hw, [4, 8, 16, 32, 64])
+        obj, dl = O.rpn_head(sd, fl)
+        props = O.find_top_rpn_proposals(anchors, obj, dl, sizes, 2000, 1000)
+        x = O.roi_pool(fl[:4], [pp["boxes"] for pp in props]).flatten(1)
+        x = F.relu(F.linear(x, sd["roi_heads.box_head.fc1.weight"], sd["roi_heads.box_head.fc1.bias"]))
+        x = F.relu(F.linear(x, sd["roi_heads.box_head.fc2.weight"], sd["roi_heads.box_head.fc2.bias"]))
+        s_x = x.std().item()
+    sd[p + "cls_score.weight"] = torch.randn(81, 1024, generator=g) * (2.5 / (s_x * 32))
+    b = torch.zeros(81); b[80] = 3.0
+    sd[p + "cls_score.bias"] = b
+    sd[p + "bbox_pred.weight"] = torch.randn(4, 1024, generator=g) * (0.5 / (s_x * 32))
+    sd[p + "bbox_pred_std.weight"] = torch.randn(4, 1024, generator=g) * (0.5 / (s_x * 32))
+    return sd
+
+
+def test_rcnn_full_semisup_step_parity():
+    from ubteacher.engine import UBRCNNTeacherTrainer
+    cfg = rcnn_cfg()
+    torch.manual_seed(0)
+    prod, orac = make_batch(31, 2, 2, H, W, "cuda")
+    tr = UBRCNNTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+    mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1)
+    pstd = torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1)
+    sd_s = tune(cpu_state(tr.model), [d["image"] for d in orac[3]], mean, pstd)
+    sd_t = dict(sd_s)
+    sd_t["roi_heads.box_predictor.bbox_pred_std.bias"] = torch.full((4,), -3.0)
+    tr.model.load_state_dict(sd_s)
+    tr.model_teacher.load_state_dict(sd_t)
+    tr.iter = 1
+    tr.optimizer.param_groups[0]["lr"] = 0.01
+
+    g = torch.Generator().manual_seed(99)
+    rpn_keys, roi_keys = [], []
+
+    def rpn_src(n, m, device):
+        k = torch.rand(n, m, generator=g)
+        rpn_keys.append(k)
+        return k.to(device)
+
+    def roi_src(n, m, device):
+        k = torch.rand(n, m, generator=g)
+        roi_keys.append(k)
+        return k.to(device)
+
+    tr.model.proposal_generator.sample_keys = rpn_src
+    tr.model.roi_heads.sample_keys = roi_src
+    tr.run_step_full_semisup()
+    rec = tr.flush_metrics()
+    torch.cuda.synchronize()
+    assert len(rpn_keys) == 2 and len(roi_keys) == 2
+
+    # oracle keys in its compact (proposals ++ gts) convention
+    post = cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN
+    samp_sup = None
+
+    def compact_roi(keys, nprops, ngts):
+        return [torch.cat((keys[i, :nprops[i]], keys[i, post:post + ngts[i]])) for i in range(keys.shape[0])]
+
+    # supervised pass: proposals counts come from the oracle itself (must equal the product's if parity holds)
+    mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1)
+    pstd = torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1)
+    t_sd = O.ema_update(sd_s, sd_t, cfg.SEMISUPNET.EMA_KEEP_RATE)
+    with torch.no_grad():
+        pseudo, _ = O.rcnn_teacher(t_sd, [d["image"] for d in orac[3]], mean, pstd, thr=cfg.SEMISUPNET.BBOX_THRESHOLD)
+        _, props_sup, _ = O.rcnn_student_losses(sd_s, [d["image"] for d in orac[0] + orac[1]], [d["gt"] for d in orac[0] + orac[1]],
+                                                rpn_keys[0], [torch.zeros(2000)] * 4, False, mean, pstd)
+        _, props_uns, _ = O.rcnn_student_losses(sd_s, [d["image"] for d in orac[2]], pseudo, rpn_keys[1], [torch.zeros(2000)] * 2,
+                                                True, mean, pstd)
+    assert sum(len(p["boxes"]) for p in pseudo) > 0, "test setup: teacher produced no pseudo boxes"
+    gl = tr._last_pseudo
+    for i, p in enumerate(pseudo):
+        assert int(gl["valid"][i].sum()) == len(p["boxes"])
+    keys = dict(rpn_sup=rpn_keys[0], rpn_unsup=rpn_keys[1],
+                roi_sup=compact_roi(roi_keys[0], [len(p["boxes"]) for p in props_sup], [len(d["gt"]["boxes"]) for d in orac[0] + orac[1]]),
+                roi_unsup=compact_roi(roi_keys[1], [len(p["boxes"]) for p in props_uns], [len(p["boxes"]) for p in pseudo]))
+    rec_o, new_s, new_t, grads, _ = O.rcnn_semisup_step(sd_s, sd_t, orac, keys, keep_rate=cfg.SEMISUPNET.EMA_KEEP_RATE,
+                                                       lam_u=cfg.SEMISUPNET.UNSUP_LOSS_WEIGHT, lam_r=cfg.SEMISUPNET.UNSUP_REG_LOSS_WEIGHT,
+                                                       thr=cfg.SEMISUPNET.BBOX_THRESHOLD, lr=0.01, mean=mean, pix_std=pstd)
+    for k, v in rec_o.items():
+        assert k in rec, k
+        # loss_rpn_loc_pseudo (weight 0 in the objective, trainer.py:888-890) sums over anchors made positive by
+        # the Matcher's exact-equality low-quality rule against pseudo boxes that differ by 1e-5 between the
+        # two teachers: an ill-conditioned selection, compared loosely.
+        tol = 2e-2 if k == "loss_rpn_loc_pseudo" else 1e-3
+        assert abs(rec[k] - v) <= tol * max(abs(v), 1e-6), (k, rec[k], v)
+    assert rec_o["loss_box_reg_pseudo"] > 0 and rec_o["loss_rpn_cls_pseudo"] > 0
+    t_after = cpu_state(tr.model_teacher)
+    for k in new_t:
+        assert torch.equal(t_after[k], new_t[k]), k
+    s_after = cpu_state(tr.model)
+    for k in new_s:
+        err = float((s_after[k].double() - new_s[k].double()).abs().max())
+        upd = float((new_s[k].double() - sd_s[k].double()).abs().max())
+        tol = 1e-4 * float(new_s[k].abs().max()) + 5e-2 * upd + 1e-12  # discrete selections (matcher ties, ReLU gates) are ill-conditioned
+        assert err <= tol, (k, err, tol)

@@ -1,0 +1,345 @@
+// Faster-RCNN specific kernels of the UTv2 step (gfx950): batched box<->gt matching (IoU max /
+// argmax + low-quality pass), multi-level RoIAlign (aligned, adaptive sampling) NHWC fwd/bwd,
+// softmax focal loss fwd/bwd.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// Matching (D2 pairwise_iou + Matcher [D2-recall]; called from proposal_generator/rpn.py:112-148 and
+// roi_heads/roi_heads.py:213-231).  One thread per candidate box, the image's valid gts in LDS.
+//   max_iou[n][p]  = max_g IoU(gt[n][g], box[p])   (-1 when the image has no valid gt)
+//   arg[n][p]      = first g (compacted order) attaining it
+//   gt_max[n][g]   = max_p IoU (as float bits, via atomicMax; IoU >= 0 so bit order == value order)
+#define MB_MAXG 256
+__device__ __forceinline__ float iou_d2(const float4& a, const float4& b) {
+  const float aa = (a.z - a.x) * (a.w - a.y), ab = (b.z - b.x) * (b.w - b.y);
+  const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.f);
+  const float h = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.f);
+  const float inter = w * h;
+  return inter > 0.f ? inter / (aa + ab - inter) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void match_boxes_kernel(const float* __restrict__ boxes, long long box_img_stride, int P,
+                                                        const float* __restrict__ gt_boxes, const unsigned char* __restrict__ gt_valid,
+                                                        int G, float* __restrict__ max_iou, int* __restrict__ arg,
+                                                        unsigned* __restrict__ gt_max_bits) {
+  __shared__ float4 sg[MB_MAXG];
+  __shared__ int sidx[MB_MAXG];
+  __shared__ unsigned smax[MB_MAXG];
+  __shared__ int scount;
+  const int n = blockIdx.y;
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int g = 0; g < G; ++g)
+      if (gt_valid[n * G + g]) sidx[c++] = g;
+    scount = c;
+  }
+  __syncthreads();
+  const int Gv = scount;
+  for (int k = threadIdx.x; k < Gv; k += blockDim.x) {
+    sg[k] = ((const float4*)gt_boxes)[(size_t)n * G + sidx[k]];
+    smax[k] = 0u;
+  }
+  __syncthreads();
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < P) {
+    const float4 b = *(const float4*)(boxes + (size_t)n * box_img_stride + (size_t)p * 4);
+    float best = -1.f;
+    int bi = 0;
+    for (int k = 0; k < Gv; ++k) {
+      const float v = iou_d2(sg[k], b);
+      if (v > best) { best = v; bi = k; }
+      if (gt_max_bits) atomicMax(&smax[k], __float_as_uint(v));
+    }
+    max_iou[(size_t)n * P + p] = best;
+    arg[(size_t)n * P + p] = Gv > 0 ? sidx[bi] : 0;
+  }
+  __syncthreads();
+  if (gt_max_bits)
+    for (int k = threadIdx.x; k < Gv; k += blockDim.x) atomicMax(&gt_max_bits[(size_t)n * G + sidx[k]], smax[k]);
+}
+
+// lowq[n][p] = 1 if IoU(gt g, box p) == gt_max[n][g] for some valid g  (Matcher.set_low_quality_matches_)
+__global__ __launch_bounds__(256) void match_lowq_kernel(const float* __restrict__ boxes, long long box_img_stride, int P,
+                                                       const float* __restrict__ gt_boxes, const unsigned char* __restrict__ gt_valid,
+                                                       int G, const unsigned* __restrict__ gt_max_bits,
+                                                       unsigned char* __restrict__ lowq) {
+  __shared__ float4 sg[MB_MAXG];
+  __shared__ float smax[MB_MAXG];
+  __shared__ int scount;
+  const int n = blockIdx.y;
+  if (threadIdx.x == 0) scount = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int g = 0; g < G; ++g)
+      if (gt_valid[n * G + g]) {
+        sg[c] = ((const float4*)gt_boxes)[(size_t)n * G + g];
+        smax[c] = __uint_as_float(gt_max_bits[(size_t)n * G + g]);
+        ++c;
+      }
+    scount = c;
+  }
+  __syncthreads();
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const float4 b = *(const float4*)(boxes + (size_t)n * box_img_stride + (size_t)p * 4);
+  unsigned char f = 0;
+  for (int k = 0; k < scount; ++k)
+    if (iou_d2(sg[k], b) == smax[k]) f = 1;
+  lowq[(size_t)n * P + p] = f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-level RoIAlign, aligned=True, sampling_ratio=0 (torchvision.ops.roi_align via D2 ROIPooler,
+// roi_heads/roi_heads.py:28-45,118 [D2-recall]).  Features NHWC per level, output [R][PH][PW][C].
+// Level: clamp(floor(canonical_level + log2(sqrt(area)/canonical_size + 1e-8)), min_level, max_level).
+struct RoiLevels {
+  const float* feat[4];
+  float* dfeat[4];
+  int H[4], W[4];
+  float scale[4];
+  int num_levels, min_level;
+};
+
+__device__ __forceinline__ int roi_level(const float4& b, const RoiLevels& L) {
+  const float area = (b.z - b.x) * (b.w - b.y);
+  int lvl = (int)floorf(4.f + log2f(sqrtf(area) / 224.f + 1e-8f));
+  lvl = min(max(lvl, L.min_level), L.min_level + L.num_levels - 1);
+  return lvl - L.min_level;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(64) void roi_align_kernel(RoiLevels L, const float* __restrict__ rois, const int* __restrict__ roi_batch,
+                                                     const unsigned char* __restrict__ roi_valid, int C, int PH, int PW,
+                                                     float* __restrict__ out /* fwd: y, bwd: dy */) {
+  // one block per (roi, bin); 64 lanes x float4 cover up to 256 channels per pass
+  const int bin = blockIdx.x % (PH * PW);
+  const int r = blockIdx.x / (PH * PW);
+  const int ph = bin / PW, pw = bin % PW;
+  const int C4 = C >> 2;
+  float* o = out + ((size_t)r * PH * PW + bin) * C;
+  const bool ok = roi_valid ? roi_valid[r] != 0 : true;
+  if (!ok) {
+    if (!BWD)
+      for (int c = threadIdx.x; c < C4; c += 64) ((f32x4*)o)[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
+  const float4 b = ((const float4*)rois)[r];
+  const int li = roi_level(b, L);
+  const int H = L.H[li], W = L.W[li];
+  const float sc = L.scale[li];
+  const float x1 = b.x * sc - 0.5f, y1 = b.y * sc - 0.5f, x2 = b.z * sc - 0.5f, y2 = b.w * sc - 0.5f;
+  const float rw = x2 - x1, rh = y2 - y1;
+  const float bw = rw / (float)PW, bh = rh / (float)PH;
+  const int gh = (int)ceilf(rh / (float)PH), gw = (int)ceilf(rw / (float)PW);
+  const float cnt = fmaxf((float)(gh * gw), 1.f);
+  const int n = roi_batch[r];
+  const float* f = L.feat[li] + (size_t)n * H * W * C;
+  float* df = BWD ? L.dfeat[li] + (size_t)n * H * W * C : nullptr;
+  for (int c = threadIdx.x; c < C4; c += 64) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (BWD) {
+      g = ((const f32x4*)o)[c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] /= cnt;
+    }
+    for (int iy = 0; iy < gh; ++iy) {
+      float y = y1 + ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        float x = x1 + pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+        float yy = y;
+        if (yy < -1.f || yy > (float)H || x < -1.f || x > (float)W) continue;
+        if (yy <= 0.f) yy = 0.f;
+        if (x <= 0.f) x = 0.f;
+        int yl = (int)yy, xl = (int)x, yh, xh;
+        if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
+        if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+        const float ly = yy - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+        const size_t o1 = ((size_t)yl * W + xl) * C4 + c, o2 = ((size_t)yl * W + xh) * C4 + c;
+        const size_t o3 = ((size_t)yh * W + xl) * C4 + c, o4 = ((size_t)yh * W + xh) * C4 + c;
+        if (!BWD) {
+          const f32x4 v1 = ((const f32x4*)f)[o1], v2 = ((const f32x4*)f)[o2], v3 = ((const f32x4*)f)[o3], v4 = ((const f32x4*)f)[o4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            atomicAdd(df + o1 * 4 + e, g[e] * w1);
+            atomicAdd(df + o2 * 4 + e, g[e] * w2);
+            atomicAdd(df + o3 * 4 + e, g[e] * w3);
+            atomicAdd(df + o4 * 4 + e, g[e] * w4);
+          }
+        }
+      }
+    }
+    if (!BWD) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] /= cnt;
+      ((f32x4*)o)[c] = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Softmax focal loss of the ROI head (roi_heads/fast_rcnn.py:925-936 + FocalLoss :1405-1429):
+//   CE = logsumexp(x) - x[t];  p = exp(-CE);  loss = (1-p)^gamma * CE      (gamma 1.5), summed.
+// Rows with target < 0 are skipped.  One wave per row.
+__global__ __launch_bounds__(256) void softmax_focal_fwd_kernel(const float* __restrict__ logits, const int* __restrict__ target, int R, int C,
+                                                              float gamma, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int r = blockIdx.x * 4 + wid; r < R; r += gridDim.x * 4) {
+    const int t = target[r];
+    if (t < 0) continue;
+    const float* x = logits + (size_t)r * C;
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, x[c]);
+    m = wave_reduce_max(m);
+    m = __shfl(m, 0, 64);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += expf(x[c] - m);
+    s = wave_reduce_sum(s);
+    if (lane == 0) {
+      const float ce = logf(s) + m - x[t];
+      const float p = expf(-ce);
+      acc += powf(1.f - p, gamma) * ce;
+    }
+  }
+  if (lane == 0) red[wid] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// dlogits[r][c] = coef * dL/dCE * (softmax_c - [c==t]);  dL/dCE = (1-p)^g + g (1-p)^(g-1) p CE
+__global__ __launch_bounds__(256) void softmax_focal_bwd_kernel(const float* __restrict__ logits, const int* __restrict__ target, int R, int C,
+                                                              float gamma, const float* __restrict__ coef, float* __restrict__ dlogits) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const float k = coef[0];
+  for (int r = blockIdx.x * 4 + wid; r < R; r += gridDim.x * 4) {
+    const int t = target[r];
+    const float* x = logits + (size_t)r * C;
+    float* d = dlogits + (size_t)r * C;
+    if (t < 0) {
+      for (int c = lane; c < C; c += 64) d[c] = 0.f;
+      continue;
+    }
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, x[c]);
+    m = wave_reduce_max(m);
+    m = __shfl(m, 0, 64);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += expf(x[c] - m);
+    s = wave_reduce_sum(s);
+    s = __shfl(s, 0, 64);
+    const float ce = logf(s) + m - x[t];
+    const float p = expf(-ce);
+    const float om = 1.f - p;
+    const float dce = powf(om, gamma) + (om > 0.f ? gamma * powf(om, gamma - 1.f) * p * ce : 0.f);
+    for (int c = lane; c < C; c += 64) {
+      const float sm = expf(x[c] - m) / s;
+      d[c] = k * dce * (sm - (c == t ? 1.f : 0.f));
+    }
+  }
+}
+
+__global__ void sum_partials_f32(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += (double)partial[i];
+    out[0] = (float)s;
+  }
+}
+
+extern "C" {
+
+// boxes: [N][P][4] (box_img_stride = P*4) or shared anchors [P][4] (box_img_stride = 0).
+// gt_max_bits (optional, [N][G] uint32, must be zeroed by the caller) receives max-over-boxes IoU bits.
+int utv2_match_boxes(const float* boxes, int64_t box_img_stride, int N, int P, const float* gt_boxes,
+                     const unsigned char* gt_valid, int G, float* max_iou, int* arg, unsigned* gt_max_bits,
+                     hipStream_t stream) {
+  if (!boxes || !gt_boxes || !gt_valid || !max_iou || !arg || G < 1 || G > MB_MAXG) return UTV2_EARG;
+  if (P == 0) return UTV2_OK;
+  hipLaunchKernelGGL(match_boxes_kernel, dim3(cdiv(P, 256), N), dim3(256), 0, stream, boxes, (long long)box_img_stride, P,
+                     gt_boxes, gt_valid, G, max_iou, arg, gt_max_bits);
+  return utv2_launch_status();
+}
+
+int utv2_match_lowq(const float* boxes, int64_t box_img_stride, int N, int P, const float* gt_boxes,
+                    const unsigned char* gt_valid, int G, const unsigned* gt_max_bits, unsigned char* lowq,
+                    hipStream_t stream) {
+  if (!boxes || !gt_boxes || !gt_valid || !gt_max_bits || !lowq || G < 1 || G > MB_MAXG) return UTV2_EARG;
+  if (P == 0) return UTV2_OK;
+  hipLaunchKernelGGL(match_lowq_kernel, dim3(cdiv(P, 256), N), dim3(256), 0, stream, boxes, (long long)box_img_stride, P,
+                     gt_boxes, gt_valid, G, gt_max_bits, lowq);
+  return utv2_launch_status();
+}
+
+static int fill_levels(RoiLevels& L, int num_levels, int min_level, const float* const* feats, float* const* dfeats,
+                       const int* H, const int* W, const float* scales) {
+  if (num_levels < 1 || num_levels > 4) return UTV2_EARG;
+  L.num_levels = num_levels;
+  L.min_level = min_level;
+  for (int i = 0; i < 4; ++i) {
+    const bool on = i < num_levels;
+    L.feat[i] = on && feats ? feats[i] : nullptr;
+    L.dfeat[i] = on && dfeats ? dfeats[i] : nullptr;
+    L.H[i] = on ? H[i] : 0;
+    L.W[i] = on ? W[i] : 0;
+    L.scale[i] = on ? scales[i] : 0.f;
+  }
+  return UTV2_OK;
+}
+
+// feats_host: host array of num_levels device pointers (NHWC level features, same C).
+// rois [R][4] xyxy in image coordinates, roi_batch [R] image index, roi_valid [R] (optional).
+// out [R][PH][PW][C].
+int utv2_roi_align_fwd(int num_levels, int min_level, const float* const* feats_host, const int* H_host, const int* W_host,
+                       const float* scales_host, const float* rois, const int* roi_batch, const unsigned char* roi_valid,
+                       int R, int C, int PH, int PW, float* out, hipStream_t stream) {
+  RoiLevels L;
+  if (fill_levels(L, num_levels, min_level, feats_host, nullptr, H_host, W_host, scales_host) != UTV2_OK || (C & 3) || !rois ||
+      !roi_batch || !out)
+    return UTV2_EARG;
+  if (R == 0) return UTV2_OK;
+  hipLaunchKernelGGL((roi_align_kernel<false>), dim3(R * PH * PW), dim3(64), 0, stream, L, rois, roi_batch, roi_valid, C, PH, PW,
+                     out);
+  return utv2_launch_status();
+}
+
+// dfeats (+)= scatter of dy through the same sampling pattern (fp32 atomics; caller zero-fills).
+int utv2_roi_align_bwd(int num_levels, int min_level, float* const* dfeats_host, const int* H_host, const int* W_host,
+                       const float* scales_host, const float* rois, const int* roi_batch, const unsigned char* roi_valid,
+                       int R, int C, int PH, int PW, const float* dy, hipStream_t stream) {
+  RoiLevels L;
+  if (fill_levels(L, num_levels, min_level, nullptr, dfeats_host, H_host, W_host, scales_host) != UTV2_OK || (C & 3) || !rois ||
+      !roi_batch || !dy)
+    return UTV2_EARG;
+  if (R == 0) return UTV2_OK;
+  hipLaunchKernelGGL((roi_align_kernel<true>), dim3(R * PH * PW), dim3(64), 0, stream, L, rois, roi_batch, roi_valid, C, PH, PW,
+                     (float*)dy);
+  return utv2_launch_status();
+}
+
+#define SF_BLOCKS 256
+// loss_sum[0] = sum_r (1-p_r)^gamma * CE_r over rows with target >= 0.  ws >= 256 floats.
+int utv2_softmax_focal_fwd(const float* logits, const int* target, int R, int C, float gamma, float* loss_sum, float* ws,
+                           hipStream_t stream) {
+  if (!logits || !target || !loss_sum || !ws) return UTV2_EARG;
+  hipLaunchKernelGGL(softmax_focal_fwd_kernel, dim3(SF_BLOCKS), dim3(256), 0, stream, logits, target, R, C, gamma, ws);
+  hipLaunchKernelGGL(sum_partials_f32, dim3(1), dim3(64), 0, stream, (const float*)ws, SF_BLOCKS, loss_sum);
+  return utv2_launch_status();
+}
+
+int utv2_softmax_focal_bwd(const float* logits, const int* target, int R, int C, float gamma, const float* coef,
+                           float* dlogits, hipStream_t stream) {
+  if (!logits || !target || !coef || !dlogits) return UTV2_EARG;
+  if (R == 0) return UTV2_OK;
+  hipLaunchKernelGGL(softmax_focal_bwd_kernel, dim3(cdiv(R, 4) > 4096 ? 4096 : cdiv(R, 4)), dim3(256), 0, stream, logits, target,
+                     R, C, gamma, coef, dlogits);
+  return utv2_launch_status();
+}
+
+}  // extern "C"

@@ -1,6 +1,109 @@
-"""Faster-RCNN UTv2 trainer - placeholder until the RCNN path lands."""
+"""Faster-RCNN UTv2 trainer (reference engine/trainer.py:612-1023) on the arena/HIP machinery."""
+import time
+
+import torch
+
+from ..modeling.fcos import PaddedBoxes
 
 
-class UBRCNNTeacherTrainer:
-    def __init__(self, cfg, data_loader=None):
-        raise NotImplementedError("UBRCNNTeacherTrainer: Faster-RCNN path not built yet")
+def _make(base):
+    class UBRCNNTeacherTrainer(base):
+        def __init__(self, cfg, data_loader=None):
+            self.model = self.build_model(cfg)
+            self.optimizer = self.build_optimizer(cfg, self.model)
+            self.model_teacher = self.build_model(cfg)  # stays in train mode
+            self.scheduler = self.build_lr_scheduler(cfg, self.optimizer)
+            self._common_init(cfg, data_loader)
+
+        # -- pseudo-labelling (trainer.py:727-780) ----------------------------------------------------
+        def threshold_bbox(self, proposal_bbox_inst, thres=0.7, proposal_type="roih"):
+            if proposal_type != "roih":
+                raise ValueError("Error in proposal type.")
+            return proposal_bbox_inst.threshold(thres)
+
+        def process_pseudo_label(self, proposals, cur_threshold, proposal_type, psedo_label_method=""):
+            if psedo_label_method != "thresholding":
+                raise ValueError("Unkown pseudo label boxes methods")
+            out = self.threshold_bbox(proposals, thres=cur_threshold, proposal_type=proposal_type)
+            return out, out["valid"].float().sum() / max(out.n, 1)
+
+        def remove_label(self, label_data):
+            for d in label_data:
+                if "instances" in d.keys():
+                    del d["instances"]
+            return label_data
+
+        def add_label(self, unlabled_data, label):
+            if isinstance(label, PaddedBoxes):
+                for d in unlabled_data:
+                    d["instances"] = label
+            else:
+                for d, inst in zip(unlabled_data, label):
+                    d["instances"] = inst
+            return unlabled_data
+
+        def run_step_full_semisup(self):
+            cfg = self.cfg
+            S = cfg.SEMISUPNET
+            assert self.model.training, "[UBTeacherTrainer] model was changed to eval mode!"
+            start = time.perf_counter()
+            label_data_q, label_data_k, unlabel_data_q, unlabel_data_k = next(self._data_loader_iter)
+            data_time = time.perf_counter() - start
+
+            if self.iter < S.BURN_UP_STEP:
+                all_label_data = label_data_q + label_data_k if S.USE_SUP_STRONG == "both" else label_data_k
+                record_dict, _, _, _ = self.model(all_label_data, branch="supervised")
+                losses = sum(v for k, v in record_dict.items() if k[:4] == "loss")
+            else:
+                if self.iter == S.BURN_UP_STEP:
+                    self._update_teacher_model(keep_rate=0.0)
+                cur_ema_rate = S.EMA_KEEP_RATE
+                if (self.iter - S.BURN_UP_STEP) % S.TEACHER_UPDATE_ITER == 0:
+                    self._update_teacher_model(keep_rate=cur_ema_rate)
+                record_dict = {"EMA_rate": cur_ema_rate}
+
+                with torch.no_grad():
+                    _, proposals_rpn_unsup_k, proposals_roih_unsup_k, _ = self.model_teacher(unlabel_data_k, branch="unsup_data_weak")
+                pseudo, _ = self.process_pseudo_label(proposals_roih_unsup_k, S.BBOX_THRESHOLD, "roih", "thresholding")
+                # student ground truth fields
+                gt = PaddedBoxes(pseudo.image_sizes, boxes=pseudo["boxes"], classes=pseudo["classes"], valid=pseudo["valid"],
+                                 scores=pseudo["scores"], pred_boxes_std=pseudo["pred_boxes_std"])
+                self._last_pseudo = gt
+                unlabel_data_q = self.add_label(self.remove_label(unlabel_data_q), gt)
+                unlabel_data_k = self.add_label(self.remove_label(unlabel_data_k), gt)
+
+                all_label_data = label_data_q + label_data_k if S.USE_SUP_STRONG == "both" else label_data_k
+                rec_l, _, _, _ = self.model(all_label_data, branch="supervised")
+                record_dict.update(rec_l)
+                rec_u, _, _, _ = self.model(unlabel_data_q, branch="unsup_data_train")
+                for k, v in rec_u.items():
+                    record_dict[k + "_pseudo"] = v
+
+                loss_dict = {}
+                for key in record_dict.keys():
+                    if key[:4] != "loss":
+                        continue
+                    if key == "loss_rpn_loc_pseudo":
+                        loss_dict[key] = record_dict[key] * 0
+                    elif key == "loss_box_reg_pseudo":
+                        loss_dict[key] = record_dict[key] * S.UNSUP_REG_LOSS_WEIGHT
+                    elif key[-6:] == "pseudo":
+                        loss_dict[key] = record_dict[key] * S.UNSUP_LOSS_WEIGHT
+                    else:
+                        loss_dict[key] = record_dict[key]
+                losses = sum(loss_dict.values())
+
+            metrics_dict = record_dict
+            metrics_dict["data_time"] = data_time
+            self._write_metrics(metrics_dict)
+            self.optimizer.zero_grad()
+            losses.backward()
+            gscale = self._allreduce_grads()
+            self.optimizer.step(grad_scale=gscale)
+            return losses
+
+        @classmethod
+        def test(cls, cfg, model, evaluators=None):
+            raise NotImplementedError("COCO evaluation is a SURVEY 8(f) 'next' row (rank 3)")
+
+    return UBRCNNTeacherTrainer

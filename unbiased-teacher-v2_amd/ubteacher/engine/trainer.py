@@ -183,8 +183,9 @@ class _TrainerBase:
     # -- EMA (trainer.py:468-486 / :950-968) ---------------------------------------------------------
     @torch.no_grad()
     def _update_teacher_model(self, keep_rate=0.996):
-        s_keys = list(self.model.state_dict().keys())
-        t_keys = list(self.model_teacher.state_dict().keys())
+        if not hasattr(self, "_sd_keys"):  # key sets are fixed by construction: check once, not per step
+            self._sd_keys = (list(self.model.state_dict().keys()), list(self.model_teacher.state_dict().keys()))
+        s_keys, t_keys = self._sd_keys
         if s_keys != t_keys:
             sk = set(s_keys)
             for k in t_keys:
@@ -358,4 +359,6 @@ class UBTeacherTrainer(_TrainerBase):
         raise NotImplementedError("COCO evaluation is a SURVEY 8(f) 'next' row (rank 3), not part of the training step")
 
 
-from .rcnn_trainer import UBRCNNTeacherTrainer  # noqa: E402,F401
+from .rcnn_trainer import _make as _make_rcnn  # noqa: E402
+
+UBRCNNTeacherTrainer = _make_rcnn(_TrainerBase)

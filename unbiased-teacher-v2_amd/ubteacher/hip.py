@@ -384,3 +384,70 @@ def box_iou(a, b):
     out = torch.empty((A, B), dtype=torch.float32, device=a.device)
     call("utv2_box_iou", _p(a), _p(b), A, B, _p(out), _stream())
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# Faster-RCNN
+def match_boxes(boxes, gt_boxes, gt_valid, want_gt_max=False):
+    """boxes [P,4] (shared anchors) or [N,P,4]; gt_boxes [N,G,4]; gt_valid [N,G] uint8.
+    -> max_iou [N,P] (-1 if the image has no gt), argmax [N,P] int32, gt_max_bits [N,G] (or None)."""
+    N, G = gt_valid.shape
+    shared = boxes.dim() == 2
+    P = boxes.shape[-2]
+    dev = gt_boxes.device
+    mx = torch.empty((N, P), dtype=torch.float32, device=dev)
+    arg = torch.empty((N, P), dtype=torch.int32, device=dev)
+    gmax = torch.zeros((N, G), dtype=torch.int32, device=dev) if want_gt_max else None
+    call("utv2_match_boxes", _p(boxes), 0 if shared else P * 4, N, P, _p(gt_boxes), _p(gt_valid), G, _p(mx), _p(arg),
+         _p(gmax), _stream())
+    return mx, arg, gmax
+
+
+def match_lowq(boxes, gt_boxes, gt_valid, gmax):
+    N, G = gt_valid.shape
+    shared = boxes.dim() == 2
+    P = boxes.shape[-2]
+    out = torch.empty((N, P), dtype=torch.uint8, device=gt_boxes.device)
+    call("utv2_match_lowq", _p(boxes), 0 if shared else P * 4, N, P, _p(gt_boxes), _p(gt_valid), G, _p(gmax), _p(out),
+         _stream())
+    return out
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def roi_align_fwd(feats, scales, min_level, rois, roi_batch, roi_valid, out_size):
+    """feats: list of NHWC level tensors; rois [R,4]; roi_batch [R] int32 -> [R, PH, PW, C]."""
+    R = rois.shape[0]
+    C = feats[0].shape[-1]
+    out = torch.empty((R, out_size, out_size, C), dtype=torch.float32, device=rois.device)
+    fp = _ptr_array(feats)
+    H = _iarr([f.shape[1] for f in feats]); W = _iarr([f.shape[2] for f in feats]); S = _farr(scales)
+    call("utv2_roi_align_fwd", len(feats), min_level, ctypes.cast(fp, c_p), ctypes.cast(H, c_p), ctypes.cast(W, c_p),
+         ctypes.cast(S, c_p), _p(rois), _p(roi_batch), _p(roi_valid), R, C, out_size, out_size, _p(out), _stream())
+    return out
+
+
+def roi_align_bwd(dfeats, scales, min_level, rois, roi_batch, roi_valid, dy):
+    R, PH, PW, C = dy.shape
+    fp = _ptr_array(dfeats)
+    H = _iarr([f.shape[1] for f in dfeats]); W = _iarr([f.shape[2] for f in dfeats]); S = _farr(scales)
+    call("utv2_roi_align_bwd", len(dfeats), min_level, ctypes.cast(fp, c_p), ctypes.cast(H, c_p), ctypes.cast(W, c_p),
+         ctypes.cast(S, c_p), _p(rois), _p(roi_batch), _p(roi_valid), R, C, PH, PW, _p(dy), _stream())
+
+
+def softmax_focal_fwd(logits, target, gamma):
+    R, C = logits.shape
+    out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    ws = workspace(4096, logits.device, "loss")
+    call("utv2_softmax_focal_fwd", _p(logits), _p(target), R, C, float(gamma), _p(out), _p(ws), _stream())
+    return out
+
+
+def softmax_focal_bwd(logits, target, gamma, coef):
+    R, C = logits.shape
+    out = torch.empty_like(logits)
+    call("utv2_softmax_focal_bwd", _p(logits), _p(target), R, C, float(gamma), _p(coef), _p(out), _stream())
+    return out

@@ -1,0 +1,618 @@
+"""Faster-RCNN UTv2 model on the HIP path: `TwoStagePseudoLabGeneralizedRCNN`, `PseudoLabRPN`,
+`StandardROIHeadsPseudoLab` + `FastRCNNFocaltLossBoundaryVarOutputLayers`, `Box2BoxXYXYTransform`.
+
+Mirrors reference ubteacher/modeling/{meta_arch/rcnn.py:6-72, proposal_generator/rpn.py:15-225,
+roi_heads/roi_heads.py:23-270, roi_heads/fast_rcnn.py:715-1292,1405-1429, box_regression.py:11-129}
+and the Detectron2 pieces they inherit from [D2-recall, SURVEY appendix C], re-laid-out for MI355X:
+
+  * everything is batched over images on padded slots + validity masks (no per-image Python loops,
+    no nonzero()/item() host syncs); random subsampling uses per-slot random keys (the k smallest
+    keys of a class == randperm[:k] in distribution; tests inject the keys);
+  * RPN objectness + anchor deltas are one fused 1x1 conv (16 ch: 3 | 12 | pad); the box predictor's
+    cls_score / bbox_pred / bbox_pred_std are one fused 1024->96 GEMM; FC layers run on the same
+    MFMA implicit-GEMM kernel as the convs; fc1 consumes the NHWC RoIAlign output directly.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .. import hip, ops
+from ..d2.registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR_REGISTRY, ROI_HEADS_REGISTRY
+from ..d2.structures import Boxes, Instances
+from .arena_model import ArenaModel
+from .backbone import _nchw_view, _xavier_init
+from .fcos import PaddedBoxes
+
+SCALE_CLAMP = math.log(1000.0 / 16)
+RPN_CH = 16   # 3 objectness + 12 deltas + 1 pad
+PRED_CH = 96  # 81 cls + 4 deltas + 4 std + 7 pad
+
+
+# ---------------------------------------------------------------------------------------------------
+# box transforms
+def rpn_get_deltas(src, tgt, weights=(1.0, 1.0, 1.0, 1.0)):
+    """D2 Box2BoxTransform.get_deltas [D2-recall]."""
+    sw, sh = src[..., 2] - src[..., 0], src[..., 3] - src[..., 1]
+    sx, sy = src[..., 0] + 0.5 * sw, src[..., 1] + 0.5 * sh
+    tw, th = tgt[..., 2] - tgt[..., 0], tgt[..., 3] - tgt[..., 1]
+    tx, ty = tgt[..., 0] + 0.5 * tw, tgt[..., 1] + 0.5 * th
+    wx, wy, ww, wh = weights
+    return torch.stack((wx * (tx - sx) / sw, wy * (ty - sy) / sh, ww * torch.log(tw / sw), wh * torch.log(th / sh)), dim=-1)
+
+
+def rpn_apply_deltas(deltas, boxes, weights=(1.0, 1.0, 1.0, 1.0)):
+    """D2 Box2BoxTransform.apply_deltas [D2-recall]."""
+    w, h = boxes[..., 2] - boxes[..., 0], boxes[..., 3] - boxes[..., 1]
+    cx, cy = boxes[..., 0] + 0.5 * w, boxes[..., 1] + 0.5 * h
+    wx, wy, ww, wh = weights
+    dx, dy = deltas[..., 0] / wx, deltas[..., 1] / wy
+    dw = torch.clamp(deltas[..., 2] / ww, max=SCALE_CLAMP)
+    dh = torch.clamp(deltas[..., 3] / wh, max=SCALE_CLAMP)
+    pcx, pcy = dx * w + cx, dy * h + cy
+    pw, ph = torch.exp(dw) * w, torch.exp(dh) * h
+    return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph), dim=-1)
+
+
+class Box2BoxXYXYTransform:
+    """Per-boundary deltas, reference box_regression.py:11-129 (asymmetric +1, order l,r,d,u - SURVEY B3)."""
+
+    def __init__(self, weights, scale_clamp=1000.0 / 16):
+        self.weights = weights
+        self.scale_clamp = scale_clamp
+
+    def get_deltas(self, src, tgt):
+        sw = src[..., 2] - src[..., 0] + 1.0
+        sh = src[..., 3] - src[..., 1] + 1.0
+        wx, wy = self.weights[0], self.weights[1]
+        return torch.stack((wx * (tgt[..., 0] - src[..., 0]) / sw, wx * (tgt[..., 2] - src[..., 2]) / sw,
+                            wy * (tgt[..., 1] - src[..., 1]) / sh, wy * (tgt[..., 3] - src[..., 3]) / sh), dim=-1)
+
+    def apply_deltas(self, deltas, boxes):
+        w, h = boxes[..., 2] - boxes[..., 0], boxes[..., 3] - boxes[..., 1]
+        wx, wy = self.weights[0], self.weights[1]
+        c = self.scale_clamp
+        dl = torch.clamp(deltas[..., 0] / wx, max=c, min=-c)
+        dr = torch.clamp(deltas[..., 1] / wx, max=c, min=-c)
+        dd = torch.clamp(deltas[..., 2] / wy, max=c, min=-c)
+        du = torch.clamp(deltas[..., 3] / wy, max=c, min=-c)
+        return torch.stack((dl * w + boxes[..., 0], dd * h + boxes[..., 1], dr * w + boxes[..., 2], du * h + boxes[..., 3]), dim=-1)
+
+
+def float_order_key(x):
+    """int64 keys whose descending order == (value desc, flat index asc); NaN-free input assumed."""
+    i = x.contiguous().view(torch.int32)
+    mono = (i ^ ((i >> 31) & 0x7FFFFFFF)).long()
+    n = x.shape[-1]
+    idx = torch.arange(n, device=x.device, dtype=torch.int64)
+    return mono * 4294967296 + (4294967295 - idx)
+
+
+def _keys(src, n, m, device):
+    """per-slot sampling keys in [0,1): device RNG by default; tests inject a tensor or a callable."""
+    if src is None:
+        return torch.rand((n, m), device=device)
+    k = src(n, m, device) if callable(src) else src
+    assert tuple(k.shape) == (n, m), (tuple(k.shape), (n, m))
+    return k
+
+
+def sample_k_smallest(keys, mask, k):
+    """indices of the <=k smallest keys among mask (per row), ascending; returns (idx [N,k], valid [N,k])."""
+    kk = min(k, keys.shape[1])
+    v, idx = torch.topk(torch.where(mask, keys, torch.full_like(keys, 2.0)), kk, dim=1, largest=False, sorted=True)
+    return idx, v < 2.0
+
+
+# ---------------------------------------------------------------------------------------------------
+class AnchorGenerator:
+    """D2 DefaultAnchorGenerator [D2-recall]: sizes per level x aspect ratios, offset 0, order (H, W, A)."""
+
+    def __init__(self, cfg, strides):
+        self.sizes = [list(s) for s in cfg.MODEL.ANCHOR_GENERATOR.SIZES]
+        self.ratios = list(cfg.MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS[0])
+        self.strides = strides
+        self.A = len(self.sizes[0]) * len(self.ratios)
+        self._cache = {}
+
+    def cell(self, sizes):
+        out = []
+        for s in sizes:
+            area = s ** 2.0
+            for r in self.ratios:
+                w = math.sqrt(area / r)
+                h = r * w
+                out.append([-w / 2.0, -h / 2.0, w / 2.0, h / 2.0])
+        return torch.tensor(out, dtype=torch.float32)
+
+    def __call__(self, level_hw, device):
+        key = (tuple(level_hw), str(device))
+        if key not in self._cache:
+            per = []
+            for (h, w), s, sz in zip(level_hw, self.strides, self.sizes):
+                sx = torch.arange(0, w * s, step=s, dtype=torch.float32)
+                sy = torch.arange(0, h * s, step=s, dtype=torch.float32)
+                yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+                shifts = torch.stack((xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)), dim=1)
+                per.append((shifts.view(-1, 1, 4) + self.cell(sz).view(1, -1, 4)).reshape(-1, 4))
+            self._cache[key] = [p.to(device) for p in per]
+        return self._cache[key]
+
+
+@PROPOSAL_GENERATOR_REGISTRY.register()
+class PseudoLabRPN:
+    def __init__(self, cfg, store, in_channels, prefix="proposal_generator"):
+        r = cfg.MODEL.RPN
+        self.in_features = list(r.IN_FEATURES)
+        self.strides = [2 ** int(f[1:]) for f in self.in_features]
+        self.anchor_generator = AnchorGenerator(cfg, self.strides)
+        A = self.anchor_generator.A
+        assert A == 3
+        self.A = A
+        C = in_channels
+        w = store.new((C, 9 * C), "decay", lambda t: t.normal_(0.0, 0.01)).export(prefix + ".rpn_head.conv.weight", _nchw_view(C, C, 3))
+        b = store.new((C,), "decay", lambda t: t.zero_()).export(prefix + ".rpn_head.conv.bias")
+        self.conv = ops.Conv(w, C, C, 3, 1, 1, bias=b, relu=True)
+
+        def init_pred(t):
+            t.zero_()
+            t[:A + 4 * A].normal_(0.0, 0.01)
+        wp = store.new((RPN_CH, C), "decay", init_pred)
+        wp.export(prefix + ".rpn_head.objectness_logits.weight", lambda t: t[0:A].view(A, 1, 1, C).permute(0, 3, 1, 2))
+        wp.export(prefix + ".rpn_head.anchor_deltas.weight", lambda t: t[A:5 * A].view(4 * A, 1, 1, C).permute(0, 3, 1, 2))
+        bp = store.new((RPN_CH,), "decay", lambda t: t.zero_())
+        bp.export(prefix + ".rpn_head.objectness_logits.bias", lambda t: t[0:A])
+        bp.export(prefix + ".rpn_head.anchor_deltas.bias", lambda t: t[A:5 * A])
+        self.pred = ops.Conv(wp, C, RPN_CH, 1, 1, 0, bias=bp)
+        self.batch_size_per_image = r.BATCH_SIZE_PER_IMAGE
+        self.positive_fraction = r.POSITIVE_FRACTION
+        self.iou_thresholds = list(r.IOU_THRESHOLDS)
+        self.pre_nms_topk = {True: r.PRE_NMS_TOPK_TRAIN, False: r.PRE_NMS_TOPK_TEST}
+        self.post_nms_topk = {True: r.POST_NMS_TOPK_TRAIN, False: r.POST_NMS_TOPK_TEST}
+        self.nms_thresh = r.NMS_THRESH
+        self.min_box_size = cfg.MODEL.PROPOSAL_GENERATOR.MIN_SIZE
+        self.loss_weight = {"loss_rpn_cls": r.LOSS_WEIGHT, "loss_rpn_loc": r.BBOX_REG_LOSS_WEIGHT * r.LOSS_WEIGHT}
+        self.box_weights = tuple(r.BBOX_REG_WEIGHTS)
+        assert r.BOUNDARY_THRESH < 0 and r.BBOX_REG_LOSS_TYPE == "smooth_l1" and r.SMOOTH_L1_BETA == 0.0
+        self.training = True
+        self.sample_keys = None  # tests inject [N, R] keys in [0,1)
+
+    def train(self, mode=True):
+        self.training = mode
+
+    # -- head: all levels into one level-first [P,16] buffer ---------------------------------------------
+    def _head(self, feats):
+        N = feats[0].shape[0]
+        hw = [(f.shape[1], f.shape[2]) for f in feats]
+        P = N * sum(h * w for h, w in hw)
+        big = torch.empty((P, RPN_CH), dtype=torch.float32, device=feats[0].device)
+        rows, outs = [], []
+        r = 0
+        for f, (h, w) in zip(feats, hw):
+            r1 = r + N * h * w
+            outs.append(self.pred(self.conv(f), out=big[r:r1].view(N, h, w, RPN_CH)))
+            rows.append((r, r1, (N, h, w, RPN_CH)))
+            r = r1
+        return big, rows, outs, hw
+
+    def _per_image_views(self, big, N, hw):
+        """objectness [N, R] and deltas [N, R, 4] in the reference's (level, h, w, a) anchor order."""
+        A = self.A
+        obj, dl = [], []
+        r = 0
+        for (h, w) in hw:
+            blk = big[r:r + N * h * w].view(N, h * w, RPN_CH)
+            obj.append(blk[:, :, :A].reshape(N, -1))
+            dl.append(blk[:, :, A:5 * A].reshape(N, h * w * A, 4))
+            r += N * h * w
+        return obj, dl
+
+    def forward(self, image_sizes, features, gt=None, compute_loss=True, compute_val_loss=False):
+        feats = [features[f] for f in self.in_features]
+        big, rows, outs, hw = self._head(feats)
+        N = feats[0].shape[0]
+        anchors = self.anchor_generator(hw, big.device)
+        losses = {}
+        if (self.training and compute_loss) or compute_val_loss:
+            bigt = ops.assemble(big, rows, outs) if torch.is_grad_enabled() else big
+            obj, dl = self._per_image_views(bigt, N, hw)
+            losses = self.losses(torch.cat(anchors), torch.cat(obj, 1), torch.cat(dl, 1), gt)
+            losses = {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}  # applied twice
+        with torch.no_grad():
+            obj, dl = self._per_image_views(big.detach(), N, hw)
+            proposals = self.predict_proposals(anchors, obj, dl, image_sizes)
+        return proposals, losses
+
+    __call__ = forward
+
+    # -- labels + sampling (rpn.py:78-150 and D2 label_and_sample_anchors) -----------------------------------
+    @torch.no_grad()
+    def label_and_sample(self, anchors, gt):
+        N = gt.n
+        R = anchors.shape[0]
+        mx, arg, gmax = hip.match_boxes(anchors, gt["boxes"], gt["valid"], want_gt_max=True)
+        lowq = hip.match_lowq(anchors, gt["boxes"], gt["valid"], gmax)
+        lo, hi = self.iou_thresholds
+        has_gt = gt["valid"].bool().any(dim=1, keepdim=True)
+        one = torch.ones((), dtype=torch.int8, device=anchors.device)
+        labels = torch.where(mx < lo, one * 0, one * -1)
+        labels = torch.where(mx >= hi, one, labels)
+        labels = torch.where(lowq.bool(), one, labels)   # allow_low_quality_matches
+        labels = torch.where(has_gt, labels, torch.zeros_like(labels))
+        keys = _keys(self.sample_keys, N, R, anchors.device)
+        npos_max = int(self.batch_size_per_image * self.positive_fraction)
+        pidx, pval = sample_k_smallest(keys, labels == 1, npos_max)
+        npos = pval.sum(1, keepdim=True)
+        nidx, nval = sample_k_smallest(keys, labels == 0, self.batch_size_per_image)
+        nval = nval & (torch.arange(nidx.shape[1], device=anchors.device)[None, :] < (self.batch_size_per_image - npos))
+        return dict(pos_idx=pidx, pos_valid=pval, neg_idx=nidx, neg_valid=nval, matched=arg.long(), has_gt=has_gt)
+
+    def losses(self, anchors, obj, deltas, gt):
+        """rpn.py:153-225: BCE(sum) over sampled anchors (optionally weighted by the matched pseudo-box score,
+        negatives too - SURVEY B4) + L1 on positives, both / (batch_size_per_image * N), weights applied here too."""
+        N = obj.shape[0]
+        s = self.label_and_sample(anchors, gt)
+        pseudo = "scores" in gt
+        idx = torch.cat((s["pos_idx"], s["neg_idx"]), dim=1)
+        valid = torch.cat((s["pos_valid"], s["neg_valid"]), dim=1)
+        target = torch.cat((torch.ones_like(s["pos_idx"]), torch.zeros_like(s["neg_idx"])), dim=1).float()
+        logit = torch.gather(obj, 1, idx)
+        w = valid.float()
+        if pseudo:
+            conf = torch.gather(gt["scores"], 1, torch.gather(s["matched"], 1, idx))
+            w = w * torch.where(s["has_gt"], conf, torch.zeros_like(conf))
+        cls = (F.binary_cross_entropy_with_logits(logit, target, reduction="none") * w).sum()
+        pa = anchors[s["pos_idx"]]
+        pg = torch.gather(gt["boxes"], 1, torch.gather(s["matched"], 1, s["pos_idx"])[:, :, None].expand(-1, -1, 4))
+        pv = s["pos_valid"] & s["has_gt"]
+        safe = torch.tensor([0.0, 0.0, 1.0, 1.0], device=pa.device)
+        pg = torch.where(pv[:, :, None], pg, safe)
+        pa_s = torch.where(pv[:, :, None], pa, safe)
+        tgt = rpn_get_deltas(pa_s, pg, self.box_weights)
+        pd = torch.gather(deltas, 1, s["pos_idx"][:, :, None].expand(-1, -1, 4))
+        loc = ((pd - tgt).abs() * pv[:, :, None].float()).sum()
+        norm = self.batch_size_per_image * N
+        out = {"loss_rpn_cls": cls / norm, "loss_rpn_loc": loc / norm}
+        self._last_sample = s
+        return {k: v * self.loss_weight.get(k, 1.0) for k, v in out.items()}
+
+    # -- proposals (D2 find_top_rpn_proposals) -----------------------------------------------------------
+    @torch.no_grad()
+    def predict_proposals(self, anchors, obj, deltas, image_sizes):
+        N = obj[0].shape[0]
+        dev = obj[0].device
+        pre, post = self.pre_nms_topk[self.training], self.post_nms_topk[self.training]
+        boxes, scores, lvls = [], [], []
+        for l, (a, o, d) in enumerate(zip(anchors, obj, deltas)):
+            k = min(pre, o.shape[1])
+            top = torch.topk(float_order_key(o), k, dim=1, sorted=True).values
+            idx = 4294967295 - (top & 4294967295)
+            sc = torch.gather(o, 1, idx)
+            bx = rpn_apply_deltas(torch.gather(d, 1, idx[:, :, None].expand(-1, -1, 4)), a[idx], self.box_weights)
+            boxes.append(bx); scores.append(sc)
+            lvls.append(torch.full((N, k), l, dtype=torch.int32, device=dev))
+        boxes, scores, lvls = torch.cat(boxes, 1), torch.cat(scores, 1), torch.cat(lvls, 1)
+        hwt = torch.tensor([[s[1], s[0], s[1], s[0]] for s in image_sizes], dtype=torch.float32, device=dev)[:, None, :]
+        finite = torch.isfinite(boxes).all(dim=2) & torch.isfinite(scores)
+        boxes = torch.minimum(boxes.clamp(min=0), hwt)
+        keep = finite & ((boxes[..., 2] - boxes[..., 0]) > self.min_box_size) & ((boxes[..., 3] - boxes[..., 1]) > self.min_box_size)
+        boxes = boxes.contiguous()
+        scores = torch.where(finite, scores, torch.zeros_like(scores)).contiguous()
+        kidx, cnt = hip.nms_batched(boxes, scores, lvls.contiguous(), keep.to(torch.uint8).contiguous(), self.nms_thresh,
+                                    class_aware=True, post_topk=-1, max_out=post)
+        ix = kidx.clamp(min=0).long()
+        valid = (torch.arange(post, device=dev)[None, :] < cnt[:, None]).to(torch.uint8)
+        return PaddedBoxes(image_sizes, boxes=torch.gather(boxes, 1, ix[:, :, None].expand(-1, -1, 4)).contiguous(),
+                           objectness_logits=torch.gather(scores, 1, ix).contiguous(), valid=valid, count=cnt)
+
+
+# ---------------------------------------------------------------------------------------------------
+class FastRCNNFocaltLossBoundaryVarOutputLayers:
+    """Predictor + losses + inference (reference fast_rcnn.py:715-1292)."""
+
+    def __init__(self, cfg, store, in_dim, prefix):
+        rh, bh = cfg.MODEL.ROI_HEADS, cfg.MODEL.ROI_BOX_HEAD
+        assert bh.CLS_AGNOSTIC_BBOX_REG, "shipped UTv2 configs are class-agnostic (…sup1_run0.yaml:18)"
+        self.num_classes = rh.NUM_CLASSES
+        K = self.num_classes
+        self.K = K
+
+        def init_pred(t):
+            t.zero_()
+            t[:K + 1].normal_(0.0, 0.01)
+            t[K + 1:K + 5].normal_(0.0, 0.001)
+            t[K + 5:K + 9].normal_(0.0, 0.0001)
+        w = store.new((PRED_CH, in_dim), "decay", init_pred)
+        w.export(prefix + ".cls_score.weight", lambda t: t[0:K + 1])
+        w.export(prefix + ".bbox_pred.weight", lambda t: t[K + 1:K + 5])
+        w.export(prefix + ".bbox_pred_std.weight", lambda t: t[K + 5:K + 9])
+        b = store.new((PRED_CH,), "decay", lambda t: t.zero_())
+        b.export(prefix + ".cls_score.bias", lambda t: t[0:K + 1])
+        b.export(prefix + ".bbox_pred.bias", lambda t: t[K + 1:K + 5])
+        b.export(prefix + ".bbox_pred_std.bias", lambda t: t[K + 5:K + 9])
+        self.linear = ops.Conv(w, in_dim, PRED_CH, 1, 1, 0, bias=b)
+        self.box2box_transform = Box2BoxXYXYTransform(tuple(bh.BBOX_REG_WEIGHTS))
+        self.smooth_l1_beta = bh.SMOOTH_L1_BETA
+        self.test_score_thresh = rh.SCORE_THRESH_TEST
+        self.test_nms_thresh = rh.NMS_THRESH_TEST
+        self.test_topk_per_image = cfg.TEST.DETECTIONS_PER_IMAGE
+        self.box_reg_loss_type = bh.BBOX_REG_LOSS_TYPE
+        self.box_pseudo_reg_loss_type = bh.BBOX_PSEUDO_REG_LOSS_TYPE
+        self.loss_weight = {"loss_box_reg": bh.BBOX_REG_LOSS_WEIGHT}
+        self.ts_better = cfg.SEMISUPNET.TS_BETTER
+        self.t_cert = cfg.SEMISUPNET.T_CERT
+        if self.box_reg_loss_type not in ("nlloss", "smooth_l1"):
+            raise ValueError("Invalid bbox reg loss type '{}'".format(self.box_reg_loss_type))
+        if self.box_pseudo_reg_loss_type not in ("tsbetter", "smooth_l1"):
+            raise ValueError("Invalid bbox pseudo reg loss type '{}'".format(self.box_pseudo_reg_loss_type))
+
+    def __call__(self, x2d):
+        y = self.linear(x2d.view(x2d.shape[0], 1, 1, -1)).view(x2d.shape[0], PRED_CH)
+        K = self.K
+        return y[:, :K + 1], y[:, K + 1:K + 5], y[:, K + 5:K + 9]
+
+    def losses(self, predictions, sampled, branch):
+        scores, deltas, std = predictions
+        cls = sampled["gt_classes"].reshape(-1)           # -1 = empty slot
+        Rn = (cls >= 0).sum().clamp(min=1).float()        # gt_classes.numel() of the reference
+        tgt = cls.to(torch.int32).contiguous()
+        loss_cls = ops.softmax_focal_sum(scores, tgt, 1.5)[0] / Rn
+        fg = (cls >= 0) & (cls < self.num_classes)
+        pb = sampled["proposal_boxes"].reshape(-1, 4)
+        gb = sampled["gt_boxes"].reshape(-1, 4)
+        safe = torch.tensor([0.0, 0.0, 1.0, 1.0], device=pb.device)
+        pb = torch.where(fg[:, None], pb, safe)
+        gb = torch.where(fg[:, None], gb, safe)
+        fgf = fg.float()
+        gt_d = self.box2box_transform.get_deltas(pb, gb)
+        if branch == "unsup_data_train":
+            if self.box_pseudo_reg_loss_type == "tsbetter":
+                gstd = sampled["gt_loc_std"].reshape(-1, 4) if "gt_loc_std" in sampled else torch.zeros_like(std)
+                ct = 1 - gstd.sigmoid()
+                cs = 1 - std.sigmoid()
+                sel = (ct > cs + self.ts_better) & (ct > self.t_cert) & fg[:, None]
+                box = ((deltas - gt_d).abs() * sel.float()).sum()
+            else:
+                box = ((deltas - gt_d).abs() * fgf[:, None]).sum()
+        else:
+            l1 = ((deltas - gt_d).abs() * fgf[:, None]).sum()
+            if self.box_reg_loss_type == "nlloss":
+                pred = self.box2box_transform.apply_deltas(deltas, pb)
+                a1 = (gb[:, 2] - gb[:, 0]) * (gb[:, 3] - gb[:, 1])
+                a2 = (pred[:, 2] - pred[:, 0]) * (pred[:, 3] - pred[:, 1])
+                lt = torch.max(gb[:, :2], pred[:, :2])
+                rb = torch.min(gb[:, 2:], pred[:, 2:])
+                wh = (rb - lt).clamp(min=0)
+                inter = wh[:, 0] * wh[:, 1]
+                iou = inter / (a1 + a2 - inter)            # fast_rcnn.py:20-44, gradient flows
+                iou = torch.where(fg, iou, torch.zeros_like(iou))
+                sig = std.sigmoid()
+                sq = sig * sig
+                nll = ((gt_d - deltas) ** 2 / (2 * sq) + 0.5 * torch.log(sq)).sum(1) + 2 * math.log(2 * math.pi)
+                box = l1 + 0.05 * (nll * iou * fgf).sum()
+            else:
+                box = l1
+        out = {"loss_cls": loss_cls, "loss_box_reg": box / Rn}
+        return {k: v * self.loss_weight.get(k, 1.0) for k, v in out.items()}
+
+    @torch.no_grad()
+    def inference(self, predictions, proposals, max_cand=8192):
+        """fast_rcnn.py:1094-1125 + D2 fast_rcnn_inference: softmax, score > thr, class-aware NMS, top-k."""
+        scores, deltas, std = predictions
+        N, P = proposals["valid"].shape
+        K = self.K
+        pb = proposals["boxes"]
+        boxes = self.box2box_transform.apply_deltas(deltas.view(N, P, 4), pb)
+        hwt = torch.tensor([[s[1], s[0], s[1], s[0]] for s in proposals.image_sizes], dtype=torch.float32, device=pb.device)[:, None, :]
+        probs = F.softmax(scores, dim=-1).view(N, P, K + 1)[:, :, :K]
+        ok = proposals["valid"].bool() & torch.isfinite(boxes).all(dim=2) & torch.isfinite(probs).all(dim=2)
+        boxes = torch.minimum(boxes.clamp(min=0), hwt)
+        cand = (probs > self.test_score_thresh) & ok[:, :, None]
+        flat = torch.where(cand, probs, torch.full_like(probs, -1.0)).reshape(N, P * K)
+        k = min(max_cand, P * K)
+        top = torch.topk(float_order_key(flat), k, dim=1, sorted=True).values
+        idx = 4294967295 - (top & 4294967295)
+        sc = torch.gather(flat, 1, idx)
+        r, c = idx // K, (idx % K).to(torch.int32)
+        cb = torch.gather(boxes, 1, r[:, :, None].expand(-1, -1, 4)).contiguous()
+        valid = (sc > self.test_score_thresh).to(torch.uint8)
+        D = self.test_topk_per_image
+        kidx, cnt = hip.nms_batched(cb, sc.contiguous(), c.contiguous(), valid.contiguous(), self.test_nms_thresh,
+                                    class_aware=True, post_topk=-1, max_out=D)
+        ix = kidx.clamp(min=0).long()
+        keep_rows = torch.gather(r, 1, ix)
+        out = PaddedBoxes(proposals.image_sizes,
+                          boxes=torch.gather(cb, 1, ix[:, :, None].expand(-1, -1, 4)).contiguous(),
+                          scores=torch.gather(sc, 1, ix).contiguous(),
+                          classes=torch.gather(c, 1, ix).contiguous(),
+                          pred_boxes_std=torch.gather(std.view(N, P, 4), 1, keep_rows[:, :, None].expand(-1, -1, 4)).contiguous(),
+                          valid=(torch.arange(D, device=pb.device)[None, :] < cnt[:, None]).to(torch.uint8), count=cnt)
+        return out, keep_rows
+
+
+@ROI_HEADS_REGISTRY.register()
+class StandardROIHeadsPseudoLab:
+    def __init__(self, cfg, store, in_channels, prefix="roi_heads"):
+        rh, bh = cfg.MODEL.ROI_HEADS, cfg.MODEL.ROI_BOX_HEAD
+        self.in_features = list(rh.IN_FEATURES)
+        self.scales = [1.0 / (2 ** int(f[1:])) for f in self.in_features]
+        self.min_level = int(self.in_features[0][1:])
+        self.res = bh.POOLER_RESOLUTION
+        assert bh.POOLER_TYPE == "ROIAlignV2" and bh.POOLER_SAMPLING_RATIO == 0 and bh.NUM_CONV == 0
+        self.num_classes = rh.NUM_CLASSES
+        self.batch_size_per_image = rh.BATCH_SIZE_PER_IMAGE
+        self.positive_fraction = rh.POSITIVE_FRACTION
+        self.iou_threshold = rh.IOU_THRESHOLDS[0]
+        self.proposal_append_gt = rh.PROPOSAL_APPEND_GT
+        C, S, FC = in_channels, self.res, bh.FC_DIM
+        self.fcs = []
+        dim_in = C * S * S
+        for i in range(bh.NUM_FC):
+            p = "%s.box_head.fc%d" % (prefix, i + 1)
+            if i == 0:  # weight stored [FC][S][S][C]: consumes the NHWC RoIAlign output as is
+                w = store.new((FC, dim_in), "decay", _xavier_init(FC, dim_in, 1))
+                w.export(p + ".weight", lambda t, FC=FC, S=S, C=C: t.view(FC, S, S, C).permute(0, 3, 1, 2).reshape(FC, -1),
+                         load=lambda t, src, FC=FC, S=S, C=C: t.view(FC, S, S, C).copy_(src.view(FC, C, S, S).permute(0, 2, 3, 1)))
+            else:
+                w = store.new((FC, dim_in), "decay", _xavier_init(FC, dim_in, 1)).export(p + ".weight")
+            b = store.new((FC,), "decay", lambda t: t.zero_()).export(p + ".bias")
+            self.fcs.append(ops.Conv(w, dim_in, FC, 1, 1, 0, bias=b, relu=True))
+            dim_in = FC
+        if rh.LOSS != "FocalLoss_BoundaryVar":
+            raise ValueError("Unknown ROI head loss.")  # other predictors: SURVEY 8(f) rank 4
+        self.box_predictor = FastRCNNFocaltLossBoundaryVarOutputLayers(cfg, store, dim_in, prefix + ".box_predictor")
+        self.training = True
+        self.sample_keys = None
+
+    def train(self, mode=True):
+        self.training = mode
+
+    @torch.no_grad()
+    def label_and_sample_proposals(self, proposals, gt, branch=""):
+        """roi_heads.py:141-270 (+ D2 add_ground_truth_to_proposals, Matcher(0.5), subsample 512 @ 25 % fg)."""
+        pb, pv = proposals["boxes"], proposals["valid"].bool()
+        if self.proposal_append_gt:
+            pb = torch.cat((pb, gt["boxes"]), dim=1).contiguous()
+            pv = torch.cat((pv, gt["valid"].bool()), dim=1)
+        N, P = pv.shape
+        mx, arg, _ = hip.match_boxes(pb, gt["boxes"], gt["valid"])
+        arg = arg.long()
+        has_gt = gt["valid"].bool().any(dim=1, keepdim=True)
+        fgm = (mx >= self.iou_threshold) & has_gt
+        cls = torch.where(fgm, torch.gather(gt["classes"].long(), 1, arg), torch.full_like(arg, self.num_classes))
+        keys = _keys(self.sample_keys, N, P, pb.device)
+        nfg_max = int(self.batch_size_per_image * self.positive_fraction)
+        fidx, fval = sample_k_smallest(keys, pv & (cls != self.num_classes), nfg_max)
+        nfg = fval.sum(1, keepdim=True)
+        bidx, bval = sample_k_smallest(keys, pv & (cls == self.num_classes), self.batch_size_per_image)
+        bval = bval & (torch.arange(bidx.shape[1], device=pb.device)[None, :] < (self.batch_size_per_image - nfg))
+        idx = torch.cat((fidx, bidx), dim=1)
+        val = torch.cat((fval, bval), dim=1)
+        order = torch.argsort((~val).to(torch.int8), dim=1, stable=True)[:, :self.batch_size_per_image]
+        idx, val = torch.gather(idx, 1, order), torch.gather(val, 1, order)
+        g = torch.gather(arg, 1, idx)
+        hg = has_gt.expand_as(val)
+        out = dict(proposal_boxes=torch.gather(pb, 1, idx[:, :, None].expand(-1, -1, 4)).contiguous(),
+                   gt_classes=torch.where(val, torch.gather(cls, 1, idx), torch.full_like(idx, -1)),
+                   gt_boxes=torch.where((val & hg)[:, :, None], torch.gather(gt["boxes"], 1, g[:, :, None].expand(-1, -1, 4)),
+                                        torch.zeros((), device=pb.device)),
+                   valid=val.to(torch.uint8).contiguous(), sampled_idx=idx)
+        if "scores" in gt:
+            out["gt_confid"] = torch.where(val & hg, torch.gather(gt["scores"], 1, g), torch.zeros((), device=pb.device))
+            if "pred_boxes_std" in gt:
+                out["gt_loc_std"] = torch.where((val & hg)[:, :, None], torch.gather(gt["pred_boxes_std"], 1, g[:, :, None].expand(-1, -1, 4)),
+                                                torch.zeros((), device=pb.device))
+        return out
+
+    def _box_features(self, feats, boxes, valid):
+        N, P = valid.shape
+        rois = boxes.reshape(-1, 4).contiguous()
+        batch = torch.arange(N, device=rois.device, dtype=torch.int32)[:, None].expand(N, P).reshape(-1).contiguous()
+        x = ops.roi_align(feats, self.scales, self.min_level, rois, batch, valid.reshape(-1).contiguous(), self.res)
+        x = x.view(x.shape[0], 1, 1, -1)
+        for fc in self.fcs:
+            x = fc(x)
+        return x.view(x.shape[0], -1)
+
+    def forward(self, features, proposals, targets=None, compute_loss=True, branch=""):
+        feats = [features[f] for f in self.in_features]
+        if self.training and compute_loss:
+            assert targets is not None
+            sampled = self.label_and_sample_proposals(proposals, targets, branch)
+            self._last_sampled = sampled
+            x = self._box_features(feats, sampled["proposal_boxes"], sampled["valid"])
+            predictions = self.box_predictor(x)
+            return sampled, self.box_predictor.losses(predictions, sampled, branch)
+        x = self._box_features(feats, proposals["boxes"], proposals["valid"])
+        predictions = self.box_predictor(x)
+        pred_instances, _ = self.box_predictor.inference(predictions, proposals)
+        return pred_instances, predictions
+
+    __call__ = forward
+
+
+@META_ARCH_REGISTRY.register()
+class TwoStagePseudoLabGeneralizedRCNN(ArenaModel):
+    """reference meta_arch/rcnn.py:6-72: forward(batched_inputs, branch, given_proposals, val_mode) -> 4-tuple."""
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.backbone = BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg, self.store, self.folder)
+        self.proposal_generator = PROPOSAL_GENERATOR_REGISTRY.get(cfg.MODEL.PROPOSAL_GENERATOR.NAME)(
+            cfg, self.store, self.backbone.out_channels)
+        self.roi_heads = ROI_HEADS_REGISTRY.get(cfg.MODEL.ROI_HEADS.NAME)(cfg, self.store, self.backbone.out_channels)
+        # D2 GeneralizedRCNN registers pixel_mean/std as NON-persistent buffers: not in state_dict
+        self._mean_host, self._std_host = list(cfg.MODEL.PIXEL_MEAN), list(cfg.MODEL.PIXEL_STD)
+        self._finalize()
+
+    def _children(self):
+        return [self.proposal_generator, self.roi_heads]
+
+    def _gt(self, batched_inputs):
+        first = batched_inputs[0]["instances"]
+        if isinstance(first, PaddedBoxes):
+            return first
+        insts = [x["instances"] for x in batched_inputs]
+        gt = PaddedBoxes.from_instances(insts, self.device)
+        if len(insts) and insts[0].has("scores"):
+            M = gt["valid"].shape[1]
+            sc = torch.zeros((len(insts), M)); st = torch.zeros((len(insts), M, 4))
+            for i, x in enumerate(insts):
+                sc[i, :len(x)] = x.scores.detach().float().cpu()
+                if x.has("pred_boxes_std"):
+                    st[i, :len(x)] = x.pred_boxes_std.detach().float().cpu()
+            gt.f["scores"] = sc.to(self.device)
+            if insts[0].has("pred_boxes_std"):
+                gt.f["pred_boxes_std"] = st.to(self.device)
+        return gt
+
+    def forward(self, batched_inputs, branch="supervised", given_proposals=None, val_mode=False):
+        if (not self.training) and (not val_mode):
+            return self.inference(batched_inputs)
+        images = [x["image"].to(self.device) for x in batched_inputs]
+        x4, image_sizes = hip.preprocess_images(images, self._mean_host, self._std_host, self.backbone.size_divisibility)
+        gt = self._gt(batched_inputs) if "instances" in batched_inputs[0] else None
+        self.folder.fold()
+        features = self.backbone(x4)
+        if branch in ("supervised", "unsup_data_train"):
+            proposals_rpn, proposal_losses = self.proposal_generator(image_sizes, features, gt)
+            _, detector_losses = self.roi_heads(features, proposals_rpn, gt, branch=branch)
+            losses = {}
+            losses.update(detector_losses)
+            losses.update(proposal_losses)
+            return losses, [], [], None
+        elif branch == "unsup_data_weak":
+            proposals_rpn, _ = self.proposal_generator(image_sizes, features, None, compute_loss=False)
+            proposals_roih, roi_predictions = self.roi_heads(features, proposals_rpn, targets=None, compute_loss=False, branch=branch)
+            return {}, proposals_rpn, proposals_roih, roi_predictions
+        raise ValueError("Unknown branch: {}".format(branch))
+
+    __call__ = forward
+
+    @torch.no_grad()
+    def inference(self, batched_inputs):
+        images = [x["image"].to(self.device) for x in batched_inputs]
+        x4, image_sizes = hip.preprocess_images(images, self._mean_host, self._std_host, self.backbone.size_divisibility)
+        self.folder.fold()
+        features = self.backbone(x4)
+        proposals, _ = self.proposal_generator(image_sizes, features, None, compute_loss=False)
+        dets, _ = self.roi_heads(features, proposals, targets=None, compute_loss=False)
+        from .one_stage_detector import detector_postprocess
+        out = []
+        for inst, inp, size in zip(_dets_to_instances(dets), batched_inputs, image_sizes):
+            out.append({"instances": detector_postprocess(inst, inp.get("height", size[0]), inp.get("width", size[1]))})
+        return out
+
+
+def _dets_to_instances(dets):
+    res = []
+    for i in range(dets.n):
+        m = dets["valid"][i].bool()
+        inst = Instances(dets.image_sizes[i])
+        inst.pred_boxes = Boxes(dets["boxes"][i][m])
+        inst.scores = dets["scores"][i][m]
+        inst.pred_classes = dets["classes"][i][m].long()
+        if "pred_boxes_std" in dets:
+            inst.pred_boxes_std = dets["pred_boxes_std"][i][m]
+        res.append(inst)
+    return res

@@ -218,3 +218,65 @@ class _LocTermsFn(torch.autograd.Function):
 
 def fcos_loc_terms(big, labels, reg_targets, bvars, args, rows, levels):
     return _LocTermsFn.apply(big, labels, reg_targets, bvars, args, rows, *levels)
+
+
+# ------------------------------------------------------------------------------------------------
+# Faster-RCNN helpers
+class _AssembleFn(torch.autograd.Function):
+    """Makes the level-first buffer the convs wrote into (`big`) visible to autograd as one tensor:
+    output aliases `big`; backward hands each level its row range of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, big_holder, rows, *levels):
+        ctx.rows = rows
+        return big_holder[0].view(big_holder[0].shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return (None, None) + tuple(g[r0:r1].view(shape) for (r0, r1, shape) in ctx.rows)
+
+
+def assemble(big, rows, levels):
+    return _AssembleFn.apply((big,), rows, *levels)
+
+
+class _RoIAlignFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rois, roi_batch, roi_valid, cfg, *feats):
+        scales, min_level, out_size = cfg
+        ctx.cfg = cfg
+        ctx.shapes = [tuple(f.shape) for f in feats]
+        ctx.save_for_backward(rois, roi_batch, roi_valid)
+        return hip.roi_align_fwd([f.detach() for f in feats], scales, min_level, rois, roi_batch, roi_valid, out_size)
+
+    @staticmethod
+    def backward(ctx, dy):
+        rois, roi_batch, roi_valid = ctx.saved_tensors
+        scales, min_level, out_size = ctx.cfg
+        dfeats = [torch.zeros(s, dtype=torch.float32, device=dy.device) for s in ctx.shapes]
+        hip.roi_align_bwd(dfeats, scales, min_level, rois, roi_batch, roi_valid, dy.contiguous())
+        return (None, None, None, None) + tuple(dfeats)
+
+
+def roi_align(feats, scales, min_level, rois, roi_batch, roi_valid, out_size):
+    if torch.is_grad_enabled() and any(f.requires_grad for f in feats):
+        return _RoIAlignFn.apply(rois, roi_batch, roi_valid, (tuple(scales), min_level, out_size), *feats)
+    return hip.roi_align_fwd(list(feats), scales, min_level, rois, roi_batch, roi_valid, out_size)
+
+
+class _SoftmaxFocalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, gamma):
+        ctx.gamma = gamma
+        ctx.save_for_backward(logits, target)
+        return hip.softmax_focal_fwd(logits.contiguous(), target, gamma)
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target = ctx.saved_tensors
+        return hip.softmax_focal_bwd(logits.contiguous(), target, ctx.gamma, g.reshape(1).contiguous().float()), None, None
+
+
+def softmax_focal_sum(logits, target, gamma):
+    return _SoftmaxFocalFn.apply(logits, target, gamma)

@@ -22,7 +22,7 @@ _ORDER = ("decay", "nodecay", "frozen", "bn_w", "bn_b", "buffer", "bn_m", "bn_v"
 
 
 class Handle:
-    __slots__ = ("shape", "kind", "init", "numel", "offset", "t", "g", "exports")
+    __slots__ = ("shape", "kind", "init", "numel", "offset", "t", "g", "exports", "loaders")
 
     def __init__(self, shape, kind, init):
         self.shape = tuple(int(s) for s in shape)
@@ -36,9 +36,14 @@ class Handle:
         self.t = None  # view into the state arena
         self.g = None  # view into the grad arena (trainable only)
         self.exports = []  # (state_dict key, fn(view)->tensor view)
+        self.loaders = {}
 
-    def export(self, key, fn=None):
+    def export(self, key, fn=None, load=None):
+        """fn(view) -> tensor exposed under `key`; load(view, src) copies a checkpoint tensor back when the
+        exposed tensor is not a writable view (e.g. a re-ordered copy)."""
         self.exports.append((key, fn))
+        if load is not None:
+            self.loaders[key] = load
         return self
 
 
@@ -113,11 +118,19 @@ class ParamStore:
         unexpected = [k for k in sd if k not in mine]
         if strict and (missing or unexpected):
             raise RuntimeError("load_state_dict: missing %s unexpected %s" % (missing[:5], unexpected[:5]))
+        loaders = {}
+        for h in self.handles:
+            for k, fn in h.loaders.items():
+                loaders[k] = (h, fn)
         with torch.no_grad():
             for k, v in mine.items():
                 if k in sd:
                     src = sd[k]
                     if tuple(src.shape) != tuple(v.shape):
                         raise RuntimeError("size mismatch for %s: %s vs %s" % (k, tuple(src.shape), tuple(v.shape)))
-                    v.copy_(src.to(device=v.device, dtype=v.dtype))
+                    src = src.to(device=v.device, dtype=v.dtype)
+                    if k in loaders:
+                        loaders[k][1](loaders[k][0].t, src)
+                    else:
+                        v.copy_(src)
         return missing, unexpected
