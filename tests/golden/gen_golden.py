@@ -78,6 +78,24 @@ def install_shims():
         m = _Stub(n)
         m.__path__ = []
         mods[n] = m
+    class _Reg:
+        def register(self, obj=None):
+            return (lambda o: o) if obj is None else obj
+    mods["detectron2.config"].configurable = lambda f=None, **kw: f if f is not None else (lambda g: g)
+    mods["detectron2.modeling.roi_heads"].ROI_HEADS_REGISTRY = _Reg()
+    mods["detectron2.modeling.proposal_generator.build"].PROPOSAL_GENERATOR_REGISTRY = _Reg()
+    mods["detectron2.modeling.meta_arch.build"].META_ARCH_REGISTRY = _Reg()
+    mods["detectron2.modeling.roi_heads.fast_rcnn"].FastRCNNOutputLayers = torch.nn.Module
+    mods["detectron2.modeling.roi_heads.fast_rcnn"]._log_classification_stats = lambda *a, **k: None
+    mods["detectron2.modeling.roi_heads.fast_rcnn"].fast_rcnn_inference = _d2_fast_rcnn_inference
+    mods["detectron2.modeling.box_regression"]._dense_box_regression_loss = _d2_dense_box_regression_loss
+    mods["detectron2.modeling.proposal_generator.proposal_utils"].add_ground_truth_to_proposals = _d2_add_gt(structures)
+    mods["detectron2.utils.memory"].retry_if_cuda_oom = lambda f: f
+
+    class _Storage:
+        def put_scalar(self, *a, **k):
+            pass
+    mods["detectron2.utils.events"].get_event_storage = lambda: _Storage()
     fv = _Stub("fvcore")
     fv.__path__ = []
     fvnn = _Stub("fvcore.nn")
@@ -113,7 +131,42 @@ def install_shims():
     pg = _load("ubteacher.modeling.pseudo_generator", REF + "/ubteacher/modeling/pseudo_generator.py")
     _load("ubteacher.modeling.meta_arch.ts_ensemble", REF + "/ubteacher/modeling/meta_arch/ts_ensemble.py")
     tr = _load("ubteacher.engine.trainer", REF + "/ubteacher/engine/trainer.py")
+    sys.modules["ubteacher.modeling.roi_heads"] = types.ModuleType("ubteacher.modeling.roi_heads")
+    sys.modules["ubteacher.modeling.roi_heads"].__path__ = [REF + "/ubteacher/modeling/roi_heads"]
+    sys.modules["ubteacher.modeling.proposal_generator"] = types.ModuleType("ubteacher.modeling.proposal_generator")
+    sys.modules["ubteacher.modeling.proposal_generator"].__path__ = [REF + "/ubteacher/modeling/proposal_generator"]
     return structures, fo, pg, tr
+
+
+def _d2_fast_rcnn_inference(boxes, scores, image_shapes, score_thresh, nms_thresh, topk_per_image):
+    """stand-in for D2 fast_rcnn_inference built on the oracle's restatement"""
+    structures = sys.modules["_utv2_structs"]
+    res, kept = [], []
+    for b, s, shp in zip(boxes, scores, image_shapes):
+        d, rows = O.fast_rcnn_inference(b, s, shp, score_thresh, nms_thresh, topk_per_image)
+        inst = structures.Instances(shp)
+        inst.pred_boxes = structures.Boxes(d["boxes"]); inst.scores = d["scores"]; inst.pred_classes = d["classes"]
+        res.append(inst); kept.append(rows)
+    return res, kept
+
+
+def _d2_dense_box_regression_loss(anchors, box2box_transform, pred_anchor_deltas, gt_boxes, fg_mask, box_reg_loss_type="smooth_l1", smooth_l1_beta=0.0):
+    """D2 _dense_box_regression_loss (smooth_l1 branch) [D2-recall]"""
+    a = type(anchors[0]).cat(anchors).tensor
+    gt = torch.stack([O.rpn_get_deltas(a, k) for k in gt_boxes])
+    return _fv_smooth_l1(torch.cat(pred_anchor_deltas, dim=1)[fg_mask], gt[fg_mask], smooth_l1_beta, reduction="sum")
+
+
+def _d2_add_gt(structures):
+    def add(gt_boxes, proposals):
+        out = []
+        for g, p in zip(gt_boxes, proposals):
+            n = structures.Instances(p.image_size)
+            n.proposal_boxes = structures.Boxes.cat([p.proposal_boxes, g])
+            n.objectness_logits = torch.cat([p.objectness_logits, torch.full((len(g),), 23.025850929940457)])
+            out.append(n)
+        return out
+    return add
 
 
 def _fv_smooth_l1(input, target, beta, reduction="none"):
@@ -324,8 +377,130 @@ def gen_ema(tr):
     print("ema.npz:", len(d), "arrays")
 
 
+def gen_rcnn(structures):
+    br = _load("ubteacher.modeling.box_regression", REF + "/ubteacher/modeling/box_regression.py")
+    fr = _load("ubteacher.modeling.roi_heads.fast_rcnn", REF + "/ubteacher/modeling/roi_heads/fast_rcnn.py")
+    rh = _load("ubteacher.modeling.roi_heads.roi_heads", REF + "/ubteacher/modeling/roi_heads/roi_heads.py")
+    rp = _load("ubteacher.modeling.proposal_generator.rpn", REF + "/ubteacher/modeling/proposal_generator/rpn.py")
+    g = torch.Generator().manual_seed(77)
+    d = {}
+    Boxes, Instances = structures.Boxes, structures.Instances
+    # ---- Box2BoxXYXYTransform -----------------------------------------------------------------
+    tf = br.Box2BoxXYXYTransform(weights=(10.0, 10.0, 5.0, 5.0))
+    n = 50
+    xy = torch.rand(n, 2, generator=g) * 200
+    src = torch.cat([xy, xy + torch.rand(n, 2, generator=g) * 100 + 1], 1)
+    xy2 = torch.rand(n, 2, generator=g) * 200
+    tgt = torch.cat([xy2, xy2 + torch.rand(n, 2, generator=g) * 100 + 1], 1)
+    dl = torch.randn(n, 4, generator=g) * 3
+    dl[0] = torch.tensor([900.0, -900.0, 400.0, -400.0])  # exercises the +-62.5 clamp
+    d["bx_src"], d["bx_tgt"], d["bx_deltas"] = npy(src), npy(tgt), npy(dl)
+    d["bx_get"] = npy(tf.get_deltas(src, tgt)); d["bx_apply"] = npy(tf.apply_deltas(dl, src))
+    # ---- FastRCNNFocaltLossBoundaryVarOutputLayers.losses ------------------------------------------
+    cls_ = fr.FastRCNNFocaltLossBoundaryVarOutputLayers
+    duck = types.SimpleNamespace(num_classes=80, box2box_transform=tf, smooth_l1_beta=0.0, box_reg_loss_type="nlloss",
+                                 box_pseudo_reg_loss_type="tsbetter", loss_weight={"loss_box_reg": 1.0}, ts_better=0.1, t_cert=0.5)
+    for name in ("comput_focal_loss", "box_reg_loss", "box_reg_pseudo_loss"):
+        setattr(duck, name, types.MethodType(getattr(cls_, name), duck))
+    R = 60
+    gt_classes = torch.randint(0, 81, (R,), generator=g)
+    gt_classes[: R // 2] = 80
+    gt_classes[-5:] = torch.tensor([3, 7, 7, 12, 0])
+    pxy = torch.rand(R, 2, generator=g) * 150
+    prop = torch.cat([pxy, pxy + torch.rand(R, 2, generator=g) * 80 + 4], 1)
+    gtb = prop + torch.randn(R, 4, generator=g) * 4
+    gstd = torch.randn(R, 4, generator=g) * 2 - 1.0
+    inst = Instances((300, 300))
+    inst.proposal_boxes = Boxes(prop); inst.gt_boxes = Boxes(gtb); inst.gt_classes = gt_classes; inst.gt_loc_std = gstd
+    d.update(rc_prop=npy(prop), rc_gtb=npy(gtb), rc_cls=npy(gt_classes), rc_gstd=npy(gstd))
+    for branch in ("supervised", "unsup_data_train"):
+        scores = (torch.randn(R, 81, generator=g) * 2).requires_grad_(True)
+        deltas = (torch.randn(R, 4, generator=g) * 0.5).requires_grad_(True)
+        std = (torch.randn(R, 4, generator=g) * 1.5).requires_grad_(True)
+        if branch == "unsup_data_train":
+            std = (std.detach() + 1.0).requires_grad_(True)
+        ls = cls_.losses(duck, (scores, deltas, std), [inst], branch)
+        (ls["loss_cls"] + 2.0 * ls["loss_box_reg"]).backward()
+        for k, v in (("scores", scores), ("deltas", deltas), ("std", std)):
+            d["rc_%s_%s" % (branch, k)] = npy(v)
+            d["rc_%s_g%s" % (branch, k)] = npy(v.grad if v.grad is not None else torch.zeros_like(v))
+        d["rc_%s_loss_cls" % branch] = npy(ls["loss_cls"]); d["rc_%s_loss_box_reg" % branch] = npy(ls["loss_box_reg"])
+    # ---- inference (predict_boxes / probs + D2 fast_rcnn_inference stand-in + pred_boxes_std gather) -----------
+    for name in ("predict_boxes", "predict_boxes_std", "predict_probs"):
+        setattr(duck, name, types.MethodType(getattr(cls_, name), duck))
+    duck.test_score_thresh, duck.test_nms_thresh, duck.test_topk_per_image = 0.05, 0.5, 100
+    pi = Instances((300, 300)); pi.proposal_boxes = Boxes(prop)
+    sc = torch.randn(R, 81, generator=g) * 3; de = torch.randn(R, 4, generator=g) * 2; sd_ = torch.randn(R, 4, generator=g)
+    res, keep = cls_.inference(duck, (sc, de, sd_), [pi])
+    d.update(inf_scores=npy(sc), inf_deltas=npy(de), inf_std=npy(sd_), inf_boxes=npy(res[0].pred_boxes.tensor),
+             inf_sc=npy(res[0].scores), inf_cls=npy(res[0].pred_classes), inf_bstd=npy(res[0].pred_boxes_std), inf_keep=npy(keep[0]))
+    # ---- PseudoLabRPN: label_and_sample_anchors_pseudo + losses (weights on all valid anchors) ----
+    hw = [(6, 8), (3, 4)]
+    anchors = O.make_anchors(hw, [16, 32], sizes=(32, 64))
+    A = torch.cat(anchors)
+    Rn = A.shape[0]
+    keys = torch.rand(2, Rn, generator=g)
+    kit = iter([keys[0], keys[1]])
+
+    def sub(labels):
+        k = next(kit)
+        pos, neg = O.subsample_by_keys(labels, k, 16, 0.25, 0)
+        labels.fill_(-1); labels.scatter_(0, pos, 1); labels.scatter_(0, neg, 0)
+        return labels
+    rduck = types.SimpleNamespace(anchor_matcher=lambda m: O.matcher(m, [0.3, 0.7], [0, -1, 1], True), anchor_boundary_thresh=-1,
+                                  _subsample_labels=sub, box2box_transform=None, box_reg_loss_type="smooth_l1", smooth_l1_beta=0.0,
+                                  batch_size_per_image=16, loss_weight={"loss_rpn_cls": 1.0, "loss_rpn_loc": 1.0})
+    gi = []
+    for i in range(2):
+        G = 3 if i == 0 else 0
+        c = torch.rand(G, 2, generator=g) * torch.tensor([100.0, 70.0])
+        b = torch.cat([c, c + torch.rand(G, 2, generator=g) * 60 + 10], 1)
+        x = Instances((96, 128)); x.gt_boxes = Boxes(b); x.scores = torch.rand(G, generator=g) * 0.3 + 0.7
+        gi.append(x)
+        d["rpn_gt%d" % i] = npy(b); d["rpn_sc%d" % i] = npy(x.scores)
+    labs, mboxes, confs = rp.PseudoLabRPN.label_and_sample_anchors_pseudo(rduck, [Boxes(a) for a in anchors], gi)
+    obj = [(torch.randn(2, a.shape[0], generator=g)).requires_grad_(True) for a in anchors]
+    dls = [(torch.randn(2, a.shape[0], 4, generator=g) * 0.3).requires_grad_(True) for a in anchors]
+    ls = rp.PseudoLabRPN.losses(rduck, [Boxes(a) for a in anchors], obj, labs, dls, mboxes, confs)
+    (ls["loss_rpn_cls"] + ls["loss_rpn_loc"]).backward()
+    d.update(rpn_keys=npy(keys), rpn_labels=npy(torch.stack(labs)), rpn_conf=npy(torch.stack(confs).float()),
+             rpn_loss_cls=npy(ls["loss_rpn_cls"]), rpn_loss_loc=npy(ls["loss_rpn_loc"]))
+    for l in range(2):
+        d["rpn_obj%d" % l], d["rpn_dl%d" % l] = npy(obj[l]), npy(dls[l])
+        d["rpn_gobj%d" % l], d["rpn_gdl%d" % l] = npy(obj[l].grad), npy(dls[l].grad)
+    # ---- StandardROIHeadsPseudoLab.label_and_sample_proposals_pseudo ---------------------------------------
+    P = 40
+    pc = torch.rand(P, 2, generator=g) * 200
+    pbx = torch.cat([pc, pc + torch.rand(P, 2, generator=g) * 80 + 5], 1)
+    G = 4
+    gb = pbx[:G] + torch.randn(G, 4, generator=g) * 3
+    t = Instances((300, 300)); t.gt_boxes = Boxes(gb); t.gt_classes = torch.randint(0, 80, (G,), generator=g)
+    t.scores = torch.rand(G, generator=g); t.pred_boxes_std = torch.randn(G, 4, generator=g)
+    pr = Instances((300, 300)); pr.proposal_boxes = Boxes(pbx); pr.objectness_logits = torch.randn(P, generator=g)
+    rkeys = torch.rand(P + G, generator=g)
+
+    def samp(matched_idxs, matched_labels, gt_classes):
+        cls = gt_classes[matched_idxs].clone()
+        cls[matched_labels == 0] = 80
+        fgi, bgi = O.subsample_by_keys(cls, rkeys, 16, 0.25, 80)
+        s = torch.cat([fgi, bgi])
+        return s, cls[s]
+    hduck = types.SimpleNamespace(proposal_append_gt=True, proposal_matcher=lambda m: O.matcher(m, [0.5], [0, 1], False),
+                                  _sample_proposals=samp, num_classes=80)
+    out = rh.StandardROIHeadsPseudoLab.label_and_sample_proposals_pseudo.__wrapped__(hduck, [pr], [t], branch="x") \
+        if hasattr(rh.StandardROIHeadsPseudoLab.label_and_sample_proposals_pseudo, "__wrapped__") else \
+        rh.StandardROIHeadsPseudoLab.label_and_sample_proposals_pseudo(hduck, [pr], [t], branch="x")
+    o = out[0]
+    d.update(roi_prop=npy(pbx), roi_gtb=npy(gb), roi_gtc=npy(t.gt_classes), roi_gts=npy(t.scores), roi_gtstd=npy(t.pred_boxes_std),
+             roi_keys=npy(rkeys), roi_out_prop=npy(o.proposal_boxes.tensor), roi_out_cls=npy(o.gt_classes),
+             roi_out_gtb=npy(o.gt_boxes.tensor), roi_out_conf=npy(o.gt_confid), roi_out_std=npy(o.gt_loc_std))
+    np.savez_compressed(os.path.join(HERE, "rcnn.npz"), **d)
+    print("rcnn.npz:", len(d), "arrays")
+
+
 if __name__ == "__main__":
     structures, fo, pg, tr = install_shims()
+    gen_rcnn(structures)
     gen_fcos(structures, fo, pg)
     gen_small_ops(fo)
     gen_ema(tr)

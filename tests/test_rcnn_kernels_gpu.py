@@ -1,0 +1,178 @@
+"""HIP Faster-RCNN pieces (RoIAlign fwd/bwd, matcher, softmax focal, predictor losses/inference, RPN
+pseudo losses, proposal sampling) vs golden vectors from the reference and vs the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import utv2_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda"
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.allclose(a, b, rtol=rtol, atol=atol), (float(np.abs(a - b).max()), float(np.abs(b).max()))
+
+
+@pytest.fixture(scope="module")
+def rc():
+    return dict(np.load(os.path.join(G, "rcnn.npz")))
+
+
+def rcnn_cfg():
+    from ubteacher.presets import get_config
+    return get_config("rcnn", 1, ["MODEL.DEVICE", DEV])
+
+
+def test_roi_align_fwd_bwd_vs_oracle():
+    from ubteacher import ops
+    g = torch.Generator().manual_seed(3)
+    N, C = 2, 64
+    shapes = [(24, 32), (12, 16), (6, 8), (3, 4)]
+    feats = [torch.randn(N, C, h, w, generator=g) for h, w in shapes]
+    R = 37
+    xy = torch.rand(R, 2, generator=g) * torch.tensor([90.0, 60.0])
+    wh = torch.exp(torch.rand(R, 2, generator=g) * 4.0 + 1.0)
+    rois = torch.cat([xy, xy + wh], 1)
+    rois[0] = torch.tensor([-20.0, -10.0, 200.0, 150.0])  # sticks out of the image
+    batch = torch.randint(0, N, (R,), generator=g)
+    fr = [f.clone().requires_grad_(True) for f in feats]
+    outs = []
+    for r in range(R):  # oracle, roi by roi (its pooler wants per-image lists)
+        outs.append(O.roi_pool([f[batch[r]:batch[r] + 1] for f in fr], [rois[r:r + 1]]))
+    ref = torch.cat(outs)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    fh = [f.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True) for f in feats]
+    y = ops.roi_align(fh, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 2, rois.to(DEV), batch.to(torch.int32).to(DEV),
+                      torch.ones(R, dtype=torch.uint8, device=DEV), 7)
+    close(y.permute(0, 3, 1, 2), ref.detach(), rtol=1e-4, atol=1e-5)
+    y.backward(dy.permute(0, 2, 3, 1).contiguous().to(DEV))
+    for a, b in zip(fh, fr):
+        close(a.grad.permute(0, 3, 1, 2), b.grad if b.grad is not None else torch.zeros_like(b), rtol=1e-3, atol=1e-5)
+
+
+def test_match_boxes_and_lowq_vs_oracle():
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(8)
+    anchors = torch.cat(O.make_anchors([(12, 16), (6, 8)], [8, 16], sizes=(32, 64)))
+    N, Gm = 3, 16
+    gb = torch.zeros(N, Gm, 4); gv = torch.zeros(N, Gm, dtype=torch.uint8)
+    for n, k in enumerate((5, 0, 9)):
+        c = torch.rand(k, 2, generator=g) * torch.tensor([100.0, 70.0])
+        gb[n, :k] = torch.cat([c, c + torch.rand(k, 2, generator=g) * 60 + 8], 1)
+        gv[n, :k] = 1
+    gv[2, 3] = 0  # a hole: thresholded-away pseudo box
+    mx, arg, gmax = hip.match_boxes(anchors.to(DEV), gb.to(DEV), gv.to(DEV), want_gt_max=True)
+    lowq = hip.match_lowq(anchors.to(DEV), gb.to(DEV), gv.to(DEV), gmax)
+    for n in range(N):
+        vi = gv[n].bool().nonzero().squeeze(1)
+        if len(vi) == 0:
+            assert float(mx[n].max()) == -1.0
+            continue
+        iou = O.pairwise_iou(gb[n][vi], anchors)
+        v, i = iou.max(dim=0)
+        assert torch.equal(mx[n].cpu(), v)                       # same fp32 formula -> bit exact
+        assert torch.equal(vi[i], arg[n].cpu().long())
+        _, lab = O.matcher(iou, [0.3, 0.7], [0, -1, 1], True)
+        _, lab_nolq = O.matcher(iou, [0.3, 0.7], [0, -1, 1], False)
+        assert torch.equal(lowq[n].cpu().bool(), (iou == iou.max(dim=1)[0][:, None]).any(dim=0))
+
+
+@pytest.mark.parametrize("branch", ["supervised", "unsup_data_train"])
+def test_predictor_losses_vs_reference_golden(rc, branch):
+    from ubteacher.modeling.rcnn import FastRCNNFocaltLossBoundaryVarOutputLayers
+    from ubteacher.params import ParamStore
+    st = ParamStore()
+    pred = FastRCNNFocaltLossBoundaryVarOutputLayers(rcnn_cfg(), st, 1024, "roi_heads.box_predictor")
+    R = rc["rc_cls"].shape[0]
+    pad = 4  # empty slots must be ignored
+    def padded(x, fill=0.0):
+        x = T(x).float()
+        return torch.cat([x, torch.full((pad,) + tuple(x.shape[1:]), fill)]).to(DEV)
+    scores, deltas, std = (padded(rc["rc_%s_%s" % (branch, k)]).requires_grad_(True) for k in ("scores", "deltas", "std"))
+    sampled = dict(gt_classes=torch.cat([T(rc["rc_cls"]).long(), torch.full((pad,), -1)]).to(DEV)[None],
+                   proposal_boxes=padded(rc["rc_prop"])[None], gt_boxes=padded(rc["rc_gtb"])[None], gt_loc_std=padded(rc["rc_gstd"])[None])
+    ls = pred.losses((scores, deltas, std), sampled, branch)
+    close(ls["loss_cls"], rc["rc_%s_loss_cls" % branch], rtol=2e-5); close(ls["loss_box_reg"], rc["rc_%s_loss_box_reg" % branch], rtol=2e-5)
+    (ls["loss_cls"] + 2.0 * ls["loss_box_reg"]).backward()
+    for k, v in (("scores", scores), ("deltas", deltas), ("std", std)):
+        gv = v.grad if v.grad is not None else torch.zeros_like(v)
+        close(gv[:R], rc["rc_%s_g%s" % (branch, k)], rtol=1e-4, atol=2e-7)
+        assert float(gv[R:].abs().max()) == 0.0
+
+
+def test_predictor_inference_vs_reference_golden(rc):
+    from ubteacher.modeling.fcos import PaddedBoxes
+    from ubteacher.modeling.rcnn import FastRCNNFocaltLossBoundaryVarOutputLayers
+    from ubteacher.params import ParamStore
+    pred = FastRCNNFocaltLossBoundaryVarOutputLayers(rcnn_cfg(), ParamStore(), 1024, "roi_heads.box_predictor")
+    R = rc["rc_prop"].shape[0]
+    props = PaddedBoxes([(300, 300)], boxes=T(rc["rc_prop"]).float()[None].to(DEV), valid=torch.ones(1, R, dtype=torch.uint8, device=DEV))
+    dets, rows = pred.inference((T(rc["inf_scores"]).to(DEV), T(rc["inf_deltas"]).to(DEV), T(rc["inf_std"]).to(DEV)), props)
+    n = int(dets["count"][0])
+    assert n == len(rc["inf_keep"])
+    assert np.array_equal(rows[0, :n].cpu().numpy(), rc["inf_keep"])
+    assert np.array_equal(dets["classes"][0, :n].cpu().numpy(), rc["inf_cls"])
+    close(dets["boxes"][0, :n], rc["inf_boxes"], atol=2e-4); close(dets["scores"][0, :n], rc["inf_sc"], rtol=2e-5)
+    close(dets["pred_boxes_std"][0, :n], rc["inf_bstd"])
+
+
+def test_rpn_pseudo_losses_vs_reference_golden(rc):
+    from ubteacher.modeling.fcos import PaddedBoxes
+    from ubteacher.modeling.rcnn import PseudoLabRPN
+    from ubteacher.params import ParamStore
+    cfg = rcnn_cfg()
+    cfg.MODEL.RPN.BATCH_SIZE_PER_IMAGE = 16
+    rpn = PseudoLabRPN(cfg, ParamStore(), 256)
+    anchors = torch.cat(O.make_anchors([(6, 8), (3, 4)], [16, 32], sizes=(32, 64))).to(DEV)
+    obj = torch.cat([T(rc["rpn_obj%d" % l]) for l in range(2)], 1).to(DEV).requires_grad_(True)
+    dl = torch.cat([T(rc["rpn_dl%d" % l]) for l in range(2)], 1).to(DEV).requires_grad_(True)
+    gb = torch.zeros(2, 16, 4); gs = torch.zeros(2, 16); gv = torch.zeros(2, 16, dtype=torch.uint8)
+    for i in range(2):
+        b = T(rc["rpn_gt%d" % i]).float().reshape(-1, 4)
+        gb[i, :len(b)] = b; gs[i, :len(b)] = T(rc["rpn_sc%d" % i]).float(); gv[i, :len(b)] = 1
+    gt = PaddedBoxes([(96, 128)] * 2, boxes=gb.to(DEV), scores=gs.to(DEV), valid=gv.to(DEV), classes=torch.zeros(2, 16, dtype=torch.int32, device=DEV))
+    rpn.sample_keys = T(rc["rpn_keys"]).float().to(DEV)
+    ls = rpn.losses(anchors, obj, dl, gt)
+    close(ls["loss_rpn_cls"], rc["rpn_loss_cls"], rtol=2e-5); close(ls["loss_rpn_loc"], rc["rpn_loss_loc"], rtol=2e-5)
+    (ls["loss_rpn_cls"] + ls["loss_rpn_loc"]).backward()
+    n0 = rc["rpn_obj0"].shape[1]
+    close(obj.grad[:, :n0], rc["rpn_gobj0"], rtol=1e-4, atol=1e-8); close(obj.grad[:, n0:], rc["rpn_gobj1"], rtol=1e-4, atol=1e-8)
+    close(dl.grad[:, :n0], rc["rpn_gdl0"], rtol=1e-4, atol=1e-8); close(dl.grad[:, n0:], rc["rpn_gdl1"], rtol=1e-4, atol=1e-8)
+
+
+def test_roi_sampling_vs_reference_golden(rc):
+    from ubteacher.modeling.fcos import PaddedBoxes
+    from ubteacher.modeling.rcnn import StandardROIHeadsPseudoLab
+    from ubteacher.params import ParamStore
+    cfg = rcnn_cfg()
+    cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = 16
+    heads = StandardROIHeadsPseudoLab(cfg, ParamStore(), 256)
+    P, Gn, MG = rc["roi_prop"].shape[0], rc["roi_gtb"].shape[0], 16
+    props = PaddedBoxes([(300, 300)], boxes=T(rc["roi_prop"]).float()[None].to(DEV), valid=torch.ones(1, P, dtype=torch.uint8, device=DEV))
+    gb = torch.zeros(1, MG, 4); gc = torch.zeros(1, MG, dtype=torch.int32); gs = torch.zeros(1, MG); gst = torch.zeros(1, MG, 4)
+    gv = torch.zeros(1, MG, dtype=torch.uint8)
+    gb[0, :Gn] = T(rc["roi_gtb"]); gc[0, :Gn] = T(rc["roi_gtc"]).to(torch.int32); gs[0, :Gn] = T(rc["roi_gts"]); gst[0, :Gn] = T(rc["roi_gtstd"]); gv[0, :Gn] = 1
+    gt = PaddedBoxes([(300, 300)], boxes=gb.to(DEV), classes=gc.to(DEV), scores=gs.to(DEV), pred_boxes_std=gst.to(DEV), valid=gv.to(DEV))
+    keys = torch.full((1, P + MG), 0.5)
+    keys[0, :P] = T(rc["roi_keys"])[:P]; keys[0, P:P + Gn] = T(rc["roi_keys"])[P:]
+    heads.sample_keys = keys.to(DEV)
+    out = heads.label_and_sample_proposals(props, gt, "x")
+    n = int(out["valid"].sum())
+    assert n == len(rc["roi_out_cls"])
+    assert np.array_equal(out["gt_classes"][0, :n].cpu().numpy(), rc["roi_out_cls"])
+    close(out["proposal_boxes"][0, :n], rc["roi_out_prop"]); close(out["gt_boxes"][0, :n], rc["roi_out_gtb"])
+    close(out["gt_confid"][0, :n], rc["roi_out_conf"]); close(out["gt_loc_std"][0, :n], rc["roi_out_std"])
