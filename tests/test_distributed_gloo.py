@@ -1,0 +1,98 @@
+"""N>1 host logic on CPU: world_size-2 gloo process groups (one process per rank) exercise the pieces
+of the data-parallel step that do not need a GPU: the flat gradient all-reduce + 1/world scaling, the
+fused [num_pos, sum ctrness] normaliser all-reduce, per-rank batch sharding of the loader, and the
+rank-0 metric gather/averaging."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "unbiased-teacher-v2_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ubteacher.engine.trainer import _TrainerBase
+    from ubteacher.modeling.fcos import FCOSOutputs
+    from ubteacher.presets import get_config
+    from ubteacher.utils import comm
+    from ubteacher.data.synthetic import SyntheticTwoCropLoader
+    out = {}
+    # (1) flat gradient all-reduce: SUM then the optimizer's 1/world scale == DDP mean
+    class Store:
+        pass
+    class Model:
+        pass
+    tr = _TrainerBase.__new__(_TrainerBase)
+    tr.world_size = comm.get_world_size()
+    tr.model = Model(); tr.model.store = Store()
+    g = torch.Generator().manual_seed(100 + rank)
+    tr.model.store.grad = torch.randn(1000, generator=g)
+    local = tr.model.store.grad.clone()
+    scale = tr._allreduce_grads()
+    out["grad_mean"] = (tr.model.store.grad * scale)
+    out["local"] = local
+    # (2) fused loss normalisers
+    sums = torch.tensor([3.0 + rank, 1.5 * (rank + 1), 0, 0, 0, 0, 0, 0])
+    npa, den = FCOSOutputs._normalisers(sums)
+    out["npa"], out["den"] = float(npa), float(den)
+    sums0 = torch.zeros(8)
+    npa0, den0 = FCOSOutputs._normalisers(sums0)
+    out["npa0"], out["den0"] = float(npa0), float(den0)
+    # (3) loader sharding
+    cfg = get_config("fcos", 1, ["SOLVER.IMG_PER_BATCH_LABEL", 4, "SOLVER.IMG_PER_BATCH_UNLABEL", 2, "MODEL.DEVICE", "cpu"])
+    ld = SyntheticTwoCropLoader(cfg, height=32, width=48, device="cpu")
+    lq, lk, uq, uk = next(iter(ld))
+    out["sizes"] = (len(lq), len(lk), len(uq), len(uk))
+    out["img0"] = lk[0]["image"].clone()
+    # (4) metric gather on rank 0
+    tr.model.device = torch.device("cpu")
+    tr.iter = 0; tr.storage = None; tr._pending_metrics = None; tr._last_metrics = {}
+    tr.log_period = 1
+    tr._write_metrics({"loss_a": torch.tensor(1.0 + rank), "loss_b": 2.0 * (rank + 1), "data_time": 0.1 * (rank + 1), "other": 7.0})
+    out["metrics"] = tr._last_metrics
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mean = (res[0]["local"] + res[1]["local"]) / 2
+    for r in range(world):
+        assert torch.allclose(res[r]["grad_mean"], mean)          # identical averaged grads on every rank
+        assert res[r]["npa"] == pytest.approx((3.0 + 4.0) / 2)      # == single-process value on the concatenated batch / world
+        assert res[r]["den"] == pytest.approx((1.5 + 3.0) / 2)
+        assert res[r]["npa0"] == 1.0 and res[r]["den0"] == pytest.approx(1e-6)   # clamps (fcos_outputs.py:321,362)
+        assert res[r]["sizes"] == (2, 2, 1, 1)                      # IMG_PER_BATCH_* // world (data/build.py:240-241)
+    assert not torch.equal(res[0]["img0"], res[1]["img0"])          # ranks see different images
+    m = res[0]["metrics"]
+    assert m["loss_a"] == pytest.approx(1.5) and m["loss_b"] == pytest.approx(3.0) and m["other"] == pytest.approx(7.0)
+    assert m["total_loss"] == pytest.approx(4.5)                    # sum of averaged keys starting with "loss"
+    assert res[1]["metrics"] == {}                                  # only the main process aggregates
