@@ -40,6 +40,16 @@ int utv2_colsum(const float* g, float* db, float* ws, int M, int C, int accumula
 /* wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci]  (weight image consumed by dgrad) */
 int utv2_weight_flip_transpose(const float* w, float* wt, int K, int KH, int KW, int C, utv2_stream_t stream);
 
+/* Multi-level "same" conv on a level-first [sum_l N*H_l*W_l][C] buffer: ONE launch for every FPN level of a
+ * shared head (fcos/fcos.py:338-376 loops the towers over the levels; D2 StandardRPNHead likewise).
+ * Doubles as its own dgrad (flipped/transposed weights, pad = k-1-pad).  H_host/W_host: host int[nlev]. */
+int utv2_conv2d_ml_fwd(const float* x, const float* w, float* y, const float* scale, const float* bias,
+                       const float* residual, int nlev, const int* H_host, const int* W_host, int N, int C, int K, int KH,
+                       int KW, int pad, int relu, int accumulate, utv2_stream_t stream);
+int utv2_conv2d_ml_wgrad(const float* x, const float* dy, float* dw, float* ws, int nlev, const int* H_host,
+                         const int* W_host, int N, int C, int K, int KH, int KW, int pad, int accumulate,
+                         utv2_stream_t stream);
+
 /* ---- teacher EMA: engine/trainer.py:468-486 (FCOS), :950-968 (RCNN) --------------------------
  * teacher = student*(1-keep) + teacher*keep, evaluated with the reference's three roundings. */
 int utv2_ema_axpby(float* teacher, const float* student, int64_t n, double keep_rate, utv2_stream_t stream);

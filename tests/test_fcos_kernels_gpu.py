@@ -46,33 +46,22 @@ def fcos_cfg():
 
 
 def build_head_out(fc, requires_grad=False):
-    """golden NCHW head tensors -> the product's level-first NHWC buffers + per-level views."""
+    """golden NCHW head tensors -> the product's level-first [P, 80] buffers."""
+    from ubteacher.ops import LevelMeta
     N = int(fc["N"])
     level_hw = [tuple(fc["logits%d" % l].shape[2:]) for l in range(5)]
-    P = N * sum(h * w for h, w in level_hw)
-    logits_all = torch.zeros((P, 80), device=DEV)
-    box_all = torch.zeros((P, 80), device=DEV)
-    lo, bo, rows_l, rows_b = [], [], [], []
-    r = 0
-    for l, (h, w) in enumerate(level_hw):
-        r1 = r + N * h * w
-        logits_all[r:r1] = T(fc["logits%d" % l]).permute(0, 2, 3, 1).reshape(-1, 80).to(DEV)
-        box_all[r:r1, :68] = T(fc["reg%d" % l]).permute(0, 2, 3, 1).reshape(-1, 68).to(DEV)
-        box_all[r:r1, 68:72] = T(fc["std%d" % l]).permute(0, 2, 3, 1).reshape(-1, 4).to(DEV)
-        box_all[r:r1, 72] = T(fc["ctr%d" % l]).permute(0, 2, 3, 1).reshape(-1).to(DEV)
-        r = r1
-    r = 0
-    for l, (h, w) in enumerate(level_hw):
-        r1 = r + N * h * w
-        a = logits_all[r:r1].view(N, h, w, 80)
-        b = box_all[r:r1].view(N, h, w, 80)
-        if requires_grad:
-            a = a.detach().requires_grad_(True)
-            b = b.detach().requires_grad_(True)
-        lo.append(a); bo.append(b)
-        rows_l.append((r, r1, (N, h, w, 80))); rows_b.append((r, r1, (N, h, w, 80)))
-        r = r1
-    return (lo, bo, logits_all, box_all, rows_l, rows_b), level_hw
+    meta = LevelMeta(N, level_hw)
+    logits_all = torch.zeros((meta.P, 80), device=DEV)
+    box_all = torch.zeros((meta.P, 80), device=DEV)
+    for l, (r0, r1) in enumerate(meta.rows):
+        logits_all[r0:r1] = T(fc["logits%d" % l]).permute(0, 2, 3, 1).reshape(-1, 80).to(DEV)
+        box_all[r0:r1, :68] = T(fc["reg%d" % l]).permute(0, 2, 3, 1).reshape(-1, 68).to(DEV)
+        box_all[r0:r1, 68:72] = T(fc["std%d" % l]).permute(0, 2, 3, 1).reshape(-1, 4).to(DEV)
+        box_all[r0:r1, 72] = T(fc["ctr%d" % l]).permute(0, 2, 3, 1).reshape(-1).to(DEV)
+    if requires_grad:
+        logits_all.requires_grad_(True)
+        box_all.requires_grad_(True)
+    return {"logits": logits_all, "box": box_all, "meta": meta}, level_hw
 
 
 def padded_gt(fc, prefix, N):
@@ -90,12 +79,13 @@ def padded_gt(fc, prefix, N):
     return PaddedBoxes.from_instances(insts, DEV)
 
 
-def level_grads(fc, case, nm_list, lo, bo):
+def level_grads(fc, case, head_out):
     """compare d/d(head outputs) with the golden NCHW grads"""
+    meta = head_out["meta"]
     for l in range(5):
-        gl = lo[l].grad
+        gl = meta.level_view(head_out["logits"].grad, l)
         close(gl.permute(0, 3, 1, 2), fc["%s_glogits%d" % (case, l)], rtol=1e-4, atol=2e-7)
-        gb = bo[l].grad
+        gb = meta.level_view(head_out["box"].grad, l)
         close(gb[..., :68].permute(0, 3, 1, 2), fc["%s_greg%d" % (case, l)], rtol=1e-4, atol=2e-7)
         close(gb[..., 68:72].permute(0, 3, 1, 2), fc["%s_gstd%d" % (case, l)], rtol=1e-4, atol=2e-7)
         close(gb[..., 72:73].permute(0, 3, 1, 2), fc["%s_gctr%d" % (case, l)], rtol=1e-4, atol=2e-7)
@@ -126,7 +116,7 @@ def test_supervised_losses(fc, case):
         r += N * h * w
     tot = losses["loss_fcos_cls"] + 2.0 * losses["loss_fcos_loc"] + 3.0 * losses["loss_fcos_ctr"]
     tot.backward()
-    level_grads(fc, case, None, head_out[0], head_out[1])
+    level_grads(fc, case, head_out)
 
 
 def test_pseudo_losses(fc):
@@ -140,7 +130,7 @@ def test_pseudo_losses(fc):
         close(losses[k], fc["pseudo_%s" % k], rtol=2e-5)
     tot = losses["loss_fcos_cls"] + 2.0 * losses["loss_fcos_loc"] + 3.0 * losses["loss_fcos_ctr"]
     tot.backward()
-    level_grads(fc, "pseudo", None, head_out[0], head_out[1])
+    level_grads(fc, "pseudo", head_out)
 
 
 @pytest.mark.parametrize("method", ["cls", "cls_n_ctr", "cls_n_loc"])

@@ -18,7 +18,17 @@
 // an input-dilation predicate (for strided forward convs).
 #include "common.h"
 
+#define CONV_MAX_LEVELS 8
+// Multi-level ("ragged") activations: rows [start[l], start[l+1]) hold N images of H[l] x W[l] pixels
+// (level-first layout of DESIGN.md section 2), so ONE launch covers every FPN level of a shared head.
+struct LevelTab {
+  int n;                         // 0 = single dense NHWC tensor
+  int start[CONV_MAX_LEVELS + 1];
+  int H[CONV_MAX_LEVELS], W[CONV_MAX_LEVELS];
+};
+
 struct ConvArgs {
+  LevelTab lt;
   const float* x;
   const float* w;
   float* y;
@@ -37,7 +47,21 @@ struct ConvArgs {
 // MODE 0: C % 16 == 0 (a 16-wide k chunk never straddles a filter tap)
 // MODE 1: C == 4 (stem on the NHWC4-padded image): each float4 is one tap
 // MODE 2: generic scalar gather (any C), weight rows unaligned
-template <int BN, int MODE>
+__device__ __forceinline__ void ml_decode(const LevelTab& lt, int m, int& pixbase, int& H, int& W, int& oh, int& ow) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < CONV_MAX_LEVELS; ++i)
+    if (i < lt.n && m >= lt.start[i]) l = i;
+  H = lt.H[l];
+  W = lt.W[l];
+  const int r = m - lt.start[l], hw = H * W;
+  const int n = r / hw, rem = r - n * hw;
+  oh = rem / W;
+  ow = rem - oh * W;
+  pixbase = lt.start[l] + n * hw;
+}
+
+template <int BN, int MODE, bool ML = false>
 __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   constexpr int BM = 128, BK = 16, LDK = 20;
   constexpr int TM = 2, TN = BN / 64;
@@ -67,18 +91,29 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   // per-thread A rows
   int ih0[2], iw0[2];
   long long pixbase[2];
+  int Hr[2], Wr[2];
   bool mvalid[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const int m = m0 + lrow + 64 * r;
     mvalid[r] = m < p.M;
     const int mm = mvalid[r] ? m : 0;
-    const int hw = p.OH * p.OW;
-    const int n = mm / hw, rem = mm - n * hw;
-    const int oh = rem / p.OW, ow = rem - oh * p.OW;
-    ih0[r] = oh * p.stride - p.pad;
-    iw0[r] = ow * p.stride - p.pad;
-    pixbase[r] = (long long)n * p.H * p.W;
+    if constexpr (ML) {
+      int pb, oh, ow;
+      ml_decode(p.lt, mm, pb, Hr[r], Wr[r], oh, ow);
+      ih0[r] = oh - p.pad;
+      iw0[r] = ow - p.pad;
+      pixbase[r] = pb;
+    } else {
+      const int hw = p.OH * p.OW;
+      const int n = mm / hw, rem = mm - n * hw;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      ih0[r] = oh * p.stride - p.pad;
+      iw0[r] = ow * p.stride - p.pad;
+      pixbase[r] = (long long)n * p.H * p.W;
+      Hr[r] = p.H;
+      Wr[r] = p.W;
+    }
   }
   bool bvalid[BROWS];
   const float* wrow[BROWS];
@@ -114,9 +149,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
           ih = ihn / p.in_dil;
           iw = iwn / p.in_dil;
         }
-        ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        ok = ok && (unsigned)ih < (unsigned)Hr[r] && (unsigned)iw < (unsigned)Wr[r];
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *(const f32x4*)(p.x + (size_t)(pixbase[r] + (long long)ih * p.W + iw) * p.C + c0 + lk4 * 4);
+        if (ok) v = *(const f32x4*)(p.x + (size_t)(pixbase[r] + (long long)ih * Wr[r] + iw) * p.C + c0 + lk4 * 4);
         ra[r] = v;
       }
 #pragma unroll
@@ -259,6 +294,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
 // contiguous pixel ranges; every split writes its own [K][Kred] slab (deterministic), a second
 // kernel sums the slabs into (accumulates onto) the gradient.
 struct WgradArgs {
+  LevelTab lt;
   const float* x;   // forward input  [N][H][W][C]
   const float* dy;  // output grad    [N][OH][OW][K]
   float* ws;        // [splits][K][Kred]
@@ -266,7 +302,7 @@ struct WgradArgs {
   int Kred, M, splits, chunks_per_split;
 };
 
-template <int VEC>
+template <int VEC, bool ML = false>
 __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs p) {
   constexpr int BM = 128, BN = 128, BK = 16;
   constexpr int TM = 2, TN = 2;
@@ -333,14 +369,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs p) {
       const int m = chunk * BK + lp + 8 * r;
       const bool mv = m < p.M;
       const int mm = mv ? m : 0;
-      const int n = mm / hw, rem = mm - n * hw;
-      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      int n, oh, ow, Hh = p.H, Ww = p.W;
+      long long pb;
+      if constexpr (ML) {
+        int pbi;
+        ml_decode(p.lt, mm, pbi, Hh, Ww, oh, ow);
+        pb = pbi;
+        n = 0;
+      } else {
+        n = mm / hw;
+        const int rem = mm - n * hw;
+        oh = rem / p.OW;
+        ow = rem - oh * p.OW;
+        pb = (long long)n * p.H * p.W;
+      }
       f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
       if constexpr (VEC) {
         if (mv && coidx < p.K) va = *(const f32x4*)(p.dy + (size_t)mm * p.K + coidx);
         const int ih = oh * p.stride - p.pad + tkh[0], iw = ow * p.stride - p.pad + tkw[0];
-        if (mv && kok[0] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-          vb = *(const f32x4*)(p.x + ((size_t)((long long)n * p.H + ih) * p.W + iw) * p.C + tci[0]);
+        if (mv && kok[0] && (unsigned)ih < (unsigned)Hh && (unsigned)iw < (unsigned)Ww)
+          vb = *(const f32x4*)(p.x + (size_t)(pb + (long long)ih * Ww + iw) * p.C + tci[0]);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -454,7 +502,67 @@ __global__ void weight_flip_transpose_f32(const float* __restrict__ w, float* __
   }
 }
 
+extern "C" int utv2_conv2d_wgrad_splits(int N, int OH, int OW, int K, int Kred);
+
+static int fill_levels(LevelTab& lt, int nlev, int N, const int* H, const int* W) {
+  lt.n = nlev;
+  int off = 0;
+  for (int l = 0; l < CONV_MAX_LEVELS; ++l) {
+    lt.start[l] = off;
+    if (l < nlev) {
+      lt.H[l] = H[l];
+      lt.W[l] = W[l];
+      off += N * H[l] * W[l];
+    } else {
+      lt.H[l] = lt.W[l] = 1;
+    }
+  }
+  lt.start[CONV_MAX_LEVELS] = off;
+  return off;
+}
+
 extern "C" {
+
+// Multi-level "same" convolution (stride 1, pad (k-1)/2) on a level-first [P][C] buffer: one launch for all
+// FPN levels of a shared head (towers, prediction convs, RPN conv).  H_host/W_host: host int[nlev].
+// Also serves as its own dgrad (pass the flipped/transposed weight image, pad = k-1-pad).
+int utv2_conv2d_ml_fwd(const float* x, const float* w, float* y, const float* scale, const float* bias,
+                       const float* residual, int nlev, const int* H_host, const int* W_host, int N, int C, int K, int KH,
+                       int KW, int pad, int relu, int accumulate, hipStream_t stream) {
+  if (!x || !w || !y || nlev < 1 || nlev > CONV_MAX_LEVELS || (C % 16) || N <= 0) return UTV2_EARG;
+  ConvArgs a;
+  a.M = fill_levels(a.lt, nlev, N, H_host, W_host);
+  a.x = x; a.w = w; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual;
+  a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW;
+  a.stride = 1; a.pad = pad; a.in_dil = 1; a.relu = relu; a.accumulate = accumulate;
+  a.Kred = KH * KW * C;
+  const bool small = K <= 64;
+  const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
+  if (small) hipLaunchKernelGGL((conv_igemm_f32<64, 0, true>), dim3(tiles), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv_igemm_f32<128, 0, true>), dim3(tiles), dim3(256), 0, stream, a);
+  return utv2_launch_status();
+}
+
+int utv2_conv2d_ml_wgrad(const float* x, const float* dy, float* dw, float* ws, int nlev, const int* H_host,
+                         const int* W_host, int N, int C, int K, int KH, int KW, int pad, int accumulate,
+                         hipStream_t stream) {
+  if (!x || !dy || !dw || !ws || nlev < 1 || nlev > CONV_MAX_LEVELS || (C & 3) || (K & 3)) return UTV2_EARG;
+  WgradArgs a;
+  a.M = fill_levels(a.lt, nlev, N, H_host, W_host);
+  a.x = x; a.dy = dy; a.ws = ws;
+  a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 1; a.OW = a.M; a.K = K; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad;
+  a.Kred = KH * KW * C;
+  a.splits = utv2_conv2d_wgrad_splits(1, 1, a.M, K, a.Kred);
+  const int chunks = cdiv(a.M, 16);
+  a.chunks_per_split = cdiv(chunks, a.splits);
+  const int tiles = cdiv(K, 128) * cdiv(a.Kred, 128);
+  hipLaunchKernelGGL((conv_wgrad_f32<1, true>), dim3(tiles * a.splits), dim3(256), 0, stream, a);
+  const size_t n = (size_t)K * a.Kred;
+  int rb = cdiv((int64_t)n, 256);
+  if (rb > 4096) rb = 4096;
+  hipLaunchKernelGGL(reduce_slabs_f32, dim3(rb), dim3(256), 0, stream, (const float*)ws, dw, n, a.splits, accumulate);
+  return utv2_launch_status();
+}
 
 // Forward / dgrad implicit GEMM.  x:[N,H,W,C] w:[K][Kred] y:[N,OH,OW,K].
 // y = relu?( conv(x,w) * scale[co] + bias[co] + residual ) (+ y if accumulate)
@@ -464,6 +572,7 @@ int utv2_conv2d_nhwc_fwd(const float* x, const float* w, float* y, const float* 
                          int in_dil, int OH, int OW, int relu, int accumulate, int Kred, hipStream_t stream) {
   if (!x || !w || !y || N <= 0 || C <= 0 || K <= 0) return UTV2_EARG;
   ConvArgs a;
+  a.lt.n = 0;
   a.x = x; a.w = w; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual;
   a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.K = K; a.KH = KH; a.KW = KW;
   a.stride = stride; a.pad = pad; a.in_dil = in_dil < 1 ? 1 : in_dil; a.relu = relu; a.accumulate = accumulate;
@@ -513,6 +622,7 @@ int utv2_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw, float* ws
                            int KH, int KW, int stride, int pad, int OH, int OW, int accumulate, hipStream_t stream) {
   if (!x || !dy || !dw || !ws) return UTV2_EARG;
   WgradArgs a;
+  a.lt.n = 0;
   a.x = x; a.dy = dy; a.ws = ws;
   a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.K = K; a.KH = KH; a.KW = KW;
   a.stride = stride; a.pad = pad;

@@ -244,10 +244,10 @@ def frozenbn_fold(w, b, mean, var, scale, shift, eps=1e-5):
     call("utv2_frozenbn_fold", _p(w), _p(b), _p(mean), _p(var), _p(scale), _p(shift), w.numel(), float(eps), _stream())
 
 
-def groupnorm_relu_fwd(x, gamma, beta, G=32, eps=1e-5, relu=True):
+def groupnorm_relu_fwd(x, gamma, beta, G=32, eps=1e-5, relu=True, out=None):
     N, H, W, C = x.shape
     HW = H * W
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
     mean = torch.empty((N, G), dtype=torch.float32, device=x.device)
     rstd = torch.empty((N, G), dtype=torch.float32, device=x.device)
     ws = workspace(load().utv2_groupnorm_workspace_floats(N, HW, C), x.device, "gn")
@@ -256,10 +256,10 @@ def groupnorm_relu_fwd(x, gamma, beta, G=32, eps=1e-5, relu=True):
     return y, mean, rstd
 
 
-def groupnorm_relu_bwd(dy, y, x, mean, rstd, gamma, dgamma, dbeta, G=32, relu=True):
+def groupnorm_relu_bwd(dy, y, x, mean, rstd, gamma, dgamma, dbeta, G=32, relu=True, out=None):
     N, H, W, C = x.shape
     HW = H * W
-    dx = torch.empty_like(x)
+    dx = torch.empty_like(x) if out is None else out
     ws = workspace(load().utv2_groupnorm_workspace_floats(N, HW, C), x.device, "gn")
     call("utv2_groupnorm_relu_bwd", _p(dy), _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta),
          _p(ws), N, HW, C, G, int(relu), _stream())
@@ -451,3 +451,33 @@ def softmax_focal_bwd(logits, target, gamma, coef):
     out = torch.empty_like(logits)
     call("utv2_softmax_focal_bwd", _p(logits), _p(target), R, C, float(gamma), _p(coef), _p(out), _stream())
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# multi-level ("level-first") convs: one launch for all FPN levels of a shared head
+def conv2d_ml_fwd(x2d, w, level_hw, N, scale=None, bias=None, residual=None, k=3, pad=1, relu=False, out=None, accumulate=False):
+    P, C = x2d.shape
+    K = w.shape[0]
+    assert P == N * sum(h * w_ for h, w_ in level_hw)
+    if out is None:
+        out = torch.empty((P, K), dtype=torch.float32, device=x2d.device)
+    H = _iarr([h for h, _ in level_hw]); W = _iarr([w_ for _, w_ in level_hw])
+    call("utv2_conv2d_ml_fwd", _p(x2d), _p(w), _p(out), _p(scale), _p(bias), _p(residual), len(level_hw), ctypes.cast(H, c_p),
+         ctypes.cast(W, c_p), N, C, K, k, k, pad, int(relu), int(accumulate), _stream())
+    return out
+
+
+def conv2d_ml_dgrad(dy2d, w_t, level_hw, N, k, pad, out=None):
+    """w_t [C, k*k*K] flipped/transposed image; returns dx [P, C]."""
+    return conv2d_ml_fwd(dy2d, w_t, level_hw, N, k=k, pad=k - 1 - pad, out=out)
+
+
+def conv2d_ml_wgrad(x2d, dy2d, dw, level_hw, N, k, pad, accumulate=True):
+    P, C = x2d.shape
+    K = dy2d.shape[1]
+    nws = load().utv2_conv2d_wgrad_workspace_floats(1, 1, P, K, k * k * C)
+    ws = workspace(nws, x2d.device, "wgrad")
+    H = _iarr([h for h, _ in level_hw]); W = _iarr([w_ for _, w_ in level_hw])
+    call("utv2_conv2d_ml_wgrad", _p(x2d), _p(dy2d), _p(dw), _p(ws), len(level_hw), ctypes.cast(H, c_p), ctypes.cast(W, c_p), N, C, K,
+         k, k, pad, int(accumulate), _stream())
+    return dw

@@ -185,7 +185,23 @@ class FPN:
         self.size_divisibility = self.bottom_up.strides[self.in_features[-1]]
 
     def __call__(self, x4):
+        """Returns {p_l: NHWC level tensor}.  All levels are rows of ONE level-first buffer
+        (`results["_levelfirst"] = (big [P,C], LevelMeta)`) so shared heads run one launch for all levels."""
         feats = self.bottom_up(x4)
+        N = x4.shape[0]
+        C = self.out_channels
+        hw = {}
+        for f in self.in_features:
+            hw["p%d" % int(math.log2(self.bottom_up.strides[f]))] = (feats[f].shape[1], feats[f].shape[2])
+        last = "p%d" % int(math.log2(self.bottom_up.strides[self.in_features[-1]]))
+        nlast = int(last[1:])
+        h, w = hw[last]
+        for i in range(len(self.out_names) - len(self.in_features)):
+            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1   # conv3x3 s2 p1 == max_pool(k1,s2) output size
+            hw["p%d" % (nlast + 1 + i)] = (h, w)
+        meta = ops.LevelMeta(N, [hw[k] for k in self.out_names])
+        big = torch.empty((meta.P, C), dtype=torch.float32, device=x4.device)
+        slot = {k: meta.alias_view(big, i) for i, k in enumerate(self.out_names)}
         results = {}
         prev = None
         for f in reversed(self.in_features):
@@ -193,21 +209,26 @@ class FPN:
             if prev is not None:
                 lat = ops.upsample2x_add(lat, prev)
             prev = lat
-            stage = int(math.log2(self.bottom_up.strides[f]))
-            results["p%d" % stage] = self.output[f](lat)
-        last = "p%d" % int(math.log2(self.bottom_up.strides[self.in_features[-1]]))
+            name = "p%d" % int(math.log2(self.bottom_up.strides[f]))
+            results[name] = self.output[f](lat, out=slot[name])
         if self.top_block_kind == "p6p7":
-            p6 = self.top[0](results[last])
-            p7 = self.top[1](ops.relu(p6))
-            n = int(last[1:])
-            results["p%d" % (n + 1)] = p6
-            results["p%d" % (n + 2)] = p7
+            p6 = self.top[0](results[last], out=slot["p%d" % (nlast + 1)])
+            p7 = self.top[1](ops.relu(p6), out=slot["p%d" % (nlast + 2)])
+            results["p%d" % (nlast + 1)] = p6
+            results["p%d" % (nlast + 2)] = p7
         elif self.top_block_kind == "p6":
-            results["p%d" % (int(last[1:]) + 1)] = self.top[0](results[last])
+            results["p%d" % (nlast + 1)] = self.top[0](results[last], out=slot["p%d" % (nlast + 1)])
         elif self.top_block_kind == "maxpool":
             # LastLevelMaxPool: max_pool2d(kernel 1, stride 2) == strided subsample
-            results["p%d" % (int(last[1:]) + 1)] = results[last][:, ::2, ::2, :].contiguous()
-        return {k: results[k] for k in self.out_names}
+            results["p%d" % (nlast + 1)] = ops.subsample2_into(results[last], slot["p%d" % (nlast + 1)])
+        out = {k: results[k] for k in self.out_names}
+        levels = [out[k] for k in self.out_names]
+        if torch.is_grad_enabled() and any(t.requires_grad for t in levels):
+            bigt = ops.assemble(big, [(r0, r1, tuple(t.shape)) for (r0, r1), t in zip(meta.rows, levels)], levels)
+        else:
+            bigt = big
+        out["_levelfirst"] = (bigt, meta)
+        return out
 
 
 @BACKBONE_REGISTRY.register()

@@ -169,35 +169,21 @@ class FCOSHead:
             self.scales = [store.new((1,), "decay", lambda t: t.fill_(1.0)).export("%s.scales.%d.scale" % (prefix, l))
                            for l in range(self.num_levels)]
 
-    def __call__(self, feats):
-        """feats: list of NHWC level features. Returns (logits_levels, box_levels, logits_all, box_all, rows)."""
-        N = feats[0].shape[0]
-        hw = [f.shape[1] * f.shape[2] for f in feats]
-        P = N * sum(hw)
-        dev = feats[0].device
-        logits_all = torch.empty((P, self.num_classes), dtype=torch.float32, device=dev)
-        box_all = torch.empty((P, BOX_STRIDE), dtype=torch.float32, device=dev)
-        rows_l, rows_b, lo, bo = [], [], [], []
-        r = 0
-        for l, f in enumerate(feats):
-            n, h, w, _ = f.shape
-            t = f
-            for conv, gn in self.towers["share"]:
-                t = gn(conv(t))
-            tc = t
-            for conv, gn in self.towers["cls"]:
-                tc = gn(conv(tc))
-            tb = t
-            for conv, gn in self.towers["bbox"]:
-                tb = gn(conv(tb))
-            r1 = r + n * h * w
-            lo.append(self.cls_logits(tc, out=logits_all[r:r1].view(n, h, w, self.num_classes)))
-            bo.append(self.box_head(tb, out=box_all[r:r1].view(n, h, w, BOX_STRIDE),
-                                    colscale_handle=self.scales[l] if self.scales is not None else None))
-            rows_l.append((r, r1, (n, h, w, self.num_classes)))
-            rows_b.append((r, r1, (n, h, w, BOX_STRIDE)))
-            r = r1
-        return lo, bo, logits_all, box_all, rows_l, rows_b
+    def __call__(self, big, meta):
+        """big: level-first [P, C] features of all levels; ONE launch per conv for all levels.
+        Returns dict(logits [P,80], box [P,80], meta)."""
+        t = big
+        for conv, gn in self.towers["share"]:
+            t = gn(conv(t, meta=meta), meta)
+        tc = t
+        for conv, gn in self.towers["cls"]:
+            tc = gn(conv(tc, meta=meta), meta)
+        tb = t
+        for conv, gn in self.towers["bbox"]:
+            tb = gn(conv(tb, meta=meta), meta)
+        logits = self.cls_logits(tc, meta=meta)
+        box = self.box_head(tb, meta=meta, colscale_handle=self.scales)
+        return {"logits": logits, "box": box, "meta": meta}
 
 
 class FCOSOutputs:
@@ -257,10 +243,10 @@ class FCOSOutputs:
     def losses(self, head_out, level_hw, gt, branch="labeled"):
         if branch != "labeled":
             raise ValueError("Incorrect branch name")
-        lo, bo, logits_all, box_all, rows_l, rows_b = head_out
+        logits_all, box_all = head_out["logits"], head_out["box"]
         labels, reg_t, bvars, gt_inds = self._targets(level_hw, gt, drop_empty=1)
-        focal = ops.focal_loss_sum(logits_all, labels, self.focal_loss_alpha, self.focal_loss_gamma, rows_l, lo)
-        sums = ops.fcos_loc_terms(box_all, labels, reg_t, None, (self.num_classes, self.reg_max, 0.0, 0.0), rows_b, bo)
+        focal = ops.focal_loss_sum(logits_all, labels, self.focal_loss_alpha, self.focal_loss_gamma)
+        sums = ops.fcos_loc_terms(box_all, labels, reg_t, None, (self.num_classes, self.reg_max, 0.0, 0.0))
         npa, den = self._normalisers(sums)
         w = self.kl_loss_weight
         nll_mean = sums[4] / sums[0].detach().clamp(min=1.0)
@@ -275,20 +261,20 @@ class FCOSOutputs:
     # -- pseudo branch (fcos_outputs.py:447-631) -----------------------------------------------------
     def pseudo_losses(self, head_out, level_hw, gt_dict, branch="unlabeled"):
         assert branch == "unlabeled"
-        lo, bo, logits_all, box_all, rows_l, rows_b = head_out
+        logits_all, box_all = head_out["logits"], head_out["box"]
         losses, extras = {}, {}
         for labeltype, gt in gt_dict.items():
             labels, reg_t, bvars, gt_inds = self._targets(level_hw, gt, drop_empty=0)
             if labeltype == "cls":
-                focal = ops.focal_loss_sum(logits_all, labels, self.focal_loss_alpha, self.focal_loss_gamma, rows_l, lo)
-                sums = ops.fcos_loc_terms(box_all, labels, reg_t, None, (self.num_classes, self.reg_max, 0.0, 0.0), rows_b, bo)
+                focal = ops.focal_loss_sum(logits_all, labels, self.focal_loss_alpha, self.focal_loss_gamma)
+                sums = ops.fcos_loc_terms(box_all, labels, reg_t, None, (self.num_classes, self.reg_max, 0.0, 0.0))
                 npa, den = self._normalisers(sums)
                 losses["loss_fcos_cls"] = focal[0] / npa
                 ctr = sums[2] / npa
                 losses["loss_fcos_ctr"] = ctr * 0 if self.unify_ctrcls else ctr
             elif labeltype == "reg":
                 sums = ops.fcos_loc_terms(box_all, labels, reg_t, bvars,
-                                          (self.num_classes, self.reg_max, self.tsbetter_reg, self.tsbetter_reg_cert), rows_b, bo)
+                                          (self.num_classes, self.reg_max, self.tsbetter_reg, self.tsbetter_reg_cert))
                 self._normalisers(sums)  # the reference issues the same two reductions here (:504,:521)
                 losses["loss_fcos_loc"] = sums[6] / sums[5].detach().clamp(min=1.0)
                 losses["teacher_better_student"] = sums[5].detach()
@@ -307,8 +293,9 @@ class FCOSOutputs:
         if nms_method not in METHODS:
             raise ValueError("Undefined nms criteria")
         method = METHODS[nms_method]
-        lo, bo, logits_all, box_all, rows_l, rows_b = head_out
-        N = lo[0].shape[0]
+        meta = head_out["meta"]
+        logits_all, box_all = head_out["logits"].detach(), head_out["box"].detach()
+        N = meta.N
         dev = logits_all.device
         ks = [min(pre, h * w * self.num_classes) for (h, w) in level_hw]
         MAXC = sum(ks)
@@ -325,7 +312,8 @@ class FCOSOutputs:
         )
         slot0 = 0
         for l, (h, w) in enumerate(level_hw):
-            lg, bx = lo[l].detach(), bo[l].detach()
+            r0, r1 = meta.rows[l]
+            lg, bx = logits_all[r0:r1], box_all[r0:r1]
             keys = hip.fcos_rank_keys(lg, bx, self.reg_max, N, h * w, th, method)
             top = torch.topk(keys, ks[l], dim=1, sorted=True).values.contiguous()
             hip.fcos_decode(top, lg, bx, self.reg_max, N, h * w, w, self.strides[l], l, method, slot0, outs)
@@ -368,9 +356,16 @@ class FCOS:
                 ignore_near=False, branch="labeled"):
         feats = [features[f] for f in self.in_features]
         level_hw = [(f.shape[1], f.shape[2]) for f in feats]
-        head_out = self.fcos_head(feats)
+        lf = features.get("_levelfirst")
+        if lf is not None and lf[1].level_hw == level_hw:
+            big, meta = lf
+        else:  # features that do not share a level-first buffer: build one (copy)
+            meta = ops.LevelMeta(feats[0].shape[0], level_hw)
+            big = torch.cat([f.reshape(-1, f.shape[-1]) for f in feats], dim=0)
+        head_out = self.fcos_head(big, meta)
         raw_output = {"head_out": head_out, "level_hw": level_hw, "image_sizes": image_sizes,
-                      "logits_pred": head_out[0], "box_pred": head_out[1]}
+                      "logits_pred": [meta.level_view(head_out["logits"], l) for l in range(len(level_hw))],
+                      "box_pred": [meta.level_view(head_out["box"], l) for l in range(len(level_hw))]}
         results = {}
         if self.training:
             if ignore_near:

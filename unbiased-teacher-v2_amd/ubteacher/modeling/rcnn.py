@@ -180,20 +180,18 @@ class PseudoLabRPN:
     def train(self, mode=True):
         self.training = mode
 
-    # -- head: all levels into one level-first [P,16] buffer ---------------------------------------------
-    def _head(self, feats):
-        N = feats[0].shape[0]
+    # -- head: one launch per layer for all levels, output level-first [P,16] ----------------------------------
+    def _head(self, features):
+        feats = [features[f] for f in self.in_features]
         hw = [(f.shape[1], f.shape[2]) for f in feats]
-        P = N * sum(h * w for h, w in hw)
-        big = torch.empty((P, RPN_CH), dtype=torch.float32, device=feats[0].device)
-        rows, outs = [], []
-        r = 0
-        for f, (h, w) in zip(feats, hw):
-            r1 = r + N * h * w
-            outs.append(self.pred(self.conv(f), out=big[r:r1].view(N, h, w, RPN_CH)))
-            rows.append((r, r1, (N, h, w, RPN_CH)))
-            r = r1
-        return big, rows, outs, hw
+        lf = features.get("_levelfirst")
+        if lf is not None and lf[1].level_hw == hw:
+            big, meta = lf
+        else:
+            meta = ops.LevelMeta(feats[0].shape[0], hw)
+            big = torch.cat([f.reshape(-1, f.shape[-1]) for f in feats], dim=0)
+        out = self.pred(self.conv(big, meta=meta), meta=meta)
+        return out, hw, meta.N
 
     def _per_image_views(self, big, N, hw):
         """objectness [N, R] and deltas [N, R, 4] in the reference's (level, h, w, a) anchor order."""
@@ -208,14 +206,11 @@ class PseudoLabRPN:
         return obj, dl
 
     def forward(self, image_sizes, features, gt=None, compute_loss=True, compute_val_loss=False):
-        feats = [features[f] for f in self.in_features]
-        big, rows, outs, hw = self._head(feats)
-        N = feats[0].shape[0]
+        big, hw, N = self._head(features)
         anchors = self.anchor_generator(hw, big.device)
         losses = {}
         if (self.training and compute_loss) or compute_val_loss:
-            bigt = ops.assemble(big, rows, outs) if torch.is_grad_enabled() else big
-            obj, dl = self._per_image_views(bigt, N, hw)
+            obj, dl = self._per_image_views(big, N, hw)
             losses = self.losses(torch.cat(anchors), torch.cat(obj, 1), torch.cat(dl, 1), gt)
             losses = {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}  # applied twice
         with torch.no_grad():

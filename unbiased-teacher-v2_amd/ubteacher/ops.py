@@ -29,6 +29,34 @@ def bump_version():
     _VERSION[0] += 1
 
 
+class LevelMeta:
+    """Geometry of a level-first [P, C] activation: N images on every FPN level."""
+
+    def __init__(self, N, level_hw):
+        self.N = N
+        self.level_hw = [tuple(x) for x in level_hw]
+        self.rows = []
+        r = 0
+        for h, w in self.level_hw:
+            self.rows.append((r, r + N * h * w))
+            r += N * h * w
+        self.P = r
+
+    def level_view(self, t2d, l):
+        r0, r1 = self.rows[l]
+        h, w = self.level_hw[l]
+        return t2d[r0:r1].view(self.N, h, w, t2d.shape[1])
+
+    def alias_view(self, t2d, l):
+        """Same memory as level_view() but NOT an autograd view of `t2d` (separate version counter): used
+        as the destination of per-level producers so autograd's view+inplace bookkeeping stays out of it."""
+        r0, r1 = self.rows[l]
+        h, w = self.level_hw[l]
+        C = t2d.shape[1]
+        return torch.empty((0,), dtype=t2d.dtype, device=t2d.device).set_(
+            t2d.untyped_storage(), t2d.storage_offset() + r0 * C, (self.N, h, w, C), (h * w * C, w * C, C, 1))
+
+
 class Conv:
     """One convolution (+ optional folded FrozenBN or bias, ReLU, residual) bound to arena handles."""
 
@@ -56,28 +84,44 @@ class Conv:
             self._wt_version = _VERSION[0]
         return self._wt
 
-    def __call__(self, x, residual=None, out=None, colscale_handle=None):
+    def __call__(self, x, residual=None, out=None, colscale_handle=None, meta=None):
+        """x: NHWC tensor, or a level-first [P, C] matrix with `meta` (one launch for all levels; k x k
+        'same' convs only).  colscale_handle: a Handle, or one Handle per level when `meta` is given."""
         if torch.is_grad_enabled() and self.trainable:
-            return _ConvFn.apply(x, residual, hook(x.device), self, (out,), colscale_handle)
+            return _ConvFn.apply(x, residual, hook(x.device), self, (out,), colscale_handle, meta)
+        return self._forward(x, residual, out, colscale_handle, meta)
+
+    def _forward(self, x, residual, out, cs, meta):
         sc, sh = self.scale_shift()
-        y = hip.conv2d_fwd(x, self.w.t, scale=sc, bias=sh, residual=residual, stride=self.stride, pad=self.pad,
-                           relu=self.relu, kh=self.k, kw=self.k, out=out)
-        if colscale_handle is not None:
-            hip.scale_cols(y.view(-1, self.cout), self.colscale, colscale_handle.t)
+        if meta is not None and self.k > 1:
+            assert self.stride == 1 and self.pad == (self.k - 1) // 2
+            y = hip.conv2d_ml_fwd(x, self.w.t, meta.level_hw, meta.N, scale=sc, bias=sh, residual=residual, k=self.k,
+                                  pad=self.pad, relu=self.relu, out=out)
+        elif meta is not None:  # 1x1 on a level-first matrix: plain GEMM rows
+            y = hip.conv2d_fwd(x.view(1, x.shape[0], 1, x.shape[1]), self.w.t, scale=sc, bias=sh,
+                               residual=None if residual is None else residual.view(1, x.shape[0], 1, -1), relu=self.relu,
+                               out=None if out is None else out.view(1, x.shape[0], 1, -1)).view(x.shape[0], self.cout)
+        else:
+            y = hip.conv2d_fwd(x, self.w.t, scale=sc, bias=sh, residual=residual, stride=self.stride, pad=self.pad,
+                               relu=self.relu, kh=self.k, kw=self.k, out=out)
+        if cs is not None:
+            if meta is not None:
+                for l, h in enumerate(cs):
+                    r0, r1 = meta.rows[l]
+                    hip.scale_cols(y[r0:r1], self.colscale, h.t)
+            else:
+                hip.scale_cols(y.view(-1, self.cout), self.colscale, cs.t)
         return y
 
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, hk, layer, out_holder, cs):
+    def forward(ctx, x, residual, hk, layer, out_holder, cs, meta):
         out = out_holder[0]  # optional destination view (kept out of autograd's sight on purpose)
-        sc, sh = layer.scale_shift()
-        y = hip.conv2d_fwd(x, layer.w.t, scale=sc, bias=sh, residual=residual, stride=layer.stride, pad=layer.pad,
-                           relu=layer.relu, kh=layer.k, kw=layer.k, out=out)
-        if cs is not None:
-            hip.scale_cols(y.view(-1, layer.cout), layer.colscale, cs.t)
+        y = layer._forward(x, residual, out, cs, meta)
         ctx.layer = layer
         ctx.cs = cs
+        ctx.meta = meta
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, y if (layer.relu or cs is not None) else None)
         ctx.xshape = tuple(x.shape)
@@ -89,10 +133,17 @@ class _ConvFn(torch.autograd.Function):
         x, y = ctx.saved_tensors
         dy = dy.contiguous()
         sc, _ = layer.scale_shift()
+        meta = ctx.meta
         if ctx.cs is not None:
             g = dy.clone()
-            dsum = hip.scale_cols_bwd(g.view(-1, layer.cout), y.view(-1, layer.cout), layer.colscale, ctx.cs.t)
-            ctx.cs.g.add_(dsum / ctx.cs.t.view(-1))
+            if meta is not None:
+                for l, h in enumerate(ctx.cs):
+                    r0, r1 = meta.rows[l]
+                    dsum = hip.scale_cols_bwd(g[r0:r1], y[r0:r1], layer.colscale, h.t)
+                    h.g.add_(dsum / h.t.view(-1))
+            else:
+                dsum = hip.scale_cols_bwd(g.view(-1, layer.cout), y.view(-1, layer.cout), layer.colscale, ctx.cs.t)
+                ctx.cs.g.add_(dsum / ctx.cs.t.view(-1))
             dy = g
         gres = None
         if ctx.has_res:
@@ -105,40 +156,66 @@ class _ConvFn(torch.autograd.Function):
             else:
                 g = dy
         dx = None
-        if ctx.needs_input_grad[0]:
-            dx = hip.conv2d_dgrad(g, layer.wt(), ctx.xshape, layer.stride, layer.pad, layer.k, layer.k)
-        hip.conv2d_wgrad(x, g, layer.w.g, layer.stride, layer.pad, layer.k, layer.k, accumulate=True)
+        if meta is not None and layer.k > 1:
+            if ctx.needs_input_grad[0]:
+                dx = hip.conv2d_ml_dgrad(g, layer.wt(), meta.level_hw, meta.N, layer.k, layer.pad)
+            hip.conv2d_ml_wgrad(x, g, layer.w.g, meta.level_hw, meta.N, layer.k, layer.pad, accumulate=True)
+        else:
+            x4 = x.view(1, x.shape[0], 1, x.shape[1]) if meta is not None else x
+            g4 = g.view(1, g.shape[0], 1, g.shape[1]) if meta is not None else g
+            if ctx.needs_input_grad[0]:
+                dx = hip.conv2d_dgrad(g4, layer.wt(), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k)
+                if meta is not None:
+                    dx = dx.view(x.shape)
+            hip.conv2d_wgrad(x4, g4, layer.w.g, layer.stride, layer.pad, layer.k, layer.k, accumulate=True)
         if layer.bias is not None:
             hip.colsum(g.view(-1, layer.cout), layer.bias.g, accumulate=True)
-        return dx, gres, None, None, None, None
+        return dx, gres, None, None, None, None, None
 
 
 class GroupNormReLU:
     def __init__(self, gamma, beta, groups=32, eps=1e-5, relu=True):
         self.gamma, self.beta, self.groups, self.eps, self.relu = gamma, beta, groups, eps, relu
 
-    def __call__(self, x):
+    def __call__(self, x, meta=None):
         if torch.is_grad_enabled():
-            return _GNFn.apply(x, hook(x.device), self)
-        y, _, _ = hip.groupnorm_relu_fwd(x, self.gamma.t, self.beta.t, self.groups, self.eps, self.relu)
-        return y
+            return _GNFn.apply(x, hook(x.device), self, meta)
+        return self._fwd(x, meta)[0]
+
+    def _fwd(self, x, meta):
+        if meta is None:
+            return hip.groupnorm_relu_fwd(x, self.gamma.t, self.beta.t, self.groups, self.eps, self.relu)
+        y = torch.empty_like(x)
+        means, rstds = [], []
+        for l in range(len(meta.level_hw)):  # statistics are per (image, level, group)
+            yl, m, r = hip.groupnorm_relu_fwd(meta.level_view(x, l), self.gamma.t, self.beta.t, self.groups, self.eps, self.relu,
+                                              out=meta.level_view(y, l))
+            means.append(m); rstds.append(r)
+        return y, torch.stack(means), torch.stack(rstds)
 
 
 class _GNFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, hk, layer):
-        y, mean, rstd = hip.groupnorm_relu_fwd(x, layer.gamma.t, layer.beta.t, layer.groups, layer.eps, layer.relu)
+    def forward(ctx, x, hk, layer, meta):
+        y, mean, rstd = layer._fwd(x, meta)
         ctx.layer = layer
+        ctx.meta = meta
         ctx.save_for_backward(x, y, mean, rstd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        layer = ctx.layer
+        layer, meta = ctx.layer, ctx.meta
         x, y, mean, rstd = ctx.saved_tensors
-        dx = hip.groupnorm_relu_bwd(dy.contiguous(), y, x, mean, rstd, layer.gamma.t, layer.gamma.g, layer.beta.g,
-                                    layer.groups, layer.relu)
-        return dx, None, None
+        dy = dy.contiguous()
+        if meta is None:
+            dx = hip.groupnorm_relu_bwd(dy, y, x, mean, rstd, layer.gamma.t, layer.gamma.g, layer.beta.g, layer.groups, layer.relu)
+        else:
+            dx = torch.empty_like(x)
+            for l in range(len(meta.level_hw)):
+                hip.groupnorm_relu_bwd(meta.level_view(dy, l), meta.level_view(y, l), meta.level_view(x, l), mean[l], rstd[l],
+                                       layer.gamma.t, layer.gamma.g, layer.beta.g, layer.groups, layer.relu, out=meta.level_view(dx, l))
+        return dx, None, None, None
 
 
 class _UpAddFn(torch.autograd.Function):
@@ -180,44 +257,41 @@ def relu(x):
 # level-first buffer (`big`), so no cat/permute is materialised.
 class _FocalSumFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, big, labels, alpha, gamma, rows, *levels):
-        ctx.big, ctx.labels, ctx.alpha, ctx.gamma, ctx.rows = big, labels, alpha, gamma, rows
-        return hip.sigmoid_focal_fwd(big, labels, alpha, gamma)
+    def forward(ctx, logits, labels, alpha, gamma):
+        ctx.alpha, ctx.gamma = alpha, gamma
+        ctx.save_for_backward(logits, labels)
+        return hip.sigmoid_focal_fwd(logits, labels, alpha, gamma)
 
     @staticmethod
     def backward(ctx, gout):
-        coef = gout.reshape(1).contiguous().float()
-        d = hip.sigmoid_focal_bwd(ctx.big, ctx.labels, ctx.alpha, ctx.gamma, coef)
-        grads = []
-        for (r0, r1, shape) in ctx.rows:
-            grads.append(d[r0:r1].view(shape))
-        return (None, None, None, None, None) + tuple(grads)
+        logits, labels = ctx.saved_tensors
+        return hip.sigmoid_focal_bwd(logits, labels, ctx.alpha, ctx.gamma, gout.reshape(1).contiguous().float()), None, None, None
 
 
-def focal_loss_sum(big, labels, alpha, gamma, rows, levels):
-    return _FocalSumFn.apply(big, labels, alpha, gamma, rows, *levels)
+def focal_loss_sum(logits, labels, alpha, gamma):
+    return _FocalSumFn.apply(logits, labels, alpha, gamma)
 
 
 class _LocTermsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, big, labels, reg_targets, bvars, args, rows, *levels):
-        ctx.big, ctx.labels, ctx.reg_targets, ctx.bvars, ctx.args, ctx.rows = big, labels, reg_targets, bvars, args, rows
+    def forward(ctx, box, labels, reg_targets, bvars, args):
+        ctx.args = args
+        ctx.has_bv = bvars is not None
+        ctx.save_for_backward(box, labels, reg_targets, bvars if bvars is not None else labels)
         nc, reg_max, tsb, tsc = args
-        return hip.fcos_loc_terms_fwd(labels, big, reg_targets, bvars, nc, reg_max, tsb, tsc)
+        return hip.fcos_loc_terms_fwd(labels, box, reg_targets, bvars, nc, reg_max, tsb, tsc)
 
     @staticmethod
     def backward(ctx, gsums):
+        box, labels, reg_targets, bv = ctx.saved_tensors
         nc, reg_max, tsb, tsc = ctx.args
         coef = torch.stack((gsums[2], gsums[3], gsums[4], gsums[6])).contiguous().float()
-        d = hip.fcos_loc_terms_bwd(ctx.labels, ctx.big, ctx.reg_targets, ctx.bvars, nc, reg_max, tsb, tsc, coef)
-        grads = []
-        for (r0, r1, shape) in ctx.rows:
-            grads.append(d[r0:r1].view(shape))
-        return (None, None, None, None, None, None) + tuple(grads)
+        d = hip.fcos_loc_terms_bwd(labels, box, reg_targets, bv if ctx.has_bv else None, nc, reg_max, tsb, tsc, coef)
+        return d, None, None, None, None
 
 
-def fcos_loc_terms(big, labels, reg_targets, bvars, args, rows, levels):
-    return _LocTermsFn.apply(big, labels, reg_targets, bvars, args, rows, *levels)
+def fcos_loc_terms(box, labels, reg_targets, bvars, args):
+    return _LocTermsFn.apply(box, labels, reg_targets, bvars, args)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -280,3 +354,27 @@ class _SoftmaxFocalFn(torch.autograd.Function):
 
 def softmax_focal_sum(logits, target, gamma):
     return _SoftmaxFocalFn.apply(logits, target, gamma)
+
+
+class _Subsample2Fn(torch.autograd.Function):
+    """x[:, ::2, ::2, :] written into a given destination view (LastLevelMaxPool: max_pool2d(k=1, s=2))."""
+
+    @staticmethod
+    def forward(ctx, x, out_holder):
+        ctx.shape = tuple(x.shape)
+        out = out_holder[0]
+        out.copy_(x[:, ::2, ::2, :])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        dx = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        dx[:, ::2, ::2, :] = g
+        return dx, None
+
+
+def subsample2_into(x, out):
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _Subsample2Fn.apply(x, (out,))
+    out.copy_(x[:, ::2, ::2, :])
+    return out
