@@ -20,7 +20,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse headline)
 
 
 def tune_for_pseudo_labels(trainer, batch, target_std=1.5, bias=-6.0):
@@ -33,50 +34,54 @@ def tune_for_pseudo_labels(trainer, batch, target_std=1.5, bias=-6.0):
     g = torch.Generator(device="cpu").manual_seed(0)
     w.copy_((torch.randn(w.shape, generator=g) * 0.01).to(w.device))
     b.zero_()
+    m.store.touch()
     m.eval()
     with torch.no_grad():
         _, raw = m(batch[3], output_raw=True, nms_method="cls", branch="teacher_weak")
         s = torch.cat([x.reshape(-1) for x in raw["logits_pred"]]).std()
     m.train()
+    m.store.touch()
     w.mul_(target_std / s.clamp(min=1e-12))
     b.fill_(bias)
     sd["proposal_generator.fcos_head.bbox_pred_std.bias"].fill_(-3.0)
+    m.store.touch()
     trainer._update_teacher_model(keep_rate=0.0)  # teacher := student
     sd["proposal_generator.fcos_head.bbox_pred_std.bias"].fill_(0.0)  # student less certain than teacher
+    m.store.touch()  # weights were edited in place: invalidate the bf16 mirror
 
 
 class ConvTimer:
-    """HIP-event timing of the dominant kernel (conv_igemm_f32<128,0>: every forward/dgrad conv with
-    Cout > 64 and Cin % 16 == 0) on the stream it is launched on, live inside the timed region."""
+    """HIP-event timing (torch events recorded on the stream the kernels are launched on) of every launch of
+    the dominant kernel inside the timed region.  Dominant kernel = the plain-NHWC implicit-GEMM conv with
+    Cout > 64 (forward AND dgrad launches of backbone / FPN / box-head layers):
+        bf16: conv_igemm_bf16<128,false>      f32: conv_igemm_f32<128,0,false>"""
 
-    def __init__(self):
+    def __init__(self, dtype):
         self.pairs = []
         self.enabled = False
+        self.entry = "utv2_conv2d_nhwc_fwd_bf16" if dtype == "bf16" else "utv2_conv2d_nhwc_fwd"
+        self.kernel = "conv_igemm_bf16<128,false>" if dtype == "bf16" else "conv_igemm_f32<128,0,false>"
 
     def install(self):
         from ubteacher import hip
-        orig = hip.conv2d_fwd
+        orig = hip.call
         timer = self
 
-        def wrapped(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, relu=False, kh=1, kw=1, out=None,
-                    in_dil=1, out_hw=None, accumulate=False):
-            N, H, W, C = x.shape
-            K = w.shape[0]
-            dominant = timer.enabled and K > 64 and C % 16 == 0 and w.shape[1] == kh * kw * C
-            if dominant:
-                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-            y = orig(x, w, scale, bias, residual, stride, pad, relu, kh, kw, out, in_dil, out_hw, accumulate)
-            if dominant:
-                e1.record()
-                if in_dil > 1:  # dgrad of a strided conv: algorithmic work is that of the forward conv
-                    macs = x.shape[0] * x.shape[1] * x.shape[2] * C * K * kh * kw
-                else:
-                    macs = y.shape[0] * y.shape[1] * y.shape[2] * K * kh * kw * C
-                timer.pairs.append((e0, e1, 2.0 * macs))
-            return y
+        def call(name, *args):
+            if not (timer.enabled and name == timer.entry):
+                return orig(name, *args)
+            N, H, W, C, K, KH, KW, stride, pad, in_dil, OH, OW = args[6:18]
+            if K <= 64 or C % 16 != 0 or (name == "utv2_conv2d_nhwc_fwd" and args[20] != KH * KW * C):
+                return orig(name, *args)  # another template instance
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(name, *args)
+            e1.record()
+            # algorithmic MACs: a strided conv's dgrad (in_dil > 1) does the forward conv's work
+            macs = N * OH * OW * K * KH * KW * C / (in_dil * in_dil if in_dil > 1 else 1)
+            timer.pairs.append((e0, e1, 2.0 * macs))
 
-        hip.conv2d_fwd = wrapped
+        hip.call = call
 
     def summary(self):
         if not self.pairs:
@@ -124,6 +129,8 @@ def main():
     ap.add_argument("--label", type=int, default=4, help="labeled images per GPU")
     ap.add_argument("--unlabel", type=int, default=4, help="unlabeled images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
+                    help="conv arithmetic: bf16 = the config's SOLVER.AMP.ENABLED path (bf16 MFMA, fp32 accumulate); f32 = exact-f32 MFMA")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -139,10 +146,10 @@ def main():
     from ubteacher import hip
     hip.load()
     cfg = get_config("fcos", 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label * world, "SOLVER.IMG_PER_BATCH_UNLABEL",
-                                 args.unlabel * world, "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", False,
+                                 args.unlabel * world, "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", args.dtype == "bf16",
                                  "MODEL.DEVICE", "cuda:%d" % local_rank])
     torch.manual_seed(0)
-    timer = ConvTimer()
+    timer = ConvTimer(args.dtype)
     timer.install()
     tr = UBTeacherTrainer(cfg)
     batch = tr._data_loader.batches[0]
@@ -182,16 +189,18 @@ def main():
             "metric": "images/sec/node (labeled+unlabeled) UTv2 step, R50-FPN 1333x800",
             "value": per_step_images * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "FCOS R50-FPN UTv2 sup1 (configs[1]): %d labeled + %d unlabeled 1333x800 images per GPU, "
                                    "post-burn-in semi-supervised step" % (args.label, args.unlabel),
-                       "global_batch": per_step_images, "parallelism": "dp%d" % world, "precision": "fp32 MFMA"},
+                       "global_batch": per_step_images, "parallelism": "dp%d" % world,
+                       "precision": "bf16 MFMA operands, fp32 accumulate/activations/master weights (config SOLVER.AMP.ENABLED)" if args.dtype == "bf16" else "fp32 MFMA"},
             "losses": {k: v for k, v in metrics.items() if k.startswith("loss") or k.startswith("teacher")},
         }
         if conv:
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_f32<128,0> (all fwd+dgrad launches)",
-                               "achieved": conv["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": conv["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+            out["roofline"] = {"bound": "mfma", "kernel": timer.kernel + " (all fwd+dgrad launches)",
+                               "achieved": conv["tflops"], "peak": peak, "unit": "TFLOP/s",
+                               "frac": conv["tflops"] / peak, "traffic": None,
                                "launches": conv["launches"], "avg_us": conv["avg_us"],
                                "time_share": conv["total_ms"] / (1e3 * dt)}
         if world == 1 and not args.no_cpu_baseline:

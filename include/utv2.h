@@ -50,6 +50,19 @@ int utv2_conv2d_ml_wgrad(const float* x, const float* dy, float* dw, float* ws, 
                          const int* W_host, int N, int C, int K, int KH, int KW, int pad, int accumulate,
                          utv2_stream_t stream);
 
+/* ---- mixed precision (the reference's SOLVER.AMP.ENABLED configs: autocast at engine/trainer.py:194-198,318-349):
+ * bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 activations in HBM (converted while
+ * staging into LDS), weights from a bf16 mirror of the arena.  Same contracts as the fp32 entry points. */
+int utv2_conv2d_bf16_supported(int C, int KH, int KW);
+int utv2_conv2d_nhwc_fwd_bf16(const float* x, const void* w16, float* y, const float* scale, const float* bias,
+                              const float* residual, int N, int H, int W, int C, int K, int KH, int KW, int stride, int pad,
+                              int in_dil, int OH, int OW, int relu, int accumulate, utv2_stream_t stream);
+int utv2_conv2d_ml_fwd_bf16(const float* x, const void* w16, float* y, const float* scale, const float* bias,
+                            const float* residual, int nlev, const int* H_host, const int* W_host, int N, int C, int K, int KH,
+                            int KW, int pad, int relu, int accumulate, utv2_stream_t stream);
+int utv2_f32_to_bf16(const float* src, void* dst16, int64_t n, utv2_stream_t stream);
+int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, int K, int KH, int KW, int C, utv2_stream_t stream);
+
 /* ---- teacher EMA: engine/trainer.py:468-486 (FCOS), :950-968 (RCNN) --------------------------
  * teacher = student*(1-keep) + teacher*keep, evaluated with the reference's three roundings. */
 int utv2_ema_axpby(float* teacher, const float* student, int64_t n, double keep_rate, utv2_stream_t stream);

@@ -26,6 +26,28 @@ import torch.nn.functional as F
 
 INF = 100000000
 
+# Emulation of the product's mixed-precision (AMP) conv path for parity tests: when set to "bf16", the
+# operands of every conv / linear whose input-channel count is a multiple of 32 are rounded to bf16
+# (round-to-nearest-even) before an fp32 convolution - exactly what the bf16-MFMA kernels compute
+# (bf16 operands, fp32 accumulate).  None = the reference's fp32 CPU arithmetic.
+CONV_ROUND = [None]
+
+
+def _r16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _conv2d(x, w, b=None, stride=1, padding=0):
+    if CONV_ROUND[0] == "bf16" and x.shape[1] % 32 == 0:
+        x, w = _r16(x), _r16(w)
+    return F.conv2d(x, w, b, stride, padding)
+
+
+def _linear(x, w, b=None):
+    if CONV_ROUND[0] == "bf16" and x.shape[1] % 32 == 0:
+        x, w = _r16(x), _r16(w)
+    return F.linear(x, w, b)
+
 
 # =================================================================================================
 # Third-party primitives (restated)
@@ -100,7 +122,7 @@ def frozen_bn(x, sd, prefix, eps=1e-5):
 def resnet50(sd, x, prefix, out_features):
     """D2 ResNet-50, STRIDE_IN_1X1 True, FrozenBN [D2-recall, SURVEY appendix C]."""
     outs = {}
-    x = F.conv2d(x, sd[prefix + ".stem.conv1.weight"], None, 2, 3)
+    x = _conv2d(x, sd[prefix + ".stem.conv1.weight"], None, 2, 3)
     x = F.relu(frozen_bn(x, sd, prefix + ".stem.conv1.norm"))
     x = F.max_pool2d(x, 3, 2, 1)
     for name, nblocks in (("res2", 3), ("res3", 4), ("res4", 6), ("res5", 3)):
@@ -108,12 +130,12 @@ def resnet50(sd, x, prefix, out_features):
             p = "%s.%s.%d" % (prefix, name, b)
             stride = 2 if (b == 0 and name != "res2") else 1
             if (p + ".shortcut.weight") in sd:
-                sc = frozen_bn(F.conv2d(x, sd[p + ".shortcut.weight"], None, stride), sd, p + ".shortcut.norm")
+                sc = frozen_bn(_conv2d(x, sd[p + ".shortcut.weight"], None, stride), sd, p + ".shortcut.norm")
             else:
                 sc = x
-            o = F.relu(frozen_bn(F.conv2d(x, sd[p + ".conv1.weight"], None, stride), sd, p + ".conv1.norm"))
-            o = F.relu(frozen_bn(F.conv2d(o, sd[p + ".conv2.weight"], None, 1, 1), sd, p + ".conv2.norm"))
-            o = frozen_bn(F.conv2d(o, sd[p + ".conv3.weight"], None, 1), sd, p + ".conv3.norm")
+            o = F.relu(frozen_bn(_conv2d(x, sd[p + ".conv1.weight"], None, stride), sd, p + ".conv1.norm"))
+            o = F.relu(frozen_bn(_conv2d(o, sd[p + ".conv2.weight"], None, 1, 1), sd, p + ".conv2.norm"))
+            o = frozen_bn(_conv2d(o, sd[p + ".conv3.weight"], None, 1), sd, p + ".conv3.norm")
             x = F.relu(o + sc)
         if name in out_features:
             outs[name] = x
@@ -127,15 +149,15 @@ def fpn(sd, feats, in_features, top="p6p7", prefix="backbone"):
     prev = None
     for f in reversed(in_features):
         s = stage[f]
-        lat = F.conv2d(feats[f], sd["%s.fpn_lateral%d.weight" % (prefix, s)], sd["%s.fpn_lateral%d.bias" % (prefix, s)])
+        lat = _conv2d(feats[f], sd["%s.fpn_lateral%d.weight" % (prefix, s)], sd["%s.fpn_lateral%d.bias" % (prefix, s)])
         if prev is not None:
             lat = lat + F.interpolate(prev, scale_factor=2.0, mode="nearest")
         prev = lat
-        res["p%d" % s] = F.conv2d(lat, sd["%s.fpn_output%d.weight" % (prefix, s)], sd["%s.fpn_output%d.bias" % (prefix, s)], 1, 1)
+        res["p%d" % s] = _conv2d(lat, sd["%s.fpn_output%d.weight" % (prefix, s)], sd["%s.fpn_output%d.bias" % (prefix, s)], 1, 1)
     last = stage[in_features[-1]]
     if top == "p6p7":
-        p6 = F.conv2d(res["p%d" % last], sd[prefix + ".top_block.p6.weight"], sd[prefix + ".top_block.p6.bias"], 2, 1)
-        p7 = F.conv2d(F.relu(p6), sd[prefix + ".top_block.p7.weight"], sd[prefix + ".top_block.p7.bias"], 2, 1)
+        p6 = _conv2d(res["p%d" % last], sd[prefix + ".top_block.p6.weight"], sd[prefix + ".top_block.p6.bias"], 2, 1)
+        p7 = _conv2d(F.relu(p6), sd[prefix + ".top_block.p7.weight"], sd[prefix + ".top_block.p7.bias"], 2, 1)
         res["p%d" % (last + 1)] = p6
         res["p%d" % (last + 2)] = p7
     elif top == "maxpool":
@@ -164,21 +186,21 @@ def fcos_head(sd, feats, num_levels=5, prefix="proposal_generator.fcos_head"):
         def tower(name, x):
             i = 0
             while "%s.%s_tower.%d.weight" % (prefix, name, 3 * i) in sd:
-                x = F.conv2d(x, sd["%s.%s_tower.%d.weight" % (prefix, name, 3 * i)], sd["%s.%s_tower.%d.bias" % (prefix, name, 3 * i)], 1, 1)
+                x = _conv2d(x, sd["%s.%s_tower.%d.weight" % (prefix, name, 3 * i)], sd["%s.%s_tower.%d.bias" % (prefix, name, 3 * i)], 1, 1)
                 x = F.group_norm(x, 32, sd["%s.%s_tower.%d.weight" % (prefix, name, 3 * i + 1)], sd["%s.%s_tower.%d.bias" % (prefix, name, 3 * i + 1)])
                 x = F.relu(x)
                 i += 1
             return x
         f = tower("share", f)
         ct, bt = tower("cls", f), tower("bbox", f)
-        logits.append(F.conv2d(ct, sd[prefix + ".cls_logits.weight"], sd[prefix + ".cls_logits.bias"], 1, 1))
-        ctr.append(F.conv2d(bt, sd[prefix + ".ctrness.weight"], sd[prefix + ".ctrness.bias"], 1, 1))
-        r = F.conv2d(bt, sd[prefix + ".bbox_pred.weight"], sd[prefix + ".bbox_pred.bias"], 1, 1)
+        logits.append(_conv2d(ct, sd[prefix + ".cls_logits.weight"], sd[prefix + ".cls_logits.bias"], 1, 1))
+        ctr.append(_conv2d(bt, sd[prefix + ".ctrness.weight"], sd[prefix + ".ctrness.bias"], 1, 1))
+        r = _conv2d(bt, sd[prefix + ".bbox_pred.weight"], sd[prefix + ".bbox_pred.bias"], 1, 1)
         key = "%s.scales.%d.scale" % (prefix, l)
         if key in sd:
             r = r * sd[key]
         reg.append(r)  # REG_DISCRETE: no relu (fcos.py:360-364)
-        std.append(F.conv2d(bt, sd[prefix + ".bbox_pred_std.weight"], sd[prefix + ".bbox_pred_std.bias"], 1, 1))
+        std.append(_conv2d(bt, sd[prefix + ".bbox_pred_std.weight"], sd[prefix + ".bbox_pred_std.bias"], 1, 1))
     return logits, reg, std, ctr
 
 
@@ -509,7 +531,8 @@ def fcos_forward(sd, images, mean, std_pix, trainable_keys=None):
 
 
 def fcos_semisup_step(cfg, student_sd, teacher_sd, batch, keep_rate, lam_u=3.0, lam_r=0.2, thr_cls=0.5, thr_reg=0.5,
-                      lr=0.01, momentum=0.9, wd=1e-4, bufs=None, mean=None, pix_std=None, frozen_prefixes=("backbone.bottom_up.stem", "backbone.bottom_up.res2")):
+                      lr=0.01, momentum=0.9, wd=1e-4, bufs=None, mean=None, pix_std=None, frozen_prefixes=("backbone.bottom_up.stem", "backbone.bottom_up.res2"),
+                      pseudo_override=None):
     """One post-burn-in iteration of UBTeacherTrainer.run_step_full_semisup (engine/trainer.py:212-429),
     fp32 (no AMP).  batch = (label_q, label_k, unlabel_q, unlabel_k) lists of dicts with 'image' (+ 'gt')."""
     mean = mean if mean is not None else torch.tensor([103.53, 116.28, 123.675]).view(3, 1, 1)
@@ -523,6 +546,8 @@ def fcos_semisup_step(cfg, student_sd, teacher_sd, batch, keep_rate, lam_u=3.0, 
         det_loc = fcos_predict(cfg, *tl[:4], tl[4], tl[5], "cls_n_loc")
     pseudo_cls = [threshold_bbox(d, thr_cls) for d in det_cls]
     pseudo_reg = [threshold_bbox(d, thr_reg) for d in det_loc]
+    if pseudo_override is not None:  # (mixed-precision tests: decouple the student check from teacher selection noise)
+        pseudo_cls, pseudo_reg = pseudo_override
     params = {k: v.clone().requires_grad_(True) for k, v in student_sd.items()
               if v.dtype.is_floating_point and "norm." not in k and not k.startswith(frozen_prefixes)
               and k not in ("pixel_mean", "pixel_std") and not k.endswith("integral.project")}
@@ -654,9 +679,9 @@ def rpn_head(sd, feats, prefix="proposal_generator.rpn_head"):
     """D2 StandardRPNHead [D2-recall]; outputs flattened to the (H, W, A) anchor order of rpn.py:33-46."""
     obj, dl = [], []
     for f in feats:
-        t = F.relu(F.conv2d(f, sd[prefix + ".conv.weight"], sd[prefix + ".conv.bias"], 1, 1))
-        o = F.conv2d(t, sd[prefix + ".objectness_logits.weight"], sd[prefix + ".objectness_logits.bias"])
-        d = F.conv2d(t, sd[prefix + ".anchor_deltas.weight"], sd[prefix + ".anchor_deltas.bias"])
+        t = F.relu(_conv2d(f, sd[prefix + ".conv.weight"], sd[prefix + ".conv.bias"], 1, 1))
+        o = _conv2d(t, sd[prefix + ".objectness_logits.weight"], sd[prefix + ".objectness_logits.bias"])
+        d = _conv2d(t, sd[prefix + ".anchor_deltas.weight"], sd[prefix + ".anchor_deltas.bias"])
         obj.append(o.permute(0, 2, 3, 1).flatten(1))
         dl.append(d.view(d.shape[0], -1, 4, d.shape[-2], d.shape[-1]).permute(0, 3, 4, 1, 2).flatten(1, -2))
     return obj, dl
@@ -764,12 +789,12 @@ def roi_pool(feats, boxes_per_im, out=7):
 
 def box_head(sd, x, prefix="roi_heads"):
     x = x.flatten(1)
-    x = F.relu(F.linear(x, sd[prefix + ".box_head.fc1.weight"], sd[prefix + ".box_head.fc1.bias"]))
-    x = F.relu(F.linear(x, sd[prefix + ".box_head.fc2.weight"], sd[prefix + ".box_head.fc2.bias"]))
+    x = F.relu(_linear(x, sd[prefix + ".box_head.fc1.weight"], sd[prefix + ".box_head.fc1.bias"]))
+    x = F.relu(_linear(x, sd[prefix + ".box_head.fc2.weight"], sd[prefix + ".box_head.fc2.bias"]))
     p = prefix + ".box_predictor"
-    return (F.linear(x, sd[p + ".cls_score.weight"], sd[p + ".cls_score.bias"]),
-            F.linear(x, sd[p + ".bbox_pred.weight"], sd[p + ".bbox_pred.bias"]),
-            F.linear(x, sd[p + ".bbox_pred_std.weight"], sd[p + ".bbox_pred_std.bias"]))
+    return (_linear(x, sd[p + ".cls_score.weight"], sd[p + ".cls_score.bias"]),
+            _linear(x, sd[p + ".bbox_pred.weight"], sd[p + ".bbox_pred.bias"]),
+            _linear(x, sd[p + ".bbox_pred_std.weight"], sd[p + ".bbox_pred_std.bias"]))
 
 
 def softmax_focal(scores, gt_classes, gamma=1.5):

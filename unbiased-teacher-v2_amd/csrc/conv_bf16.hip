@@ -1,0 +1,324 @@
+// Mixed-precision (AMP) implicit-GEMM convolution for gfx950: bf16 operands on
+// v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s dense), fp32 accumulate, fp32 activations in HBM.
+//
+// This is the MI355X counterpart of the reference's `SOLVER.AMP.ENABLED: True` FCOS configs
+// (autocast around the model calls, ubteacher/engine/trainer.py:194-198,318-349): conv operands
+// are rounded to a 16-bit float, products accumulate in fp32.  Activations stay fp32 in memory
+// (so every non-conv kernel is shared with the fp32 path); the loader converts them to bf16
+// (round-to-nearest-even) while staging into LDS.  Weights come from a bf16 mirror of the arena.
+//
+// Same tiling as conv.hip (128 x BN tile, 4 waves as 2x2, each 2 x TN 32x32 accumulators) with
+// BK = 32: a row of the LDS tile is 32 bf16 = 64 B (+16 B pad -> the same conflict-free 80-byte
+// stride); each thread stages 8 consecutive k of a row (two 16-byte global loads -> one
+// ds_write_b128); each MFMA reads one ds_read_b128 per operand fragment.
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+#define CONV_MAX_LEVELS 8
+struct LevelTab {
+  int n;
+  int start[CONV_MAX_LEVELS + 1];
+  int H[CONV_MAX_LEVELS], W[CONV_MAX_LEVELS];
+};
+
+struct ConvArgs16 {
+  LevelTab lt;
+  const float* x;            // fp32 NHWC activations
+  const __bf16* w;           // bf16 [K][Kred]
+  float* y;
+  const float* scale;
+  const float* bias;
+  const float* residual;
+  int N, H, W, C, OH, OW, K, KH, KW, stride, pad, in_dil, relu, Kred, M, accumulate;
+};
+
+__device__ __forceinline__ void ml_decode16(const LevelTab& lt, int m, int& pixbase, int& H, int& W, int& oh, int& ow) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < CONV_MAX_LEVELS; ++i)
+    if (i < lt.n && m >= lt.start[i]) l = i;
+  H = lt.H[l];
+  W = lt.W[l];
+  const int r = m - lt.start[l], hw = H * W;
+  const int n = r / hw, rem = r - n * hw;
+  oh = rem / W;
+  ow = rem - oh * W;
+  pixbase = lt.start[l] + n * hw;
+}
+
+template <int BN, bool ML>
+__global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
+  constexpr int BM = 128, BK = 32, LDB = 80;  // LDS row stride in BYTES
+  constexpr int TM = 2, TN = BN / 64, BROWS = BN / 64;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * LDB];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + 2 * BM * LDB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tilesN = (p.K + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  int tile;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int mt = tile / tilesN, nt = tile - mt * tilesN;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int lrow = tid >> 2, kg = tid & 3;
+
+  int ih0[2], iw0[2], Hr[2], Wr[2];
+  long long pixbase[2];
+  bool mvalid[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int m = m0 + lrow + 64 * r;
+    mvalid[r] = m < p.M;
+    const int mm = mvalid[r] ? m : 0;
+    if constexpr (ML) {
+      int pb, oh, ow;
+      ml_decode16(p.lt, mm, pb, Hr[r], Wr[r], oh, ow);
+      ih0[r] = oh - p.pad;
+      iw0[r] = ow - p.pad;
+      pixbase[r] = pb;
+    } else {
+      const int hw = p.OH * p.OW;
+      const int n = mm / hw, rem = mm - n * hw;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      ih0[r] = oh * p.stride - p.pad;
+      iw0[r] = ow * p.stride - p.pad;
+      pixbase[r] = (long long)n * p.H * p.W;
+      Hr[r] = p.H;
+      Wr[r] = p.W;
+    }
+  }
+  bool bvalid[BROWS];
+  const __bf16* wrow[BROWS];
+#pragma unroll
+  for (int r = 0; r < BROWS; ++r) {
+    const int co = n0 + lrow + 64 * r;
+    bvalid[r] = co < p.K;
+    wrow[r] = p.w + (size_t)(bvalid[r] ? co : 0) * p.Kred;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nchunks = p.Kred / BK;
+  int kh = 0, kw = 0, c0 = 0;
+  f32x4 ra[2][2];
+  bf16x8_t rb[BROWS];
+
+  auto gload = [&](int kc) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      int ihn = ih0[r] + kh, iwn = iw0[r] + kw;
+      bool ok = mvalid[r];
+      int ih = ihn, iw = iwn;
+      if (p.in_dil > 1) {
+        ok = ok && (ihn % p.in_dil == 0) && (iwn % p.in_dil == 0);
+        ih = ihn / p.in_dil;
+        iw = iwn / p.in_dil;
+      }
+      ok = ok && (unsigned)ih < (unsigned)Hr[r] && (unsigned)iw < (unsigned)Wr[r];
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const float* src = p.x + (size_t)(pixbase[r] + (long long)ih * Wr[r] + iw) * p.C + c0 + kg * 8;
+        v0 = *(const f32x4*)src;
+        v1 = *(const f32x4*)(src + 4);
+      }
+      ra[r][0] = v0;
+      ra[r][1] = v1;
+    }
+#pragma unroll
+    for (int r = 0; r < BROWS; ++r) {
+      bf16x8_t v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+      if (bvalid[r]) v = *(const bf16x8_t*)(wrow[r] + kc * BK + kg * 8);
+      rb[r] = v;
+    }
+    c0 += BK;
+    if (c0 == p.C) {
+      c0 = 0;
+      if (++kw == p.KW) { kw = 0; ++kh; }
+    }
+  };
+  auto lds_store = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      bf16x8_t v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = (__bf16)ra[r][0][e];
+        v[4 + e] = (__bf16)ra[r][1][e];
+      }
+      *(bf16x8_t*)(As + buf * BM * LDB + (lrow + 64 * r) * LDB + kg * 16) = v;
+    }
+#pragma unroll
+    for (int r = 0; r < BROWS; ++r) *(bf16x8_t*)(Bs + buf * BN * LDB + (lrow + 64 * r) * LDB + kg * 16) = rb[r];
+  };
+
+  gload(0);
+  lds_store(0);
+  __syncthreads();
+  const int frow = lane & 31, fh = lane >> 5;
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nchunks) gload(kc + 1);
+    bf16x8_t a[TM][2], b[TN][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const unsigned char* ap = As + buf * BM * LDB + (wm * 64 + i * 32 + frow) * LDB + fh * 16;
+      a[i][0] = *(const bf16x8_t*)ap;
+      a[i][1] = *(const bf16x8_t*)(ap + 32);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const unsigned char* bp = Bs + buf * BN * LDB + (wn * (BN / 2) + j * 32 + frow) * LDB + fh * 16;
+      b[j][0] = *(const bf16x8_t*)bp;
+      b[j][1] = *(const bf16x8_t*)(bp + 32);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    if (kc + 1 < nchunks) lds_store(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + wn * (BN / 2) + j * 32 + frow;
+    if (co >= p.K) continue;
+    const float sc = p.scale ? p.scale[co] : 1.f;
+    const float bi = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (m >= p.M) continue;
+        const size_t off = (size_t)m * p.K + co;
+        float v = acc[i][j][e] * sc + bi;
+        if (p.residual) v += p.residual[off];
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.accumulate) v += p.y[off];
+        p.y[off] = v;
+      }
+    }
+  }
+}
+
+// dst bf16 = RNE(src fp32)
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n4) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    const f32x4 v = ((const f32x4*)src)[i];
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    bf16x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+    ((bf16x4_t*)dst)[i] = o;
+  }
+}
+
+// wt16[ci][KH-1-kh][KW-1-kw][co] = bf16(w[co][kh][kw][ci])
+__global__ void weight_flip_transpose_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int K, int KH, int KW, int C) {
+  const size_t n = (size_t)K * KH * KW * C;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    size_t t = i;
+    const int co = (int)(t % K); t /= K;
+    const int kwp = (int)(t % KW); t /= KW;
+    const int khp = (int)(t % KH); t /= KH;
+    const int ci = (int)t;
+    wt[i] = (__bf16)w[(((size_t)co * KH + (KH - 1 - khp)) * KW + (KW - 1 - kwp)) * C + ci];
+  }
+}
+
+static int fill_levels16(LevelTab& lt, int nlev, int N, const int* H, const int* W) {
+  lt.n = nlev;
+  int off = 0;
+  for (int l = 0; l < CONV_MAX_LEVELS; ++l) {
+    lt.start[l] = off;
+    if (l < nlev) {
+      lt.H[l] = H[l];
+      lt.W[l] = W[l];
+      off += N * H[l] * W[l];
+    } else {
+      lt.H[l] = lt.W[l] = 1;
+    }
+  }
+  lt.start[CONV_MAX_LEVELS] = off;
+  return off;
+}
+
+extern "C" {
+
+// 1 if the bf16 MFMA kernel supports this conv (C % 32 == 0), else the caller uses the fp32 kernel
+int utv2_conv2d_bf16_supported(int C, int KH, int KW) { return (C % 32 == 0) ? 1 : 0; }
+
+// w16: bf16 [K][KH*KW*C].  Otherwise identical contract to utv2_conv2d_nhwc_fwd (also serves as dgrad).
+int utv2_conv2d_nhwc_fwd_bf16(const float* x, const void* w16, float* y, const float* scale, const float* bias,
+                              const float* residual, int N, int H, int W, int C, int K, int KH, int KW, int stride, int pad,
+                              int in_dil, int OH, int OW, int relu, int accumulate, hipStream_t stream) {
+  if (!x || !w16 || !y || (C % 32)) return UTV2_EARG;
+  ConvArgs16 a;
+  a.lt.n = 0;
+  a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.K = K; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+  a.in_dil = in_dil < 1 ? 1 : in_dil; a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.M = N * OH * OW;
+  const bool small = K <= 64;
+  const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
+  if (small) hipLaunchKernelGGL((conv_igemm_bf16<64, false>), dim3(tiles), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv_igemm_bf16<128, false>), dim3(tiles), dim3(256), 0, stream, a);
+  return utv2_launch_status();
+}
+
+int utv2_conv2d_ml_fwd_bf16(const float* x, const void* w16, float* y, const float* scale, const float* bias,
+                            const float* residual, int nlev, const int* H_host, const int* W_host, int N, int C, int K, int KH,
+                            int KW, int pad, int relu, int accumulate, hipStream_t stream) {
+  if (!x || !w16 || !y || nlev < 1 || nlev > CONV_MAX_LEVELS || (C % 32) || N <= 0) return UTV2_EARG;
+  ConvArgs16 a;
+  a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
+  a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual;
+  a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad; a.in_dil = 1;
+  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C;
+  const bool small = K <= 64;
+  const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
+  if (small) hipLaunchKernelGGL((conv_igemm_bf16<64, true>), dim3(tiles), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv_igemm_bf16<128, true>), dim3(tiles), dim3(256), 0, stream, a);
+  return utv2_launch_status();
+}
+
+// n must be a multiple of 4; dst16: bf16[n]
+int utv2_f32_to_bf16(const float* src, void* dst16, int64_t n, hipStream_t stream) {
+  if (!src || !dst16 || (n & 3)) return UTV2_EARG;
+  if (n == 0) return UTV2_OK;
+  size_t nb = ((size_t)n / 4 + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((int)nb), dim3(256), 0, stream, src, (__bf16*)dst16, (size_t)n / 4);
+  return utv2_launch_status();
+}
+
+int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, int K, int KH, int KW, int C, hipStream_t stream) {
+  if (!w || !wt16) return UTV2_EARG;
+  const size_t n = (size_t)K * KH * KW * C;
+  int nb = cdiv((int64_t)n, 256);
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(weight_flip_transpose_bf16_kernel, dim3(nb), dim3(256), 0, stream, w, (__bf16*)wt16, K, KH, KW, C);
+  return utv2_launch_status();
+}
+
+}  // extern "C"

@@ -56,6 +56,7 @@ class ArenaSGD:
             if e > s:
                 hip.sgd_momentum(st.flat[s:e], st.grad[s:e], st.mom[s:e], lr, self.momentum, wd, grad_scale, zero_grad=False)
         ops.bump_version()
+        st.touch()
 
     def state_dict(self):
         return {"momentum_buffer": self.store.mom, "lr": self.param_groups[0]["lr"]}
@@ -138,6 +139,10 @@ class _TrainerBase:
 
     def _common_init(self, cfg, data_loader=None):
         self.cfg = cfg
+        # SOLVER.AMP.ENABLED (reference: autocast + GradScaler, trainer.py:194-198,423-426) selects the bf16-MFMA conv
+        # kernels; bf16 has fp32's exponent range so no loss scaling is needed.  UTV2_PRECISION overrides.
+        import os
+        ops.set_precision(os.environ.get("UTV2_PRECISION", "bf16" if cfg.SOLVER.AMP.ENABLED else "fp32"))
         self.start_iter = 0
         self.max_iter = cfg.SOLVER.MAX_ITER
         self.iter = 0
@@ -192,6 +197,7 @@ class _TrainerBase:
                 if k not in sk:
                     raise Exception("{} is not found in student model".format(k))
         hip.ema_axpby(self.model_teacher.flat_state(), self.model.flat_state(), keep_rate)
+        self.model_teacher.store.touch()
 
     # -- gradient exchange: ONE flat all-reduce (DDP mean semantics) -------------------------------------
     def _allreduce_grads(self):

@@ -53,7 +53,7 @@ def _parse_header(path):
 
 
 _SIGS = _parse_header(HEADER_PATH)
-_PLAIN = {"utv2_conv2d_wgrad_splits", "utv2_conv2d_wgrad_workspace_floats", "utv2_groupnorm_workspace_floats",
+_PLAIN = {"utv2_conv2d_bf16_supported", "utv2_conv2d_wgrad_splits", "utv2_conv2d_wgrad_workspace_floats", "utv2_groupnorm_workspace_floats",
           "utv2_nms_mpad", "utv2_nms_workspace_bytes"}  # return a value, not a status
 
 
@@ -481,3 +481,52 @@ def conv2d_ml_wgrad(x2d, dy2d, dw, level_hw, N, k, pad, accumulate=True):
     call("utv2_conv2d_ml_wgrad", _p(x2d), _p(dy2d), _p(dw), _p(ws), len(level_hw), ctypes.cast(H, c_p), ctypes.cast(W, c_p), N, C, K,
          k, k, pad, int(accumulate), _stream())
     return dw
+
+
+# --------------------------------------------------------------------------------------------
+# mixed precision (bf16 MFMA operands, fp32 accumulate / activations)
+def f32_to_bf16(src, dst16):
+    call("utv2_f32_to_bf16", _p(src), _p(dst16), src.numel(), _stream())
+
+
+def weight_flip_transpose_bf16(w, K, kh, kw, C):
+    wt = torch.empty((C, kh * kw * K), dtype=torch.bfloat16, device=w.device)
+    call("utv2_weight_flip_transpose_bf16", _p(w), _p(wt), K, kh, kw, C, _stream())
+    return wt
+
+
+def conv2d_fwd_bf16(x, w16, scale=None, bias=None, residual=None, stride=1, pad=0, relu=False, kh=1, kw=1, out=None,
+                    in_dil=1, out_hw=None, accumulate=False):
+    N, H, W, C = x.shape
+    K = w16.shape[0]
+    assert w16.dtype == torch.bfloat16 and C % 32 == 0
+    if out_hw is None:
+        OH, OW = conv_out_size(H, kh, stride, pad), conv_out_size(W, kw, stride, pad)
+    else:
+        OH, OW = out_hw
+    if out is None:
+        out = torch.empty((N, OH, OW, K), dtype=torch.float32, device=x.device)
+    call("utv2_conv2d_nhwc_fwd_bf16", _p(x), _p(w16), _p(out), _p(scale), _p(bias), _p(residual), N, H, W, C, K, kh, kw, stride,
+         pad, in_dil, OH, OW, int(relu), int(accumulate), _stream())
+    return out
+
+
+def conv2d_dgrad_bf16(dy, wt16, in_shape, stride, pad, kh, kw, out=None):
+    N, H, W, C = in_shape
+    _, OH, OW, K = dy.shape
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
+    call("utv2_conv2d_nhwc_fwd_bf16", _p(dy), _p(wt16), _p(out), c_p(0), c_p(0), c_p(0), N, OH, OW, K, C, kh, kw, 1, kh - 1 - pad,
+         stride, H, W, 0, 0, _stream())
+    return out
+
+
+def conv2d_ml_fwd_bf16(x2d, w16, level_hw, N, scale=None, bias=None, residual=None, k=3, pad=1, relu=False, out=None):
+    P, C = x2d.shape
+    K = w16.shape[0]
+    if out is None:
+        out = torch.empty((P, K), dtype=torch.float32, device=x2d.device)
+    H = _iarr([h for h, _ in level_hw]); W = _iarr([w_ for _, w_ in level_hw])
+    call("utv2_conv2d_ml_fwd_bf16", _p(x2d), _p(w16), _p(out), _p(scale), _p(bias), _p(residual), len(level_hw), ctypes.cast(H, c_p),
+         ctypes.cast(W, c_p), N, C, K, k, k, pad, int(relu), 0, _stream())
+    return out

@@ -13,6 +13,14 @@ import torch
 from . import hip
 
 _HOOKS = {}
+PRECISION = ["fp32"]  # "fp32" (exact-f32 MFMA; the parity path) or "bf16" (AMP: bf16 MFMA operands, fp32 accumulate)
+
+
+def set_precision(p):
+    assert p in ("fp32", "bf16")
+    PRECISION[0] = p
+
+
 _VERSION = [0]  # bumped by the optimizer step: invalidates cached dgrad weight images
 
 
@@ -79,10 +87,24 @@ class Conv:
         return None, (self.bias.t if self.bias is not None else None)
 
     def wt(self):
-        if self._wt is None or self._wt_version != _VERSION[0]:
+        v = (_VERSION[0], self.w.store.version)
+        if self._wt is None or self._wt_version != v:
             self._wt = hip.weight_flip_transpose(self.w.t, self.cout, self.k, self.k, self.cin)
-            self._wt_version = _VERSION[0]
+            self._wt_version = v
         return self._wt
+
+    def wt16(self):
+        v = (_VERSION[0], self.w.store.version)
+        if getattr(self, "_wt16", None) is None or self._wt16_version != v:
+            self._wt16 = hip.weight_flip_transpose_bf16(self.w.t, self.cout, self.k, self.k, self.cin)
+            self._wt16_version = v
+        return self._wt16
+
+    def use_bf16(self):
+        return PRECISION[0] == "bf16" and self.cin % 32 == 0 and self.kred == self.k * self.k * self.cin
+
+    def use_bf16_dgrad(self):
+        return PRECISION[0] == "bf16" and self.cout % 32 == 0
 
     def __call__(self, x, residual=None, out=None, colscale_handle=None, meta=None):
         """x: NHWC tensor, or a level-first [P, C] matrix with `meta` (one launch for all levels; k x k
@@ -93,17 +115,21 @@ class Conv:
 
     def _forward(self, x, residual, out, cs, meta):
         sc, sh = self.scale_shift()
+        b16 = self.use_bf16()
+        w = self.w.store.bf16(self.w) if b16 else self.w.t
         if meta is not None and self.k > 1:
             assert self.stride == 1 and self.pad == (self.k - 1) // 2
-            y = hip.conv2d_ml_fwd(x, self.w.t, meta.level_hw, meta.N, scale=sc, bias=sh, residual=residual, k=self.k,
-                                  pad=self.pad, relu=self.relu, out=out)
+            fn = hip.conv2d_ml_fwd_bf16 if b16 else hip.conv2d_ml_fwd
+            y = fn(x, w, meta.level_hw, meta.N, scale=sc, bias=sh, residual=residual, k=self.k, pad=self.pad, relu=self.relu, out=out)
         elif meta is not None:  # 1x1 on a level-first matrix: plain GEMM rows
-            y = hip.conv2d_fwd(x.view(1, x.shape[0], 1, x.shape[1]), self.w.t, scale=sc, bias=sh,
-                               residual=None if residual is None else residual.view(1, x.shape[0], 1, -1), relu=self.relu,
-                               out=None if out is None else out.view(1, x.shape[0], 1, -1)).view(x.shape[0], self.cout)
+            fn = hip.conv2d_fwd_bf16 if b16 else hip.conv2d_fwd
+            y = fn(x.view(1, x.shape[0], 1, x.shape[1]), w, scale=sc, bias=sh,
+                   residual=None if residual is None else residual.view(1, x.shape[0], 1, -1), relu=self.relu,
+                   out=None if out is None else out.view(1, x.shape[0], 1, -1)).view(x.shape[0], self.cout)
         else:
-            y = hip.conv2d_fwd(x, self.w.t, scale=sc, bias=sh, residual=residual, stride=self.stride, pad=self.pad,
-                               relu=self.relu, kh=self.k, kw=self.k, out=out)
+            fn = hip.conv2d_fwd_bf16 if b16 else hip.conv2d_fwd
+            y = fn(x, w, scale=sc, bias=sh, residual=residual, stride=self.stride, pad=self.pad, relu=self.relu, kh=self.k,
+                   kw=self.k, out=out)
         if cs is not None:
             if meta is not None:
                 for l, h in enumerate(cs):
@@ -156,15 +182,22 @@ class _ConvFn(torch.autograd.Function):
             else:
                 g = dy
         dx = None
+        d16 = layer.use_bf16_dgrad()
         if meta is not None and layer.k > 1:
             if ctx.needs_input_grad[0]:
-                dx = hip.conv2d_ml_dgrad(g, layer.wt(), meta.level_hw, meta.N, layer.k, layer.pad)
+                if d16:
+                    dx = hip.conv2d_ml_fwd_bf16(g, layer.wt16(), meta.level_hw, meta.N, k=layer.k, pad=layer.k - 1 - layer.pad)
+                else:
+                    dx = hip.conv2d_ml_dgrad(g, layer.wt(), meta.level_hw, meta.N, layer.k, layer.pad)
             hip.conv2d_ml_wgrad(x, g, layer.w.g, meta.level_hw, meta.N, layer.k, layer.pad, accumulate=True)
         else:
             x4 = x.view(1, x.shape[0], 1, x.shape[1]) if meta is not None else x
             g4 = g.view(1, g.shape[0], 1, g.shape[1]) if meta is not None else g
             if ctx.needs_input_grad[0]:
-                dx = hip.conv2d_dgrad(g4, layer.wt(), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k)
+                if d16:
+                    dx = hip.conv2d_dgrad_bf16(g4, layer.wt16(), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k)
+                else:
+                    dx = hip.conv2d_dgrad(g4, layer.wt(), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k)
                 if meta is not None:
                     dx = dx.view(x.shape)
             hip.conv2d_wgrad(x4, g4, layer.w.g, layer.stride, layer.pad, layer.k, layer.k, accumulate=True)

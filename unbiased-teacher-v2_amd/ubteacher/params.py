@@ -22,7 +22,7 @@ _ORDER = ("decay", "nodecay", "frozen", "bn_w", "bn_b", "buffer", "bn_m", "bn_v"
 
 
 class Handle:
-    __slots__ = ("shape", "kind", "init", "numel", "offset", "t", "g", "exports", "loaders")
+    __slots__ = ("shape", "kind", "init", "numel", "offset", "t", "g", "exports", "loaders", "store")
 
     def __init__(self, shape, kind, init):
         self.shape = tuple(int(s) for s in shape)
@@ -56,6 +56,7 @@ class ParamStore:
         assert not self.finalized
         assert kind in _ORDER, kind
         h = Handle(shape, kind, init)
+        h.store = self
         self.handles.append(h)
         return h
 
@@ -83,10 +84,26 @@ class ParamStore:
             if h.kind in ("decay", "nodecay"):
                 h.g = self.grad[h.offset: h.offset + h.numel].view(h.shape)
         self.finalized = True
+        self.version = 0      # bumped whenever the arena content changes (SGD step, EMA, load_state_dict)
+        self._flat16 = None   # bf16 mirror for the mixed-precision conv kernels
+        self._v16 = -1
         for h in self.handles:
             if h.init is not None:
                 h.init(h.t)
         return self
+
+    def touch(self):
+        self.version += 1
+
+    def bf16(self, h):
+        """bf16 view of handle `h` from the arena's bf16 mirror (ONE conversion launch per arena version)."""
+        if self._flat16 is None:
+            self._flat16 = torch.empty(self.total, dtype=torch.bfloat16, device=self.flat.device)
+        if self._v16 != self.version:
+            from . import hip
+            hip.f32_to_bf16(self.flat, self._flat16)
+            self._v16 = self.version
+        return self._flat16[h.offset: h.offset + h.numel].view(h.shape)
 
     def region(self, kind):
         s, e = self.ranges[kind]
@@ -133,4 +150,5 @@ class ParamStore:
                         loaders[k][1](loaders[k][0].t, src)
                     else:
                         v.copy_(src)
+        self.touch()
         return missing, unexpected
