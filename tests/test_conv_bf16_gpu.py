@@ -118,3 +118,41 @@ def test_fcos_step_bf16_vs_rounding_oracle():
     t_after = cpu_state(tr.model_teacher)
     for k in new_t:
         assert torch.equal(t_after[k], new_t[k]), k
+
+
+@pytest.mark.parametrize("case", [(2, 25, 42, 256, 256, 3, 1, 1), (2, 13, 21, 64, 128, 3, 2, 1), (2, 50, 84, 64, 256, 1, 1, 0),
+                                  (2, 30, 40, 256, 512, 1, 2, 0), (1, 20, 20, 128, 80, 3, 1, 1), (3, 9, 9, 32, 40, 3, 1, 1)])
+def test_conv_bf16_wgrad(case):
+    from ubteacher import hip
+    N, H, W, C, K, k, s, p = case
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = (torch.randn(K, C, k, k, generator=g) * 0.05).requires_grad_(True)
+    y = F.conv2d(r16(x), w, None, s, p)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(r16(dy))
+    ref = w.grad.permute(0, 2, 3, 1).reshape(K, -1)
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    dyh = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    ri = hip.rowinfo_nhwc(N, H, W, dyh.shape[1], dyh.shape[2], s, p, "cuda")
+    dw = torch.zeros(K, k * k * C, device="cuda")
+    hip.conv2d_wgrad_bf16(xh, dyh.reshape(-1, K), dw, ri, C, k, k, accumulate=True)
+    hip.conv2d_wgrad_bf16(xh, dyh.reshape(-1, K), dw, ri, C, k, k, accumulate=True)
+    assert relerr(dw.cpu() / 2, ref) < 2e-4
+
+
+def test_conv_ml_bf16_wgrad():
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(3)
+    N, C, K, k = 2, 64, 80, 3
+    level_hw = [(12, 16), (6, 8), (3, 4), (2, 2), (1, 1)]
+    xs = [torch.randn(N, C, h, w, generator=g) for h, w in level_hw]
+    wt = (torch.randn(K, C, k, k, generator=g) * 0.1).requires_grad_(True)
+    ys = [F.conv2d(r16(x), wt, None, 1, 1) for x in xs]
+    dys = [torch.randn(y.shape, generator=g) for y in ys]
+    torch.autograd.backward(ys, [r16(d) for d in dys])
+    big = torch.cat([x.permute(0, 2, 3, 1).reshape(-1, C) for x in xs]).cuda()
+    dy = torch.cat([d.permute(0, 2, 3, 1).reshape(-1, K) for d in dys]).cuda()
+    dw = torch.zeros(K, k * k * C, device="cuda")
+    hip.conv2d_wgrad_bf16(big, dy, dw, hip.rowinfo_ml(N, level_hw, 1, "cuda"), C, k, k, accumulate=False)
+    assert relerr(dw.cpu(), wt.grad.permute(0, 2, 3, 1).reshape(K, -1)) < 2e-4

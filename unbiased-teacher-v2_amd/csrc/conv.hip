@@ -157,13 +157,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < BROWS; ++r) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (bvalid[r]) v = *(const f32x4*)(wrow[r] + kc * BK + lk4 * 4);
+        if (bvalid[r]) v = *(const f32x4*)(wrow[r] + (kh * p.KW + kw) * p.C + c0 + lk4 * 4);
         rb[r] = v;
       }
-      c0 += BK;
-      if (c0 == p.C) {
-        c0 = 0;
-        if (++kw == p.KW) { kw = 0; ++kh; }
+      // taps innermost: the KH*KW shifted reads of one channel slab stay L1/L2 resident
+      if (++kw == p.KW) {
+        kw = 0;
+        if (++kh == p.KH) { kh = 0; c0 += BK; }
       }
     } else if constexpr (MODE == 1) {
       const int tap = kc * 4 + lk4;

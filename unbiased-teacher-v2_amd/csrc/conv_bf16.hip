@@ -141,13 +141,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
       bf16x8_t v;
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
-      if (bvalid[r]) v = *(const bf16x8_t*)(wrow[r] + kc * BK + kg * 8);
+      if (bvalid[r]) v = *(const bf16x8_t*)(wrow[r] + (kh * p.KW + kw) * p.C + c0 + kg * 8);
       rb[r] = v;
     }
-    c0 += BK;
-    if (c0 == p.C) {
-      c0 = 0;
-      if (++kw == p.KW) { kw = 0; ++kh; }
+    // taps innermost: the KH*KW shifted reads of one 32-channel slab stay L1/L2 resident
+    if (++kw == p.KW) {
+      kw = 0;
+      if (++kh == p.KH) { kh = 0; c0 += BK; }
     }
   };
   auto lds_store = [&](int buf) {
@@ -318,6 +318,207 @@ int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, int K, int KH, i
   int nb = cdiv((int64_t)n, 256);
   if (nb > 8192) nb = 8192;
   hipLaunchKernelGGL(weight_flip_transpose_bf16_kernel, dim3(nb), dim3(256), 0, stream, w, (__bf16*)wt16, K, KH, KW, C);
+  return utv2_launch_status();
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// bf16 wgrad:  dW[co][k] = sum_m dY[m][co] * Xcol[m][k]   (operands rounded to bf16, fp32 accumulate)
+//
+// Both GEMM operands are pixel-major in memory ([m][c], c contiguous) but the MFMA wants 8 consecutive
+// REDUCTION elements (m) per lane.  Each staging thread therefore loads a 4(c) x 8(m) patch (8 coalesced
+// float4 loads down 8 consecutive pixel rows), converts it, and writes four 16-byte LDS rows - a register
+// transpose, no extra pass.  LDS image per operand: 128 rows x 80 B, row r' = c*32 + cq holds the 32 pixels of
+// element (4*cq + c): consecutive lanes write consecutive rows (conflict-free ds_write_b128) and an MFMA
+// tile reads 32 consecutive rows (conflict-free ds_read_b128); the row permutation is undone in the epilogue.
+// Threads 0..127 stage dY, threads 128..255 stage the im2col operand.  Pixel geometry comes from a
+// precomputed per-row table (no integer divisions in the loop, any mix of FPN levels):
+//   rowinfo[m] = { input pixel base of the image, oh*stride - pad, ow*stride - pad, (H << 16) | W }.
+struct Wgrad16Args {
+  const float* x;
+  const float* dy;
+  float* ws;
+  const int4* rowinfo;
+  int C, K, KH, KW, Kred, M, splits, chunks_per_split;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
+  constexpr int BK = 32, LDB = 80;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 256 * LDB];  // [buf][A rows 0..127 | B rows 128..255]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tilesN = (p.Kred + 127) / 128, tilesM = (p.K + 127) / 128;
+  // XCD-aware order: block b runs on XCD b % 8 (observed dispatch rule; speed only).  All tiles of one pixel split
+  // are given to ONE XCD so the dY / X chunks they share are fetched into that XCD's L2 once, not 8 times.
+  const int tiles = tilesM * tilesN;
+  int split, bid;
+  if ((p.splits & 7) == 0) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    split = xcd + 8 * (idx / tiles);
+    bid = idx % tiles;
+  } else {
+    split = blockIdx.x / tiles;
+    bid = blockIdx.x - split * tiles;
+  }
+  const int mt = bid / tilesN, nt = bid - mt * tilesN;
+  const int i0 = mt * 128, j0 = nt * 128;
+
+  const bool isB = tid >= 128;
+  const int t = tid & 127;
+  const int cq = t & 31, mo = t >> 5;  // channel quad, pixel octet
+  // fixed per thread: which 4 channels
+  const int cbase = (isB ? j0 : i0) + cq * 4;
+  int tkh = 0, tkw = 0, tci = 0;
+  bool cok;
+  if (isB) {
+    cok = cbase < p.Kred;
+    const int kk = cok ? cbase : 0;
+    const int tap = kk / p.C;
+    tci = kk - tap * p.C;
+    tkh = tap / p.KW;
+    tkw = tap - tkh * p.KW;
+  } else {
+    cok = cbase < p.K;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int chunk_begin = split * p.chunks_per_split;
+  const int total_chunks = (p.M + BK - 1) / BK;
+  int chunk_end = chunk_begin + p.chunks_per_split;
+  if (chunk_end > total_chunks) chunk_end = total_chunks;
+
+  f32x4 rg[8];
+  auto gload = [&](int chunk) {
+    const int mbase = chunk * BK + mo * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int m = mbase + e;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (cok && m < p.M) {
+        if (isB) {
+          const int4 ri = p.rowinfo[m];
+          const int ih = ri.y + tkh, iw = ri.z + tkw;
+          const int H = ri.w >> 16, W = ri.w & 0xFFFF;
+          if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+            v = *(const f32x4*)(p.x + ((size_t)ri.x + (size_t)ih * W + iw) * p.C + tci);
+        } else {
+          v = *(const f32x4*)(p.dy + (size_t)m * p.K + cbase);
+        }
+      }
+      rg[e] = v;
+    }
+  };
+  auto lds_store = [&](int buf) {
+    unsigned char* base = smem + buf * 256 * LDB + (isB ? 128 * LDB : 0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      bf16x8_t v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (__bf16)rg[e][c];
+      *(bf16x8_t*)(base + (c * 32 + cq) * LDB + mo * 16) = v;
+    }
+  };
+
+  const int frow = lane & 31, fh = lane >> 5;
+  if (chunk_begin < chunk_end) {
+    gload(chunk_begin);
+    lds_store(0);
+    __syncthreads();
+    for (int ch = chunk_begin; ch < chunk_end; ++ch) {
+      const int buf = (ch - chunk_begin) & 1;
+      if (ch + 1 < chunk_end) gload(ch + 1);
+      const unsigned char* ab = smem + buf * 256 * LDB;
+      const unsigned char* bb = ab + 128 * LDB;
+      bf16x8_t a[2][2], b[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned char* ap = ab + (wm * 64 + i * 32 + frow) * LDB + fh * 16;
+        a[i][0] = *(const bf16x8_t*)ap;
+        a[i][1] = *(const bf16x8_t*)(ap + 32);
+        const unsigned char* bp = bb + (wn * 64 + i * 32 + frow) * LDB + fh * 16;
+        b[i][0] = *(const bf16x8_t*)bp;
+        b[i][1] = *(const bf16x8_t*)(bp + 32);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+      if (ch + 1 < chunk_end) lds_store(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // LDS row r' = c*32 + cq  <->  element 4*cq + c ;  wave tile (wm, i) covers r' = (wm*2+i)*32 + row
+  float* out = p.ws + (size_t)split * p.K * p.Kred;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = j0 + 4 * frow + (wn * 2 + j);
+    if (k >= p.Kred) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const int co = i0 + 4 * row + (wm * 2 + i);
+        if (co < p.K) out[(size_t)co * p.Kred + k] = acc[i][j][e];
+      }
+  }
+}
+
+__global__ void reduce_slabs16_f32(const float* __restrict__ ws, float* __restrict__ dst, size_t n, int splits, int accumulate) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[(size_t)k * n + i];
+    dst[i] = accumulate ? dst[i] + s : s;
+  }
+}
+
+extern "C" {
+
+int utv2_conv2d_wgrad_bf16_splits(int M, int K, int Kred) {
+  const int chunks = cdiv(M, 32);
+  const int tiles = cdiv(K, 128) * cdiv(Kred, 128);
+  int splits = cdiv(1024, tiles);
+  const int max_by_chunks = chunks / 8 > 0 ? chunks / 8 : 1;
+  if (splits > max_by_chunks) splits = max_by_chunks;
+  if (splits < 1) splits = 1;
+  if (splits > 256) splits = 256;
+  if (splits >= 8) splits = (splits + 7) / 8 * 8 <= max_by_chunks ? (splits + 7) / 8 * 8 : splits / 8 * 8;  // one split group per XCD
+  return splits;
+}
+
+int64_t utv2_conv2d_wgrad_bf16_workspace_floats(int M, int K, int Kred) {
+  return (int64_t)utv2_conv2d_wgrad_bf16_splits(M, K, Kred) * K * Kred;
+}
+
+// rowinfo: device int32[M][4] = {input pixel base, oh*stride-pad, ow*stride-pad, (H<<16)|W} for every OUTPUT pixel m
+// (built once per geometry by the host).  C % 4 == 0, K % 4 == 0.  dw (+)= result.
+int utv2_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, float* ws, const int* rowinfo, int M, int C, int K,
+                           int KH, int KW, int accumulate, hipStream_t stream) {
+  if (!x || !dy || !dw || !ws || !rowinfo || (C & 3) || (K & 3) || M <= 0) return UTV2_EARG;
+  Wgrad16Args a;
+  a.x = x; a.dy = dy; a.ws = ws; a.rowinfo = (const int4*)rowinfo;
+  a.C = C; a.K = K; a.KH = KH; a.KW = KW; a.Kred = KH * KW * C; a.M = M;
+  a.splits = utv2_conv2d_wgrad_bf16_splits(M, K, a.Kred);
+  a.chunks_per_split = cdiv(cdiv(M, 32), a.splits);
+  const int tiles = cdiv(K, 128) * cdiv(a.Kred, 128);
+  hipLaunchKernelGGL(conv_wgrad_bf16, dim3(tiles * a.splits), dim3(256), 0, stream, a);
+  const size_t n = (size_t)K * a.Kred;
+  int rb = cdiv((int64_t)n, 256);
+  if (rb > 4096) rb = 4096;
+  hipLaunchKernelGGL(reduce_slabs16_f32, dim3(rb), dim3(256), 0, stream, (const float*)ws, dw, n, a.splits, accumulate);
   return utv2_launch_status();
 }
 

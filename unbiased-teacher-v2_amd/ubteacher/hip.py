@@ -53,7 +53,7 @@ def _parse_header(path):
 
 
 _SIGS = _parse_header(HEADER_PATH)
-_PLAIN = {"utv2_conv2d_bf16_supported", "utv2_conv2d_wgrad_splits", "utv2_conv2d_wgrad_workspace_floats", "utv2_groupnorm_workspace_floats",
+_PLAIN = {"utv2_conv2d_wgrad_bf16_splits", "utv2_conv2d_wgrad_bf16_workspace_floats", "utv2_conv2d_bf16_supported", "utv2_conv2d_wgrad_splits", "utv2_conv2d_wgrad_workspace_floats", "utv2_groupnorm_workspace_floats",
           "utv2_nms_mpad", "utv2_nms_workspace_bytes"}  # return a value, not a status
 
 
@@ -530,3 +530,45 @@ def conv2d_ml_fwd_bf16(x2d, w16, level_hw, N, scale=None, bias=None, residual=No
     call("utv2_conv2d_ml_fwd_bf16", _p(x2d), _p(w16), _p(out), _p(scale), _p(bias), _p(residual), len(level_hw), ctypes.cast(H, c_p),
          ctypes.cast(W, c_p), N, C, K, k, k, pad, int(relu), 0, _stream())
     return out
+
+
+_rowinfo_cache = {}
+
+
+def rowinfo_nhwc(N, H, W, OH, OW, stride, pad, device):
+    """per-output-pixel geometry table for the bf16 wgrad kernel (cached per geometry)."""
+    key = ("nhwc", N, H, W, OH, OW, stride, pad, str(device))
+    t = _rowinfo_cache.get(key)
+    if t is None:
+        n = torch.arange(N, dtype=torch.int32).view(N, 1, 1).expand(N, OH, OW)
+        oh = torch.arange(OH, dtype=torch.int32).view(1, OH, 1).expand(N, OH, OW)
+        ow = torch.arange(OW, dtype=torch.int32).view(1, 1, OW).expand(N, OH, OW)
+        t = torch.stack((n * (H * W), oh * stride - pad, ow * stride - pad, torch.full_like(n, (H << 16) | W)), dim=-1)
+        t = t.reshape(-1, 4).contiguous().to(device)
+        _rowinfo_cache[key] = t
+    return t
+
+
+def rowinfo_ml(N, level_hw, pad, device):
+    key = ("ml", N, tuple(level_hw), pad, str(device))
+    t = _rowinfo_cache.get(key)
+    if t is None:
+        parts, start = [], 0
+        for (h, w) in level_hw:
+            n = torch.arange(N, dtype=torch.int32).view(N, 1, 1).expand(N, h, w)
+            oh = torch.arange(h, dtype=torch.int32).view(1, h, 1).expand(N, h, w)
+            ow = torch.arange(w, dtype=torch.int32).view(1, 1, w).expand(N, h, w)
+            parts.append(torch.stack((start + n * (h * w), oh - pad, ow - pad, torch.full_like(n, (h << 16) | w)), dim=-1).reshape(-1, 4))
+            start += N * h * w
+        t = torch.cat(parts).contiguous().to(device)
+        _rowinfo_cache[key] = t
+    return t
+
+
+def conv2d_wgrad_bf16(x, dy2d, dw, rowinfo, C, kh, kw, accumulate=True):
+    """x: fp32 activations (any layout consistent with rowinfo), dy2d [M,K] fp32; dw [K, kh*kw*C] (+)= wgrad."""
+    M, K = dy2d.shape
+    nws = load().utv2_conv2d_wgrad_bf16_workspace_floats(M, K, kh * kw * C)
+    ws = workspace(nws, dy2d.device, "wgrad")
+    call("utv2_conv2d_wgrad_bf16", _p(x), _p(dy2d), _p(dw), _p(ws), _p(rowinfo), M, C, K, kh, kw, int(accumulate), _stream())
+    return dw

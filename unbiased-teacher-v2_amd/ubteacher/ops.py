@@ -103,6 +103,9 @@ class Conv:
     def use_bf16(self):
         return PRECISION[0] == "bf16" and self.cin % 32 == 0 and self.kred == self.k * self.k * self.cin
 
+    def use_bf16_wgrad(self):
+        return PRECISION[0] == "bf16" and self.cin % 4 == 0 and self.cout % 4 == 0 and self.kred == self.k * self.k * self.cin
+
     def use_bf16_dgrad(self):
         return PRECISION[0] == "bf16" and self.cout % 32 == 0
 
@@ -189,7 +192,11 @@ class _ConvFn(torch.autograd.Function):
                     dx = hip.conv2d_ml_fwd_bf16(g, layer.wt16(), meta.level_hw, meta.N, k=layer.k, pad=layer.k - 1 - layer.pad)
                 else:
                     dx = hip.conv2d_ml_dgrad(g, layer.wt(), meta.level_hw, meta.N, layer.k, layer.pad)
-            hip.conv2d_ml_wgrad(x, g, layer.w.g, meta.level_hw, meta.N, layer.k, layer.pad, accumulate=True)
+            if layer.use_bf16_wgrad():
+                hip.conv2d_wgrad_bf16(x, g, layer.w.g, hip.rowinfo_ml(meta.N, meta.level_hw, layer.pad, x.device), layer.cin,
+                                      layer.k, layer.k, accumulate=True)
+            else:
+                hip.conv2d_ml_wgrad(x, g, layer.w.g, meta.level_hw, meta.N, layer.k, layer.pad, accumulate=True)
         else:
             x4 = x.view(1, x.shape[0], 1, x.shape[1]) if meta is not None else x
             g4 = g.view(1, g.shape[0], 1, g.shape[1]) if meta is not None else g
@@ -200,7 +207,12 @@ class _ConvFn(torch.autograd.Function):
                     dx = hip.conv2d_dgrad(g4, layer.wt(), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k)
                 if meta is not None:
                     dx = dx.view(x.shape)
-            hip.conv2d_wgrad(x4, g4, layer.w.g, layer.stride, layer.pad, layer.k, layer.k, accumulate=True)
+            if layer.use_bf16_wgrad():
+                n_, h_, w_, _ = x4.shape
+                ri = hip.rowinfo_nhwc(n_, h_, w_, g4.shape[1], g4.shape[2], layer.stride, layer.pad, x.device)
+                hip.conv2d_wgrad_bf16(x4, g4.reshape(-1, layer.cout), layer.w.g, ri, layer.cin, layer.k, layer.k, accumulate=True)
+            else:
+                hip.conv2d_wgrad(x4, g4, layer.w.g, layer.stride, layer.pad, layer.k, layer.k, accumulate=True)
         if layer.bias is not None:
             hip.colsum(g.view(-1, layer.cout), layer.bias.g, accumulate=True)
         return dx, gres, None, None, None, None, None
