@@ -396,24 +396,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
   if (chunk_end > total_chunks) chunk_end = total_chunks;
 
   f32x4 rg[8];
+  // Loads are UNCONDITIONAL on clamped (always valid) addresses and masked afterwards: a per-element
+  // "load or zero" branch makes hipcc wait for each load in turn (guide section 5, trap (c)).
   auto gload = [&](int chunk) {
     const int mbase = chunk * BK + mo * 8;
+    if (isB) {
+      int4 ri[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int m = mbase + e;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (cok && m < p.M) {
-        if (isB) {
-          const int4 ri = p.rowinfo[m];
-          const int ih = ri.y + tkh, iw = ri.z + tkw;
-          const int H = ri.w >> 16, W = ri.w & 0xFFFF;
-          if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-            v = *(const f32x4*)(p.x + ((size_t)ri.x + (size_t)ih * W + iw) * p.C + tci);
-        } else {
-          v = *(const f32x4*)(p.dy + (size_t)m * p.K + cbase);
-        }
+      for (int e = 0; e < 8; ++e) {
+        int m = mbase + e;
+        m = m < p.M ? m : p.M - 1;
+        ri[e] = p.rowinfo[m];
       }
-      rg[e] = v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int H = ri[e].w >> 16, W = ri[e].w & 0xFFFF;
+        const int ih = ri[e].y + tkh, iw = ri[e].z + tkw;
+        const bool ok = cok && (mbase + e) < p.M && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);
+        f32x4 v = *(const f32x4*)(p.x + ((size_t)ri[e].x + (size_t)ihc * W + iwc) * p.C + tci);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ok ? v[q] : 0.f;
+        rg[e] = v;
+      }
+    } else {
+      const int cb = cok ? cbase : 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int m = mbase + e;
+        const bool ok = cok && m < p.M;
+        m = m < p.M ? m : p.M - 1;
+        f32x4 v = *(const f32x4*)(p.dy + (size_t)m * p.K + cb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ok ? v[q] : 0.f;
+        rg[e] = v;
+      }
     }
   };
   auto lds_store = [&](int buf) {
