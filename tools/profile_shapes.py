@@ -11,14 +11,25 @@ orig_call = hip.call
 enabled = [False]
 
 def call(name, *args):
-    if enabled[0] and name in ("utv2_conv2d_nhwc_fwd", "utv2_conv2d_nhwc_wgrad"):
+    names = ("utv2_conv2d_nhwc_fwd", "utv2_conv2d_nhwc_wgrad", "utv2_conv2d_nhwc_fwd_bf16", "utv2_conv2d_ml_fwd_bf16",
+             "utv2_conv2d_ml_fwd", "utv2_conv2d_wgrad_bf16", "utv2_conv2d_ml_wgrad")
+    if enabled[0] and name in names:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(); orig_call(name, *args); e1.record()
-        if name == "utv2_conv2d_nhwc_fwd":
+        if name in ("utv2_conv2d_nhwc_fwd", "utv2_conv2d_nhwc_fwd_bf16"):
             N, H, W, C, K, KH, KW, stride, pad, in_dil, OH, OW = args[6:18]
-            kind = "dgrad" if (args[3].value is None and args[4].value is None and in_dil >= 1 and args[19] == 0 and args[18] == 0 and pad == KH - 1 - (KH // 2) and False) else "fwd"
-            key = ("igemm", N, H, W, C, K, KH, stride, in_dil, OH, OW)
+            key = ("ig16" if "bf16" in name else "ig32", N, H, W, C, K, KH, stride, in_dil, OH, OW)
             fl = 2.0 * N * OH * OW * K * KH * KW * C / (in_dil * in_dil if in_dil > 1 else 1)
+        elif name in ("utv2_conv2d_ml_fwd_bf16", "utv2_conv2d_ml_fwd"):
+            nlev, _, _, N, C, K, KH, KW = args[6:14]
+            key = ("ml16" if "bf16" in name else "ml32", N, 0, 0, C, K, KH, 1, 1, 0, 0)
+            fl = 2.0 * N * 29841 * K * KH * KW * C
+        elif name == "utv2_conv2d_wgrad_bf16":
+            M, C, K, KH, KW = args[5:10]
+            key = ("wg16", M, 0, 0, C, K, KH, 1, 1, 0, 0)
+            fl = 2.0 * M * K * KH * KW * C
+        elif name == "utv2_conv2d_ml_wgrad":
+            key = ("mlwg32", 0, 0, 0, 0, 0, 0, 1, 1, 0, 0); fl = 0
         else:
             N, H, W, C, K, KH, KW, stride, pad, OH, OW = args[4:15]
             key = ("wgrad", N, H, W, C, K, KH, stride, 1, OH, OW)
@@ -44,5 +55,5 @@ rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
 tot = sum(v[1] for v in agg.values())
 print("total conv ms (2 steps): %.1f" % tot)
 print("%-8s %3s %4s %4s %5s %5s %2s %2s %2s %4s %4s | %5s %9s %8s %6s" % ("kind","N","H","W","C","K","k","s","d","OH","OW","calls","ms","TF","pct"))
-for key, (n, ms, fl) in rows[:60]:
-    print("%-8s %3d %4d %4d %5d %5d %2d %2d %2d %4d %4d | %5d %9.3f %8.1f %5.1f%%" % (key + (n, ms, fl / ms / 1e9, 100 * ms / tot)))
+for key, (n, ms, fl) in rows[:45]:
+    print("%-8s %6d %4d %4d %5d %5d %2d %2d %2d %4d %4d | %5d %9.3f %8.1f %5.1f%%" % (key + (n, ms, fl / ms / 1e9, 100 * ms / tot)))

@@ -44,4 +44,63 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
   return r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Coalesced epilogue for the 32x32-MFMA conv kernels.  Each wave owns a 64 x (TN*32) output sub-tile held
+// as acc[TM=2][TN] (row = (e&3) + 8*(e>>2) + 4*(lane>>5), col = lane&31).  Writing it straight from the
+// accumulators costs 16*TM*TN dword stores per lane that each cover only two 128-byte row pieces; instead
+// the wave bounces one 32-row slab at a time through a private LDS patch and writes full rows with 16-byte
+// stores (and reads the residual the same way).  `lds` = wave-private float[32 * (TN*32 + 4)].
+template <int TN>
+__device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float* lds, int lane, float* __restrict__ y,
+                                              const float* __restrict__ scale, const float* __restrict__ bias,
+                                              const float* __restrict__ residual, int relu, int accumulate, int m_base,
+                                              int co_base, int M, int K) {
+  constexpr int COLS = TN * 32, LD = COLS + 4, C4 = COLS / 4, RPI = 64 / C4;  // rows per store instruction
+  const int frow = lane & 31, fh = lane >> 5;
+  const int c4 = lane % C4, rsub = lane / C4;
+  const int co = co_base + c4 * 4;
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+  const bool cok = co < K;  // K % 4 == 0 is required by the caller
+  if (cok) {
+    if (scale) sc = *(const f32x4*)(scale + co);
+    if (bias) bi = *(const f32x4*)(bias + co);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) lds[((e & 3) + 8 * (e >> 2) + 4 * fh) * LD + j * 32 + frow] = acc[i][j][e];
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed (wave-private patch)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int row = it * RPI + rsub;
+      const int m = m_base + i * 32 + row;
+      if (m < M && cok) {
+        f32x4 v = *(const f32x4*)(lds + row * LD + c4 * 4);
+        const size_t off = (size_t)m * K + co;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q] + bi[q];
+        if (residual) {
+          const f32x4 r = *(const f32x4*)(residual + off);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += r[q];
+        }
+        if (relu) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+        if (accumulate) {
+          const f32x4 o = *(const f32x4*)(y + off);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += o[q];
+        }
+        *(f32x4*)(y + off) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

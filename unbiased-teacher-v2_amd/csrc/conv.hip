@@ -264,6 +264,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
     __syncthreads();
   }
 
+  if ((p.K & 3) == 0) {
+    // all MFMAs retired and every wave is past the last barrier of the K loop: the staging LDS is free
+    float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
+    epilogue_rows<TN>(acc, patch, lane, p.y, p.scale, p.bias, p.residual, p.relu, p.accumulate, m0 + wm * 64,
+                      n0 + wn * (BN / 2), p.M, p.K);
+    return;
+  }
   // epilogue: D[row][col]: col = lane&31 (cout), row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {

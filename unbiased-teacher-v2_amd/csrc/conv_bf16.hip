@@ -195,6 +195,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
     __syncthreads();
   }
 
+  if ((p.K & 3) == 0) {
+    // all MFMAs retired and every wave is past the last barrier of the K loop: the staging LDS is free
+    float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
+    epilogue_rows<TN>(acc, patch, lane, p.y, p.scale, p.bias, p.residual, p.relu, p.accumulate, m0 + wm * 64,
+                      n0 + wn * (BN / 2), p.M, p.K);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = n0 + wn * (BN / 2) + j * 32 + frow;
