@@ -35,7 +35,7 @@ int64_t utv2_conv2d_wgrad_workspace_floats(int N, int OH, int OW, int K, int Kre
 /* dw[K][KH*KW*C] (+)= sum_m dy[m][k] * im2col(x)[m][:]; deterministic split reduction through ws. */
 int utv2_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw, float* ws, int N, int H, int W, int C, int K,
                            int KH, int KW, int stride, int pad, int OH, int OW, int accumulate, utv2_stream_t stream);
-/* db[C] (+)= column sums of g[M][C] (conv bias gradient).  ws >= 64*C floats. */
+/* db[C] (+)= column sums of g[M][C] (conv bias gradient).  ws >= 1024*C floats. */
 int utv2_colsum(const float* g, float* db, float* ws, int M, int C, int accumulate, utv2_stream_t stream);
 /* wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci]  (weight image consumed by dgrad) */
 int utv2_weight_flip_transpose(const float* w, float* wt, int K, int KH, int KW, int C, utv2_stream_t stream);
@@ -91,7 +91,15 @@ int utv2_preprocess_image(const void* src, int is_u8, float* dst, int H, int W, 
 /* D2 FrozenBatchNorm2d.forward: scale = w*rsqrt(var+eps), shift = b - mean*scale, all layers at once */
 int utv2_frozenbn_fold(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift,
                        int n, float eps, utv2_stream_t stream);
-/* GroupNorm(32)+ReLU of the FCOS towers: fcos/fcos.py:263-264,283 */
+/* GroupNorm(32)+ReLU of the FCOS towers: fcos/fcos.py:263-264,283.  The _seg forms normalise every
+ * (image, FPN level) segment of a level-first [rows][C] buffer in one launch (seg_rows_host: host int[nseg]). */
+int64_t utv2_groupnorm_seg_workspace_floats(int nseg, const int* seg_rows_host, int C);
+int utv2_groupnorm_relu_seg_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                float* ws, int nseg, const int* seg_rows_host, int C, int G, float eps, int relu,
+                                utv2_stream_t stream);
+int utv2_groupnorm_relu_seg_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
+                                const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws, int nseg,
+                                const int* seg_rows_host, int C, int G, int relu, utv2_stream_t stream);
 int64_t utv2_groupnorm_workspace_floats(int N, int HW, int C);
 int utv2_groupnorm_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                             float* ws, int N, int HW, int C, int G, float eps, int relu, utv2_stream_t stream);

@@ -491,6 +491,25 @@ __global__ __launch_bounds__(256) void colsum_partial_f32(const float* __restric
   if (rl == 0 && c < C) partial[(size_t)blockIdx.y * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// vectorised column sums: thread t owns channel quad t % C4 and row lane t / C4; rows [r0, r0+rows) per block
+__global__ __launch_bounds__(256) void colsum_partial_vec_f32(const float* __restrict__ g, float* __restrict__ partial, int M,
+                                                            int C, int rows_per_block) {
+  __shared__ f32x4 red[256];
+  const int C4 = C >> 2;
+  const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, RL = 256 / C4;
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int r = r0 + rl; r < r1; r += RL) acc += ((const f32x4*)g)[(size_t)r * C4 + c4];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (rl == 0) {
+    for (int k = 1; k < RL; ++k) acc += red[k * C4 + c4];
+    ((f32x4*)partial)[(size_t)blockIdx.x * C4 + c4] = acc;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight image for dgrad:  wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci]
 __global__ void weight_flip_transpose_f32(const float* __restrict__ w, float* __restrict__ wt, int K, int KH, int KW,
@@ -650,9 +669,17 @@ int utv2_conv2d_nhwc_wgrad(const float* x, const float* dy, float* dw, float* ws
   return utv2_launch_status();
 }
 
-// db[C] (+)= column sums of g[M][C].  ws: >= 64*C floats.
+// db[C] (+)= column sums of g[M][C].  ws: >= 1024*C floats.
 int utv2_colsum(const float* g, float* db, float* ws, int M, int C, int accumulate, hipStream_t stream) {
   if (!g || !db || !ws) return UTV2_EARG;
+  if ((C & 3) == 0 && C / 4 <= 256 && 256 % (C / 4) == 0 && M >= 1024) {
+    int rows = 256;
+    while (cdiv(M, rows) > 1024) rows *= 2;
+    const int nb = cdiv(M, rows);
+    hipLaunchKernelGGL(colsum_partial_vec_f32, dim3(nb), dim3(256), 0, stream, g, ws, M, C, rows);
+    hipLaunchKernelGGL(reduce_slabs_f32, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)ws, db, (size_t)C, nb, accumulate);
+    return utv2_launch_status();
+  }
   int P = cdiv(M, 512);
   if (P > 64) P = 64;
   if (P < 1) P = 1;

@@ -186,32 +186,48 @@ __global__ void frozenbn_fold_f32(const float* __restrict__ w, const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-// GroupNorm(G groups) + ReLU on NHWC [N][HW][C]  (fcos/fcos.py:263-264, 283)
-// stage 1: per (n, chunk) partial sum / sumsq per group -> part[n][chunk][G][2]
-// stage 2: mean / rstd per (n, g)                        (double combine)
-// stage 3: y = relu((x - mean) * rstd * gamma + beta)
-#define GN_ROWS 64
-__global__ __launch_bounds__(256) void gn_stats_partial(const float* __restrict__ x, float* __restrict__ part, int HW, int C,
-                                                      int G, int nchunks) {
+// GroupNorm(G groups) + ReLU (fcos/fcos.py:263-264, 283) over SEGMENTS of a [rows][C] matrix: a segment is
+// one (image, FPN level) = a run of consecutive rows that shares statistics, so ONE launch normalises every
+// level of a shared tower.  Work is cut into chunks of GN_ROWS rows that never straddle a segment.
+//   stage 1  per chunk: partial sum / sumsq per group            -> part[chunk][G][2]
+//   stage 2  per (segment, group): mean / rstd (double combine)   -> mean, rstd [seg][G]
+//   stage 3  per chunk: y = relu((x - mean) * rstd * gamma + beta)
+#define GN_ROWS 256
+#define GN_MAX_SEG 160
+struct GnSegs {
+  int nseg;
+  int row0[GN_MAX_SEG + 1];    // first row of each segment (prefix sums)
+  int chunk0[GN_MAX_SEG + 1];  // first chunk of each segment
+};
+
+__device__ __forceinline__ void gn_locate(const GnSegs& sg, int chunk, int& seg, int& r0, int& r1) {
+  int s = 0;
+  for (int i = 1; i < sg.nseg; ++i)
+    if (chunk >= sg.chunk0[i]) s = i;
+  seg = s;
+  r0 = sg.row0[s] + (chunk - sg.chunk0[s]) * GN_ROWS;
+  r1 = r0 + GN_ROWS;
+  if (r1 > sg.row0[s + 1]) r1 = sg.row0[s + 1];
+}
+
+__global__ __launch_bounds__(256) void gn_stats_partial(GnSegs sg, const float* __restrict__ x, float* __restrict__ part, int C, int G) {
   // thread t owns channel quad c4 = t % C4 and row lane t / C4 (deterministic reduction order)
   __shared__ float red[2][256];
-  const int n = blockIdx.y, chunk = blockIdx.x;
+  int seg, r0, r1;
+  gn_locate(sg, blockIdx.x, seg, r0, r1);
   const int C4 = C >> 2;
-  const int r0 = chunk * GN_ROWS;
-  int r1 = r0 + GN_ROWS;
-  if (r1 > HW) r1 = HW;
   const int cpg4 = (C / G) >> 2;  // channel quads per group
   const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, RL = blockDim.x / C4;
   float s = 0.f, q = 0.f;
   for (int row = r0 + rl; row < r1; row += RL) {
-    const f32x4 v = ((const f32x4*)x)[((size_t)n * HW + row) * C4 + c4];
+    const f32x4 v = ((const f32x4*)x)[(size_t)row * C4 + c4];
     s += (v[0] + v[1]) + (v[2] + v[3]);
     q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
   }
   red[0][threadIdx.x] = s;
   red[1][threadIdx.x] = q;
   __syncthreads();
-  float* out = part + ((size_t)(n * nchunks + chunk) * G) * 2;
+  float* out = part + (size_t)blockIdx.x * G * 2;
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
     float a = 0.f, b = 0.f;
     for (int k = 0; k < RL; ++k)
@@ -224,67 +240,69 @@ __global__ __launch_bounds__(256) void gn_stats_partial(const float* __restrict_
   }
 }
 
-__global__ void gn_stats_final(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd, int NG,
-                               int G, int nchunks, double cnt, float eps) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (n, g)
-  if (i >= NG) return;
-  const int n = i / G, g = i % G;
+// one block per segment: thread (g = t % G, lane = t / G) sums every (256/G)-th chunk, LDS-combined in order
+__global__ __launch_bounds__(256) void gn_stats_final(GnSegs sg, const float* __restrict__ part, float* __restrict__ mean,
+                                                    float* __restrict__ rstd, int G, int cpg, float eps) {
+  __shared__ double red[2][256];
+  const int seg = blockIdx.x;
+  const int g = threadIdx.x % G, ln = threadIdx.x / G, L = blockDim.x / G;
   double s = 0.0, q = 0.0;
-  for (int c = 0; c < nchunks; ++c) {
-    const float* p = part + ((size_t)(n * nchunks + c) * G + g) * 2;
+  for (int c = sg.chunk0[seg] + ln; c < sg.chunk0[seg + 1]; c += L) {
+    const float* p = part + ((size_t)c * G + g) * 2;
     s += (double)p[0];
     q += (double)p[1];
   }
-  const double m = s / cnt;
-  double var = q / cnt - m * m;
-  if (var < 0.0) var = 0.0;
-  mean[i] = (float)m;
-  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  if (ln == 0) {
+    for (int k = 1; k < L; ++k) { s += red[0][k * G + g]; q += red[1][k * G + g]; }
+    const double cnt = (double)(sg.row0[seg + 1] - sg.row0[seg]) * cpg;
+    const double m = s / cnt;
+    double var = q / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[seg * G + g] = (float)m;
+    rstd[seg * G + g] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
-__global__ __launch_bounds__(256) void gn_apply_relu(const float* __restrict__ x, const float* __restrict__ mean,
+__global__ __launch_bounds__(256) void gn_apply_relu(GnSegs sg, const float* __restrict__ x, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                   const float* __restrict__ beta, float* __restrict__ y, int N, int HW,
-                                                   int C, int G, int relu) {
+                                                   const float* __restrict__ beta, float* __restrict__ y, int C, int G, int relu) {
+  int seg, r0, r1;
+  gn_locate(sg, blockIdx.x, seg, r0, r1);
   const int C4 = C >> 2, cpg = C / G;
-  const size_t total = (size_t)N * HW * C4;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < total; i += stride) {
-    const int c4 = (int)(i % C4);
-    const int n = (int)(i / ((size_t)HW * C4));
-    const int g = (c4 * 4) / cpg;
-    const float m = mean[n * G + g], r = rstd[n * G + g];
+  const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, RL = blockDim.x / C4;
+  const int g = (c4 * 4) / cpg;
+  const float m = mean[seg * G + g], r = rstd[seg * G + g];
+  const f32x4 ga = ((const f32x4*)gamma)[c4], be = ((const f32x4*)beta)[c4];
+  for (int row = r0 + rl; row < r1; row += RL) {
+    const size_t i = (size_t)row * C4 + c4;
     const f32x4 v = ((const f32x4*)x)[i];
-    const f32x4 ga = ((const f32x4*)gamma)[c4], be = ((const f32x4*)beta)[c4];
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float t = (v[e] - m) * r * ga[e] + be[e];
+      const float t = (v[e] - m) * r * ga[e] + be[e];
       o[e] = relu ? fmaxf(t, 0.f) : t;
     }
     ((f32x4*)y)[i] = o;
   }
 }
 
-// backward stage 1: per (n, chunk, c): A = sum g*xhat, B = sum g   with g = dy * (y > 0)
-__global__ __launch_bounds__(256) void gn_bwd_partial(const float* __restrict__ dy, const float* __restrict__ y,
+// backward stage 1: per (chunk, c): A = sum g*xhat, B = sum g   with g = dy * (y > 0)
+__global__ __launch_bounds__(256) void gn_bwd_partial(GnSegs sg, const float* __restrict__ dy, const float* __restrict__ y,
                                                     const float* __restrict__ x, const float* __restrict__ mean,
-                                                    const float* __restrict__ rstd, float* __restrict__ part, int HW, int C,
-                                                    int G, int nchunks, int relu) {
-  // blockDim.x == 256 threads: thread t owns channel quad c4 = t % C4 (C4 <= 256, 256 % C4 == 0)
+                                                    const float* __restrict__ rstd, float* __restrict__ part, int C, int G, int relu) {
   __shared__ float red[2][256 * 4];
-  const int n = blockIdx.y, chunk = blockIdx.x;
+  int seg, r0, r1;
+  gn_locate(sg, blockIdx.x, seg, r0, r1);
   const int C4 = C >> 2, cpg = C / G;
-  const int r0 = chunk * GN_ROWS;
-  int r1 = r0 + GN_ROWS;
-  if (r1 > HW) r1 = HW;
   const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, RL = blockDim.x / C4;
   const int g = (c4 * 4) / cpg;
-  const float m = mean[n * G + g], r = rstd[n * G + g];
+  const float m = mean[seg * G + g], r = rstd[seg * G + g];
   f32x4 A = {0.f, 0.f, 0.f, 0.f}, B = {0.f, 0.f, 0.f, 0.f};
   for (int row = r0 + rl; row < r1; row += RL) {
-    const size_t o = ((size_t)n * HW + row) * C4 + c4;
+    const size_t o = (size_t)row * C4 + c4;
     f32x4 gg = ((const f32x4*)dy)[o];
     const f32x4 xx = ((const f32x4*)x)[o];
     if (relu) {
@@ -311,7 +329,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial(const float* __restrict__ 
         A[e] += red[0][(k * C4 + c4) * 4 + e];
         B[e] += red[1][(k * C4 + c4) * 4 + e];
       }
-    float* out = part + ((size_t)(n * nchunks + chunk) * C + c4 * 4) * 2;
+    float* out = part + ((size_t)blockIdx.x * C + c4 * 4) * 2;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       out[e * 2] = A[e];
@@ -320,22 +338,22 @@ __global__ __launch_bounds__(256) void gn_bwd_partial(const float* __restrict__ 
   }
 }
 
-// backward stage 2: AB[n][c][2] = sum over chunks; then per (n,g): s1 = sum gamma*A, s2 = sum gamma*B;
-// dgamma[c] += sum_n A ; dbeta[c] += sum_n B.   One block per n handles s1/s2; block N.. handles dgamma.
-__global__ void gn_bwd_reduce(const float* __restrict__ part, const float* __restrict__ gamma, float* __restrict__ AB,
-                              float* __restrict__ s12, int N, int C, int G, int nchunks) {
-  const int n = blockIdx.x;
+// backward stage 2 (one block per segment): AB[seg][c][2] = sum over the segment's chunks; s1 = sum_c gamma*A,
+// s2 = sum_c gamma*B per group.
+__global__ __launch_bounds__(256) void gn_bwd_reduce(GnSegs sg, const float* __restrict__ part, const float* __restrict__ gamma,
+                                                   float* __restrict__ AB, float* __restrict__ s12, int C, int G) {
+  const int seg = blockIdx.x;
   const int cpg = C / G;
   extern __shared__ float sh[];  // [C][2]
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float a = 0.f, b = 0.f;
-    for (int k = 0; k < nchunks; ++k) {
-      const float* p = part + ((size_t)(n * nchunks + k) * C + c) * 2;
+    for (int k = sg.chunk0[seg]; k < sg.chunk0[seg + 1]; ++k) {
+      const float* p = part + ((size_t)k * C + c) * 2;
       a += p[0];
       b += p[1];
     }
-    AB[((size_t)n * C + c) * 2] = a;
-    AB[((size_t)n * C + c) * 2 + 1] = b;
+    AB[((size_t)seg * C + c) * 2] = a;
+    AB[((size_t)seg * C + c) * 2 + 1] = b;
     sh[c * 2] = a * gamma[c];
     sh[c * 2 + 1] = b * gamma[c];
   }
@@ -346,16 +364,16 @@ __global__ void gn_bwd_reduce(const float* __restrict__ part, const float* __res
       s1 += sh[(g * cpg + k) * 2];
       s2 += sh[(g * cpg + k) * 2 + 1];
     }
-    s12[(n * G + g) * 2] = s1;
-    s12[(n * G + g) * 2 + 1] = s2;
+    s12[(seg * G + g) * 2] = s1;
+    s12[(seg * G + g) * 2 + 1] = s2;
   }
 }
 
-__global__ void gn_bwd_param(const float* __restrict__ AB, float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C) {
+__global__ void gn_bwd_param(const float* __restrict__ AB, float* __restrict__ dgamma, float* __restrict__ dbeta, int S, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float a = 0.f, b = 0.f;
-  for (int n = 0; n < N; ++n) {
+  for (int n = 0; n < S; ++n) {
     a += AB[((size_t)n * C + c) * 2];
     b += AB[((size_t)n * C + c) * 2 + 1];
   }
@@ -364,24 +382,23 @@ __global__ void gn_bwd_param(const float* __restrict__ AB, float* __restrict__ d
 }
 
 // backward stage 3: dx = rstd * (g*gamma - (s2 + xhat*s1)/cnt)
-__global__ __launch_bounds__(256) void gn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void gn_bwd_apply(GnSegs sg, const float* __restrict__ dy, const float* __restrict__ y,
                                                   const float* __restrict__ x, const float* __restrict__ mean,
                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                  const float* __restrict__ s12, float* __restrict__ dx, int N, int HW, int C,
-                                                  int G, float inv_cnt, int relu) {
+                                                  const float* __restrict__ s12, float* __restrict__ dx, int C, int G, int relu) {
+  int seg, r0, r1;
+  gn_locate(sg, blockIdx.x, seg, r0, r1);
   const int C4 = C >> 2, cpg = C / G;
-  const size_t total = (size_t)N * HW * C4;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < total; i += stride) {
-    const int c4 = (int)(i % C4);
-    const int n = (int)(i / ((size_t)HW * C4));
-    const int g = (c4 * 4) / cpg;
-    const float m = mean[n * G + g], r = rstd[n * G + g];
-    const float s1 = s12[(n * G + g) * 2], s2 = s12[(n * G + g) * 2 + 1];
+  const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, RL = blockDim.x / C4;
+  const int g = (c4 * 4) / cpg;
+  const float m = mean[seg * G + g], r = rstd[seg * G + g];
+  const float s1 = s12[(seg * G + g) * 2], s2 = s12[(seg * G + g) * 2 + 1];
+  const float inv_cnt = 1.0f / ((float)(sg.row0[seg + 1] - sg.row0[seg]) * cpg);
+  const f32x4 ga = ((const f32x4*)gamma)[c4];
+  for (int row = r0 + rl; row < r1; row += RL) {
+    const size_t i = (size_t)row * C4 + c4;
     f32x4 gg = ((const f32x4*)dy)[i];
     const f32x4 xx = ((const f32x4*)x)[i];
-    const f32x4 ga = ((const f32x4*)gamma)[c4];
     if (relu) {
       const f32x4 yy = ((const f32x4*)y)[i];
 #pragma unroll
@@ -395,6 +412,19 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(const float* __restrict__ dy
     }
     ((f32x4*)dx)[i] = o;
   }
+}
+
+static int gn_fill(GnSegs& sg, int nseg, const int* seg_rows) {
+  sg.nseg = nseg;
+  int r = 0, c = 0;
+  for (int s = 0; s < nseg; ++s) {
+    sg.row0[s] = r;
+    sg.chunk0[s] = c;
+    r += seg_rows[s];
+    c += (seg_rows[s] + GN_ROWS - 1) / GN_ROWS;
+  }
+  for (int s = nseg; s <= GN_MAX_SEG; ++s) { sg.row0[s] = r; sg.chunk0[s] = c; }
+  return c;
 }
 
 static inline int grid_for(size_t n, int block = 256, int cap = 256 * 16) {
@@ -489,41 +519,71 @@ int utv2_frozenbn_fold(const float* w, const float* b, const float* mean, const 
   return utv2_launch_status();
 }
 
-int64_t utv2_groupnorm_workspace_floats(int N, int HW, int C) {
-  const int nchunks = cdiv(HW, GN_ROWS);
-  return (int64_t)N * nchunks * C * 2 + (int64_t)N * C * 2 + (int64_t)N * C;
+// Segmented API: seg_rows_host = host int[nseg] (rows of each (image, level) segment, consecutive in memory).
+int64_t utv2_groupnorm_seg_workspace_floats(int nseg, const int* seg_rows_host, int C) {
+  int64_t chunks = 0;
+  for (int s = 0; s < nseg; ++s) chunks += (seg_rows_host[s] + GN_ROWS - 1) / GN_ROWS;
+  return chunks * C * 2 + (int64_t)nseg * C * 2 + (int64_t)nseg * C;
 }
 
-// x,y: [N][HW][C]; mean,rstd: [N][G] (saved for backward).  C % 4 == 0, (C/G) % 4 == 0, 256 % (C/4) == 0.
-int utv2_groupnorm_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                            float* ws, int N, int HW, int C, int G, float eps, int relu, hipStream_t stream) {
-  if (!x || !y || !mean || !rstd || !ws || (C & 3) || ((C / G) & 3) || C / 4 > 256 || (256 % (C / 4))) return UTV2_EARG;
-  const int nchunks = cdiv(HW, GN_ROWS);
-  hipLaunchKernelGGL(gn_stats_partial, dim3(nchunks, N), dim3(256), 0, stream, x, ws, HW, C, G, nchunks);
-  hipLaunchKernelGGL(gn_stats_final, dim3(cdiv(N * G, 64)), dim3(64), 0, stream, (const float*)ws, mean, rstd, N * G, G,
-                     nchunks, (double)HW * (C / G), eps);
-  hipLaunchKernelGGL(gn_apply_relu, dim3(grid_for((size_t)N * HW * C / 4, 256, 1 << 16)), dim3(256), 0, stream, x,
-                     (const float*)mean, (const float*)rstd, gamma, beta, y, N, HW, C, G, relu);
+static int gn_check(int nseg, int C, int G) {
+  return !(nseg < 1 || nseg > GN_MAX_SEG || (C & 3) || ((C / G) & 3) || C / 4 > 256 || (256 % (C / 4)) || (256 % G));
+}
+
+// x,y: [rows][C]; mean,rstd: [nseg][G] (saved for backward).
+int utv2_groupnorm_relu_seg_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                float* ws, int nseg, const int* seg_rows_host, int C, int G, float eps, int relu,
+                                hipStream_t stream) {
+  if (!x || !y || !mean || !rstd || !ws || !gn_check(nseg, C, G)) return UTV2_EARG;
+  GnSegs sg;
+  const int chunks = gn_fill(sg, nseg, seg_rows_host);
+  hipLaunchKernelGGL(gn_stats_partial, dim3(chunks), dim3(256), 0, stream, sg, x, ws, C, G);
+  hipLaunchKernelGGL(gn_stats_final, dim3(nseg), dim3(256), 0, stream, sg, (const float*)ws, mean, rstd, G, C / G, eps);
+  hipLaunchKernelGGL(gn_apply_relu, dim3(chunks), dim3(256), 0, stream, sg, x, (const float*)mean, (const float*)rstd, gamma,
+                     beta, y, C, G, relu);
   return utv2_launch_status();
 }
 
 // dx written; dgamma/dbeta accumulated (+=).
+int utv2_groupnorm_relu_seg_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
+                                const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws, int nseg,
+                                const int* seg_rows_host, int C, int G, int relu, hipStream_t stream) {
+  if (!dy || !x || !dx || !ws || !gn_check(nseg, C, G)) return UTV2_EARG;
+  GnSegs sg;
+  const int chunks = gn_fill(sg, nseg, seg_rows_host);
+  float* part = ws;
+  float* AB = ws + (size_t)chunks * C * 2;
+  float* s12 = AB + (size_t)nseg * C * 2;
+  hipLaunchKernelGGL(gn_bwd_partial, dim3(chunks), dim3(256), 0, stream, sg, dy, y, x, mean, rstd, part, C, G, relu);
+  hipLaunchKernelGGL(gn_bwd_reduce, dim3(nseg), dim3(256), 2 * C * sizeof(float), stream, sg, (const float*)part, gamma, AB, s12, C, G);
+  hipLaunchKernelGGL(gn_bwd_param, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)AB, dgamma, dbeta, nseg, C);
+  hipLaunchKernelGGL(gn_bwd_apply, dim3(chunks), dim3(256), 0, stream, sg, dy, y, x, mean, rstd, gamma, (const float*)s12, dx, C, G, relu);
+  return utv2_launch_status();
+}
+
+// Dense [N][HW][C] convenience forms (one segment per image).
+int64_t utv2_groupnorm_workspace_floats(int N, int HW, int C) {
+  int rows[GN_MAX_SEG];
+  if (N > GN_MAX_SEG) return -1;
+  for (int i = 0; i < N; ++i) rows[i] = HW;
+  return utv2_groupnorm_seg_workspace_floats(N, rows, C);
+}
+
+int utv2_groupnorm_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                            float* ws, int N, int HW, int C, int G, float eps, int relu, hipStream_t stream) {
+  int rows[GN_MAX_SEG];
+  if (N > GN_MAX_SEG) return UTV2_EARG;
+  for (int i = 0; i < N; ++i) rows[i] = HW;
+  return utv2_groupnorm_relu_seg_fwd(x, gamma, beta, y, mean, rstd, ws, N, rows, C, G, eps, relu, stream);
+}
+
 int utv2_groupnorm_relu_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
                             const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws, int N, int HW, int C,
                             int G, int relu, hipStream_t stream) {
-  if (!dy || !x || !dx || !ws || (C & 3) || ((C / G) & 3) || C / 4 > 256 || (256 % (C / 4))) return UTV2_EARG;
-  const int nchunks = cdiv(HW, GN_ROWS);
-  float* part = ws;
-  float* AB = ws + (size_t)N * nchunks * C * 2;
-  float* s12 = AB + (size_t)N * C * 2;
-  hipLaunchKernelGGL(gn_bwd_partial, dim3(nchunks, N), dim3(256), 0, stream, dy, y, x, mean, rstd, part, HW, C, G, nchunks,
-                     relu);
-  hipLaunchKernelGGL(gn_bwd_reduce, dim3(N), dim3(256), 2 * C * sizeof(float), stream, (const float*)part, gamma, AB, s12, N,
-                     C, G, nchunks);
-  hipLaunchKernelGGL(gn_bwd_param, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)AB, dgamma, dbeta, N, C);
-  hipLaunchKernelGGL(gn_bwd_apply, dim3(grid_for((size_t)N * HW * C / 4, 256, 1 << 16)), dim3(256), 0, stream, dy, y, x,
-                     mean, rstd, gamma, (const float*)s12, dx, N, HW, C, G, 1.0f / ((float)HW * (C / G)), relu);
-  return utv2_launch_status();
+  int rows[GN_MAX_SEG];
+  if (N > GN_MAX_SEG) return UTV2_EARG;
+  for (int i = 0; i < N; ++i) rows[i] = HW;
+  return utv2_groupnorm_relu_seg_bwd(dy, y, x, mean, rstd, gamma, dx, dgamma, dbeta, ws, N, rows, C, G, relu, stream);
 }
 
 }  // extern "C"

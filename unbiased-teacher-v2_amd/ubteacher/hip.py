@@ -53,7 +53,7 @@ def _parse_header(path):
 
 
 _SIGS = _parse_header(HEADER_PATH)
-_PLAIN = {"utv2_conv2d_wgrad_bf16_splits", "utv2_conv2d_wgrad_bf16_workspace_floats", "utv2_conv2d_bf16_supported", "utv2_conv2d_wgrad_splits", "utv2_conv2d_wgrad_workspace_floats", "utv2_groupnorm_workspace_floats",
+_PLAIN = {"utv2_groupnorm_seg_workspace_floats", "utv2_conv2d_wgrad_bf16_splits", "utv2_conv2d_wgrad_bf16_workspace_floats", "utv2_conv2d_bf16_supported", "utv2_conv2d_wgrad_splits", "utv2_conv2d_wgrad_workspace_floats", "utv2_groupnorm_workspace_floats",
           "utv2_nms_mpad", "utv2_nms_workspace_bytes"}  # return a value, not a status
 
 
@@ -166,7 +166,7 @@ def conv2d_wgrad(x, dy, dw, stride, pad, kh, kw, accumulate=True):
 
 def colsum(g2d, db, accumulate=True):
     M, C = g2d.shape
-    ws = workspace(64 * C, g2d.device, "colsum")
+    ws = workspace(1024 * C, g2d.device, "colsum")
     call("utv2_colsum", _p(g2d), _p(db), _p(ws), M, C, int(accumulate), _stream())
     return db
 
@@ -572,3 +572,29 @@ def conv2d_wgrad_bf16(x, dy2d, dw, rowinfo, C, kh, kw, accumulate=True):
     ws = workspace(nws, dy2d.device, "wgrad")
     call("utv2_conv2d_wgrad_bf16", _p(x), _p(dy2d), _p(dw), _p(ws), _p(rowinfo), M, C, K, kh, kw, int(accumulate), _stream())
     return dw
+
+
+def groupnorm_relu_seg_fwd(x2d, seg_rows, gamma, beta, G=32, eps=1e-5, relu=True):
+    """x2d [rows, C]; seg_rows: rows of each consecutive (image, level) segment."""
+    rows, C = x2d.shape
+    assert sum(seg_rows) == rows
+    y = torch.empty_like(x2d)
+    S = len(seg_rows)
+    mean = torch.empty((S, G), dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty((S, G), dtype=torch.float32, device=x2d.device)
+    sr = _iarr(seg_rows)
+    ws = workspace(load().utv2_groupnorm_seg_workspace_floats(S, ctypes.cast(sr, c_p), C), x2d.device, "gn")
+    call("utv2_groupnorm_relu_seg_fwd", _p(x2d), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(ws), S, ctypes.cast(sr, c_p), C, G,
+         float(eps), int(relu), _stream())
+    return y, mean, rstd
+
+
+def groupnorm_relu_seg_bwd(dy, y, x2d, seg_rows, mean, rstd, gamma, dgamma, dbeta, G=32, relu=True):
+    rows, C = x2d.shape
+    S = len(seg_rows)
+    dx = torch.empty_like(x2d)
+    sr = _iarr(seg_rows)
+    ws = workspace(load().utv2_groupnorm_seg_workspace_floats(S, ctypes.cast(sr, c_p), C), x2d.device, "gn")
+    call("utv2_groupnorm_relu_seg_bwd", _p(dy), _p(y), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _p(ws), S,
+         ctypes.cast(sr, c_p), C, G, int(relu), _stream())
+    return dx

@@ -49,6 +49,7 @@ class LevelMeta:
             self.rows.append((r, r + N * h * w))
             r += N * h * w
         self.P = r
+        self.seg_rows = [h * w for (h, w) in self.level_hw for _ in range(N)]  # (level, image) segments in memory order
 
     def level_view(self, t2d, l):
         r0, r1 = self.rows[l]
@@ -230,13 +231,8 @@ class GroupNormReLU:
     def _fwd(self, x, meta):
         if meta is None:
             return hip.groupnorm_relu_fwd(x, self.gamma.t, self.beta.t, self.groups, self.eps, self.relu)
-        y = torch.empty_like(x)
-        means, rstds = [], []
-        for l in range(len(meta.level_hw)):  # statistics are per (image, level, group)
-            yl, m, r = hip.groupnorm_relu_fwd(meta.level_view(x, l), self.gamma.t, self.beta.t, self.groups, self.eps, self.relu,
-                                              out=meta.level_view(y, l))
-            means.append(m); rstds.append(r)
-        return y, torch.stack(means), torch.stack(rstds)
+        # statistics are per (image, level, group): ONE launch over all (level, image) segments
+        return hip.groupnorm_relu_seg_fwd(x, meta.seg_rows, self.gamma.t, self.beta.t, self.groups, self.eps, self.relu)
 
 
 class _GNFn(torch.autograd.Function):
@@ -256,10 +252,8 @@ class _GNFn(torch.autograd.Function):
         if meta is None:
             dx = hip.groupnorm_relu_bwd(dy, y, x, mean, rstd, layer.gamma.t, layer.gamma.g, layer.beta.g, layer.groups, layer.relu)
         else:
-            dx = torch.empty_like(x)
-            for l in range(len(meta.level_hw)):
-                hip.groupnorm_relu_bwd(meta.level_view(dy, l), meta.level_view(y, l), meta.level_view(x, l), mean[l], rstd[l],
-                                       layer.gamma.t, layer.gamma.g, layer.beta.g, layer.groups, layer.relu, out=meta.level_view(dx, l))
+            dx = hip.groupnorm_relu_seg_bwd(dy, y, x, meta.seg_rows, mean, rstd, layer.gamma.t, layer.gamma.g, layer.beta.g,
+                                            layer.groups, layer.relu)
         return dx, None, None, None
 
 
