@@ -63,8 +63,8 @@ int utv2_conv2d_ml_fwd_bf16(const float* x, const void* w16, float* y, const flo
 /* bf16 wgrad; rowinfo = device int32[M][4] {input pixel base, oh*stride-pad, ow*stride-pad, (H<<16)|W} per output pixel */
 int utv2_conv2d_wgrad_bf16_splits(int M, int K, int Kred);
 int64_t utv2_conv2d_wgrad_bf16_workspace_floats(int M, int K, int Kred);
-int utv2_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, float* ws, const int* rowinfo, int M, int C, int K,
-                           int KH, int KW, int accumulate, utv2_stream_t stream);
+int utv2_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, float* db, float* ws, const int* rowinfo, int M, int C,
+                           int K, int KH, int KW, int accumulate, utv2_stream_t stream);
 int utv2_f32_to_bf16(const float* src, void* dst16, int64_t n, utv2_stream_t stream);
 int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, int K, int KH, int KW, int C, utv2_stream_t stream);
 

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 INF = 100000000
 
 # Emulation of the product's mixed-precision (AMP) conv path for parity tests: when set to "bf16", the
-# operands of every conv / linear whose input-channel count is a multiple of 32 are rounded to bf16
+# operands of every conv / linear whose input-channel count is a multiple of 8 are rounded to bf16
 # (round-to-nearest-even) before an fp32 convolution - exactly what the bf16-MFMA kernels compute
 # (bf16 operands, fp32 accumulate).  None = the reference's fp32 CPU arithmetic.
 CONV_ROUND = [None]
@@ -38,13 +38,13 @@ def _r16(t):
 
 
 def _conv2d(x, w, b=None, stride=1, padding=0):
-    if CONV_ROUND[0] == "bf16" and x.shape[1] % 32 == 0:
+    if CONV_ROUND[0] == "bf16" and x.shape[1] % 8 == 0:
         x, w = _r16(x), _r16(w)
     return F.conv2d(x, w, b, stride, padding)
 
 
 def _linear(x, w, b=None):
-    if CONV_ROUND[0] == "bf16" and x.shape[1] % 32 == 0:
+    if CONV_ROUND[0] == "bf16" and x.shape[1] % 8 == 0:
         x, w = _r16(x), _r16(w)
     return F.linear(x, w, b)
 

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nchunks = p.Kred / BK;
+  const int nchunks = p.KH * p.KW * ((p.C + BK - 1) / BK);  // a 32-channel slab per tap; the last slab may be partial (C % 8 == 0)
   int kh = 0, kw = 0, c0 = 0;
   f32x4 ra[2][2];
   bf16x8_t rb[BROWS];
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
         ih = ihn / p.in_dil;
         iw = iwn / p.in_dil;
       }
-      ok = ok && (unsigned)ih < (unsigned)Hr[r] && (unsigned)iw < (unsigned)Wr[r];
+      ok = ok && (unsigned)ih < (unsigned)Hr[r] && (unsigned)iw < (unsigned)Wr[r] && (c0 + kg * 8 < p.C);
       f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
       if (ok) {
         const float* src = p.x + (size_t)(pixbase[r] + (long long)ih * Wr[r] + iw) * p.C + c0 + kg * 8;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
       bf16x8_t v;
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
-      if (bvalid[r]) v = *(const bf16x8_t*)(wrow[r] + (kh * p.KW + kw) * p.C + c0 + kg * 8);
+      if (bvalid[r] && (c0 + kg * 8 < p.C)) v = *(const bf16x8_t*)(wrow[r] + (kh * p.KW + kw) * p.C + c0 + kg * 8);
       rb[r] = v;
     }
     // taps innermost: the KH*KW shifted reads of one 32-channel slab stay L1/L2 resident
@@ -274,13 +274,13 @@ static int fill_levels16(LevelTab& lt, int nlev, int N, const int* H, const int*
 extern "C" {
 
 // 1 if the bf16 MFMA kernel supports this conv (C % 32 == 0), else the caller uses the fp32 kernel
-int utv2_conv2d_bf16_supported(int C, int KH, int KW) { return (C % 32 == 0) ? 1 : 0; }
+int utv2_conv2d_bf16_supported(int C, int KH, int KW) { return (C % 8 == 0) ? 1 : 0; }
 
 // w16: bf16 [K][KH*KW*C].  Otherwise identical contract to utv2_conv2d_nhwc_fwd (also serves as dgrad).
 int utv2_conv2d_nhwc_fwd_bf16(const float* x, const void* w16, float* y, const float* scale, const float* bias,
                               const float* residual, int N, int H, int W, int C, int K, int KH, int KW, int stride, int pad,
                               int in_dil, int OH, int OW, int relu, int accumulate, hipStream_t stream) {
-  if (!x || !w16 || !y || (C % 32)) return UTV2_EARG;
+  if (!x || !w16 || !y || (C % 8)) return UTV2_EARG;
   ConvArgs16 a;
   a.lt.n = 0;
   a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual;
@@ -296,7 +296,7 @@ int utv2_conv2d_nhwc_fwd_bf16(const float* x, const void* w16, float* y, const f
 int utv2_conv2d_ml_fwd_bf16(const float* x, const void* w16, float* y, const float* scale, const float* bias,
                             const float* residual, int nlev, const int* H_host, const int* W_host, int N, int C, int K, int KH,
                             int KW, int pad, int relu, int accumulate, hipStream_t stream) {
-  if (!x || !w16 || !y || nlev < 1 || nlev > CONV_MAX_LEVELS || (C % 32) || N <= 0) return UTV2_EARG;
+  if (!x || !w16 || !y || nlev < 1 || nlev > CONV_MAX_LEVELS || (C % 8) || N <= 0) return UTV2_EARG;
   ConvArgs16 a;
   a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
   a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual;
@@ -347,6 +347,7 @@ struct Wgrad16Args {
   const float* dy;
   float* ws;
   const int4* rowinfo;
+  float* bias_ws;  // optional [splits][K]: per-split column sums of dY (conv bias gradient), fused into the dY staging
   int C, K, KH, KW, Kred, M, splits, chunks_per_split;
 };
 
@@ -403,6 +404,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
   if (chunk_end > total_chunks) chunk_end = total_chunks;
 
   f32x4 rg[8];
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = p.bias_ws != nullptr && !isB && nt == 0;
   // Loads are UNCONDITIONAL on clamped (always valid) addresses and masked afterwards: a per-element
   // "load or zero" branch makes hipcc wait for each load in turn (guide section 5, trap (c)).
   auto gload = [&](int chunk) {
@@ -440,6 +443,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
       }
     }
   };
+  auto bias_acc = [&]() {
+    if (do_bias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bsum += rg[e];
+    }
+  };
   auto lds_store = [&](int buf) {
     unsigned char* base = smem + buf * 256 * LDB + (isB ? 128 * LDB : 0);
 #pragma unroll
@@ -454,6 +463,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
   const int frow = lane & 31, fh = lane >> 5;
   if (chunk_begin < chunk_end) {
     gload(chunk_begin);
+    bias_acc();
     lds_store(0);
     __syncthreads();
     for (int ch = chunk_begin; ch < chunk_end; ++ch) {
@@ -477,9 +487,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-      if (ch + 1 < chunk_end) lds_store(buf ^ 1);
+      if (ch + 1 < chunk_end) { bias_acc(); lds_store(buf ^ 1); }
       __syncthreads();
     }
+  }
+  if (p.bias_ws != nullptr && nt == 0) {  // block-uniform: fixed-order combine of the 4 pixel-octet lanes per channel quad
+    f32x4* red = (f32x4*)smem;
+    if (!isB) red[t] = bsum;
+    __syncthreads();
+    if (!isB && mo == 0 && cok) {
+      f32x4 v = red[cq] + red[32 + cq] + red[64 + cq] + red[96 + cq];
+      *(f32x4*)(p.bias_ws + (size_t)split * p.K + cbase) = v;
+    }
+    __syncthreads();
   }
 
   // LDS row r' = c*32 + cq  <->  element 4*cq + c ;  wave tile (wm, i) covers r' = (wm*2+i)*32 + row
@@ -524,25 +544,29 @@ int utv2_conv2d_wgrad_bf16_splits(int M, int K, int Kred) {
 }
 
 int64_t utv2_conv2d_wgrad_bf16_workspace_floats(int M, int K, int Kred) {
-  return (int64_t)utv2_conv2d_wgrad_bf16_splits(M, K, Kred) * K * Kred;
+  return (int64_t)utv2_conv2d_wgrad_bf16_splits(M, K, Kred) * ((int64_t)K * Kred + K);
 }
 
 // rowinfo: device int32[M][4] = {input pixel base, oh*stride-pad, ow*stride-pad, (H<<16)|W} for every OUTPUT pixel m
-// (built once per geometry by the host).  C % 4 == 0, K % 4 == 0.  dw (+)= result.
-int utv2_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, float* ws, const int* rowinfo, int M, int C, int K,
-                           int KH, int KW, int accumulate, hipStream_t stream) {
+// (built once per geometry by the host).  C % 4 == 0, K % 4 == 0.  dw (+)= result; db (optional, [K]) (+)= column sums of dy.
+int utv2_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, float* db, float* ws, const int* rowinfo, int M, int C,
+                           int K, int KH, int KW, int accumulate, hipStream_t stream) {
   if (!x || !dy || !dw || !ws || !rowinfo || (C & 3) || (K & 3) || M <= 0) return UTV2_EARG;
   Wgrad16Args a;
   a.x = x; a.dy = dy; a.ws = ws; a.rowinfo = (const int4*)rowinfo;
   a.C = C; a.K = K; a.KH = KH; a.KW = KW; a.Kred = KH * KW * C; a.M = M;
   a.splits = utv2_conv2d_wgrad_bf16_splits(M, K, a.Kred);
   a.chunks_per_split = cdiv(cdiv(M, 32), a.splits);
+  const size_t n = (size_t)K * a.Kred;
+  a.bias_ws = db ? ws + (size_t)a.splits * n : nullptr;   // bias slabs sit behind the weight slabs
   const int tiles = cdiv(K, 128) * cdiv(a.Kred, 128);
   hipLaunchKernelGGL(conv_wgrad_bf16, dim3(tiles * a.splits), dim3(256), 0, stream, a);
-  const size_t n = (size_t)K * a.Kred;
   int rb = cdiv((int64_t)n, 256);
   if (rb > 4096) rb = 4096;
   hipLaunchKernelGGL(reduce_slabs16_f32, dim3(rb), dim3(256), 0, stream, (const float*)ws, dw, n, a.splits, accumulate);
+  if (db)
+    hipLaunchKernelGGL(reduce_slabs16_f32, dim3(cdiv(K, 256)), dim3(256), 0, stream, (const float*)a.bias_ws, db, (size_t)K, a.splits,
+                       accumulate);
   return utv2_launch_status();
 }
 

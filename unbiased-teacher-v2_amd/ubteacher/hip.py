@@ -499,7 +499,7 @@ def conv2d_fwd_bf16(x, w16, scale=None, bias=None, residual=None, stride=1, pad=
                     in_dil=1, out_hw=None, accumulate=False):
     N, H, W, C = x.shape
     K = w16.shape[0]
-    assert w16.dtype == torch.bfloat16 and C % 32 == 0
+    assert w16.dtype == torch.bfloat16 and C % 8 == 0
     if out_hw is None:
         OH, OW = conv_out_size(H, kh, stride, pad), conv_out_size(W, kw, stride, pad)
     else:
@@ -565,12 +565,13 @@ def rowinfo_ml(N, level_hw, pad, device):
     return t
 
 
-def conv2d_wgrad_bf16(x, dy2d, dw, rowinfo, C, kh, kw, accumulate=True):
-    """x: fp32 activations (any layout consistent with rowinfo), dy2d [M,K] fp32; dw [K, kh*kw*C] (+)= wgrad."""
+def conv2d_wgrad_bf16(x, dy2d, dw, rowinfo, C, kh, kw, accumulate=True, db=None):
+    """x: fp32 activations (any layout consistent with rowinfo), dy2d [M,K] fp32; dw [K, kh*kw*C] (+)= wgrad;
+    db [K] (optional) (+)= column sums of dy (bias gradient, fused into the dY staging)."""
     M, K = dy2d.shape
     nws = load().utv2_conv2d_wgrad_bf16_workspace_floats(M, K, kh * kw * C)
     ws = workspace(nws, dy2d.device, "wgrad")
-    call("utv2_conv2d_wgrad_bf16", _p(x), _p(dy2d), _p(dw), _p(ws), _p(rowinfo), M, C, K, kh, kw, int(accumulate), _stream())
+    call("utv2_conv2d_wgrad_bf16", _p(x), _p(dy2d), _p(dw), _p(db), _p(ws), _p(rowinfo), M, C, K, kh, kw, int(accumulate), _stream())
     return dw
 
 

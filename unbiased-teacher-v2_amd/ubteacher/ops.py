@@ -102,13 +102,13 @@ class Conv:
         return self._wt16
 
     def use_bf16(self):
-        return PRECISION[0] == "bf16" and self.cin % 32 == 0 and self.kred == self.k * self.k * self.cin
+        return PRECISION[0] == "bf16" and self.cin % 8 == 0 and self.kred == self.k * self.k * self.cin
 
     def use_bf16_wgrad(self):
         return PRECISION[0] == "bf16" and self.cin % 4 == 0 and self.cout % 4 == 0 and self.kred == self.k * self.k * self.cin
 
     def use_bf16_dgrad(self):
-        return PRECISION[0] == "bf16" and self.cout % 32 == 0
+        return PRECISION[0] == "bf16" and self.cout % 8 == 0
 
     def __call__(self, x, residual=None, out=None, colscale_handle=None, meta=None):
         """x: NHWC tensor, or a level-first [P, C] matrix with `meta` (one launch for all levels; k x k
@@ -187,6 +187,7 @@ class _ConvFn(torch.autograd.Function):
                 g = dy
         dx = None
         d16 = layer.use_bf16_dgrad()
+        bias_done = False
         if meta is not None and layer.k > 1:
             if ctx.needs_input_grad[0]:
                 if d16:
@@ -195,7 +196,8 @@ class _ConvFn(torch.autograd.Function):
                     dx = hip.conv2d_ml_dgrad(g, layer.wt(), meta.level_hw, meta.N, layer.k, layer.pad)
             if layer.use_bf16_wgrad():
                 hip.conv2d_wgrad_bf16(x, g, layer.w.g, hip.rowinfo_ml(meta.N, meta.level_hw, layer.pad, x.device), layer.cin,
-                                      layer.k, layer.k, accumulate=True)
+                                      layer.k, layer.k, accumulate=True, db=layer.bias.g if layer.bias is not None else None)
+                bias_done = True
             else:
                 hip.conv2d_ml_wgrad(x, g, layer.w.g, meta.level_hw, meta.N, layer.k, layer.pad, accumulate=True)
         else:
@@ -211,10 +213,12 @@ class _ConvFn(torch.autograd.Function):
             if layer.use_bf16_wgrad():
                 n_, h_, w_, _ = x4.shape
                 ri = hip.rowinfo_nhwc(n_, h_, w_, g4.shape[1], g4.shape[2], layer.stride, layer.pad, x.device)
-                hip.conv2d_wgrad_bf16(x4, g4.reshape(-1, layer.cout), layer.w.g, ri, layer.cin, layer.k, layer.k, accumulate=True)
+                hip.conv2d_wgrad_bf16(x4, g4.reshape(-1, layer.cout), layer.w.g, ri, layer.cin, layer.k, layer.k, accumulate=True,
+                                      db=layer.bias.g if layer.bias is not None else None)
+                bias_done = True
             else:
                 hip.conv2d_wgrad(x4, g4, layer.w.g, layer.stride, layer.pad, layer.k, layer.k, accumulate=True)
-        if layer.bias is not None:
+        if layer.bias is not None and not bias_done:
             hip.colsum(g.view(-1, layer.cout), layer.bias.g, accumulate=True)
         return dx, gres, None, None, None, None, None
 
