@@ -70,8 +70,10 @@ class ConvTimer:
         def call(name, *args):
             if not (timer.enabled and name == timer.entry):
                 return orig(name, *args)
-            N, H, W, C, K, KH, KW, stride, pad, in_dil, OH, OW = args[6:18]
-            if K <= 64 or C % 16 != 0 or (name == "utv2_conv2d_nhwc_fwd" and args[20] != KH * KW * C):
+            b16 = name.endswith("bf16")
+            o = 8 if b16 else 6   # the bf16 entry point carries x_dtype / y_dtype
+            N, H, W, C, K, KH, KW, stride, pad, in_dil, OH, OW = args[o:o + 12]
+            if K <= 64 or C % 16 != 0 or (not b16 and args[20] != KH * KW * C):
                 return orig(name, *args)  # another template instance
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -79,9 +81,11 @@ class ConvTimer:
             e1.record()
             # algorithmic MACs: a strided conv's dgrad (in_dil > 1) does the forward conv's work
             macs = N * OH * OW * K * KH * KW * C / (in_dil * in_dil if in_dil > 1 else 1)
-            # algorithmic HBM bytes: fp32 activations in and out (+ residual / accumulate read), weights once
-            wb = 2 if name.endswith("bf16") else 4
-            bts = 4 * N * H * W * C + wb * K * KH * KW * C + 4 * N * OH * OW * K * (1 + bool(args[5]) + bool(args[19]))
+            # algorithmic HBM bytes: activations in and out (+ residual / accumulate read) at their element size, weights once
+            xb = (2 if args[1] else 4) if b16 else 4
+            yb = (2 if args[4] else 4) if b16 else 4
+            res, acc = (args[7], args[21]) if b16 else (args[5], args[19])
+            bts = xb * N * H * W * C + (2 if b16 else 4) * K * KH * KW * C + yb * N * OH * OW * K * (1 + bool(res.value if hasattr(res, "value") else res) + bool(acc))
             timer.pairs.append((e0, e1, 2.0 * macs, float(bts)))
 
         hip.call = call

@@ -51,20 +51,26 @@ int utv2_conv2d_ml_wgrad(const float* x, const float* dy, float* dw, float* ws, 
                          utv2_stream_t stream);
 
 /* ---- mixed precision (the reference's SOLVER.AMP.ENABLED configs: autocast at engine/trainer.py:194-198,318-349):
- * bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 activations in HBM (converted while
- * staging into LDS), weights from a bf16 mirror of the arena.  Same contracts as the fp32 entry points. */
+ * bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate, weights from a bf16 mirror of the fp32 master arena.
+ * Activations and activation gradients are bf16 in HBM (autocast stores conv outputs in 16 bit too); every tensor
+ * argument carries its element type (`*_dtype`: UTV2_F32 or UTV2_BF16) so fp32 tensors - the loss-side head outputs,
+ * their gradients, RoIAlign output - enter and leave without a cast pass.  `residual` has y's type.
+ * Same contracts as the fp32 entry points otherwise. */
+#define UTV2_F32 0
+#define UTV2_BF16 1
 int utv2_conv2d_bf16_supported(int C, int KH, int KW);
-int utv2_conv2d_nhwc_fwd_bf16(const float* x, const void* w16, float* y, const float* scale, const float* bias,
-                              const float* residual, int N, int H, int W, int C, int K, int KH, int KW, int stride, int pad,
-                              int in_dil, int OH, int OW, int relu, int accumulate, utv2_stream_t stream);
-int utv2_conv2d_ml_fwd_bf16(const float* x, const void* w16, float* y, const float* scale, const float* bias,
-                            const float* residual, int nlev, const int* H_host, const int* W_host, int N, int C, int K, int KH,
-                            int KW, int pad, int relu, int accumulate, utv2_stream_t stream);
-/* bf16 wgrad; rowinfo = device int32[M][4] {input pixel base, oh*stride-pad, ow*stride-pad, (H<<16)|W} per output pixel */
+int utv2_conv2d_nhwc_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
+                              const float* bias, const void* residual, int N, int H, int W, int C, int K, int KH, int KW,
+                              int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate, utv2_stream_t stream);
+int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
+                            const float* bias, const void* residual, int nlev, const int* H_host, const int* W_host, int N,
+                            int C, int K, int KH, int KW, int pad, int relu, int accumulate, utv2_stream_t stream);
+/* bf16 wgrad (+ fused bias gradient); rowinfo = device int32[M][2] per OUTPUT pixel:
+ * {input pixel index of tap (0,0), (W << 16) | mask of the taps that fall inside the image}; KH*KW <= 16 */
 int utv2_conv2d_wgrad_bf16_splits(int M, int K, int Kred);
 int64_t utv2_conv2d_wgrad_bf16_workspace_floats(int M, int K, int Kred);
-int utv2_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, float* db, float* ws, const int* rowinfo, int M, int C,
-                           int K, int KH, int KW, int accumulate, utv2_stream_t stream);
+int utv2_conv2d_wgrad_bf16(const void* x, int x_dtype, const void* dy, int dy_dtype, float* dw, float* db, float* ws,
+                           const int* rowinfo, int M, int C, int K, int KH, int KW, int accumulate, utv2_stream_t stream);
 int utv2_f32_to_bf16(const float* src, void* dst16, int64_t n, utv2_stream_t stream);
 int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, int K, int KH, int KW, int C, utv2_stream_t stream);
 
@@ -77,13 +83,14 @@ int utv2_sgd_momentum(float* param, float* grad, float* mom_buf, int64_t n, floa
                       float grad_scale, int zero_grad, utv2_stream_t stream);
 
 /* ---- elementwise pieces of ResNet / FPN ([D2-recall]) ------------------ */
-int utv2_relu_bwd_scale(const float* dy, const float* y, const float* scale, float* out, int64_t M, int C,
+int utv2_relu_bwd_scale(const void* dy, const void* y, const float* scale, void* out, int64_t M, int C, int dtype,
                         utv2_stream_t stream);
 int utv2_add(const float* a, const float* b, float* out, int64_t n, utv2_stream_t stream);
-int utv2_maxpool3x3s2_nhwc(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, utv2_stream_t stream);
-int utv2_upsample2x_add_nhwc(const float* lateral, const float* top, float* out, int N, int H, int W, int C,
+int utv2_maxpool3x3s2_nhwc(const void* x, int x_dtype, void* y, int y_dtype, int N, int H, int W, int C, int OH, int OW,
+                           utv2_stream_t stream);
+int utv2_upsample2x_add_nhwc(const void* lateral, const void* top, void* out, int N, int H, int W, int C, int dtype,
                              utv2_stream_t stream);
-int utv2_downsample2x_sum_nhwc(const float* g, float* dtop, int N, int TH, int TW, int C, int accumulate,
+int utv2_downsample2x_sum_nhwc(const void* g, void* dtop, int N, int TH, int TW, int C, int accumulate, int dtype,
                                utv2_stream_t stream);
 /* modeling/one_stage_detector.py:88-90 / meta_arch/rcnn.py:18 (preprocess_image + ImageList pad) */
 int utv2_preprocess_image(const void* src, int is_u8, float* dst, int H, int W, int Hp, int Wp,
@@ -94,12 +101,12 @@ int utv2_frozenbn_fold(const float* w, const float* b, const float* mean, const 
 /* GroupNorm(32)+ReLU of the FCOS towers: fcos/fcos.py:263-264,283.  The _seg forms normalise every
  * (image, FPN level) segment of a level-first [rows][C] buffer in one launch (seg_rows_host: host int[nseg]). */
 int64_t utv2_groupnorm_seg_workspace_floats(int nseg, const int* seg_rows_host, int C);
-int utv2_groupnorm_relu_seg_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                                float* ws, int nseg, const int* seg_rows_host, int C, int G, float eps, int relu,
+int utv2_groupnorm_relu_seg_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                float* ws, int nseg, const int* seg_rows_host, int C, int G, float eps, int relu, int dtype,
                                 utv2_stream_t stream);
-int utv2_groupnorm_relu_seg_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
-                                const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws, int nseg,
-                                const int* seg_rows_host, int C, int G, int relu, utv2_stream_t stream);
+int utv2_groupnorm_relu_seg_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
+                                const float* gamma, void* dx, float* dgamma, float* dbeta, float* ws, int nseg,
+                                const int* seg_rows_host, int C, int G, int relu, int dtype, utv2_stream_t stream);
 int64_t utv2_groupnorm_workspace_floats(int N, int HW, int C);
 int utv2_groupnorm_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                             float* ws, int N, int HW, int C, int G, float eps, int relu, utv2_stream_t stream);

@@ -15,9 +15,20 @@ def r16(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+BF = torch.bfloat16
+
+
+def close16(y, ref):
+    """y (bf16 tensor) == RNE(ref') for some ref' within accumulation-order noise of ref"""
+    y = y.float()
+    tol = 2.0 ** -8 * ref.abs() + 2e-4 * ref.abs().max()
+    return bool(((y - ref).abs() <= tol).all())
+
+
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (BF, BF), (torch.float32, BF), (BF, torch.float32)])
 @pytest.mark.parametrize("case", [(2, 25, 42, 256, 256, 3, 1, 1), (2, 13, 21, 256, 256, 3, 2, 1), (2, 50, 84, 64, 256, 1, 1, 0),
                                   (2, 50, 84, 256, 512, 1, 2, 0), (1, 20, 20, 128, 80, 3, 1, 1), (1, 9, 9, 32, 40, 3, 1, 1), (2, 12, 10, 80, 256, 3, 1, 1), (1, 7, 9, 24, 64, 1, 1, 0)])
-def test_conv_bf16_fwd_dgrad(case):
+def test_conv_bf16_fwd_dgrad(case, xdt, ydt):
     from ubteacher import hip
     N, H, W, C, K, k, s, p = case
     g = torch.Generator().manual_seed(0)
@@ -25,23 +36,34 @@ def test_conv_bf16_fwd_dgrad(case):
     w = torch.randn(K, C, k, k, generator=g) * 0.05
     b = torch.randn(K, generator=g)
     yref = F.conv2d(r16(x), r16(w), b, s, p)
-    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda().to(xdt)
     w2 = w.permute(0, 2, 3, 1).reshape(K, -1).contiguous().cuda()
     w16 = torch.empty_like(w2, dtype=torch.bfloat16)
     hip.f32_to_bf16(w2, w16)
     assert torch.equal(w16.cpu(), w2.cpu().to(torch.bfloat16))       # RNE conversion == torch's
-    y = hip.conv2d_fwd_bf16(xh, w16, bias=b.cuda(), stride=s, pad=p, kh=k, kw=k)
-    assert relerr(y.cpu().permute(0, 3, 1, 2), yref) < 2e-4
+    y = hip.conv2d_fwd_bf16(xh, w16, bias=b.cuda(), stride=s, pad=p, kh=k, kw=k, out_dtype=ydt)
+    assert y.dtype == ydt
+    yc = y.cpu().permute(0, 3, 1, 2)
+    assert relerr(yc, yref) < 2e-4 if ydt == torch.float32 else close16(yc, yref)
+    # fused epilogue: residual (y's type) + ReLU, one rounding at the store
+    res = torch.randn(yref.shape, generator=g)
+    resh = res.permute(0, 2, 3, 1).contiguous().cuda().to(ydt)
+    y2 = hip.conv2d_fwd_bf16(xh, w16, bias=b.cuda(), residual=resh, stride=s, pad=p, kh=k, kw=k, relu=True, out_dtype=ydt)
+    ref2 = torch.relu(yref + resh.float().cpu().permute(0, 3, 1, 2))
+    y2c = y2.cpu().permute(0, 3, 1, 2)
+    assert relerr(y2c, ref2) < 2e-4 if ydt == torch.float32 else close16(y2c, ref2)
     if K % 8 == 0:
         dy = torch.randn(yref.shape, generator=g)
         xr = x.clone().requires_grad_(True)
         F.conv2d(xr, r16(w), None, s, p).backward(r16(dy))
         wt16 = hip.weight_flip_transpose_bf16(w2, K, k, k, C)
-        dx = hip.conv2d_dgrad_bf16(dy.permute(0, 2, 3, 1).contiguous().cuda(), wt16, (N, H, W, C), s, p, k, k)
-        assert relerr(dx.cpu().permute(0, 3, 1, 2), xr.grad) < 2e-4
+        dx = hip.conv2d_dgrad_bf16(dy.permute(0, 2, 3, 1).contiguous().cuda().to(xdt), wt16, (N, H, W, C), s, p, k, k, out_dtype=ydt)
+        dxc = dx.cpu().permute(0, 3, 1, 2)
+        assert relerr(dxc, xr.grad) < 2e-4 if ydt == torch.float32 else close16(dxc, xr.grad)
 
 
-def test_conv_ml_bf16():
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (BF, BF), (BF, torch.float32)])
+def test_conv_ml_bf16(xdt, ydt):
     from ubteacher import hip
     from ubteacher.ops import LevelMeta
     g = torch.Generator().manual_seed(1)
@@ -50,11 +72,13 @@ def test_conv_ml_bf16():
     meta = LevelMeta(N, level_hw)
     xs = [torch.randn(N, C, h, w, generator=g) for h, w in level_hw]
     wt = torch.randn(K, C, k, k, generator=g) * 0.1
-    big = torch.cat([x.permute(0, 2, 3, 1).reshape(-1, C) for x in xs]).cuda()
+    big = torch.cat([x.permute(0, 2, 3, 1).reshape(-1, C) for x in xs]).cuda().to(xdt)
     w16 = wt.permute(0, 2, 3, 1).reshape(K, -1).contiguous().cuda().to(torch.bfloat16)
-    y = hip.conv2d_ml_fwd_bf16(big, w16, level_hw, N, k=k, pad=1)
+    y = hip.conv2d_ml_fwd_bf16(big, w16, level_hw, N, k=k, pad=1, out_dtype=ydt)
     for l, x in enumerate(xs):
-        assert relerr(meta.level_view(y, l).permute(0, 3, 1, 2).cpu(), F.conv2d(r16(x), r16(wt), None, 1, 1)) < 2e-4
+        ref = F.conv2d(r16(x), r16(wt), None, 1, 1)
+        got = meta.level_view(y, l).permute(0, 3, 1, 2).cpu()
+        assert relerr(got, ref) < 2e-4 if ydt == torch.float32 else close16(got, ref)
 
 
 def _to_oracle_pseudo(pb):
@@ -120,9 +144,11 @@ def test_fcos_step_bf16_vs_rounding_oracle():
         assert torch.equal(t_after[k], new_t[k]), k
 
 
+@pytest.mark.parametrize("xdt,dydt", [(torch.float32, torch.float32), (BF, BF), (BF, torch.float32), (torch.float32, BF)])
 @pytest.mark.parametrize("case", [(2, 25, 42, 256, 256, 3, 1, 1), (2, 13, 21, 64, 128, 3, 2, 1), (2, 50, 84, 64, 256, 1, 1, 0),
-                                  (2, 30, 40, 256, 512, 1, 2, 0), (1, 20, 20, 128, 80, 3, 1, 1), (3, 9, 9, 32, 40, 3, 1, 1)])
-def test_conv_bf16_wgrad(case):
+                                  (2, 30, 40, 256, 512, 1, 2, 0), (1, 20, 20, 128, 80, 3, 1, 1), (3, 9, 9, 32, 40, 3, 1, 1),
+                                  (1, 11, 7, 24, 16, 3, 1, 1), (2, 8, 8, 200, 136, 1, 1, 0)])
+def test_conv_bf16_wgrad(case, xdt, dydt):
     from ubteacher import hip
     N, H, W, C, K, k, s, p = case
     g = torch.Generator().manual_seed(2)
@@ -132,18 +158,22 @@ def test_conv_bf16_wgrad(case):
     dy = torch.randn(y.shape, generator=g)
     y.backward(r16(dy))
     ref = w.grad.permute(0, 2, 3, 1).reshape(K, -1)
-    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
-    dyh = dy.permute(0, 2, 3, 1).contiguous().cuda()
-    ri = hip.rowinfo_nhwc(N, H, W, dyh.shape[1], dyh.shape[2], s, p, "cuda")
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda().to(xdt)
+    dyh = dy.permute(0, 2, 3, 1).contiguous().cuda().to(dydt)
+    ri = hip.rowinfo_nhwc(N, H, W, dyh.shape[1], dyh.shape[2], s, p, k, k, "cuda")
     dw = torch.zeros(K, k * k * C, device="cuda")
     db = torch.zeros(K, device="cuda")
     hip.conv2d_wgrad_bf16(xh, dyh.reshape(-1, K), dw, ri, C, k, k, accumulate=True, db=db)
     hip.conv2d_wgrad_bf16(xh, dyh.reshape(-1, K), dw, ri, C, k, k, accumulate=True, db=db)
     assert relerr(dw.cpu() / 2, ref) < 2e-4
-    assert relerr(db.cpu() / 2, dy.sum((0, 2, 3))) < 2e-5      # bias gradient: fp32 column sums of the UNROUNDED dy
+    assert relerr(db.cpu() / 2, r16(dy).sum((0, 2, 3))) < 2e-5      # bias gradient: fp32 column sums of the bf16 dy operand
+    dw2 = torch.zeros_like(dw)
+    hip.conv2d_wgrad_bf16(xh, dyh.reshape(-1, K), dw2, ri, C, k, k, accumulate=False)
+    assert torch.equal(dw2 * 2, dw)                                   # deterministic (fixed-order slab reduction)
 
 
-def test_conv_ml_bf16_wgrad():
+@pytest.mark.parametrize("xdt,dydt", [(torch.float32, torch.float32), (BF, BF), (BF, torch.float32)])
+def test_conv_ml_bf16_wgrad(xdt, dydt):
     from ubteacher import hip
     g = torch.Generator().manual_seed(3)
     N, C, K, k = 2, 64, 80, 3
@@ -153,8 +183,38 @@ def test_conv_ml_bf16_wgrad():
     ys = [F.conv2d(r16(x), wt, None, 1, 1) for x in xs]
     dys = [torch.randn(y.shape, generator=g) for y in ys]
     torch.autograd.backward(ys, [r16(d) for d in dys])
-    big = torch.cat([x.permute(0, 2, 3, 1).reshape(-1, C) for x in xs]).cuda()
-    dy = torch.cat([d.permute(0, 2, 3, 1).reshape(-1, K) for d in dys]).cuda()
+    big = torch.cat([x.permute(0, 2, 3, 1).reshape(-1, C) for x in xs]).cuda().to(xdt)
+    dy = torch.cat([d.permute(0, 2, 3, 1).reshape(-1, K) for d in dys]).cuda().to(dydt)
     dw = torch.zeros(K, k * k * C, device="cuda")
-    hip.conv2d_wgrad_bf16(big, dy, dw, hip.rowinfo_ml(N, level_hw, 1, "cuda"), C, k, k, accumulate=False)
+    hip.conv2d_wgrad_bf16(big, dy, dw, hip.rowinfo_ml(N, level_hw, 1, k, "cuda"), C, k, k, accumulate=False)
     assert relerr(dw.cpu(), wt.grad.permute(0, 2, 3, 1).reshape(K, -1)) < 2e-4
+
+
+def test_elementwise_bf16():
+    """bf16-I/O forms of the glue kernels == the fp32 kernels applied to the same (bf16-representable) values, rounded once."""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(4)
+    N, H, W, C = 2, 12, 16, 128
+    x = r16(torch.randn(N, H, W, C, generator=g)).cuda()
+    dy = r16(torch.randn(N, H, W, C, generator=g)).cuda()
+    sc = torch.rand(C, generator=g).cuda() + 0.5
+    y = torch.relu(x)
+    a = hip.relu_bwd_scale(dy.to(BF), y.to(BF), sc)
+    assert a.dtype == BF and torch.equal(a, hip.relu_bwd_scale(dy, y, sc).to(BF))
+    assert torch.equal(hip.maxpool3x3s2(x, out_dtype=BF), hip.maxpool3x3s2(x).to(BF))
+    assert torch.equal(hip.maxpool3x3s2(x.to(BF)), hip.maxpool3x3s2(x).to(BF))
+    top = r16(torch.randn(N, H // 2, W // 2, C, generator=g)).cuda()
+    assert torch.equal(hip.upsample2x_add(x.to(BF), top.to(BF)), hip.upsample2x_add(x, top).to(BF))
+    assert torch.equal(hip.downsample2x_sum(dy.to(BF)), hip.downsample2x_sum(dy).to(BF))
+    # GroupNorm: same statistics (fp32 from the same values), one rounding of y / dx
+    ga = (torch.rand(C, generator=g) + 0.5).cuda(); be = torch.randn(C, generator=g).cuda()
+    seg = [H * W] * N
+    y32, m32, r32 = hip.groupnorm_relu_seg_fwd(x.view(-1, C), seg, ga, be, 32, 1e-5, True)
+    y16, m16, r16_ = hip.groupnorm_relu_seg_fwd(x.view(-1, C).to(BF), seg, ga, be, 32, 1e-5, True)
+    assert torch.equal(m32, m16) and torch.equal(r32, r16_) and torch.equal(y16, y32.to(BF))
+    dg32 = torch.zeros(C, device="cuda"); db32 = torch.zeros(C, device="cuda")
+    dg16 = torch.zeros(C, device="cuda"); db16 = torch.zeros(C, device="cuda")
+    y16f = y16.float()   # the mask (y > 0) and x must be identical in both runs
+    dx32 = hip.groupnorm_relu_seg_bwd(dy.view(-1, C), y16f, x.view(-1, C), seg, m32, r32, ga, dg32, db32, 32, True)
+    dx16 = hip.groupnorm_relu_seg_bwd(dy.view(-1, C).to(BF), y16, x.view(-1, C).to(BF), seg, m32, r32, ga, dg16, db16, 32, True)
+    assert torch.equal(dx16, dx32.to(BF)) and torch.equal(dg16, dg32) and torch.equal(db16, db32)

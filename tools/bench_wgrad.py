@@ -21,7 +21,7 @@ x = torch.randn(P, C, device="cuda"); dy = torch.randn(P, K, device="cuda")
 w = torch.randn(K, 9 * C, device="cuda") * 0.05
 w16 = w.to(torch.bfloat16)
 dw = torch.zeros_like(w)
-ri = hip.rowinfo_ml(N, level_hw, 1, "cuda")
+ri = hip.rowinfo_ml(N, level_hw, 1, 3, "cuda")
 fl = 2.0 * P * K * 9 * C
 t = timeit(lambda: hip.conv2d_wgrad_bf16(x, dy, dw, ri, C, 3, 3, accumulate=True)); print("tower wgrad bf16 %.3f ms %.1f TF" % (t, fl / t / 1e9))
 t = timeit(lambda: hip.conv2d_ml_wgrad(x, dy, dw, level_hw, N, 3, 1, accumulate=True)); print("tower wgrad f32  %.3f ms %.1f TF" % (t, fl / t / 1e9))
@@ -32,7 +32,7 @@ for (n, h, ww, c, k, ks, s, p) in [(8, 50, 84, 1024, 256, 1, 1, 0), (8, 50, 84, 
     xx = torch.randn(n, h, ww, c, device="cuda"); wt = torch.randn(k, ks * ks * c, device="cuda") * 0.05
     yy = hip.conv2d_fwd(xx, wt, stride=s, pad=p, kh=ks, kw=ks)
     dyy = torch.randn_like(yy); dww = torch.zeros_like(wt)
-    rr = hip.rowinfo_nhwc(n, h, ww, yy.shape[1], yy.shape[2], s, p, "cuda")
+    rr = hip.rowinfo_nhwc(n, h, ww, yy.shape[1], yy.shape[2], s, p, ks, ks, "cuda")
     f = 2.0 * yy.shape[0] * yy.shape[1] * yy.shape[2] * k * ks * ks * c
     t1 = timeit(lambda: hip.conv2d_wgrad_bf16(xx, dyy.view(-1, k), dww, rr, c, ks, ks, accumulate=True))
     t2 = timeit(lambda: hip.conv2d_wgrad(xx, dyy, dww, s, p, ks, ks, accumulate=True))

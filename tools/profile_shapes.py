@@ -17,24 +17,37 @@ def call(name, *args):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(); orig_call(name, *args); e1.record()
         if name in ("utv2_conv2d_nhwc_fwd", "utv2_conv2d_nhwc_fwd_bf16"):
-            N, H, W, C, K, KH, KW, stride, pad, in_dil, OH, OW = args[6:18]
+            b16 = "bf16" in name
+            o = 8 if b16 else 6
+            N, H, W, C, K, KH, KW, stride, pad, in_dil, OH, OW = args[o:o + 12]
+            xb = (2 if args[1] else 4) if b16 else 4
+            yb = (2 if args[4] else 4) if b16 else 4
+            res, acc = (args[7], args[21]) if b16 else (args[5], args[19])
             key = ("ig16" if "bf16" in name else "ig32", N, H, W, C, K, KH, stride, in_dil, OH, OW)
             fl = 2.0 * N * OH * OW * K * KH * KW * C / (in_dil * in_dil if in_dil > 1 else 1)
+            by = xb * N * H * W * C + yb * N * OH * OW * K * (1 + bool(res.value if hasattr(res, "value") else res) + bool(acc)) + 2.0 * K * KH * KW * C
         elif name in ("utv2_conv2d_ml_fwd_bf16", "utv2_conv2d_ml_fwd"):
-            nlev, _, _, N, C, K, KH, KW = args[6:14]
-            key = ("ml16" if "bf16" in name else "ml32", N, 0, 0, C, K, KH, 1, 1, 0, 0)
+            b16 = "bf16" in name
+            o = 8 if b16 else 6
+            nlev, _, _, N, C, K, KH, KW = args[o:o + 8]
+            key = ("ml16" if b16 else "ml32", N, 0, 0, C, K, KH, 1, 1, 0, 0)
             fl = 2.0 * N * 29841 * K * KH * KW * C
+            xb = (2 if args[1] else 4) if b16 else 4
+            yb = (2 if args[4] else 4) if b16 else 4
+            by = N * 29841 * (xb * C + yb * K)
         elif name == "utv2_conv2d_wgrad_bf16":
-            M, C, K, KH, KW = args[5:10]
+            M, C, K, KH, KW = args[8:13]
             key = ("wg16", M, 0, 0, C, K, KH, 1, 1, 0, 0)
             fl = 2.0 * M * K * KH * KW * C
+            by = M * ((2 if args[1] else 4) * C + (2 if args[3] else 4) * K)
         elif name == "utv2_conv2d_ml_wgrad":
-            key = ("mlwg32", 0, 0, 0, 0, 0, 0, 1, 1, 0, 0); fl = 0
+            key = ("mlwg32", 0, 0, 0, 0, 0, 0, 1, 1, 0, 0); fl = 0; by = 0
         else:
             N, H, W, C, K, KH, KW, stride, pad, OH, OW = args[4:15]
             key = ("wgrad", N, H, W, C, K, KH, stride, 1, OH, OW)
             fl = 2.0 * N * OH * OW * K * KH * KW * C
-        recs.append((key, e0, e1, fl))
+            by = 4.0 * N * (H * W * C + OH * OW * K)
+        recs.append((key, e0, e1, fl, by))
     else:
         orig_call(name, *args)
 
@@ -49,11 +62,11 @@ bench.ConvTimer = T
 bench.main()
 torch.cuda.synchronize()
 agg = collections.OrderedDict()
-for key, e0, e1, fl in recs:
-    a = agg.setdefault(key, [0, 0.0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl
+for key, e0, e1, fl, by in recs:
+    a = agg.setdefault(key, [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl; a[3] += by
 rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
 tot = sum(v[1] for v in agg.values())
 print("total conv ms (2 steps): %.1f" % tot)
-print("%-8s %3s %4s %4s %5s %5s %2s %2s %2s %4s %4s | %5s %9s %8s %6s" % ("kind","N","H","W","C","K","k","s","d","OH","OW","calls","ms","TF","pct"))
-for key, (n, ms, fl) in rows[:45]:
-    print("%-8s %6d %4d %4d %5d %5d %2d %2d %2d %4d %4d | %5d %9.3f %8.1f %5.1f%%" % (key + (n, ms, fl / ms / 1e9, 100 * ms / tot)))
+print("%-8s %3s %4s %4s %5s %5s %2s %2s %2s %4s %4s | %5s %9s %8s %8s %6s" % ("kind","N","H","W","C","K","k","s","d","OH","OW","calls","ms","TF","GB/s","pct"))
+for key, (n, ms, fl, by) in rows[:70]:
+    print("%-8s %6d %4d %4d %5d %5d %2d %2d %2d %4d %4d | %5d %9.3f %8.1f %8.0f %5.1f%%" % (key + (n, ms, fl / ms / 1e9, by / ms / 1e6, 100 * ms / tot)))

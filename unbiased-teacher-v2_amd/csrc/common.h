@@ -16,6 +16,29 @@ static inline int utv2_launch_status() {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// activation element types of the C-ABI (`*_dtype` arguments)
+#define UTV2_F32 0
+#define UTV2_BF16 1
+
+// quad (4 consecutive elements) load / store of an activation tensor, arithmetic always in fp32
+__device__ __forceinline__ f32x4 ld4(const float* p, size_t i4) { return ((const f32x4*)p)[i4]; }
+__device__ __forceinline__ f32x4 ld4(const __bf16* p, size_t i4) {
+  const bf16x4_t v = ((const bf16x4_t*)p)[i4];
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (float)v[e];
+  return o;
+}
+__device__ __forceinline__ void st4(float* p, size_t i4, f32x4 v) { ((f32x4*)p)[i4] = v; }
+__device__ __forceinline__ void st4(__bf16* p, size_t i4, f32x4 v) {
+  bf16x4_t o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];  // round-to-nearest-even
+  ((bf16x4_t*)p)[i4] = o;
+}
 
 #define WAVE 64
 
@@ -50,10 +73,11 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
 // accumulators costs 16*TM*TN dword stores per lane that each cover only two 128-byte row pieces; instead
 // the wave bounces one 32-row slab at a time through a private LDS patch and writes full rows with 16-byte
 // stores (and reads the residual the same way).  `lds` = wave-private float[32 * (TN*32 + 4)].
-template <int TN>
-__device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float* lds, int lane, float* __restrict__ y,
+// TO = element type of y / residual (float or __bf16); arithmetic is fp32, one rounding at the store.
+template <int TN, typename TO = float>
+__device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float* lds, int lane, TO* __restrict__ y,
                                               const float* __restrict__ scale, const float* __restrict__ bias,
-                                              const float* __restrict__ residual, int relu, int accumulate, int m_base,
+                                              const TO* __restrict__ residual, int relu, int accumulate, int m_base,
                                               int co_base, int M, int K) {
   constexpr int COLS = TN * 32, LD = COLS + 4, C4 = COLS / 4, RPI = 64 / C4;  // rows per store instruction
   const int frow = lane & 31, fh = lane >> 5;
@@ -83,7 +107,7 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q] + bi[q];
         if (residual) {
-          const f32x4 r = *(const f32x4*)(residual + off);
+          const f32x4 r = ld4(residual, off >> 2);
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] += r[q];
         }
@@ -92,11 +116,11 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
           for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
         }
         if (accumulate) {
-          const f32x4 o = *(const f32x4*)(y + off);
+          const f32x4 o = ld4(y, off >> 2);
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] += o[q];
         }
-        *(f32x4*)(y + off) = v;
+        st4(y, off >> 2, v);
       }
     }
     __builtin_amdgcn_wave_barrier();

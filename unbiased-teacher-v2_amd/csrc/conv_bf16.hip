@@ -1,19 +1,20 @@
 // Mixed-precision (AMP) implicit-GEMM convolution for gfx950: bf16 operands on
-// v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s dense), fp32 accumulate, fp32 activations in HBM.
+// v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s dense), fp32 accumulate.
 //
 // This is the MI355X counterpart of the reference's `SOLVER.AMP.ENABLED: True` FCOS configs
 // (autocast around the model calls, ubteacher/engine/trainer.py:194-198,318-349): conv operands
-// are rounded to a 16-bit float, products accumulate in fp32.  Activations stay fp32 in memory
-// (so every non-conv kernel is shared with the fp32 path); the loader converts them to bf16
-// (round-to-nearest-even) while staging into LDS.  Weights come from a bf16 mirror of the arena.
+// are 16-bit floats, products accumulate in fp32, conv outputs are stored as 16-bit floats.
+// Activations (and activation gradients) are bf16 in HBM - half the traffic of the HBM-bound 1x1
+// convs and elementwise passes; the kernels are templated on the input / output element type so
+// fp32 tensors (loss-side head outputs and their gradients, RoIAlign output) enter and leave
+// without a cast pass: an fp32 input is rounded to bf16 (RNE) while it is staged into LDS.
+// Weights come from a bf16 mirror of the fp32 master arena.
 //
 // Same tiling as conv.hip (128 x BN tile, 4 waves as 2x2, each 2 x TN 32x32 accumulators) with
 // BK = 32: a row of the LDS tile is 32 bf16 = 64 B (+16 B pad -> the same conflict-free 80-byte
 // stride); each thread stages 8 consecutive k of a row (two 16-byte global loads -> one
 // ds_write_b128); each MFMA reads one ds_read_b128 per operand fragment.
 #include "common.h"
-
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 #define CONV_MAX_LEVELS 8
 struct LevelTab {
@@ -24,12 +25,12 @@ struct LevelTab {
 
 struct ConvArgs16 {
   LevelTab lt;
-  const float* x;            // fp32 NHWC activations
+  const void* x;             // NHWC activations, element type TI
   const __bf16* w;           // bf16 [K][Kred]
-  float* y;
+  void* y;                   // element type TO
   const float* scale;
   const float* bias;
-  const float* residual;
+  const void* residual;      // element type TO
   int N, H, W, C, OH, OW, K, KH, KW, stride, pad, in_dil, relu, Kred, M, accumulate;
 };
 
@@ -47,8 +48,9 @@ __device__ __forceinline__ void ml_decode16(const LevelTab& lt, int m, int& pixb
   pixbase = lt.start[l] + n * hw;
 }
 
-template <int BN, bool ML>
+template <int BN, bool ML, typename TI, typename TO>
 __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
+  constexpr bool IN16 = sizeof(TI) == 2;
   constexpr int BM = 128, BK = 32, LDB = 80;  // LDS row stride in BYTES
   constexpr int TM = 2, TN = BN / 64, BROWS = BN / 64;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * LDB];
@@ -112,7 +114,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
 
   const int nchunks = p.KH * p.KW * ((p.C + BK - 1) / BK);  // a 32-channel slab per tap; the last slab may be partial (C % 8 == 0)
   int kh = 0, kw = 0, c0 = 0;
-  f32x4 ra[2][2];
+  f32x4 ra[2][2];     // TI = float: two quads per row, converted when written to LDS
+  bf16x8_t ra16[2];   // TI = bf16: staged as is
   bf16x8_t rb[BROWS];
 
   auto gload = [&](int kc) {
@@ -127,14 +130,23 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
         iw = iwn / p.in_dil;
       }
       ok = ok && (unsigned)ih < (unsigned)Hr[r] && (unsigned)iw < (unsigned)Wr[r] && (c0 + kg * 8 < p.C);
-      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const float* src = p.x + (size_t)(pixbase[r] + (long long)ih * Wr[r] + iw) * p.C + c0 + kg * 8;
-        v0 = *(const f32x4*)src;
-        v1 = *(const f32x4*)(src + 4);
+      const size_t eoff = (size_t)(pixbase[r] + (long long)ih * Wr[r] + iw) * p.C + c0 + kg * 8;
+      if constexpr (IN16) {
+        bf16x8_t v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+        if (ok) v = *(const bf16x8_t*)((const __bf16*)p.x + eoff);
+        ra16[r] = v;
+      } else {
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          const float* src = (const float*)p.x + eoff;
+          v0 = *(const f32x4*)src;
+          v1 = *(const f32x4*)(src + 4);
+        }
+        ra[r][0] = v0;
+        ra[r][1] = v1;
       }
-      ra[r][0] = v0;
-      ra[r][1] = v1;
     }
 #pragma unroll
     for (int r = 0; r < BROWS; ++r) {
@@ -154,10 +166,14 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       bf16x8_t v;
+      if constexpr (IN16) {
+        v = ra16[r];
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = (__bf16)ra[r][0][e];
-        v[4 + e] = (__bf16)ra[r][1][e];
+        for (int e = 0; e < 4; ++e) {
+          v[e] = (__bf16)ra[r][0][e];
+          v[4 + e] = (__bf16)ra[r][1][e];
+        }
       }
       *(bf16x8_t*)(As + buf * BM * LDB + (lrow + 64 * r) * LDB + kg * 16) = v;
     }
@@ -198,10 +214,12 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
   if ((p.K & 3) == 0) {
     // all MFMAs retired and every wave is past the last barrier of the K loop: the staging LDS is free
     float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
-    epilogue_rows<TN>(acc, patch, lane, p.y, p.scale, p.bias, p.residual, p.relu, p.accumulate, m0 + wm * 64,
-                      n0 + wn * (BN / 2), p.M, p.K);
+    epilogue_rows<TN, TO>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
+                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K);
     return;
   }
+  TO* yo = (TO*)p.y;
+  const TO* res = (const TO*)p.residual;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = n0 + wn * (BN / 2) + j * 32 + frow;
@@ -216,10 +234,10 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
         if (m >= p.M) continue;
         const size_t off = (size_t)m * p.K + co;
         float v = acc[i][j][e] * sc + bi;
-        if (p.residual) v += p.residual[off];
+        if (res) v += (float)res[off];
         if (p.relu) v = fmaxf(v, 0.f);
-        if (p.accumulate) v += p.y[off];
-        p.y[off] = v;
+        if (p.accumulate) v += (float)yo[off];
+        yo[off] = (TO)v;
       }
     }
   }
@@ -271,16 +289,32 @@ static int fill_levels16(LevelTab& lt, int nlev, int N, const int* H, const int*
   return off;
 }
 
+
+template <int BN, bool ML>
+static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dtype, hipStream_t stream) {
+  const dim3 g(tiles), b(256);
+  if (x_dtype == UTV2_BF16) {
+    if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, __bf16, __bf16>), g, b, 0, stream, a);
+    else hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, __bf16, float>), g, b, 0, stream, a);
+  } else {
+    if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, float, __bf16>), g, b, 0, stream, a);
+    else hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, float, float>), g, b, 0, stream, a);
+  }
+}
+
+static inline bool bad_dtype(int d) { return d != UTV2_F32 && d != UTV2_BF16; }
+
 extern "C" {
 
-// 1 if the bf16 MFMA kernel supports this conv (C % 32 == 0), else the caller uses the fp32 kernel
+// 1 if the bf16 MFMA kernel supports this conv (C % 8 == 0), else the caller uses the fp32 kernel
 int utv2_conv2d_bf16_supported(int C, int KH, int KW) { return (C % 8 == 0) ? 1 : 0; }
 
-// w16: bf16 [K][KH*KW*C].  Otherwise identical contract to utv2_conv2d_nhwc_fwd (also serves as dgrad).
-int utv2_conv2d_nhwc_fwd_bf16(const float* x, const void* w16, float* y, const float* scale, const float* bias,
-                              const float* residual, int N, int H, int W, int C, int K, int KH, int KW, int stride, int pad,
-                              int in_dil, int OH, int OW, int relu, int accumulate, hipStream_t stream) {
-  if (!x || !w16 || !y || (C % 8)) return UTV2_EARG;
+// w16: bf16 [K][KH*KW*C].  x is `x_dtype`, y and residual are `y_dtype` (UTV2_F32 / UTV2_BF16).  Otherwise the
+// contract of utv2_conv2d_nhwc_fwd (also serves as dgrad).
+int utv2_conv2d_nhwc_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
+                              const float* bias, const void* residual, int N, int H, int W, int C, int K, int KH, int KW,
+                              int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate, hipStream_t stream) {
+  if (!x || !w16 || !y || (C % 8) || bad_dtype(x_dtype) || bad_dtype(y_dtype)) return UTV2_EARG;
   ConvArgs16 a;
   a.lt.n = 0;
   a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual;
@@ -288,15 +322,16 @@ int utv2_conv2d_nhwc_fwd_bf16(const float* x, const void* w16, float* y, const f
   a.in_dil = in_dil < 1 ? 1 : in_dil; a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.M = N * OH * OW;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
-  if (small) hipLaunchKernelGGL((conv_igemm_bf16<64, false>), dim3(tiles), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((conv_igemm_bf16<128, false>), dim3(tiles), dim3(256), 0, stream, a);
+  if (small) launch_igemm16<64, false>(a, tiles, x_dtype, y_dtype, stream);
+  else launch_igemm16<128, false>(a, tiles, x_dtype, y_dtype, stream);
   return utv2_launch_status();
 }
 
-int utv2_conv2d_ml_fwd_bf16(const float* x, const void* w16, float* y, const float* scale, const float* bias,
-                            const float* residual, int nlev, const int* H_host, const int* W_host, int N, int C, int K, int KH,
-                            int KW, int pad, int relu, int accumulate, hipStream_t stream) {
-  if (!x || !w16 || !y || nlev < 1 || nlev > CONV_MAX_LEVELS || (C % 8) || N <= 0) return UTV2_EARG;
+int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
+                            const float* bias, const void* residual, int nlev, const int* H_host, const int* W_host, int N,
+                            int C, int K, int KH, int KW, int pad, int relu, int accumulate, hipStream_t stream) {
+  if (!x || !w16 || !y || nlev < 1 || nlev > CONV_MAX_LEVELS || (C % 8) || N <= 0 || bad_dtype(x_dtype) || bad_dtype(y_dtype))
+    return UTV2_EARG;
   ConvArgs16 a;
   a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
   a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual;
@@ -304,8 +339,8 @@ int utv2_conv2d_ml_fwd_bf16(const float* x, const void* w16, float* y, const flo
   a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
-  if (small) hipLaunchKernelGGL((conv_igemm_bf16<64, true>), dim3(tiles), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((conv_igemm_bf16<128, true>), dim3(tiles), dim3(256), 0, stream, a);
+  if (small) launch_igemm16<64, true>(a, tiles, x_dtype, y_dtype, stream);
+  else launch_igemm16<128, true>(a, tiles, x_dtype, y_dtype, stream);
   return utv2_launch_status();
 }
 
@@ -331,29 +366,41 @@ int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, int K, int KH, i
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------
-// bf16 wgrad:  dW[co][k] = sum_m dY[m][co] * Xcol[m][k]   (operands rounded to bf16, fp32 accumulate)
+// bf16 wgrad:  dW[co][k] = sum_m dY[m][co] * Xcol[m][k]   (bf16 operands, fp32 accumulate)
 //
-// Both GEMM operands are pixel-major in memory ([m][c], c contiguous) but the MFMA wants 8 consecutive
-// REDUCTION elements (m) per lane.  Each staging thread therefore loads a 4(c) x 8(m) patch (8 coalesced
-// float4 loads down 8 consecutive pixel rows), converts it, and writes four 16-byte LDS rows - a register
-// transpose, no extra pass.  LDS image per operand: 128 rows x 80 B, row r' = c*32 + cq holds the 32 pixels of
-// element (4*cq + c): consecutive lanes write consecutive rows (conflict-free ds_write_b128) and an MFMA
-// tile reads 32 consecutive rows (conflict-free ds_read_b128); the row permutation is undone in the epilogue.
-// Threads 0..127 stage dY, threads 128..255 stage the im2col operand.  Pixel geometry comes from a
-// precomputed per-row table (no integer divisions in the loop, any mix of FPN levels):
-//   rowinfo[m] = { input pixel base of the image, oh*stride - pad, ow*stride - pad, (H << 16) | W }.
+// Both GEMM operands are pixel-major in memory ([m][c], c contiguous) while the MFMA wants 8 consecutive
+// REDUCTION elements (pixels m) per lane.  The tiles are therefore staged into LDS exactly as they lie in
+// memory - [32 pixels][128 channels] bf16, 16-byte copies, no register shuffling - and the fragments are
+// fetched with gfx950's transposing LDS read: ds_read_b64_tr_b16 hands lane i of a 16-lane group the 4-pixel
+// column i of the [4 pixels][16 channels] block whose rows the group addresses (measured semantics: result
+// element j of lane i = element i%4 of the 8-byte chunk addressed by lane 4j + i/4).  Two such reads form one
+// 8-deep MFMA operand; A and B use the same pixel -> k-slot map, which is all the reduction needs.
+// LDS rows are 256 B + 64 B pad: the 4 rows x 64 B a 32-lane half reads land on 64 distinct banks.
+//
+// Pixel geometry comes from a per-output-pixel table (no divisions in the loop, any mix of FPN levels / strides):
+//   rowinfo[m] = { anchor = input pixel index of tap (0,0) (may lie outside the image), (W << 16) | tapmask }
+// tap (kh,kw) of output pixel m reads input pixel anchor + kh*W + kw iff bit kh*KW+kw of tapmask is set.
 struct Wgrad16Args {
-  const float* x;
-  const float* dy;
+  const void* x;
+  const void* dy;
   float* ws;
-  const int4* rowinfo;
+  const int2* rowinfo;
   float* bias_ws;  // optional [splits][K]: per-split column sums of dY (conv bias gradient), fused into the dY staging
   int C, K, KH, KW, Kred, M, splits, chunks_per_split;
 };
 
+__device__ __forceinline__ bf16x4_t lds_read_tr16(const unsigned char* p) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  return __builtin_bit_cast(bf16x4_t, v);
+}
+
+template <typename TX, typename TDY>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
-  constexpr int BK = 32, LDB = 80;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 256 * LDB];  // [buf][A rows 0..127 | B rows 128..255]
+  constexpr int BK = 32, LDR = 320;           // pixels per chunk; LDS row stride in bytes (128 bf16 + pad)
+  constexpr int OPB = BK * LDR;               // one operand tile
+  constexpr bool X16 = sizeof(TX) == 2, DY16 = sizeof(TDY) == 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * OPB];  // [buf][A | B]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tilesN = (p.Kred + 127) / 128, tilesM = (p.K + 127) / 128;
@@ -372,23 +419,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
   const int mt = bid / tilesN, nt = bid - mt * tilesN;
   const int i0 = mt * 128, j0 = nt * 128;
 
-  const bool isB = tid >= 128;
-  const int t = tid & 127;
-  const int cq = t & 31, mo = t >> 5;  // channel quad, pixel octet
-  // fixed per thread: which 4 channels
-  const int cbase = (isB ? j0 : i0) + cq * 4;
-  int tkh = 0, tkw = 0, tci = 0;
-  bool cok;
-  if (isB) {
-    cok = cbase < p.Kred;
-    const int kk = cok ? cbase : 0;
-    const int tap = kk / p.C;
-    tci = kk - tap * p.C;
-    tkh = tap / p.KW;
-    tkw = tap - tkh * p.KW;
-  } else {
-    cok = cbase < p.K;
-  }
+  // staging: thread -> 8-channel group cg of pixel rows pl0 and pl0 + 16 of BOTH operand tiles
+  const int cg = tid & 15, pl0 = tid >> 4;
+  const int co8 = i0 + cg * 8;
+  const bool aok = co8 < p.K;
+  const int kk = j0 + cg * 8;
+  const bool bok = kk < p.Kred;
+  const int tap = bok ? kk / p.C : 0;
+  const int ci = bok ? kk - tap * p.C : 0;
+  const int dh = tap / p.KW, dw = tap - dh * p.KW;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -403,84 +442,105 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
   int chunk_end = chunk_begin + p.chunks_per_split;
   if (chunk_end > total_chunks) chunk_end = total_chunks;
 
-  f32x4 rg[8];
-  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = p.bias_ws != nullptr && !isB && nt == 0;
-  // Loads are UNCONDITIONAL on clamped (always valid) addresses and masked afterwards: a per-element
-  // "load or zero" branch makes hipcc wait for each load in turn (guide section 5, trap (c)).
-  auto gload = [&](int chunk) {
-    const int mbase = chunk * BK + mo * 8;
-    if (isB) {
-      int4 ri[8];
+  int2 ri[2];
+  bf16x8_t ra[2], rb[2];
+  float bsum[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        int m = mbase + e;
-        m = m < p.M ? m : p.M - 1;
-        ri[e] = p.rowinfo[m];
-      }
+  for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+  const bool do_bias = p.bias_ws != nullptr && nt == 0;
+
+  auto rload = [&](int chunk) {  // geometry of the chunk AFTER the one whose data is being loaded: off the critical path
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int H = ri[e].w >> 16, W = ri[e].w & 0xFFFF;
-        const int ih = ri[e].y + tkh, iw = ri[e].z + tkw;
-        const bool ok = cok && (mbase + e) < p.M && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-        const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);
-        f32x4 v = *(const f32x4*)(p.x + ((size_t)ri[e].x + (size_t)ihc * W + iwc) * p.C + tci);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = ok ? v[q] : 0.f;
-        rg[e] = v;
-      }
+    for (int r = 0; r < 2; ++r) {
+      int m = chunk * BK + pl0 + 16 * r;
+      m = m < p.M ? m : p.M - 1;
+      ri[r] = p.rowinfo[m];
+    }
+  };
+  auto load8 = [&](const void* base, size_t eoff, bool is16, bool ok) -> bf16x8_t {
+    bf16x8_t v;
+    if (is16) {
+      v = *(const bf16x8_t*)((const __bf16*)base + eoff);
     } else {
-      const int cb = cok ? cbase : 0;
+      const f32x4 v0 = *(const f32x4*)((const float*)base + eoff), v1 = *(const f32x4*)((const float*)base + eoff + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        int m = mbase + e;
-        const bool ok = cok && m < p.M;
-        m = m < p.M ? m : p.M - 1;
-        f32x4 v = *(const f32x4*)(p.dy + (size_t)m * p.K + cb);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = ok ? v[q] : 0.f;
-        rg[e] = v;
+      for (int e = 0; e < 4; ++e) {
+        v[e] = (__bf16)v0[e];
+        v[4 + e] = (__bf16)v1[e];
       }
+    }
+    // loads are unconditional on a clamped (always valid) address and masked afterwards: a per-element
+    // "load or zero" branch makes hipcc wait for each load in turn
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 b = __builtin_bit_cast(i32x4, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[e] = ok ? b[e] : 0;
+    return __builtin_bit_cast(bf16x8_t, b);
+  };
+  auto gload = [&](int chunk) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int m = chunk * BK + pl0 + 16 * r;
+      const bool mok = m < p.M;
+      const int mc = mok ? m : p.M - 1;
+      ra[r] = load8(p.dy, (size_t)mc * p.K + (aok ? co8 : 0), DY16, mok && aok);
+      const int W = ri[r].y >> 16;
+      const bool ok = mok && bok && ((ri[r].y >> tap) & 1);
+      const int pix = ok ? ri[r].x + dh * W + dw : 0;
+      rb[r] = load8(p.x, (size_t)pix * p.C + ci, X16, ok);
     }
   };
   auto bias_acc = [&]() {
     if (do_bias) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bsum += rg[e];
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[e] += (float)ra[r][e];
     }
   };
   auto lds_store = [&](int buf) {
-    unsigned char* base = smem + buf * 256 * LDB + (isB ? 128 * LDB : 0);
+    unsigned char* ab = smem + buf * 2 * OPB;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      bf16x8_t v;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (__bf16)rg[e][c];
-      *(bf16x8_t*)(base + (c * 32 + cq) * LDB + mo * 16) = v;
+    for (int r = 0; r < 2; ++r) {
+      *(bf16x8_t*)(ab + (pl0 + 16 * r) * LDR + cg * 16) = ra[r];
+      *(bf16x8_t*)(ab + OPB + (pl0 + 16 * r) * LDR + cg * 16) = rb[r];
     }
   };
 
-  const int frow = lane & 31, fh = lane >> 5;
+  // transposing fragment reads: lane (G = lane >> 4, t = lane & 15) addresses pixel row 8*(G>>1) + (t>>2),
+  // channels 16*(G&1) + 4*(t&3) .. +3 of its 32-channel MFMA tile, and receives channel 16*(G&1) + t.
+  const int G = lane >> 4, t = lane & 15;
+  const int frag_off = (8 * (G >> 1) + (t >> 2)) * LDR + (16 * (G & 1) + 4 * (t & 3)) * 2;
   if (chunk_begin < chunk_end) {
+    rload(chunk_begin);
     gload(chunk_begin);
+    if (chunk_begin + 1 < chunk_end) rload(chunk_begin + 1);
     bias_acc();
     lds_store(0);
     __syncthreads();
     for (int ch = chunk_begin; ch < chunk_end; ++ch) {
       const int buf = (ch - chunk_begin) & 1;
-      if (ch + 1 < chunk_end) gload(ch + 1);
-      const unsigned char* ab = smem + buf * 256 * LDB;
-      const unsigned char* bb = ab + 128 * LDB;
+      if (ch + 1 < chunk_end) {
+        gload(ch + 1);
+        if (ch + 2 < chunk_end) rload(ch + 2);
+      }
+      const unsigned char* ab = smem + buf * 2 * OPB + frag_off;
+      const unsigned char* bb = ab + OPB;
       bf16x8_t a[2][2], b[2][2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const unsigned char* ap = ab + (wm * 64 + i * 32 + frow) * LDB + fh * 16;
-        a[i][0] = *(const bf16x8_t*)ap;
-        a[i][1] = *(const bf16x8_t*)(ap + 32);
-        const unsigned char* bp = bb + (wn * 64 + i * 32 + frow) * LDB + fh * 16;
-        b[i][0] = *(const bf16x8_t*)bp;
-        b[i][1] = *(const bf16x8_t*)(bp + 32);
-      }
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const unsigned char* ap = ab + s * 16 * LDR + (wm * 64 + i * 32) * 2;
+          const bf16x4_t a0 = lds_read_tr16(ap), a1 = lds_read_tr16(ap + 4 * LDR);
+          const unsigned char* bp = bb + s * 16 * LDR + (wn * 64 + i * 32) * 2;
+          const bf16x4_t b0 = lds_read_tr16(bp), b1 = lds_read_tr16(bp + 4 * LDR);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a[i][s][e] = a0[e]; a[i][s][4 + e] = a1[e];
+            b[i][s][e] = b0[e]; b[i][s][4 + e] = b1[e];
+          }
+        }
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -491,29 +551,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
       __syncthreads();
     }
   }
-  if (p.bias_ws != nullptr && nt == 0) {  // block-uniform: fixed-order combine of the 4 pixel-octet lanes per channel quad
-    f32x4* red = (f32x4*)smem;
-    if (!isB) red[t] = bsum;
+  if (p.bias_ws != nullptr && nt == 0) {  // block-uniform: fixed-order combine of the 16 pixel lanes per channel group
+    float* red = (float*)smem;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bsum[e];
     __syncthreads();
-    if (!isB && mo == 0 && cok) {
-      f32x4 v = red[cq] + red[32 + cq] + red[64 + cq] + red[96 + cq];
-      *(f32x4*)(p.bias_ws + (size_t)split * p.K + cbase) = v;
+    if (tid < 128 && i0 + tid < p.K) {  // channel i0 + tid = group tid >> 3, element tid & 7
+      float s = 0.f;
+      for (int k = 0; k < 16; ++k) s += red[(k * 16 + (tid >> 3)) * 8 + (tid & 7)];
+      p.bias_ws[(size_t)split * p.K + i0 + tid] = s;
     }
     __syncthreads();
   }
 
-  // LDS row r' = c*32 + cq  <->  element 4*cq + c ;  wave tile (wm, i) covers r' = (wm*2+i)*32 + row
+  const int frow = lane & 31, fh = lane >> 5;
   float* out = p.ws + (size_t)split * p.K * p.Kred;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int k = j0 + 4 * frow + (wn * 2 + j);
+    const int k = j0 + wn * 64 + j * 32 + frow;
     if (k >= p.Kred) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * fh;
-        const int co = i0 + 4 * row + (wm * 2 + i);
+        const int co = i0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         if (co < p.K) out[(size_t)co * p.Kred + k] = acc[i][j][e];
       }
   }
@@ -547,20 +608,30 @@ int64_t utv2_conv2d_wgrad_bf16_workspace_floats(int M, int K, int Kred) {
   return (int64_t)utv2_conv2d_wgrad_bf16_splits(M, K, Kred) * ((int64_t)K * Kred + K);
 }
 
-// rowinfo: device int32[M][4] = {input pixel base, oh*stride-pad, ow*stride-pad, (H<<16)|W} for every OUTPUT pixel m
-// (built once per geometry by the host).  C % 4 == 0, K % 4 == 0.  dw (+)= result; db (optional, [K]) (+)= column sums of dy.
-int utv2_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, float* db, float* ws, const int* rowinfo, int M, int C,
-                           int K, int KH, int KW, int accumulate, hipStream_t stream) {
-  if (!x || !dy || !dw || !ws || !rowinfo || (C & 3) || (K & 3) || M <= 0) return UTV2_EARG;
+// rowinfo: device int32[M][2] = {anchor input pixel, (W << 16) | tapmask} for every OUTPUT pixel m (built once per
+// geometry by the host).  x is `x_dtype` with C channels per pixel, dy is `dy_dtype` [M][K].  C % 8 == 0, K % 8 == 0,
+// KH*KW <= 16.  dw (+)= result; db (optional, [K]) (+)= column sums of dy.
+int utv2_conv2d_wgrad_bf16(const void* x, int x_dtype, const void* dy, int dy_dtype, float* dw, float* db, float* ws,
+                           const int* rowinfo, int M, int C, int K, int KH, int KW, int accumulate, hipStream_t stream) {
+  if (!x || !dy || !dw || !ws || !rowinfo || (C & 7) || (K & 7) || M <= 0 || KH * KW > 16 || bad_dtype(x_dtype) ||
+      bad_dtype(dy_dtype))
+    return UTV2_EARG;
   Wgrad16Args a;
-  a.x = x; a.dy = dy; a.ws = ws; a.rowinfo = (const int4*)rowinfo;
+  a.x = x; a.dy = dy; a.ws = ws; a.rowinfo = (const int2*)rowinfo;
   a.C = C; a.K = K; a.KH = KH; a.KW = KW; a.Kred = KH * KW * C; a.M = M;
   a.splits = utv2_conv2d_wgrad_bf16_splits(M, K, a.Kred);
   a.chunks_per_split = cdiv(cdiv(M, 32), a.splits);
   const size_t n = (size_t)K * a.Kred;
   a.bias_ws = db ? ws + (size_t)a.splits * n : nullptr;   // bias slabs sit behind the weight slabs
   const int tiles = cdiv(K, 128) * cdiv(a.Kred, 128);
-  hipLaunchKernelGGL(conv_wgrad_bf16, dim3(tiles * a.splits), dim3(256), 0, stream, a);
+  const dim3 g(tiles * a.splits), b(256);
+  if (x_dtype == UTV2_BF16) {
+    if (dy_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_wgrad_bf16<__bf16, __bf16>), g, b, 0, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_bf16<__bf16, float>), g, b, 0, stream, a);
+  } else {
+    if (dy_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_wgrad_bf16<float, __bf16>), g, b, 0, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_bf16<float, float>), g, b, 0, stream, a);
+  }
   int rb = cdiv((int64_t)n, 256);
   if (rb > 4096) rb = 4096;
   hipLaunchKernelGGL(reduce_slabs16_f32, dim3(rb), dim3(256), 0, stream, (const float*)ws, dw, n, a.splits, accumulate);

@@ -48,15 +48,16 @@ __global__ __launch_bounds__(256) void sgd_momentum_f32(float* __restrict__ p, f
 
 // ---------------------------------------------------------------------------------------------
 // out = (mask_y ? (y > 0 ? dy : 0) : dy) * (scale ? scale[c] : 1)     on [M][C]
-__global__ __launch_bounds__(256) void relu_bwd_scale_f32(const float* __restrict__ dy, const float* __restrict__ y,
-                                                        const float* __restrict__ scale, float* __restrict__ out,
-                                                        size_t n4, int C4) {
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_scale_k(const T* __restrict__ dy, const T* __restrict__ y,
+                                                      const float* __restrict__ scale, T* __restrict__ out,
+                                                      size_t n4, int C4) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < n4; i += stride) {
-    f32x4 g = ((const f32x4*)dy)[i];
+    f32x4 g = ld4(dy, i);
     if (y) {
-      const f32x4 yy = ((const f32x4*)y)[i];
+      const f32x4 yy = ld4(y, i);
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
     }
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void relu_bwd_scale_f32(const float* __restric
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] *= s[e];
     }
-    ((f32x4*)out)[i] = g;
+    st4(out, i, g);
   }
 }
 
@@ -79,8 +80,9 @@ __global__ __launch_bounds__(256) void add_f32(const float* __restrict__ a, cons
 
 // ---------------------------------------------------------------------------------------------
 // 3x3 stride-2 pad-1 max pool, NHWC (ResNet stem; frozen => forward only)
-__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_f32(const float* __restrict__ x, float* __restrict__ y, int N, int H,
-                                                           int W, int C4, int OH, int OW) {
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_k(const TI* __restrict__ x, TO* __restrict__ y, int N, int H,
+                                                         int W, int C4, int OH, int OW) {
   const size_t total = (size_t)N * OH * OW * C4;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -99,18 +101,19 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_f32(const float* __rest
       for (int dw = 0; dw < 3; ++dw) {
         const int iw = ow * 2 - 1 + dw;
         if ((unsigned)iw >= (unsigned)W) continue;
-        const f32x4 v = ((const f32x4*)x)[((size_t)(n * H + ih) * W + iw) * C4 + c];
+        const f32x4 v = ld4(x, ((size_t)(n * H + ih) * W + iw) * C4 + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
       }
     }
-    ((f32x4*)y)[i] = m;
+    st4(y, i, m);
   }
 }
 
 // FPN top-down: out[n,h,w,:] = lateral[n,h,w,:] + top[n,h/2,w/2,:]   (nearest x2)
-__global__ __launch_bounds__(256) void upsample2x_add_nhwc_f32(const float* __restrict__ lat, const float* __restrict__ top,
-                                                             float* __restrict__ out, int N, int H, int W, int C4) {
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_add_nhwc_k(const T* __restrict__ lat, const T* __restrict__ top,
+                                                           T* __restrict__ out, int N, int H, int W, int C4) {
   const size_t total = (size_t)N * H * W * C4;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -121,15 +124,16 @@ __global__ __launch_bounds__(256) void upsample2x_add_nhwc_f32(const float* __re
     const int w = (int)(t % W); t /= W;
     const int h = (int)(t % H); t /= H;
     const int n = (int)t;
-    const f32x4 a = ((const f32x4*)lat)[i];
-    const f32x4 b = ((const f32x4*)top)[((size_t)(n * TH + (h >> 1)) * TW + (w >> 1)) * C4 + c];
-    ((f32x4*)out)[i] = a + b;
+    const f32x4 a = ld4(lat, i);
+    const f32x4 b = ld4(top, ((size_t)(n * TH + (h >> 1)) * TW + (w >> 1)) * C4 + c);
+    st4(out, i, a + b);
   }
 }
 
 // backward of the nearest x2 upsample: dtop[n,h,w,:] (+)= sum of the 2x2 block of g
-__global__ __launch_bounds__(256) void downsample2x_sum_nhwc_f32(const float* __restrict__ g, float* __restrict__ dtop, int N,
-                                                               int TH, int TW, int C4, int accumulate) {
+template <typename T>
+__global__ __launch_bounds__(256) void downsample2x_sum_nhwc_k(const T* __restrict__ g, T* __restrict__ dtop, int N,
+                                                             int TH, int TW, int C4, int accumulate) {
   const size_t total = (size_t)N * TH * TW * C4;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -140,11 +144,10 @@ __global__ __launch_bounds__(256) void downsample2x_sum_nhwc_f32(const float* __
     const int w = (int)(t % TW); t /= TW;
     const int h = (int)(t % TH); t /= TH;
     const int n = (int)t;
-    const f32x4* gp = (const f32x4*)g;
     const size_t b = ((size_t)(n * H + 2 * h) * W + 2 * w) * C4 + c;
-    f32x4 s = gp[b] + gp[b + C4] + gp[b + (size_t)W * C4] + gp[b + (size_t)W * C4 + C4];
-    if (accumulate) s += ((f32x4*)dtop)[i];
-    ((f32x4*)dtop)[i] = s;
+    f32x4 s = ld4(g, b) + ld4(g, b + C4) + ld4(g, b + (size_t)W * C4) + ld4(g, b + (size_t)W * C4 + C4);
+    if (accumulate) s += ld4(dtop, i);
+    st4(dtop, i, s);
   }
 }
 
@@ -210,7 +213,8 @@ __device__ __forceinline__ void gn_locate(const GnSegs& sg, int chunk, int& seg,
   if (r1 > sg.row0[s + 1]) r1 = sg.row0[s + 1];
 }
 
-__global__ __launch_bounds__(256) void gn_stats_partial(GnSegs sg, const float* __restrict__ x, float* __restrict__ part, int C, int G) {
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_partial(GnSegs sg, const T* __restrict__ x, float* __restrict__ part, int C, int G) {
   // thread t owns channel quad c4 = t % C4 and row lane t / C4 (deterministic reduction order)
   __shared__ float red[2][256];
   int seg, r0, r1;
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(256) void gn_stats_partial(GnSegs sg, const float* 
   const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, RL = blockDim.x / C4;
   float s = 0.f, q = 0.f;
   for (int row = r0 + rl; row < r1; row += RL) {
-    const f32x4 v = ((const f32x4*)x)[(size_t)row * C4 + c4];
+    const f32x4 v = ld4(x, (size_t)row * C4 + c4);
     s += (v[0] + v[1]) + (v[2] + v[3]);
     q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
   }
@@ -266,9 +270,10 @@ __global__ __launch_bounds__(256) void gn_stats_final(GnSegs sg, const float* __
   }
 }
 
-__global__ __launch_bounds__(256) void gn_apply_relu(GnSegs sg, const float* __restrict__ x, const float* __restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_relu(GnSegs sg, const T* __restrict__ x, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                   const float* __restrict__ beta, float* __restrict__ y, int C, int G, int relu) {
+                                                   const float* __restrict__ beta, T* __restrict__ y, int C, int G, int relu) {
   int seg, r0, r1;
   gn_locate(sg, blockIdx.x, seg, r0, r1);
   const int C4 = C >> 2, cpg = C / G;
@@ -278,20 +283,21 @@ __global__ __launch_bounds__(256) void gn_apply_relu(GnSegs sg, const float* __r
   const f32x4 ga = ((const f32x4*)gamma)[c4], be = ((const f32x4*)beta)[c4];
   for (int row = r0 + rl; row < r1; row += RL) {
     const size_t i = (size_t)row * C4 + c4;
-    const f32x4 v = ((const f32x4*)x)[i];
+    const f32x4 v = ld4(x, i);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float t = (v[e] - m) * r * ga[e] + be[e];
       o[e] = relu ? fmaxf(t, 0.f) : t;
     }
-    ((f32x4*)y)[i] = o;
+    st4(y, i, o);
   }
 }
 
 // backward stage 1: per (chunk, c): A = sum g*xhat, B = sum g   with g = dy * (y > 0)
-__global__ __launch_bounds__(256) void gn_bwd_partial(GnSegs sg, const float* __restrict__ dy, const float* __restrict__ y,
-                                                    const float* __restrict__ x, const float* __restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_partial(GnSegs sg, const T* __restrict__ dy, const T* __restrict__ y,
+                                                    const T* __restrict__ x, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, float* __restrict__ part, int C, int G, int relu) {
   __shared__ float red[2][256 * 4];
   int seg, r0, r1;
@@ -303,10 +309,10 @@ __global__ __launch_bounds__(256) void gn_bwd_partial(GnSegs sg, const float* __
   f32x4 A = {0.f, 0.f, 0.f, 0.f}, B = {0.f, 0.f, 0.f, 0.f};
   for (int row = r0 + rl; row < r1; row += RL) {
     const size_t o = (size_t)row * C4 + c4;
-    f32x4 gg = ((const f32x4*)dy)[o];
-    const f32x4 xx = ((const f32x4*)x)[o];
+    f32x4 gg = ld4(dy, o);
+    const f32x4 xx = ld4(x, o);
     if (relu) {
-      const f32x4 yy = ((const f32x4*)y)[o];
+      const f32x4 yy = ld4(y, o);
 #pragma unroll
       for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
     }
@@ -382,10 +388,11 @@ __global__ void gn_bwd_param(const float* __restrict__ AB, float* __restrict__ d
 }
 
 // backward stage 3: dx = rstd * (g*gamma - (s2 + xhat*s1)/cnt)
-__global__ __launch_bounds__(256) void gn_bwd_apply(GnSegs sg, const float* __restrict__ dy, const float* __restrict__ y,
-                                                  const float* __restrict__ x, const float* __restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply(GnSegs sg, const T* __restrict__ dy, const T* __restrict__ y,
+                                                  const T* __restrict__ x, const float* __restrict__ mean,
                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                  const float* __restrict__ s12, float* __restrict__ dx, int C, int G, int relu) {
+                                                  const float* __restrict__ s12, T* __restrict__ dx, int C, int G, int relu) {
   int seg, r0, r1;
   gn_locate(sg, blockIdx.x, seg, r0, r1);
   const int C4 = C >> 2, cpg = C / G;
@@ -397,10 +404,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(GnSegs sg, const float* __re
   const f32x4 ga = ((const f32x4*)gamma)[c4];
   for (int row = r0 + rl; row < r1; row += RL) {
     const size_t i = (size_t)row * C4 + c4;
-    f32x4 gg = ((const f32x4*)dy)[i];
-    const f32x4 xx = ((const f32x4*)x)[i];
+    f32x4 gg = ld4(dy, i);
+    const f32x4 xx = ld4(x, i);
     if (relu) {
-      const f32x4 yy = ((const f32x4*)y)[i];
+      const f32x4 yy = ld4(y, i);
 #pragma unroll
       for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
     }
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(GnSegs sg, const float* __re
       const float xh = (xx[e] - m) * r;
       o[e] = r * (gg[e] * ga[e] - (s2 + xh * s1) * inv_cnt);
     }
-    ((f32x4*)dx)[i] = o;
+    st4(dx, i, o);
   }
 }
 
@@ -434,6 +441,30 @@ static inline int grid_for(size_t n, int block = 256, int cap = 256 * 16) {
   return (int)b;
 }
 
+template <typename T>
+static void gn_fwd_launch(const GnSegs& sg, int chunks, int nseg, const void* x, const float* gamma, const float* beta, void* y,
+                          float* mean, float* rstd, float* ws, int C, int G, float eps, int relu, hipStream_t stream) {
+  hipLaunchKernelGGL(gn_stats_partial<T>, dim3(chunks), dim3(256), 0, stream, sg, (const T*)x, ws, C, G);
+  hipLaunchKernelGGL(gn_stats_final, dim3(nseg), dim3(256), 0, stream, sg, (const float*)ws, mean, rstd, G, C / G, eps);
+  hipLaunchKernelGGL(gn_apply_relu<T>, dim3(chunks), dim3(256), 0, stream, sg, (const T*)x, (const float*)mean, (const float*)rstd,
+                     gamma, beta, (T*)y, C, G, relu);
+}
+
+template <typename T>
+static void gn_bwd_launch(const GnSegs& sg, int chunks, int nseg, const void* dy, const void* y, const void* x, const float* mean,
+                          const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, float* ws, int C, int G,
+                          int relu, hipStream_t stream) {
+  float* part = ws;
+  float* AB = ws + (size_t)chunks * C * 2;
+  float* s12 = AB + (size_t)nseg * C * 2;
+  hipLaunchKernelGGL(gn_bwd_partial<T>, dim3(chunks), dim3(256), 0, stream, sg, (const T*)dy, (const T*)y, (const T*)x, mean, rstd,
+                     part, C, G, relu);
+  hipLaunchKernelGGL(gn_bwd_reduce, dim3(nseg), dim3(256), 2 * C * sizeof(float), stream, sg, (const float*)part, gamma, AB, s12, C, G);
+  hipLaunchKernelGGL(gn_bwd_param, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)AB, dgamma, dbeta, nseg, C);
+  hipLaunchKernelGGL(gn_bwd_apply<T>, dim3(chunks), dim3(256), 0, stream, sg, (const T*)dy, (const T*)y, (const T*)x, mean, rstd,
+                     gamma, (const float*)s12, (T*)dx, C, G, relu);
+}
+
 extern "C" {
 
 int utv2_ema_axpby(float* teacher, const float* student, int64_t n, double keep_rate, hipStream_t stream) {
@@ -455,13 +486,18 @@ int utv2_sgd_momentum(float* param, float* grad, float* mom_buf, int64_t n, floa
   return utv2_launch_status();
 }
 
-// out[M][C] = (y? relu-mask by y : 1) * dy * (scale? scale[c] : 1).  C % 4 == 0.
-int utv2_relu_bwd_scale(const float* dy, const float* y, const float* scale, float* out, int64_t M, int C,
+// out[M][C] = (y? relu-mask by y : 1) * dy * (scale? scale[c] : 1).  C % 4 == 0.  dy / y / out are `dtype`.
+int utv2_relu_bwd_scale(const void* dy, const void* y, const float* scale, void* out, int64_t M, int C, int dtype,
                         hipStream_t stream) {
-  if (!dy || !out || (C & 3)) return UTV2_EARG;
+  if (!dy || !out || (C & 3) || (dtype != UTV2_F32 && dtype != UTV2_BF16)) return UTV2_EARG;
   const size_t n4 = (size_t)M * C / 4;
   if (n4 == 0) return UTV2_OK;
-  hipLaunchKernelGGL(relu_bwd_scale_f32, dim3(grid_for(n4)), dim3(256), 0, stream, dy, y, scale, out, n4, C / 4);
+  if (dtype == UTV2_BF16)
+    hipLaunchKernelGGL(relu_bwd_scale_k<__bf16>, dim3(grid_for(n4)), dim3(256), 0, stream, (const __bf16*)dy, (const __bf16*)y,
+                       scale, (__bf16*)out, n4, C / 4);
+  else
+    hipLaunchKernelGGL(relu_bwd_scale_k<float>, dim3(grid_for(n4)), dim3(256), 0, stream, (const float*)dy, (const float*)y,
+                       scale, (float*)out, n4, C / 4);
   return utv2_launch_status();
 }
 
@@ -472,26 +508,48 @@ int utv2_add(const float* a, const float* b, float* out, int64_t n, hipStream_t 
   return utv2_launch_status();
 }
 
-int utv2_maxpool3x3s2_nhwc(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, hipStream_t stream) {
+// x is `x_dtype`, y is `y_dtype` (the stem conv writes fp32, the bf16 activation pipeline starts here)
+int utv2_maxpool3x3s2_nhwc(const void* x, int x_dtype, void* y, int y_dtype, int N, int H, int W, int C, int OH, int OW,
+                           hipStream_t stream) {
   if (!x || !y || (C & 3)) return UTV2_EARG;
-  hipLaunchKernelGGL(maxpool3x3s2_nhwc_f32, dim3(grid_for((size_t)N * OH * OW * C / 4, 256, 1 << 16)), dim3(256), 0, stream,
-                     x, y, N, H, W, C / 4, OH, OW);
+  const dim3 g(grid_for((size_t)N * OH * OW * C / 4, 256, 1 << 16)), b(256);
+  if (x_dtype == UTV2_F32 && y_dtype == UTV2_F32)
+    hipLaunchKernelGGL((maxpool3x3s2_nhwc_k<float, float>), g, b, 0, stream, (const float*)x, (float*)y, N, H, W, C / 4, OH, OW);
+  else if (x_dtype == UTV2_F32 && y_dtype == UTV2_BF16)
+    hipLaunchKernelGGL((maxpool3x3s2_nhwc_k<float, __bf16>), g, b, 0, stream, (const float*)x, (__bf16*)y, N, H, W, C / 4, OH, OW);
+  else if (x_dtype == UTV2_BF16 && y_dtype == UTV2_BF16)
+    hipLaunchKernelGGL((maxpool3x3s2_nhwc_k<__bf16, __bf16>), g, b, 0, stream, (const __bf16*)x, (__bf16*)y, N, H, W, C / 4, OH, OW);
+  else
+    return UTV2_EARG;
   return utv2_launch_status();
 }
 
-int utv2_upsample2x_add_nhwc(const float* lateral, const float* top, float* out, int N, int H, int W, int C,
+int utv2_upsample2x_add_nhwc(const void* lateral, const void* top, void* out, int N, int H, int W, int C, int dtype,
                              hipStream_t stream) {
   if (!lateral || !top || !out || (C & 3) || (H & 1) || (W & 1)) return UTV2_EARG;
-  hipLaunchKernelGGL(upsample2x_add_nhwc_f32, dim3(grid_for((size_t)N * H * W * C / 4, 256, 1 << 16)), dim3(256), 0, stream,
-                     lateral, top, out, N, H, W, C / 4);
+  const dim3 g(grid_for((size_t)N * H * W * C / 4, 256, 1 << 16)), b(256);
+  if (dtype == UTV2_BF16)
+    hipLaunchKernelGGL(upsample2x_add_nhwc_k<__bf16>, g, b, 0, stream, (const __bf16*)lateral, (const __bf16*)top, (__bf16*)out, N,
+                       H, W, C / 4);
+  else if (dtype == UTV2_F32)
+    hipLaunchKernelGGL(upsample2x_add_nhwc_k<float>, g, b, 0, stream, (const float*)lateral, (const float*)top, (float*)out, N, H,
+                       W, C / 4);
+  else
+    return UTV2_EARG;
   return utv2_launch_status();
 }
 
-int utv2_downsample2x_sum_nhwc(const float* g, float* dtop, int N, int TH, int TW, int C, int accumulate,
+int utv2_downsample2x_sum_nhwc(const void* g, void* dtop, int N, int TH, int TW, int C, int accumulate, int dtype,
                                hipStream_t stream) {
   if (!g || !dtop || (C & 3)) return UTV2_EARG;
-  hipLaunchKernelGGL(downsample2x_sum_nhwc_f32, dim3(grid_for((size_t)N * TH * TW * C / 4, 256, 1 << 16)), dim3(256), 0,
-                     stream, g, dtop, N, TH, TW, C / 4, accumulate);
+  const dim3 gr(grid_for((size_t)N * TH * TW * C / 4, 256, 1 << 16)), b(256);
+  if (dtype == UTV2_BF16)
+    hipLaunchKernelGGL(downsample2x_sum_nhwc_k<__bf16>, gr, b, 0, stream, (const __bf16*)g, (__bf16*)dtop, N, TH, TW, C / 4,
+                       accumulate);
+  else if (dtype == UTV2_F32)
+    hipLaunchKernelGGL(downsample2x_sum_nhwc_k<float>, gr, b, 0, stream, (const float*)g, (float*)dtop, N, TH, TW, C / 4, accumulate);
+  else
+    return UTV2_EARG;
   return utv2_launch_status();
 }
 
@@ -530,34 +588,27 @@ static int gn_check(int nseg, int C, int G) {
   return !(nseg < 1 || nseg > GN_MAX_SEG || (C & 3) || ((C / G) & 3) || C / 4 > 256 || (256 % (C / 4)) || (256 % G));
 }
 
-// x,y: [rows][C]; mean,rstd: [nseg][G] (saved for backward).
-int utv2_groupnorm_relu_seg_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                                float* ws, int nseg, const int* seg_rows_host, int C, int G, float eps, int relu,
+// x,y: [rows][C] of `dtype`; mean,rstd: fp32 [nseg][G] (saved for backward).  Statistics and arithmetic are fp32.
+int utv2_groupnorm_relu_seg_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                float* ws, int nseg, const int* seg_rows_host, int C, int G, float eps, int relu, int dtype,
                                 hipStream_t stream) {
-  if (!x || !y || !mean || !rstd || !ws || !gn_check(nseg, C, G)) return UTV2_EARG;
+  if (!x || !y || !mean || !rstd || !ws || !gn_check(nseg, C, G) || (dtype != UTV2_F32 && dtype != UTV2_BF16)) return UTV2_EARG;
   GnSegs sg;
   const int chunks = gn_fill(sg, nseg, seg_rows_host);
-  hipLaunchKernelGGL(gn_stats_partial, dim3(chunks), dim3(256), 0, stream, sg, x, ws, C, G);
-  hipLaunchKernelGGL(gn_stats_final, dim3(nseg), dim3(256), 0, stream, sg, (const float*)ws, mean, rstd, G, C / G, eps);
-  hipLaunchKernelGGL(gn_apply_relu, dim3(chunks), dim3(256), 0, stream, sg, x, (const float*)mean, (const float*)rstd, gamma,
-                     beta, y, C, G, relu);
+  if (dtype == UTV2_BF16) gn_fwd_launch<__bf16>(sg, chunks, nseg, x, gamma, beta, y, mean, rstd, ws, C, G, eps, relu, stream);
+  else gn_fwd_launch<float>(sg, chunks, nseg, x, gamma, beta, y, mean, rstd, ws, C, G, eps, relu, stream);
   return utv2_launch_status();
 }
 
-// dx written; dgamma/dbeta accumulated (+=).
-int utv2_groupnorm_relu_seg_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
-                                const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws, int nseg,
-                                const int* seg_rows_host, int C, int G, int relu, hipStream_t stream) {
-  if (!dy || !x || !dx || !ws || !gn_check(nseg, C, G)) return UTV2_EARG;
+// dx written (`dtype`, like dy / y / x); dgamma/dbeta (fp32) accumulated (+=).
+int utv2_groupnorm_relu_seg_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
+                                const float* gamma, void* dx, float* dgamma, float* dbeta, float* ws, int nseg,
+                                const int* seg_rows_host, int C, int G, int relu, int dtype, hipStream_t stream) {
+  if (!dy || !x || !dx || !ws || !gn_check(nseg, C, G) || (dtype != UTV2_F32 && dtype != UTV2_BF16)) return UTV2_EARG;
   GnSegs sg;
   const int chunks = gn_fill(sg, nseg, seg_rows_host);
-  float* part = ws;
-  float* AB = ws + (size_t)chunks * C * 2;
-  float* s12 = AB + (size_t)nseg * C * 2;
-  hipLaunchKernelGGL(gn_bwd_partial, dim3(chunks), dim3(256), 0, stream, sg, dy, y, x, mean, rstd, part, C, G, relu);
-  hipLaunchKernelGGL(gn_bwd_reduce, dim3(nseg), dim3(256), 2 * C * sizeof(float), stream, sg, (const float*)part, gamma, AB, s12, C, G);
-  hipLaunchKernelGGL(gn_bwd_param, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)AB, dgamma, dbeta, nseg, C);
-  hipLaunchKernelGGL(gn_bwd_apply, dim3(chunks), dim3(256), 0, stream, sg, dy, y, x, mean, rstd, gamma, (const float*)s12, dx, C, G, relu);
+  if (dtype == UTV2_BF16) gn_bwd_launch<__bf16>(sg, chunks, nseg, dy, y, x, mean, rstd, gamma, dx, dgamma, dbeta, ws, C, G, relu, stream);
+  else gn_bwd_launch<float>(sg, chunks, nseg, dy, y, x, mean, rstd, gamma, dx, dgamma, dbeta, ws, C, G, relu, stream);
   return utv2_launch_status();
 }
 
@@ -574,7 +625,7 @@ int utv2_groupnorm_relu_fwd(const float* x, const float* gamma, const float* bet
   int rows[GN_MAX_SEG];
   if (N > GN_MAX_SEG) return UTV2_EARG;
   for (int i = 0; i < N; ++i) rows[i] = HW;
-  return utv2_groupnorm_relu_seg_fwd(x, gamma, beta, y, mean, rstd, ws, N, rows, C, G, eps, relu, stream);
+  return utv2_groupnorm_relu_seg_fwd(x, gamma, beta, y, mean, rstd, ws, N, rows, C, G, eps, relu, UTV2_F32, stream);
 }
 
 int utv2_groupnorm_relu_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
@@ -583,7 +634,7 @@ int utv2_groupnorm_relu_bwd(const float* dy, const float* y, const float* x, con
   int rows[GN_MAX_SEG];
   if (N > GN_MAX_SEG) return UTV2_EARG;
   for (int i = 0; i < N; ++i) rows[i] = HW;
-  return utv2_groupnorm_relu_seg_bwd(dy, y, x, mean, rstd, gamma, dx, dgamma, dbeta, ws, N, rows, C, G, relu, stream);
+  return utv2_groupnorm_relu_seg_bwd(dy, y, x, mean, rstd, gamma, dx, dgamma, dbeta, ws, N, rows, C, G, relu, UTV2_F32, stream);
 }
 
 }  // extern "C"

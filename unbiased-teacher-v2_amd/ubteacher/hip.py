@@ -90,6 +90,21 @@ def _p(t):
     return c_p(t.data_ptr())
 
 
+def _dt(t):
+    """element-type code of an activation tensor (UTV2_F32 / UTV2_BF16 in include/utv2.h)"""
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise TypeError("activation tensors are fp32 or bf16, got %s" % t.dtype)
+
+
+def _same_dt(*ts):
+    ts = [t for t in ts if t is not None]
+    assert all(t.dtype == ts[0].dtype for t in ts), [t.dtype for t in ts]
+    return _dt(ts[0])
+
+
 def _check(rc, name):
     if rc != 0:
         raise RuntimeError("%s failed with code %d" % (name, rc))
@@ -188,7 +203,7 @@ def relu_bwd_scale(dy, y=None, scale=None, out=None):
     M = dy.numel() // C
     if out is None:
         out = torch.empty_like(dy)
-    call("utv2_relu_bwd_scale", _p(dy), _p(y), _p(scale), _p(out), M, C, _stream())
+    call("utv2_relu_bwd_scale", _p(dy), _p(y), _p(scale), _p(out), M, C, _same_dt(dy, y, out), _stream())
     return out
 
 
@@ -199,11 +214,11 @@ def add(a, b, out=None):
     return out
 
 
-def maxpool3x3s2(x):
+def maxpool3x3s2(x, out_dtype=None):
     N, H, W, C = x.shape
     OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
-    y = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device)
-    call("utv2_maxpool3x3s2_nhwc", _p(x), _p(y), N, H, W, C, OH, OW, _stream())
+    y = torch.empty((N, OH, OW, C), dtype=out_dtype or x.dtype, device=x.device)
+    call("utv2_maxpool3x3s2_nhwc", _p(x), _dt(x), _p(y), _dt(y), N, H, W, C, OH, OW, _stream())
     return y
 
 
@@ -211,15 +226,15 @@ def upsample2x_add(lateral, top):
     N, H, W, C = lateral.shape
     assert top.shape == (N, H // 2, W // 2, C), (lateral.shape, top.shape)
     out = torch.empty_like(lateral)
-    call("utv2_upsample2x_add_nhwc", _p(lateral), _p(top), _p(out), N, H, W, C, _stream())
+    call("utv2_upsample2x_add_nhwc", _p(lateral), _p(top), _p(out), N, H, W, C, _same_dt(lateral, top), _stream())
     return out
 
 
 def downsample2x_sum(g, out=None, accumulate=False):
     N, H, W, C = g.shape
     if out is None:
-        out = torch.empty((N, H // 2, W // 2, C), dtype=torch.float32, device=g.device)
-    call("utv2_downsample2x_sum_nhwc", _p(g), _p(out), N, H // 2, W // 2, C, int(accumulate), _stream())
+        out = torch.empty((N, H // 2, W // 2, C), dtype=g.dtype, device=g.device)
+    call("utv2_downsample2x_sum_nhwc", _p(g), _p(out), N, H // 2, W // 2, C, int(accumulate), _same_dt(g, out), _stream())
     return out
 
 
@@ -495,8 +510,13 @@ def weight_flip_transpose_bf16(w, K, kh, kw, C):
     return wt
 
 
+def _act_dtype(x, out_dtype):
+    return out_dtype if out_dtype is not None else x.dtype
+
+
 def conv2d_fwd_bf16(x, w16, scale=None, bias=None, residual=None, stride=1, pad=0, relu=False, kh=1, kw=1, out=None,
-                    in_dil=1, out_hw=None, accumulate=False):
+                    in_dil=1, out_hw=None, accumulate=False, out_dtype=None):
+    """x: fp32 or bf16 NHWC; the output (and `residual`) element type is out_dtype (default: x's)."""
     N, H, W, C = x.shape
     K = w16.shape[0]
     assert w16.dtype == torch.bfloat16 and C % 8 == 0
@@ -505,60 +525,70 @@ def conv2d_fwd_bf16(x, w16, scale=None, bias=None, residual=None, stride=1, pad=
     else:
         OH, OW = out_hw
     if out is None:
-        out = torch.empty((N, OH, OW, K), dtype=torch.float32, device=x.device)
-    call("utv2_conv2d_nhwc_fwd_bf16", _p(x), _p(w16), _p(out), _p(scale), _p(bias), _p(residual), N, H, W, C, K, kh, kw, stride,
-         pad, in_dil, OH, OW, int(relu), int(accumulate), _stream())
+        out = torch.empty((N, OH, OW, K), dtype=_act_dtype(x, out_dtype), device=x.device)
+    call("utv2_conv2d_nhwc_fwd_bf16", _p(x), _dt(x), _p(w16), _p(out), _same_dt(out, residual), _p(scale), _p(bias), _p(residual),
+         N, H, W, C, K, kh, kw, stride, pad, in_dil, OH, OW, int(relu), int(accumulate), _stream())
     return out
 
 
-def conv2d_dgrad_bf16(dy, wt16, in_shape, stride, pad, kh, kw, out=None):
+def conv2d_dgrad_bf16(dy, wt16, in_shape, stride, pad, kh, kw, out=None, out_dtype=None):
     N, H, W, C = in_shape
     _, OH, OW, K = dy.shape
     if out is None:
-        out = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
-    call("utv2_conv2d_nhwc_fwd_bf16", _p(dy), _p(wt16), _p(out), c_p(0), c_p(0), c_p(0), N, OH, OW, K, C, kh, kw, 1, kh - 1 - pad,
-         stride, H, W, 0, 0, _stream())
+        out = torch.empty((N, H, W, C), dtype=_act_dtype(dy, out_dtype), device=dy.device)
+    call("utv2_conv2d_nhwc_fwd_bf16", _p(dy), _dt(dy), _p(wt16), _p(out), _dt(out), c_p(0), c_p(0), c_p(0), N, OH, OW, K, C, kh, kw,
+         1, kh - 1 - pad, stride, H, W, 0, 0, _stream())
     return out
 
 
-def conv2d_ml_fwd_bf16(x2d, w16, level_hw, N, scale=None, bias=None, residual=None, k=3, pad=1, relu=False, out=None):
+def conv2d_ml_fwd_bf16(x2d, w16, level_hw, N, scale=None, bias=None, residual=None, k=3, pad=1, relu=False, out=None,
+                       out_dtype=None):
     P, C = x2d.shape
     K = w16.shape[0]
     if out is None:
-        out = torch.empty((P, K), dtype=torch.float32, device=x2d.device)
+        out = torch.empty((P, K), dtype=_act_dtype(x2d, out_dtype), device=x2d.device)
     H = _iarr([h for h, _ in level_hw]); W = _iarr([w_ for _, w_ in level_hw])
-    call("utv2_conv2d_ml_fwd_bf16", _p(x2d), _p(w16), _p(out), _p(scale), _p(bias), _p(residual), len(level_hw), ctypes.cast(H, c_p),
-         ctypes.cast(W, c_p), N, C, K, k, k, pad, int(relu), 0, _stream())
+    call("utv2_conv2d_ml_fwd_bf16", _p(x2d), _dt(x2d), _p(w16), _p(out), _same_dt(out, residual), _p(scale), _p(bias), _p(residual),
+         len(level_hw), ctypes.cast(H, c_p), ctypes.cast(W, c_p), N, C, K, k, k, pad, int(relu), 0, _stream())
     return out
 
 
 _rowinfo_cache = {}
 
 
-def rowinfo_nhwc(N, H, W, OH, OW, stride, pad, device):
+def _rowinfo_part(N, H, W, OH, OW, stride, pad, kh, kw, start):
+    """[N*OH*OW, 2] int32: {input pixel index of tap (0,0), (W << 16) | mask of the taps inside the image}"""
+    n = torch.arange(N, dtype=torch.int64).view(N, 1, 1)
+    ih0 = (torch.arange(OH, dtype=torch.int64) * stride - pad).view(1, OH, 1)
+    iw0 = (torch.arange(OW, dtype=torch.int64) * stride - pad).view(1, 1, OW)
+    anchor = (start + n * (H * W) + ih0 * W + iw0).expand(N, OH, OW)
+    mask = torch.zeros((1, OH, OW), dtype=torch.int64)
+    for a in range(kh):
+        for b in range(kw):
+            ok = ((ih0 + a >= 0) & (ih0 + a < H)) & ((iw0 + b >= 0) & (iw0 + b < W))
+            mask = mask | (ok.to(torch.int64) << (a * kw + b))
+    word = ((W << 16) | mask).expand(N, OH, OW)
+    return torch.stack((anchor, word), dim=-1).reshape(-1, 2).to(torch.int32)
+
+
+def rowinfo_nhwc(N, H, W, OH, OW, stride, pad, kh, kw, device):
     """per-output-pixel geometry table for the bf16 wgrad kernel (cached per geometry)."""
-    key = ("nhwc", N, H, W, OH, OW, stride, pad, str(device))
+    assert kh * kw <= 16 and W < 32768
+    key = ("nhwc", N, H, W, OH, OW, stride, pad, kh, kw, str(device))
     t = _rowinfo_cache.get(key)
     if t is None:
-        n = torch.arange(N, dtype=torch.int32).view(N, 1, 1).expand(N, OH, OW)
-        oh = torch.arange(OH, dtype=torch.int32).view(1, OH, 1).expand(N, OH, OW)
-        ow = torch.arange(OW, dtype=torch.int32).view(1, 1, OW).expand(N, OH, OW)
-        t = torch.stack((n * (H * W), oh * stride - pad, ow * stride - pad, torch.full_like(n, (H << 16) | W)), dim=-1)
-        t = t.reshape(-1, 4).contiguous().to(device)
+        t = _rowinfo_part(N, H, W, OH, OW, stride, pad, kh, kw, 0).contiguous().to(device)
         _rowinfo_cache[key] = t
     return t
 
 
-def rowinfo_ml(N, level_hw, pad, device):
-    key = ("ml", N, tuple(level_hw), pad, str(device))
+def rowinfo_ml(N, level_hw, pad, k, device):
+    key = ("ml", N, tuple(level_hw), pad, k, str(device))
     t = _rowinfo_cache.get(key)
     if t is None:
         parts, start = [], 0
         for (h, w) in level_hw:
-            n = torch.arange(N, dtype=torch.int32).view(N, 1, 1).expand(N, h, w)
-            oh = torch.arange(h, dtype=torch.int32).view(1, h, 1).expand(N, h, w)
-            ow = torch.arange(w, dtype=torch.int32).view(1, 1, w).expand(N, h, w)
-            parts.append(torch.stack((start + n * (h * w), oh - pad, ow - pad, torch.full_like(n, (h << 16) | w)), dim=-1).reshape(-1, 4))
+            parts.append(_rowinfo_part(N, h, w, h, w, 1, pad, k, k, start))
             start += N * h * w
         t = torch.cat(parts).contiguous().to(device)
         _rowinfo_cache[key] = t
@@ -566,12 +596,13 @@ def rowinfo_ml(N, level_hw, pad, device):
 
 
 def conv2d_wgrad_bf16(x, dy2d, dw, rowinfo, C, kh, kw, accumulate=True, db=None):
-    """x: fp32 activations (any layout consistent with rowinfo), dy2d [M,K] fp32; dw [K, kh*kw*C] (+)= wgrad;
+    """x: fp32/bf16 activations (any layout consistent with rowinfo), dy2d [M,K] fp32/bf16; dw [K, kh*kw*C] (+)= wgrad;
     db [K] (optional) (+)= column sums of dy (bias gradient, fused into the dY staging)."""
     M, K = dy2d.shape
     nws = load().utv2_conv2d_wgrad_bf16_workspace_floats(M, K, kh * kw * C)
     ws = workspace(nws, dy2d.device, "wgrad")
-    call("utv2_conv2d_wgrad_bf16", _p(x), _p(dy2d), _p(dw), _p(db), _p(ws), _p(rowinfo), M, C, K, kh, kw, int(accumulate), _stream())
+    call("utv2_conv2d_wgrad_bf16", _p(x), _dt(x), _p(dy2d), _dt(dy2d), _p(dw), _p(db), _p(ws), _p(rowinfo), M, C, K, kh, kw,
+         int(accumulate), _stream())
     return dw
 
 
@@ -586,7 +617,7 @@ def groupnorm_relu_seg_fwd(x2d, seg_rows, gamma, beta, G=32, eps=1e-5, relu=True
     sr = _iarr(seg_rows)
     ws = workspace(load().utv2_groupnorm_seg_workspace_floats(S, ctypes.cast(sr, c_p), C), x2d.device, "gn")
     call("utv2_groupnorm_relu_seg_fwd", _p(x2d), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(ws), S, ctypes.cast(sr, c_p), C, G,
-         float(eps), int(relu), _stream())
+         float(eps), int(relu), _dt(x2d), _stream())
     return y, mean, rstd
 
 
@@ -597,5 +628,5 @@ def groupnorm_relu_seg_bwd(dy, y, x2d, seg_rows, mean, rstd, gamma, dgamma, dbet
     sr = _iarr(seg_rows)
     ws = workspace(load().utv2_groupnorm_seg_workspace_floats(S, ctypes.cast(sr, c_p), C), x2d.device, "gn")
     call("utv2_groupnorm_relu_seg_bwd", _p(dy), _p(y), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _p(ws), S,
-         ctypes.cast(sr, c_p), C, G, int(relu), _stream())
+         ctypes.cast(sr, c_p), C, G, int(relu), _same_dt(dy, y, x2d), _stream())
     return dx

@@ -136,7 +136,7 @@ class ResNet50:
         outs = {}
         with torch.no_grad():
             x = self.stem(x4)
-            x = hip.maxpool3x3s2(x)
+            x = hip.maxpool3x3s2(x, out_dtype=ops.act_dtype())  # AMP: the bf16 activation pipeline starts here
         for name, blocks, trainable in self.stages:
             if trainable:
                 for b in blocks:
@@ -171,6 +171,8 @@ class FPN:
             self.lateral[f] = _conv_bias(store, "backbone.fpn_lateral%d" % stage, self.bottom_up.channels[f], oc, 1, 1, 0, _xavier_init)
             self.output[f] = _conv_bias(store, "backbone.fpn_output%d" % stage, oc, oc, 3, 1, 1, _xavier_init)
         self.top_block_kind = top_block_kind
+        # AMP: the maxpool-topped FPN feeds RoIAlign (fp32 kernel) -> keep its level buffer fp32
+        self.levels_fp32 = top_block_kind == "maxpool"
         self.top = []
         if top_block_kind == "p6p7":
             self.top = [_conv_bias(store, "backbone.top_block.p6", oc, oc, 3, 2, 1, _xavier_init),
@@ -200,7 +202,7 @@ class FPN:
             h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1   # conv3x3 s2 p1 == max_pool(k1,s2) output size
             hw["p%d" % (nlast + 1 + i)] = (h, w)
         meta = ops.LevelMeta(N, [hw[k] for k in self.out_names])
-        big = torch.empty((meta.P, C), dtype=torch.float32, device=x4.device)
+        big = torch.empty((meta.P, C), dtype=torch.float32 if self.levels_fp32 else ops.act_dtype(), device=x4.device)
         slot = {k: meta.alias_view(big, i) for i, k in enumerate(self.out_names)}
         results = {}
         prev = None

@@ -139,7 +139,7 @@ class FCOSHead:
         bias_value = -math.log((1 - prior) / prior)
         w = store.new((nc, 9 * C), "decay", lambda t: t.normal_(0.0, 0.01)).export(prefix + ".cls_logits.weight", _nchw_view(nc, C, 3))
         b = store.new((nc,), "decay", lambda t: t.fill_(bias_value)).export(prefix + ".cls_logits.bias")
-        self.cls_logits = ops.Conv(w, C, nc, 3, 1, 1, bias=b)
+        self.cls_logits = ops.Conv(w, C, nc, 3, 1, 1, bias=b, out_fp32=True)
         # fused box head: rows [0:R4) bbox_pred, [R4:R4+4) bbox_pred_std, [R4+4] ctrness, rest zero padding
         R4 = 4 * (self.reg_max + 1)
         self.R4 = R4
@@ -163,7 +163,7 @@ class FCOSHead:
         bb.export(prefix + ".bbox_pred.bias", lambda t: t[0:R4])
         bb.export(prefix + ".bbox_pred_std.bias", lambda t: t[R4:R4 + 4])
         bb.export(prefix + ".ctrness.bias", lambda t: t[R4 + 4:R4 + 5])
-        self.box_head = ops.Conv(wb, C, BOX_STRIDE, 3, 1, 1, bias=bb, colscale=R4)
+        self.box_head = ops.Conv(wb, C, BOX_STRIDE, 3, 1, 1, bias=bb, colscale=R4, out_fp32=True)
         self.scales = None
         if fc.USE_SCALE:
             self.scales = [store.new((1,), "decay", lambda t: t.fill_(1.0)).export("%s.scales.%d.scale" % (prefix, l))

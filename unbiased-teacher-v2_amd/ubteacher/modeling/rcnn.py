@@ -163,7 +163,7 @@ class PseudoLabRPN:
         bp = store.new((RPN_CH,), "decay", lambda t: t.zero_())
         bp.export(prefix + ".rpn_head.objectness_logits.bias", lambda t: t[0:A])
         bp.export(prefix + ".rpn_head.anchor_deltas.bias", lambda t: t[A:5 * A])
-        self.pred = ops.Conv(wp, C, RPN_CH, 1, 1, 0, bias=bp)
+        self.pred = ops.Conv(wp, C, RPN_CH, 1, 1, 0, bias=bp, out_fp32=True)
         self.batch_size_per_image = r.BATCH_SIZE_PER_IMAGE
         self.positive_fraction = r.POSITIVE_FRACTION
         self.iou_thresholds = list(r.IOU_THRESHOLDS)
@@ -325,7 +325,7 @@ class FastRCNNFocaltLossBoundaryVarOutputLayers:
         b.export(prefix + ".cls_score.bias", lambda t: t[0:K + 1])
         b.export(prefix + ".bbox_pred.bias", lambda t: t[K + 1:K + 5])
         b.export(prefix + ".bbox_pred_std.bias", lambda t: t[K + 5:K + 9])
-        self.linear = ops.Conv(w, in_dim, PRED_CH, 1, 1, 0, bias=b)
+        self.linear = ops.Conv(w, in_dim, PRED_CH, 1, 1, 0, bias=b, out_fp32=True)
         self.box2box_transform = Box2BoxXYXYTransform(tuple(bh.BBOX_REG_WEIGHTS))
         self.smooth_l1_beta = bh.SMOOTH_L1_BETA
         self.test_score_thresh = rh.SCORE_THRESH_TEST

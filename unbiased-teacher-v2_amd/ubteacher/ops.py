@@ -1,7 +1,7 @@
 """Autograd wrappers around the C-ABI HIP kernels (ubteacher.hip).
 
 Design notes (MI355X-first, not a translation of torch.nn):
-  * activations are NHWC fp32 tensors; weights live in the flat ParamStore arena;
+  * activations are NHWC tensors - fp32, or bf16 under AMP (`act_dtype()`); weights live in the flat fp32 ParamStore arena;
   * parameter gradients are NOT returned to autograd: every backward accumulates straight into
     the flat gradient arena (`handle.g`), so one flat RCCL all-reduce + one SGD launch follow;
   * a per-device `hook` tensor (requires_grad) is threaded through every Function so backward
@@ -19,6 +19,11 @@ PRECISION = ["fp32"]  # "fp32" (exact-f32 MFMA; the parity path) or "bf16" (AMP:
 def set_precision(p):
     assert p in ("fp32", "bf16")
     PRECISION[0] = p
+
+
+def act_dtype():
+    """Element type of activations (and their gradients) in HBM: bf16 under AMP, like autocast's conv outputs."""
+    return torch.bfloat16 if PRECISION[0] == "bf16" else torch.float32
 
 
 _VERSION = [0]  # bumped by the optimizer step: invalidates cached dgrad weight images
@@ -70,7 +75,7 @@ class Conv:
     """One convolution (+ optional folded FrozenBN or bias, ReLU, residual) bound to arena handles."""
 
     def __init__(self, w, cin, cout, k, stride=1, pad=0, bias=None, bn=None, relu=False, trainable=True,
-                 kred=None, colscale=None):
+                 kred=None, colscale=None, out_fp32=False):
         self.w = w  # Handle, shape [cout, kred]
         self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
         self.bias = bias  # Handle [cout] or None
@@ -79,6 +84,7 @@ class Conv:
         self.trainable = trainable
         self.kred = kred if kred is not None else k * k * cin
         self.colscale = colscale  # (Handle scalar, ncols): Scale layer on the first ncols output channels
+        self.out_fp32 = out_fp32  # AMP: keep this layer's output fp32 (loss-side head outputs, RoIAlign inputs)
         self._wt = None
         self._wt_version = -1
 
@@ -105,7 +111,8 @@ class Conv:
         return PRECISION[0] == "bf16" and self.cin % 8 == 0 and self.kred == self.k * self.k * self.cin
 
     def use_bf16_wgrad(self):
-        return PRECISION[0] == "bf16" and self.cin % 4 == 0 and self.cout % 4 == 0 and self.kred == self.k * self.k * self.cin
+        return (PRECISION[0] == "bf16" and self.cin % 8 == 0 and self.cout % 8 == 0 and self.k * self.k <= 16
+                and self.kred == self.k * self.k * self.cin)
 
     def use_bf16_dgrad(self):
         return PRECISION[0] == "bf16" and self.cout % 8 == 0
@@ -121,20 +128,27 @@ class Conv:
         sc, sh = self.scale_shift()
         b16 = self.use_bf16()
         w = self.w.store.bf16(self.w) if b16 else self.w.t
+        kw = {}
+        if b16:  # output element type: the destination's if one is given, else bf16 unless this layer feeds fp32 consumers
+            kw["out_dtype"] = out.dtype if out is not None else (torch.float32 if self.out_fp32 else torch.bfloat16)
+        else:
+            assert x.dtype == torch.float32, "the fp32 conv kernels take fp32 activations (layer cin=%d)" % self.cin
         if meta is not None and self.k > 1:
             assert self.stride == 1 and self.pad == (self.k - 1) // 2
             fn = hip.conv2d_ml_fwd_bf16 if b16 else hip.conv2d_ml_fwd
-            y = fn(x, w, meta.level_hw, meta.N, scale=sc, bias=sh, residual=residual, k=self.k, pad=self.pad, relu=self.relu, out=out)
+            y = fn(x, w, meta.level_hw, meta.N, scale=sc, bias=sh, residual=residual, k=self.k, pad=self.pad, relu=self.relu, out=out,
+                   **kw)
         elif meta is not None:  # 1x1 on a level-first matrix: plain GEMM rows
             fn = hip.conv2d_fwd_bf16 if b16 else hip.conv2d_fwd
             y = fn(x.view(1, x.shape[0], 1, x.shape[1]), w, scale=sc, bias=sh,
                    residual=None if residual is None else residual.view(1, x.shape[0], 1, -1), relu=self.relu,
-                   out=None if out is None else out.view(1, x.shape[0], 1, -1)).view(x.shape[0], self.cout)
+                   out=None if out is None else out.view(1, x.shape[0], 1, -1), **kw).view(x.shape[0], self.cout)
         else:
             fn = hip.conv2d_fwd_bf16 if b16 else hip.conv2d_fwd
             y = fn(x, w, scale=sc, bias=sh, residual=residual, stride=self.stride, pad=self.pad, relu=self.relu, kh=self.k,
-                   kw=self.k, out=out)
+                   kw=self.k, out=out, **kw)
         if cs is not None:
+            assert y.dtype == torch.float32
             if meta is not None:
                 for l, h in enumerate(cs):
                     r0, r1 = meta.rows[l]
@@ -191,11 +205,12 @@ class _ConvFn(torch.autograd.Function):
         if meta is not None and layer.k > 1:
             if ctx.needs_input_grad[0]:
                 if d16:
-                    dx = hip.conv2d_ml_fwd_bf16(g, layer.wt16(), meta.level_hw, meta.N, k=layer.k, pad=layer.k - 1 - layer.pad)
+                    dx = hip.conv2d_ml_fwd_bf16(g, layer.wt16(), meta.level_hw, meta.N, k=layer.k, pad=layer.k - 1 - layer.pad,
+                                                out_dtype=x.dtype)
                 else:
                     dx = hip.conv2d_ml_dgrad(g, layer.wt(), meta.level_hw, meta.N, layer.k, layer.pad)
             if layer.use_bf16_wgrad():
-                hip.conv2d_wgrad_bf16(x, g, layer.w.g, hip.rowinfo_ml(meta.N, meta.level_hw, layer.pad, x.device), layer.cin,
+                hip.conv2d_wgrad_bf16(x, g, layer.w.g, hip.rowinfo_ml(meta.N, meta.level_hw, layer.pad, layer.k, x.device), layer.cin,
                                       layer.k, layer.k, accumulate=True, db=layer.bias.g if layer.bias is not None else None)
                 bias_done = True
             else:
@@ -205,14 +220,15 @@ class _ConvFn(torch.autograd.Function):
             g4 = g.view(1, g.shape[0], 1, g.shape[1]) if meta is not None else g
             if ctx.needs_input_grad[0]:
                 if d16:
-                    dx = hip.conv2d_dgrad_bf16(g4, layer.wt16(), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k)
+                    dx = hip.conv2d_dgrad_bf16(g4, layer.wt16(), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k,
+                                               out_dtype=x.dtype)
                 else:
                     dx = hip.conv2d_dgrad(g4, layer.wt(), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k)
                 if meta is not None:
                     dx = dx.view(x.shape)
             if layer.use_bf16_wgrad():
                 n_, h_, w_, _ = x4.shape
-                ri = hip.rowinfo_nhwc(n_, h_, w_, g4.shape[1], g4.shape[2], layer.stride, layer.pad, x.device)
+                ri = hip.rowinfo_nhwc(n_, h_, w_, g4.shape[1], g4.shape[2], layer.stride, layer.pad, layer.k, layer.k, x.device)
                 hip.conv2d_wgrad_bf16(x4, g4.reshape(-1, layer.cout), layer.w.g, ri, layer.cin, layer.k, layer.k, accumulate=True,
                                       db=layer.bias.g if layer.bias is not None else None)
                 bias_done = True
@@ -233,8 +249,11 @@ class GroupNormReLU:
         return self._fwd(x, meta)[0]
 
     def _fwd(self, x, meta):
-        if meta is None:
-            return hip.groupnorm_relu_fwd(x, self.gamma.t, self.beta.t, self.groups, self.eps, self.relu)
+        if meta is None:  # one NHWC tensor: a segment per image
+            N, H, W, C = x.shape
+            y, mean, rstd = hip.groupnorm_relu_seg_fwd(x.view(-1, C), [H * W] * N, self.gamma.t, self.beta.t, self.groups, self.eps,
+                                                       self.relu)
+            return y.view(x.shape), mean, rstd
         # statistics are per (image, level, group): ONE launch over all (level, image) segments
         return hip.groupnorm_relu_seg_fwd(x, meta.seg_rows, self.gamma.t, self.beta.t, self.groups, self.eps, self.relu)
 
@@ -254,7 +273,9 @@ class _GNFn(torch.autograd.Function):
         x, y, mean, rstd = ctx.saved_tensors
         dy = dy.contiguous()
         if meta is None:
-            dx = hip.groupnorm_relu_bwd(dy, y, x, mean, rstd, layer.gamma.t, layer.gamma.g, layer.beta.g, layer.groups, layer.relu)
+            N, H, W, C = x.shape
+            dx = hip.groupnorm_relu_seg_bwd(dy.view(-1, C), y.view(-1, C), x.view(-1, C), [H * W] * N, mean, rstd, layer.gamma.t,
+                                            layer.gamma.g, layer.beta.g, layer.groups, layer.relu).view(x.shape)
         else:
             dx = hip.groupnorm_relu_seg_bwd(dy, y, x, meta.seg_rows, mean, rstd, layer.gamma.t, layer.gamma.g, layer.beta.g,
                                             layer.groups, layer.relu)
