@@ -22,4 +22,4 @@ def pmc(path, top=12):
 
 
 if __name__ == "__main__":
-    print(pmc(sys.argv[1]))
+    print(pmc(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 12))

@@ -74,21 +74,30 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
 // the wave bounces one 32-row slab at a time through a private LDS patch and writes full rows with 16-byte
 // stores (and reads the residual the same way).  `lds` = wave-private float[32 * (TN*32 + 4)].
 // TO = element type of y / residual (float or __bf16); arithmetic is fp32, one rounding at the store.
+// Every lane moves 16 bytes per access: 4 fp32 or 8 bf16 channels.
 template <int TN, typename TO = float>
 __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float* lds, int lane, TO* __restrict__ y,
                                               const float* __restrict__ scale, const float* __restrict__ bias,
                                               const TO* __restrict__ residual, int relu, int accumulate, int m_base,
                                               int co_base, int M, int K) {
-  constexpr int COLS = TN * 32, LD = COLS + 4, C4 = COLS / 4, RPI = 64 / C4;  // rows per store instruction
+  constexpr int VEC = sizeof(TO) == 2 ? 8 : 4, NQ = VEC / 4;  // channels per lane, as NQ quads
+  constexpr int COLS = TN * 32, LD = COLS + 4, CV = COLS / VEC, RPI = 64 / CV;  // rows per store instruction
   const int frow = lane & 31, fh = lane >> 5;
-  const int c4 = lane % C4, rsub = lane / C4;
-  const int co = co_base + c4 * 4;
-  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
-  const bool cok = co < K;  // K % 4 == 0 is required by the caller
-  if (cok) {
-    if (scale) sc = *(const f32x4*)(scale + co);
-    if (bias) bi = *(const f32x4*)(bias + co);
+  const int cv = lane % CV, rsub = lane / CV;
+  const int co = co_base + cv * VEC;
+  f32x4 sc[NQ], bi[NQ];
+  bool cok[NQ];  // K % 4 == 0 is required by the caller; a bf16 octet may be half outside
+#pragma unroll
+  for (int h = 0; h < NQ; ++h) {
+    sc[h] = f32x4{1.f, 1.f, 1.f, 1.f};
+    bi[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    cok[h] = co + 4 * h < K;
+    if (cok[h]) {
+      if (scale) sc[h] = *(const f32x4*)(scale + co + 4 * h);
+      if (bias) bi[h] = *(const f32x4*)(bias + co + 4 * h);
+    }
   }
+  const bool full = cok[NQ - 1] && (K & 7) == 0;  // keeps the 16-byte accesses 16-byte aligned
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -101,26 +110,50 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
     for (int it = 0; it < 32 / RPI; ++it) {
       const int row = it * RPI + rsub;
       const int m = m_base + i * 32 + row;
-      if (m < M && cok) {
-        f32x4 v = *(const f32x4*)(lds + row * LD + c4 * 4);
+      if (m < M && cok[0]) {
         const size_t off = (size_t)m * K + co;
+        f32x4 v[NQ];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q] + bi[q];
-        if (residual) {
-          const f32x4 r = ld4(residual, off >> 2);
+        for (int h = 0; h < NQ; ++h) {
+          v[h] = *(const f32x4*)(lds + row * LD + cv * VEC + 4 * h);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] += r[q];
+          for (int q = 0; q < 4; ++q) v[h][q] = v[h][q] * sc[h][q] + bi[h][q];
         }
-        if (relu) {
+        if constexpr (NQ == 2) {
+          if (full) {  // 16-byte bf16 accesses
+            if (residual) {
+              const bf16x8_t r = *(const bf16x8_t*)(residual + off);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-        }
-        if (accumulate) {
-          const f32x4 o = ld4(y, off >> 2);
+              for (int q = 0; q < 8; ++q) v[q >> 2][q & 3] += (float)r[q];
+            }
+            if (relu) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] += o[q];
+              for (int q = 0; q < 8; ++q) v[q >> 2][q & 3] = fmaxf(v[q >> 2][q & 3], 0.f);
+            }
+            if (accumulate) {
+              const bf16x8_t o = *(const bf16x8_t*)(y + off);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q >> 2][q & 3] += (float)o[q];
+            }
+            bf16x8_t o;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = (__bf16)v[q >> 2][q & 3];
+            *(bf16x8_t*)(y + off) = o;
+            continue;
+          }
         }
-        st4(y, off >> 2, v);
+#pragma unroll
+        for (int h = 0; h < NQ; ++h) {
+          if (!cok[h]) continue;
+          const size_t o4 = (off >> 2) + h;
+          if (residual) v[h] += ld4(residual, o4);
+          if (relu) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[h][q] = fmaxf(v[h][q], 0.f);
+          }
+          if (accumulate) v[h] += ld4(y, o4);
+          st4(y, o4, v[h]);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();

@@ -15,6 +15,7 @@
 // stride); each thread stages 8 consecutive k of a row (two 16-byte global loads -> one
 // ds_write_b128); each MFMA reads one ds_read_b128 per operand fragment.
 #include "common.h"
+#include <stdlib.h>
 
 #define CONV_MAX_LEVELS 8
 struct LevelTab {
@@ -290,9 +291,209 @@ static int fill_levels16(LevelTab& lt, int nlev, int N, const int* H, const int*
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Deep-K variant for bf16 activations with C % 64 == 0 (every backbone / FPN / tower layer):  BK = 64.
+//   * the im2col address work is hoisted out of the K loop: per staged row a 32-bit element offset of tap (0,0),
+//     W*C and a 16-bit tap-validity mask are computed once; a chunk then costs a multiply-add and a bit test per row
+//     (the BK = 32 kernel spent ~3x more VALU than MFMA cycles on 64-bit address arithmetic and bounds checks);
+//   * one register set, software-pipelined one full iteration deep: chunk k+1 (loaded during iteration k-1) is
+//     written to LDS at the top of iteration k and the loads of chunk k+2 are issued right behind it, so they have
+//     a whole 16-MFMA iteration to land;
+//   * 8 consecutive lanes stage one 128-byte row (full cache lines from HBM, conflict-free ds_write_b128);
+//     LDS rows are unpadded, 16-byte slot s of row r is stored at slot s ^ ((r >> 1) & 7): the 16 rows a
+//     ds_read_b128 lane group touches then fall on 16 distinct slots of the 256-byte bank row.
+// Stride-1-in-the-input only (in_dil == 1); KH*KW <= 16.
+template <int BN, bool ML, typename TO>
+__global__ __launch_bounds__(256) void conv_igemm_bf16_k64(ConvArgs16 p) {
+  constexpr int BM = 128, BK = 64, ROWB = 128;  // LDS row = 64 bf16
+  constexpr int TM = 2, TN = BN / 64, AP = 4, BP = BN / 32;  // 16-byte pieces per thread per chunk
+  constexpr int ABUF = BM * ROWB, BBUF = BN * ROWB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (ABUF + BBUF)];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + 2 * ABUF;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tilesN = (p.K + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  int tile;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int mt = tile / tilesN, nt = tile - mt * tilesN;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int lrow = tid >> 3, slot = tid & 7;  // staged rows lrow + 32*j, channels slot*8 .. +7 of the chunk
+  const int ntaps = p.KH * p.KW;
+
+  int aoff[AP], awc[AP];
+  unsigned amask[AP];
+#pragma unroll
+  for (int j = 0; j < AP; ++j) {
+    const int m = m0 + lrow + 32 * j;
+    const bool mv = m < p.M;
+    const int mm = mv ? m : 0;
+    int pb, H, W, ih0, iw0;
+    if constexpr (ML) {
+      int oh, ow;
+      ml_decode16(p.lt, mm, pb, H, W, oh, ow);
+      ih0 = oh - p.pad;
+      iw0 = ow - p.pad;
+    } else {
+      const int hw = p.OH * p.OW;
+      const int n = mm / hw, rem = mm - n * hw;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      ih0 = oh * p.stride - p.pad;
+      iw0 = ow * p.stride - p.pad;
+      pb = n * p.H * p.W;
+      H = p.H;
+      W = p.W;
+    }
+    aoff[j] = (pb + ih0 * W + iw0) * p.C + slot * 8;
+    awc[j] = W * p.C;
+    unsigned mk = 0;
+    for (int kh = 0; kh < p.KH; ++kh)
+      for (int kw = 0; kw < p.KW; ++kw)
+        if (mv && (unsigned)(ih0 + kh) < (unsigned)H && (unsigned)(iw0 + kw) < (unsigned)W) mk |= 1u << (kh * p.KW + kw);
+    amask[j] = mk;
+  }
+  int boff[BP];
+  bool bvalid[BP];
+#pragma unroll
+  for (int j = 0; j < BP; ++j) {
+    const int co = n0 + lrow + 32 * j;
+    bvalid[j] = co < p.K;
+    boff[j] = (bvalid[j] ? co : 0) * p.Kred + slot * 8;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const __bf16* __restrict__ xb = (const __bf16*)p.x;
+  const int nchunks = ntaps * (p.C / BK);
+  int kh = 0, kw = 0, c0 = 0, tap = 0;
+  bf16x8_t ra[AP], rb[BP];
+
+  auto gload = [&]() {  // issues the loads of the next chunk in (c0, tap) order and advances the cursor
+    const int ua = kw * p.C + c0;       // wave-uniform parts
+    const int ub = tap * p.C + c0;
+#pragma unroll
+    for (int j = 0; j < AP; ++j) {
+      bf16x8_t v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+      if ((amask[j] >> tap) & 1u) v = *(const bf16x8_t*)(xb + (unsigned)(aoff[j] + kh * awc[j] + ua));
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+      bf16x8_t v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+      if (bvalid[j]) v = *(const bf16x8_t*)(p.w + (unsigned)(boff[j] + ub));
+      rb[j] = v;
+    }
+    // taps innermost: the KH*KW shifted reads of one 64-channel slab stay L1/L2 resident
+    ++tap;
+    if (++kw == p.KW) {
+      kw = 0;
+      if (++kh == p.KH) { kh = 0; tap = 0; c0 += BK; }
+    }
+  };
+  const int wslot = (slot ^ ((lrow >> 1) & 7)) * 16;  // (row >> 1) & 7 is the same for rows lrow + 32*j
+  auto lds_store = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < AP; ++j) *(bf16x8_t*)(As + buf * ABUF + (lrow + 32 * j) * ROWB + wslot) = ra[j];
+#pragma unroll
+    for (int j = 0; j < BP; ++j) *(bf16x8_t*)(Bs + buf * BBUF + (lrow + 32 * j) * ROWB + wslot) = rb[j];
+  };
+
+  const int frow = lane & 31, fh = lane >> 5;
+  const int swz = (frow >> 1) & 7;
+  int koff[4];  // byte offset of the lane's 8 k-elements of k16-step s inside its (swizzled) row
+#pragma unroll
+  for (int s = 0; s < 4; ++s) koff[s] = ((2 * s + fh) ^ swz) * 16;
+  const int arow = (wm * 64 + frow) * ROWB, brow = (wn * (BN / 2) + frow) * ROWB;
+
+  gload();
+  lds_store(0);
+  if (nchunks > 1) gload();
+  __syncthreads();
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nchunks) {
+      lds_store(buf ^ 1);              // chunk kc+1: its loads were issued one full iteration ago
+      if (kc + 2 < nchunks) gload();   // chunk kc+2
+    }
+    const unsigned char* ab = As + buf * ABUF + arow;
+    const unsigned char* bb = Bs + buf * BBUF + brow;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8_t a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8_t*)(ab + i * 32 * ROWB + koff[s]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8_t*)(bb + j * 32 * ROWB + koff[s]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  if ((p.K & 3) == 0) {
+    float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
+    epilogue_rows<TN, TO>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
+                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K);
+    return;
+  }
+  TO* yo = (TO*)p.y;
+  const TO* res = (const TO*)p.residual;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + wn * (BN / 2) + j * 32 + frow;
+    if (co >= p.K) continue;
+    const float sc = p.scale ? p.scale[co] : 1.f;
+    const float bi = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (m >= p.M) continue;
+        const size_t off = (size_t)m * p.K + co;
+        float v = acc[i][j][e] * sc + bi;
+        if (res) v += (float)res[off];
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.accumulate) v += (float)yo[off];
+        yo[off] = (TO)v;
+      }
+    }
+  }
+}
+
 template <int BN, bool ML>
 static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dtype, hipStream_t stream) {
   const dim3 g(tiles), b(256);
+  // deep-K kernel: bf16 input, 64-channel slabs, 32-bit element offsets, plain (non-dilated) gather
+  const int64_t xelems = ML ? (int64_t)a.M * a.C : (int64_t)a.N * a.H * a.W * a.C;
+  // It holds 2 workgroups per CU (64 KB LDS) against 3 for the BK = 32 kernel: worth it for long K loops (MFMA-bound
+  // 3x3 / wide 1x1 layers) unless the grid is a little over one 512-slot round (tail), not for short HBM-bound ones.
+  static int k64_min_kred = -1;
+  if (k64_min_kred < 0) { const char* e = getenv("UTV2_K64_MIN_KRED"); k64_min_kred = e ? atoi(e) : 1024; }
+  const bool tail = tiles > 512 && tiles <= 768;
+  if (x_dtype == UTV2_BF16 && a.C % 64 == 0 && a.in_dil == 1 && a.KH * a.KW <= 16 && xelems < (1ll << 31) &&
+      (int64_t)a.K * a.Kred < (1ll << 31) && a.Kred >= k64_min_kred && !tail) {
+    if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_k64<BN, ML, __bf16>), g, b, 0, stream, a);
+    else hipLaunchKernelGGL((conv_igemm_bf16_k64<BN, ML, float>), g, b, 0, stream, a);
+    return;
+  }
   if (x_dtype == UTV2_BF16) {
     if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, __bf16, __bf16>), g, b, 0, stream, a);
     else hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, __bf16, float>), g, b, 0, stream, a);
@@ -595,7 +796,9 @@ extern "C" {
 int utv2_conv2d_wgrad_bf16_splits(int M, int K, int Kred) {
   const int chunks = cdiv(M, 32);
   const int tiles = cdiv(K, 128) * cdiv(Kred, 128);
-  int splits = cdiv(1024, tiles);
+  static int target = 0;
+  if (!target) { const char* e = getenv("UTV2_WGRAD_TARGET"); target = e ? atoi(e) : 1024; }
+  int splits = cdiv(target, tiles);
   const int max_by_chunks = chunks / 8 > 0 ? chunks / 8 : 1;
   if (splits > max_by_chunks) splits = max_by_chunks;
   if (splits < 1) splits = 1;
