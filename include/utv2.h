@@ -30,6 +30,11 @@ typedef struct ihipStream_t* utv2_stream_t; /* == hipStream_t */
 int utv2_conv2d_nhwc_fwd(const float* x, const float* w, float* y, const float* scale, const float* bias,
                          const float* residual, int N, int H, int W, int C, int K, int KH, int KW, int stride, int pad,
                          int in_dil, int OH, int OW, int relu, int accumulate, int Kred, utv2_stream_t stream);
+/* D2 BasicStem conv1 on the zero-padded NHWC4 image (C == 4, weight rows padded to Kred % 16 == 0); y_dtype selects
+ * the output element type (UTV2_F32 / UTV2_BF16, defined below) */
+int utv2_conv2d_stem_fwd(const float* x, const float* w, void* y, int y_dtype, const float* scale, const float* bias, int N,
+                         int H, int W, int K, int KH, int KW, int stride, int pad, int OH, int OW, int relu, int Kred,
+                         utv2_stream_t stream);
 int utv2_conv2d_wgrad_splits(int N, int OH, int OW, int K, int Kred);
 int64_t utv2_conv2d_wgrad_workspace_floats(int N, int OH, int OW, int K, int Kred);
 /* dw[K][KH*KW*C] (+)= sum_m dy[m][k] * im2col(x)[m][:]; deterministic split reduction through ws. */
@@ -69,10 +74,14 @@ int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y
  * {input pixel index of tap (0,0), (W << 16) | mask of the taps that fall inside the image}; KH*KW <= 16 */
 int utv2_conv2d_wgrad_bf16_splits(int M, int K, int Kred);
 int64_t utv2_conv2d_wgrad_bf16_workspace_floats(int M, int K, int Kred);
+/* rowscale (optional, [K]): per-output-channel multiplier of the result (the folded FrozenBN scale: the kernels then
+ * consume the gradient of the BN OUTPUT directly); the dgrad weight image takes the same multiplier at flip time */
 int utv2_conv2d_wgrad_bf16(const void* x, int x_dtype, const void* dy, int dy_dtype, float* dw, float* db, float* ws,
-                           const int* rowinfo, int M, int C, int K, int KH, int KW, int accumulate, utv2_stream_t stream);
+                           const int* rowinfo, const float* rowscale, int M, int C, int K, int KH, int KW, int accumulate,
+                           utv2_stream_t stream);
 int utv2_f32_to_bf16(const float* src, void* dst16, int64_t n, utv2_stream_t stream);
-int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, int K, int KH, int KW, int C, utv2_stream_t stream);
+int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, const float* scale, int K, int KH, int KW, int C,
+                                    utv2_stream_t stream);
 
 /* ---- teacher EMA: engine/trainer.py:468-486 (FCOS), :950-968 (RCNN) --------------------------
  * teacher = student*(1-keep) + teacher*keep, evaluated with the reference's three roundings. */

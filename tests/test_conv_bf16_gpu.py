@@ -218,3 +218,23 @@ def test_elementwise_bf16():
     dx32 = hip.groupnorm_relu_seg_bwd(dy.view(-1, C), y16f, x.view(-1, C), seg, m32, r32, ga, dg32, db32, 32, True)
     dx16 = hip.groupnorm_relu_seg_bwd(dy.view(-1, C).to(BF), y16, x.view(-1, C).to(BF), seg, m32, r32, ga, dg16, db16, 32, True)
     assert torch.equal(dx16, dx32.to(BF)) and torch.equal(dg16, dg32) and torch.equal(db16, db32)
+
+
+def test_bn_scale_folding():
+    """rowscale / flip-time scale == scaling the result rows (wgrad) / the weights before the bf16 rounding (dgrad image)."""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(5)
+    N, H, W, C, K, k = 2, 10, 12, 64, 128, 3
+    w2 = (torch.randn(K, k * k * C, generator=g) * 0.05).cuda()
+    sc = (torch.rand(K, generator=g) + 0.5).cuda()
+    a = hip.weight_flip_transpose_bf16(w2, K, k, k, C, sc)
+    b = hip.weight_flip_transpose_bf16((w2 * sc[:, None]).contiguous(), K, k, k, C)
+    assert torch.equal(a, b)
+    x = torch.randn(N, H, W, C, generator=g).cuda().to(BF)
+    dy = torch.randn(N * H * W, K, generator=g).cuda().to(BF)
+    ri = hip.rowinfo_nhwc(N, H, W, H, W, 1, 1, k, k, "cuda")
+    d0 = torch.zeros(K, k * k * C, device="cuda"); d1 = torch.zeros_like(d0)
+    b0 = torch.zeros(K, device="cuda"); b1 = torch.zeros_like(b0)
+    hip.conv2d_wgrad_bf16(x, dy, d0, ri, C, k, k, accumulate=False, db=b0)
+    hip.conv2d_wgrad_bf16(x, dy, d1, ri, C, k, k, accumulate=False, db=b1, rowscale=sc)
+    assert torch.equal(d1, d0 * sc[:, None]) and torch.equal(b1, b0 * sc)

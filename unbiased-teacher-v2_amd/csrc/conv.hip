@@ -42,6 +42,7 @@ struct ConvArgs {
   int Kred;               // reduction length of one weight row (may be padded, MODE 1)
   int M;                  // N*OH*OW
   int accumulate;         // y += result (used by dgrad into an existing gradient)
+  int y_bf16;             // store y as bf16 (the image stem under AMP: the bf16 activation pipeline starts at its output)
 };
 
 // MODE 0: C % 16 == 0 (a 16-wide k chunk never straddles a filter tap)
@@ -267,6 +268,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   if ((p.K & 3) == 0) {
     // all MFMAs retired and every wave is past the last barrier of the K loop: the staging LDS is free
     float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
+    if constexpr (MODE == 1) {
+      if (p.y_bf16) {  // no residual / accumulate on this path
+        epilogue_rows<TN, __bf16>(acc, patch, lane, (__bf16*)p.y, p.scale, p.bias, (const __bf16*)nullptr, p.relu, 0, m0 + wm * 64,
+                                  n0 + wn * (BN / 2), p.M, p.K);
+        return;
+      }
+    }
     epilogue_rows<TN>(acc, patch, lane, p.y, p.scale, p.bias, p.residual, p.relu, p.accumulate, m0 + wm * 64,
                       n0 + wn * (BN / 2), p.M, p.K);
     return;
@@ -560,7 +568,7 @@ int utv2_conv2d_ml_fwd(const float* x, const float* w, float* y, const float* sc
   a.M = fill_levels(a.lt, nlev, N, H_host, W_host);
   a.x = x; a.w = w; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual;
   a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW;
-  a.stride = 1; a.pad = pad; a.in_dil = 1; a.relu = relu; a.accumulate = accumulate;
+  a.stride = 1; a.pad = pad; a.in_dil = 1; a.relu = relu; a.accumulate = accumulate; a.y_bf16 = 0;
   a.Kred = KH * KW * C;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
@@ -603,6 +611,7 @@ int utv2_conv2d_nhwc_fwd(const float* x, const float* w, float* y, const float* 
   a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.K = K; a.KH = KH; a.KW = KW;
   a.stride = stride; a.pad = pad; a.in_dil = in_dil < 1 ? 1 : in_dil; a.relu = relu; a.accumulate = accumulate;
   a.M = N * OH * OW;
+  a.y_bf16 = 0;
   const int kred_nat = KH * KW * C;
   int mode;
   if (C % 16 == 0 && Kred == kred_nat) mode = 0;
@@ -623,6 +632,29 @@ int utv2_conv2d_nhwc_fwd(const float* x, const float* w, float* y, const float* 
     if (small) hipLaunchKernelGGL((conv_igemm_f32<64, 2>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((conv_igemm_f32<128, 2>), grid, block, 0, stream, a);
   }
+  return utv2_launch_status();
+}
+
+// The image stem (C == 4: zero-padded NHWC4 image, weight rows padded to Kred % 16 == 0) with a selectable output
+// element type: under AMP it writes bf16, so the 7x7 conv's large output is stored and re-read at half the bytes.
+int utv2_conv2d_stem_fwd(const float* x, const float* w, void* y, int y_dtype, const float* scale, const float* bias, int N,
+                         int H, int W, int K, int KH, int KW, int stride, int pad, int OH, int OW, int relu, int Kred,
+                         hipStream_t stream) {
+  if (!x || !w || !y || N <= 0 || K <= 0 || (K & 3) || (Kred & 15) || Kred < KH * KW * 4 ||
+      (y_dtype != UTV2_F32 && y_dtype != UTV2_BF16))
+    return UTV2_EARG;
+  ConvArgs a;
+  a.lt.n = 0;
+  a.x = x; a.w = w; a.y = (float*)y; a.scale = scale; a.bias = bias; a.residual = nullptr;
+  a.N = N; a.H = H; a.W = W; a.C = 4; a.OH = OH; a.OW = OW; a.K = K; a.KH = KH; a.KW = KW;
+  a.stride = stride; a.pad = pad; a.in_dil = 1; a.relu = relu; a.accumulate = 0;
+  a.M = N * OH * OW;
+  a.y_bf16 = y_dtype == UTV2_BF16;
+  a.Kred = Kred;
+  const bool small = K <= 64;
+  const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
+  if (small) hipLaunchKernelGGL((conv_igemm_f32<64, 1>), dim3(tiles), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv_igemm_f32<128, 1>), dim3(tiles), dim3(256), 0, stream, a);
   return utv2_launch_status();
 }
 

@@ -15,7 +15,6 @@
 // stride); each thread stages 8 consecutive k of a row (two 16-byte global loads -> one
 // ds_write_b128); each MFMA reads one ds_read_b128 per operand fragment.
 #include "common.h"
-#include <stdlib.h>
 
 #define CONV_MAX_LEVELS 8
 struct LevelTab {
@@ -258,8 +257,10 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
   }
 }
 
-// wt16[ci][KH-1-kh][KW-1-kw][co] = bf16(w[co][kh][kw][ci])
-__global__ void weight_flip_transpose_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int K, int KH, int KW, int C) {
+// wt16[ci][KH-1-kh][KW-1-kw][co] = bf16(w[co][kh][kw][ci] * scale[co])   (scale optional: the folded FrozenBN multiplier,
+// so dgrad consumes the UNscaled output gradient and no "dy * scale" pass is ever materialised)
+__global__ void weight_flip_transpose_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, const float* __restrict__ scale,
+                                                  int K, int KH, int KW, int C) {
   const size_t n = (size_t)K * KH * KW * C;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -269,7 +270,9 @@ __global__ void weight_flip_transpose_bf16_kernel(const float* __restrict__ w, _
     const int kwp = (int)(t % KW); t /= KW;
     const int khp = (int)(t % KH); t /= KH;
     const int ci = (int)t;
-    wt[i] = (__bf16)w[(((size_t)co * KH + (KH - 1 - khp)) * KW + (KW - 1 - kwp)) * C + ci];
+    float v = w[(((size_t)co * KH + (KH - 1 - khp)) * KW + (KW - 1 - kwp)) * C + ci];
+    if (scale) v *= scale[co];
+    wt[i] = (__bf16)v;
   }
 }
 
@@ -485,8 +488,7 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
   const int64_t xelems = ML ? (int64_t)a.M * a.C : (int64_t)a.N * a.H * a.W * a.C;
   // It holds 2 workgroups per CU (64 KB LDS) against 3 for the BK = 32 kernel: worth it for long K loops (MFMA-bound
   // 3x3 / wide 1x1 layers) unless the grid is a little over one 512-slot round (tail), not for short HBM-bound ones.
-  static int k64_min_kred = -1;
-  if (k64_min_kred < 0) { const char* e = getenv("UTV2_K64_MIN_KRED"); k64_min_kred = e ? atoi(e) : 1024; }
+  const int k64_min_kred = 1024;
   const bool tail = tiles > 512 && tiles <= 768;
   if (x_dtype == UTV2_BF16 && a.C % 64 == 0 && a.in_dil == 1 && a.KH * a.KW <= 16 && xelems < (1ll << 31) &&
       (int64_t)a.K * a.Kred < (1ll << 31) && a.Kred >= k64_min_kred && !tail) {
@@ -555,12 +557,13 @@ int utv2_f32_to_bf16(const float* src, void* dst16, int64_t n, hipStream_t strea
   return utv2_launch_status();
 }
 
-int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, int K, int KH, int KW, int C, hipStream_t stream) {
+int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, const float* scale, int K, int KH, int KW, int C,
+                                    hipStream_t stream) {
   if (!w || !wt16) return UTV2_EARG;
   const size_t n = (size_t)K * KH * KW * C;
   int nb = cdiv((int64_t)n, 256);
   if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(weight_flip_transpose_bf16_kernel, dim3(nb), dim3(256), 0, stream, w, (__bf16*)wt16, K, KH, KW, C);
+  hipLaunchKernelGGL(weight_flip_transpose_bf16_kernel, dim3(nb), dim3(256), 0, stream, w, (__bf16*)wt16, scale, K, KH, KW, C);
   return utv2_launch_status();
 }
 
@@ -781,12 +784,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
   }
 }
 
-__global__ void reduce_slabs16_f32(const float* __restrict__ ws, float* __restrict__ dst, size_t n, int splits, int accumulate) {
+// dst[i] (+)= rowscale[i / rowlen] * sum_k ws[k][i]   (fixed order; rowscale optional: the folded FrozenBN multiplier of
+// the output channel, applied here instead of to the output gradient)
+__global__ void reduce_slabs16_f32(const float* __restrict__ ws, float* __restrict__ dst, size_t n, int splits, int accumulate,
+                                   const float* __restrict__ rowscale, int rowlen) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += ws[(size_t)k * n + i];
+    if (rowscale) s *= rowscale[i / rowlen];
     dst[i] = accumulate ? dst[i] + s : s;
   }
 }
@@ -796,9 +803,9 @@ extern "C" {
 int utv2_conv2d_wgrad_bf16_splits(int M, int K, int Kred) {
   const int chunks = cdiv(M, 32);
   const int tiles = cdiv(K, 128) * cdiv(Kred, 128);
-  static int target = 0;
-  if (!target) { const char* e = getenv("UTV2_WGRAD_TARGET"); target = e ? atoi(e) : 1024; }
-  int splits = cdiv(target, tiles);
+  // ~4 workgroups per CU for the few-tile (tower-like) GEMMs; half of that once the slab traffic
+  // (splits * K * Kred floats written and re-read) rivals the operand traffic
+  int splits = cdiv(tiles <= 48 ? 1024 : 512, tiles);
   const int max_by_chunks = chunks / 8 > 0 ? chunks / 8 : 1;
   if (splits > max_by_chunks) splits = max_by_chunks;
   if (splits < 1) splits = 1;
@@ -813,9 +820,10 @@ int64_t utv2_conv2d_wgrad_bf16_workspace_floats(int M, int K, int Kred) {
 
 // rowinfo: device int32[M][2] = {anchor input pixel, (W << 16) | tapmask} for every OUTPUT pixel m (built once per
 // geometry by the host).  x is `x_dtype` with C channels per pixel, dy is `dy_dtype` [M][K].  C % 8 == 0, K % 8 == 0,
-// KH*KW <= 16.  dw (+)= result; db (optional, [K]) (+)= column sums of dy.
+// KH*KW <= 16.  dw (+)= rowscale[co] * result; db (optional, [K]) (+)= rowscale[co] * column sums of dy; rowscale optional.
 int utv2_conv2d_wgrad_bf16(const void* x, int x_dtype, const void* dy, int dy_dtype, float* dw, float* db, float* ws,
-                           const int* rowinfo, int M, int C, int K, int KH, int KW, int accumulate, hipStream_t stream) {
+                           const int* rowinfo, const float* rowscale, int M, int C, int K, int KH, int KW, int accumulate,
+                           hipStream_t stream) {
   if (!x || !dy || !dw || !ws || !rowinfo || (C & 7) || (K & 7) || M <= 0 || KH * KW > 16 || bad_dtype(x_dtype) ||
       bad_dtype(dy_dtype))
     return UTV2_EARG;
@@ -837,10 +845,11 @@ int utv2_conv2d_wgrad_bf16(const void* x, int x_dtype, const void* dy, int dy_dt
   }
   int rb = cdiv((int64_t)n, 256);
   if (rb > 4096) rb = 4096;
-  hipLaunchKernelGGL(reduce_slabs16_f32, dim3(rb), dim3(256), 0, stream, (const float*)ws, dw, n, a.splits, accumulate);
+  hipLaunchKernelGGL(reduce_slabs16_f32, dim3(rb), dim3(256), 0, stream, (const float*)ws, dw, n, a.splits, accumulate, rowscale,
+                     a.Kred);
   if (db)
     hipLaunchKernelGGL(reduce_slabs16_f32, dim3(cdiv(K, 256)), dim3(256), 0, stream, (const float*)a.bias_ws, db, (size_t)K, a.splits,
-                       accumulate);
+                       accumulate, rowscale, 1);
   return utv2_launch_status();
 }
 

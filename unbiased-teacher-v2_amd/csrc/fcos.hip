@@ -165,13 +165,21 @@ __global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict_
   }
 }
 
-__global__ void sum_partials_kernel(const float* __restrict__ partial, int n, int ncols, float* __restrict__ out) {
-  // out[c] = sum_r partial[r*ncols + c]  (double accumulate, fixed order)
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncols) return;
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int n, int ncols,
+                                                           float* __restrict__ out) {
+  // out[c] = sum_r partial[r*ncols + c]: block c, thread t adds rows t, t+256, ... in double, then a fixed-order
+  // LDS tree - deterministic, and ~n/256 dependent loads deep instead of n.
+  __shared__ double red[256];
+  const int c = blockIdx.x;
   double s = 0.0;
-  for (int r = 0; r < n; ++r) s += (double)partial[(size_t)r * ncols + c];
-  out[c] = (float)s;
+  for (int r = threadIdx.x; r < n; r += 256) s += (double)partial[(size_t)r * ncols + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = (float)red[0];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -520,7 +528,7 @@ int utv2_sigmoid_focal_fwd(const float* logits, const int* labels, int64_t P, in
                            float* loss_sum, float* ws, hipStream_t stream) {
   if (!logits || !labels || !loss_sum || !ws) return UTV2_EARG;
   hipLaunchKernelGGL(focal_fwd_kernel, dim3(FOCAL_BLOCKS), dim3(256), 0, stream, logits, labels, (size_t)P, C, alpha, gamma, ws);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws, FOCAL_BLOCKS, 1, loss_sum);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, FOCAL_BLOCKS, 1, loss_sum);
   return utv2_launch_status();
 }
 
@@ -539,7 +547,7 @@ int utv2_fcos_loc_terms_fwd(const int* labels, const float* box, int box_stride,
   if (!labels || !box || !reg_targets || !sums || !ws || reg_max != 16 || box_stride < 4 * 17 + 5 || (box_stride & 3)) return UTV2_EARG;
   hipLaunchKernelGGL((fcos_loc_fwd_kernel<17>), dim3(LOC_BLOCKS), dim3(128), 0, stream, labels, box, box_stride, reg_targets,
                      bvars, (size_t)P, num_classes, ts_better, ts_cert, ws);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws, LOC_BLOCKS, LT_NSUM, sums);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(LT_NSUM), dim3(256), 0, stream, (const float*)ws, LOC_BLOCKS, LT_NSUM, sums);
   return utv2_launch_status();
 }
 
@@ -589,7 +597,7 @@ int utv2_scale_cols_bwd(float* g, const float* ypost, int64_t rows, int row_stri
   int nb = cdiv(rows * ncols, 256);
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(scale_cols_bwd_kernel, dim3(nb), dim3(256), 0, stream, g, ypost, (size_t)rows, row_stride, ncols, s, ws);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws, nb, 1, dsum);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, nb, 1, dsum);
   return utv2_launch_status();
 }
 

@@ -150,6 +150,18 @@ def conv2d_fwd(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, relu
     return out
 
 
+def conv2d_stem_fwd(x4, w, scale, bias, stride, pad, kh, kw, relu, out_dtype):
+    """x4 [N,H,W,4] fp32 image; w [K, Kred] (16-padded rows); output fp32 or bf16."""
+    N, H, W, C = x4.shape
+    assert C == 4
+    K, Kred = w.shape
+    OH, OW = conv_out_size(H, kh, stride, pad), conv_out_size(W, kw, stride, pad)
+    out = torch.empty((N, OH, OW, K), dtype=out_dtype, device=x4.device)
+    call("utv2_conv2d_stem_fwd", _p(x4), _p(w), _p(out), _dt(out), _p(scale), _p(bias), N, H, W, K, kh, kw, stride, pad, OH, OW,
+         int(relu), Kred, _stream())
+    return out
+
+
 def conv2d_dgrad(dy, w_t, in_shape, stride, pad, kh, kw, out=None, accumulate=False):
     """dy [N,OH,OW,K]; w_t [C, kh*kw*K] (flipped/transposed image of w); returns dx [N,H,W,C]."""
     N, H, W, C = in_shape
@@ -504,9 +516,10 @@ def f32_to_bf16(src, dst16):
     call("utv2_f32_to_bf16", _p(src), _p(dst16), src.numel(), _stream())
 
 
-def weight_flip_transpose_bf16(w, K, kh, kw, C):
+def weight_flip_transpose_bf16(w, K, kh, kw, C, scale=None):
+    """dgrad weight image; scale [K] (optional) = folded FrozenBN multiplier applied per output channel"""
     wt = torch.empty((C, kh * kw * K), dtype=torch.bfloat16, device=w.device)
-    call("utv2_weight_flip_transpose_bf16", _p(w), _p(wt), K, kh, kw, C, _stream())
+    call("utv2_weight_flip_transpose_bf16", _p(w), _p(wt), _p(scale), K, kh, kw, C, _stream())
     return wt
 
 
@@ -595,14 +608,14 @@ def rowinfo_ml(N, level_hw, pad, k, device):
     return t
 
 
-def conv2d_wgrad_bf16(x, dy2d, dw, rowinfo, C, kh, kw, accumulate=True, db=None):
+def conv2d_wgrad_bf16(x, dy2d, dw, rowinfo, C, kh, kw, accumulate=True, db=None, rowscale=None):
     """x: fp32/bf16 activations (any layout consistent with rowinfo), dy2d [M,K] fp32/bf16; dw [K, kh*kw*C] (+)= wgrad;
     db [K] (optional) (+)= column sums of dy (bias gradient, fused into the dY staging)."""
     M, K = dy2d.shape
     nws = load().utv2_conv2d_wgrad_bf16_workspace_floats(M, K, kh * kw * C)
     ws = workspace(nws, dy2d.device, "wgrad")
-    call("utv2_conv2d_wgrad_bf16", _p(x), _dt(x), _p(dy2d), _dt(dy2d), _p(dw), _p(db), _p(ws), _p(rowinfo), M, C, K, kh, kw,
-         int(accumulate), _stream())
+    call("utv2_conv2d_wgrad_bf16", _p(x), _dt(x), _p(dy2d), _dt(dy2d), _p(dw), _p(db), _p(ws), _p(rowinfo), _p(rowscale), M, C, K, kh,
+         kw, int(accumulate), _stream())
     return dw
 
 

@@ -134,9 +134,12 @@ class ResNet50:
 
     def __call__(self, x4):
         outs = {}
-        with torch.no_grad():
-            x = self.stem(x4)
-            x = hip.maxpool3x3s2(x, out_dtype=ops.act_dtype())  # AMP: the bf16 activation pipeline starts here
+        if self.stem.trainable:
+            raise NotImplementedError("MODEL.BACKBONE.FREEZE_AT < 1 (trainable stem) is not built: no shipped config uses it")
+        # frozen stem + pool run outside autograd; under AMP the bf16 activation pipeline starts at the stem's output
+        sc, sh = self.stem.scale_shift()
+        x = hip.conv2d_stem_fwd(x4, self.stem_w.t, sc, sh, 2, 3, 7, 7, True, ops.act_dtype())
+        x = hip.maxpool3x3s2(x)
         for name, blocks, trainable in self.stages:
             if trainable:
                 for b in blocks:

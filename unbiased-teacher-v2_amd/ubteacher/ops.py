@@ -100,10 +100,11 @@ class Conv:
             self._wt_version = v
         return self._wt
 
-    def wt16(self):
-        v = (_VERSION[0], self.w.store.version)
+    def wt16(self, scale=None):
+        """bf16 dgrad weight image; `scale` (the folded FrozenBN multiplier) is baked in per output channel"""
+        v = (_VERSION[0], self.w.store.version, scale is not None)
         if getattr(self, "_wt16", None) is None or self._wt16_version != v:
-            self._wt16 = hip.weight_flip_transpose_bf16(self.w.t, self.cout, self.k, self.k, self.cin)
+            self._wt16 = hip.weight_flip_transpose_bf16(self.w.t, self.cout, self.k, self.k, self.cin, scale)
             self._wt16_version = v
         return self._wt16
 
@@ -190,7 +191,15 @@ class _ConvFn(torch.autograd.Function):
                 ctx.cs.g.add_(dsum / ctx.cs.t.view(-1))
             dy = g
         gres = None
-        if ctx.has_res:
+        d16 = layer.use_bf16_dgrad()
+        # AMP + FrozenBN: the BN multiplier is folded into the dgrad weight image and the wgrad slab reduction, so the
+        # only elementwise backward pass left is the ReLU mask (none at all for the ReLU-less shortcut convs)
+        fold = sc is not None and d16 and layer.use_bf16_wgrad() and layer.bias is None
+        wsc = sc if fold else None
+        if fold:
+            g = hip.relu_bwd_scale(dy, y, None) if layer.relu else dy
+            gres = g if ctx.has_res else None
+        elif ctx.has_res:
             gm = hip.relu_bwd_scale(dy, y if layer.relu else None, None) if layer.relu else dy
             gres = gm
             g = hip.relu_bwd_scale(gm, None, sc) if sc is not None else gm
@@ -200,18 +209,18 @@ class _ConvFn(torch.autograd.Function):
             else:
                 g = dy
         dx = None
-        d16 = layer.use_bf16_dgrad()
         bias_done = False
         if meta is not None and layer.k > 1:
             if ctx.needs_input_grad[0]:
                 if d16:
-                    dx = hip.conv2d_ml_fwd_bf16(g, layer.wt16(), meta.level_hw, meta.N, k=layer.k, pad=layer.k - 1 - layer.pad,
+                    dx = hip.conv2d_ml_fwd_bf16(g, layer.wt16(wsc), meta.level_hw, meta.N, k=layer.k, pad=layer.k - 1 - layer.pad,
                                                 out_dtype=x.dtype)
                 else:
                     dx = hip.conv2d_ml_dgrad(g, layer.wt(), meta.level_hw, meta.N, layer.k, layer.pad)
             if layer.use_bf16_wgrad():
                 hip.conv2d_wgrad_bf16(x, g, layer.w.g, hip.rowinfo_ml(meta.N, meta.level_hw, layer.pad, layer.k, x.device), layer.cin,
-                                      layer.k, layer.k, accumulate=True, db=layer.bias.g if layer.bias is not None else None)
+                                      layer.k, layer.k, accumulate=True, db=layer.bias.g if layer.bias is not None else None,
+                                      rowscale=wsc)
                 bias_done = True
             else:
                 hip.conv2d_ml_wgrad(x, g, layer.w.g, meta.level_hw, meta.N, layer.k, layer.pad, accumulate=True)
@@ -220,7 +229,7 @@ class _ConvFn(torch.autograd.Function):
             g4 = g.view(1, g.shape[0], 1, g.shape[1]) if meta is not None else g
             if ctx.needs_input_grad[0]:
                 if d16:
-                    dx = hip.conv2d_dgrad_bf16(g4, layer.wt16(), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k,
+                    dx = hip.conv2d_dgrad_bf16(g4, layer.wt16(wsc), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k,
                                                out_dtype=x.dtype)
                 else:
                     dx = hip.conv2d_dgrad(g4, layer.wt(), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k)
@@ -230,7 +239,7 @@ class _ConvFn(torch.autograd.Function):
                 n_, h_, w_, _ = x4.shape
                 ri = hip.rowinfo_nhwc(n_, h_, w_, g4.shape[1], g4.shape[2], layer.stride, layer.pad, layer.k, layer.k, x.device)
                 hip.conv2d_wgrad_bf16(x4, g4.reshape(-1, layer.cout), layer.w.g, ri, layer.cin, layer.k, layer.k, accumulate=True,
-                                      db=layer.bias.g if layer.bias is not None else None)
+                                      db=layer.bias.g if layer.bias is not None else None, rowscale=wsc)
                 bias_done = True
             else:
                 hip.conv2d_wgrad(x4, g4, layer.w.g, layer.stride, layer.pad, layer.k, layer.k, accumulate=True)
