@@ -16,6 +16,11 @@
 // ds_write_b128); each MFMA reads one ds_read_b128 per operand fragment.
 #include "common.h"
 
+// 64 zero bytes: out-of-image / out-of-range operand pieces are loaded from here, so every staging load is
+// unconditional (no exec-mask branches) and needs no masking of the loaded data (which would force the wave to wait for
+// its loads right after issuing them)
+__device__ uint4 g_zero64[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};  // never written (non-const keeps it in the global address space: global_load, not flat_load)
+
 #define CONV_MAX_LEVELS 8
 struct LevelTab {
   int n;
@@ -385,21 +390,16 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_k64(ConvArgs16 p) {
   auto gload = [&]() {  // issues the loads of the next chunk in (c0, tap) order and advances the cursor
     const int ua = kw * p.C + c0;       // wave-uniform parts
     const int ub = tap * p.C + c0;
+    const __bf16* zero = (const __bf16*)g_zero64;  // halo / out-of-range pieces read zeros: no branches, no data masking
 #pragma unroll
     for (int j = 0; j < AP; ++j) {
-      bf16x8_t v;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
-      if ((amask[j] >> tap) & 1u) v = *(const bf16x8_t*)(xb + (unsigned)(aoff[j] + kh * awc[j] + ua));
-      ra[j] = v;
+      const __bf16* src = ((amask[j] >> tap) & 1u) ? xb + (unsigned)(aoff[j] + kh * awc[j] + ua) : zero;
+      ra[j] = *(const bf16x8_t*)src;
     }
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
-      bf16x8_t v;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
-      if (bvalid[j]) v = *(const bf16x8_t*)(p.w + (unsigned)(boff[j] + ub));
-      rb[j] = v;
+      const __bf16* src = bvalid[j] ? p.w + (unsigned)(boff[j] + ub) : zero;
+      rb[j] = *(const bf16x8_t*)src;
     }
     // taps innermost: the KH*KW shifted reads of one 64-channel slab stay L1/L2 resident
     ++tap;
@@ -664,34 +664,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
   auto load8 = [&](const void* base, size_t eoff, bool is16, bool ok) -> bf16x8_t {
     bf16x8_t v;
     if (is16) {
-      v = *(const bf16x8_t*)((const __bf16*)base + eoff);
+      const __bf16* src = ok ? (const __bf16*)base + eoff : (const __bf16*)g_zero64;
+      v = *(const bf16x8_t*)src;
     } else {
-      const f32x4 v0 = *(const f32x4*)((const float*)base + eoff), v1 = *(const f32x4*)((const float*)base + eoff + 4);
+      const float* src = ok ? (const float*)base + eoff : (const float*)g_zero64;
+      const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         v[e] = (__bf16)v0[e];
         v[4 + e] = (__bf16)v1[e];
       }
     }
-    // loads are unconditional on a clamped (always valid) address and masked afterwards: a per-element
-    // "load or zero" branch makes hipcc wait for each load in turn
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    i32x4 b = __builtin_bit_cast(i32x4, v);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) b[e] = ok ? b[e] : 0;
-    return __builtin_bit_cast(bf16x8_t, b);
+    return v;
   };
   auto gload = [&](int chunk) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int m = chunk * BK + pl0 + 16 * r;
       const bool mok = m < p.M;
-      const int mc = mok ? m : p.M - 1;
-      ra[r] = load8(p.dy, (size_t)mc * p.K + (aok ? co8 : 0), DY16, mok && aok);
+      ra[r] = load8(p.dy, (size_t)m * p.K + co8, DY16, mok && aok);
       const int W = ri[r].y >> 16;
       const bool ok = mok && bok && ((ri[r].y >> tap) & 1);
-      const int pix = ok ? ri[r].x + dh * W + dw : 0;
-      rb[r] = load8(p.x, (size_t)pix * p.C + ci, X16, ok);
+      rb[r] = load8(p.x, (size_t)(ri[r].x + dh * W + dw) * p.C + ci, X16, ok);
     }
   };
   auto bias_acc = [&]() {
@@ -803,9 +797,10 @@ extern "C" {
 int utv2_conv2d_wgrad_bf16_splits(int M, int K, int Kred) {
   const int chunks = cdiv(M, 32);
   const int tiles = cdiv(K, 128) * cdiv(Kred, 128);
-  // ~4 workgroups per CU for the few-tile (tower-like) GEMMs; half of that once the slab traffic
-  // (splits * K * Kred floats written and re-read) rivals the operand traffic
-  int splits = cdiv(tiles <= 48 ? 1024 : 512, tiles);
+  // ~2 workgroups per CU: every split costs a K x Kred fp32 slab written and re-read, which rivals the operand traffic
+  // of the HBM-bound layers; ~4 per CU only when a workgroup's share of the MFMA work is large (load balance wins)
+  const double flop = 2.0 * M * K * Kred;
+  int splits = cdiv(flop > 512 * 2.0e8 ? 1024 : 512, tiles);
   const int max_by_chunks = chunks / 8 > 0 ? chunks / 8 : 1;
   if (splits > max_by_chunks) splits = max_by_chunks;
   if (splits < 1) splits = 1;
