@@ -300,23 +300,27 @@ static int fill_levels16(LevelTab& lt, int nlev, int N, const int* H, const int*
 
 
 // ---------------------------------------------------------------------------------------------
-// Deep-K variant for bf16 activations with C % 64 == 0 (every backbone / FPN / tower layer):  BK = 64.
+// Main kernel for bf16 activations (every backbone / FPN / tower layer): BK = 64 (C % 64 == 0; long, MFMA-bound K loops)
+// or BK = 32 (C % 32 == 0; short HBM-bound 1x1 layers, where 32 KB of LDS keeps 4 workgroups per CU in flight).
 //   * the im2col address work is hoisted out of the K loop: per staged row a 32-bit element offset of tap (0,0),
 //     W*C and a 16-bit tap-validity mask are computed once; a chunk then costs a multiply-add and a bit test per row
 //     (the BK = 32 kernel spent ~3x more VALU than MFMA cycles on 64-bit address arithmetic and bounds checks);
 //   * one register set, software-pipelined one full iteration deep: chunk k+1 (loaded during iteration k-1) is
 //     written to LDS at the top of iteration k and the loads of chunk k+2 are issued right behind it, so they have
 //     a whole 16-MFMA iteration to land;
-//   * 8 consecutive lanes stage one 128-byte row (full cache lines from HBM, conflict-free ds_write_b128);
-//     LDS rows are unpadded, 16-byte slot s of row r is stored at slot s ^ ((r >> 1) & 7): the 16 rows a
-//     ds_read_b128 lane group touches then fall on 16 distinct slots of the 256-byte bank row.
+//   * BK/8 consecutive lanes stage one row of BK bf16 (BK = 64: full 128-byte lines from HBM; conflict-free
+//     ds_write_b128); LDS rows are unpadded, 16-byte slot s of row r is stored at slot s ^ ((r >> 1) & 7) (BK = 64) or
+//     s ^ ((r >> 2) & 3) (BK = 32): the 16 rows a ds_read_b128 lane group touches then fall on 16 distinct slots of the
+//     256-byte bank row (the padded 80-byte rows of the fp32-input kernel cost 2-way ds_write conflicts).
 // Stride-1-in-the-input only (in_dil == 1); KH*KW <= 16.
-template <int BN, bool ML, typename TO>
-__global__ __launch_bounds__(256) void conv_igemm_bf16_k64(ConvArgs16 p) {
-  constexpr int BM = 128, BK = 64, ROWB = 128;  // LDS row = 64 bf16
-  constexpr int TM = 2, TN = BN / 64, AP = 4, BP = BN / 32;  // 16-byte pieces per thread per chunk
+template <int BN, bool ML, int BK, typename TO>
+__global__ __launch_bounds__(256) void conv_igemm_bf16_v2(ConvArgs16 p) {
+  constexpr int BM = 128, ROWB = BK * 2;              // LDS row = BK bf16
+  constexpr int SLOTS = BK / 8, RPP = 256 / SLOTS;    // 16-byte slots per row; rows staged per pass of the 256 threads
+  constexpr int TM = 2, TN = BN / 64, AP = BM / RPP, BP = BN / RPP, KS = BK / 16;  // pieces per thread; k16 steps per chunk
   constexpr int ABUF = BM * ROWB, BBUF = BN * ROWB;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (ABUF + BBUF)];
+  constexpr int STAGE = 2 * (ABUF + BBUF), PATCH = 4 * 32 * ((BN / 2) + 4) * 4;  // staging buffers; epilogue patches
+  __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE > PATCH ? STAGE : PATCH];
   unsigned char* As = smem;
   unsigned char* Bs = smem + 2 * ABUF;
 
@@ -331,14 +335,14 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_k64(ConvArgs16 p) {
   }
   const int mt = tile / tilesN, nt = tile - mt * tilesN;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int lrow = tid >> 3, slot = tid & 7;  // staged rows lrow + 32*j, channels slot*8 .. +7 of the chunk
+  const int lrow = tid / SLOTS, slot = tid % SLOTS;  // staged rows lrow + RPP*j, channels slot*8 .. +7 of the chunk
   const int ntaps = p.KH * p.KW;
 
   int aoff[AP], awc[AP];
   unsigned amask[AP];
 #pragma unroll
   for (int j = 0; j < AP; ++j) {
-    const int m = m0 + lrow + 32 * j;
+    const int m = m0 + lrow + RPP * j;
     const bool mv = m < p.M;
     const int mm = mv ? m : 0;
     int pb, H, W, ih0, iw0;
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_k64(ConvArgs16 p) {
   bool bvalid[BP];
 #pragma unroll
   for (int j = 0; j < BP; ++j) {
-    const int co = n0 + lrow + 32 * j;
+    const int co = n0 + lrow + RPP * j;
     bvalid[j] = co < p.K;
     boff[j] = (bvalid[j] ? co : 0) * p.Kred + slot * 8;
   }
@@ -408,19 +412,20 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_k64(ConvArgs16 p) {
       if (++kh == p.KH) { kh = 0; tap = 0; c0 += BK; }
     }
   };
-  const int wslot = (slot ^ ((lrow >> 1) & 7)) * 16;  // (row >> 1) & 7 is the same for rows lrow + 32*j
+  auto swizzle = [](int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; };
+  const int wslot = (slot ^ swizzle(lrow)) * 16;  // the swizzle is the same for rows lrow + RPP*j
   auto lds_store = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < AP; ++j) *(bf16x8_t*)(As + buf * ABUF + (lrow + 32 * j) * ROWB + wslot) = ra[j];
+    for (int j = 0; j < AP; ++j) *(bf16x8_t*)(As + buf * ABUF + (lrow + RPP * j) * ROWB + wslot) = ra[j];
 #pragma unroll
-    for (int j = 0; j < BP; ++j) *(bf16x8_t*)(Bs + buf * BBUF + (lrow + 32 * j) * ROWB + wslot) = rb[j];
+    for (int j = 0; j < BP; ++j) *(bf16x8_t*)(Bs + buf * BBUF + (lrow + RPP * j) * ROWB + wslot) = rb[j];
   };
 
   const int frow = lane & 31, fh = lane >> 5;
-  const int swz = (frow >> 1) & 7;
-  int koff[4];  // byte offset of the lane's 8 k-elements of k16-step s inside its (swizzled) row
+  const int swz = swizzle(frow);
+  int koff[KS];  // byte offset of the lane's 8 k-elements of k16-step s inside its (swizzled) row
 #pragma unroll
-  for (int s = 0; s < 4; ++s) koff[s] = ((2 * s + fh) ^ swz) * 16;
+  for (int s = 0; s < KS; ++s) koff[s] = ((2 * s + fh) ^ swz) * 16;
   const int arow = (wm * 64 + frow) * ROWB, brow = (wn * (BN / 2) + frow) * ROWB;
 
   gload();
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_k64(ConvArgs16 p) {
     const unsigned char* ab = As + buf * ABUF + arow;
     const unsigned char* bb = Bs + buf * BBUF + brow;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < KS; ++s) {
       bf16x8_t a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8_t*)(ab + i * 32 * ROWB + koff[s]);
@@ -451,6 +456,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_k64(ConvArgs16 p) {
   }
 
   if ((p.K & 3) == 0) {
+    static_assert(sizeof(smem) >= 4 * 32 * ((BN / 2) + 4) * sizeof(float), "epilogue patches must fit the staging LDS");
     float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
     epilogue_rows<TN, TO>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
                           m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K);
@@ -484,16 +490,21 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_k64(ConvArgs16 p) {
 template <int BN, bool ML>
 static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dtype, hipStream_t stream) {
   const dim3 g(tiles), b(256);
-  // deep-K kernel: bf16 input, 64-channel slabs, 32-bit element offsets, plain (non-dilated) gather
+  // v2 kernels: bf16 input, 32-bit element offsets, plain (non-dilated) gather, <= 16 taps
   const int64_t xelems = ML ? (int64_t)a.M * a.C : (int64_t)a.N * a.H * a.W * a.C;
-  // It holds 2 workgroups per CU (64 KB LDS) against 3 for the BK = 32 kernel: worth it for long K loops (MFMA-bound
-  // 3x3 / wide 1x1 layers) unless the grid is a little over one 512-slot round (tail), not for short HBM-bound ones.
-  const int k64_min_kred = 1024;
-  const bool tail = tiles > 512 && tiles <= 768;
-  if (x_dtype == UTV2_BF16 && a.C % 64 == 0 && a.in_dil == 1 && a.KH * a.KW <= 16 && xelems < (1ll << 31) &&
-      (int64_t)a.K * a.Kred < (1ll << 31) && a.Kred >= k64_min_kred && !tail) {
-    if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_k64<BN, ML, __bf16>), g, b, 0, stream, a);
-    else hipLaunchKernelGGL((conv_igemm_bf16_k64<BN, ML, float>), g, b, 0, stream, a);
+  if (x_dtype == UTV2_BF16 && a.C % 32 == 0 && a.in_dil == 1 && a.KH * a.KW <= 16 && xelems < (1ll << 31) &&
+      (int64_t)a.K * a.Kred < (1ll << 31)) {
+    // BK = 64 holds 2 workgroups per CU (64 KB LDS) against 4 for BK = 32: worth it for long K loops (MFMA-bound 3x3 /
+    // wide 1x1 layers) unless the grid is a little over one 512-slot round (tail), not for short HBM-bound ones.
+    const bool tail = tiles > 512 && tiles <= 768;
+    const bool deep = a.C % 64 == 0 && a.Kred >= 1024 && !tail;
+    if (deep) {
+      if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 64, __bf16>), g, b, 0, stream, a);
+      else hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 64, float>), g, b, 0, stream, a);
+    } else {
+      if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 32, __bf16>), g, b, 0, stream, a);
+      else hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 32, float>), g, b, 0, stream, a);
+    }
     return;
   }
   if (x_dtype == UTV2_BF16) {
