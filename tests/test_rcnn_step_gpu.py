@@ -137,3 +137,43 @@ def test_rcnn_full_semisup_step_parity():
         upd = float((new_s[k].double() - sd_s[k].double()).abs().max())
         tol = 1e-4 * float(new_s[k].abs().max()) + 5e-2 * upd + 1e-12  # discrete selections (matcher ties, ReLU gates) are ill-conditioned
         assert err <= tol, (k, err, tol)
+
+
+def test_rcnn_step_amp_close_to_fp32():
+    """The AMP (bf16 activations / MFMA operands) Faster-RCNN step runs through every typed kernel path - fp32 FPN levels
+    into RoIAlign, bf16 backbone / heads, fp32 loss-side outputs - and its supervised losses stay within a few per cent
+    of the fp32 step on the same seeded batch and sampling keys (proposal selection is discrete, hence the loose bound)."""
+    from ubteacher import ops
+    from ubteacher.engine import UBRCNNTeacherTrainer
+    recs = {}
+    try:
+        for amp in (False, True):
+            cfg = rcnn_cfg()
+            cfg.SOLVER.AMP.ENABLED = amp
+            torch.manual_seed(0)
+            prod, orac = make_batch(31, 2, 2, H, W, "cuda")
+            tr = UBRCNNTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+            assert ops.PRECISION[0] == ("bf16" if amp else "fp32")
+            mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1)
+            pstd = torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1)
+            sd_s = tune(cpu_state(tr.model), [d["image"] for d in orac[3]], mean, pstd)
+            sd_t = dict(sd_s)
+            sd_t["roi_heads.box_predictor.bbox_pred_std.bias"] = torch.full((4,), -3.0)
+            tr.model.load_state_dict(sd_s)
+            tr.model_teacher.load_state_dict(sd_t)
+            tr.iter = 1
+            tr.optimizer.param_groups[0]["lr"] = 0.01
+            g = torch.Generator().manual_seed(99)
+            src = lambda n, m, device: torch.rand(n, m, generator=g).to(device)  # noqa: E731
+            tr.model.proposal_generator.sample_keys = src
+            tr.model.roi_heads.sample_keys = src
+            tr.run_step_full_semisup()
+            recs[amp] = tr.flush_metrics()
+            after = cpu_state(tr.model)
+            assert all(torch.isfinite(v).all() for v in after.values())
+            assert any(not torch.equal(after[k], sd_s[k]) for k in sd_s if k.endswith("weight"))
+    finally:
+        ops.set_precision("fp32")
+    for k in ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"):
+        a, b = recs[True][k], recs[False][k]
+        assert np.isfinite(a) and abs(a - b) <= 5e-2 * max(abs(b), 1e-6), (k, a, b)

@@ -314,7 +314,7 @@ static int fill_levels16(LevelTab& lt, int nlev, int N, const int* H, const int*
 //     256-byte bank row (the padded 80-byte rows of the fp32-input kernel cost 2-way ds_write conflicts).
 // Stride-1-in-the-input only (in_dil == 1); KH*KW <= 16.
 template <int BN, bool ML, int BK, typename TO>
-__global__ __launch_bounds__(256) void conv_igemm_bf16_v2(ConvArgs16 p) {
+__global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(ConvArgs16 p) {
   constexpr int BM = 128, ROWB = BK * 2;              // LDS row = BK bf16
   constexpr int SLOTS = BK / 8, RPP = 256 / SLOTS;    // 16-byte slots per row; rows staged per pass of the 256 threads
   constexpr int TM = 2, TN = BN / 64, AP = BM / RPP, BP = BN / RPP, KS = BK / 16;  // pieces per thread; k16 steps per chunk
