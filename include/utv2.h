@@ -144,9 +144,10 @@ int utv2_fcos_loc_terms_fwd(const int* labels, const float* box, int box_stride,
 int utv2_fcos_loc_terms_bwd(const int* labels, const float* box, int box_stride, const float* reg_targets,
                             const float* bvars, int64_t P, int num_classes, int reg_max, float ts_better, float ts_cert,
                             const float* coef, float* dbox, utv2_stream_t stream);
-/* :1146-1195 ranking score -> sortable int64 key (method 0 cls, 1 cls_n_ctr, 2 ctr, 3 cls_n_loc) */
+/* :1146-1195 ranking score -> sortable int64 key (method 0 cls, 1 cls_n_ctr, 2 ctr, 3 cls_n_loc); image n's HW*C keys
+ * start at keys + n*key_row_stride (>= HW*C: rows of a wider matrix shared by all FPN levels) */
 int utv2_fcos_rank_keys(const float* logits, const float* box, int box_stride, int reg_max, int N, int HW, int C,
-                        float thr, int method, long long* keys, utv2_stream_t stream);
+                        float thr, int method, long long* keys, int64_t key_row_stride, utv2_stream_t stream);
 /* :1093-1104,:1258-1296 decode of the selected candidates of one level into padded slots */
 int utv2_fcos_decode(const long long* topkeys, int K, const float* logits, const float* box, int box_stride, int reg_max,
                      int N, int HW, int Wl, int C, int stride, int level, int method, int MAXC, int slot0, float* oboxes,

@@ -15,6 +15,7 @@
 // stride); each thread stages 8 consecutive k of a row (two 16-byte global loads -> one
 // ds_write_b128); each MFMA reads one ds_read_b128 per operand fragment.
 #include "common.h"
+#include <type_traits>
 
 // 64 zero bytes: out-of-image / out-of-range operand pieces are loaded from here, so every staging load is
 // unconditional (no exec-mask branches) and needs no masking of the loaded data (which would force the wave to wait for
@@ -391,34 +392,34 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
   int kh = 0, kw = 0, c0 = 0, tap = 0;
   bf16x8_t ra[AP], rb[BP];
 
-  auto gload = [&]() {  // issues the loads of the next chunk in (c0, tap) order and advances the cursor
-    const int ua = kw * p.C + c0;       // wave-uniform parts
-    const int ub = tap * p.C + c0;
-    const __bf16* zero = (const __bf16*)g_zero64;  // halo / out-of-range pieces read zeros: no branches, no data masking
-#pragma unroll
-    for (int j = 0; j < AP; ++j) {
-      const __bf16* src = ((amask[j] >> tap) & 1u) ? xb + (unsigned)(aoff[j] + kh * awc[j] + ua) : zero;
-      ra[j] = *(const bf16x8_t*)src;
-    }
-#pragma unroll
-    for (int j = 0; j < BP; ++j) {
-      const __bf16* src = bvalid[j] ? p.w + (unsigned)(boff[j] + ub) : zero;
-      rb[j] = *(const bf16x8_t*)src;
-    }
-    // taps innermost: the KH*KW shifted reads of one 64-channel slab stay L1/L2 resident
+  constexpr int NP = AP + BP;  // staged 16-byte pieces per thread per chunk: A pieces 0..AP-1, then B pieces
+  int ua = 0, ub = 0, ukh = 0, utap = 0;  // cursor of the chunk being loaded (wave-uniform)
+  auto cursor_next = [&]() {  // latch the chunk (kh, kw, c0) to load next and advance; taps innermost: the KH*KW shifted
+    ua = kw * p.C + c0;       // reads of one BK-channel slab stay L1/L2 resident
+    ub = tap * p.C + c0;
+    ukh = kh;
+    utap = tap;
     ++tap;
     if (++kw == p.KW) {
       kw = 0;
       if (++kh == p.KH) { kh = 0; tap = 0; c0 += BK; }
     }
   };
+  const __bf16* zero = (const __bf16*)g_zero64;  // halo / out-of-range pieces read zeros: no branches, no data masking
+  auto load_piece = [&](int q) {
+    if (q < AP) {
+      const __bf16* src = ((amask[q] >> utap) & 1u) ? xb + (unsigned)(aoff[q] + ukh * awc[q] + ua) : zero;
+      ra[q] = *(const bf16x8_t*)src;
+    } else {
+      const __bf16* src = bvalid[q - AP] ? p.w + (unsigned)(boff[q - AP] + ub) : zero;
+      rb[q - AP] = *(const bf16x8_t*)src;
+    }
+  };
   auto swizzle = [](int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; };
   const int wslot = (slot ^ swizzle(lrow)) * 16;  // the swizzle is the same for rows lrow + RPP*j
-  auto lds_store = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < AP; ++j) *(bf16x8_t*)(As + buf * ABUF + (lrow + RPP * j) * ROWB + wslot) = ra[j];
-#pragma unroll
-    for (int j = 0; j < BP; ++j) *(bf16x8_t*)(Bs + buf * BBUF + (lrow + RPP * j) * ROWB + wslot) = rb[j];
+  auto store_piece = [&](int buf, int q) {
+    if (q < AP) *(bf16x8_t*)(As + buf * ABUF + (lrow + RPP * q) * ROWB + wslot) = ra[q];
+    else *(bf16x8_t*)(Bs + buf * BBUF + (lrow + RPP * (q - AP)) * ROWB + wslot) = rb[q - AP];
   };
 
   const int frow = lane & 31, fh = lane >> 5;
@@ -428,16 +429,24 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
   for (int s = 0; s < KS; ++s) koff[s] = ((2 * s + fh) ^ swz) * 16;
   const int arow = (wm * 64 + frow) * ROWB, brow = (wn * (BN / 2) + frow) * ROWB;
 
-  gload();
-  lds_store(0);
-  if (nchunks > 1) gload();
+  cursor_next();
+#pragma unroll
+  for (int q = 0; q < NP; ++q) load_piece(q);
+#pragma unroll
+  for (int q = 0; q < NP; ++q) store_piece(0, q);
+  if (nchunks > 1) {
+    cursor_next();
+#pragma unroll
+    for (int q = 0; q < NP; ++q) load_piece(q);
+  }
   __syncthreads();
-  for (int kc = 0; kc < nchunks; ++kc) {
-    const int buf = kc & 1;
-    if (kc + 1 < nchunks) {
-      lds_store(buf ^ 1);              // chunk kc+1: its loads were issued one full iteration ago
-      if (kc + 2 < nchunks) gload();   // chunk kc+2
-    }
+  // One K iteration.  Chunk kc+1 (its loads were issued one full iteration ago) moves registers -> LDS and the loads of
+  // chunk kc+2 are re-issued into the same registers, piece by piece BEHIND the MFMAs of the k16 steps, so the staging
+  // instructions issue in the shadow of the matrix pipe instead of ahead of it.  STORE / LOAD are compile-time so the
+  // steady-state loop body is one basic block (branches inside it make the compiler fall back to vmcnt(0) waits).
+  auto iteration = [&](int buf, auto do_store, auto do_load) {
+    constexpr bool STORE = decltype(do_store)::value, LOAD = decltype(do_load)::value;
+    if constexpr (LOAD) cursor_next();
     const unsigned char* ab = As + buf * ABUF + arow;
     const unsigned char* bb = Bs + buf * BBUF + brow;
 #pragma unroll
@@ -451,9 +460,21 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int q = s * NP / KS; q < (s + 1) * NP / KS; ++q) {
+        if constexpr (STORE) store_piece(buf ^ 1, q);
+        if constexpr (LOAD) load_piece(q);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
-  }
+  };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
+  int kc = 0;
+  for (; kc + 2 < nchunks; ++kc) iteration(kc & 1, yes{}, yes{});
+  if (kc + 1 < nchunks) { iteration(kc & 1, yes{}, no{}); ++kc; }
+  iteration(kc & 1, no{}, no{});
 
   if ((p.K & 3) == 0) {
     static_assert(sizeof(smem) >= 4 * 32 * ((BN / 2) + 4) * sizeof(float), "epilogue patches must fit the staging LDS");

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(128) void fcos_loc_bwd_kernel(const int* __restrict
 // method: 0 cls, 1 cls_n_ctr, 2 ctr, 3 cls_n_loc
 __global__ __launch_bounds__(256) void fcos_rank_keys_kernel(const float* __restrict__ logits, const float* __restrict__ box, int BS,
                                                            int R4, int HW, int C, float thr, int method,
-                                                           long long* __restrict__ keys) {
+                                                           long long* __restrict__ keys, size_t key_stride) {
   // grid.y = image; rows of this (level, image): [HW][C]
   const int n = blockIdx.y;
   const size_t total = (size_t)HW * C;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void fcos_rank_keys_kernel(const float* __rest
       }
       key = ((long long)__float_as_uint(r) << 32) | (long long)(0xFFFFFFFFu - (unsigned)i);
     }
-    keys[(size_t)n * total + i] = key;
+    keys[(size_t)n * key_stride + i] = key;
   }
 }
 
@@ -562,12 +562,12 @@ int utv2_fcos_loc_terms_bwd(const int* labels, const float* box, int box_stride,
 
 // one level: logits [N][HW][C], box [N][HW][BS] -> keys [N][HW*C]
 int utv2_fcos_rank_keys(const float* logits, const float* box, int box_stride, int reg_max, int N, int HW, int C, float thr,
-                        int method, long long* keys, hipStream_t stream) {
-  if (!logits || !box || !keys || method < 0 || method > 3) return UTV2_EARG;
+                        int method, long long* keys, int64_t key_row_stride, hipStream_t stream) {
+  if (!logits || !box || !keys || method < 0 || method > 3 || key_row_stride < (int64_t)HW * C) return UTV2_EARG;
   int gx = cdiv((int64_t)HW * C, 256);
   if (gx > 4096) gx = 4096;
   hipLaunchKernelGGL(fcos_rank_keys_kernel, dim3(gx, N), dim3(256), 0, stream, logits, box, box_stride, 4 * (reg_max + 1), HW, C,
-                     thr, method, keys);
+                     thr, method, keys, (size_t)key_row_stride);
   return utv2_launch_status();
 }
 

@@ -105,6 +105,10 @@ def _same_dt(*ts):
     return _dt(ts[0])
 
 
+def _p_any(t):
+    return c_p(t.data_ptr())
+
+
 def _check(rc, name):
     if rc != 0:
         raise RuntimeError("%s failed with code %d" % (name, rc))
@@ -360,12 +364,17 @@ def fcos_loc_terms_bwd(labels, box, reg_targets, bvars, num_classes, reg_max, ts
     return out
 
 
-def fcos_rank_keys(logits, box, reg_max, N, HW, thr, method):
+def fcos_rank_keys(logits, box, reg_max, N, HW, thr, method, out=None, row_stride=None):
+    """keys [N][HW*C] int64 (or written into the first HW*C columns of `out`, whose rows are row_stride apart)"""
     C = logits.shape[-1]
     BS = box.shape[-1]
-    keys = torch.empty((N, HW * C), dtype=torch.int64, device=logits.device)
-    call("utv2_fcos_rank_keys", _p(logits), _p(box), BS, reg_max, N, HW, C, float(thr), method, _p(keys), _stream())
-    return keys
+    if out is None:
+        out = torch.empty((N, HW * C), dtype=torch.int64, device=logits.device)
+        row_stride = HW * C
+    assert out.stride(1) == 1 and out.stride(0) == row_stride and out.shape[0] == N and out.shape[1] >= HW * C
+    call("utv2_fcos_rank_keys", _p_any(logits), _p_any(box), BS, reg_max, N, HW, C, float(thr), method, c_p(out.data_ptr()),
+         int(row_stride), _stream())
+    return out
 
 
 def fcos_decode(topkeys, logits, box, reg_max, N, HW, Wl, stride, level, method, slot0, outs):

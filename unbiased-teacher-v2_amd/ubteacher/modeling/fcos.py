@@ -310,13 +310,22 @@ class FCOSOutputs:
             fpn_levels=torch.empty((N, MAXC), dtype=torch.int32, device=dev),
             valid=torch.empty((N, MAXC), dtype=torch.uint8, device=dev),
         )
+        # per-level top-k (fcos_outputs.py:1238-1241) as ONE batched selection: the ranking keys of every (level, image)
+        # are rows of a [L*N, max HW*C] matrix padded with -1 (= "no candidate", sorts last), so torch.topk's multi-pass
+        # radix select runs once instead of once per level
+        L = len(level_hw)
+        width = max(h * w for h, w in level_hw) * self.num_classes
+        keys = torch.full((L * N, width), -1, dtype=torch.int64, device=dev)
+        for l, (h, w) in enumerate(level_hw):
+            r0, r1 = meta.rows[l]
+            hip.fcos_rank_keys(logits_all[r0:r1], box_all[r0:r1], self.reg_max, N, h * w, th, method,
+                               out=keys[l * N:(l + 1) * N], row_stride=width)
+        top_all = torch.topk(keys, max(ks), dim=1, sorted=True).values
         slot0 = 0
         for l, (h, w) in enumerate(level_hw):
             r0, r1 = meta.rows[l]
-            lg, bx = logits_all[r0:r1], box_all[r0:r1]
-            keys = hip.fcos_rank_keys(lg, bx, self.reg_max, N, h * w, th, method)
-            top = torch.topk(keys, ks[l], dim=1, sorted=True).values.contiguous()
-            hip.fcos_decode(top, lg, bx, self.reg_max, N, h * w, w, self.strides[l], l, method, slot0, outs)
+            top = top_all[l * N:(l + 1) * N, :ks[l]].contiguous()
+            hip.fcos_decode(top, logits_all[r0:r1], box_all[r0:r1], self.reg_max, N, h * w, w, self.strides[l], l, method, slot0, outs)
             slot0 += ks[l]
         keep, cnt = hip.nms_batched(outs["boxes"], outs["scores"], outs["classes"], outs["valid"], self.nms_thresh,
                                     class_aware=True, post_topk=post, max_out=max_det)
