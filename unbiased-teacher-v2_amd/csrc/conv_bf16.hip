@@ -685,7 +685,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
   for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
   const bool do_bias = p.bias_ws != nullptr && nt == 0;
 
-  auto rload = [&](int chunk) {  // geometry of the chunk AFTER the one whose data is being loaded: off the critical path
+  // Software pipeline (one register set, like the forward kernel): per iteration ch the pieces of chunk ch+1 (loaded
+  // during iteration ch-1) go registers -> LDS, each followed by the re-issue of the same piece of chunk ch+2; the pixel
+  // geometry (rowinfo) runs one more chunk ahead, so no load waits on another load.
+  // pieces q: 0,1 = dY rows pl0, pl0+16;  2,3 = im2col rows pl0, pl0+16
+  auto rload = [&](int chunk) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       int m = chunk * BK + pl0 + 16 * r;
@@ -709,31 +713,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
     }
     return v;
   };
-  auto gload = [&](int chunk) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int m = chunk * BK + pl0 + 16 * r;
-      const bool mok = m < p.M;
+  auto load_piece = [&](int chunk, int q) {
+    const int r = q & 1;
+    const int m = chunk * BK + pl0 + 16 * r;
+    const bool mok = m < p.M;
+    if (q < 2) {
       ra[r] = load8(p.dy, (size_t)m * p.K + co8, DY16, mok && aok);
+    } else {
       const int W = ri[r].y >> 16;
       const bool ok = mok && bok && ((ri[r].y >> tap) & 1);
       rb[r] = load8(p.x, (size_t)(ri[r].x + dh * W + dw) * p.C + ci, X16, ok);
     }
   };
-  auto bias_acc = [&]() {
-    if (do_bias) {
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
+  auto store_piece = [&](int buf, int q) {
+    const int r = q & 1;
+    unsigned char* dst = smem + buf * 2 * OPB + (q < 2 ? 0 : OPB) + (pl0 + 16 * r) * LDR + cg * 16;
+    if (q < 2) {
+      *(bf16x8_t*)dst = ra[r];
+      if (do_bias) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) bsum[e] += (float)ra[r][e];
-    }
-  };
-  auto lds_store = [&](int buf) {
-    unsigned char* ab = smem + buf * 2 * OPB;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      *(bf16x8_t*)(ab + (pl0 + 16 * r) * LDR + cg * 16) = ra[r];
-      *(bf16x8_t*)(ab + OPB + (pl0 + 16 * r) * LDR + cg * 16) = rb[r];
+      }
+    } else {
+      *(bf16x8_t*)dst = rb[r];
     }
   };
 
@@ -741,45 +743,61 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
   // channels 16*(G&1) + 4*(t&3) .. +3 of its 32-channel MFMA tile, and receives channel 16*(G&1) + t.
   const int G = lane >> 4, t = lane & 15;
   const int frag_off = (8 * (G >> 1) + (t >> 2)) * LDR + (16 * (G & 1) + 4 * (t & 3)) * 2;
-  if (chunk_begin < chunk_end) {
-    rload(chunk_begin);
-    gload(chunk_begin);
-    if (chunk_begin + 1 < chunk_end) rload(chunk_begin + 1);
-    bias_acc();
-    lds_store(0);
-    __syncthreads();
-    for (int ch = chunk_begin; ch < chunk_end; ++ch) {
-      const int buf = (ch - chunk_begin) & 1;
-      if (ch + 1 < chunk_end) {
-        gload(ch + 1);
-        if (ch + 2 < chunk_end) rload(ch + 2);
+  auto iteration = [&](int ch, int buf, auto do_store, auto do_load) {
+    constexpr bool STORE = decltype(do_store)::value, LOAD = decltype(do_load)::value;
+    const unsigned char* ab = smem + buf * 2 * OPB + frag_off;
+    const unsigned char* bb = ab + OPB;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8_t a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned char* ap = ab + s * 16 * LDR + (wm * 64 + i * 32) * 2;
+        const bf16x4_t a0 = lds_read_tr16(ap), a1 = lds_read_tr16(ap + 4 * LDR);
+        const unsigned char* bp = bb + s * 16 * LDR + (wn * 64 + i * 32) * 2;
+        const bf16x4_t b0 = lds_read_tr16(bp), b1 = lds_read_tr16(bp + 4 * LDR);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[i][e] = a0[e]; a[i][4 + e] = a1[e];
+          b[i][e] = b0[e]; b[i][4 + e] = b1[e];
+        }
       }
-      const unsigned char* ab = smem + buf * 2 * OPB + frag_off;
-      const unsigned char* bb = ab + OPB;
-      bf16x8_t a[2][2], b[2][2];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const unsigned char* ap = ab + s * 16 * LDR + (wm * 64 + i * 32) * 2;
-          const bf16x4_t a0 = lds_read_tr16(ap), a1 = lds_read_tr16(ap + 4 * LDR);
-          const unsigned char* bp = bb + s * 16 * LDR + (wn * 64 + i * 32) * 2;
-          const bf16x4_t b0 = lds_read_tr16(bp), b1 = lds_read_tr16(bp + 4 * LDR);
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      // s = 0: the im2col pieces (they consume the rowinfo registers), s = 1: the dY pieces, then the next geometry
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            a[i][s][e] = a0[e]; a[i][s][4 + e] = a1[e];
-            b[i][s][e] = b0[e]; b[i][s][4 + e] = b1[e];
-          }
-        }
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-      if (ch + 1 < chunk_end) { bias_acc(); lds_store(buf ^ 1); }
-      __syncthreads();
+      for (int q = (s == 0 ? 2 : 0); q < (s == 0 ? 4 : 2); ++q) {
+        if constexpr (STORE) store_piece(buf ^ 1, q);
+        if constexpr (LOAD) load_piece(ch + 2, q);
+      }
+      if constexpr (LOAD) {
+        if (s == 0) rload(ch + 3);  // clamped inside; consumed by the im2col loads of the NEXT iteration
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    __syncthreads();
+  };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
+  if (chunk_begin < chunk_end) {
+    rload(chunk_begin);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_piece(chunk_begin, q);
+    rload(chunk_begin + 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) store_piece(0, q);
+    if (chunk_begin + 1 < chunk_end) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) load_piece(chunk_begin + 1, q);
+      rload(chunk_begin + 2);
+    }
+    __syncthreads();
+    int ch = chunk_begin;
+    for (; ch + 2 < chunk_end; ++ch) iteration(ch, (ch - chunk_begin) & 1, yes{}, yes{});
+    if (ch + 1 < chunk_end) { iteration(ch, (ch - chunk_begin) & 1, yes{}, no{}); ++ch; }
+    iteration(ch, (ch - chunk_begin) & 1, no{}, no{});
   }
   if (p.bias_ws != nullptr && nt == 0) {  // block-uniform: fixed-order combine of the 16 pixel lanes per channel group
     float* red = (float*)smem;
