@@ -829,17 +829,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
 }
 
 // dst[i] (+)= rowscale[i / rowlen] * sum_k ws[k][i]   (fixed order; rowscale optional: the folded FrozenBN multiplier of
-// the output channel, applied here instead of to the output gradient)
-__global__ void reduce_slabs16_f32(const float* __restrict__ ws, float* __restrict__ dst, size_t n, int splits, int accumulate,
-                                   const float* __restrict__ rowscale, int rowlen) {
+// the output channel, applied here instead of to the output gradient).  Four elements per thread (16-byte accesses),
+// four independent partial sums over k mod 4 combined in a fixed order: deterministic, and 4 loads in flight per thread.
+__global__ __launch_bounds__(256) void reduce_slabs16_f32(const float* __restrict__ ws, float* __restrict__ dst, size_t n, int splits,
+                                                          int accumulate, const float* __restrict__ rowscale, int rowlen) {
+  const size_t n4 = n >> 2;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) {
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += ws[(size_t)k * n + i];
-    if (rowscale) s *= rowscale[i / rowlen];
-    dst[i] = accumulate ? dst[i] + s : s;
+  for (; i < n4; i += stride) {
+    f32x4 s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] += ((const f32x4*)(ws + (size_t)(k + u) * n))[i];
+    }
+    for (; k < splits; ++k) s[0] += ((const f32x4*)(ws + (size_t)k * n))[i];
+    f32x4 t = (s[0] + s[1]) + (s[2] + s[3]);
+    if (rowscale) {
+      const float r = rowscale[(i * 4) / rowlen];  // rowlen % 4 == 0 (or 1 with n % 4 == 0 handled by the tail kernel)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] *= r;
+    }
+    if (accumulate) t += ((const f32x4*)dst)[i];
+    ((f32x4*)dst)[i] = t;
   }
+}
+
+// scalar form (bias slabs: n = K, one "row" per element)
+__global__ void reduce_slabs16_scalar_f32(const float* __restrict__ ws, float* __restrict__ dst, size_t n, int splits, int accumulate,
+                                          const float* __restrict__ rowscale) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += ws[(size_t)k * n + i];
+  if (rowscale) s *= rowscale[i];
+  dst[i] = accumulate ? dst[i] + s : s;
 }
 
 extern "C" {
@@ -888,13 +914,13 @@ int utv2_conv2d_wgrad_bf16(const void* x, int x_dtype, const void* dy, int dy_dt
     if (dy_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_wgrad_bf16<float, __bf16>), g, b, 0, stream, a);
     else hipLaunchKernelGGL((conv_wgrad_bf16<float, float>), g, b, 0, stream, a);
   }
-  int rb = cdiv((int64_t)n, 256);
-  if (rb > 4096) rb = 4096;
+  int rb = cdiv((int64_t)n / 4, 256);   // n = K * Kred, both multiples of 8
+  if (rb > 8192) rb = 8192;
   hipLaunchKernelGGL(reduce_slabs16_f32, dim3(rb), dim3(256), 0, stream, (const float*)ws, dw, n, a.splits, accumulate, rowscale,
                      a.Kred);
   if (db)
-    hipLaunchKernelGGL(reduce_slabs16_f32, dim3(cdiv(K, 256)), dim3(256), 0, stream, (const float*)a.bias_ws, db, (size_t)K, a.splits,
-                       accumulate, rowscale, 1);
+    hipLaunchKernelGGL(reduce_slabs16_scalar_f32, dim3(cdiv(K, 256)), dim3(256), 0, stream, (const float*)a.bias_ws, db, (size_t)K,
+                       a.splits, accumulate, rowscale);
   return utv2_launch_status();
 }
 

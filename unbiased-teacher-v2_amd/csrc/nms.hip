@@ -165,6 +165,14 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
         if (w < nchunks && w > c) removed[s] |= r[w];
       }
     }
+    // kthvalue rule below keeps only scores >= the post_topk-th kept score; candidates are in descending score order,
+    // so once post_topk are kept and the next chunk starts below that score nothing later can survive: stop scanning
+    if (post_topk > 0 && post_topk <= max_out && count >= post_topk && (c + 1) * 64 < nv) {
+      __syncthreads();  // single wave: keep[] stores of this wave are visible to its loads
+      const float kth = scores[(size_t)n * M + keep[(size_t)n * max_out + post_topk - 1]];
+      const float nxt = scores[(size_t)n * M + sidx[(size_t)n * Mpad + (c + 1) * 64]];
+      if (nxt < kth) break;
+    }
   }
   if (count > max_out) count = max_out;
   __syncthreads();  // single wave: orders the keep[] stores before the reads below
