@@ -93,3 +93,34 @@ def test_full_semisup_step_parity():
             assert relerr(gview, grads[k]) < (1e-2 if k.startswith("backbone.bottom_up") else 3e-3), k
             checked += 1
     assert checked > 100
+
+
+def test_fused_student_pass_equals_two_passes():
+    """The fused student pass (labeled + pseudo-labeled images in one batch, each loss branch masked to its own
+    images) reproduces the reference's two separate forwards: same losses, same updated student."""
+    from ubteacher.engine import UBTeacherTrainer
+    outs = {}
+    for fuse in (True, False):
+        cfg = small_fcos_cfg()
+        torch.manual_seed(0)
+        prod, orac = make_batch(12, 2, 2, H, W, "cuda")
+        tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+        tr.fuse_student_passes = fuse
+        sd_s = tune_state_for_pseudo_labels(cpu_state(tr.model), [d["image"] for d in orac[3]])
+        sd_t = dict(sd_s)
+        sd_t["proposal_generator.fcos_head.bbox_pred_std.bias"] = torch.full((4,), -3.0)
+        tr.model.load_state_dict(sd_s)
+        tr.model_teacher.load_state_dict(sd_t)
+        tr.iter = 1
+        tr.optimizer.param_groups[0]["lr"] = 0.01
+        tr.run_step_full_semisup()
+        outs[fuse] = (tr.flush_metrics(), cpu_state(tr.model), sd_s)
+    rec_f, s_f, sd0 = outs[True]
+    rec_u, s_u, _ = outs[False]
+    for k, v in rec_u.items():
+        if k.startswith("loss") or k.startswith("teacher"):
+            assert abs(rec_f[k] - v) <= 1e-5 * max(abs(v), 1e-6), (k, rec_f[k], v)
+    for k in s_u:
+        upd = float((s_u[k].double() - sd0[k].double()).abs().max())
+        err = float((s_f[k].double() - s_u[k].double()).abs().max())
+        assert err <= 1e-6 * float(s_u[k].abs().max()) + 2e-3 * upd + 1e-12, (k, err, upd)

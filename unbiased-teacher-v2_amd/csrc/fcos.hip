@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void fcos_targets_kernel(LevelTable lt, int N,
                                                          const int* __restrict__ gt_classes,
                                                          const unsigned char* __restrict__ gt_valid,
                                                          const float* __restrict__ gt_std, int num_classes, int drop_empty,
+                                                         const unsigned char* __restrict__ img_active,
                                                          int* __restrict__ labels, float* __restrict__ reg_targets,
                                                          float* __restrict__ bvars, int* __restrict__ gt_inds) {
   __shared__ float sb[TG_MAXG][4];
@@ -75,8 +76,10 @@ __global__ __launch_bounds__(256) void fcos_targets_kernel(LevelTable lt, int N,
   const float xs = (float)(x * lt.stride[l]) + (float)(lt.stride[l] / 2);
   const float ys = (float)(y * lt.stride[l]) + (float)(lt.stride[l] / 2);
   const size_t p = (size_t)N * lt.off[l] + (size_t)n * HWl + hw;
-  if (G == 0) {
-    labels[p] = drop_empty ? -1 : num_classes;
+  // an inactive image (it belongs to the other loss branch of a fused student pass) is ignored like a dropped one
+  const bool inactive = img_active != nullptr && !img_active[n];
+  if (G == 0 || inactive) {
+    labels[p] = (drop_empty || inactive) ? -1 : num_classes;
     gt_inds[p] = -1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { reg_targets[p * 4 + e] = 0.f; bvars[p * 4 + e] = 0.f; }
@@ -510,15 +513,15 @@ extern "C" {
 // H,W,strides: host int[num_levels]; soi: host float[2*num_levels] (lo,hi per level).
 int utv2_fcos_targets(int num_levels, const int* H, const int* W, const int* strides, const float* soi, int N, int MAXG,
                       const float* gt_boxes, const int* gt_classes, const unsigned char* gt_valid, const float* gt_std,
-                      int num_classes, int drop_empty, int* labels, float* reg_targets, float* bvars, int* gt_inds,
-                      hipStream_t stream) {
+                      int num_classes, int drop_empty, const unsigned char* img_active, int* labels, float* reg_targets,
+                      float* bvars, int* gt_inds, hipStream_t stream) {
   if (num_levels < 1 || num_levels > MAX_LEVELS || MAXG > TG_MAXG || MAXG < 1 || !gt_boxes || !gt_classes || !gt_valid ||
       !labels || !reg_targets || !bvars || !gt_inds)
     return UTV2_EARG;
   LevelTable t = make_table(num_levels, H, W, strides, soi);
   const int L = t.off[num_levels];
   hipLaunchKernelGGL(fcos_targets_kernel, dim3(cdiv(L, 256), N), dim3(256), 0, stream, t, N, MAXG, gt_boxes, gt_classes,
-                     gt_valid, gt_std, num_classes, drop_empty, labels, reg_targets, bvars, gt_inds);
+                     gt_valid, gt_std, num_classes, drop_empty, img_active, labels, reg_targets, bvars, gt_inds);
   return utv2_launch_status();
 }
 

@@ -13,6 +13,7 @@ run_step_full_semisup, _update_teacher_model, test) with the step re-designed fo
     of ~30 `.item()` calls per step.
 """
 import logging
+import os
 import time
 from collections import OrderedDict
 
@@ -253,6 +254,7 @@ class UBTeacherTrainer(_TrainerBase):
         self.model_teacher.eval()  # trainer.py:55
         self.scheduler = self.build_lr_scheduler(cfg, self.optimizer)
         self.pseudo_generator = PseudoGenerator(cfg)
+        self.fuse_student_passes = os.environ.get("UTV2_FUSE_STUDENT_PASSES", "1") != "0"
         self._common_init(cfg, data_loader)
 
     # pseudo-label dict surgery (trainer.py:161-175)
@@ -327,9 +329,18 @@ class UBTeacherTrainer(_TrainerBase):
             all_label_data = label_data_q + label_data_k
             all_unlabel_data = unlabel_data_q
 
-            record_dict.update(self.model(all_label_data, branch="labeled"))
-            record_unl, raw_pred_student, instance_reg = self.model(
-                all_unlabel_data, output_raw=True, ignore_near=S.PSEUDO_CLS_IGNORE_NEAR, branch="unlabeled")
+            # The reference runs two student forwards (trainer.py:396-411).  Every layer is per-image (FrozenBN, per-image
+            # GroupNorm), so when both lists pad to the same canvas they are ONE batch here: larger GEMMs, one weight
+            # gradient per layer instead of two.  Different canvases (zero padding differs) keep the two passes.
+            fuse = (self.fuse_student_passes and not S.PSEUDO_CLS_IGNORE_NEAR
+                    and self.model.padded_canvas(all_label_data) == self.model.padded_canvas(all_unlabel_data))
+            if fuse:
+                rec_l, record_unl = self.model.forward_joint(all_label_data, all_unlabel_data)
+                record_dict.update(rec_l)
+            else:
+                record_dict.update(self.model(all_label_data, branch="labeled"))
+                record_unl, raw_pred_student, instance_reg = self.model(
+                    all_unlabel_data, output_raw=True, ignore_near=S.PSEUDO_CLS_IGNORE_NEAR, branch="unlabeled")
             for k, v in record_unl.items():
                 record_dict[k + "_pseudo"] = v
 

@@ -45,6 +45,20 @@ class PaddedBoxes:
     def n(self):
         return self.f["valid"].shape[0]
 
+    def pad_images(self, before, after):
+        """The same boxes inside a longer batch: `before` / `after` empty images are added around them (device-side cat, no
+        sync) - the ground truth of one loss branch of a fused student pass."""
+        out = {}
+        for k, v in self.f.items():
+            if k == "count":
+                continue
+            z0 = v.new_zeros((before,) + tuple(v.shape[1:]))
+            z1 = v.new_zeros((after,) + tuple(v.shape[1:]))
+            out[k] = torch.cat((z0, v, z1), dim=0).contiguous()
+        sizes = list(self.image_sizes)
+        pad = sizes[0] if sizes else (0, 0)
+        return PaddedBoxes([pad] * before + sizes + [pad] * after, **out)
+
     def threshold(self, thr, ctr_thr=None):
         """pseudo_generator.py:62-131: keep scores > thr (or cls_confid > thr0 & centerness > thr1)."""
         if ctr_thr is None:
@@ -223,10 +237,10 @@ class FCOSOutputs:
         self.training = True
 
     # -- targets --------------------------------------------------------------------------------
-    def _targets(self, level_hw, gt, drop_empty):
+    def _targets(self, level_hw, gt, drop_empty, active=None):
         std = gt["reg_pred_std"] if "reg_pred_std" in gt else None
         return hip.fcos_targets(level_hw, self.strides, self.sizes_of_interest, gt["boxes"], gt["classes"],
-                                gt["valid"], std, self.num_classes, drop_empty)
+                                gt["valid"], std, self.num_classes, drop_empty, active)
 
     @staticmethod
     def _normalisers(sums):
@@ -240,11 +254,12 @@ class FCOSOutputs:
         return npa, den
 
     # -- supervised branch (fcos_outputs.py:212-444) -------------------------------------------------
-    def losses(self, head_out, level_hw, gt, branch="labeled"):
+    def losses(self, head_out, level_hw, gt, branch="labeled", active=None):
+        """active (optional, uint8 [N]): images of the batch this branch owns (fused student pass); the others are ignored."""
         if branch != "labeled":
             raise ValueError("Incorrect branch name")
         logits_all, box_all = head_out["logits"], head_out["box"]
-        labels, reg_t, bvars, gt_inds = self._targets(level_hw, gt, drop_empty=1)
+        labels, reg_t, bvars, gt_inds = self._targets(level_hw, gt, drop_empty=1, active=active)
         focal = ops.focal_loss_sum(logits_all, labels, self.focal_loss_alpha, self.focal_loss_gamma)
         sums = ops.fcos_loc_terms(box_all, labels, reg_t, None, (self.num_classes, self.reg_max, 0.0, 0.0))
         npa, den = self._normalisers(sums)
@@ -259,12 +274,12 @@ class FCOSOutputs:
         return extras, losses
 
     # -- pseudo branch (fcos_outputs.py:447-631) -----------------------------------------------------
-    def pseudo_losses(self, head_out, level_hw, gt_dict, branch="unlabeled"):
+    def pseudo_losses(self, head_out, level_hw, gt_dict, branch="unlabeled", active=None):
         assert branch == "unlabeled"
         logits_all, box_all = head_out["logits"], head_out["box"]
         losses, extras = {}, {}
         for labeltype, gt in gt_dict.items():
-            labels, reg_t, bvars, gt_inds = self._targets(level_hw, gt, drop_empty=0)
+            labels, reg_t, bvars, gt_inds = self._targets(level_hw, gt, drop_empty=0, active=active)
             if labeltype == "cls":
                 focal = ops.focal_loss_sum(logits_all, labels, self.focal_loss_alpha, self.focal_loss_gamma)
                 sums = ops.fcos_loc_terms(box_all, labels, reg_t, None, (self.num_classes, self.reg_max, 0.0, 0.0))
@@ -397,5 +412,22 @@ class FCOS:
         if output_raw:
             return results, {}, raw_output
         return results, {}
+
+    def forward_joint(self, image_sizes, features, n_labeled, gt_labeled, gt_unlabeled):
+        """Both student passes of one UTv2 iteration on ONE batch: images [0, n_labeled) carry ground truth (branch
+        "labeled"), the rest pseudo labels (branch "unlabeled").  Every op of the network is per-image (FrozenBN,
+        per-image GroupNorm), so this equals the two separate forwards whenever both groups share one padded canvas."""
+        assert self.training
+        feats = [features[f] for f in self.in_features]
+        level_hw = [(f.shape[1], f.shape[2]) for f in feats]
+        big, meta = features["_levelfirst"]
+        N = meta.N
+        head_out = self.fcos_head(big, meta)
+        act = torch.zeros(N, dtype=torch.uint8, device=big.device)
+        act[:n_labeled] = 1
+        _, l_sup = self.fcos_outputs.losses(head_out, level_hw, gt_labeled.pad_images(0, N - n_labeled), active=act)
+        gtu = {k: v.pad_images(n_labeled, 0) for k, v in gt_unlabeled.items()}
+        _, l_uns = self.fcos_outputs.pseudo_losses(head_out, level_hw, gtu, active=(1 - act))
+        return l_sup, l_uns
 
     __call__ = forward

@@ -78,9 +78,27 @@ class PseudoProposalNetwork(ArenaModel):
 
     __call__ = forward
 
+    def padded_canvas(self, batched_inputs):
+        """(H, W) the batch is zero-padded to by preprocess_image (ImageList.from_tensors with size_divisibility)."""
+        d = self.backbone.size_divisibility
+        h = max(int(x["image"].shape[1]) for x in batched_inputs)
+        w = max(int(x["image"].shape[2]) for x in batched_inputs)
+        return ((h + d - 1) // d * d, (w + d - 1) // d * d) if d > 1 else (h, w)
+
 
 @META_ARCH_REGISTRY.register()
 class OneStageDetector(PseudoProposalNetwork):
+    def forward_joint(self, labeled_inputs, unlabeled_inputs):
+        """model(labeled, branch="labeled") and model(unlabeled, branch="unlabeled") of one iteration
+        (reference trainer.py:396-411) as ONE forward over the concatenated batch; returns the two loss dicts.
+        Only valid when padded_canvas() of the two lists coincide (the caller checks)."""
+        assert self.training
+        both = list(labeled_inputs) + list(unlabeled_inputs)
+        features, image_sizes = self._features(both)
+        gt_l = self._gt(labeled_inputs, "instances")
+        gt_u = {"cls": self._gt(unlabeled_inputs, "instances_class"), "reg": self._gt(unlabeled_inputs, "instances_reg")}
+        return self.proposal_generator.forward_joint(image_sizes, features, len(labeled_inputs), gt_l, gt_u)
+
     def forward(self, batched_inputs, output_raw=False, nms_method="cls_n_ctr", ignore_near=False, branch="labeled"):
         if self.training:
             features, image_sizes = self._features(batched_inputs)
