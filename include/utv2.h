@@ -79,6 +79,10 @@ int64_t utv2_conv2d_wgrad_bf16_workspace_floats(int M, int K, int Kred);
 int utv2_conv2d_wgrad_bf16(const void* x, int x_dtype, const void* dy, int dy_dtype, float* dw, float* db, float* ws,
                            const int* rowinfo, const float* rowscale, int M, int C, int K, int KH, int KW, int accumulate,
                            utv2_stream_t stream);
+/* D2 BasicStem conv1 on bf16 MFMA: xpad16 = bf16 [N][H+6][W+8][4], the normalised NHWC4 image inside a zero border
+ * (written by utv2_preprocess_image_bf16pad); w16s = bf16 [K][7][32] (7 taps x 4 channels + 4 zeros per kernel row) */
+int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int y_dtype, const float* scale,
+                              const float* bias, int N, int H, int W, int K, int OH, int OW, int relu, utv2_stream_t stream);
 int utv2_f32_to_bf16(const float* src, void* dst16, int64_t n, utv2_stream_t stream);
 int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, const float* scale, int K, int KH, int KW, int C,
                                     utv2_stream_t stream);
@@ -101,9 +105,15 @@ int utv2_upsample2x_add_nhwc(const void* lateral, const void* top, void* out, in
                              utv2_stream_t stream);
 int utv2_downsample2x_sum_nhwc(const void* g, void* dtop, int N, int TH, int TW, int C, int accumulate, int dtype,
                                utv2_stream_t stream);
+/* dgrad of a stride-2 1x1 conv (D2 STRIDE_IN_1X1 bottlenecks): dst[n,2i,2j,:] = src[n,i,j,:], zeros elsewhere;
+ * src is [N][(H+1)/2][(W+1)/2][C] - the compact gradient comes from a plain GEMM instead of a 4x larger masked one */
+int utv2_zero_interleave2x_nhwc(const void* src, void* dst, int N, int H, int W, int C, int dtype, utv2_stream_t stream);
 /* modeling/one_stage_detector.py:88-90 / meta_arch/rcnn.py:18 (preprocess_image + ImageList pad) */
 int utv2_preprocess_image(const void* src, int is_u8, float* dst, int H, int W, int Hp, int Wp,
                           const float* mean3_host, const float* std3_host, utv2_stream_t stream);
+/* same, as bf16 at pixel offset (3,3) of one [Hp+6][Wp+8][4] slot of the zero-bordered bf16 stem input */
+int utv2_preprocess_image_bf16pad(const void* src, int is_u8, void* dst16, int H, int W, int Hp, int Wp,
+                                  const float* mean3_host, const float* std3_host, utv2_stream_t stream);
 /* D2 FrozenBatchNorm2d.forward: scale = w*rsqrt(var+eps), shift = b - mean*scale, all layers at once */
 int utv2_frozenbn_fold(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift,
                        int n, float eps, utv2_stream_t stream);

@@ -238,3 +238,45 @@ def test_bn_scale_folding():
     hip.conv2d_wgrad_bf16(x, dy, d0, ri, C, k, k, accumulate=False, db=b0)
     hip.conv2d_wgrad_bf16(x, dy, d1, ri, C, k, k, accumulate=False, db=b1, rowscale=sc)
     assert torch.equal(d1, d0 * sc[:, None]) and torch.equal(b1, b0 * sc)
+
+
+def test_stride2_1x1_dgrad_compact_path():
+    """compact GEMM + zero interleave == the dilated-gather dgrad kernel for a stride-2 1x1 conv (odd sizes included)"""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(6)
+    for (N, H, W, C, K) in [(2, 12, 10, 64, 128), (1, 13, 9, 256, 64)]:
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        w2 = (torch.randn(K, C, generator=g) * 0.05).cuda()
+        wt16 = hip.weight_flip_transpose_bf16(w2, K, 1, 1, C)
+        dy = torch.randn(N, OH, OW, K, generator=g).cuda().to(BF)
+        ref = hip.conv2d_dgrad_bf16(dy, wt16, (N, H, W, C), 2, 0, 1, 1, out_dtype=BF)
+        got = hip.zero_interleave2x(hip.conv2d_fwd_bf16(dy, wt16, out_dtype=BF), H, W)
+        assert torch.equal(ref, got)
+
+
+def test_stem_bf16():
+    """bf16-MFMA image stem (7x7 s2 p3 as KH=7, KW=1, C=32 with a 4-element pixel pitch on the zero-bordered bf16 image)
+    == conv2d on the bf16-rounded image and weights, FrozenBN scale/shift + ReLU fused."""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(7)
+    ims = [torch.randn(3, 50, 70, generator=g) * 50 + 100, torch.randn(3, 64, 61, generator=g) * 50 + 100]
+    mean, std = [103.53, 116.28, 123.675], [57.0, 58.0, 59.0]
+    x16, sizes = hip.preprocess_images([i.cuda() for i in ims], mean, std, 32, bf16_stem=True)
+    x4, _ = hip.preprocess_images([i.cuda() for i in ims], mean, std, 32)
+    Hp, Wp = x16.canvas
+    assert (Hp, Wp) == tuple(x4.shape[1:3]) and x16.shape == (2, Hp + 6, Wp + 8, 4)
+    assert torch.equal(x16[:, 3:3 + Hp, 3:3 + Wp], x4.to(BF))
+    border = x16.clone(); border[:, 3:3 + Hp, 3:3 + Wp] = 0
+    assert float(border.float().abs().max()) == 0.0
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    w208 = torch.zeros(64, 208)
+    w208[:, :196].view(64, 7, 7, 4)[..., :3] = w.permute(0, 2, 3, 1)
+    sc = (torch.rand(64, generator=g) + 0.5); sh = torch.randn(64, generator=g) * 0.1
+    y = hip.conv2d_stem_fwd_bf16(x16, hip.stem_weight_image(w208.cuda()), sc.cuda(), sh.cuda(), True, BF)
+    xin = x4[..., :3].permute(0, 3, 1, 2).cpu()
+    ref = torch.relu(F.conv2d(r16(xin), r16(w), None, 2, 3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    assert y.shape == (2, Hp // 2, Wp // 2, 64)
+    assert close16(y.cpu().permute(0, 3, 1, 2), ref)
+    # second call reuses the cached zero-bordered buffer
+    x16b, _ = hip.preprocess_images([i.cuda() for i in ims], mean, std, 32, bf16_stem=True)
+    assert x16b.data_ptr() == x16.data_ptr()

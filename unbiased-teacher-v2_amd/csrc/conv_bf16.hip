@@ -38,6 +38,7 @@ struct ConvArgs16 {
   const float* bias;
   const void* residual;      // element type TO
   int N, H, W, C, OH, OW, K, KH, KW, stride, pad, in_dil, relu, Kred, M, accumulate;
+  int xs;                    // elements between consecutive input pixels (= C except for the image stem's overlapping 8-pixel reads)
 };
 
 __device__ __forceinline__ void ml_decode16(const LevelTab& lt, int m, int& pixbase, int& H, int& W, int& oh, int& ow) {
@@ -362,8 +363,8 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
       H = p.H;
       W = p.W;
     }
-    aoff[j] = (pb + ih0 * W + iw0) * p.C + slot * 8;
-    awc[j] = W * p.C;
+    aoff[j] = (pb + ih0 * W + iw0) * p.xs + slot * 8;
+    awc[j] = W * p.xs;
     unsigned mk = 0;
     for (int kh = 0; kh < p.KH; ++kh)
       for (int kw = 0; kw < p.KW; ++kw)
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
   constexpr int NP = AP + BP;  // staged 16-byte pieces per thread per chunk: A pieces 0..AP-1, then B pieces
   int ua = 0, ub = 0, ukh = 0, utap = 0;  // cursor of the chunk being loaded (wave-uniform)
   auto cursor_next = [&]() {  // latch the chunk (kh, kw, c0) to load next and advance; taps innermost: the KH*KW shifted
-    ua = kw * p.C + c0;       // reads of one BK-channel slab stay L1/L2 resident
+    ua = kw * p.xs + c0;      // reads of one BK-channel slab stay L1/L2 resident
     ub = tap * p.C + c0;
     ukh = kh;
     utap = tap;
@@ -555,6 +556,7 @@ int utv2_conv2d_nhwc_fwd_bf16(const void* x, int x_dtype, const void* w16, void*
   a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual;
   a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.K = K; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
   a.in_dil = in_dil < 1 ? 1 : in_dil; a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.M = N * OH * OW;
+  a.xs = C;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   if (small) launch_igemm16<64, false>(a, tiles, x_dtype, y_dtype, stream);
@@ -571,11 +573,39 @@ int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y
   a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
   a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual;
   a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad; a.in_dil = 1;
-  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C;
+  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = C;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   if (small) launch_igemm16<64, true>(a, tiles, x_dtype, y_dtype, stream);
   else launch_igemm16<128, true>(a, tiles, x_dtype, y_dtype, stream);
+  return utv2_launch_status();
+}
+
+// Image stem (7x7 stride 2 pad 3 on the 3-channel image) on bf16 MFMA.  xpad16: bf16 [N][H+6][W+8][4], the normalised NHWC4
+// image inside a zero border of 3 pixels (5 on the right), so no tap is ever out of bounds and every read is 16-byte
+// aligned.  One kernel row kh of an output pixel reads 8 consecutive input pixels = 32 contiguous bf16 (7 taps x 4
+// channels + one zero-weighted pixel): the conv is run as KH = 7, KW = 1, C = 32 with a 4-element pixel pitch.
+// w16s: bf16 [K][7][32] (last 4 of each 32 zero).  H, W: the padded image canvas (even).
+int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int y_dtype, const float* scale, const float* bias,
+                              int N, int H, int W, int K, int OH, int OW, int relu, hipStream_t stream) {
+  if (!xpad16 || !w16s || !y || N <= 0 || (W & 1) || (K & 3) || bad_dtype(y_dtype) || OH != (H + 6 - 7) / 2 + 1 ||
+      OW != (W + 6 - 7) / 2 + 1 || (int64_t)N * (H + 6) * (W + 8) * 4 >= (1ll << 31))
+    return UTV2_EARG;
+  ConvArgs16 a;
+  a.lt.n = 0;
+  a.x = xpad16; a.w = (const __bf16*)w16s; a.y = y; a.scale = scale; a.bias = bias; a.residual = nullptr;
+  a.N = N; a.H = H + 6; a.W = W + 8; a.C = 32; a.OH = OH; a.OW = OW; a.K = K; a.KH = 7; a.KW = 1; a.stride = 2; a.pad = 0;
+  a.in_dil = 1; a.relu = relu; a.accumulate = 0; a.Kred = 7 * 32; a.M = N * OH * OW; a.xs = 4;
+  const bool small = K <= 64;
+  const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
+  const dim3 g(tiles), b(256);
+  if (small) {
+    if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<64, false, 32, __bf16>), g, b, 0, stream, a);
+    else hipLaunchKernelGGL((conv_igemm_bf16_v2<64, false, 32, float>), g, b, 0, stream, a);
+  } else {
+    if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<128, false, 32, __bf16>), g, b, 0, stream, a);
+    else hipLaunchKernelGGL((conv_igemm_bf16_v2<128, false, 32, float>), g, b, 0, stream, a);
+  }
   return utv2_launch_status();
 }
 

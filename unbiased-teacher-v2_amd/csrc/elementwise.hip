@@ -151,6 +151,25 @@ __global__ __launch_bounds__(256) void downsample2x_sum_nhwc_k(const T* __restri
   }
 }
 
+// dgrad of a stride-2 1x1 conv: the compact gradient [N][TH][TW][C] lands on the even pixels of [N][H][W][C], zeros elsewhere
+template <typename T>
+__global__ __launch_bounds__(256) void zero_interleave2x_nhwc_k(const T* __restrict__ src, T* __restrict__ dst, int N, int H, int W,
+                                                              int TH, int TW, int C4) {
+  const size_t total = (size_t)N * H * W * C4;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    size_t t = i;
+    const int c = (int)(t % C4); t /= C4;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); t /= H;
+    const int n = (int)t;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!((h | w) & 1)) v = ld4(src, ((size_t)(n * TH + (h >> 1)) * TW + (w >> 1)) * C4 + c);
+    st4(dst, i, v);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Image normalisation + CHW -> padded NHWC4 (one_stage_detector.py:88-90 / D2 preprocess_image +
 // ImageList.from_tensors): dst[n,h,w,c] = (src[c,h,w] - mean[c]) / std[c] for h<H,w<W, else 0.
@@ -171,6 +190,28 @@ __global__ __launch_bounds__(256) void preprocess_chw_to_nhwc4(const T* __restri
       v[2] = ((float)src[2 * hw + o] - m2) / s2;
     }
     ((f32x4*)dst)[i] = v;
+  }
+}
+
+// bf16 form for the MFMA stem: the image lands at pixel offset (3, 3) of a [Hp+6][Wp+8][4] bf16 buffer whose border the
+// caller zeroed once (rows pitch Wp+8); the padded canvas beyond the image is written as zeros here.
+template <typename T>
+__global__ __launch_bounds__(256) void preprocess_chw_to_nhwc4_bf16pad(const T* __restrict__ src, __bf16* __restrict__ dst, int H, int W,
+                                                                     int Hp, int Wp, float m0, float m1, float m2, float s0,
+                                                                     float s1, float s2) {
+  const size_t total = (size_t)Hp * Wp;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int h = (int)(i / Wp), w = (int)(i % Wp);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (h < H && w < W) {
+      const size_t o = (size_t)h * W + w, hw = (size_t)H * W;
+      v[0] = ((float)src[o] - m0) / s0;
+      v[1] = ((float)src[hw + o] - m1) / s1;
+      v[2] = ((float)src[2 * hw + o] - m2) / s2;
+    }
+    st4(dst, (size_t)(h + 3) * (Wp + 8) + (w + 3), v);
   }
 }
 
@@ -553,6 +594,20 @@ int utv2_downsample2x_sum_nhwc(const void* g, void* dtop, int N, int TH, int TW,
   return utv2_launch_status();
 }
 
+// dst[n,2i,2j,:] = src[n,i,j,:], zero elsewhere.  TH = (H+1)/2, TW = (W+1)/2.
+int utv2_zero_interleave2x_nhwc(const void* src, void* dst, int N, int H, int W, int C, int dtype, hipStream_t stream) {
+  if (!src || !dst || (C & 3)) return UTV2_EARG;
+  const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+  const dim3 g(grid_for((size_t)N * H * W * C / 4, 256, 1 << 16)), b(256);
+  if (dtype == UTV2_BF16)
+    hipLaunchKernelGGL(zero_interleave2x_nhwc_k<__bf16>, g, b, 0, stream, (const __bf16*)src, (__bf16*)dst, N, H, W, TH, TW, C / 4);
+  else if (dtype == UTV2_F32)
+    hipLaunchKernelGGL(zero_interleave2x_nhwc_k<float>, g, b, 0, stream, (const float*)src, (float*)dst, N, H, W, TH, TW, C / 4);
+  else
+    return UTV2_EARG;
+  return utv2_launch_status();
+}
+
 // src: one image [3][H][W], uint8 (is_u8) or fp32; dst: one padded NHWC4 image [Hp][Wp][4]
 int utv2_preprocess_image(const void* src, int is_u8, float* dst, int H, int W, int Hp, int Wp, const float* mean3_host,
                           const float* std3_host, hipStream_t stream) {
@@ -566,6 +621,22 @@ int utv2_preprocess_image(const void* src, int is_u8, float* dst, int H, int W, 
   else
     hipLaunchKernelGGL((preprocess_chw_to_nhwc4<float>), dim3(g), dim3(256), 0, stream, (const float*)src, dst, H, W, Hp,
                        Wp, m0, m1, m2, s0, s1, s2);
+  return utv2_launch_status();
+}
+
+// dst16: one image slot [Hp+6][Wp+8][4] bf16 of the zero-bordered stem input (see utv2_conv2d_stem_fwd_bf16)
+int utv2_preprocess_image_bf16pad(const void* src, int is_u8, void* dst16, int H, int W, int Hp, int Wp, const float* mean3_host,
+                                  const float* std3_host, hipStream_t stream) {
+  if (!src || !dst16 || H > Hp || W > Wp) return UTV2_EARG;
+  const float m0 = mean3_host[0], m1 = mean3_host[1], m2 = mean3_host[2];
+  const float s0 = std3_host[0], s1 = std3_host[1], s2 = std3_host[2];
+  const int g = grid_for((size_t)Hp * Wp, 256, 1 << 16);
+  if (is_u8)
+    hipLaunchKernelGGL((preprocess_chw_to_nhwc4_bf16pad<unsigned char>), dim3(g), dim3(256), 0, stream, (const unsigned char*)src,
+                       (__bf16*)dst16, H, W, Hp, Wp, m0, m1, m2, s0, s1, s2);
+  else
+    hipLaunchKernelGGL((preprocess_chw_to_nhwc4_bf16pad<float>), dim3(g), dim3(256), 0, stream, (const float*)src, (__bf16*)dst16,
+                       H, W, Hp, Wp, m0, m1, m2, s0, s1, s2);
   return utv2_launch_status();
 }
 

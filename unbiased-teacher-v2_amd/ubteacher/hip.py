@@ -254,21 +254,70 @@ def downsample2x_sum(g, out=None, accumulate=False):
     return out
 
 
-def preprocess_images(images, mean, std, size_divisibility):
-    """list of [3,H,W] uint8/float CUDA tensors -> ([N,Hp,Wp,4] fp32 NHWC4, image_sizes)."""
+def zero_interleave2x(src, H, W):
+    """[N,(H+1)//2,(W+1)//2,C] -> [N,H,W,C] with src on the even pixels and zeros elsewhere"""
+    N, TH, TW, C = src.shape
+    assert TH == (H + 1) // 2 and TW == (W + 1) // 2
+    out = torch.empty((N, H, W, C), dtype=src.dtype, device=src.device)
+    call("utv2_zero_interleave2x_nhwc", _p(src), _p(out), N, H, W, C, _dt(src), _stream())
+    return out
+
+
+_stem_in_cache = {}
+
+
+def preprocess_images(images, mean, std, size_divisibility, bf16_stem=False):
+    """list of [3,H,W] uint8/float CUDA tensors -> ([N,Hp,Wp,4] fp32 NHWC4, image_sizes).
+    bf16_stem: instead the input image of the bf16-MFMA stem, bf16 [N,Hp+6,Wp+8,4] with the image at pixel offset (3,3)
+    inside a zero border (`.canvas` = (Hp, Wp)); the buffer is cached per shape (its border is zeroed once, the interior
+    is rewritten in full by every call)."""
     sizes = [(int(im.shape[1]), int(im.shape[2])) for im in images]
     Hm, Wm = max(s[0] for s in sizes), max(s[1] for s in sizes)
     d = size_divisibility
     if d > 1:
         Hm, Wm = (Hm + d - 1) // d * d, (Wm + d - 1) // d * d
-    out = torch.empty((len(images), Hm, Wm, 4), dtype=torch.float32, device=images[0].device)
+    dev = images[0].device
     m = (ctypes.c_float * 3)(*[float(v) for v in mean])
     s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    if bf16_stem and Wm % 2 == 0:
+        key = (len(images), Hm, Wm, str(dev))
+        out = _stem_in_cache.get(key)
+        if out is None:
+            if len(_stem_in_cache) > 8:
+                _stem_in_cache.clear()
+            out = torch.zeros((len(images), Hm + 6, Wm + 8, 4), dtype=torch.bfloat16, device=dev)
+            _stem_in_cache[key] = out
+        for i, im in enumerate(images):
+            assert im.is_contiguous() and im.dtype in (torch.uint8, torch.float32)
+            call("utv2_preprocess_image_bf16pad", _p(im), int(im.dtype == torch.uint8), c_p(out[i].data_ptr()), sizes[i][0],
+                 sizes[i][1], Hm, Wm, ctypes.cast(m, c_p), ctypes.cast(s, c_p), _stream())
+        out.canvas = (Hm, Wm)
+        return out, sizes
+    out = torch.empty((len(images), Hm, Wm, 4), dtype=torch.float32, device=dev)
     for i, im in enumerate(images):
         assert im.is_contiguous() and im.dtype in (torch.uint8, torch.float32)
         call("utv2_preprocess_image", _p(im), int(im.dtype == torch.uint8), c_p(out[i].data_ptr()), sizes[i][0],
              sizes[i][1], Hm, Wm, ctypes.cast(m, c_p), ctypes.cast(s, c_p), _stream())
     return out, sizes
+
+
+def conv2d_stem_fwd_bf16(xpad16, w16s, scale, bias, relu, out_dtype):
+    """xpad16 from preprocess_images(bf16_stem=True); w16s bf16 [K, 7*32] (stem_weight_image); 7x7 stride 2 pad 3."""
+    N = xpad16.shape[0]
+    H, W = xpad16.canvas
+    K = w16s.shape[0]
+    OH, OW = conv_out_size(H, 7, 2, 3), conv_out_size(W, 7, 2, 3)
+    out = torch.empty((N, OH, OW, K), dtype=out_dtype, device=xpad16.device)
+    call("utv2_conv2d_stem_fwd_bf16", _p(xpad16), _p(w16s), _p(out), _dt(out), _p(scale), _p(bias), N, H, W, K, OH, OW,
+         int(relu), _stream())
+    return out
+
+
+def stem_weight_image(w208):
+    """fp32 [K, 208] (7x7x4 taps, 16-padded rows) -> bf16 [K, 7*32]: per kernel row 7 taps x 4 channels + 4 zeros"""
+    K = w208.shape[0]
+    w = w208[:, :196].reshape(K, 7, 28)
+    return torch.nn.functional.pad(w, (0, 4)).reshape(K, 224).to(torch.bfloat16).contiguous()
 
 
 def frozenbn_fold(w, b, mean, var, scale, shift, eps=1e-5):

@@ -138,7 +138,14 @@ class ResNet50:
             raise NotImplementedError("MODEL.BACKBONE.FREEZE_AT < 1 (trainable stem) is not built: no shipped config uses it")
         # frozen stem + pool run outside autograd; under AMP the bf16 activation pipeline starts at the stem's output
         sc, sh = self.stem.scale_shift()
-        x = hip.conv2d_stem_fwd(x4, self.stem_w.t, sc, sh, 2, 3, 7, 7, True, ops.act_dtype())
+        if x4.dtype == torch.bfloat16:  # AMP: bf16-MFMA stem on the zero-bordered bf16 image
+            v = self.stem_w.store.version
+            if getattr(self, "_w16s_version", None) != v:
+                self._w16s = hip.stem_weight_image(self.stem_w.t)
+                self._w16s_version = v
+            x = hip.conv2d_stem_fwd_bf16(x4, self._w16s, sc, sh, True, torch.bfloat16)
+        else:
+            x = hip.conv2d_stem_fwd(x4, self.stem_w.t, sc, sh, 2, 3, 7, 7, True, ops.act_dtype())
         x = hip.maxpool3x3s2(x)
         for name, blocks, trainable in self.stages:
             if trainable:

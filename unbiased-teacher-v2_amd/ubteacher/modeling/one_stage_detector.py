@@ -4,7 +4,7 @@ ubteacher/modeling/one_stage_detector.py:46-240): same registry names, same forw
 and the same return shapes per branch; numerics on the HIP path."""
 import torch
 
-from .. import hip
+from .. import hip, ops
 from ..d2.registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR_REGISTRY
 from ..d2.structures import Instances
 from .arena_model import ArenaModel
@@ -44,7 +44,8 @@ class PseudoProposalNetwork(ArenaModel):
         images = [x["image"].to(self.device) for x in batched_inputs]
         # (x - pixel_mean) / pixel_std + pad to size_divisibility, fused into the NHWC4 conversion.
         # Host copies of mean/std are used (the device buffers only change by EMA rounding).
-        x4, image_sizes = hip.preprocess_images(images, self._mean_host, self._std_host, self.backbone.size_divisibility)
+        x4, image_sizes = hip.preprocess_images(images, self._mean_host, self._std_host, self.backbone.size_divisibility,
+                                                 bf16_stem=ops.PRECISION[0] == "bf16")
         self.folder.fold()
         return self.backbone(x4), image_sizes
 

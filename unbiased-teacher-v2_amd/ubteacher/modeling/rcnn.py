@@ -565,7 +565,8 @@ class TwoStagePseudoLabGeneralizedRCNN(ArenaModel):
         if (not self.training) and (not val_mode):
             return self.inference(batched_inputs)
         images = [x["image"].to(self.device) for x in batched_inputs]
-        x4, image_sizes = hip.preprocess_images(images, self._mean_host, self._std_host, self.backbone.size_divisibility)
+        x4, image_sizes = hip.preprocess_images(images, self._mean_host, self._std_host, self.backbone.size_divisibility,
+                                                 bf16_stem=ops.PRECISION[0] == "bf16")
         gt = self._gt(batched_inputs) if "instances" in batched_inputs[0] else None
         self.folder.fold()
         features = self.backbone(x4)
@@ -587,7 +588,8 @@ class TwoStagePseudoLabGeneralizedRCNN(ArenaModel):
     @torch.no_grad()
     def inference(self, batched_inputs):
         images = [x["image"].to(self.device) for x in batched_inputs]
-        x4, image_sizes = hip.preprocess_images(images, self._mean_host, self._std_host, self.backbone.size_divisibility)
+        x4, image_sizes = hip.preprocess_images(images, self._mean_host, self._std_host, self.backbone.size_divisibility,
+                                                 bf16_stem=ops.PRECISION[0] == "bf16")
         self.folder.fold()
         features = self.backbone(x4)
         proposals, _ = self.proposal_generator(image_sizes, features, None, compute_loss=False)

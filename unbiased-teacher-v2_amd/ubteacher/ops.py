@@ -228,7 +228,12 @@ class _ConvFn(torch.autograd.Function):
             x4 = x.view(1, x.shape[0], 1, x.shape[1]) if meta is not None else x
             g4 = g.view(1, g.shape[0], 1, g.shape[1]) if meta is not None else g
             if ctx.needs_input_grad[0]:
-                if d16:
+                if d16 and layer.k == 1 and layer.stride == 2 and layer.pad == 0:
+                    # only the even input pixels receive gradient: a plain GEMM on the compact grid + a zero-interleave,
+                    # instead of a 4x larger dilated gather that is 3/4 masked
+                    dxc = hip.conv2d_fwd_bf16(g4, layer.wt16(wsc), out_dtype=x.dtype)
+                    dx = hip.zero_interleave2x(dxc, x4.shape[1], x4.shape[2])
+                elif d16:
                     dx = hip.conv2d_dgrad_bf16(g4, layer.wt16(wsc), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k,
                                                out_dtype=x.dtype)
                 else:
