@@ -123,9 +123,10 @@ int64_t utv2_groupnorm_seg_workspace_floats(int nseg, const int* seg_rows_host, 
 int utv2_groupnorm_relu_seg_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                 float* ws, int nseg, const int* seg_rows_host, int C, int G, float eps, int relu, int dtype,
                                 utv2_stream_t stream);
+/* beta (optional): the ReLU mask is recomputed from x with the forward expression instead of read from y (y may be null) */
 int utv2_groupnorm_relu_seg_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
-                                const float* gamma, void* dx, float* dgamma, float* dbeta, float* ws, int nseg,
-                                const int* seg_rows_host, int C, int G, int relu, int dtype, utv2_stream_t stream);
+                                const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, float* ws,
+                                int nseg, const int* seg_rows_host, int C, int G, int relu, int dtype, utv2_stream_t stream);
 int64_t utv2_groupnorm_workspace_floats(int N, int HW, int C);
 int utv2_groupnorm_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                             float* ws, int N, int HW, int C, int G, float eps, int relu, utv2_stream_t stream);

@@ -218,6 +218,10 @@ def test_elementwise_bf16():
     dx32 = hip.groupnorm_relu_seg_bwd(dy.view(-1, C), y16f, x.view(-1, C), seg, m32, r32, ga, dg32, db32, 32, True)
     dx16 = hip.groupnorm_relu_seg_bwd(dy.view(-1, C).to(BF), y16, x.view(-1, C).to(BF), seg, m32, r32, ga, dg16, db16, 32, True)
     assert torch.equal(dx16, dx32.to(BF)) and torch.equal(dg16, dg32) and torch.equal(db16, db32)
+    # ReLU mask recomputed from x (beta given) == mask read from the stored y
+    dg3 = torch.zeros(C, device="cuda"); db3 = torch.zeros(C, device="cuda")
+    dx3 = hip.groupnorm_relu_seg_bwd(dy.view(-1, C).to(BF), y16, x.view(-1, C).to(BF), seg, m32, r32, ga, dg3, db3, 32, True, beta=be)
+    assert torch.equal(dx3, dx16) and torch.equal(dg3, dg16) and torch.equal(db3, db16)
 
 
 def test_bn_scale_folding():

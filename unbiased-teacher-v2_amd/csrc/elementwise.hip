@@ -339,7 +339,9 @@ __global__ __launch_bounds__(256) void gn_apply_relu(GnSegs sg, const T* __restr
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_partial(GnSegs sg, const T* __restrict__ dy, const T* __restrict__ y,
                                                     const T* __restrict__ x, const float* __restrict__ mean,
-                                                    const float* __restrict__ rstd, float* __restrict__ part, int C, int G, int relu) {
+                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float* __restrict__ part, int C, int G,
+                                                    int relu) {
   __shared__ float red[2][256 * 4];
   int seg, r0, r1;
   gn_locate(sg, blockIdx.x, seg, r0, r1);
@@ -348,11 +350,19 @@ __global__ __launch_bounds__(256) void gn_bwd_partial(GnSegs sg, const T* __rest
   const int g = (c4 * 4) / cpg;
   const float m = mean[seg * G + g], r = rstd[seg * G + g];
   f32x4 A = {0.f, 0.f, 0.f, 0.f}, B = {0.f, 0.f, 0.f, 0.f};
+  // ReLU mask: with beta given it is RECOMPUTED from x with the forward's exact expression (same sign as the stored y)
+  // instead of re-reading y - one tensor read less in each backward pass
+  const bool remask = relu && beta != nullptr;
+  f32x4 ga = {0.f, 0.f, 0.f, 0.f}, be = {0.f, 0.f, 0.f, 0.f};
+  if (remask) { ga = ((const f32x4*)gamma)[c4]; be = ((const f32x4*)beta)[c4]; }
   for (int row = r0 + rl; row < r1; row += RL) {
     const size_t o = (size_t)row * C4 + c4;
     f32x4 gg = ld4(dy, o);
     const f32x4 xx = ld4(x, o);
-    if (relu) {
+    if (remask) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gg[e] = ((xx[e] - m) * r * ga[e] + be[e]) > 0.f ? gg[e] : 0.f;
+    } else if (relu) {
       const f32x4 yy = ld4(y, o);
 #pragma unroll
       for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
@@ -433,7 +443,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_apply(GnSegs sg, const T* __restrict__ dy, const T* __restrict__ y,
                                                   const T* __restrict__ x, const float* __restrict__ mean,
                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                  const float* __restrict__ s12, T* __restrict__ dx, int C, int G, int relu) {
+                                                  const float* __restrict__ beta, const float* __restrict__ s12,
+                                                  T* __restrict__ dx, int C, int G, int relu) {
   int seg, r0, r1;
   gn_locate(sg, blockIdx.x, seg, r0, r1);
   const int C4 = C >> 2, cpg = C / G;
@@ -443,11 +454,17 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(GnSegs sg, const T* __restri
   const float s1 = s12[(seg * G + g) * 2], s2 = s12[(seg * G + g) * 2 + 1];
   const float inv_cnt = 1.0f / ((float)(sg.row0[seg + 1] - sg.row0[seg]) * cpg);
   const f32x4 ga = ((const f32x4*)gamma)[c4];
+  const bool remask = relu && beta != nullptr;
+  f32x4 be = {0.f, 0.f, 0.f, 0.f};
+  if (remask) be = ((const f32x4*)beta)[c4];
   for (int row = r0 + rl; row < r1; row += RL) {
     const size_t i = (size_t)row * C4 + c4;
     f32x4 gg = ld4(dy, i);
     const f32x4 xx = ld4(x, i);
-    if (relu) {
+    if (remask) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gg[e] = ((xx[e] - m) * r * ga[e] + be[e]) > 0.f ? gg[e] : 0.f;
+    } else if (relu) {
       const f32x4 yy = ld4(y, i);
 #pragma unroll
       for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
@@ -493,17 +510,17 @@ static void gn_fwd_launch(const GnSegs& sg, int chunks, int nseg, const void* x,
 
 template <typename T>
 static void gn_bwd_launch(const GnSegs& sg, int chunks, int nseg, const void* dy, const void* y, const void* x, const float* mean,
-                          const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, float* ws, int C, int G,
-                          int relu, hipStream_t stream) {
+                          const float* rstd, const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta,
+                          float* ws, int C, int G, int relu, hipStream_t stream) {
   float* part = ws;
   float* AB = ws + (size_t)chunks * C * 2;
   float* s12 = AB + (size_t)nseg * C * 2;
   hipLaunchKernelGGL(gn_bwd_partial<T>, dim3(chunks), dim3(256), 0, stream, sg, (const T*)dy, (const T*)y, (const T*)x, mean, rstd,
-                     part, C, G, relu);
+                     gamma, beta, part, C, G, relu);
   hipLaunchKernelGGL(gn_bwd_reduce, dim3(nseg), dim3(256), 2 * C * sizeof(float), stream, sg, (const float*)part, gamma, AB, s12, C, G);
   hipLaunchKernelGGL(gn_bwd_param, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)AB, dgamma, dbeta, nseg, C);
   hipLaunchKernelGGL(gn_bwd_apply<T>, dim3(chunks), dim3(256), 0, stream, sg, (const T*)dy, (const T*)y, (const T*)x, mean, rstd,
-                     gamma, (const float*)s12, (T*)dx, C, G, relu);
+                     gamma, beta, (const float*)s12, (T*)dx, C, G, relu);
 }
 
 extern "C" {
@@ -671,15 +688,17 @@ int utv2_groupnorm_relu_seg_fwd(const void* x, const float* gamma, const float* 
   return utv2_launch_status();
 }
 
-// dx written (`dtype`, like dy / y / x); dgamma/dbeta (fp32) accumulated (+=).
+// dx written (`dtype`, like dy / y / x); dgamma/dbeta (fp32) accumulated (+=).  The ReLU mask comes from y, or - when
+// beta is given - is recomputed from x (y may then be null).
 int utv2_groupnorm_relu_seg_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
-                                const float* gamma, void* dx, float* dgamma, float* dbeta, float* ws, int nseg,
-                                const int* seg_rows_host, int C, int G, int relu, int dtype, hipStream_t stream) {
-  if (!dy || !x || !dx || !ws || !gn_check(nseg, C, G) || (dtype != UTV2_F32 && dtype != UTV2_BF16)) return UTV2_EARG;
+                                const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, float* ws,
+                                int nseg, const int* seg_rows_host, int C, int G, int relu, int dtype, hipStream_t stream) {
+  if (!dy || !x || !dx || !ws || !gn_check(nseg, C, G) || (dtype != UTV2_F32 && dtype != UTV2_BF16) || (relu && !y && !beta))
+    return UTV2_EARG;
   GnSegs sg;
   const int chunks = gn_fill(sg, nseg, seg_rows_host);
-  if (dtype == UTV2_BF16) gn_bwd_launch<__bf16>(sg, chunks, nseg, dy, y, x, mean, rstd, gamma, dx, dgamma, dbeta, ws, C, G, relu, stream);
-  else gn_bwd_launch<float>(sg, chunks, nseg, dy, y, x, mean, rstd, gamma, dx, dgamma, dbeta, ws, C, G, relu, stream);
+  if (dtype == UTV2_BF16) gn_bwd_launch<__bf16>(sg, chunks, nseg, dy, y, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, ws, C, G, relu, stream);
+  else gn_bwd_launch<float>(sg, chunks, nseg, dy, y, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, ws, C, G, relu, stream);
   return utv2_launch_status();
 }
 
@@ -705,7 +724,7 @@ int utv2_groupnorm_relu_bwd(const float* dy, const float* y, const float* x, con
   int rows[GN_MAX_SEG];
   if (N > GN_MAX_SEG) return UTV2_EARG;
   for (int i = 0; i < N; ++i) rows[i] = HW;
-  return utv2_groupnorm_relu_seg_bwd(dy, y, x, mean, rstd, gamma, dx, dgamma, dbeta, ws, N, rows, C, G, relu, UTV2_F32, stream);
+  return utv2_groupnorm_relu_seg_bwd(dy, y, x, mean, rstd, gamma, nullptr, dx, dgamma, dbeta, ws, N, rows, C, G, relu, UTV2_F32, stream);
 }
 
 }  // extern "C"

@@ -692,12 +692,12 @@ def groupnorm_relu_seg_fwd(x2d, seg_rows, gamma, beta, G=32, eps=1e-5, relu=True
     return y, mean, rstd
 
 
-def groupnorm_relu_seg_bwd(dy, y, x2d, seg_rows, mean, rstd, gamma, dgamma, dbeta, G=32, relu=True):
+def groupnorm_relu_seg_bwd(dy, y, x2d, seg_rows, mean, rstd, gamma, dgamma, dbeta, G=32, relu=True, beta=None):
     rows, C = x2d.shape
     S = len(seg_rows)
     dx = torch.empty_like(x2d)
     sr = _iarr(seg_rows)
     ws = workspace(load().utv2_groupnorm_seg_workspace_floats(S, ctypes.cast(sr, c_p), C), x2d.device, "gn")
-    call("utv2_groupnorm_relu_seg_bwd", _p(dy), _p(y), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _p(ws), S,
-         ctypes.cast(sr, c_p), C, G, int(relu), _same_dt(dy, y, x2d), _stream())
+    call("utv2_groupnorm_relu_seg_bwd", _p(dy), _p(y), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx), _p(dgamma), _p(dbeta),
+         _p(ws), S, ctypes.cast(sr, c_p), C, G, int(relu), _same_dt(dy, y, x2d), _stream())
     return dx

@@ -325,22 +325,28 @@ class FCOSOutputs:
             fpn_levels=torch.empty((N, MAXC), dtype=torch.int32, device=dev),
             valid=torch.empty((N, MAXC), dtype=torch.uint8, device=dev),
         )
-        # per-level top-k (fcos_outputs.py:1238-1241) as ONE batched selection: the ranking keys of every (level, image)
-        # are rows of a [L*N, max HW*C] matrix padded with -1 (= "no candidate", sorts last), so torch.topk's multi-pass
-        # radix select runs once instead of once per level
+        # per-level top-k (fcos_outputs.py:1238-1241) as batched selections: the ranking keys of the (level, image) pairs of
+        # a group are rows of one [rows, max HW*C] matrix padded with -1 (= "no candidate", sorts last), so torch.topk's
+        # multi-pass radix select runs once per group instead of once per level.  The finest level is 4x larger than the
+        # next one: it forms its own group, the rest share the second (less padding than one group for all).
         L = len(level_hw)
-        width = max(h * w for h, w in level_hw) * self.num_classes
-        keys = torch.full((L * N, width), -1, dtype=torch.int64, device=dev)
-        for l, (h, w) in enumerate(level_hw):
-            r0, r1 = meta.rows[l]
-            hip.fcos_rank_keys(logits_all[r0:r1], box_all[r0:r1], self.reg_max, N, h * w, th, method,
-                               out=keys[l * N:(l + 1) * N], row_stride=width)
-        top_all = torch.topk(keys, max(ks), dim=1, sorted=True).values
+        groups = [[0], list(range(1, L))] if L > 1 else [[0]]
+        tops = {}
+        for grp in groups:
+            width = max(level_hw[l][0] * level_hw[l][1] for l in grp) * self.num_classes
+            keys = torch.full((len(grp) * N, width), -1, dtype=torch.int64, device=dev)
+            for i, l in enumerate(grp):
+                h, w = level_hw[l]
+                r0, r1 = meta.rows[l]
+                hip.fcos_rank_keys(logits_all[r0:r1], box_all[r0:r1], self.reg_max, N, h * w, th, method,
+                                   out=keys[i * N:(i + 1) * N], row_stride=width)
+            top_all = torch.topk(keys, max(ks[l] for l in grp), dim=1, sorted=True).values
+            for i, l in enumerate(grp):
+                tops[l] = top_all[i * N:(i + 1) * N, :ks[l]].contiguous()
         slot0 = 0
         for l, (h, w) in enumerate(level_hw):
             r0, r1 = meta.rows[l]
-            top = top_all[l * N:(l + 1) * N, :ks[l]].contiguous()
-            hip.fcos_decode(top, logits_all[r0:r1], box_all[r0:r1], self.reg_max, N, h * w, w, self.strides[l], l, method, slot0, outs)
+            hip.fcos_decode(tops[l], logits_all[r0:r1], box_all[r0:r1], self.reg_max, N, h * w, w, self.strides[l], l, method, slot0, outs)
             slot0 += ks[l]
         keep, cnt = hip.nms_batched(outs["boxes"], outs["scores"], outs["classes"], outs["valid"], self.nms_thresh,
                                     class_aware=True, post_topk=post, max_out=max_det)

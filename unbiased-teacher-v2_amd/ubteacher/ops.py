@@ -289,10 +289,10 @@ class _GNFn(torch.autograd.Function):
         if meta is None:
             N, H, W, C = x.shape
             dx = hip.groupnorm_relu_seg_bwd(dy.view(-1, C), y.view(-1, C), x.view(-1, C), [H * W] * N, mean, rstd, layer.gamma.t,
-                                            layer.gamma.g, layer.beta.g, layer.groups, layer.relu).view(x.shape)
+                                            layer.gamma.g, layer.beta.g, layer.groups, layer.relu, beta=layer.beta.t).view(x.shape)
         else:
             dx = hip.groupnorm_relu_seg_bwd(dy, y, x, meta.seg_rows, mean, rstd, layer.gamma.t, layer.gamma.g, layer.beta.g,
-                                            layer.groups, layer.relu)
+                                            layer.groups, layer.relu, beta=layer.beta.t)
         return dx, None, None, None
 
 
