@@ -51,44 +51,47 @@ def tune_for_pseudo_labels(trainer, batch, target_std=1.5, bias=-6.0):
 
 
 class ConvTimer:
-    """HIP-event timing (torch events recorded on the stream the kernels are launched on) of every launch of
-    the dominant kernel inside the timed region.  Dominant kernel = the plain-NHWC implicit-GEMM conv with
-    Cout > 64 (forward AND dgrad launches of backbone / FPN / box-head layers):
-        bf16: conv_igemm_bf16<128,false>      f32: conv_igemm_f32<128,0,false>"""
+    """HIP-event timing (torch events recorded on the stream the kernels are launched on) of every launch of the
+    dominant kernel inside the timed region.  Dominant kernel (largest share of GPU time in profiles/): the multi-level
+    3x3 implicit-GEMM conv of the shared FCOS towers - forward AND dgrad launches, 256 -> 256 channels over all five FPN
+    levels of the student batch in one launch:
+        bf16: conv_igemm_bf16_v2<128,true,64,__bf16>      f32: conv_igemm_f32<128,0,true>"""
 
     def __init__(self, dtype):
         self.pairs = []
         self.enabled = False
-        self.entry = "utv2_conv2d_nhwc_fwd_bf16" if dtype == "bf16" else "utv2_conv2d_nhwc_fwd"
-        self.kernel = "conv_igemm_bf16<128,false>" if dtype == "bf16" else "conv_igemm_f32<128,0,false>"
+        self.bf16 = dtype == "bf16"
+        self.entry = "conv2d_ml_fwd_bf16" if self.bf16 else "conv2d_ml_fwd"
+        self.kernel = "conv_igemm_bf16_v2<128,true,64,__bf16>" if self.bf16 else "conv_igemm_f32<128,0,true>"
 
     def install(self):
         from ubteacher import hip
-        orig = hip.call
+        orig = getattr(hip, self.entry)
         timer = self
 
-        def call(name, *args):
-            if not (timer.enabled and name == timer.entry):
-                return orig(name, *args)
-            b16 = name.endswith("bf16")
-            o = 8 if b16 else 6   # the bf16 entry point carries x_dtype / y_dtype
-            N, H, W, C, K, KH, KW, stride, pad, in_dil, OH, OW = args[o:o + 12]
-            if K <= 64 or C % 16 != 0 or (not b16 and args[20] != KH * KW * C):
-                return orig(name, *args)  # another template instance
+        def wrapped(x2d, w, level_hw, N, *args, **kw):
+            P, C = x2d.shape
+            K, Kred = w.shape
+            tiles = -(-P // 128) * -(-K // 128)
+            if timer.bf16:  # the dispatch rule of launch_igemm16 (csrc/conv_bf16.hip) for this template instance
+                out_dt = kw["out"].dtype if kw.get("out") is not None else kw.get("out_dtype", x2d.dtype)
+                mine = (x2d.dtype == torch.bfloat16 and out_dt == torch.bfloat16 and K > 64 and C % 64 == 0 and Kred >= 1024
+                        and not (512 < tiles <= 768))
+            else:
+                mine = K > 64 and C % 16 == 0
+            if not (timer.enabled and mine):
+                return orig(x2d, w, level_hw, N, *args, **kw)
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            orig(name, *args)
+            y = orig(x2d, w, level_hw, N, *args, **kw)
             e1.record()
-            # algorithmic MACs: a strided conv's dgrad (in_dil > 1) does the forward conv's work
-            macs = N * OH * OW * K * KH * KW * C / (in_dil * in_dil if in_dil > 1 else 1)
-            # algorithmic HBM bytes: activations in and out (+ residual / accumulate read) at their element size, weights once
-            xb = (2 if args[1] else 4) if b16 else 4
-            yb = (2 if args[4] else 4) if b16 else 4
-            res, acc = (args[7], args[21]) if b16 else (args[5], args[19])
-            bts = xb * N * H * W * C + (2 if b16 else 4) * K * KH * KW * C + yb * N * OH * OW * K * (1 + bool(res.value if hasattr(res, "value") else res) + bool(acc))
-            timer.pairs.append((e0, e1, 2.0 * macs, float(bts)))
+            eb = 2 if timer.bf16 else 4
+            # algorithmic HBM bytes: activations in and out (+ residual read) and the weights once
+            bts = eb * P * C + eb * K * Kred + eb * P * K * (1 + (kw.get("residual") is not None))
+            timer.pairs.append((e0, e1, 2.0 * P * K * Kred, float(bts)))
+            return y
 
-        hip.call = call
+        setattr(hip, self.entry, wrapped)
 
     def summary(self):
         if not self.pairs:
@@ -221,7 +224,7 @@ def main():
         }
         if conv:
             peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-            out["roofline"] = {"bound": "mfma", "kernel": timer.kernel + " (all fwd+dgrad launches)",
+            out["roofline"] = {"bound": "mfma", "kernel": timer.kernel + " (FCOS tower 3x3 convs, all fwd+dgrad launches)",
                                "achieved": conv["tflops"], "peak": peak, "unit": "TFLOP/s",
                                "frac": conv["tflops"] / peak, "traffic": pmc_traffic(timer.kernel),
                                "algorithmic_bytes": conv["alg_bytes"], "algorithmic_GBps": conv["alg_gbps"],
