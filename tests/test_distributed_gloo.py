@@ -67,6 +67,34 @@ def _worker(rank, world, port, q):
     tr.log_period = 1
     tr._write_metrics({"loss_a": torch.tensor(1.0 + rank), "loss_b": 2.0 * (rank + 1), "data_time": 0.1 * (rank + 1), "other": 7.0})
     out["metrics"] = tr._last_metrics
+    # (5) bucketed, backward-overlapped all-reduce of the gradient arena == one flat all-reduce
+    from ubteacher.utils.grad_sync import GradBuckets
+
+    class H:
+        def __init__(self, offset, numel, g):
+            self.offset, self.numel, self.g = offset, numel, g
+    gflat = torch.randn(5000, generator=torch.Generator().manual_seed(7 + rank))
+    ref = gflat.clone()
+    sizes, hs, off = [700, 300, 1200, 40, 900, 1000, 860], [], 0
+    for n in sizes:
+        hs.append(H(off, n, gflat[off:off + n])); off += n
+    gb = GradBuckets(gflat, hs, bucket_bytes=4 * 1000)
+    out["nbuckets"] = len(gb.bounds)
+    out["cover"] = (gb.bounds[0][0], gb.bounds[-1][1], all(gb.bounds[i][1] == gb.bounds[i + 1][0] for i in range(len(gb.bounds) - 1)))
+    gb.on_forward(hs)          # every layer used once ...
+    gb.on_forward(hs[2:4])     # ... two of them twice (a second student pass)
+    gb.arm()
+    early = []
+    for h in reversed(hs):     # backward reports in reverse order
+        gb.on_backward_done([h])
+        early.append(sum(gb.launched))
+    out["launched_before_finish"] = sum(gb.launched)
+    gb.on_backward_done(hs[2:4])
+    out["launched_after_second_pass"] = sum(gb.launched)
+    gb.finish()
+    dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+    out["bucketed_equals_flat"] = bool(torch.equal(gflat, ref))
+    out["reset"] = (sum(gb.pending), sum(gb.launched), len(gb.works))
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -96,3 +124,8 @@ def test_world_size_2_gloo():
     assert m["loss_a"] == pytest.approx(1.5) and m["loss_b"] == pytest.approx(3.0) and m["other"] == pytest.approx(7.0)
     assert m["total_loss"] == pytest.approx(4.5)                    # sum of averaged keys starting with "loss"
     assert res[1]["metrics"] == {}                                  # only the main process aggregates
+    for r in range(world):
+        assert res[r]["nbuckets"] >= 3 and res[r]["cover"] == (0, 5000, True)
+        assert 0 < res[r]["launched_before_finish"] < res[r]["nbuckets"]     # buckets with a layer still pending wait
+        assert res[r]["launched_after_second_pass"] == res[r]["nbuckets"]
+        assert res[r]["bucketed_equals_flat"] and res[r]["reset"] == (0, 0, 0)

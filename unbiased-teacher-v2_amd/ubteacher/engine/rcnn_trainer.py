@@ -97,7 +97,7 @@ def _make(base):
             metrics_dict["data_time"] = data_time
             self._write_metrics(metrics_dict)
             self.optimizer.zero_grad()
-            losses.backward()
+            self._backward(losses)
             gscale = self._allreduce_grads()
             self.optimizer.step(grad_scale=gscale)
             return losses

@@ -156,6 +156,7 @@ class _TrainerBase:
         ensem = EnsembleTSModel(self.model_teacher, self.model)
         self.ensem_ts_model = ensem
         self.checkpointer = DetectionTSCheckpointer(ensem, cfg.OUTPUT_DIR, optimizer=self.optimizer, scheduler=self.scheduler)
+        self._setup_grad_sync()
 
     # -- reference API ------------------------------------------------------------------------
     def resume_or_load(self, resume=True):
@@ -201,9 +202,29 @@ class _TrainerBase:
         self.model_teacher.store.touch()
 
     # -- gradient exchange: ONE flat all-reduce (DDP mean semantics) -------------------------------------
+    def _setup_grad_sync(self):
+        """data parallel: cut the gradient arena into buckets that are all-reduced while backward is still running"""
+        self._grad_sync = None
+        if self.world_size > 1 and os.environ.get("UTV2_OVERLAP_ALLREDUCE", "1") != "0":
+            from ..utils.grad_sync import GradBuckets
+            st = self.model.store
+            hs = [h for h in st.handles if h.g is not None]
+            self._grad_sync = GradBuckets(st.grad, hs)
+            ops.GRAD_SYNC[0] = self._grad_sync
+
+    def _backward(self, losses):
+        gs = getattr(self, "_grad_sync", None)
+        if gs is not None:
+            gs.arm()
+        losses.backward()
+
     def _allreduce_grads(self):
         if self.world_size > 1:
-            dist.all_reduce(self.model.store.grad, op=dist.ReduceOp.SUM)
+            gs = getattr(self, "_grad_sync", None)
+            if gs is not None:
+                gs.finish()
+            else:
+                dist.all_reduce(self.model.store.grad, op=dist.ReduceOp.SUM)
             return 1.0 / self.world_size
         return 1.0
 
@@ -366,7 +387,7 @@ class UBTeacherTrainer(_TrainerBase):
         self._write_metrics(metrics_dict)
 
         self.optimizer.zero_grad()
-        losses.backward()
+        self._backward(losses)
         gscale = self._allreduce_grads()
         self.optimizer.step(grad_scale=gscale)
         return losses

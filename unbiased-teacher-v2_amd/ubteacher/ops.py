@@ -27,6 +27,15 @@ def act_dtype():
 
 
 _VERSION = [0]  # bumped by the optimizer step: invalidates cached dgrad weight images
+GRAD_SYNC = [None]  # utils.grad_sync.GradBuckets when data parallel: backward-overlapped all-reduce of the gradient arena
+
+
+def _sync_handles(layer, cs=None):
+    from .utils.grad_sync import param_handles
+    hs = param_handles(layer)
+    if cs is not None:
+        hs = hs + (list(cs) if isinstance(cs, (list, tuple)) else [cs])
+    return hs
 
 
 def hook(device):
@@ -168,6 +177,8 @@ class _ConvFn(torch.autograd.Function):
         ctx.cs = cs
         ctx.meta = meta
         ctx.has_res = residual is not None
+        if GRAD_SYNC[0] is not None:
+            GRAD_SYNC[0].on_forward(_sync_handles(layer, cs))
         ctx.save_for_backward(x, y if (layer.relu or cs is not None) else None)
         ctx.xshape = tuple(x.shape)
         return y
@@ -250,6 +261,8 @@ class _ConvFn(torch.autograd.Function):
                 hip.conv2d_wgrad(x4, g4, layer.w.g, layer.stride, layer.pad, layer.k, layer.k, accumulate=True)
         if layer.bias is not None and not bias_done:
             hip.colsum(g.view(-1, layer.cout), layer.bias.g, accumulate=True)
+        if GRAD_SYNC[0] is not None:
+            GRAD_SYNC[0].on_backward_done(_sync_handles(layer, ctx.cs))
         return dx, gres, None, None, None, None, None
 
 
@@ -278,6 +291,8 @@ class _GNFn(torch.autograd.Function):
         y, mean, rstd = layer._fwd(x, meta)
         ctx.layer = layer
         ctx.meta = meta
+        if GRAD_SYNC[0] is not None:
+            GRAD_SYNC[0].on_forward(_sync_handles(layer))
         ctx.save_for_backward(x, y, mean, rstd)
         return y
 
@@ -293,6 +308,8 @@ class _GNFn(torch.autograd.Function):
         else:
             dx = hip.groupnorm_relu_seg_bwd(dy, y, x, meta.seg_rows, mean, rstd, layer.gamma.t, layer.gamma.g, layer.beta.g,
                                             layer.groups, layer.relu, beta=layer.beta.t)
+        if GRAD_SYNC[0] is not None:
+            GRAD_SYNC[0].on_backward_done(_sync_handles(layer))
         return dx, None, None, None
 
 

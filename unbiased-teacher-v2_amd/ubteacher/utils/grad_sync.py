@@ -1,0 +1,86 @@
+"""Bucketed, backward-overlapped all-reduce of the flat gradient arena (data parallel).
+
+The reference wraps the student in DistributedDataParallel (engine/trainer.py:59-63), whose reducer all-reduces gradient
+buckets while backward is still running.  Here all parameter gradients live in ONE flat fp32 arena that the backward
+kernels accumulate into directly, so the same overlap is a matter of bookkeeping: the arena is cut into contiguous
+buckets (at parameter boundaries); every autograd Function that will write gradients registers its parameters at forward
+time and reports them at the end of its backward; when the last writer of a bucket has reported, the bucket's
+all-reduce(SUM) is launched asynchronously (RCCL enqueues it behind the kernels already on the stream and runs it on its
+own stream, overlapping the rest of backward over xGMI).  `finish()` launches whatever is left and waits.
+The 1/world scale stays folded into the SGD kernel.  With world_size 1 nothing is registered or launched.
+"""
+import bisect
+
+import torch
+import torch.distributed as dist
+
+
+class GradBuckets:
+    def __init__(self, grad_flat, handles, bucket_bytes=16 << 20):
+        """grad_flat: the flat gradient arena; handles: objects with .offset / .numel inside it (arena order)."""
+        self.grad = grad_flat
+        n = grad_flat.numel()
+        spans = sorted((int(h.offset), int(h.offset) + int(h.numel)) for h in handles if h.offset < n)
+        cap = max(1, bucket_bytes // 4)
+        starts = [0]
+        for s, _ in spans:  # cut only at parameter starts, once the running bucket is large enough
+            if s - starts[-1] >= cap:
+                starts.append(s)
+        self.starts = starts
+        self.bounds = [(starts[i], starts[i + 1] if i + 1 < len(starts) else n) for i in range(len(starts))]
+        nb = len(self.bounds)
+        self.pending = [0] * nb
+        self.launched = [False] * nb
+        self.works = []
+        self.armed = False
+
+    def bucket_of(self, h):
+        return bisect.bisect_right(self.starts, int(h.offset)) - 1
+
+    # -- called by the autograd Functions ------------------------------------------------------
+    def on_forward(self, handles):
+        for h in handles:
+            if h is not None and h.g is not None:
+                self.pending[self.bucket_of(h)] += 1
+
+    def on_backward_done(self, handles):
+        for h in handles:
+            if h is None or h.g is None:
+                continue
+            b = self.bucket_of(h)
+            self.pending[b] -= 1
+            if self.armed and self.pending[b] == 0 and not self.launched[b]:
+                self._launch(b)
+
+    # -- called by the trainer -----------------------------------------------------------------
+    def arm(self):
+        """right before losses.backward(): every writer of this step has registered by now"""
+        self.armed = True
+
+    def _launch(self, b):
+        s, e = self.bounds[b]
+        self.launched[b] = True
+        if e > s:
+            self.works.append(dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        """after backward: reduce the buckets whose writers never all reported (unused layers), wait for everything"""
+        for b in range(len(self.bounds)):
+            if not self.launched[b]:
+                self._launch(b)
+        for w in self.works:
+            w.wait()
+        self.works = []
+        self.armed = False
+        self.pending = [0] * len(self.bounds)
+        self.launched = [False] * len(self.bounds)
+
+
+def param_handles(layer):
+    """the arena handles a conv / norm layer's backward accumulates into"""
+    hs = []
+    for name in ("w", "bias", "gamma", "beta"):
+        h = getattr(layer, name, None)
+        if h is not None and getattr(h, "g", None) is not None:
+            hs.append(h)
+    return hs
