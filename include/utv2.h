@@ -162,6 +162,11 @@ int utv2_fcos_loc_terms_bwd(const int* labels, const float* box, int box_stride,
  * start at keys + n*key_row_stride (>= HW*C: rows of a wider matrix shared by all FPN levels) */
 int utv2_fcos_rank_keys(const float* logits, const float* box, int box_stride, int reg_max, int N, int HW, int C,
                         float thr, int method, long long* keys, int64_t key_row_stride, utv2_stream_t stream);
+/* :1238-1241 `topk(pre_nms_top_n)` for every (image, level) row at once: exact MSD radix select over ragged rows
+ * (row r = keys[row_off[r] .. row_off[r+1]), row_off device int64[rows+1]); out[rows][k] descending, -1 padded; k <= 2048 */
+int64_t utv2_topk_rows_workspace_bytes(int rows, int k);
+int utv2_topk_rows_i64(const long long* keys, const long long* row_off, int rows, int64_t max_width, int k, long long* out,
+                       void* ws, utv2_stream_t stream);
 /* :1093-1104,:1258-1296 decode of the selected candidates of one level into padded slots */
 int utv2_fcos_decode(const long long* topkeys, int K, const float* logits, const float* box, int box_stride, int reg_max,
                      int N, int HW, int Wl, int C, int stride, int level, int method, int MAXC, int slot0, float* oboxes,

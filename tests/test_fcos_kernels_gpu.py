@@ -257,3 +257,35 @@ def test_pool_upsample_preprocess_fold():
     hip.frozenbn_fold(w.to(DEV), b.to(DEV), m.to(DEV), v.to(DEV), sc, sh)
     rsc = w * (v + 1e-5).rsqrt()
     close(sc, rsc, rtol=1e-6); close(sh, b - m * rsc, rtol=1e-5, atol=1e-6)
+
+
+def test_topk_rows_exact():
+    """utv2_topk_rows_i64 == torch.topk(sorted=True) on ragged rows of unique keys with -1 holes: heavy ties in the high
+    (score) bits, rows shorter than k, an all-empty row."""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(11)
+    widths = [50000, 7000, 300, 64, 5000]
+    k = 1000
+    rows = []
+    for i, wd in enumerate(widths):
+        idx = torch.arange(wd, dtype=torch.int64)
+        if i == 0:      # few distinct scores -> long runs of equal high words, ties broken by the low (index) word
+            hi = torch.randint(0x3D000000, 0x3D000008, (wd,), generator=g, dtype=torch.int64)
+        elif i == 4:    # saturated: every candidate has the same score
+            hi = torch.full((wd,), 0x3F800000, dtype=torch.int64)
+        else:
+            hi = torch.randint(0x3C000000, 0x3F800000, (wd,), generator=g, dtype=torch.int64)
+        key = (hi << 32) | (0xFFFFFFFF - idx)
+        hole = torch.rand(wd, generator=g) < (0.5 if i != 3 else 2.0)   # row 3: all empty
+        key[hole] = -1
+        rows.append(key)
+    flat = torch.cat(rows).to(DEV)
+    offs = torch.tensor([0] + list(torch.tensor(widths).cumsum(0)), dtype=torch.int64, device=DEV)
+    got = hip.topk_rows(flat, offs, len(widths), max(widths), k)
+    for i, r in enumerate(rows):
+        kk = min(k, r.numel())
+        ref = torch.topk(r, kk, sorted=True).values
+        assert torch.equal(got[i, :kk].cpu(), ref), i
+        assert bool((got[i, kk:] == -1).all())
+    got2 = hip.topk_rows(flat, offs, len(widths), max(widths), k)
+    assert torch.equal(got, got2)

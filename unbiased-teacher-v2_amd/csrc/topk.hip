@@ -1,0 +1,212 @@
+// Exact per-row top-k of 64-bit ranking keys (the pre-NMS top-k of FCOS' predict_proposals,
+// fcos_outputs.py:1238-1241: `per_candidate_scores.topk(pre_nms_top_n, sorted=False)` for every (image, FPN level)).
+//
+// keys are the sortable int64 of utv2_fcos_rank_keys: (score bits << 32) | (~flat index) for candidates, -1 otherwise -
+// all candidates of a row are distinct, so "the k largest, descending" is unique.  torch.topk's multi-block radix select
+// costs ~17 tiny launches per call over a DENSE matrix; this is an MSD radix select with 6 digits over ragged rows
+// (every (image, level) row has its own width, nothing is padded):
+//   per digit:  hist   - one read of the keys, atomics only for candidates that still match the decided prefix (sparse)
+//               pick   - per row: scan the 2048-bin histogram from the top, fix the digit, update the remaining count
+//   collect   - keys >= the k-th key go to the output (arbitrary order), then one workgroup per row bitonic-sorts them.
+// Deterministic (the selected SET is exact, the sort fixes the order); no host synchronisation.
+#include "common.h"
+
+#define TK_BINS 2048
+#define TK_MAXK 2048
+
+struct TkState {
+  unsigned long long prefix;  // decided high bits of the k-th largest key
+  int krem;                   // how many keys of the current prefix group are still to be taken
+  int count;                  // collect cursor
+};
+
+__constant__ const int tk_shift[6] = {52, 41, 30, 20, 10, 0};
+__constant__ const int tk_bits[6] = {11, 11, 11, 10, 10, 10};
+
+__global__ __launch_bounds__(256) void topk_init_kernel(TkState* __restrict__ st, unsigned* __restrict__ hist, int* __restrict__ cursors,
+                                                       int ncursors, int rows, int k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows) { st[i].prefix = 0ull; st[i].krem = k; st[i].count = 0; }
+  if (i < ncursors) cursors[i] = 0;
+  for (size_t j = i; j < (size_t)rows * TK_BINS; j += (size_t)gridDim.x * blockDim.x) hist[j] = 0u;
+}
+
+__global__ __launch_bounds__(256) void topk_hist_kernel(const long long* __restrict__ keys, const long long* __restrict__ row_off,
+                                                       const TkState* __restrict__ st, unsigned* __restrict__ hist, int digit) {
+  // block-private LDS histogram, flushed with one global atomic per non-empty bin: the candidates of a row share their
+  // high (exponent) bits, so global atomics straight from the lanes would serialise on a handful of addresses
+  __shared__ unsigned lh[TK_BINS];
+  const int row = blockIdx.y;
+  const long long base = row_off[row], width = row_off[row + 1] - base;
+  if ((long long)blockIdx.x * blockDim.x >= width) return;  // block-uniform
+  const int shift = tk_shift[digit], bits = tk_bits[digit];
+  const unsigned long long prefix = st[row].prefix;
+  const int hi = shift + bits;  // bits >= hi are decided
+  for (int i = threadIdx.x; i < TK_BINS; i += blockDim.x) lh[i] = 0u;
+  __syncthreads();
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < width; i += (long long)gridDim.x * blockDim.x) {
+    const long long key = keys[base + i];
+    if (key < 0) continue;
+    const unsigned long long u = (unsigned long long)key;
+    if (hi < 64 && (u >> hi) != (prefix >> hi)) continue;
+    atomicAdd(&lh[(u >> shift) & ((1u << bits) - 1u)], 1u);
+  }
+  __syncthreads();
+  unsigned* h = hist + (size_t)row * TK_BINS;
+  for (int i = threadIdx.x; i < TK_BINS; i += blockDim.x) {
+    const unsigned v = lh[i];
+    if (v) atomicAdd(&h[i], v);
+  }
+}
+
+// one block per row: choose the digit of the k-th largest key among the keys matching the prefix; clears the histogram
+__global__ __launch_bounds__(256) void topk_pick_kernel(TkState* __restrict__ st, unsigned* __restrict__ hist, int digit) {
+  __shared__ unsigned part[256];
+  __shared__ int chosen;
+  __shared__ unsigned above;
+  const int row = blockIdx.x, t = threadIdx.x;
+  const int shift = tk_shift[digit], nb = 1 << tk_bits[digit];
+  unsigned* h = hist + (size_t)row * TK_BINS;
+  const int krem = st[row].krem;
+  // thread t owns bins [t*8, t*8+8) counted from the TOP (descending digit order)
+  constexpr int PER = TK_BINS / 256;
+  unsigned loc[PER], sum = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int d = nb - 1 - (t * PER + j);
+    loc[j] = d >= 0 ? h[d] : 0u;
+    sum += loc[j];
+  }
+  part[t] = sum;
+  if (t == 0) { chosen = -1; above = 0u; }
+  __syncthreads();
+  // exclusive prefix over threads (256 values: serial in one lane is fine, this kernel is tiny)
+  if (t == 0) {
+    unsigned run = 0;
+    for (int i = 0; i < 256; ++i) { const unsigned v = part[i]; part[i] = run; run += v; }
+  }
+  __syncthreads();
+  unsigned run = part[t];
+  if (krem > 0) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int d = nb - 1 - (t * PER + j);
+      if (d >= 0 && run < (unsigned)krem && run + loc[j] >= (unsigned)krem) { chosen = d; above = run; }
+      run += loc[j];
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    if (chosen >= 0) {
+      st[row].prefix |= (unsigned long long)chosen << shift;
+      st[row].krem = krem - (int)above;
+    } else {
+      st[row].krem = 0;  // fewer than k candidates match: take them all (remaining digits stay 0 => threshold = prefix)
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) h[t * PER + j] = 0u;
+}
+
+// keys >= the k-th key go to one of TK_SPREAD staging lists of the row (same-address atomics serialise at ~50 ns each:
+// one cursor for a whole row would cost k of them back to back)
+#define TK_SPREAD 16
+__global__ __launch_bounds__(256) void topk_collect_kernel(const long long* __restrict__ keys, const long long* __restrict__ row_off,
+                                                          const TkState* __restrict__ st, int* __restrict__ cursors,
+                                                          long long* __restrict__ stage, int k) {
+  const int row = blockIdx.y;
+  const long long base = row_off[row], width = row_off[row + 1] - base;
+  if ((long long)blockIdx.x * blockDim.x >= width) return;
+  const long long thr = (long long)st[row].prefix;  // the k-th largest key (or 0 when the row has fewer than k candidates)
+  const int lane_list = (blockIdx.x + (threadIdx.x >> 6)) % TK_SPREAD;
+  int* cur = cursors + row * TK_SPREAD + lane_list;
+  long long* dst = stage + ((size_t)row * TK_SPREAD + lane_list) * k;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < width; i += (long long)gridDim.x * blockDim.x) {
+    const long long key = keys[base + i];
+    if (key < 0 || key < thr) continue;
+    const int pos = atomicAdd(cur, 1);
+    if (pos < k) dst[pos] = key;
+  }
+}
+
+// one block per row: gather the staging lists, descending bitonic sort (padded with -1 to a power of two) in LDS
+__global__ __launch_bounds__(256) void topk_sort_kernel(const int* __restrict__ cursors, const long long* __restrict__ stage,
+                                                       long long* __restrict__ out, int k, int kpad) {
+  extern __shared__ long long sk[];
+  __shared__ int start[TK_SPREAD + 1];
+  const int row = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int j = 0; j < TK_SPREAD; ++j) {
+      start[j] = run;
+      int c = cursors[row * TK_SPREAD + j];
+      if (c > k) c = k;
+      run += c;
+    }
+    start[TK_SPREAD] = run < kpad ? run : kpad;  // == min(k, #candidates): exactly the selected set
+  }
+  for (int i = threadIdx.x; i < kpad; i += blockDim.x) sk[i] = -1ll;
+  __syncthreads();
+  for (int j = 0; j < TK_SPREAD; ++j) {
+    const int s0 = start[j], n = (j + 1 < TK_SPREAD ? start[j + 1] : start[TK_SPREAD]) - s0;
+    const long long* src = stage + ((size_t)row * TK_SPREAD + j) * k;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+      if (s0 + i < kpad) sk[s0 + i] = src[i];
+  }
+  __syncthreads();
+  for (int size = 2; size <= kpad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = threadIdx.x; i < kpad / 2; i += blockDim.x) {
+        const int lo = 2 * i - (i & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = (lo & size) == 0;
+        const long long a = sk[lo], b = sk[hi];
+        if (desc ? a < b : a > b) { sk[lo] = b; sk[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  long long* o = out + (size_t)row * k;
+  for (int i = threadIdx.x; i < k; i += blockDim.x) o[i] = sk[i];
+}
+
+extern "C" {
+
+static inline size_t tk_align(size_t n) { return (n + 255) & ~(size_t)255; }
+
+int64_t utv2_topk_rows_workspace_bytes(int rows, int k) {
+  return (int64_t)(tk_align((size_t)rows * sizeof(TkState)) + tk_align((size_t)rows * TK_BINS * sizeof(unsigned)) +
+                   tk_align((size_t)rows * TK_SPREAD * sizeof(int)) + (size_t)rows * TK_SPREAD * k * sizeof(long long));
+}
+
+// keys: ragged rows, row r = keys[row_off[r] .. row_off[r+1]) (row_off: device int64[rows+1]); max_width = widest row (host).
+// out[rows][k] = the k largest keys of every row in descending order, -1 padded.  1 <= k <= 2048.
+int utv2_topk_rows_i64(const long long* keys, const long long* row_off, int rows, int64_t max_width, int k, long long* out, void* ws,
+                       hipStream_t stream) {
+  if (!keys || !row_off || !out || !ws || rows <= 0 || k < 1 || k > TK_MAXK || max_width < 1) return UTV2_EARG;
+  char* w = (char*)ws;
+  TkState* st = (TkState*)w;
+  w += tk_align((size_t)rows * sizeof(TkState));
+  unsigned* hist = (unsigned*)w;
+  w += tk_align((size_t)rows * TK_BINS * sizeof(unsigned));
+  int* cursors = (int*)w;
+  w += tk_align((size_t)rows * TK_SPREAD * sizeof(int));
+  long long* stage = (long long*)w;
+  int gx = cdiv(max_width, 256 * 16);
+  if (gx > 256) gx = 256;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(topk_init_kernel, dim3(cdiv(rows * TK_BINS, 256 * 8)), dim3(256), 0, stream, st, hist, cursors, rows * TK_SPREAD,
+                     rows, k);
+  for (int d = 0; d < 6; ++d) {
+    hipLaunchKernelGGL(topk_hist_kernel, dim3(gx, rows), dim3(256), 0, stream, keys, row_off, (const TkState*)st, hist, d);
+    hipLaunchKernelGGL(topk_pick_kernel, dim3(rows), dim3(256), 0, stream, st, hist, d);
+  }
+  hipLaunchKernelGGL(topk_collect_kernel, dim3(gx, rows), dim3(256), 0, stream, keys, row_off, (const TkState*)st, cursors, stage, k);
+  int kpad = 2;
+  while (kpad < k) kpad <<= 1;
+  hipLaunchKernelGGL(topk_sort_kernel, dim3(rows), dim3(256), kpad * sizeof(long long), stream, (const int*)cursors,
+                     (const long long*)stage, out, k, kpad);
+  return utv2_launch_status();
+}
+
+}  // extern "C"

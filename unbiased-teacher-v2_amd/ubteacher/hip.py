@@ -53,7 +53,7 @@ def _parse_header(path):
 
 
 _SIGS = _parse_header(HEADER_PATH)
-_PLAIN = {"utv2_groupnorm_seg_workspace_floats", "utv2_conv2d_wgrad_bf16_splits", "utv2_conv2d_wgrad_bf16_workspace_floats", "utv2_conv2d_bf16_supported", "utv2_conv2d_wgrad_splits", "utv2_conv2d_wgrad_workspace_floats", "utv2_groupnorm_workspace_floats",
+_PLAIN = {"utv2_topk_rows_workspace_bytes", "utv2_groupnorm_seg_workspace_floats", "utv2_conv2d_wgrad_bf16_splits", "utv2_conv2d_wgrad_bf16_workspace_floats", "utv2_conv2d_bf16_supported", "utv2_conv2d_wgrad_splits", "utv2_conv2d_wgrad_workspace_floats", "utv2_groupnorm_workspace_floats",
           "utv2_nms_mpad", "utv2_nms_workspace_bytes"}  # return a value, not a status
 
 
@@ -423,6 +423,15 @@ def fcos_rank_keys(logits, box, reg_max, N, HW, thr, method, out=None, row_strid
     assert out.stride(1) == 1 and out.stride(0) == row_stride and out.shape[0] == N and out.shape[1] >= HW * C
     call("utv2_fcos_rank_keys", _p_any(logits), _p_any(box), BS, reg_max, N, HW, C, float(thr), method, c_p(out.data_ptr()),
          int(row_stride), _stream())
+    return out
+
+
+def topk_rows(keys_flat, row_off, rows, max_width, k):
+    """exact descending top-k of every ragged row of int64 keys (-1 = empty); returns [rows, k] int64, -1 padded"""
+    out = torch.empty((rows, k), dtype=torch.int64, device=keys_flat.device)
+    nbytes = load().utv2_topk_rows_workspace_bytes(rows, int(k))
+    ws = workspace((nbytes + 3) // 4, keys_flat.device, "topk")
+    call("utv2_topk_rows_i64", _p(keys_flat), _p(row_off), rows, int(max_width), int(k), _p(out), _p(ws), _stream())
     return out
 
 

@@ -325,24 +325,48 @@ class FCOSOutputs:
             fpn_levels=torch.empty((N, MAXC), dtype=torch.int32, device=dev),
             valid=torch.empty((N, MAXC), dtype=torch.uint8, device=dev),
         )
-        # per-level top-k (fcos_outputs.py:1238-1241) as batched selections: the ranking keys of the (level, image) pairs of
-        # a group are rows of one [rows, max HW*C] matrix padded with -1 (= "no candidate", sorts last), so torch.topk's
-        # multi-pass radix select runs once per group instead of once per level.  The finest level is 4x larger than the
-        # next one: it forms its own group, the rest share the second (less padding than one group for all).
+        # per-level top-k (fcos_outputs.py:1238-1241): the ranking keys of every (level, image) pair are the ragged rows of ONE
+        # flat buffer and one exact radix select (utv2_topk_rows_i64) serves them all - no padding, no per-level launches
         L = len(level_hw)
-        groups = [[0], list(range(1, L))] if L > 1 else [[0]]
-        tops = {}
-        for grp in groups:
-            width = max(level_hw[l][0] * level_hw[l][1] for l in grp) * self.num_classes
-            keys = torch.full((len(grp) * N, width), -1, dtype=torch.int64, device=dev)
-            for i, l in enumerate(grp):
-                h, w = level_hw[l]
+        C = self.num_classes
+        widths = [h * w * C for h, w in level_hw]
+        kmax = max(ks)
+        if kmax <= 2048:
+            ck = (N, tuple(level_hw), C, str(dev))
+            cached = getattr(self, "_topk_rows", None)
+            if cached is None or cached[0] != ck:
+                offs, o = [], 0
+                for wd in widths:
+                    for n in range(N):
+                        offs.append(o + n * wd)
+                    o += N * wd
+                offs.append(o)
+                cached = (ck, torch.tensor(offs, dtype=torch.int64, device=dev), o)
+                self._topk_rows = cached
+            row_off, total = cached[1], cached[2]
+            keys = torch.empty(total, dtype=torch.int64, device=dev)
+            o = 0
+            for l, (h, w) in enumerate(level_hw):
                 r0, r1 = meta.rows[l]
                 hip.fcos_rank_keys(logits_all[r0:r1], box_all[r0:r1], self.reg_max, N, h * w, th, method,
-                                   out=keys[i * N:(i + 1) * N], row_stride=width)
-            top_all = torch.topk(keys, max(ks[l] for l in grp), dim=1, sorted=True).values
-            for i, l in enumerate(grp):
-                tops[l] = top_all[i * N:(i + 1) * N, :ks[l]].contiguous()
+                                   out=keys[o:o + N * widths[l]].view(N, widths[l]), row_stride=widths[l])
+                o += N * widths[l]
+            top_all = hip.topk_rows(keys, row_off, L * N, max(widths), kmax)
+            tops = {l: top_all[l * N:(l + 1) * N, :ks[l]].contiguous() for l in range(L)}
+        else:  # very large PRE_NMS_TOPK: torch's radix select, one padded matrix per group of levels
+            groups = [[0], list(range(1, L))] if L > 1 else [[0]]
+            tops = {}
+            for grp in groups:
+                width = max(widths[l] for l in grp)
+                keys = torch.full((len(grp) * N, width), -1, dtype=torch.int64, device=dev)
+                for i, l in enumerate(grp):
+                    h, w = level_hw[l]
+                    r0, r1 = meta.rows[l]
+                    hip.fcos_rank_keys(logits_all[r0:r1], box_all[r0:r1], self.reg_max, N, h * w, th, method,
+                                       out=keys[i * N:(i + 1) * N], row_stride=width)
+                top_all = torch.topk(keys, max(ks[l] for l in grp), dim=1, sorted=True).values
+                for i, l in enumerate(grp):
+                    tops[l] = top_all[i * N:(i + 1) * N, :ks[l]].contiguous()
         slot0 = 0
         for l, (h, w) in enumerate(level_hw):
             r0, r1 = meta.rows[l]
