@@ -64,9 +64,12 @@ int utv2_conv2d_ml_wgrad(const float* x, const float* dy, float* dw, float* ws, 
 #define UTV2_F32 0
 #define UTV2_BF16 1
 int utv2_conv2d_bf16_supported(int C, int KH, int KW);
+/* mask (optional, y's type and shape): y = mask > 0 ? conv*scale+bias : 0, before the residual add - the ReLU backward of the
+ * layer that produced the input, fused into the dgrad launch that computes its gradient */
 int utv2_conv2d_nhwc_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
-                              const float* bias, const void* residual, int N, int H, int W, int C, int K, int KH, int KW,
-                              int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate, utv2_stream_t stream);
+                              const float* bias, const void* residual, const void* mask, int N, int H, int W, int C, int K,
+                              int KH, int KW, int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate,
+                              utv2_stream_t stream);
 int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
                             const float* bias, const void* residual, int nlev, const int* H_host, const int* W_host, int N,
                             int C, int K, int KH, int KW, int pad, int relu, int accumulate, utv2_stream_t stream);

@@ -284,3 +284,20 @@ def test_stem_bf16():
     # second call reuses the cached zero-bordered buffer
     x16b, _ = hip.preprocess_images([i.cuda() for i in ims], mean, std, 32, bf16_stem=True)
     assert x16b.data_ptr() == x16.data_ptr()
+
+
+def test_dgrad_epilogue_mask_and_residual():
+    """fused dgrad epilogue (ReLU mask of the producing layer, residual gradient add) == the separate passes, bit for bit"""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(8)
+    N, H, W, C, K, k = 2, 14, 18, 64, 128, 3
+    w2 = (torch.randn(K, k * k * C, generator=g) * 0.05).cuda()
+    wt16 = hip.weight_flip_transpose_bf16(w2, K, k, k, C)
+    dy = torch.randn(N, H, W, K, generator=g).cuda().to(BF)
+    act = torch.relu(torch.randn(N, H, W, C, generator=g)).cuda().to(BF)   # forward activation the dgrad output belongs to
+    res = torch.randn(N, H, W, C, generator=g).cuda().to(BF)
+    plain = hip.conv2d_dgrad_bf16(dy, wt16, (N, H, W, C), 1, 1, k, k, out_dtype=torch.float32)
+    fused_m = hip.conv2d_dgrad_bf16(dy, wt16, (N, H, W, C), 1, 1, k, k, out_dtype=BF, mask=act)
+    assert torch.equal(fused_m, torch.where(act > 0, plain, torch.zeros_like(plain)).to(BF))
+    fused_r = hip.conv2d_dgrad_bf16(dy, wt16, (N, H, W, C), 1, 1, k, k, out_dtype=BF, residual=res)
+    assert torch.equal(fused_r, (plain + res.float()).to(BF))

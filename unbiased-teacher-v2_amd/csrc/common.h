@@ -79,7 +79,9 @@ template <int TN, typename TO = float>
 __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float* lds, int lane, TO* __restrict__ y,
                                               const float* __restrict__ scale, const float* __restrict__ bias,
                                               const TO* __restrict__ residual, int relu, int accumulate, int m_base,
-                                              int co_base, int M, int K) {
+                                              int co_base, int M, int K, const TO* __restrict__ mask = nullptr) {
+  // mask (optional, y's type and shape): y = mask > 0 ? value : 0, applied before the residual add - the ReLU backward of
+  // the layer that produced this conv's input, fused into the dgrad that computes its gradient
   constexpr int VEC = sizeof(TO) == 2 ? 8 : 4, NQ = VEC / 4;  // channels per lane, as NQ quads
   constexpr int COLS = TN * 32, LD = COLS + 4, CV = COLS / VEC, RPI = 64 / CV;  // rows per store instruction
   const int frow = lane & 31, fh = lane >> 5;
@@ -121,6 +123,11 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
         }
         if constexpr (NQ == 2) {
           if (full) {  // 16-byte bf16 accesses
+            if (mask) {
+              const bf16x8_t mk = *(const bf16x8_t*)(mask + off);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q >> 2][q & 3] = (float)mk[q] > 0.f ? v[q >> 2][q & 3] : 0.f;
+            }
             if (residual) {
               const bf16x8_t r = *(const bf16x8_t*)(residual + off);
 #pragma unroll
@@ -146,6 +153,11 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
         for (int h = 0; h < NQ; ++h) {
           if (!cok[h]) continue;
           const size_t o4 = (off >> 2) + h;
+          if (mask) {
+            const f32x4 mk = ld4(mask, o4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[h][q] = mk[q] > 0.f ? v[h][q] : 0.f;
+          }
           if (residual) v[h] += ld4(residual, o4);
           if (relu) {
 #pragma unroll

@@ -595,7 +595,7 @@ def _act_dtype(x, out_dtype):
 
 
 def conv2d_fwd_bf16(x, w16, scale=None, bias=None, residual=None, stride=1, pad=0, relu=False, kh=1, kw=1, out=None,
-                    in_dil=1, out_hw=None, accumulate=False, out_dtype=None):
+                    in_dil=1, out_hw=None, accumulate=False, out_dtype=None, mask=None):
     """x: fp32 or bf16 NHWC; the output (and `residual`) element type is out_dtype (default: x's)."""
     N, H, W, C = x.shape
     K = w16.shape[0]
@@ -606,18 +606,19 @@ def conv2d_fwd_bf16(x, w16, scale=None, bias=None, residual=None, stride=1, pad=
         OH, OW = out_hw
     if out is None:
         out = torch.empty((N, OH, OW, K), dtype=_act_dtype(x, out_dtype), device=x.device)
-    call("utv2_conv2d_nhwc_fwd_bf16", _p(x), _dt(x), _p(w16), _p(out), _same_dt(out, residual), _p(scale), _p(bias), _p(residual),
-         N, H, W, C, K, kh, kw, stride, pad, in_dil, OH, OW, int(relu), int(accumulate), _stream())
+    call("utv2_conv2d_nhwc_fwd_bf16", _p(x), _dt(x), _p(w16), _p(out), _same_dt(out, residual, mask), _p(scale), _p(bias),
+         _p(residual), _p(mask), N, H, W, C, K, kh, kw, stride, pad, in_dil, OH, OW, int(relu), int(accumulate), _stream())
     return out
 
 
-def conv2d_dgrad_bf16(dy, wt16, in_shape, stride, pad, kh, kw, out=None, out_dtype=None):
+def conv2d_dgrad_bf16(dy, wt16, in_shape, stride, pad, kh, kw, out=None, out_dtype=None, mask=None, residual=None):
+    """dx = dgrad(dy); mask (the forward activation dx is the gradient of): dx = mask > 0 ? dx : 0; residual: dx += residual"""
     N, H, W, C = in_shape
     _, OH, OW, K = dy.shape
     if out is None:
         out = torch.empty((N, H, W, C), dtype=_act_dtype(dy, out_dtype), device=dy.device)
-    call("utv2_conv2d_nhwc_fwd_bf16", _p(dy), _dt(dy), _p(wt16), _p(out), _dt(out), c_p(0), c_p(0), c_p(0), N, OH, OW, K, C, kh, kw,
-         1, kh - 1 - pad, stride, H, W, 0, 0, _stream())
+    call("utv2_conv2d_nhwc_fwd_bf16", _p(dy), _dt(dy), _p(wt16), _p(out), _same_dt(out, residual, mask), c_p(0), c_p(0), _p(residual),
+         _p(mask), N, OH, OW, K, C, kh, kw, 1, kh - 1 - pad, stride, H, W, 0, 0, _stream())
     return out
 
 

@@ -99,10 +99,7 @@ class Bottleneck:
             self.shortcut = _conv_bn(store, folder, prefix + ".shortcut", cin, cout, 1, stride, 0, False, trainable)
 
     def __call__(self, x):
-        sc = self.shortcut(x) if self.shortcut is not None else x
-        out = self.conv1(x)
-        out = self.conv2(out)
-        return self.conv3(out, residual=sc)
+        return ops.bottleneck(self, x)
 
 
 class ResNet50:

@@ -266,6 +266,85 @@ class _ConvFn(torch.autograd.Function):
         return dx, gres, None, None, None, None, None
 
 
+# ------------------------------------------------------------------------------------------------
+# AMP ResNet bottleneck as ONE autograd node: the backward chains the three (four) convs explicitly so that the ReLU
+# backward of conv1 / conv2 rides in the epilogue of the dgrad that produces their gradient (mask), the identity / shortcut
+# gradient is added in the epilogue of conv1's dgrad (residual) and a stride-2 block interleaves zeros once for both
+# branches.  Left as elementwise work: one ReLU-mask pass over the block output's gradient.
+def _wgrad16(layer, x4, g4):
+    n_, h_, w_, _ = x4.shape
+    ri = hip.rowinfo_nhwc(n_, h_, w_, g4.shape[1], g4.shape[2], layer.stride, layer.pad, layer.k, layer.k, x4.device)
+    hip.conv2d_wgrad_bf16(x4, g4.reshape(-1, layer.cout), layer.w.g, ri, layer.cin, layer.k, layer.k, accumulate=True,
+                          rowscale=layer.bn.scale)
+
+
+def _dgrad16(layer, g4, in_shape, mask=None, residual=None):
+    return hip.conv2d_dgrad_bf16(g4, layer.wt16(layer.bn.scale), tuple(in_shape), layer.stride, layer.pad, layer.k, layer.k,
+                                 out_dtype=torch.bfloat16, mask=mask, residual=residual)
+
+
+class _BottleneckFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, hk, block):
+        c1, c2, c3, cs = block.conv1, block.conv2, block.conv3, block.shortcut
+        res = cs._forward(x, None, None, None, None) if cs is not None else x
+        y1 = c1._forward(x, None, None, None, None)
+        y2 = c2._forward(y1, None, None, None, None)
+        y3 = c3._forward(y2, res, None, None, None)
+        ctx.block = block
+        ctx.save_for_backward(x, y1, y2, y3)
+        if GRAD_SYNC[0] is not None:
+            for l in (c1, c2, c3, cs):
+                if l is not None:
+                    GRAD_SYNC[0].on_forward(_sync_handles(l))
+        return y3
+
+    @staticmethod
+    def backward(ctx, dy):
+        block = ctx.block
+        c1, c2, c3, cs = block.conv1, block.conv2, block.conv3, block.shortcut
+        x, y1, y2, y3 = ctx.saved_tensors
+        gm = hip.relu_bwd_scale(dy.contiguous(), y3, None)         # gradient at conv3's BN output == at the residual input
+        _wgrad16(c3, y2, gm)
+        g2 = _dgrad16(c3, gm, y2.shape, mask=y2)                    # ... through ReLU(conv2): at conv2's BN output
+        _wgrad16(c2, y1, g2)
+        g1 = _dgrad16(c2, g2, y1.shape, mask=y1)
+        _wgrad16(c1, x, g1)
+        if cs is not None:
+            _wgrad16(cs, x, gm)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if cs is None:
+                dx = _dgrad16(c1, g1, x.shape, residual=gm)         # identity branch added in the epilogue
+            elif c1.stride == 2:
+                c = hip.conv2d_fwd_bf16(gm, cs.wt16(cs.bn.scale), out_dtype=torch.bfloat16)       # compact grids: only the
+                c = hip.conv2d_fwd_bf16(g1, c1.wt16(c1.bn.scale), residual=c, out_dtype=torch.bfloat16)   # even pixels get gradient
+                dx = hip.zero_interleave2x(c, x.shape[1], x.shape[2])
+            else:
+                d = _dgrad16(cs, gm, x.shape)
+                dx = _dgrad16(c1, g1, x.shape, residual=d)
+        if GRAD_SYNC[0] is not None:
+            for l in (c3, c2, c1, cs):
+                if l is not None:
+                    GRAD_SYNC[0].on_backward_done(_sync_handles(l))
+        return dx, None, None
+
+
+def bottleneck(block, x):
+    """one fused autograd node when every conv of the block runs on the bf16 kernels, else the per-conv graph"""
+    convs = [c for c in (block.conv1, block.conv2, block.conv3, block.shortcut) if c is not None]
+    fused = (PRECISION[0] == "bf16" and torch.is_grad_enabled() and x.dtype == torch.bfloat16
+             and all(c.trainable and c.bn is not None and c.bias is None and c.use_bf16() and c.use_bf16_wgrad() and c.use_bf16_dgrad()
+                     for c in convs)
+             and block.conv1.stride in (1, 2) and block.conv1.k == 1 and block.conv3.k == 1)
+    if fused:
+        return _BottleneckFn.apply(x, hook(x.device), block)
+    sc = block.shortcut(x) if block.shortcut is not None else x
+    out = block.conv1(x)
+    out = block.conv2(out)
+    return block.conv3(out, residual=sc)
+
+
 class GroupNormReLU:
     def __init__(self, gamma, beta, groups=32, eps=1e-5, relu=True):
         self.gamma, self.beta, self.groups, self.eps, self.relu = gamma, beta, groups, eps, relu
