@@ -2,8 +2,79 @@
 state is saved as {model: {modelTeacher.*, modelStudent.*}, optimizer, scheduler, iteration}; an
 ImageNet backbone checkpoint (no modelTeacher./modelStudent. prefixes) loads into the student only."""
 import os
+import pickle
+import re
 
 import torch
+
+
+# ---- Caffe2 / Detectron ImageNet backbones (R-50.pkl): Detectron2's c2_model_loading [D2-recall] ------------------------
+def convert_c2_detectron_names(weights):
+    """blob names of a Caffe2 ResNet (`conv1_w`, `res_conv1_bn_s`, `res2_0_branch2a_w`, `res2_0_branch2a_bn_b`, ...) ->
+    Detectron2 ResNet names (`stem.conv1.weight`, `stem.conv1.norm.weight`, `res2.0.conv1.weight`, ...).  Momentum /
+    classifier blobs are dropped.  Returns {new_name: value} in the original order."""
+    out = {}
+    for k, v in weights.items():
+        if k.endswith("_momentum") or k.startswith("fc1000") or k in ("pred_w", "pred_b"):
+            continue
+        n = k.replace("_", ".")
+        n = re.sub(r"\.b$", ".bias", n)
+        n = re.sub(r"\.w$", ".weight", n)
+        n = re.sub(r"bn\.s$", "norm.weight", n)
+        n = re.sub(r"bn\.bias$", "norm.bias", n)
+        n = re.sub(r"bn\.rm$", "norm.running_mean", n)
+        n = re.sub(r"bn\.running\.mean$", "norm.running_mean", n)
+        n = re.sub(r"bn\.riv$", "norm.running_var", n)
+        n = re.sub(r"bn\.running\.var$", "norm.running_var", n)
+        n = re.sub(r"bn\.gamma$", "norm.weight", n)
+        n = re.sub(r"bn\.beta$", "norm.bias", n)
+        n = re.sub(r"gn\.s$", "norm.weight", n)
+        n = re.sub(r"gn\.bias$", "norm.bias", n)
+        n = re.sub(r"^res\.conv1\.norm\.", "conv1.norm.", n)   # the stem's BN blobs are called res_conv1_bn_*
+        n = re.sub(r"^conv1\.", "stem.conv1.", n)
+        n = n.replace(".branch1.", ".shortcut.").replace(".branch2a.", ".conv1.").replace(".branch2b.", ".conv2.")
+        n = n.replace(".branch2c.", ".conv3.")
+        out[n] = v
+    return out
+
+
+def align_and_update_state_dicts(model_sd, ckpt_sd, c2_conversion=True):
+    """Name-matching heuristic of Detectron2: a checkpoint key is given to the model key it is the longest dot-suffix of
+    (`res2.0.conv1.weight` -> `backbone.bottom_up.res2.0.conv1.weight`); shape mismatches are skipped.
+    Returns ({model_key: tensor}, unmatched_checkpoint_keys)."""
+    if c2_conversion:
+        ckpt_sd = convert_c2_detectron_names(ckpt_sd)
+    ckeys = sorted(ckpt_sd.keys())
+    matched, used = {}, set()
+    for mk in model_sd:
+        best = None
+        for ck in ckeys:
+            if mk == ck or mk.endswith("." + ck):
+                if best is None or len(ck) > len(best):
+                    best = ck
+        if best is None:
+            continue
+        v = torch.as_tensor(ckpt_sd[best])
+        if tuple(v.shape) != tuple(model_sd[mk].shape):
+            continue
+        matched[mk] = v
+        used.add(best)
+    return matched, [k for k in ckeys if k not in used]
+
+
+def load_checkpoint_file(path):
+    """.pth -> torch.load; .pkl -> Caffe2 / Detectron pickle: {"model": blobs, "__author__": "Caffe2", "matching_heuristics": True}
+    (DetectionCheckpointer._load_file [D2-recall])."""
+    if path.endswith(".pkl"):
+        with open(path, "rb") as f:
+            data = pickle.load(f, encoding="latin1")
+        if isinstance(data, dict) and "model" in data and "__author__" in data:
+            return data
+        if isinstance(data, dict) and "blobs" in data:
+            data = data["blobs"]
+        data = {k: v for k, v in data.items() if not k.endswith("_momentum")}
+        return {"model": data, "__author__": "Caffe2", "matching_heuristics": True}
+    return torch.load(path, map_location="cpu")
 
 
 class DetectionTSCheckpointer:
@@ -39,9 +110,16 @@ class DetectionTSCheckpointer:
     def load(self, path):
         if not path:
             return {}
-        ck = torch.load(path, map_location="cpu")
+        ck = load_checkpoint_file(path)
         sd = ck.get("model", ck)
-        if any(k.startswith("modelTeacher.") or k.startswith("modelStudent.") for k in sd):
+        if ck.get("__author__", None) == "Caffe2":
+            # pretrained ImageNet backbone: name-matching heuristics, STUDENT only (detection_checkpoint.py:11-37); the
+            # teacher receives it at the burn-in boundary through _update_teacher_model(keep_rate=0)
+            student = self.model.modelStudent
+            matched, unmatched = align_and_update_state_dicts(student.state_dict(), sd, c2_conversion=True)
+            student.load_state_dict(matched, strict=False)
+            self.last_load_report = {"matched": sorted(matched), "unmatched_checkpoint_keys": unmatched}
+        elif any(k.startswith("modelTeacher.") or k.startswith("modelStudent.") for k in sd):
             self.model.load_state_dict(sd, strict=False)
         else:  # backbone-only weights -> student only (detection_checkpoint.py:21-49)
             self.model.modelStudent.load_state_dict(sd, strict=False)

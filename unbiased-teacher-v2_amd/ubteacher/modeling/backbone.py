@@ -45,7 +45,9 @@ class FrozenBN:
         self.w = store.new((c,), "bn_w", lambda t: t.fill_(1.0)).export(prefix + ".weight")
         self.b = store.new((c,), "bn_b", lambda t: t.zero_()).export(prefix + ".bias")
         self.m = store.new((c,), "bn_m", lambda t: t.zero_()).export(prefix + ".running_mean")
-        self.v = store.new((c,), "bn_v", lambda t: t.fill_(1.0)).export(prefix + ".running_var")
+        # D2 FrozenBatchNorm2d initialises running_var to 1 - eps so that an affine-only checkpoint (R-50.pkl has no running
+        # statistics) yields scale == weight exactly [D2-recall]
+        self.v = store.new((c,), "bn_v", lambda t: t.fill_(1.0 - 1e-5)).export(prefix + ".running_var")
         self.c = c
         self.scale = None
         self.shift = None
