@@ -200,12 +200,14 @@ int utv2_match_lowq(const float* boxes, int64_t box_img_stride, int N, int P, co
                     utv2_stream_t stream);
 /* torchvision roi_align(aligned=True, sampling_ratio=0) through D2 ROIPooler level assignment
  * (roi_heads/roi_heads.py:28-45,118).  feats_host / dfeats_host: HOST arrays of device pointers. */
-int utv2_roi_align_fwd(int num_levels, int min_level, const float* const* feats_host, const int* H_host,
+int utv2_roi_align_fwd(int num_levels, int min_level, const void* const* feats_host, const int* H_host,
                        const int* W_host, const float* scales_host, const float* rois, const int* roi_batch,
-                       const unsigned char* roi_valid, int R, int C, int PH, int PW, float* out, utv2_stream_t stream);
+                       const unsigned char* roi_valid, int R, int C, int PH, int PW, void* out, int dtype,
+                       utv2_stream_t stream);
+/* features / out / dy are `dtype` (UTV2_F32 / UTV2_BF16); the gradient buffers dfeats stay fp32 (atomics) */
 int utv2_roi_align_bwd(int num_levels, int min_level, float* const* dfeats_host, const int* H_host, const int* W_host,
                        const float* scales_host, const float* rois, const int* roi_batch, const unsigned char* roi_valid,
-                       int R, int C, int PH, int PW, const float* dy, utv2_stream_t stream);
+                       int R, int C, int PH, int PW, const void* dy, int dtype, utv2_stream_t stream);
 /* roi_heads/fast_rcnn.py:925-936 + FocalLoss :1405-1429 (softmax CE focal, gamma 1.5), summed */
 int utv2_softmax_focal_fwd(const float* logits, const int* target, int R, int C, float gamma, float* loss_sum, float* ws,
                            utv2_stream_t stream);

@@ -176,3 +176,29 @@ def test_roi_sampling_vs_reference_golden(rc):
     assert np.array_equal(out["gt_classes"][0, :n].cpu().numpy(), rc["roi_out_cls"])
     close(out["proposal_boxes"][0, :n], rc["roi_out_prop"]); close(out["gt_boxes"][0, :n], rc["roi_out_gtb"])
     close(out["gt_confid"][0, :n], rc["roi_out_conf"]); close(out["gt_loc_std"][0, :n], rc["roi_out_std"])
+
+
+def test_roi_align_bf16_io():
+    """bf16 features / output / dy: forward == the fp32 kernel on the same (bf16-representable) features rounded once;
+    backward scatters the same fp32 values."""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(21)
+    feats32 = [torch.randn(2, h, w, 256, generator=g).to(torch.bfloat16).float().cuda() for h, w in ((50, 64), (25, 32), (13, 16), (7, 8))]
+    feats16 = [f.to(torch.bfloat16) for f in feats32]
+    R = 64
+    x1 = torch.rand(R, generator=g) * 180; y1 = torch.rand(R, generator=g) * 140
+    wh = torch.exp(torch.rand(R, 2, generator=g) * 4.5 + 1.0)
+    rois = torch.stack((x1, y1, (x1 + wh[:, 0]).clamp(max=255), (y1 + wh[:, 1]).clamp(max=199)), 1).cuda()
+    batch = torch.randint(0, 2, (R,), generator=g).to(torch.int32).cuda()
+    valid = torch.ones(R, dtype=torch.uint8).cuda()
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    y32 = hip.roi_align_fwd(feats32, scales, 2, rois, batch, valid, 7)
+    y16 = hip.roi_align_fwd(feats16, scales, 2, rois, batch, valid, 7)
+    assert y16.dtype == torch.bfloat16 and torch.equal(y16, y32.to(torch.bfloat16))
+    dy = torch.randn(R, 7, 7, 256, generator=g).to(torch.bfloat16).cuda()
+    d32 = [torch.zeros_like(f) for f in feats32]
+    d16 = [torch.zeros_like(f) for f in feats32]
+    hip.roi_align_bwd(d32, scales, 2, rois, batch, valid, dy.float())
+    hip.roi_align_bwd(d16, scales, 2, rois, batch, valid, dy)
+    for a, b in zip(d16, d32):   # fp32 atomics: the summation order differs between launches
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max() + 1e-6)

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void match_lowq_kernel(const float* __restrict
 // roi_heads/roi_heads.py:28-45,118 [D2-recall]).  Features NHWC per level, output [R][PH][PW][C].
 // Level: clamp(floor(canonical_level + log2(sqrt(area)/canonical_size + 1e-8)), min_level, max_level).
 struct RoiLevels {
-  const float* feat[4];
+  const void* feat[4];   // element type = the launch's T
   float* dfeat[4];
   int H[4], W[4];
   float scale[4];
@@ -108,20 +108,63 @@ __device__ __forceinline__ int roi_level(const float4& b, const RoiLevels& L) {
   return lvl - L.min_level;
 }
 
-template <bool BWD>
+// The gh x gw bilinear samples of a bin are SEPARABLE: sample (iy, ix) puts weight wy(iy, Y) * wx(ix, X) on pixel (Y, X) and is
+// skipped iff its y or its x is out of range, so the total weight of a pixel is WY[Y] * WX[X] with WY / WX summed per axis.
+// A bin therefore touches (rows x cols) pixels once - (gh+1)(gw+1) loads / atomics instead of 4*gh*gw.
+#define ROI_MAXT 18  // taps per axis kept in registers; larger bins (never with the D2 level assignment) take the slow path
+struct AxisTaps {
+  int lo, n;            // first pixel index, number of pixels
+  float w[ROI_MAXT];
+};
+
+__device__ __forceinline__ bool axis_taps(float start, float bin, int g, int size, AxisTaps& t) {
+  // accumulate the weights of the g samples of one axis onto pixel indices; returns false if they do not fit
+  int lo = 1 << 30, hi = -1;
+  for (int i = 0; i < g; ++i) {
+    float v = start + ((float)i + 0.5f) * bin / (float)g;
+    if (v < -1.f || v > (float)size) continue;
+    if (v <= 0.f) v = 0.f;
+    int l = (int)v;
+    if (l >= size - 1) l = size - 1;
+    const int h = l >= size - 1 ? l : l + 1;
+    lo = min(lo, l);
+    hi = max(hi, h);
+  }
+  t.lo = lo;
+  t.n = hi >= lo ? hi - lo + 1 : 0;
+  if (t.n > ROI_MAXT) return false;
+#pragma unroll
+  for (int k = 0; k < ROI_MAXT; ++k) t.w[k] = 0.f;
+  for (int i = 0; i < g; ++i) {
+    float v = start + ((float)i + 0.5f) * bin / (float)g;
+    if (v < -1.f || v > (float)size) continue;
+    if (v <= 0.f) v = 0.f;
+    int l = (int)v, h;
+    if (l >= size - 1) { h = l = size - 1; v = (float)l; } else h = l + 1;
+    const float fr = v - (float)l;
+#pragma unroll
+    for (int k = 0; k < ROI_MAXT; ++k) {   // register array: no dynamic indexing
+      if (k == l - lo) t.w[k] += 1.f - fr;
+      if (k == h - lo) t.w[k] += fr;
+    }
+  }
+  return true;
+}
+
+template <bool BWD, typename T>
 __global__ __launch_bounds__(64) void roi_align_kernel(RoiLevels L, const float* __restrict__ rois, const int* __restrict__ roi_batch,
                                                      const unsigned char* __restrict__ roi_valid, int C, int PH, int PW,
-                                                     float* __restrict__ out /* fwd: y, bwd: dy */) {
-  // one block per (roi, bin); 64 lanes x float4 cover up to 256 channels per pass
+                                                     T* __restrict__ out /* fwd: y, bwd: dy */) {
+  // one block per (roi, bin); 64 lanes x 4 channels cover up to 256 channels per pass
   const int bin = blockIdx.x % (PH * PW);
   const int r = blockIdx.x / (PH * PW);
   const int ph = bin / PW, pw = bin % PW;
   const int C4 = C >> 2;
-  float* o = out + ((size_t)r * PH * PW + bin) * C;
+  T* o = out + ((size_t)r * PH * PW + bin) * C;
   const bool ok = roi_valid ? roi_valid[r] != 0 : true;
   if (!ok) {
     if (!BWD)
-      for (int c = threadIdx.x; c < C4; c += 64) ((f32x4*)o)[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = threadIdx.x; c < C4; c += 64) st4(o, c, f32x4{0.f, 0.f, 0.f, 0.f});
     return;
   }
   const float4 b = ((const float4*)rois)[r];
@@ -134,13 +177,57 @@ __global__ __launch_bounds__(64) void roi_align_kernel(RoiLevels L, const float*
   const int gh = (int)ceilf(rh / (float)PH), gw = (int)ceilf(rw / (float)PW);
   const float cnt = fmaxf((float)(gh * gw), 1.f);
   const int n = roi_batch[r];
-  const float* f = L.feat[li] + (size_t)n * H * W * C;
+  const T* f = (const T*)L.feat[li] + (size_t)n * H * W * C;
   float* df = BWD ? L.dfeat[li] + (size_t)n * H * W * C : nullptr;
+  AxisTaps ty, tx;
+  const bool fits = axis_taps(y1 + ph * bh, bh, gh, H, ty) && axis_taps(x1 + pw * bw, bw, gw, W, tx);
+  if (fits) {
+    for (int c = threadIdx.x; c < C4; c += 64) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      if (BWD) {
+        g = ld4((const T*)o, c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] /= cnt;
+      }
+#pragma unroll 1
+      for (int a = 0; a < ty.n; ++a) {
+        float wy = 0.f;
+#pragma unroll
+        for (int k = 0; k < ROI_MAXT; ++k) wy = k == a ? ty.w[k] : wy;
+        if (wy == 0.f) continue;
+#pragma unroll 1
+        for (int bq = 0; bq < tx.n; ++bq) {
+          float wx = 0.f;
+#pragma unroll
+          for (int k = 0; k < ROI_MAXT; ++k) wx = k == bq ? tx.w[k] : wx;
+          const float w = wy * wx;
+          if (w == 0.f) continue;
+          const size_t off = ((size_t)(ty.lo + a) * W + (tx.lo + bq)) * C4 + c;
+          if (!BWD) {
+            const f32x4 v = ld4(f, off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += w * v[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(df + off * 4 + e, g[e] * w);
+          }
+        }
+      }
+      if (!BWD) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] /= cnt;
+        st4(o, c, acc);
+      }
+    }
+    return;
+  }
+  // generic path: every sample, four taps each
   for (int c = threadIdx.x; c < C4; c += 64) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     f32x4 g = {0.f, 0.f, 0.f, 0.f};
     if (BWD) {
-      g = ((const f32x4*)o)[c];
+      g = ld4((const T*)o, c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] /= cnt;
     }
@@ -160,7 +247,7 @@ __global__ __launch_bounds__(64) void roi_align_kernel(RoiLevels L, const float*
         const size_t o1 = ((size_t)yl * W + xl) * C4 + c, o2 = ((size_t)yl * W + xh) * C4 + c;
         const size_t o3 = ((size_t)yh * W + xl) * C4 + c, o4 = ((size_t)yh * W + xh) * C4 + c;
         if (!BWD) {
-          const f32x4 v1 = ((const f32x4*)f)[o1], v2 = ((const f32x4*)f)[o2], v3 = ((const f32x4*)f)[o3], v4 = ((const f32x4*)f)[o4];
+          const f32x4 v1 = ld4(f, o1), v2 = ld4(f, o2), v3 = ld4(f, o3), v4 = ld4(f, o4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[e] += w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
         } else {
@@ -177,7 +264,7 @@ __global__ __launch_bounds__(64) void roi_align_kernel(RoiLevels L, const float*
     if (!BWD) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[e] /= cnt;
-      ((f32x4*)o)[c] = acc;
+      st4(o, c, acc);
     }
   }
 }
@@ -277,7 +364,7 @@ int utv2_match_lowq(const float* boxes, int64_t box_img_stride, int N, int P, co
   return utv2_launch_status();
 }
 
-static int fill_levels(RoiLevels& L, int num_levels, int min_level, const float* const* feats, float* const* dfeats,
+static int fill_levels(RoiLevels& L, int num_levels, int min_level, const void* const* feats, float* const* dfeats,
                        const int* H, const int* W, const float* scales) {
   if (num_levels < 1 || num_levels > 4) return UTV2_EARG;
   L.num_levels = num_levels;
@@ -293,33 +380,41 @@ static int fill_levels(RoiLevels& L, int num_levels, int min_level, const float*
   return UTV2_OK;
 }
 
-// feats_host: host array of num_levels device pointers (NHWC level features, same C).
+// feats_host: host array of num_levels device pointers (NHWC level features of element type `dtype`, same C).
 // rois [R][4] xyxy in image coordinates, roi_batch [R] image index, roi_valid [R] (optional).
-// out [R][PH][PW][C].
-int utv2_roi_align_fwd(int num_levels, int min_level, const float* const* feats_host, const int* H_host, const int* W_host,
+// out [R][PH][PW][C] of element type `dtype`.
+int utv2_roi_align_fwd(int num_levels, int min_level, const void* const* feats_host, const int* H_host, const int* W_host,
                        const float* scales_host, const float* rois, const int* roi_batch, const unsigned char* roi_valid,
-                       int R, int C, int PH, int PW, float* out, hipStream_t stream) {
+                       int R, int C, int PH, int PW, void* out, int dtype, hipStream_t stream) {
   RoiLevels L;
   if (fill_levels(L, num_levels, min_level, feats_host, nullptr, H_host, W_host, scales_host) != UTV2_OK || (C & 3) || !rois ||
-      !roi_batch || !out)
+      !roi_batch || !out || (dtype != UTV2_F32 && dtype != UTV2_BF16))
     return UTV2_EARG;
   if (R == 0) return UTV2_OK;
-  hipLaunchKernelGGL((roi_align_kernel<false>), dim3(R * PH * PW), dim3(64), 0, stream, L, rois, roi_batch, roi_valid, C, PH, PW,
-                     out);
+  if (dtype == UTV2_BF16)
+    hipLaunchKernelGGL((roi_align_kernel<false, __bf16>), dim3(R * PH * PW), dim3(64), 0, stream, L, rois, roi_batch, roi_valid, C, PH,
+                       PW, (__bf16*)out);
+  else
+    hipLaunchKernelGGL((roi_align_kernel<false, float>), dim3(R * PH * PW), dim3(64), 0, stream, L, rois, roi_batch, roi_valid, C, PH,
+                       PW, (float*)out);
   return utv2_launch_status();
 }
 
-// dfeats (+)= scatter of dy through the same sampling pattern (fp32 atomics; caller zero-fills).
+// dfeats (fp32, += : caller zero-fills) receive the scatter of dy (element type `dtype`) through the same sampling pattern.
 int utv2_roi_align_bwd(int num_levels, int min_level, float* const* dfeats_host, const int* H_host, const int* W_host,
                        const float* scales_host, const float* rois, const int* roi_batch, const unsigned char* roi_valid,
-                       int R, int C, int PH, int PW, const float* dy, hipStream_t stream) {
+                       int R, int C, int PH, int PW, const void* dy, int dtype, hipStream_t stream) {
   RoiLevels L;
   if (fill_levels(L, num_levels, min_level, nullptr, dfeats_host, H_host, W_host, scales_host) != UTV2_OK || (C & 3) || !rois ||
-      !roi_batch || !dy)
+      !roi_batch || !dy || (dtype != UTV2_F32 && dtype != UTV2_BF16))
     return UTV2_EARG;
   if (R == 0) return UTV2_OK;
-  hipLaunchKernelGGL((roi_align_kernel<true>), dim3(R * PH * PW), dim3(64), 0, stream, L, rois, roi_batch, roi_valid, C, PH, PW,
-                     (float*)dy);
+  if (dtype == UTV2_BF16)
+    hipLaunchKernelGGL((roi_align_kernel<true, __bf16>), dim3(R * PH * PW), dim3(64), 0, stream, L, rois, roi_batch, roi_valid, C, PH,
+                       PW, (__bf16*)dy);
+  else
+    hipLaunchKernelGGL((roi_align_kernel<true, float>), dim3(R * PH * PW), dim3(64), 0, stream, L, rois, roi_batch, roi_valid, C, PH,
+                       PW, (float*)dy);
   return utv2_launch_status();
 }
 

@@ -516,11 +516,11 @@ def roi_align_fwd(feats, scales, min_level, rois, roi_batch, roi_valid, out_size
     """feats: list of NHWC level tensors; rois [R,4]; roi_batch [R] int32 -> [R, PH, PW, C]."""
     R = rois.shape[0]
     C = feats[0].shape[-1]
-    out = torch.empty((R, out_size, out_size, C), dtype=torch.float32, device=rois.device)
+    out = torch.empty((R, out_size, out_size, C), dtype=feats[0].dtype, device=rois.device)
     fp = _ptr_array(feats)
     H = _iarr([f.shape[1] for f in feats]); W = _iarr([f.shape[2] for f in feats]); S = _farr(scales)
     call("utv2_roi_align_fwd", len(feats), min_level, ctypes.cast(fp, c_p), ctypes.cast(H, c_p), ctypes.cast(W, c_p),
-         ctypes.cast(S, c_p), _p(rois), _p(roi_batch), _p(roi_valid), R, C, out_size, out_size, _p(out), _stream())
+         ctypes.cast(S, c_p), _p(rois), _p(roi_batch), _p(roi_valid), R, C, out_size, out_size, _p(out), _same_dt(*feats), _stream())
     return out
 
 
@@ -529,7 +529,7 @@ def roi_align_bwd(dfeats, scales, min_level, rois, roi_batch, roi_valid, dy):
     fp = _ptr_array(dfeats)
     H = _iarr([f.shape[1] for f in dfeats]); W = _iarr([f.shape[2] for f in dfeats]); S = _farr(scales)
     call("utv2_roi_align_bwd", len(dfeats), min_level, ctypes.cast(fp, c_p), ctypes.cast(H, c_p), ctypes.cast(W, c_p),
-         ctypes.cast(S, c_p), _p(rois), _p(roi_batch), _p(roi_valid), R, C, PH, PW, _p(dy), _stream())
+         ctypes.cast(S, c_p), _p(rois), _p(roi_batch), _p(roi_valid), R, C, PH, PW, _p(dy), _dt(dy), _stream())
 
 
 def softmax_focal_fwd(logits, target, gamma):

@@ -180,8 +180,7 @@ class FPN:
             self.lateral[f] = _conv_bias(store, "backbone.fpn_lateral%d" % stage, self.bottom_up.channels[f], oc, 1, 1, 0, _xavier_init)
             self.output[f] = _conv_bias(store, "backbone.fpn_output%d" % stage, oc, oc, 3, 1, 1, _xavier_init)
         self.top_block_kind = top_block_kind
-        # AMP: the maxpool-topped FPN feeds RoIAlign (fp32 kernel) -> keep its level buffer fp32
-        self.levels_fp32 = top_block_kind == "maxpool"
+        self.levels_fp32 = False  # every consumer of the level buffer (tower / RPN convs, RoIAlign) takes bf16 under AMP
         self.top = []
         if top_block_kind == "p6p7":
             self.top = [_conv_bias(store, "backbone.top_block.p6", oc, oc, 3, 2, 1, _xavier_init),

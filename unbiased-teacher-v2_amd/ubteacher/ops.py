@@ -495,6 +495,7 @@ class _RoIAlignFn(torch.autograd.Function):
         scales, min_level, out_size = cfg
         ctx.cfg = cfg
         ctx.shapes = [tuple(f.shape) for f in feats]
+        ctx.fdtype = feats[0].dtype
         ctx.save_for_backward(rois, roi_batch, roi_valid)
         return hip.roi_align_fwd([f.detach() for f in feats], scales, min_level, rois, roi_batch, roi_valid, out_size)
 
@@ -502,8 +503,10 @@ class _RoIAlignFn(torch.autograd.Function):
     def backward(ctx, dy):
         rois, roi_batch, roi_valid = ctx.saved_tensors
         scales, min_level, out_size = ctx.cfg
-        dfeats = [torch.zeros(s, dtype=torch.float32, device=dy.device) for s in ctx.shapes]
+        dfeats = [torch.zeros(s, dtype=torch.float32, device=dy.device) for s in ctx.shapes]   # fp32: atomics
         hip.roi_align_bwd(dfeats, scales, min_level, rois, roi_batch, roi_valid, dy.contiguous())
+        if ctx.fdtype != torch.float32:
+            dfeats = [d.to(ctx.fdtype) for d in dfeats]
         return (None, None, None, None) + tuple(dfeats)
 
 
