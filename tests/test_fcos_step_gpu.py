@@ -124,3 +124,39 @@ def test_fused_student_pass_equals_two_passes():
         upd = float((s_u[k].double() - sd0[k].double()).abs().max())
         err = float((s_f[k].double() - s_u[k].double()).abs().max())
         assert err <= 1e-6 * float(s_u[k].abs().max()) + 2e-3 * upd + 1e-12, (k, err, upd)
+
+
+def test_ragged_batch_and_empty_gt_step_parity():
+    """Images of different sizes (ImageList zero padding to the batch canvas, different canvases for the labeled and the
+    unlabeled lists => the two student passes stay separate) and a labeled image without ground truth:
+    losses still within 1e-3 of the oracle, identical pseudo-label sets, EMA bit exact."""
+    from ubteacher.engine import UBTeacherTrainer
+    cfg = small_fcos_cfg()
+    torch.manual_seed(0)
+    sizes = [(96, 128), (64, 160), (128, 96), (96, 96)]
+    prod, orac = make_batch(13, 2, 2, H, W, "cuda", sizes=sizes, empty_gt=(1,))
+    tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+    assert tr.model.padded_canvas(prod[0] + prod[1]) != tr.model.padded_canvas(prod[2])
+    sd_s = tune_state_for_pseudo_labels(cpu_state(tr.model), [d["image"] for d in orac[3]])
+    sd_t = dict(sd_s)
+    sd_t["proposal_generator.fcos_head.bbox_pred_std.bias"] = torch.full((4,), -3.0)
+    tr.model.load_state_dict(sd_s)
+    tr.model_teacher.load_state_dict(sd_t)
+    tr.iter = 1
+    tr.optimizer.param_groups[0]["lr"] = 0.01
+    tr.run_step_full_semisup()
+    rec = tr.flush_metrics()
+    rec_o, new_s, new_t, grads, bufs, pseudo = O.fcos_semisup_step(
+        O.FCOSCfg(), sd_s, sd_t, orac, keep_rate=cfg.SEMISUPNET.EMA_KEEP_RATE, lam_u=cfg.SEMISUPNET.UNSUP_LOSS_WEIGHT,
+        lam_r=cfg.SEMISUPNET.UNSUP_REG_LOSS_WEIGHT, lr=0.01, momentum=0.9, wd=1e-4,
+        mean=sd_s["pixel_mean"], pix_std=sd_s["pixel_std"])
+    pc, pr = tr._last_pseudo
+    for i, p in enumerate(pseudo[0]):
+        assert int(pc["valid"][i].sum()) == len(p["boxes"])
+    for i, p in enumerate(pseudo[1]):
+        assert int(pr["valid"][i].sum()) == len(p["boxes"])
+    for k, v in rec_o.items():
+        assert abs(rec[k] - v) <= 1e-3 * max(abs(v), 1e-6), (k, rec[k], v)
+    t_after = cpu_state(tr.model_teacher)
+    for k in new_t:
+        assert torch.equal(t_after[k], new_t[k]), k

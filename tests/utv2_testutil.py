@@ -11,20 +11,26 @@ def small_fcos_cfg(bl=2, bu=2, device="cuda"):
                                   "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", False, "MODEL.DEVICE", device])
 
 
-def make_batch(seed, bl, bu, H, W, device):
-    """(loader-style batch for the product, same batch for the oracle)."""
+def make_batch(seed, bl, bu, H, W, device, sizes=None, empty_gt=()):
+    """(loader-style batch for the product, same batch for the oracle).
+    sizes: optional per-sample (H, W) for the bl labeled then the bu unlabeled samples (ragged batches: both views of a
+    sample share its size); empty_gt: indices of labeled samples that get no ground-truth boxes."""
     from ubteacher.d2.structures import Boxes, Instances
     rng = np.random.default_rng(seed)
     g = torch.Generator().manual_seed(seed)
 
+    cur = [H, W]
+
     def img():
         # smooth-ish random image so the backbone sees structure, uint8 BGR CHW
+        H, W = cur
         base = torch.rand(3, H // 8 + 1, W // 8 + 1, generator=g)
         im = torch.nn.functional.interpolate(base[None], size=(H, W), mode="bilinear", align_corners=False)[0]
         im = (im * 255 + torch.randn(3, H, W, generator=g) * 20).clamp(0, 255)
         return im.to(torch.uint8)
 
     def gt():
+        H, W = cur
         G = int(rng.integers(1, 5))
         cx, cy = rng.uniform(0, W, G), rng.uniform(0, H, G)
         bw, bh = np.exp(rng.uniform(2.5, 4.5, G)), np.exp(rng.uniform(2.5, 4.5, G))
@@ -33,16 +39,24 @@ def make_batch(seed, bl, bu, H, W, device):
 
     prod = ([], [], [], [])
     orac = ([], [], [], [])
-    for _ in range(bl):
+    for i in range(bl):
+        if sizes is not None:
+            cur[:] = sizes[i]
         wk, st = img(), img()
         boxes, classes = gt()
+        if i in empty_gt:
+            boxes, classes = boxes[:0], classes[:0]
         for dst_p, dst_o, im in ((prod[1], orac[1], wk), (prod[0], orac[0], st)):
+            H, W = cur
             inst = Instances((H, W))
             inst.gt_boxes = Boxes(boxes.clone())
             inst.gt_classes = classes.clone()
             dst_p.append({"image": im.to(device), "height": H, "width": W, "instances": inst})
             dst_o.append({"image": im, "gt": dict(boxes=boxes, classes=classes)})
-    for _ in range(bu):
+    for i in range(bu):
+        if sizes is not None:
+            cur[:] = sizes[bl + i]
+        H, W = cur
         wk, st = img(), img()
         prod[3].append({"image": wk.to(device), "height": H, "width": W}); orac[3].append({"image": wk})
         prod[2].append({"image": st.to(device), "height": H, "width": W}); orac[2].append({"image": st})
