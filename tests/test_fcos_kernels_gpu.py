@@ -289,3 +289,29 @@ def test_topk_rows_exact():
         assert bool((got[i, kk:] == -1).all())
     got2 = hip.topk_rows(flat, offs, len(widths), max(widths), k)
     assert torch.equal(got, got2)
+
+
+def test_nms_class_parallel_scan_post_topk():
+    """class-parallel scan (independent per-class chains on 8 waves) with the post-NMS kthvalue rule and its early exit:
+    bit-exact index selection vs the oracle for RPN-like (5 levels, thousands of candidates) and FCOS-like (80 classes) inputs."""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(9)
+    for (N, M, thr, ncls, post) in [(2, 6000, 0.7, 5, 1000), (1, 4000, 0.6, 80, 100), (2, 900, 0.5, 3, 50), (1, 200, 0.6, 80, 100)]:
+        ctr = torch.rand(N, M, 2, generator=g) * 400
+        wh = torch.rand(N, M, 2, generator=g) * 90 + 4
+        boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], dim=2)
+        scores = torch.rand(N, M, generator=g)
+        scores[:, ::5] = torch.round(scores[:, ::5] * 20) / 20   # many exact ties, also around the k-th score
+        cls = torch.randint(0, ncls, (N, M), generator=g, dtype=torch.int32)
+        valid = (torch.rand(N, M, generator=g) > 0.05).to(torch.uint8)
+        keep, cnt = hip.nms_batched(boxes.to(DEV), scores.to(DEV), cls.to(DEV), valid.to(DEV), thr, class_aware=True,
+                                    post_topk=post, max_out=M)
+        keep, cnt = keep.cpu(), cnt.cpu()
+        for n in range(N):
+            vi = valid[n].bool().nonzero().squeeze(1)
+            ref = vi[O.batched_nms(boxes[n][vi], scores[n][vi], cls[n][vi].long(), thr)]
+            if len(ref) > post:
+                kth = scores[n][ref[post - 1]]
+                ref = ref[scores[n][ref] >= kth]
+            assert int(cnt[n]) == len(ref), (N, M, ncls, int(cnt[n]), len(ref))
+            assert torch.equal(keep[n, : len(ref)].long(), ref)

@@ -27,7 +27,7 @@ __device__ __forceinline__ unsigned order_bits_desc(float s) {
 __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                       const int* __restrict__ cls, const unsigned char* __restrict__ valid, int M,
                                                       int Mpad, int class_aware, float* __restrict__ sboxes,
-                                                      int* __restrict__ sidx, int* __restrict__ nvalid) {
+                                                      int* __restrict__ sidx, int* __restrict__ scls, int* __restrict__ nvalid) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // [Mpad]
   __shared__ float redmax[16];
   __shared__ int redcnt[16];
@@ -70,14 +70,16 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
   for (int i = threadIdx.x; i < Mpad; i += blockDim.x) {
     const unsigned long long k = keys[i];
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    int id = -1;
+    int id = -1, c = 0;
     if (k != ~0ull) {
       id = (int)(k & 0xFFFFFFFFull);
-      const float offs = class_aware ? (float)cls[(size_t)n * M + id] * off1 : 0.f;
+      c = class_aware ? cls[(size_t)n * M + id] : 0;
+      const float offs = class_aware ? (float)c * off1 : 0.f;
       o = make_float4(b[id * 4] + offs, b[id * 4 + 1] + offs, b[id * 4 + 2] + offs, b[id * 4 + 3] + offs);
     }
     ((float4*)sboxes)[(size_t)n * Mpad + i] = o;
     sidx[(size_t)n * Mpad + i] = id;
+    scls[(size_t)n * Mpad + i] = c;
   }
 }
 
@@ -191,6 +193,112 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
   for (int i = count + lane; i < max_out; i += 64) keep[(size_t)n * max_out + i] = -1;
 }
 
+// Class-parallel scan: boxes of different classes never suppress each other (the coordinate trick makes their IoU 0), so the
+// greedy chain splits into independent per-class chains.  Wave w of the block owns the candidates with class % NMS_PW == w
+// and walks only those (in global score order): the serial part - one v_readlane round per candidate - shrinks by the number
+// of busy waves (5 FPN levels for the RPN, 80 categories for FCOS / the ROI head).  The per-wave early exit is the same rule
+// as above applied to the wave's own kept list (a sub-list of the global one, so its k-th score bounds the global k-th).
+#define NMS_PW 8
+__global__ __launch_bounds__(64 * NMS_PW) void nms_scan_par_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ sidx,
+                                                                   const int* __restrict__ scls, const int* __restrict__ nvalid,
+                                                                   const float* __restrict__ scores, int M, int Mpad, int post_topk,
+                                                                   int max_out, int* __restrict__ keep, int* __restrict__ keep_count) {
+  __shared__ unsigned long long keepw[64 * NMS_MAXW];  // kept bits per 64-candidate chunk, all classes
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int W = Mpad >> 6;
+  const int nv = nvalid[n];
+  const int nchunks = (nv + 63) >> 6;
+  for (int i = threadIdx.x; i < 64 * NMS_MAXW; i += blockDim.x) keepw[i] = 0ull;
+  __syncthreads();
+  const unsigned long long* mrow = mask + (size_t)n * Mpad * W;
+  const int* cl = scls + (size_t)n * Mpad;
+  const int* si = sidx + (size_t)n * Mpad;
+  const float* sc = scores + (size_t)n * M;
+  unsigned long long removed[NMS_MAXW];
+#pragma unroll
+  for (int s = 0; s < NMS_MAXW; ++s) removed[s] = 0ull;
+  int count = 0;
+  bool have_kth = false;
+  float kth = 0.f;
+  for (int c = 0; c < nchunks; ++c) {
+    const int row = c * 64 + lane;
+    const bool mine = row < nv && (int)((unsigned)cl[row] % NMS_PW) == wv;
+    const unsigned long long cm = __ballot(mine);
+    if (cm == 0ull) continue;  // wave-uniform
+    if (have_kth) {            // post_topk already kept by this wave: stop once its candidates fall below that score
+      const int first = c * 64 + (__ffsll((long long)cm) - 1);
+      if (sc[si[first]] < kth) break;
+    }
+    unsigned long long rw = 0ull;
+#pragma unroll
+    for (int s = 0; s < NMS_MAXW; ++s)
+      if ((c >> 6) == s) rw = bcast64(removed[s], c & 63);
+    const unsigned long long diag = mine ? mrow[(size_t)row * W + c] : 0ull;
+    unsigned long long keepbits = 0ull, todo = cm;
+    while (todo) {
+      const int b = __ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      const unsigned long long db = bcast64(diag, b);
+      if (!((rw >> b) & 1ull)) { keepbits |= 1ull << b; rw |= db; }
+    }
+    if (keepbits) {
+      if (lane == 0) atomicOr(&keepw[c], keepbits);
+      if (post_topk > 0 && !have_kth && count + __popcll(keepbits) >= post_topk) {
+        // the post_topk-th kept candidate of this wave sits in this chunk: its score bounds the global k-th score
+        int need = post_topk - count;
+        unsigned long long kb = keepbits;
+        int b = 0;
+        while (need > 0) { b = __ffsll((long long)kb) - 1; kb &= kb - 1ull; --need; }
+        kth = sc[si[c * 64 + b]];
+        have_kth = true;
+      }
+      count += __popcll(keepbits);
+      unsigned long long kb = keepbits;
+      while (kb) {
+        const int b = __ffsll((long long)kb) - 1;
+        kb &= kb - 1ull;
+        const unsigned long long* r = mrow + (size_t)(c * 64 + b) * W;
+#pragma unroll
+        for (int s = 0; s < NMS_MAXW; ++s) {
+          const int w = s * 64 + lane;
+          if (w < nchunks && w > c) removed[s] |= r[w];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // wave 0: emit the kept slots of all classes in global (descending score) order
+  int total = 0;
+  if (wv == 0) {
+    for (int c = 0; c < nchunks; ++c) {
+      const unsigned long long kb = keepw[c];
+      if (kb == 0ull) continue;
+      const int row = c * 64 + lane;
+      if ((kb >> lane) & 1ull) {
+        const int pos = total + __popcll(kb & ((1ull << lane) - 1ull));
+        if (pos < max_out) keep[(size_t)n * max_out + pos] = si[row];
+      }
+      total += __popcll(kb);
+    }
+  }
+  __syncthreads();  // orders the keep[] stores before the reads below
+  if (wv != 0) return;
+  int cnt = total > max_out ? max_out : total;
+  // kthvalue rule: keep all with score >= score of the post_topk-th kept
+  if (post_topk > 0 && cnt > post_topk) {
+    const float thr = sc[keep[(size_t)n * max_out + post_topk - 1]];
+    int c2 = 0;
+    for (int base = 0; base < cnt; base += 64) {
+      const int i = base + lane;
+      const bool ok = i < cnt && sc[keep[(size_t)n * max_out + i]] >= thr;
+      c2 += __popcll(__ballot(ok));
+    }
+    cnt = c2;
+  }
+  if (lane == 0) keep_count[n] = cnt;
+  for (int i = cnt + lane; i < max_out; i += 64) keep[(size_t)n * max_out + i] = -1;
+}
+
 // pairwise IoU  (D2 pairwise_iou [D2-recall]): iou = inter > 0 ? inter / (a1 + a2 - inter) : 0
 __global__ __launch_bounds__(256) void box_iou_kernel(const float* __restrict__ a, const float* __restrict__ b, int A, int B,
                                                     float* __restrict__ out) {
@@ -223,10 +331,10 @@ extern "C" {
 
 int utv2_nms_mpad(int M) { return next_pow2(M); }
 
-// workspace bytes: sorted boxes + sorted idx + nvalid + mask
+// workspace bytes: sorted boxes + sorted idx + sorted class + nvalid + mask
 int64_t utv2_nms_workspace_bytes(int N, int M) {
   const int64_t Mpad = next_pow2(M);
-  return N * (Mpad * 16 + Mpad * 4 + 64 + Mpad * (Mpad / 64) * 8);
+  return N * (Mpad * 16 + Mpad * 4 + Mpad * 4 + 64 + Mpad * (Mpad / 64) * 8);
 }
 
 // boxes [N][M][4] xyxy, scores [N][M], cls [N][M] (int32), valid [N][M] (u8)
@@ -240,17 +348,22 @@ int utv2_nms_batched(const float* boxes, const float* scores, const int* cls, co
   char* p = (char*)ws;
   float* sboxes = (float*)p; p += (size_t)N * Mpad * 16;
   int* sidx = (int*)p; p += (size_t)N * Mpad * 4;
+  int* scls = (int*)p; p += (size_t)N * Mpad * 4;
   int* nvalid = (int*)p; p += 64 * (size_t)N;
   unsigned long long* mask = (unsigned long long*)p;
   const size_t lds = (size_t)Mpad * 8;
   (void)hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(nms_sort_kernel, dim3(N), dim3(1024), lds, stream, boxes, scores, cls, valid, M, Mpad, class_aware, sboxes,
-                     sidx, nvalid);
+                     sidx, scls, nvalid);
   const int nb = Mpad / 64;
   hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb, N), dim3(64), 0, stream, (const float*)sboxes, (const int*)nvalid, Mpad,
                      iou_thr, mask);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(64), 0, stream, (const unsigned long long*)mask, (const int*)sidx,
-                     (const int*)nvalid, scores, M, Mpad, post_topk, max_out, keep, keep_count);
+  if (class_aware)  // independent per-class chains: NMS_PW waves per image
+    hipLaunchKernelGGL(nms_scan_par_kernel, dim3(N), dim3(64 * NMS_PW), 0, stream, (const unsigned long long*)mask, (const int*)sidx,
+                       (const int*)scls, (const int*)nvalid, scores, M, Mpad, post_topk, max_out, keep, keep_count);
+  else
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(64), 0, stream, (const unsigned long long*)mask, (const int*)sidx,
+                       (const int*)nvalid, scores, M, Mpad, post_topk, max_out, keep, keep_count);
   return utv2_launch_status();
 }
 
