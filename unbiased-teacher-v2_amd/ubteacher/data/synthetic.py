@@ -86,3 +86,26 @@ class SyntheticTwoCropLoader:
         self._i += 1
         # fresh dicts: the trainer deletes / adds keys in place (trainer.py:161-175)
         return tuple([dict(d) for d in part] for part in b)
+
+
+class SyntheticTestLoader:
+    """Fixed-length test loader (batch size 1 per iteration, like D2's build_detection_test_loader): dicts with `image`
+    (already at the network input size), the ORIGINAL `height` / `width` the detections are rescaled to, `image_id` and
+    the ground truth `instances` in original-image coordinates."""
+
+    def __init__(self, cfg, num_images=8, height=800, width=1333, orig_scale=1.25, seed=123, device=None):
+        dev = torch.device(device if device is not None else cfg.MODEL.DEVICE)
+        rng = np.random.default_rng(seed)
+        nc = cfg.MODEL.FCOS.NUM_CLASSES if "FCOS" in cfg.MODEL else 80
+        self.items = []
+        for i in range(num_images):
+            oh, ow = int(round(height * orig_scale)), int(round(width * orig_scale))
+            gt = make_gt(rng, oh, ow, nc)
+            self.items.append([{"image": make_image(rng, height, width).to(dev), "height": oh, "width": ow, "image_id": i,
+                                "instances": gt}])
+
+    def __len__(self):
+        return len(self.items)
+
+    def __iter__(self):
+        return iter([[dict(d) for d in b] for b in self.items])

@@ -104,6 +104,6 @@ def _make(base):
 
         @classmethod
         def test(cls, cfg, model, evaluators=None):
-            raise NotImplementedError("COCO evaluation is a SURVEY 8(f) 'next' row (rank 3)")
+            raise NotImplementedError("the evaluation loop (SURVEY 8f rank 3) is built for the FCOS trainer only so far")
 
     return UBRCNNTeacherTrainer
