@@ -59,3 +59,38 @@ def test_library_exports_every_declared_symbol():
     assert len(hip.symbols()) >= 30
     for name in hip.symbols():
         assert hasattr(lib, name), name
+
+
+def test_lr_schedulers():
+    """reference solver/build.py:9-45 + lr_scheduler.py:9-57: the three scheduler names, warmup, stage factors."""
+    import math
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "unbiased-teacher-v2_amd"))
+    import pytest
+    from ubteacher.engine.trainer import build_lr_scheduler
+    from ubteacher.presets import get_config
+
+    class Opt:
+        def __init__(self):
+            self.param_groups = [{"lr": 0.0}]
+    base = ["SOLVER.BASE_LR", 0.01, "SOLVER.WARMUP_ITERS", 100, "SOLVER.WARMUP_FACTOR", 0.001, "SOLVER.MAX_ITER", 1000]
+    cfg = get_config("fcos", 1, base + ["SOLVER.LR_SCHEDULER_NAME", "WarmupTwoStageMultiStepLR", "SOLVER.STEPS", (300, 600),
+                                        "SOLVER.FACTOR_LIST", (1, 0.5, 0.05)])
+    o = Opt()
+    sch = build_lr_scheduler(cfg, o)
+    assert o.param_groups[0]["lr"] == pytest.approx(0.01 * 0.001)                 # it = 0: warmup factor
+    assert sch.lr_at(50) == pytest.approx(0.01 * (0.001 * 0.5 + 0.5))             # linear warmup
+    assert sch.lr_at(299) == pytest.approx(0.01) and sch.lr_at(300) == pytest.approx(0.005) and sch.lr_at(999) == pytest.approx(0.0005)
+    for _ in range(300):
+        sch.step()
+    assert o.param_groups[0]["lr"] == pytest.approx(0.005)
+    with pytest.raises(ValueError):
+        build_lr_scheduler(get_config("fcos", 1, base + ["SOLVER.LR_SCHEDULER_NAME", "WarmupTwoStageMultiStepLR", "SOLVER.STEPS", (300, 600),
+                                                         "SOLVER.FACTOR_LIST", (1, 0.5)]), Opt())
+    cos = build_lr_scheduler(get_config("fcos", 1, base + ["SOLVER.LR_SCHEDULER_NAME", "WarmupCosineLR"]), Opt())
+    assert cos.lr_at(500) == pytest.approx(0.01 * 0.5 * (1 + math.cos(math.pi * 0.5)))
+    ms = build_lr_scheduler(get_config("fcos", 1, base + ["SOLVER.STEPS", (300,), "SOLVER.GAMMA", 0.1]), Opt())
+    assert ms.lr_at(400) == pytest.approx(0.001)
+    with pytest.raises(ValueError):
+        build_lr_scheduler(get_config("fcos", 1, base + ["SOLVER.LR_SCHEDULER_NAME", "Nope"]), Opt())

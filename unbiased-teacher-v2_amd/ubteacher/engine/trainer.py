@@ -82,16 +82,20 @@ class WarmupMultiStepLR:
         self.last_iter = 0
         self._apply()
 
+    def _warmup(self, it):
+        """D2 _get_warmup_factor_at_iter [D2-recall]"""
+        if it >= self.warmup_iters:
+            return 1.0
+        if self.method == "constant":
+            return self.warmup_factor
+        if self.method == "linear":
+            a = it / self.warmup_iters
+            return self.warmup_factor * (1 - a) + a
+        raise ValueError("Unknown warmup method: {}".format(self.method))
+
     def lr_at(self, it):
         k = sum(1 for m in self.steps if m <= it)
-        lr = self.base * (self.gamma ** k)
-        if it < self.warmup_iters:
-            if self.method == "linear":
-                a = it / self.warmup_iters
-                lr *= self.warmup_factor * (1 - a) + a
-            elif self.method == "constant":
-                lr *= self.warmup_factor
-        return lr
+        return self.base * (self.gamma ** k) * self._warmup(it)
 
     def _apply(self):
         self.opt.param_groups[0]["lr"] = self.lr_at(self.last_iter)
@@ -108,10 +112,46 @@ class WarmupMultiStepLR:
         self._apply()
 
 
+class WarmupTwoStageMultiStepLR(WarmupMultiStepLR):
+    """reference solver/lr_scheduler.py:9-57: lr = base * warmup(it) * FACTOR_LIST[#milestones <= it] (an explicit factor per
+    stage instead of gamma^k; len(FACTOR_LIST) == len(STEPS) + 1, milestones increasing)."""
+
+    def __init__(self, cfg, optimizer):
+        s = cfg.SOLVER
+        self.milestones = list(s.STEPS)
+        self.factors = list(s.FACTOR_LIST)
+        if self.milestones != sorted(self.milestones):
+            raise ValueError("Milestones should be a list of increasing integers. Got {}".format(self.milestones))
+        if len(self.milestones) + 1 != len(self.factors):
+            raise ValueError("Length of milestones should match length of factor_list.")
+        super().__init__(cfg, optimizer)
+
+    def lr_at(self, it):
+        k = sum(1 for m in self.milestones if m <= it)
+        return self.base * self.factors[k] * self._warmup(it)
+
+
+class WarmupCosineLR(WarmupMultiStepLR):
+    """D2 WarmupCosineLR [D2-recall]: lr = base * warmup(it) * 0.5 * (1 + cos(pi * it / MAX_ITER))"""
+
+    def __init__(self, cfg, optimizer):
+        self.max_iter = cfg.SOLVER.MAX_ITER
+        super().__init__(cfg, optimizer)
+
+    def lr_at(self, it):
+        import math
+        return self.base * self._warmup(it) * 0.5 * (1.0 + math.cos(math.pi * it / self.max_iter))
+
+
 def build_lr_scheduler(cfg, optimizer):
+    """reference solver/build.py:9-45"""
     name = cfg.SOLVER.LR_SCHEDULER_NAME
     if name == "WarmupMultiStepLR":
         return WarmupMultiStepLR(cfg, optimizer)
+    if name == "WarmupCosineLR":
+        return WarmupCosineLR(cfg, optimizer)
+    if name == "WarmupTwoStageMultiStepLR":
+        return WarmupTwoStageMultiStepLR(cfg, optimizer)
     raise ValueError("Unknown LR scheduler: {}".format(name))
 
 
