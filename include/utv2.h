@@ -138,14 +138,15 @@ int utv2_groupnorm_relu_bwd(const float* dy, const float* y, const float* x, con
                             int G, int relu, utv2_stream_t stream);
 
 /* ---- FCOS targets / losses / decode: modeling/fcos/fcos_outputs.py --------------------------- */
-/* :649-698,:772-906 (CENTER_SAMPLE False).  H,W,strides,soi are HOST arrays.  img_active (optional, device uint8[N]):
+/* :649-698,:772-906; center_radius > 0 = CENTER_SAMPLE with POS_RADIUS (get_sample_region :700-770), 0 = plain in-box test.
+ * H,W,strides,soi are HOST arrays.  img_active (optional, device uint8[N]):
  * images flagged 0 get label -1 everywhere (ignored by the loss kernels) - the two student passes of one iteration
  * (trainer.py:396-411) run as one batch and each loss branch sees only its own images. */
 int utv2_fcos_targets(int num_levels, const int* H_host, const int* W_host, const int* strides_host,
                       const float* soi_host, int N, int MAXG, const float* gt_boxes, const int* gt_classes,
                       const unsigned char* gt_valid, const float* gt_std, int num_classes, int drop_empty,
-                      const unsigned char* img_active, int* labels, float* reg_targets, float* bvars, int* gt_inds,
-                      utv2_stream_t stream);
+                      float center_radius, const unsigned char* img_active, int* labels, float* reg_targets, float* bvars,
+                      int* gt_inds, utv2_stream_t stream);
 /* fvcore sigmoid_focal_loss_jit at :329-338,:619-628 with on-the-fly one-hot.  ws >= 1024 floats */
 int utv2_sigmoid_focal_fwd(const float* logits, const int* labels, int64_t P, int C, float alpha, float gamma,
                            float* loss_sum, float* ws, utv2_stream_t stream);

@@ -282,6 +282,7 @@ class FCOSCfg:
         self.pre_nms_thresh, self.pre_nms_topk, self.post_nms_topk = 0.05, 1000, 100
         self.nms_thresh = 0.6
         self.unify_ctrcls = False
+        self.center_sample, self.radius = False, 1.5  # MODEL.FCOS.CENTER_SAMPLE / POS_RADIUS (config.py defaults)
         self.__dict__.update(kw)
         soi, prev = [], -1
         for s in self.soi_edges:
@@ -291,8 +292,35 @@ class FCOSCfg:
         self.soi = soi
 
 
+def center_sample_region(cfg, boxes, num_loc, xs, ys):
+    """fcos_outputs.py:700-770 get_sample_region (no bitmasks): a location is positive for a box only inside the square of
+    half-width radius*stride around the box centre, clipped to the box.  Quirk kept: an all-False mask when the FIRST box's
+    centre x is 0 (`center_x[..., 0].sum() == 0`)."""
+    cx = boxes[:, [0, 2]].sum(dim=-1) * 0.5
+    cy = boxes[:, [1, 3]].sum(dim=-1) * 0.5
+    K, G = len(xs), boxes.shape[0]
+    if cx.numel() == 0 or float(cx[0]) * K == 0:
+        return torch.zeros((K, G), dtype=torch.bool)
+    b = boxes[None].expand(K, G, 4)
+    cxe, cye = cx[None].expand(K, G), cy[None].expand(K, G)
+    cg = torch.zeros((K, G, 4), dtype=boxes.dtype)
+    beg = 0
+    for level, n in enumerate(num_loc):
+        end = beg + n
+        st = cfg.strides[level] * cfg.radius
+        xmin, ymin, xmax, ymax = cxe[beg:end] - st, cye[beg:end] - st, cxe[beg:end] + st, cye[beg:end] + st
+        cg[beg:end, :, 0] = torch.where(xmin > b[beg:end, :, 0], xmin, b[beg:end, :, 0])
+        cg[beg:end, :, 1] = torch.where(ymin > b[beg:end, :, 1], ymin, b[beg:end, :, 1])
+        cg[beg:end, :, 2] = torch.where(xmax > b[beg:end, :, 2], b[beg:end, :, 2], xmax)
+        cg[beg:end, :, 3] = torch.where(ymax > b[beg:end, :, 3], b[beg:end, :, 3], ymax)
+        beg = end
+    left, right = xs[:, None] - cg[..., 0], cg[..., 2] - xs[:, None]
+    top, bottom = ys[:, None] - cg[..., 1], cg[..., 3] - ys[:, None]
+    return torch.stack((left, top, right, bottom), -1).min(-1)[0] > 0
+
+
 def fcos_targets(cfg, locations, gts):
-    """fcos_outputs.py:649-698 + 772-906 (CENTER_SAMPLE False, ignore_near False).
+    """fcos_outputs.py:649-698 + 772-906 (ignore_near False; CENTER_SAMPLE per cfg.center_sample).
     gts: list of dict(boxes [G,4], classes [G] long, reg_pred_std [G,4] optional).
     Returns level-first dict of lists (labels, reg_targets (stride-normalised), boundary_vars, target_inds,
     keep_locations)."""
@@ -319,7 +347,10 @@ def fcos_targets(cfg, locations, gts):
         r = bboxes[:, 2][None] - xs[:, None]
         b = bboxes[:, 3][None] - ys[:, None]
         reg = torch.stack([l, t, r, b], dim=2)
-        is_in = reg.min(dim=2)[0] > 0
+        if cfg.center_sample:
+            is_in = center_sample_region(cfg, bboxes, num_loc, xs, ys)
+        else:
+            is_in = reg.min(dim=2)[0] > 0
         mx = reg.max(dim=2)[0]
         cared = (mx >= size_ranges[:, [0]]) & (mx <= size_ranges[:, [1]])
         a = area[None].repeat(L, 1)

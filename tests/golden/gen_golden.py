@@ -327,6 +327,38 @@ def gen_fcos(structures, fo, pg):
     print("fcos_outputs.npz:", len(d), "arrays")
 
 
+def gen_fcos_center_sample(structures, fo):
+    """CENTER_SAMPLE True (config-reachable variant, fcos_outputs.py:700-770): targets + supervised losses / gradients."""
+    cfg = fcos_cfg()
+    cfg.MODEL.FCOS.CENTER_SAMPLE = True
+    outm = fo.FCOSOutputs(cfg)
+    g = torch.Generator().manual_seed(4321)
+    N, H, W = 3, 128, 160
+    strides = [8, 16, 32, 64, 128]
+    d = {"N": N, "H": H, "W": W, "radius": 1.5}
+    logits, reg, std, ctr, locs = make_head_outputs(g, N, H, W, strides)
+    for l in range(5):
+        d["logits%d" % l], d["reg%d" % l], d["std%d" % l], d["ctr%d" % l] = map(npy, (logits[l], reg[l], std[l], ctr[l]))
+    gts = make_gts(g, N, H, W, structures, empty_image=2)
+    gts_to_arrays("gt", gts, d)
+    leaves = [[t.clone().requires_grad_(True) for t in lst] for lst in (logits, reg, std, ctr)]
+    extras, losses = outm.losses(leaves[0], leaves[1], leaves[3], locs, gts, leaves[2], [], False, branch="labeled")
+    tot = losses["loss_fcos_cls"] + 2.0 * losses["loss_fcos_loc"] + 3.0 * losses["loss_fcos_ctr"]
+    tot.backward()
+    for k, v in losses.items():
+        d["loss_%s" % k] = npy(v)
+    for nm, lst in zip(("logits", "reg", "std", "ctr"), leaves):
+        for l in range(5):
+            d["g%s%d" % (nm, l)] = npy(lst[l].grad if lst[l].grad is not None else torch.zeros_like(lst[l]))
+    tt = outm._get_ground_truth(locs, gts)
+    for l in range(5):
+        d["labels%d" % l] = npy(tt["labels"][l])
+        d["regt%d" % l] = npy(tt["reg_targets"][l])
+        d["tinds%d" % l] = npy(tt["target_inds"][l])
+    np.savez_compressed(os.path.join(HERE, "fcos_center_sample.npz"), **d)
+    print("fcos_center_sample.npz:", len(d), "arrays")
+
+
 def gen_small_ops(fo):
     from ubteacher.layers import IOULoss, NLLoss
     g = torch.Generator().manual_seed(7)
@@ -502,5 +534,6 @@ if __name__ == "__main__":
     structures, fo, pg, tr = install_shims()
     gen_rcnn(structures)
     gen_fcos(structures, fo, pg)
+    gen_fcos_center_sample(structures, fo)
     gen_small_ops(fo)
     gen_ema(tr)

@@ -315,3 +315,48 @@ def test_nms_class_parallel_scan_post_topk():
                 ref = ref[scores[n][ref] >= kth]
             assert int(cnt[n]) == len(ref), (N, M, ncls, int(cnt[n]), len(ref))
             assert torch.equal(keep[n, : len(ref)].long(), ref)
+
+
+def test_center_sample_variant_vs_reference_golden():
+    """MODEL.FCOS.CENTER_SAMPLE True through the product (target kernel with the radius*stride centre region): labels, regression
+    targets, losses and head gradients vs the reference's own outputs (fcos_center_sample.npz); also the first-box-centre quirk."""
+    from ubteacher import hip
+    from ubteacher.modeling.fcos import FCOSOutputs
+    cs = dict(np.load(os.path.join(G, "fcos_center_sample.npz")))
+    cfg = fcos_cfg()
+    cfg.MODEL.FCOS.CENTER_SAMPLE = True
+    cfg.MODEL.FCOS.POS_RADIUS = float(cs["radius"])
+    outm = FCOSOutputs(cfg)
+    head_out, level_hw = build_head_out(cs, True)
+    N = int(cs["N"])
+    gt = padded_gt(cs, "gt", N)
+    extras, losses = outm.losses(head_out, level_hw, gt)
+    for k in ("loss_fcos_cls", "loss_fcos_loc", "loss_fcos_ctr"):
+        close(losses[k], cs["loss_%s" % k], rtol=2e-5)
+    lab = extras["labels"].cpu().numpy()
+    r = 0
+    for l, (h, w) in enumerate(level_hw):
+        gl = cs["labels%d" % l]
+        mine = lab[r:r + N * h * w]
+        keep = mine >= 0                       # the empty third image is dropped (-1) in the supervised branch
+        assert np.array_equal(mine[keep], gl[keep]) and (~keep).sum() == h * w
+        close(extras["reg_targets"][r:r + N * h * w][torch.from_numpy(keep).to(DEV)], cs["regt%d" % l][keep])
+        r += N * h * w
+    tot = losses["loss_fcos_cls"] + 2.0 * losses["loss_fcos_loc"] + 3.0 * losses["loss_fcos_ctr"]
+    tot.backward()
+    meta = head_out["meta"]
+    for l in range(5):
+        close(meta.level_view(head_out["logits"].grad, l).permute(0, 3, 1, 2), cs["glogits%d" % l], rtol=1e-4, atol=2e-7)
+        gb = meta.level_view(head_out["box"].grad, l)
+        close(gb[..., :68].permute(0, 3, 1, 2), cs["greg%d" % l], rtol=1e-4, atol=2e-7)
+        close(gb[..., 72:73].permute(0, 3, 1, 2), cs["gctr%d" % l], rtol=1e-4, atol=2e-7)
+    # quirk (`center_x[..., 0].sum() == 0`): a first box centred at x = 0 switches every positive off - vs the oracle
+    boxes = torch.tensor([[[-10.0, 20.0, 10.0, 60.0], [30.0, 30.0, 90.0, 100.0]]], device=DEV)
+    classes = torch.tensor([[3, 5]], dtype=torch.int32, device=DEV)
+    valid = torch.ones((1, 2), dtype=torch.uint8, device=DEV)
+    soi = [[-1, 64], [64, 128], [128, 256], [256, 512], [512, 1e8]]
+    labels, _, _, _ = hip.fcos_targets(level_hw, [8, 16, 32, 64, 128], soi, boxes, classes, valid, None, 80, 0, center_radius=1.5)
+    assert int((labels < 80).sum()) == 0
+    locs = [O.compute_locations(h, w, s) for (h, w), s in zip(level_hw, (8, 16, 32, 64, 128))]
+    tg = O.fcos_targets(O.FCOSCfg(center_sample=True), locs, [dict(boxes=boxes[0].cpu(), classes=classes[0].long().cpu())])
+    assert sum(int((x < 80).sum()) for x in tg["labels"]) == 0

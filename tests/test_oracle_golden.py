@@ -131,3 +131,31 @@ def test_ema_bit_exact():
         out = O.ema_update(s, t, keep)
         for k in keys:
             assert np.array_equal(out[k].numpy(), d["%s_out_%s" % (tag, k)])  # bit exact
+
+
+def test_center_sample_variant():
+    """MODEL.FCOS.CENTER_SAMPLE True (config-reachable): targets, losses and gradients of the oracle vs the
+    reference's own get_sample_region path (tests/golden/fcos_center_sample.npz)."""
+    cs = dict(np.load(os.path.join(G, "fcos_center_sample.npz")))
+    cfg = O.FCOSCfg(center_sample=True, radius=float(cs["radius"]))
+    (lg, rg, sd, ct), locs = head(cs, True)
+    N = int(cs["N"])
+    losses, tg = O.fcos_losses(cfg, lg, rg, sd, ct, locs, gts(cs, "gt", N))
+    for k in ("loss_fcos_cls", "loss_fcos_loc", "loss_fcos_ctr"):
+        close(losses[k].detach(), cs["loss_%s" % k])
+    tot = losses["loss_fcos_cls"] + 2.0 * losses["loss_fcos_loc"] + 3.0 * losses["loss_fcos_ctr"]
+    tot.backward()
+    for nm, lst in zip(("logits", "reg", "std", "ctr"), (lg, rg, sd, ct)):
+        for l in range(5):
+            g = lst[l].grad if lst[l].grad is not None else torch.zeros_like(lst[l])
+            close(g, cs["g%s%d" % (nm, l)], rtol=1e-4, atol=1e-7)
+    npos = 0
+    for l in range(5):
+        assert np.array_equal(tg["labels"][l].numpy(), cs["labels%d" % l])
+        assert np.array_equal(tg["target_inds"][l].numpy(), cs["tinds%d" % l])
+        close(tg["reg_targets"][l], cs["regt%d" % l])
+        npos += int((cs["labels%d" % l] < 80).sum())
+    assert npos > 0
+    # the plain in-box rule gives MORE positives on the same inputs: the variant is really exercised
+    _, tg0 = O.fcos_losses(O.FCOSCfg(), lg, rg, sd, ct, locs, gts(cs, "gt", N))
+    assert sum(int((tg0["labels"][l] < 80).sum()) for l in range(5)) > npos

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void fcos_targets_kernel(LevelTable lt, int N,
                                                          const int* __restrict__ gt_classes,
                                                          const unsigned char* __restrict__ gt_valid,
                                                          const float* __restrict__ gt_std, int num_classes, int drop_empty,
-                                                         const unsigned char* __restrict__ img_active,
+                                                         float center_radius, const unsigned char* __restrict__ img_active,
                                                          int* __restrict__ labels, float* __restrict__ reg_targets,
                                                          float* __restrict__ bvars, int* __restrict__ gt_inds) {
   __shared__ float sb[TG_MAXG][4];
@@ -88,10 +88,22 @@ __global__ __launch_bounds__(256) void fcos_targets_kernel(LevelTable lt, int N,
   const float INF = 100000000.f;
   float best = INF;
   int bi = 0;
+  // CENTER_SAMPLE (get_sample_region, fcos_outputs.py:700-770): positives only inside the radius*stride square around the box
+  // centre, clipped to the box; the reference returns an all-False mask when the first box's centre x is 0
+  const bool cs = center_radius > 0.f;
+  const float sr = s * center_radius;
+  const bool cs_none = cs && (sb[0][0] + sb[0][2]) * 0.5f * (float)L == 0.f;
   for (int k = 0; k < G; ++k) {
     const float lft = xs - sb[k][0], top = ys - sb[k][1], rgt = sb[k][2] - xs, bot = sb[k][3] - ys;
-    const float mn = fminf(fminf(lft, top), fminf(rgt, bot));
+    float mn = fminf(fminf(lft, top), fminf(rgt, bot));
     const float mx = fmaxf(fmaxf(lft, top), fmaxf(rgt, bot));
+    if (cs) {
+      const float cx = (sb[k][0] + sb[k][2]) * 0.5f, cy = (sb[k][1] + sb[k][3]) * 0.5f;
+      const float xmin = cx - sr, ymin = cy - sr, xmax = cx + sr, ymax = cy + sr;
+      const float x0 = xmin > sb[k][0] ? xmin : sb[k][0], y0 = ymin > sb[k][1] ? ymin : sb[k][1];
+      const float x1 = xmax > sb[k][2] ? sb[k][2] : xmax, y1 = ymax > sb[k][3] ? sb[k][3] : ymax;
+      mn = cs_none ? -1.f : fminf(fminf(xs - x0, ys - y0), fminf(x1 - xs, y1 - ys));
+    }
     float a = sarea[k];
     if (!(mn > 0.f)) a = INF;
     if (!(mx >= lt.soi_lo[l] && mx <= lt.soi_hi[l])) a = INF;
@@ -513,15 +525,15 @@ extern "C" {
 // H,W,strides: host int[num_levels]; soi: host float[2*num_levels] (lo,hi per level).
 int utv2_fcos_targets(int num_levels, const int* H, const int* W, const int* strides, const float* soi, int N, int MAXG,
                       const float* gt_boxes, const int* gt_classes, const unsigned char* gt_valid, const float* gt_std,
-                      int num_classes, int drop_empty, const unsigned char* img_active, int* labels, float* reg_targets,
-                      float* bvars, int* gt_inds, hipStream_t stream) {
+                      int num_classes, int drop_empty, float center_radius, const unsigned char* img_active, int* labels,
+                      float* reg_targets, float* bvars, int* gt_inds, hipStream_t stream) {
   if (num_levels < 1 || num_levels > MAX_LEVELS || MAXG > TG_MAXG || MAXG < 1 || !gt_boxes || !gt_classes || !gt_valid ||
       !labels || !reg_targets || !bvars || !gt_inds)
     return UTV2_EARG;
   LevelTable t = make_table(num_levels, H, W, strides, soi);
   const int L = t.off[num_levels];
   hipLaunchKernelGGL(fcos_targets_kernel, dim3(cdiv(L, 256), N), dim3(256), 0, stream, t, N, MAXG, gt_boxes, gt_classes,
-                     gt_valid, gt_std, num_classes, drop_empty, img_active, labels, reg_targets, bvars, gt_inds);
+                     gt_valid, gt_std, num_classes, drop_empty, center_radius, img_active, labels, reg_targets, bvars, gt_inds);
   return utv2_launch_status();
 }
 

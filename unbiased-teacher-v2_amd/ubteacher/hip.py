@@ -356,7 +356,8 @@ def _farr(vals):
     return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
 
 
-def fcos_targets(level_hw, strides, soi, gt_boxes, gt_classes, gt_valid, gt_std, num_classes, drop_empty, active=None):
+def fcos_targets(level_hw, strides, soi, gt_boxes, gt_classes, gt_valid, gt_std, num_classes, drop_empty, active=None,
+                 center_radius=0.0):
     """gt_* padded [N,MAXG,...]; returns labels[int32 P], reg_targets[P,4], bvars[P,4], gt_inds[P]."""
     N, MAXG = gt_classes.shape
     L = sum(h * w for h, w in level_hw)
@@ -375,7 +376,7 @@ def fcos_targets(level_hw, strides, soi, gt_boxes, gt_classes, gt_valid, gt_std,
     so = _farr(flat)
     call("utv2_fcos_targets", len(level_hw), ctypes.cast(H, c_p), ctypes.cast(W, c_p), ctypes.cast(S, c_p),
          ctypes.cast(so, c_p), N, MAXG, _p(gt_boxes), _p(gt_classes), _p(gt_valid), _p(gt_std), num_classes,
-         int(drop_empty), _p(active), _p(labels), _p(reg), _p(bv), _p(gi), _stream())
+         int(drop_empty), float(center_radius), _p(active), _p(labels), _p(reg), _p(bv), _p(gi), _stream())
     return labels, reg, bv, gi
 
 

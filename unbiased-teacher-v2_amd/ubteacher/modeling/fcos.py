@@ -207,7 +207,7 @@ class FCOSOutputs:
         fc = cfg.MODEL.FCOS
         self.focal_loss_alpha = fc.LOSS_ALPHA
         self.focal_loss_gamma = fc.LOSS_GAMMA
-        assert not fc.CENTER_SAMPLE, "CENTER_SAMPLE True is a SURVEY 8(f) 'next' row"
+        self.center_radius = float(fc.POS_RADIUS) if fc.CENTER_SAMPLE else 0.0   # get_sample_region (fcos_outputs.py:700-770)
         self.pre_nms_thresh_train = fc.INFERENCE_TH_TRAIN
         self.pre_nms_topk_train = fc.PRE_NMS_TOPK_TRAIN
         self.post_nms_topk_train = fc.POST_NMS_TOPK_TRAIN
@@ -240,7 +240,7 @@ class FCOSOutputs:
     def _targets(self, level_hw, gt, drop_empty, active=None):
         std = gt["reg_pred_std"] if "reg_pred_std" in gt else None
         return hip.fcos_targets(level_hw, self.strides, self.sizes_of_interest, gt["boxes"], gt["classes"],
-                                gt["valid"], std, self.num_classes, drop_empty, active)
+                                gt["valid"], std, self.num_classes, drop_empty, active, center_radius=self.center_radius)
 
     @staticmethod
     def _normalisers(sums):
