@@ -162,10 +162,14 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    # dry-run hooks for boxes with ONE GPU (tests of the N > 1 code path): all ranks on device 0 over gloo
+    if os.environ.get("UTV2_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # nccl == RCCL over xGMI on ROCm
+        # nccl == RCCL over xGMI on ROCm
+        dist.init_process_group(os.environ.get("UTV2_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from ubteacher.engine import UBTeacherTrainer
     from ubteacher.presets import get_config
@@ -219,7 +223,7 @@ def main():
             "config": {"workload": "FCOS R50-FPN UTv2 sup1 (configs[1]): %d labeled + %d unlabeled 1333x800 images per GPU, "
                                    "post-burn-in semi-supervised step" % (args.label, args.unlabel),
                        "global_batch": per_step_images, "parallelism": "dp%d" % world,
-                       "precision": "bf16 MFMA operands, fp32 accumulate/activations/master weights (config SOLVER.AMP.ENABLED)" if args.dtype == "bf16" else "fp32 MFMA"},
+                       "precision": "AMP (config SOLVER.AMP.ENABLED): bf16 MFMA operands, bf16 activations and activation gradients in HBM, fp32 accumulate / losses / weight gradients / master weights" if args.dtype == "bf16" else "fp32 MFMA, fp32 everywhere"},
             "losses": {k: v for k, v in metrics.items() if k.startswith("loss") or k.startswith("teacher")},
         }
         if conv:
