@@ -89,6 +89,10 @@ int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int
 int utv2_f32_to_bf16(const float* src, void* dst16, int64_t n, utv2_stream_t stream);
 int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, const float* scale, int K, int KH, int KW, int C,
                                     utv2_stream_t stream);
+/* every dgrad weight image of a model in one launch; table = device array of nlayers 40-byte records
+ * {int64 w_off (elements into arena), int64 dst_off (into bank), int64 scale_off (into scales, -1 = none), int32 K, KH, KW, C} */
+int utv2_weight_flip_transpose_bf16_batched(const float* arena, const float* scales, void* bank, const void* table, int nlayers,
+                                            utv2_stream_t stream);
 
 /* ---- teacher EMA: engine/trainer.py:468-486 (FCOS), :950-968 (RCNN) --------------------------
  * teacher = student*(1-keep) + teacher*keep, evaluated with the reference's three roundings. */

@@ -286,6 +286,34 @@ __global__ void weight_flip_transpose_bf16_kernel(const float* __restrict__ w, _
   }
 }
 
+// All dgrad weight images of a model in ONE launch: blockIdx.y = layer, the table lives on the device.
+struct FlipDesc {
+  long long w_off;      // element offset of the layer's [K][KH][KW][C] fp32 weights in the parameter arena
+  long long dst_off;    // element offset of its [C][KH][KW][K] bf16 image in the bank buffer
+  long long scale_off;  // element offset of its per-output-channel multiplier in `scales`, or -1
+  int K, KH, KW, C;
+};
+
+__global__ __launch_bounds__(256) void weight_flip_transpose_bf16_batched_kernel(const float* __restrict__ arena, const float* __restrict__ scales,
+                                                                               __bf16* __restrict__ bank, const FlipDesc* __restrict__ table) {
+  const FlipDesc d = table[blockIdx.y];
+  const float* w = arena + d.w_off;
+  const float* scale = d.scale_off >= 0 ? scales + d.scale_off : nullptr;
+  __bf16* wt = bank + d.dst_off;
+  const size_t n = (size_t)d.K * d.KH * d.KW * d.C;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    size_t t = i;
+    const int co = (int)(t % d.K); t /= d.K;
+    const int kwp = (int)(t % d.KW); t /= d.KW;
+    const int khp = (int)(t % d.KH); t /= d.KH;
+    const int ci = (int)t;
+    float v = w[(((size_t)co * d.KH + (d.KH - 1 - khp)) * d.KW + (d.KW - 1 - kwp)) * d.C + ci];
+    if (scale) v *= scale[co];
+    wt[i] = (__bf16)v;
+  }
+}
+
 static int fill_levels16(LevelTab& lt, int nlev, int N, const int* H, const int* W) {
   lt.n = nlev;
   int off = 0;
@@ -631,6 +659,17 @@ int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, const float* sca
   int nb = cdiv((int64_t)n, 256);
   if (nb > 8192) nb = 8192;
   hipLaunchKernelGGL(weight_flip_transpose_bf16_kernel, dim3(nb), dim3(256), 0, stream, w, (__bf16*)wt16, scale, K, KH, KW, C);
+  return utv2_launch_status();
+}
+
+// table: device array of nlayers records {int64 w_off, dst_off, scale_off; int32 K, KH, KW, C} (40 bytes each, see FlipDesc):
+// bank[dst_off ..] = bf16 flip/transpose of arena[w_off ..] (* scales[scale_off + co] when scale_off >= 0) for every layer.
+int utv2_weight_flip_transpose_bf16_batched(const float* arena, const float* scales, void* bank, const void* table, int nlayers,
+                                            hipStream_t stream) {
+  if (!arena || !bank || !table || nlayers < 1) return UTV2_EARG;
+  static_assert(sizeof(FlipDesc) == 40, "table record layout is part of the ABI");
+  hipLaunchKernelGGL(weight_flip_transpose_bf16_batched_kernel, dim3(64, nlayers), dim3(256), 0, stream, arena, scales, (__bf16*)bank,
+                     (const FlipDesc*)table);
   return utv2_launch_status();
 }
 

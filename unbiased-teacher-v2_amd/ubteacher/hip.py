@@ -595,6 +595,11 @@ def _act_dtype(x, out_dtype):
     return out_dtype if out_dtype is not None else x.dtype
 
 
+def weight_flip_transpose_bf16_batched(arena, scales, bank, table, nlayers):
+    call("utv2_weight_flip_transpose_bf16_batched", _p(arena), c_p(scales.data_ptr()) if scales is not None else c_p(0), _p(bank),
+         _p(table), int(nlayers), _stream())
+
+
 def conv2d_fwd_bf16(x, w16, scale=None, bias=None, residual=None, stride=1, pad=0, relu=False, kh=1, kw=1, out=None,
                     in_dil=1, out_hw=None, accumulate=False, out_dtype=None, mask=None):
     """x: fp32 or bf16 NHWC; the output (and `residual`) element type is out_dtype (default: x's)."""

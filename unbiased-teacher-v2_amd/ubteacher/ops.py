@@ -80,6 +80,69 @@ class LevelMeta:
             t2d.untyped_storage(), t2d.storage_offset() + r0 * C, (self.N, h, w, C), (h * w * C, w * C, C, 1))
 
 
+class FlipBank:
+    """dgrad weight images ([C][KH][KW][K] bf16, optionally times the FrozenBN multiplier) of every registered layer of one
+    ParamStore, refreshed by ONE launch whenever the arena changes (utv2_weight_flip_transpose_bf16_batched)."""
+
+    def __init__(self, store):
+        self.store = store
+        self.layers = []      # (layer, scale tensor or None)
+        self.slot = {}        # id(layer) -> index
+        self.dirty = False    # registrations since the tables were built
+        self.version = None
+        self.bank = None
+        self.views = []
+        self.single = {}      # id(layer) -> (version, tensor): per-layer images served before the layer is in the tables
+
+    def _current(self):
+        return (_VERSION[0], self.store.version)
+
+    def _rebuild(self):
+        import struct
+        dev = self.store.flat.device
+        offs, total = [], 0
+        for layer, _ in self.layers:
+            offs.append(total)
+            total += (layer.cout * layer.k * layer.k * layer.cin + 7) // 8 * 8
+        self.bank = torch.empty(total, dtype=torch.bfloat16, device=dev)
+        self.scales = None
+        rec = bytearray()
+        for (layer, sc), o in zip(self.layers, offs):
+            so = -1
+            if sc is not None:
+                if self.scales is None:
+                    self.scales = torch.empty(0, dtype=torch.float32, device=dev).set_(sc.untyped_storage())
+                assert sc.untyped_storage().data_ptr() == self.scales.untyped_storage().data_ptr()
+                so = sc.storage_offset()
+            rec += struct.pack("<qqqiiii", layer.w.offset, o, so, layer.cout, layer.k, layer.k, layer.cin)
+        self.table = torch.frombuffer(rec, dtype=torch.uint8).clone().to(dev)
+        self.views = [self.bank[o:o + l.cout * l.k * l.k * l.cin].view(l.cin, l.k * l.k * l.cout) for (l, _), o in zip(self.layers, offs)]
+        self.dirty = False
+        self.single.clear()
+
+    def get(self, layer, scale):
+        cur = self._current()
+        i = self.slot.get(id(layer))
+        if i is None:
+            self.slot[id(layer)] = len(self.layers)
+            self.layers.append((layer, scale))
+            self.dirty = True
+        elif self.version == cur and not self.dirty:
+            return self.views[i]
+        elif self.version != cur and (i is not None):
+            # first request after the arena changed: refresh every registered layer in one launch
+            if self.dirty or self.bank is None:
+                self._rebuild()
+            hip.weight_flip_transpose_bf16_batched(self.store.flat, self.scales, self.bank, self.table, len(self.layers))
+            self.version = cur
+            return self.views[self.slot[id(layer)]]
+        ent = self.single.get(id(layer))
+        if ent is None or ent[0] != cur:
+            ent = (cur, hip.weight_flip_transpose_bf16(layer.w.t, layer.cout, layer.k, layer.k, layer.cin, scale))
+            self.single[id(layer)] = ent
+        return ent[1]
+
+
 class Conv:
     """One convolution (+ optional folded FrozenBN or bias, ReLU, residual) bound to arena handles."""
 
@@ -110,12 +173,13 @@ class Conv:
         return self._wt
 
     def wt16(self, scale=None):
-        """bf16 dgrad weight image; `scale` (the folded FrozenBN multiplier) is baked in per output channel"""
-        v = (_VERSION[0], self.w.store.version, scale is not None)
-        if getattr(self, "_wt16", None) is None or self._wt16_version != v:
-            self._wt16 = hip.weight_flip_transpose_bf16(self.w.t, self.cout, self.k, self.k, self.cin, scale)
-            self._wt16_version = v
-        return self._wt16
+        """bf16 dgrad weight image; `scale` (the folded FrozenBN multiplier) is baked in per output channel.  Images of all
+        layers of a model come from ONE batched launch per optimizer step (FlipBank); a layer's first request registers it
+        and is served by a per-layer launch."""
+        bank = getattr(self.w.store, "_flipbank", None)
+        if bank is None:
+            bank = self.w.store._flipbank = FlipBank(self.w.store)
+        return bank.get(self, scale)
 
     def use_bf16(self):
         return PRECISION[0] == "bf16" and self.cin % 8 == 0 and self.kred == self.k * self.k * self.cin
