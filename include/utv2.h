@@ -162,10 +162,10 @@ int utv2_sigmoid_focal_bwd(const float* logits, const int* labels, int64_t P, in
  * ws >= 4096 floats. */
 int utv2_fcos_loc_terms_fwd(const int* labels, const float* box, int box_stride, const float* reg_targets,
                             const float* bvars, int64_t P, int num_classes, int reg_max, float ts_better, float ts_cert,
-                            float* sums, float* ws, utv2_stream_t stream);
+                            int flags, float* sums, float* ws, utv2_stream_t stream);
 int utv2_fcos_loc_terms_bwd(const int* labels, const float* box, int box_stride, const float* reg_targets,
                             const float* bvars, int64_t P, int num_classes, int reg_max, float ts_better, float ts_cert,
-                            const float* coef, float* dbox, utv2_stream_t stream);
+                            int flags, const float* coef, float* dbox, utv2_stream_t stream);
 /* :1146-1195 ranking score -> sortable int64 key (method 0 cls, 1 cls_n_ctr, 2 ctr, 3 cls_n_loc); image n's HW*C keys
  * start at keys + n*key_row_stride (>= HW*C: rows of a wider matrix shared by all FPN levels) */
 int utv2_fcos_rank_keys(const float* logits, const float* box, int box_stride, int reg_max, int N, int HW, int C,

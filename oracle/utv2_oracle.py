@@ -241,8 +241,8 @@ def iou_targets(pred, target):
     return (ai + 1.0) / (ta + pa - ai + 1.0)
 
 
-def giou_loss_ltrb(pred, target, weight=None):
-    """layers/iou_loss.py:20-76 with loc_loss_type 'giou'."""
+def giou_loss_ltrb(pred, target, weight=None, loc_loss_type="giou"):
+    """layers/iou_loss.py:20-76; loc_loss_type 'giou' (every shipped config), 'iou' or 'linear_iou' (:64-69)."""
     ta = (target[:, 0] + target[:, 2]) * (target[:, 1] + target[:, 3])
     pa = (pred[:, 0] + pred[:, 2]) * (pred[:, 1] + pred[:, 3])
     wi = torch.min(pred[:, 0], target[:, 0]) + torch.min(pred[:, 2], target[:, 2])
@@ -254,7 +254,14 @@ def giou_loss_ltrb(pred, target, weight=None):
     au = ta + pa - ai
     ious = (ai + 1.0) / (au + 1.0)
     gious = ious - (ac - au) / ac
-    losses = 1 - gious
+    if loc_loss_type == "iou":
+        losses = -torch.log(ious)
+    elif loc_loss_type == "linear_iou":
+        losses = 1 - ious
+    elif loc_loss_type == "giou":
+        losses = 1 - gious
+    else:
+        raise NotImplementedError
     return (losses * weight).sum() if weight is not None else losses.sum()
 
 
@@ -266,6 +273,14 @@ def nl_loss(inp, inp_std, target, iou_weight):
     second = 0.5 * torch.log(sq)
     s = (first + second).sum(dim=1) + 2 * torch.log(2 * torch.Tensor([math.pi]))
     return (s * iou_weight).mean()
+
+
+def kl_loss(inp, inp_std, target, beta=1.0):
+    """layers/kl_loss.py:11-66 (KLLoss) as fcos_outputs.py calls it: default beta 1.0, method LOC_FUN_ALL "mean"; input_std enters
+    raw (no sigmoid), the centerness / IoU weights are ignored by that method."""
+    n = torch.abs(inp - target)
+    l1_smooth = torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta)
+    return (torch.exp(-inp_std) * l1_smooth + 0.5 * inp_std).mean()
 
 
 class FCOSCfg:
@@ -283,6 +298,9 @@ class FCOSCfg:
         self.nms_thresh = 0.6
         self.unify_ctrcls = False
         self.center_sample, self.radius = False, 1.5  # MODEL.FCOS.CENTER_SAMPLE / POS_RADIUS (config.py defaults)
+        # config-reachable variants (config.py:153,168,196-198; SEMISUPNET.CONSIST_REG_LOSS :191)
+        self.kl_loss, self.kl_loss_type, self.quality_est, self.loc_loss_type = True, "nlloss", "centerness", "giou"
+        self.reg_unsup_loss = "ts_locvar_better_nms_nll_l1"
         self.__dict__.update(kw)
         soi, prev = [], -1
         for s in self.soi_edges:
@@ -407,14 +425,27 @@ def fcos_losses(cfg, logits, reg, std, ctr, locations, gts, world_size=1):
     class_loss = sigmoid_focal_loss(lg, tgt, cfg.alpha, cfg.gamma).sum(1).sum() / num_pos_avg
     rg, sdv, ct, regt = rg[pos], sdv[pos], ct[pos], regt[pos]
     reg_pred = integral(rg, cfg.reg_max) if pos.numel() > 0 else rg
-    ctr_t = ctrness_targets(regt)
+    if cfg.quality_est == "centerness":  # :353-359
+        ctr_t = ctrness_targets(regt)
+    elif cfg.quality_est == "iou":
+        ctr_t = iou_targets(reg_pred.detach(), regt)
+    else:
+        raise NotImplementedError
     loss_denorm = max(ctr_t.sum().item() / world_size, 1e-6)
     if pos.numel() > 0:
         iou_t = iou_targets(reg_pred.detach(), regt)
         ctr_loss = F.binary_cross_entropy_with_logits(ct, ctr_t, reduction="sum") / num_pos_avg
-        nll = cfg.kl_weight * nl_loss(reg_pred, sdv, regt, iou_t)  # :400
-        iou_loss = giou_loss_ltrb(reg_pred, regt, ctr_t) / loss_denorm
-        reg_loss = cfg.kl_weight * nll + iou_loss  # :416 (weight applied twice)
+        iou_loss = giou_loss_ltrb(reg_pred, regt, ctr_t, cfg.loc_loss_type) / loss_denorm
+        if cfg.kl_loss:
+            if cfg.kl_loss_type == "nlloss":
+                kl = cfg.kl_weight * nl_loss(reg_pred, sdv, regt, iou_t)  # :400
+            elif cfg.kl_loss_type == "klloss":
+                kl = cfg.kl_weight * kl_loss(reg_pred, sdv, regt)  # :381
+            else:
+                raise NotImplementedError
+            reg_loss = cfg.kl_weight * kl + iou_loss  # :397,:416 (weight applied twice)
+        else:
+            reg_loss = iou_loss  # :418-423
     else:
         reg_loss = torch.tensor(0.0)
         ctr_loss = torch.tensor(0.0)
@@ -444,6 +475,15 @@ def fcos_pseudo_losses(cfg, logits, reg, std, ctr, locations, gt_dict, world_siz
             if labeltype == "cls":
                 cl = F.binary_cross_entropy_with_logits(ct[pos], ctr_t, reduction="sum") / num_pos_avg
                 losses["loss_fcos_ctr"] = cl * 0 if cfg.unify_ctrcls else cl
+            elif not cfg.kl_loss:
+                raise ValueError  # :587-588
+            elif cfg.reg_unsup_loss != "ts_locvar_better_nms_nll_l1":  # :571-585: weight * (KL | NLL) term
+                reg_pred = integral(rg[pos], cfg.reg_max)
+                if cfg.kl_loss_type == "nlloss":
+                    term = nl_loss(reg_pred, sdv[pos], regt[pos], iou_targets(reg_pred.detach(), regt[pos]))
+                else:
+                    term = kl_loss(reg_pred, sdv[pos], regt[pos])
+                losses["loss_fcos_loc"] = cfg.kl_weight * term
             else:
                 reg_pred = integral(rg[pos], cfg.reg_max)
                 conf_s = 1 - sdv[pos].sigmoid()

@@ -359,6 +359,70 @@ def gen_fcos_center_sample(structures, fo):
     print("fcos_center_sample.npz:", len(d), "arrays")
 
 
+def gen_fcos_loss_variants(structures, fo):
+    """Config-reachable FCOS loss variants no shipped YAML selects: KL_LOSS_TYPE "klloss", KL_LOSS False,
+    QUALITY_EST "iou", LOC_LOSS_TYPE "iou" / "linear_iou", and a CONSIST_REG_LOSS other than the TS-better one (the pseudo
+    regression loss then is the KL / NLL term, fcos_outputs.py:571-585).  One set of inputs, one set of outputs per case."""
+    g = torch.Generator().manual_seed(2468)
+    N, H, W = 2, 128, 160
+    strides = [8, 16, 32, 64, 128]
+    d = {"N": N, "H": H, "W": W}
+    logits, reg, std, ctr, locs = make_head_outputs(g, N, H, W, strides)
+    for l in range(5):
+        d["logits%d" % l], d["reg%d" % l], d["std%d" % l], d["ctr%d" % l] = map(npy, (logits[l], reg[l], std[l], ctr[l]))
+    gts = make_gts(g, N, H, W, structures)
+    gts_to_arrays("gt", gts, d)
+    gcls = make_gts(g, N, H, W, structures, with_scores=True)
+    greg = make_gts(g, N, H, W, structures, with_scores=True)
+    gts_to_arrays("pcls_gt", gcls, d)
+    gts_to_arrays("preg_gt", greg, d)
+    cases = {
+        "klloss": dict(KL_LOSS_TYPE="klloss"),
+        "nokl": dict(KL_LOSS=False),
+        "iouq": dict(QUALITY_EST="iou"),
+        "lociou": dict(LOC_LOSS_TYPE="iou"),
+        "loclinear": dict(LOC_LOSS_TYPE="linear_iou"),
+        "klloss_iouq_linear": dict(KL_LOSS_TYPE="klloss", QUALITY_EST="iou", LOC_LOSS_TYPE="linear_iou"),
+    }
+    for case, over in cases.items():
+        cfg = fcos_cfg()
+        for k, v in over.items():
+            setattr(cfg.MODEL.FCOS, k, v)
+        outm = fo.FCOSOutputs(cfg)
+        leaves = [[t.clone().requires_grad_(True) for t in lst] for lst in (logits, reg, std, ctr)]
+        extras, losses = outm.losses(leaves[0], leaves[1], leaves[3], locs, gts, leaves[2], [], False, branch="labeled")
+        tot = losses["loss_fcos_cls"] + 2.0 * losses["loss_fcos_loc"] + 3.0 * losses["loss_fcos_ctr"]
+        tot.backward()
+        for k, v in losses.items():
+            d["%s_%s" % (case, k)] = npy(v)
+        for nm, lst in zip(("logits", "reg", "std", "ctr"), leaves):
+            if nm == "logits" and case != "klloss":
+                continue  # the classification path does not depend on the variant: one copy is enough
+            for l in range(5):
+                d["%s_g%s%d" % (case, nm, l)] = npy(lst[l].grad if lst[l].grad is not None else torch.zeros_like(lst[l]))
+    # pseudo regression loss = weight * KL / NLL term when CONSIST_REG_LOSS is not the TS-better selection
+    for case, over in (("pseudo_nll", dict()), ("pseudo_kl", dict(KL_LOSS_TYPE="klloss"))):
+        cfg = fcos_cfg()
+        cfg.SEMISUPNET.CONSIST_REG_LOSS = "mse_loss_all_raw"  # config.py:191 default
+        for k, v in over.items():
+            setattr(cfg.MODEL.FCOS, k, v)
+        outm = fo.FCOSOutputs(cfg)
+        leaves = [[t.clone().requires_grad_(True) for t in lst] for lst in (logits, reg, std, ctr)]
+        extras, losses = outm.pseudo_losses(leaves[0], leaves[1], leaves[3], locs, {"cls": gcls, "reg": greg}, leaves[2], [], False,
+                                            branch="unlabeled")
+        tot = losses["loss_fcos_cls"] + 2.0 * losses["loss_fcos_loc"] + 3.0 * losses["loss_fcos_ctr"]
+        tot.backward()
+        for k, v in losses.items():
+            d["%s_%s" % (case, k)] = npy(v.float() if torch.is_tensor(v) else torch.tensor(float(v)))
+        for nm, lst in zip(("logits", "reg", "std", "ctr"), leaves):
+            if nm == "logits" and case != "pseudo_nll":
+                continue
+            for l in range(5):
+                d["%s_g%s%d" % (case, nm, l)] = npy(lst[l].grad if lst[l].grad is not None else torch.zeros_like(lst[l]))
+    np.savez_compressed(os.path.join(HERE, "fcos_loss_variants.npz"), **d)
+    print("fcos_loss_variants.npz:", len(d), "arrays")
+
+
 def gen_small_ops(fo):
     from ubteacher.layers import IOULoss, NLLoss
     g = torch.Generator().manual_seed(7)
@@ -457,6 +521,17 @@ def gen_rcnn(structures):
             d["rc_%s_%s" % (branch, k)] = npy(v)
             d["rc_%s_g%s" % (branch, k)] = npy(v.grad if v.grad is not None else torch.zeros_like(v))
         d["rc_%s_loss_cls" % branch] = npy(ls["loss_cls"]); d["rc_%s_loss_box_reg" % branch] = npy(ls["loss_box_reg"])
+        # MODEL.ROI_HEADS.LOSS "CrossEntropy_BoundaryVar" (fast_rcnn.py:214-712) on the same inputs (no further random draws)
+        ce_ = fr.FastRCNNCrossEntropyBoundaryVarOutputLayers
+        cduck = types.SimpleNamespace(**vars(duck))
+        for name in ("box_reg_loss", "box_reg_pseudo_loss"):
+            setattr(cduck, name, types.MethodType(getattr(ce_, name), cduck))
+        leaves = [v.detach().clone().requires_grad_(True) for v in (scores, deltas, std)]
+        ls = ce_.losses(cduck, tuple(leaves), [inst], branch)
+        (ls["loss_cls"] + 2.0 * ls["loss_box_reg"]).backward()
+        for k, v in zip(("scores", "deltas", "std"), leaves):
+            d["rcce_%s_g%s" % (branch, k)] = npy(v.grad if v.grad is not None else torch.zeros_like(v))
+        d["rcce_%s_loss_cls" % branch] = npy(ls["loss_cls"]); d["rcce_%s_loss_box_reg" % branch] = npy(ls["loss_box_reg"])
     # ---- inference (predict_boxes / probs + D2 fast_rcnn_inference stand-in + pred_boxes_std gather) -----------
     for name in ("predict_boxes", "predict_boxes_std", "predict_probs"):
         setattr(duck, name, types.MethodType(getattr(cls_, name), duck))
@@ -535,5 +610,6 @@ if __name__ == "__main__":
     gen_rcnn(structures)
     gen_fcos(structures, fo, pg)
     gen_fcos_center_sample(structures, fo)
+    gen_fcos_loss_variants(structures, fo)
     gen_small_ops(fo)
     gen_ema(tr)

@@ -360,3 +360,65 @@ def test_center_sample_variant_vs_reference_golden():
     locs = [O.compute_locations(h, w, s) for (h, w), s in zip(level_hw, (8, 16, 32, 64, 128))]
     tg = O.fcos_targets(O.FCOSCfg(center_sample=True), locs, [dict(boxes=boxes[0].cpu(), classes=classes[0].long().cpu())])
     assert sum(int((x < 80).sum()) for x in tg["labels"]) == 0
+
+
+LOSS_VARIANTS = {
+    "klloss": dict(KL_LOSS_TYPE="klloss"),
+    "nokl": dict(KL_LOSS=False),
+    "iouq": dict(QUALITY_EST="iou"),
+    "lociou": dict(LOC_LOSS_TYPE="iou"),
+    "loclinear": dict(LOC_LOSS_TYPE="linear_iou"),
+    "klloss_iouq_linear": dict(KL_LOSS_TYPE="klloss", QUALITY_EST="iou", LOC_LOSS_TYPE="linear_iou"),
+}
+
+
+def _variant_grads(lv, case, head_out):
+    meta = head_out["meta"]
+    for l in range(5):
+        gb = meta.level_view(head_out["box"].grad, l)
+        close(gb[..., :68].permute(0, 3, 1, 2), lv["%s_greg%d" % (case, l)], rtol=1e-4, atol=2e-7)
+        close(gb[..., 68:72].permute(0, 3, 1, 2), lv["%s_gstd%d" % (case, l)], rtol=1e-4, atol=2e-7)
+        close(gb[..., 72:73].permute(0, 3, 1, 2), lv["%s_gctr%d" % (case, l)], rtol=1e-4, atol=2e-7)
+
+
+@pytest.mark.parametrize("case", sorted(LOSS_VARIANTS))
+def test_supervised_loss_variants_vs_reference_golden(case):
+    """KL_LOSS_TYPE "klloss" / KL_LOSS False / QUALITY_EST "iou" / LOC_LOSS_TYPE "iou", "linear_iou" through the product (flags of
+    the fused positive-location kernels) vs the reference's own FCOSOutputs.losses under that config (fcos_loss_variants.npz)."""
+    from ubteacher.modeling.fcos import FCOSOutputs
+    lv = dict(np.load(os.path.join(G, "fcos_loss_variants.npz")))
+    cfg = fcos_cfg()
+    for k, v in LOSS_VARIANTS[case].items():
+        setattr(cfg.MODEL.FCOS, k, v)
+    outm = FCOSOutputs(cfg)
+    head_out, level_hw = build_head_out(lv, True)
+    extras, losses = outm.losses(head_out, level_hw, padded_gt(lv, "gt", int(lv["N"])))
+    for k in ("loss_fcos_cls", "loss_fcos_loc", "loss_fcos_ctr"):
+        close(losses[k], lv["%s_%s" % (case, k)], rtol=2e-5)
+    tot = losses["loss_fcos_cls"] + 2.0 * losses["loss_fcos_loc"] + 3.0 * losses["loss_fcos_ctr"]
+    tot.backward()
+    _variant_grads(lv, case, head_out)
+
+
+@pytest.mark.parametrize("case,kl_type", [("pseudo_nll", "nlloss"), ("pseudo_kl", "klloss")])
+def test_pseudo_regression_kl_term_vs_reference_golden(case, kl_type):
+    """CONSIST_REG_LOSS other than the TS-better selection: loss_fcos_loc = KLLOSS_WEIGHT * (NLL | KL) on the regression pseudo set."""
+    from ubteacher.modeling.fcos import FCOSOutputs
+    lv = dict(np.load(os.path.join(G, "fcos_loss_variants.npz")))
+    cfg = fcos_cfg()
+    cfg.SEMISUPNET.CONSIST_REG_LOSS = "mse_loss_all_raw"
+    cfg.MODEL.FCOS.KL_LOSS_TYPE = kl_type
+    outm = FCOSOutputs(cfg)
+    head_out, level_hw = build_head_out(lv, True)
+    N = int(lv["N"])
+    gt = {"cls": padded_gt(lv, "pcls_gt", N), "reg": padded_gt(lv, "preg_gt", N)}
+    extras, losses = outm.pseudo_losses(head_out, level_hw, gt)
+    assert "teacher_better_student" not in losses
+    for k in ("loss_fcos_cls", "loss_fcos_loc", "loss_fcos_ctr"):
+        close(losses[k], lv["%s_%s" % (case, k)], rtol=2e-5)
+    tot = losses["loss_fcos_cls"] + 2.0 * losses["loss_fcos_loc"] + 3.0 * losses["loss_fcos_ctr"]
+    tot.backward()
+    _variant_grads(lv, case, head_out)
+    cfg.MODEL.FCOS.KL_LOSS = False
+    with pytest.raises(ValueError):  # fcos_outputs.py:587-588
+        FCOSOutputs(cfg).pseudo_losses(build_head_out(lv)[0], level_hw, gt)

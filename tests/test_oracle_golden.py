@@ -159,3 +159,51 @@ def test_center_sample_variant():
     # the plain in-box rule gives MORE positives on the same inputs: the variant is really exercised
     _, tg0 = O.fcos_losses(O.FCOSCfg(), lg, rg, sd, ct, locs, gts(cs, "gt", N))
     assert sum(int((tg0["labels"][l] < 80).sum()) for l in range(5)) > npos
+
+
+LOSS_VARIANTS = {
+    "klloss": dict(kl_loss_type="klloss"),
+    "nokl": dict(kl_loss=False),
+    "iouq": dict(quality_est="iou"),
+    "lociou": dict(loc_loss_type="iou"),
+    "loclinear": dict(loc_loss_type="linear_iou"),
+    "klloss_iouq_linear": dict(kl_loss_type="klloss", quality_est="iou", loc_loss_type="linear_iou"),
+}
+
+
+@pytest.mark.parametrize("case", sorted(LOSS_VARIANTS))
+def test_supervised_loss_variants(case):
+    """KL_LOSS_TYPE / KL_LOSS / QUALITY_EST / LOC_LOSS_TYPE variants (config-reachable): oracle vs the reference's own
+    FCOSOutputs.losses with that config (tests/golden/fcos_loss_variants.npz)."""
+    lv = dict(np.load(os.path.join(G, "fcos_loss_variants.npz")))
+    cfg = O.FCOSCfg(**LOSS_VARIANTS[case])
+    (lg, rg, sd, ct), locs = head(lv, True)
+    losses, _ = O.fcos_losses(cfg, lg, rg, sd, ct, locs, gts(lv, "gt", int(lv["N"])))
+    for k in ("loss_fcos_cls", "loss_fcos_loc", "loss_fcos_ctr"):
+        close(losses[k].detach(), lv["%s_%s" % (case, k)])
+    tot = losses["loss_fcos_cls"] + 2.0 * losses["loss_fcos_loc"] + 3.0 * losses["loss_fcos_ctr"]
+    tot.backward()
+    for nm, lst in zip(("reg", "std", "ctr"), (rg, sd, ct)):
+        for l in range(5):
+            g = lst[l].grad if lst[l].grad is not None else torch.zeros_like(lst[l])
+            close(g, lv["%s_g%s%d" % (case, nm, l)], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("case,kw", [("pseudo_nll", {}), ("pseudo_kl", dict(kl_loss_type="klloss"))])
+def test_pseudo_regression_kl_term(case, kw):
+    """SEMISUPNET.CONSIST_REG_LOSS other than the TS-better selection: loss_fcos_loc = KLLOSS_WEIGHT * (NLL | KL) on the regression
+    pseudo set (fcos_outputs.py:571-585)."""
+    lv = dict(np.load(os.path.join(G, "fcos_loss_variants.npz")))
+    cfg = O.FCOSCfg(reg_unsup_loss="mse_loss_all_raw", **kw)
+    (lg, rg, sd, ct), locs = head(lv, True)
+    N = int(lv["N"])
+    losses, _ = O.fcos_pseudo_losses(cfg, lg, rg, sd, ct, locs, {"cls": gts(lv, "pcls_gt", N), "reg": gts(lv, "preg_gt", N)})
+    for k in ("loss_fcos_cls", "loss_fcos_loc", "loss_fcos_ctr"):
+        close(losses[k].detach().float(), lv["%s_%s" % (case, k)])
+    assert "teacher_better_student" not in losses
+    tot = losses["loss_fcos_cls"] + 2.0 * losses["loss_fcos_loc"] + 3.0 * losses["loss_fcos_ctr"]
+    tot.backward()
+    for nm, lst in zip(("reg", "std", "ctr"), (rg, sd, ct)):
+        for l in range(5):
+            g = lst[l].grad if lst[l].grad is not None else torch.zeros_like(lst[l])
+            close(g, lv["%s_g%s%d" % (case, nm, l)], rtol=1e-4, atol=1e-7)

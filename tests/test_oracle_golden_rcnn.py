@@ -34,15 +34,16 @@ def test_box2box_xyxy(rc):
 
 
 @pytest.mark.parametrize("branch", ["supervised", "unsup_data_train"])
-def test_roi_losses(rc, branch):
+@pytest.mark.parametrize("pre,gamma", [("rc", 1.5), ("rcce", 0.0)])  # FocalLoss_BoundaryVar | CrossEntropy_BoundaryVar predictor
+def test_roi_losses(rc, branch, pre, gamma):
     scores, deltas, std = (T(rc["rc_%s_%s" % (branch, k)]).clone().requires_grad_(True) for k in ("scores", "deltas", "std"))
     cls, prop, gtb, gstd = T(rc["rc_cls"]), T(rc["rc_prop"]), T(rc["rc_gtb"]), T(rc["rc_gstd"])
-    lc = O.softmax_focal(scores, cls)
+    lc = O.softmax_focal(scores, cls, gamma)
     lb = O.roi_box_reg_loss(prop, gtb, deltas, std, cls) if branch == "supervised" else O.roi_box_reg_pseudo_loss(prop, gtb, deltas, std, gstd, cls)
-    close(lc, rc["rc_%s_loss_cls" % branch]); close(lb, rc["rc_%s_loss_box_reg" % branch])
+    close(lc, rc["%s_%s_loss_cls" % (pre, branch)]); close(lb, rc["%s_%s_loss_box_reg" % (pre, branch)])
     (lc + 2.0 * lb).backward()
     for k, v in (("scores", scores), ("deltas", deltas), ("std", std)):
-        close(v.grad if v.grad is not None else torch.zeros_like(v), rc["rc_%s_g%s" % (branch, k)], rtol=1e-4, atol=1e-7)
+        close(v.grad if v.grad is not None else torch.zeros_like(v), rc["%s_%s_g%s" % (pre, branch, k)], rtol=1e-4, atol=1e-7)
 
 
 def test_roi_inference(rc):

@@ -92,11 +92,13 @@ def test_match_boxes_and_lowq_vs_oracle():
 
 
 @pytest.mark.parametrize("branch", ["supervised", "unsup_data_train"])
-def test_predictor_losses_vs_reference_golden(rc, branch):
-    from ubteacher.modeling.rcnn import FastRCNNFocaltLossBoundaryVarOutputLayers
+@pytest.mark.parametrize("pre", ["rc", "rcce"])  # MODEL.ROI_HEADS.LOSS FocalLoss_BoundaryVar | CrossEntropy_BoundaryVar
+def test_predictor_losses_vs_reference_golden(rc, branch, pre):
+    from ubteacher.modeling import rcnn as R_
     from ubteacher.params import ParamStore
     st = ParamStore()
-    pred = FastRCNNFocaltLossBoundaryVarOutputLayers(rcnn_cfg(), st, 1024, "roi_heads.box_predictor")
+    klass = R_.FastRCNNFocaltLossBoundaryVarOutputLayers if pre == "rc" else R_.FastRCNNCrossEntropyBoundaryVarOutputLayers
+    pred = klass(rcnn_cfg(), st, 1024, "roi_heads.box_predictor")
     R = rc["rc_cls"].shape[0]
     pad = 4  # empty slots must be ignored
     def padded(x, fill=0.0):
@@ -106,11 +108,12 @@ def test_predictor_losses_vs_reference_golden(rc, branch):
     sampled = dict(gt_classes=torch.cat([T(rc["rc_cls"]).long(), torch.full((pad,), -1)]).to(DEV)[None],
                    proposal_boxes=padded(rc["rc_prop"])[None], gt_boxes=padded(rc["rc_gtb"])[None], gt_loc_std=padded(rc["rc_gstd"])[None])
     ls = pred.losses((scores, deltas, std), sampled, branch)
-    close(ls["loss_cls"], rc["rc_%s_loss_cls" % branch], rtol=2e-5); close(ls["loss_box_reg"], rc["rc_%s_loss_box_reg" % branch], rtol=2e-5)
+    close(ls["loss_cls"], rc["%s_%s_loss_cls" % (pre, branch)], rtol=2e-5)
+    close(ls["loss_box_reg"], rc["%s_%s_loss_box_reg" % (pre, branch)], rtol=2e-5)
     (ls["loss_cls"] + 2.0 * ls["loss_box_reg"]).backward()
     for k, v in (("scores", scores), ("deltas", deltas), ("std", std)):
         gv = v.grad if v.grad is not None else torch.zeros_like(v)
-        close(gv[:R], rc["rc_%s_g%s" % (branch, k)], rtol=1e-4, atol=2e-7)
+        close(gv[:R], rc["%s_%s_g%s" % (pre, branch, k)], rtol=1e-4, atol=2e-7)
         assert float(gv[R:].abs().max()) == 0.0
 
 

@@ -177,3 +177,48 @@ def test_rcnn_step_amp_close_to_fp32():
     for k in ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"):
         a, b = recs[True][k], recs[False][k]
         assert np.isfinite(a) and abs(a - b) <= 5e-2 * max(abs(b), 1e-6), (k, a, b)
+
+
+def test_rcnn_evaluation_loop_runs_and_rescales():
+    """UBRCNNTeacherTrainer.test(): the eval-mode model runs `inference` (RPN test top-k -> box head -> fast_rcnn_inference) over a
+    fixed-length loader, detections are rescaled to the ORIGINAL image size and the COCO box-AP dict comes back; the inference
+    boxes / scores / classes of the first image equal the CPU oracle's teacher path on the same weights."""
+    from ubteacher.data.synthetic import SyntheticTestLoader
+    from ubteacher.engine import UBRCNNTeacherTrainer
+    from ubteacher.evaluation import COCOBoxEvaluator
+
+    class Tr(UBRCNNTeacherTrainer):
+        @classmethod
+        def build_test_loader(cls, cfg, dataset_name):
+            return SyntheticTestLoader(cfg, num_images=3, height=H, width=W, orig_scale=1.5)
+
+    cfg = rcnn_cfg()
+    torch.manual_seed(0)
+    prod, orac = make_batch(31, 2, 2, H, W, "cuda")
+    tr = Tr(cfg, data_loader=FixedLoader(prod))
+    mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1)
+    pstd = torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1)
+    loader = Tr.build_test_loader(cfg, "x")
+    first = loader.items[0][0]["image"].cpu()
+    sd = tune(cpu_state(tr.model), [first], mean, pstd)
+    tr.model_teacher.load_state_dict(sd)
+    ev = COCOBoxEvaluator(80)
+    was = tr.model_teacher.training
+    res = Tr.test(cfg, tr.model_teacher, evaluators=ev)
+    assert tr.model_teacher.training == was
+    assert set(res["bbox"]) == {"AP", "AP50", "AP75", "APs", "APm", "APl"}
+    assert res["_speed"]["images"] >= 1
+    n_det = sum(len(p["scores"]) for p in ev._pred.values())
+    assert n_det > 0
+    for p in ev._pred.values():
+        if len(p["scores"]):
+            assert p["boxes"][:, 2].max() <= W * 1.5 + 1e-3 and p["boxes"][:, 3].max() <= H * 1.5 + 1e-3
+    # first image vs the oracle (test-time RPN top-k 1000 -> 1000, score 0.05, NMS 0.5, 100 / image), boxes scaled by 1.5
+    dets, _ = O.rcnn_teacher(sd, [first], mean, pstd, pre_topk=cfg.MODEL.RPN.PRE_NMS_TOPK_TEST, post_topk=cfg.MODEL.RPN.POST_NMS_TOPK_TEST,
+                                thr=-1.0)
+    mine = ev._pred[0]
+    ob, osc, ocl = dets[0]["boxes"] * 1.5, dets[0]["scores"], dets[0]["classes"]
+    assert len(osc) == len(mine["scores"]) and len(osc) > 0
+    assert np.array_equal(np.asarray(mine["classes"]), ocl.numpy())
+    assert np.allclose(np.asarray(mine["scores"]), osc.numpy(), rtol=1e-3, atol=1e-5)
+    assert np.allclose(np.asarray(mine["boxes"]), ob.numpy(), rtol=1e-3, atol=5e-2)

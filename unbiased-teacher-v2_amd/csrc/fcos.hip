@@ -236,7 +236,8 @@ __device__ __forceinline__ float min_grad(float a, float b) { return a < b ? 1.f
 __device__ __forceinline__ float max_grad(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }
 
 // giou loss (1 - giou) on ltrb with +1 smoothing on the IoU only; optionally its gradient wrt d
-__device__ __forceinline__ float giou_ltrb(const float* d, const float* t, float* iou_out, float* grad) {
+// loc_type (MODEL.FCOS.LOC_LOSS_TYPE, iou_loss.py:64-69): 0 giou (1 - giou), 1 iou (-log iou), 2 linear_iou (1 - iou)
+__device__ __forceinline__ float giou_ltrb(const float* d, const float* t, float* iou_out, float* grad, int loc_type = 0) {
   const float ta = (t[0] + t[2]) * (t[1] + t[3]);
   const float pw = d[0] + d[2], ph = d[1] + d[3];
   const float pa = pw * ph;
@@ -262,16 +263,26 @@ __device__ __forceinline__ float giou_ltrb(const float* d, const float* t, float
       const float diou = (dI * (U + 1.f) - (I + 1.f) * dU) / ((U + 1.f) * (U + 1.f));
       // giou = iou - 1 + U/ac
       const float dgiou = diou + dU / ac - U * dac / (ac * ac);
-      grad[b] = -dgiou;
+      // three plain assignments, not one nested ?: - hipcc (ROCm 7.2) mis-folded `t == 1 ? -diou / iou : -diou` into the un-divided
+      // numerator for t == 2 (caught by tests/test_fcos_kernels_gpu.py::test_supervised_loss_variants_vs_reference_golden[loclinear])
+      float g = -diou;
+      if (loc_type == 1) g = g / iou;
+      if (loc_type == 0) g = -dgiou;
+      grad[b] = g;
     }
   }
-  return 1.f - giou;
+  return loc_type == 0 ? 1.f - giou : (loc_type == 1 ? -logf(iou) : 1.f - iou);
 }
+
+// flags of the positive-location kernels (config-reachable variants; every shipped YAML uses 0)
+#define LT_QUALITY_IOU 1  // MODEL.FCOS.QUALITY_EST "iou": the centerness target is IoU(pred.detach, target) (fcos_outputs.py:355-359)
+#define LT_KLLOSS 2       // MODEL.FCOS.KL_LOSS_TYPE "klloss": column 4 = sum_b exp(-std_b)*smoothL1_1(d_b - t_b) + std_b/2 (kl_loss.py:11-66)
+#define LT_LOC_SHIFT 2    // bits 2-3: loc_type
 
 template <int R1>
 __global__ __launch_bounds__(128) void fcos_loc_fwd_kernel(const int* __restrict__ labels, const float* __restrict__ box, int BS,
                                                          const float* __restrict__ reg_targets, const float* __restrict__ bvars,
-                                                         size_t P, int num_classes, float ts_better, float ts_cert,
+                                                         size_t P, int num_classes, float ts_better, float ts_cert, int flags,
                                                          float* __restrict__ partial) {
   __shared__ float red[2];
   float acc[LT_NSUM];
@@ -287,19 +298,29 @@ __global__ __launch_bounds__(128) void fcos_loc_fwd_kernel(const int* __restrict
     integral4<R1>(row, d, (float(*)[R1]) nullptr);
 #pragma unroll
     for (int b = 0; b < 4; ++b) t[b] = reg_targets[i * 4 + b];
-    const float ctr_t = sqrtf((fminf(t[0], t[2]) / fmaxf(t[0], t[2])) * (fminf(t[1], t[3]) / fmaxf(t[1], t[3])));
+    float ctr_t = sqrtf((fminf(t[0], t[2]) / fmaxf(t[0], t[2])) * (fminf(t[1], t[3]) / fmaxf(t[1], t[3])));
     float iou;
-    const float gl = giou_ltrb(d, t, &iou, nullptr);
+    const float gl = giou_ltrb(d, t, &iou, nullptr, flags >> LT_LOC_SHIFT);
+    if (flags & LT_QUALITY_IOU) ctr_t = iou;
     float nll = 0.f;
     const float* sp = row + 4 * R1;
+    if (flags & LT_KLLOSS) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const float sg = 1.f / (1.f + expf(-sp[b]));
-      const float sq = sg * sg;
-      const float df = t[b] - d[b];
-      nll += (df * df) / (2.f * sq) + 0.5f * logf(sq);
+      for (int b = 0; b < 4; ++b) {
+        const float n = fabsf(d[b] - t[b]);
+        nll += expf(-sp[b]) * (n < 1.f ? 0.5f * n * n : n - 0.5f) + 0.5f * sp[b];
+      }
+      iou = 1.f;  // KLLoss ignores the IoU weight
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float sg = 1.f / (1.f + expf(-sp[b]));
+        const float sq = sg * sg;
+        const float df = t[b] - d[b];
+        nll += (df * df) / (2.f * sq) + 0.5f * logf(sq);
+      }
+      nll += 2.f * logf(2.f * 3.14159265358979323846f);
     }
-    nll += 2.f * logf(2.f * 3.14159265358979323846f);
     const float c = row[4 * R1 + 4];
     const float bce = fmaxf(c, 0.f) - c * ctr_t + log1pf(expf(-fabsf(c)));
     acc[0] += 1.f;
@@ -332,7 +353,7 @@ __global__ __launch_bounds__(128) void fcos_loc_fwd_kernel(const int* __restrict
 template <int R1>
 __global__ __launch_bounds__(128) void fcos_loc_bwd_kernel(const int* __restrict__ labels, const float* __restrict__ box, int BS,
                                                          const float* __restrict__ reg_targets, const float* __restrict__ bvars,
-                                                         size_t P, int num_classes, float ts_better, float ts_cert,
+                                                         size_t P, int num_classes, float ts_better, float ts_cert, int flags,
                                                          const float* __restrict__ coef, float* __restrict__ dbox) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -349,18 +370,27 @@ __global__ __launch_bounds__(128) void fcos_loc_bwd_kernel(const int* __restrict
     integral4<R1>(row, d, prob);
 #pragma unroll
     for (int b = 0; b < 4; ++b) t[b] = reg_targets[i * 4 + b];
-    const float ctr_t = sqrtf((fminf(t[0], t[2]) / fmaxf(t[0], t[2])) * (fminf(t[1], t[3]) / fmaxf(t[1], t[3])));
+    float ctr_t = sqrtf((fminf(t[0], t[2]) / fmaxf(t[0], t[2])) * (fminf(t[1], t[3]) / fmaxf(t[1], t[3])));
     float iou, gg[4];
-    giou_ltrb(d, t, &iou, gg);
+    giou_ltrb(d, t, &iou, gg, flags >> LT_LOC_SHIFT);
+    if (flags & LT_QUALITY_IOU) ctr_t = iou;  // detached target
     const float* sp = row + 4 * R1;
     float dd[4], ds[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const float sg = 1.f / (1.f + expf(-sp[b]));
       const float df = t[b] - d[b];
-      // nll_b = df^2/(2 sg^2) + log(sg);  d/dd = -df/sg^2 ; d/ds = (1-sg) * (1 - df^2/sg^2)
-      dd[b] = c_giou * ctr_t * gg[b] + c_nll * iou * (-df / (sg * sg));
-      ds[b] = c_nll * iou * (1.f - sg) * (1.f - (df * df) / (sg * sg));
+      if (flags & LT_KLLOSS) {
+        // kl_b = exp(-s) * sl1(n) + s/2, n = |d - t|: d/dd = exp(-s) * min(n, 1) * sign(d - t); d/ds = 1/2 - exp(-s) * sl1(n)
+        const float n = fabsf(df), es = expf(-sp[b]);
+        const float sgn = df < 0.f ? 1.f : (df > 0.f ? -1.f : 0.f);
+        dd[b] = c_giou * ctr_t * gg[b] + c_nll * es * fminf(n, 1.f) * sgn;
+        ds[b] = c_nll * (0.5f - es * (n < 1.f ? 0.5f * n * n : n - 0.5f));
+      } else {
+        // nll_b = df^2/(2 sg^2) + log(sg);  d/dd = -df/sg^2 ; d/ds = (1-sg) * (1 - df^2/sg^2)
+        dd[b] = c_giou * ctr_t * gg[b] + c_nll * iou * (-df / (sg * sg));
+        ds[b] = c_nll * iou * (1.f - sg) * (1.f - (df * df) / (sg * sg));
+      }
       if (bvars) {
         const float cs = 1.f - sg;
         const float ct = 1.f - 1.f / (1.f + expf(-bvars[i * 4 + b]));
@@ -558,20 +588,20 @@ int utv2_sigmoid_focal_bwd(const float* logits, const int* labels, int64_t P, in
 // sums[8]: see LT_NSUM comment.  ws >= LOC_BLOCKS*8 floats.  reg_max+1 must be 17.
 int utv2_fcos_loc_terms_fwd(const int* labels, const float* box, int box_stride, const float* reg_targets,
                             const float* bvars, int64_t P, int num_classes, int reg_max, float ts_better, float ts_cert,
-                            float* sums, float* ws, hipStream_t stream) {
-  if (!labels || !box || !reg_targets || !sums || !ws || reg_max != 16 || box_stride < 4 * 17 + 5 || (box_stride & 3)) return UTV2_EARG;
+                            int flags, float* sums, float* ws, hipStream_t stream) {
+  if (!labels || !box || !reg_targets || !sums || !ws || reg_max != 16 || flags < 0 || (flags >> LT_LOC_SHIFT) > 2 || box_stride < 4 * 17 + 5 || (box_stride & 3)) return UTV2_EARG;
   hipLaunchKernelGGL((fcos_loc_fwd_kernel<17>), dim3(LOC_BLOCKS), dim3(128), 0, stream, labels, box, box_stride, reg_targets,
-                     bvars, (size_t)P, num_classes, ts_better, ts_cert, ws);
+                     bvars, (size_t)P, num_classes, ts_better, ts_cert, flags, ws);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(LT_NSUM), dim3(256), 0, stream, (const float*)ws, LOC_BLOCKS, LT_NSUM, sums);
   return utv2_launch_status();
 }
 
 int utv2_fcos_loc_terms_bwd(const int* labels, const float* box, int box_stride, const float* reg_targets,
                             const float* bvars, int64_t P, int num_classes, int reg_max, float ts_better, float ts_cert,
-                            const float* coef, float* dbox, hipStream_t stream) {
-  if (!labels || !box || !reg_targets || !coef || !dbox || reg_max != 16 || box_stride < 4 * 17 + 5 || (box_stride & 3)) return UTV2_EARG;
+                            int flags, const float* coef, float* dbox, hipStream_t stream) {
+  if (!labels || !box || !reg_targets || !coef || !dbox || reg_max != 16 || flags < 0 || (flags >> LT_LOC_SHIFT) > 2 || box_stride < 4 * 17 + 5 || (box_stride & 3)) return UTV2_EARG;
   hipLaunchKernelGGL((fcos_loc_bwd_kernel<17>), dim3(cdiv(P, 128)), dim3(128), 0, stream, labels, box, box_stride, reg_targets,
-                     bvars, (size_t)P, num_classes, ts_better, ts_cert, coef, dbox);
+                     bvars, (size_t)P, num_classes, ts_better, ts_cert, flags, coef, dbox);
   return utv2_launch_status();
 }
 

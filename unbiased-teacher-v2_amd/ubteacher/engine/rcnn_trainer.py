@@ -102,8 +102,7 @@ def _make(base):
             self.optimizer.step(grad_scale=gscale)
             return losses
 
-        @classmethod
-        def test(cls, cfg, model, evaluators=None):
-            raise NotImplementedError("the evaluation loop (SURVEY 8f rank 3) is built for the FCOS trainer only so far")
+        # test() / build_test_loader() / build_evaluator() come from the shared base (reference trainer.py:986-1023 ≡ :554-608): the
+        # eval-mode model runs `inference` (RPN test top-k -> box head -> fast_rcnn_inference -> detector_postprocess).
 
     return UBRCNNTeacherTrainer

@@ -304,6 +304,37 @@ class _TrainerBase:
             self._last_metrics = md
         return self._last_metrics
 
+    # -- evaluation path (trainer.py:554-608; SURVEY 8f rank 3) --------------------------------------------------------
+    @classmethod
+    def build_test_loader(cls, cfg, dataset_name):
+        """no dataset registry here: every test-set name resolves to the synthetic COCO-shaped test loader"""
+        from ..data.synthetic import SyntheticTestLoader
+        return SyntheticTestLoader(cfg)
+
+    @classmethod
+    def build_evaluator(cls, cfg, dataset_name, output_folder=None):
+        from ..evaluation import COCOBoxEvaluator
+        rcnn = cfg.SEMISUPNET.Trainer == "ubteacher_rcnn"
+        return COCOBoxEvaluator(cfg.MODEL.ROI_HEADS.NUM_CLASSES if rcnn else cfg.MODEL.FCOS.NUM_CLASSES)
+
+    @classmethod
+    def test(cls, cfg, model, evaluators=None):
+        """dict of result metrics per test set (the single dict itself when there is one), reference trainer.py:554-608"""
+        from ..evaluation import inference_on_dataset
+        names = list(cfg.DATASETS.TEST) or ["synthetic_val"]
+        if evaluators is not None and not isinstance(evaluators, (list, tuple)):
+            evaluators = [evaluators]
+        if evaluators is not None:
+            assert len(names) == len(evaluators), "{} != {}".format(len(names), len(evaluators))
+        results = OrderedDict()
+        for idx, name in enumerate(names):
+            loader = cls.build_test_loader(cfg, name)
+            evaluator = evaluators[idx] if evaluators is not None else cls.build_evaluator(cfg, name)
+            results[name] = inference_on_dataset(model, loader, evaluator, cfg)
+        if len(results) == 1:
+            results = list(results.values())[0]
+        return results
+
 
 class UBTeacherTrainer(_TrainerBase):
     """FCOS trainer (reference trainer.py:38-608)."""
@@ -431,36 +462,6 @@ class UBTeacherTrainer(_TrainerBase):
         gscale = self._allreduce_grads()
         self.optimizer.step(grad_scale=gscale)
         return losses
-
-    # -- evaluation path (trainer.py:554-608; SURVEY 8f rank 3) --------------------------------------------------------
-    @classmethod
-    def build_test_loader(cls, cfg, dataset_name):
-        """no dataset registry here: every test-set name resolves to the synthetic COCO-shaped test loader"""
-        from ..data.synthetic import SyntheticTestLoader
-        return SyntheticTestLoader(cfg)
-
-    @classmethod
-    def build_evaluator(cls, cfg, dataset_name, output_folder=None):
-        from ..evaluation import COCOBoxEvaluator
-        return COCOBoxEvaluator(cfg.MODEL.FCOS.NUM_CLASSES if "FCOS" in cfg.MODEL else None)
-
-    @classmethod
-    def test(cls, cfg, model, evaluators=None):
-        """dict of result metrics per test set (the single dict itself when there is one), reference trainer.py:554-608"""
-        from ..evaluation import inference_on_dataset
-        names = list(cfg.DATASETS.TEST) or ["synthetic_val"]
-        if evaluators is not None and not isinstance(evaluators, (list, tuple)):
-            evaluators = [evaluators]
-        if evaluators is not None:
-            assert len(names) == len(evaluators), "{} != {}".format(len(names), len(evaluators))
-        results = OrderedDict()
-        for idx, name in enumerate(names):
-            loader = cls.build_test_loader(cfg, name)
-            evaluator = evaluators[idx] if evaluators is not None else cls.build_evaluator(cfg, name)
-            results[name] = inference_on_dataset(model, loader, evaluator, cfg)
-        if len(results) == 1:
-            results = list(results.values())[0]
-        return results
 
 
 from .rcnn_trainer import _make as _make_rcnn  # noqa: E402

@@ -23,7 +23,10 @@ def inference_on_dataset(model, data_loader, evaluator, cfg=None):
     total = len(data_loader)
     if evaluator is not None:
         evaluator.reset()
-    nms_method = cfg.MODEL.FCOS.NMS_CRITERIA_TEST if cfg is not None and "FCOS" in cfg.MODEL else None
+    # the FCOS detectors take the test-time NMS criterion (reference evaluator.py:57); the two-stage model is called plainly, as
+    # Detectron2's own inference_on_dataset does for the Faster-RCNN trainer
+    one_stage = cfg is not None and "FCOS" in cfg.MODEL and cfg.SEMISUPNET.Trainer != "ubteacher_rcnn"
+    nms_method = cfg.MODEL.FCOS.NMS_CRITERIA_TEST if one_stage else None
     num_warmup = min(5, max(total - 1, 0))
     compute, images = 0.0, 0
     with inference_context(model), torch.no_grad():

@@ -396,21 +396,24 @@ def sigmoid_focal_bwd(logits, labels, alpha, gamma, coef, out=None):
     return out
 
 
-def fcos_loc_terms_fwd(labels, box, reg_targets, bvars, num_classes, reg_max, ts_better, ts_cert):
+LT_QUALITY_IOU, LT_KLLOSS, LT_LOC_IOU, LT_LOC_LINEAR_IOU = 1, 2, 1 << 2, 2 << 2  # variant flags of the fcos_loc_terms kernels
+
+
+def fcos_loc_terms_fwd(labels, box, reg_targets, bvars, num_classes, reg_max, ts_better, ts_cert, flags=0):
     P, BS = box.shape
     sums = torch.empty(8, dtype=torch.float32, device=box.device)
     ws = workspace(4096, box.device, "loss")
     call("utv2_fcos_loc_terms_fwd", _p(labels), _p(box), BS, _p(reg_targets), _p(bvars), P, num_classes, reg_max,
-         float(ts_better), float(ts_cert), _p(sums), _p(ws), _stream())
+         float(ts_better), float(ts_cert), int(flags), _p(sums), _p(ws), _stream())
     return sums
 
 
-def fcos_loc_terms_bwd(labels, box, reg_targets, bvars, num_classes, reg_max, ts_better, ts_cert, coef, out=None):
+def fcos_loc_terms_bwd(labels, box, reg_targets, bvars, num_classes, reg_max, ts_better, ts_cert, coef, out=None, flags=0):
     P, BS = box.shape
     if out is None:
         out = torch.empty_like(box)
     call("utv2_fcos_loc_terms_bwd", _p(labels), _p(box), BS, _p(reg_targets), _p(bvars), P, num_classes, reg_max,
-         float(ts_better), float(ts_cert), _p(coef), _p(out), _stream())
+         float(ts_better), float(ts_cert), int(flags), _p(coef), _p(out), _stream())
     return out
 
 

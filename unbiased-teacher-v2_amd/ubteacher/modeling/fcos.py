@@ -128,7 +128,9 @@ class FCOSHead:
     def __init__(self, cfg, store, in_channels, prefix):
         fc = cfg.MODEL.FCOS
         assert fc.NORM == "GN", "only the GN towers of the shipped configs are built"
-        assert fc.REG_DISCRETE and fc.KL_LOSS and fc.REG_MAX == 16, "UTv2 FCOS configs: REG_DISCRETE + KL_LOSS, REG_MAX 16"
+        assert fc.REG_DISCRETE and fc.REG_MAX == 16, "UTv2 FCOS configs: REG_DISCRETE, REG_MAX 16"
+        # KL_LOSS False (config-reachable, fcos.py:300-307 then builds no bbox_pred_std): the fused box conv keeps its 4 std channels so
+        # the [reg | std | ctr] row layout is one layout; they then receive zero gradient and no consumer reads them.
         assert not fc.USE_DEFORMABLE
         self.num_classes = fc.NUM_CLASSES
         self.reg_max = fc.REG_MAX
@@ -222,10 +224,22 @@ class FCOSOutputs:
         assert cfg.SEMISUPNET.CLS_LOSS_METHOD == "focal"
         self.reg_max = fc.REG_MAX
         self.unify_ctrcls = fc.UNIFY_CTRCLS
-        assert fc.KL_LOSS and fc.KL_LOSS_TYPE == "nlloss" and fc.LOC_LOSS_TYPE == "giou" and fc.QUALITY_EST == "centerness"
+        # config-reachable variants (fcos_outputs.py:165-186): the positive-location kernels take them as flags
+        self.kl_loss, self.kl_loss_type = fc.KL_LOSS, fc.KL_LOSS_TYPE
+        if self.kl_loss and self.kl_loss_type not in ("klloss", "nlloss"):
+            raise ValueError("MODEL.FCOS.KL_LOSS_TYPE must be 'klloss' or 'nlloss'")
+        if fc.LOC_LOSS_TYPE not in ("giou", "iou", "linear_iou"):
+            raise NotImplementedError("MODEL.FCOS.LOC_LOSS_TYPE %r" % (fc.LOC_LOSS_TYPE,))  # iou_loss.py:70-71
+        if fc.QUALITY_EST not in ("centerness", "iou"):
+            raise ValueError("MODEL.FCOS.QUALITY_EST must be 'centerness' or 'iou'")
+        if fc.LOC_FUN_ALL != "mean":
+            raise NotImplementedError("MODEL.FCOS.LOC_FUN_ALL %r (only 'mean', the config.py default, is built)" % (fc.LOC_FUN_ALL,))
+        self.loc_flags = {"giou": 0, "iou": hip.LT_LOC_IOU, "linear_iou": hip.LT_LOC_LINEAR_IOU}[fc.LOC_LOSS_TYPE]
+        if self.kl_loss and self.kl_loss_type == "klloss":
+            self.loc_flags |= hip.LT_KLLOSS
+        self.quality_iou = fc.QUALITY_EST == "iou"
         self.kl_loss_weight = fc.KLLOSS_WEIGHT
         self.reg_unsup_loss = cfg.SEMISUPNET.CONSIST_REG_LOSS
-        assert self.reg_unsup_loss == "ts_locvar_better_nms_nll_l1"
         self.tsbetter_reg = cfg.SEMISUPNET.TS_BETTER
         self.tsbetter_reg_cert = cfg.SEMISUPNET.TS_BETTER_CERT
         soi, prev = [], -1
@@ -253,6 +267,12 @@ class FCOSOutputs:
         den = (pair[1] / ws).clamp(min=1e-6)
         return npa, den
 
+    def _kl_mean(self, sums):
+        """LOC_FUN_ALL "mean" of the KL-type term: NLLoss averages over positives (kl_loss.py:93-105), KLLoss over positives x 4
+        boundaries (kl_loss.py:59-60)."""
+        n = sums[0].detach().clamp(min=1.0)
+        return sums[4] / (4.0 * n) if self.kl_loss_type == "klloss" else sums[4] / n
+
     # -- supervised branch (fcos_outputs.py:212-444) -------------------------------------------------
     def losses(self, head_out, level_hw, gt, branch="labeled", active=None):
         """active (optional, uint8 [N]): images of the batch this branch owns (fused student pass); the others are ignored."""
@@ -261,15 +281,14 @@ class FCOSOutputs:
         logits_all, box_all = head_out["logits"], head_out["box"]
         labels, reg_t, bvars, gt_inds = self._targets(level_hw, gt, drop_empty=1, active=active)
         focal = ops.focal_loss_sum(logits_all, labels, self.focal_loss_alpha, self.focal_loss_gamma)
-        sums = ops.fcos_loc_terms(box_all, labels, reg_t, None, (self.num_classes, self.reg_max, 0.0, 0.0))
+        flags = self.loc_flags | (hip.LT_QUALITY_IOU if self.quality_iou else 0)  # QUALITY_EST acts on this branch only (:353-359)
+        sums = ops.fcos_loc_terms(box_all, labels, reg_t, None, (self.num_classes, self.reg_max, 0.0, 0.0, flags))
         npa, den = self._normalisers(sums)
-        w = self.kl_loss_weight
-        nll_mean = sums[4] / sums[0].detach().clamp(min=1.0)
-        losses = {
-            "loss_fcos_cls": focal[0] / npa,
-            "loss_fcos_loc": w * (w * nll_mean) + sums[3] / den,
-            "loss_fcos_ctr": sums[2] / npa,
-        }
+        loc = sums[3] / den
+        if self.kl_loss:
+            w = self.kl_loss_weight
+            loc = w * (w * self._kl_mean(sums)) + loc  # weight applied twice (:381/:397, :400/:416)
+        losses = {"loss_fcos_cls": focal[0] / npa, "loss_fcos_loc": loc, "loss_fcos_ctr": sums[2] / npa}
         extras = {"labels": labels, "reg_targets": reg_t, "gt_inds": gt_inds, "loss_denorm": den, "sums": sums}
         return extras, losses
 
@@ -282,17 +301,23 @@ class FCOSOutputs:
             labels, reg_t, bvars, gt_inds = self._targets(level_hw, gt, drop_empty=0, active=active)
             if labeltype == "cls":
                 focal = ops.focal_loss_sum(logits_all, labels, self.focal_loss_alpha, self.focal_loss_gamma)
-                sums = ops.fcos_loc_terms(box_all, labels, reg_t, None, (self.num_classes, self.reg_max, 0.0, 0.0))
+                sums = ops.fcos_loc_terms(box_all, labels, reg_t, None, (self.num_classes, self.reg_max, 0.0, 0.0, self.loc_flags))
                 npa, den = self._normalisers(sums)
                 losses["loss_fcos_cls"] = focal[0] / npa
                 ctr = sums[2] / npa
                 losses["loss_fcos_ctr"] = ctr * 0 if self.unify_ctrcls else ctr
             elif labeltype == "reg":
-                sums = ops.fcos_loc_terms(box_all, labels, reg_t, bvars,
-                                          (self.num_classes, self.reg_max, self.tsbetter_reg, self.tsbetter_reg_cert))
+                if not self.kl_loss:
+                    raise ValueError("pseudo regression loss needs MODEL.FCOS.KL_LOSS")  # fcos_outputs.py:587-588
+                tsbetter = self.reg_unsup_loss == "ts_locvar_better_nms_nll_l1"
+                sums = ops.fcos_loc_terms(box_all, labels, reg_t, bvars if tsbetter else None,
+                                          (self.num_classes, self.reg_max, self.tsbetter_reg, self.tsbetter_reg_cert, self.loc_flags))
                 self._normalisers(sums)  # the reference issues the same two reductions here (:504,:521)
-                losses["loss_fcos_loc"] = sums[6] / sums[5].detach().clamp(min=1.0)
-                losses["teacher_better_student"] = sums[5].detach()
+                if tsbetter:
+                    losses["loss_fcos_loc"] = sums[6] / sums[5].detach().clamp(min=1.0)
+                    losses["teacher_better_student"] = sums[5].detach()
+                else:  # any other CONSIST_REG_LOSS: KLLOSS_WEIGHT * (NLL | KL) term on the pseudo set (:571-585)
+                    losses["loss_fcos_loc"] = self.kl_loss_weight * self._kl_mean(sums)
             else:
                 raise ValueError(labeltype)
             extras["labels_" + labeltype] = labels

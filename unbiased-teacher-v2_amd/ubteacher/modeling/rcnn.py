@@ -304,6 +304,7 @@ class PseudoLabRPN:
 # ---------------------------------------------------------------------------------------------------
 class FastRCNNFocaltLossBoundaryVarOutputLayers:
     """Predictor + losses + inference (reference fast_rcnn.py:715-1292)."""
+    focal_gamma = 1.5  # comput_focal_loss, fast_rcnn.py:925-936
 
     def __init__(self, cfg, store, in_dim, prefix):
         rh, bh = cfg.MODEL.ROI_HEADS, cfg.MODEL.ROI_BOX_HEAD
@@ -351,7 +352,7 @@ class FastRCNNFocaltLossBoundaryVarOutputLayers:
         cls = sampled["gt_classes"].reshape(-1)           # -1 = empty slot
         Rn = (cls >= 0).sum().clamp(min=1).float()        # gt_classes.numel() of the reference
         tgt = cls.to(torch.int32).contiguous()
-        loss_cls = ops.softmax_focal_sum(scores, tgt, 1.5)[0] / Rn
+        loss_cls = ops.softmax_focal_sum(scores, tgt, self.focal_gamma)[0] / Rn
         fg = (cls >= 0) & (cls < self.num_classes)
         pb = sampled["proposal_boxes"].reshape(-1, 4)
         gb = sampled["gt_boxes"].reshape(-1, 4)
@@ -425,6 +426,12 @@ class FastRCNNFocaltLossBoundaryVarOutputLayers:
         return out, keep_rows
 
 
+class FastRCNNCrossEntropyBoundaryVarOutputLayers(FastRCNNFocaltLossBoundaryVarOutputLayers):
+    """MODEL.ROI_HEADS.LOSS "CrossEntropy_BoundaryVar" (reference fast_rcnn.py:214-712): the same predictor, box losses and inference;
+    loss_cls is the mean softmax cross-entropy (:389,:400,:412) = the focal form (1-p)^gamma * CE at gamma 0, same kernel."""
+    focal_gamma = 0.0
+
+
 @ROI_HEADS_REGISTRY.register()
 class StandardROIHeadsPseudoLab:
     def __init__(self, cfg, store, in_channels, prefix="roi_heads"):
@@ -453,9 +460,15 @@ class StandardROIHeadsPseudoLab:
             b = store.new((FC,), "decay", lambda t: t.zero_()).export(p + ".bias")
             self.fcs.append(ops.Conv(w, dim_in, FC, 1, 1, 0, bias=b, relu=True))
             dim_in = FC
-        if rh.LOSS != "FocalLoss_BoundaryVar":
-            raise ValueError("Unknown ROI head loss.")  # other predictors: SURVEY 8(f) rank 4
-        self.box_predictor = FastRCNNFocaltLossBoundaryVarOutputLayers(cfg, store, dim_in, prefix + ".box_predictor")
+        if rh.LOSS == "FocalLoss_BoundaryVar":  # roi_heads.py:52-66
+            self.box_predictor = FastRCNNFocaltLossBoundaryVarOutputLayers(cfg, store, dim_in, prefix + ".box_predictor")
+        elif rh.LOSS == "CrossEntropy_BoundaryVar":
+            self.box_predictor = FastRCNNCrossEntropyBoundaryVarOutputLayers(cfg, store, dim_in, prefix + ".box_predictor")
+        elif rh.LOSS in ("CrossEntropy", "FocalLoss"):
+            raise NotImplementedError("MODEL.ROI_HEADS.LOSS %r: the predictors without the boundary-variance head (UTv1) are not part of "
+                                      "the UTv2 path" % (rh.LOSS,))
+        else:
+            raise ValueError("Unknown ROI head loss.")
         self.training = True
         self.sample_keys = None
 

@@ -516,15 +516,16 @@ class _LocTermsFn(torch.autograd.Function):
         ctx.args = args
         ctx.has_bv = bvars is not None
         ctx.save_for_backward(box, labels, reg_targets, bvars if bvars is not None else labels)
-        nc, reg_max, tsb, tsc = args
-        return hip.fcos_loc_terms_fwd(labels, box, reg_targets, bvars, nc, reg_max, tsb, tsc)
+        nc, reg_max, tsb, tsc = args[:4]
+        return hip.fcos_loc_terms_fwd(labels, box, reg_targets, bvars, nc, reg_max, tsb, tsc, flags=args[4] if len(args) > 4 else 0)
 
     @staticmethod
     def backward(ctx, gsums):
         box, labels, reg_targets, bv = ctx.saved_tensors
-        nc, reg_max, tsb, tsc = ctx.args
+        nc, reg_max, tsb, tsc = ctx.args[:4]
         coef = torch.stack((gsums[2], gsums[3], gsums[4], gsums[6])).contiguous().float()
-        d = hip.fcos_loc_terms_bwd(labels, box, reg_targets, bv if ctx.has_bv else None, nc, reg_max, tsb, tsc, coef)
+        d = hip.fcos_loc_terms_bwd(labels, box, reg_targets, bv if ctx.has_bv else None, nc, reg_max, tsb, tsc, coef,
+                                   flags=ctx.args[4] if len(ctx.args) > 4 else 0)
         return d, None, None, None, None
 
 
