@@ -219,6 +219,30 @@ int utv2_softmax_focal_fwd(const float* logits, const int* target, int R, int C,
 int utv2_softmax_focal_bwd(const float* logits, const int* target, int R, int C, float gamma, const float* coef,
                            float* dlogits, utv2_stream_t stream);
 
+/* ---- two-crop data path: the pixel arithmetic of the reference's weak / strong views, on uint8 [H][W][3] images
+ * in HBM, bit-exact to Pillow (which Detectron2 / torchvision / the reference call on the CPU) ------------------------------------- */
+/* detectron2 ResizeTransform.apply_image (used by ubteacher/data/dataset_mapper.py:97-99) = PIL.Image.resize(BILINEAR): Resample.c
+ * two-pass 8.22 fixed-point convolution; flip != 0 also applies HFlipTransform.  ws >= utv2_aug_resize_workspace_bytes bytes */
+int64_t utv2_aug_resize_workspace_bytes(int H, int W, int OH, int OW);
+int utv2_aug_resize_bilinear_u8(const unsigned char* src, int H, int W, unsigned char* dst, int OH, int OW, int flip, void* ws,
+                                utv2_stream_t stream);
+/* ubteacher/data/detection_utils.py:20-23 ColorJitter on PIL images = ImageEnhance.{Brightness,Contrast,Color} = Blend.c ImagingBlend
+ * against a degenerate image: mode 0 black, 1 the constant *mean (from utv2_aug_gray_mean_u8: int(mean(L) + 0.5)), 2 the L image */
+int utv2_aug_gray_mean_u8(const unsigned char* img, int64_t npix, void* sum_ws, int* mean_out, utv2_stream_t stream);
+int utv2_aug_blend_u8(unsigned char* img, int64_t npix, int mode, float alpha, const int* mean, utv2_stream_t stream);
+/* torchvision F_pil.adjust_hue: Convert.c rgb2hsv, H += shift (uint8 wrap), hsv2rgb */
+int utv2_aug_hue_u8(unsigned char* img, int64_t npix, int shift, utv2_stream_t stream);
+/* detection_utils.py:24 RandomGrayscale: convert("L") replicated to 3 channels */
+int utv2_aug_grayscale_u8(unsigned char* img, int64_t npix, utv2_stream_t stream);
+/* data/transforms/augmentation_impl.py:7-22 GaussianBlur = PIL.ImageFilter.GaussianBlur = 3 + 3 passes of BoxBlur.c; one pass per call
+ * (radius / ww / fw = the pass constants of ImagingHorizontalBoxBlur), src != dst */
+int utv2_aug_box_blur_u8(const unsigned char* src, unsigned char* dst, int H, int W, int vertical, int radius, int ww, int fw,
+                         utv2_stream_t stream);
+/* detection_utils.py:27-41 ToTensor -> RandomErasing(value="random") -> ToPILImage: rectangle <- (noise[3][h][w] * 255).byte() */
+int utv2_aug_erase_u8(unsigned char* img, int H, int W, int i, int j, int h, int w, const float* noise, utv2_stream_t stream);
+/* dataset_mapper.py:139-147 image_strong_aug.transpose(2, 0, 1) */
+int utv2_aug_hwc_to_chw_u8(const unsigned char* src, unsigned char* dst, int64_t npix, utv2_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -423,6 +423,66 @@ def gen_fcos_loss_variants(structures, fo):
     print("fcos_loss_variants.npz:", len(d), "arrays")
 
 
+def gen_data_pipeline():
+    """Host logic of the two-crop loader, executed from the reference's own sources:
+    `AspectRatioGroupedSemiSupDatasetTwoCrop` (data/common.py:93-167, imported with a stand-in for its Detectron2 base class) on seeded
+    streams of (width, height) pairs, and `divide_label_unlabel` (data/build.py:30-53, the function's AST node executed on its own -
+    the module imports most of Detectron2) on a small seed table and on dataseed/COCO_supervision.txt."""
+    import ast
+    import json
+    d2c = types.ModuleType("detectron2.data.common")
+
+    class _Base:
+        def __init__(self, dataset, batch_size):
+            self.dataset, self.batch_size = dataset, batch_size
+    d2c.AspectRatioGroupedDataset = _Base
+    d2c.MapDataset = _Base
+    for name in ("detectron2", "detectron2.data"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["detectron2.data.common"] = d2c
+    cm = _load("ubteacher.data.common_ref", REF + "/ubteacher/data/common.py")
+    rng = np.random.default_rng(2024)
+    out = {}
+    for case, (bl, bu, n) in enumerate([(2, 2, 60), (4, 4, 90), (1, 3, 50), (3, 1, 50)]):
+        lab = [(int(rng.integers(300, 700)), int(rng.integers(300, 700))) for _ in range(n)]
+        unl = [(int(rng.integers(300, 700)), int(rng.integers(300, 700))) for _ in range(n)]
+
+        def stream(sizes, tag):
+            for i, (w, h) in enumerate(sizes):
+                yield ({"width": w, "height": h, "id": i, "view": tag + "s"}, {"width": w, "height": h, "id": i, "view": tag + "w"})
+        ds = cm.AspectRatioGroupedSemiSupDatasetTwoCrop((stream(lab, "l"), stream(unl, "u")), (bl, bu))
+        batches = []
+        for ls, lw, us, uw in ds:
+            assert [d["id"] for d in ls] == [d["id"] for d in lw] and [d["id"] for d in us] == [d["id"] for d in uw]
+            batches.append([[d["id"] for d in ls], [d["id"] for d in us]])
+        out["batcher_%d" % case] = dict(bl=bl, bu=bu, label_wh=lab, unlabel_wh=unl, batches=batches)
+    # divide_label_unlabel
+    src = open(REF + "/ubteacher/data/build.py").read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "divide_label_unlabel"][0]
+    ns = {"np": np, "json": json, "PathManager": types.SimpleNamespace(open=open)}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "build.py", "exec"), ns)
+    table = {"10.0": {"0": sorted(int(v) for v in rng.choice(50, 5, replace=False)), "1": [int(v) for v in rng.choice(50, 5, replace=False)]},
+             "30.0": {"0": [int(v) for v in rng.choice(50, 15, replace=False)]}}
+    seed_path = os.path.join(HERE, "supervision_small.json")
+    json.dump(table, open(seed_path, "w"))
+    dicts = [{"image_id": i} for i in range(50)]
+    small = {}
+    for pct, sd in (("10.0", 0), ("10.0", 1), ("30.0", 0)):
+        lab, unl = ns["divide_label_unlabel"](dicts, float(pct), sd, seed_path)
+        small["%s_%d" % (pct, sd)] = dict(label=[d["image_id"] for d in lab], unlabel=[d["image_id"] for d in unl])
+    out["divide_small"] = small
+    # the shipped table: COCO train2017 after Detectron2's empty-annotation filter has 117266 images (README / data seeds)
+    dicts = list(range(117266))
+    big = {}
+    for pct, sd in ((1.0, 0), (5.0, 3), (10.0, 1)):
+        lab, unl = ns["divide_label_unlabel"](dicts, pct, sd, REF + "/dataseed/COCO_supervision.txt")
+        big["%s_%d" % (pct, sd)] = dict(n_label=len(lab), n_unlabel=len(unl), label_sum=int(np.sum(lab)), label_head=[int(v) for v in lab[:8]],
+                                        unlabel_head=[int(v) for v in unl[:8]])
+    out["divide_coco"] = big
+    json.dump(out, open(os.path.join(HERE, "data_pipeline.json"), "w"))
+    print("data_pipeline.json:", len(out), "entries")
+
+
 def gen_small_ops(fo):
     from ubteacher.layers import IOULoss, NLLoss
     g = torch.Generator().manual_seed(7)
@@ -611,5 +671,6 @@ if __name__ == "__main__":
     gen_fcos(structures, fo, pg)
     gen_fcos_center_sample(structures, fo)
     gen_fcos_loss_variants(structures, fo)
+    gen_data_pipeline()
     gen_small_ops(fo)
     gen_ema(tr)

@@ -1,0 +1,95 @@
+"""Two-crop mapper (reference ubteacher/data/dataset_mapper.py:14-157) with the pixel work on the GPU.
+
+One dataset dict -> (strong dict, weak dict): the weak view is the decoded image through ResizeShortestEdge + RandomFlip, the strong
+view is the weak view through build_strong_augmentation; both dicts carry the SAME geometry, `image` uint8 [3][H][W] in cfg.INPUT.FORMAT
+channel order (device resident), the original `height` / `width`, and `instances` (gt_boxes, gt_classes) in the resized frame.
+Host work: JPEG decode (Pillow) when the dict has `file_name`, the random decisions, the box arithmetic.  Everything per-pixel runs in
+csrc/augment.hip, bit-exact to the Pillow arithmetic of the reference pipeline (tests/test_aug_gpu.py, tests/test_data_pipeline_gpu.py).
+Reference quirk kept: the strong augmentation is applied to the image in cfg.INPUT.FORMAT order (BGR) labelled "RGB"
+(dataset_mapper.py:139), so the grey weights / hue act on swapped channels."""
+import copy
+
+import numpy as np
+import torch
+
+from ..d2.structures import Boxes, Instances
+from . import transforms as T
+
+
+def read_image(dataset_dict, fmt="BGR"):
+    """uint8 [H][W][3] numpy in `fmt` channel order: in-memory `image` (RGB) or Pillow decode of `file_name`"""
+    if "image" in dataset_dict and dataset_dict["image"] is not None:
+        img = np.asarray(dataset_dict["image"])
+    else:
+        from PIL import Image
+        with Image.open(dataset_dict["file_name"]) as im:
+            img = np.asarray(im.convert("RGB"))
+    assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+    if fmt == "BGR":
+        img = img[:, :, ::-1]
+    elif fmt != "RGB":
+        raise NotImplementedError("INPUT.FORMAT %r" % (fmt,))
+    return np.ascontiguousarray(img)
+
+
+def check_image_size(dataset_dict, image):
+    if "width" in dataset_dict or "height" in dataset_dict:
+        wh, expected = (image.shape[1], image.shape[0]), (dataset_dict["width"], dataset_dict["height"])
+        if wh != expected:
+            raise ValueError("Mismatched image shape{}, got {}, expect {}.".format(
+                " for image " + dataset_dict["file_name"] if "file_name" in dataset_dict else "", wh, expected))
+    dataset_dict.setdefault("width", image.shape[1])
+    dataset_dict.setdefault("height", image.shape[0])
+
+
+class DatasetMapperTwoCropSeparate:
+    def __init__(self, cfg, is_train=True, seed=None, device=None):
+        if cfg.INPUT.CROP.ENABLED and is_train:
+            raise NotImplementedError("INPUT.CROP (no shipped UTv2 config enables it)")
+        self.resize, self.flip_prob = T.build_weak_augmentation(cfg, is_train)
+        self.img_format = cfg.INPUT.FORMAT
+        self.is_train = is_train
+        self.device = torch.device(device if device is not None else cfg.MODEL.DEVICE)
+        from ..utils import comm
+        base = int(cfg.SEED) if seed is None and int(cfg.SEED) >= 0 else (0 if seed is None else int(seed))
+        self.rng = np.random.default_rng([base, comm.get_rank()])
+        self.generator = torch.Generator(device=self.device)
+        self.generator.manual_seed(base * 1000003 + comm.get_rank())
+        self.last_params = None  # the random decisions of the most recent call (tests / debugging)
+
+    def __call__(self, dataset_dict):
+        annos_in = dataset_dict.get("annotations")
+        dataset_dict = {k: (v if k == "image" else copy.deepcopy(v)) for k, v in dataset_dict.items() if k != "annotations"}
+        image = read_image(dataset_dict, self.img_format)
+        check_image_size(dataset_dict, image)
+        dataset_dict.pop("image", None)
+        h, w = image.shape[:2]
+        newh, neww = self.resize.get_params(self.rng, h, w)
+        flip = bool(self.rng.random() < self.flip_prob) if self.flip_prob > 0 else False
+        x = torch.from_numpy(image).to(self.device, non_blocking=True)
+        weak = T.apply_weak(x, newh, neww, flip)
+        if not self.is_train:
+            dataset_dict["image"] = hip_to_chw(weak)
+            return dataset_dict
+        if annos_in is not None:
+            keep = [a for a in annos_in if a.get("iscrowd", 0) == 0]
+            boxes = T.transform_boxes([a["bbox"] for a in keep], h, w, newh, neww, flip) if keep else np.zeros((0, 4), np.float32)
+            classes = np.array([a["category_id"] for a in keep], dtype=np.int64)
+            nonempty = ((boxes[:, 2] - boxes[:, 0]) > 1e-5) & ((boxes[:, 3] - boxes[:, 1]) > 1e-5)  # filter_empty_instances
+            inst = Instances((newh, neww))
+            inst.gt_boxes = Boxes(torch.from_numpy(boxes[nonempty]))
+            inst.gt_classes = torch.from_numpy(classes[nonempty])
+            dataset_dict["instances"] = inst
+        p = T.sample_strong_params(self.rng, newh, neww)
+        self.last_params = dict(p, newh=newh, neww=neww, flip=flip)
+        strong = T.apply_strong(weak, p, generator=self.generator)
+        strong_dict = dataset_dict
+        weak_dict = dict(dataset_dict)
+        strong_dict["image"] = hip_to_chw(strong)
+        weak_dict["image"] = hip_to_chw(weak)
+        return strong_dict, weak_dict
+
+
+def hip_to_chw(img):
+    from .. import hip
+    return hip.aug_to_chw(img)

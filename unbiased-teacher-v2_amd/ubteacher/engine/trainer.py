@@ -174,8 +174,13 @@ class _TrainerBase:
 
     @classmethod
     def build_train_loader(cls, cfg):
-        # The reference's CPU two-crop COCO pipeline (ubteacher/data) is out of scope;
-        # what the step consumes is its output contract: 4 lists of dicts per iteration.
+        """trainer.py:110-112: the two-crop semi-supervised loader (ubteacher/data, GPU mapper) when the configured training sets are
+        registered in the DatasetCatalog; otherwise (no datasets exist in this environment) the synthetic COCO-shaped loader with the
+        same output contract: 4 lists of dicts per iteration."""
+        from ..data import DatasetCatalog, build_detection_semisup_train_loader_two_crops
+        names = cfg.DATASETS.TRAIN_LABEL + cfg.DATASETS.TRAIN_UNLABEL if cfg.DATASETS.CROSS_DATASET else cfg.DATASETS.TRAIN
+        if len(names) and all(n in DatasetCatalog for n in names):
+            return build_detection_semisup_train_loader_two_crops(cfg, mapper=None)
         return SyntheticTwoCropLoader(cfg)
 
     def _common_init(self, cfg, data_loader=None):

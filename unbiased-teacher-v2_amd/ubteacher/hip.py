@@ -53,7 +53,7 @@ def _parse_header(path):
 
 
 _SIGS = _parse_header(HEADER_PATH)
-_PLAIN = {"utv2_topk_rows_workspace_bytes", "utv2_groupnorm_seg_workspace_floats", "utv2_conv2d_wgrad_bf16_splits", "utv2_conv2d_wgrad_bf16_workspace_floats", "utv2_conv2d_bf16_supported", "utv2_conv2d_wgrad_splits", "utv2_conv2d_wgrad_workspace_floats", "utv2_groupnorm_workspace_floats",
+_PLAIN = {"utv2_aug_resize_workspace_bytes", "utv2_topk_rows_workspace_bytes", "utv2_groupnorm_seg_workspace_floats", "utv2_conv2d_wgrad_bf16_splits", "utv2_conv2d_wgrad_bf16_workspace_floats", "utv2_conv2d_bf16_supported", "utv2_conv2d_wgrad_splits", "utv2_conv2d_wgrad_workspace_floats", "utv2_groupnorm_workspace_floats",
           "utv2_nms_mpad", "utv2_nms_workspace_bytes"}  # return a value, not a status
 
 
@@ -720,3 +720,110 @@ def groupnorm_relu_seg_bwd(dy, y, x2d, seg_rows, mean, rstd, gamma, dgamma, dbet
     call("utv2_groupnorm_relu_seg_bwd", _p(dy), _p(y), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx), _p(dgamma), _p(dbeta),
          _p(ws), S, ctypes.cast(sr, c_p), C, G, int(relu), _same_dt(dy, y, x2d), _stream())
     return dx
+
+
+# ---- two-crop data path: Pillow-exact image arithmetic on uint8 [H][W][3] device tensors (csrc/augment.hip) ----------------------------
+def _u8_hwc(img):
+    assert img.dtype == torch.uint8 and img.dim() == 3 and img.shape[2] == 3 and img.is_cuda and img.is_contiguous(), \
+        "augmentation ops take contiguous uint8 [H][W][3] CUDA tensors"
+    return img
+
+
+def aug_resize(img, out_h, out_w, flip=False):
+    """PIL.Image.resize((out_w, out_h), BILINEAR) (+ horizontal flip) -> new uint8 [out_h][out_w][3]"""
+    _u8_hwc(img)
+    H, W = int(img.shape[0]), int(img.shape[1])
+    nbytes = load().utv2_aug_resize_workspace_bytes(H, W, int(out_h), int(out_w))
+    if nbytes < 0:
+        raise RuntimeError("utv2_aug_resize_workspace_bytes: bad argument")
+    ws = workspace((nbytes + 3) // 4, img.device, "aug_resize")
+    out = torch.empty((int(out_h), int(out_w), 3), dtype=torch.uint8, device=img.device)
+    call("utv2_aug_resize_bilinear_u8", _p(img), H, W, _p(out), int(out_h), int(out_w), int(bool(flip)), _p(ws), _stream())
+    return out
+
+
+def aug_brightness(img, factor):
+    """ImageEnhance.Brightness(img).enhance(factor), in place"""
+    _u8_hwc(img)
+    call("utv2_aug_blend_u8", _p(img), img.shape[0] * img.shape[1], 0, float(factor), c_p(0), _stream())
+    return img
+
+
+def aug_contrast(img, factor):
+    """ImageEnhance.Contrast(img).enhance(factor), in place (the grey mean is reduced on the device, no host sync)"""
+    _u8_hwc(img)
+    ws = workspace(4, img.device, "aug_mean")  # [0:2] 64-bit sum, [2] mean
+    wi = ws.view(torch.int32)
+    call("utv2_aug_gray_mean_u8", _p(img), img.shape[0] * img.shape[1], _p(ws), c_p(wi.data_ptr() + 8), _stream())
+    call("utv2_aug_blend_u8", _p(img), img.shape[0] * img.shape[1], 1, float(factor), c_p(wi.data_ptr() + 8), _stream())
+    return img
+
+
+def aug_saturation(img, factor):
+    """ImageEnhance.Color(img).enhance(factor), in place"""
+    _u8_hwc(img)
+    call("utv2_aug_blend_u8", _p(img), img.shape[0] * img.shape[1], 2, float(factor), c_p(0), _stream())
+    return img
+
+
+def aug_hue(img, hue_factor):
+    """torchvision F_pil.adjust_hue(img, hue_factor), in place"""
+    import math
+    _u8_hwc(img)
+    if not -0.5 <= hue_factor <= 0.5:
+        raise ValueError("hue_factor ({}) is not in [-0.5, 0.5].".format(hue_factor))
+    call("utv2_aug_hue_u8", _p(img), img.shape[0] * img.shape[1], int(math.trunc(hue_factor * 255)) & 255, _stream())
+    return img
+
+
+def aug_grayscale(img):
+    """img.convert("L") replicated to three channels, in place"""
+    _u8_hwc(img)
+    call("utv2_aug_grayscale_u8", _p(img), img.shape[0] * img.shape[1], _stream())
+    return img
+
+
+def _box_blur_constants(radius, passes=3):
+    """BoxBlur.c _gaussian_blur_radius + the (radius, ww, fw) of ImagingHorizontalBoxBlur, in the float32 arithmetic of the C code"""
+    import math
+    import numpy as np
+    f32 = np.float32
+    radius = f32(radius)
+    sigma2 = f32(radius * radius / f32(passes))
+    L = f32(math.sqrt(12.0 * float(sigma2) + 1.0))
+    l = f32(math.floor((float(L) - 1.0) / 2.0))
+    a = f32(f32(2 * l + 1) * f32(f32(l * f32(l + 1)) - f32(3 * sigma2)))
+    a = f32(a / f32(6 * f32(sigma2 - f32(f32(l + 1) * f32(l + 1)))))
+    fr = f32(l + a)
+    r = int(fr)
+    ww = int(f32(f32(1 << 24) / f32(fr * 2 + 1)))
+    fw = ((1 << 24) - (r * 2 + 1) * ww) // 2
+    return r, ww, fw
+
+
+def aug_gaussian_blur(img, radius, passes=3):
+    """img.filter(PIL.ImageFilter.GaussianBlur(radius)) -> uint8 [H][W][3] (may alias a scratch buffer; `img` is clobbered)"""
+    _u8_hwc(img)
+    H, W = int(img.shape[0]), int(img.shape[1])
+    r, ww, fw = _box_blur_constants(radius, passes)
+    a, b = img, torch.empty_like(img)
+    for vertical in (0, 1):
+        for _ in range(passes):
+            call("utv2_aug_box_blur_u8", _p(a), _p(b), H, W, vertical, r, ww, fw, _stream())
+            a, b = b, a
+    return a
+
+
+def aug_erase(img, i, j, h, w, noise):
+    """ToTensor -> img[..., i:i+h, j:j+w] = noise -> ToPILImage, in place; noise float32 [3][h][w]"""
+    _u8_hwc(img)
+    assert noise.dtype == torch.float32 and tuple(noise.shape) == (3, h, w)
+    call("utv2_aug_erase_u8", _p(img), int(img.shape[0]), int(img.shape[1]), int(i), int(j), int(h), int(w), _p(noise.contiguous()), _stream())
+    return img
+
+
+def aug_to_chw(img):
+    _u8_hwc(img)
+    out = torch.empty((3, img.shape[0], img.shape[1]), dtype=torch.uint8, device=img.device)
+    call("utv2_aug_hwc_to_chw_u8", _p(img), _p(out), img.shape[0] * img.shape[1], _stream())
+    return out

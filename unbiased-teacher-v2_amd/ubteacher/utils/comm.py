@@ -42,3 +42,14 @@ def gather(data, dst=0):
 def synchronize():
     if get_world_size() > 1:
         dist.barrier()
+
+
+def shared_random_seed():
+    """Detectron2 comm.shared_random_seed: a random int that is the SAME on every rank (rank 0's draw)."""
+    import numpy as np
+    seed = int(np.random.randint(2 ** 31))
+    if get_world_size() == 1:
+        return seed
+    box = [seed]
+    dist.broadcast_object_list(box, src=0)
+    return int(box[0])
