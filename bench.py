@@ -55,14 +55,15 @@ class ConvTimer:
     dominant kernel inside the timed region.  Dominant kernel (largest share of GPU time in profiles/): the multi-level
     3x3 implicit-GEMM conv of the shared FCOS towers - forward AND dgrad launches, 256 -> 256 channels over all five FPN
     levels of the student batch in one launch:
-        bf16: conv_igemm_bf16_v2<128,true,64,__bf16>      f32: conv_igemm_f32<128,0,true>"""
+        bf16: conv_igemm_bf16_w8<true,__bf16> on the whole rounds of 256 x 256 tiles + conv_igemm_bf16_v2<128,true,64,__bf16> on the
+              remaining output rows (two kernels, one C-ABI call = one timed launch)      f32: conv_igemm_f32<128,0,true>"""
 
     def __init__(self, dtype):
         self.pairs = []
         self.enabled = False
         self.bf16 = dtype == "bf16"
         self.entry = "conv2d_ml_fwd_bf16" if self.bf16 else "conv2d_ml_fwd"
-        self.kernel = "conv_igemm_bf16_v2<128,true,64,__bf16>" if self.bf16 else "conv_igemm_f32<128,0,true>"
+        self.kernel = "conv_igemm_bf16_w8<true,__bf16>+conv_igemm_bf16_v2<128,true,64,__bf16>" if self.bf16 else "conv_igemm_f32<128,0,true>"
 
     def install(self):
         from ubteacher import hip
@@ -75,8 +76,8 @@ class ConvTimer:
             tiles = -(-P // 128) * -(-K // 128)
             if timer.bf16:  # the dispatch rule of launch_igemm16 (csrc/conv_bf16.hip) for this template instance
                 out_dt = kw["out"].dtype if kw.get("out") is not None else kw.get("out_dtype", x2d.dtype)
-                mine = (x2d.dtype == torch.bfloat16 and out_dt == torch.bfloat16 and K > 64 and C % 64 == 0 and Kred >= 1024
-                        and not (512 < tiles <= 768))
+                mine = (x2d.dtype == torch.bfloat16 and out_dt == torch.bfloat16 and K >= 256 and C % 64 == 0 and Kred >= 1024
+                        and (P // 256) * -(-K // 256) >= 256)
             else:
                 mine = K > 64 and C % 16 == 0
             if not (timer.enabled and mine):

@@ -301,3 +301,48 @@ def test_dgrad_epilogue_mask_and_residual():
     assert torch.equal(fused_m, torch.where(act > 0, plain, torch.zeros_like(plain)).to(BF))
     fused_r = hip.conv2d_dgrad_bf16(dy, wt16, (N, H, W, C), 1, 1, k, k, out_dtype=BF, residual=res)
     assert torch.equal(fused_r, (plain + res.float()).to(BF))
+
+
+def test_w8_tile_kernel_bit_identical_to_128_tile_kernel(monkeypatch):
+    """Deep K >= 256 layers run whole rounds of 256 x 256 tiles on the 8-wave LDS-DMA kernel (conv_igemm_bf16_w8) and the remaining
+    output rows on the 128 x 128 kernel; both accumulate the same k16 steps in the same order in fp32, so the split launch must equal
+    the single-kernel launch (UTV2_W8=0) BIT FOR BIT - multi-level tower conv, masked + residual + ReLU epilogue, fp32 output, wide
+    1x1 - and agree with a torch fp32 conv of the same bf16 operands."""
+    import torch.nn.functional as F
+    from ubteacher import hip
+    BF = torch.bfloat16
+    torch.manual_seed(0)
+
+    def both(fn):
+        monkeypatch.setenv("UTV2_W8", "0")
+        a = fn()
+        monkeypatch.setenv("UTV2_W8", "1")
+        b = fn()
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        return b
+    N = 3
+    level_hw = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    P = N * sum(h * w for h, w in level_hw)                      # 67200 rows: one round of 256 tiles + 1664 rows on the 128 kernel
+    x = torch.randn(P, 256, device="cuda").to(BF)
+    w16 = (torch.randn(256, 9 * 256, device="cuda") * 0.05).to(BF)
+    y = both(lambda: hip.conv2d_ml_fwd_bf16(x, w16, level_hw, N, k=3, pad=1, out=torch.empty(P, 256, device="cuda", dtype=BF)).clone())
+    r0 = 0
+    wt = w16.float().view(256, 3, 3, 256).permute(0, 3, 1, 2)
+    for (h, w_) in level_hw[:2]:
+        xs = x[r0:r0 + N * h * w_].float().view(N, h, w_, 256).permute(0, 3, 1, 2)
+        ref = F.conv2d(xs, wt, padding=1).permute(0, 2, 3, 1).reshape(-1, 256)
+        got = y[r0:r0 + N * h * w_].float()
+        assert float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+        r0 += N * h * w_
+    xn = torch.randn(8, 100, 100, 512, device="cuda").to(BF)
+    wn = (torch.randn(512, 9 * 512, device="cuda") * 0.03).to(BF)
+    sc = torch.rand(512, device="cuda") + 0.5
+    bi = torch.randn(512, device="cuda")
+    res = torch.randn(8, 100, 100, 512, device="cuda").to(BF)
+    msk = torch.randn(8, 100, 100, 512, device="cuda").to(BF)
+    both(lambda: hip.conv2d_fwd_bf16(xn, wn, scale=sc, bias=bi, residual=res, stride=1, pad=1, relu=True, kh=3, kw=3, mask=msk))
+    both(lambda: hip.conv2d_fwd_bf16(xn, wn, stride=1, pad=1, kh=3, kw=3, out_dtype=torch.float32))
+    x1 = torch.randn(4, 128, 160, 1024, device="cuda").to(BF)
+    w1 = (torch.randn(256, 1024, device="cuda") * 0.03).to(BF)
+    both(lambda: hip.conv2d_fwd_bf16(x1, w1))

@@ -1,0 +1,41 @@
+"""A/B of the 256x256 8-wave conv kernel (UTV2_W8=1) against the 128x128 kernel (UTV2_W8=0): same fp32 accumulation order, so the
+outputs must be BIT-identical.  usage: check_w8.py save|cmp FILE"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "unbiased-teacher-v2_amd"))
+import torch
+from ubteacher import hip
+BF = torch.bfloat16
+torch.manual_seed(0)
+outs = {}
+# multi-level tower conv (3 images), with bias+relu epilogue
+N = 3
+level_hw = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+P = N * sum(h * w for h, w in level_hw)
+x = torch.randn(P, 256, device="cuda").to(BF)
+w16 = (torch.randn(256, 9 * 256, device="cuda") * 0.05).to(BF)
+y = torch.empty(P, 256, device="cuda", dtype=BF)
+hip.conv2d_ml_fwd_bf16(x, w16, level_hw, N, k=3, pad=1, out=y)
+outs["ml"] = y.clone()
+# plain conv, K = 512, C = 512 3x3 (res5-like), stride 1, mask + residual epilogue, fp32 output too
+xn = torch.randn(8, 100, 100, 512, device="cuda").to(BF)
+wn = (torch.randn(512, 9 * 512, device="cuda") * 0.03).to(BF)
+sc = torch.rand(512, device="cuda") + 0.5; bi = torch.randn(512, device="cuda")
+res = torch.randn(8, 100, 100, 512, device="cuda").to(BF)
+msk = torch.randn(8, 100, 100, 512, device="cuda").to(BF)
+outs["n1"] = hip.conv2d_fwd_bf16(xn, wn, scale=sc, bias=bi, residual=res, stride=1, pad=1, relu=True, kh=3, kw=3, mask=msk)
+outs["n2"] = hip.conv2d_fwd_bf16(xn, wn, stride=1, pad=1, kh=3, kw=3, out_dtype=torch.float32)
+# 1x1 wide (C = 1024 -> K = 256, Kred = 1024)
+x1 = torch.randn(4, 128, 160, 1024, device="cuda").to(BF)
+w1 = (torch.randn(256, 1024, device="cuda") * 0.03).to(BF)
+outs["p1"] = hip.conv2d_fwd_bf16(x1, w1)
+torch.cuda.synchronize()
+if sys.argv[1] == "save":
+    torch.save({k: v.cpu() for k, v in outs.items()}, sys.argv[2])
+    print("saved", {k: tuple(v.shape) for k, v in outs.items()})
+else:
+    ref = torch.load(sys.argv[2])
+    for k, v in outs.items():
+        same = torch.equal(v.cpu(), ref[k])
+        d = (v.cpu().float() - ref[k].float()).abs().max().item()
+        print(k, "bit-identical" if same else "DIFF max %.4g" % d, "nan" if torch.isnan(v).any() else "")

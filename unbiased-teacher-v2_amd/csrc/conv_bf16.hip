@@ -14,6 +14,7 @@
 // BK = 32: a row of the LDS tile is 32 bf16 = 64 B (+16 B pad -> the same conflict-free 80-byte
 // stride); each thread stages 8 consecutive k of a row (two 16-byte global loads -> one
 // ds_write_b128); each MFMA reads one ds_read_b128 per operand fragment.
+#include <stdlib.h>
 #include "common.h"
 #include <type_traits>
 
@@ -40,6 +41,7 @@ struct ConvArgs16 {
   const void* mask;          // element type TO (optional): y = mask > 0 ? y : 0 before the residual add
   int N, H, W, C, OH, OW, K, KH, KW, stride, pad, in_dil, relu, Kred, M, accumulate;
   int xs;                    // elements between consecutive input pixels (= C except for the image stem's overlapping 8-pixel reads)
+  int m_begin;               // first output row of this launch (a conv may be split over two kernels by output-row range)
 };
 
 __device__ __forceinline__ void ml_decode16(const LevelTab& lt, int m, int& pixbase, int& H, int& W, int& oh, int& ow) {
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int mt = tile / tilesN, nt = tile - mt * tilesN;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
   const int lrow = tid / SLOTS, slot = tid % SLOTS;  // staged rows lrow + RPP*j, channels slot*8 .. +7 of the chunk
   const int ntaps = p.KH * p.KW;
 
@@ -542,6 +544,175 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves (2 x 4), 128 x 64 per wave, BK = 64, operands staged by LDS-DMA (global_load_lds_dwordx4) into a
+// double-buffered 128 KB LDS image, one workgroup per CU.  Against the 128 x 128 / 4-wave kernel above: 6 fragment reads feed
+// 8 MFMAs per k16 step (was 4 : 4), a barrier every 32 MFMAs per wave (was 16), the loads of the next chunk have 2048+ matrix-pipe
+// cycles to land, no staging VGPRs and no ds_write pass.  Same hoisted im2col addressing, zero page, source-side swizzle and
+// epilogue.  For deep MFMA-bound layers with K >= 256 on plain NHWC bf16 inputs; launched on whole rounds of 256 tiles, the
+// remaining output rows go to the 128 x 128 kernel (ConvArgs16::m_begin).
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <bool ML, typename TO>
+__global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
+  constexpr int BM = 256, BN = 256, BK = 64, ROWB = BK * 2;
+  constexpr int SLOTS = 8, RPP = 512 / SLOTS;                      // 64 rows staged per pass of the 512 threads
+  constexpr int TM = 4, TN = 2, AP = BM / RPP, BP = BN / RPP, KS = BK / 16;
+  constexpr int ABUF = BM * ROWB, BBUF = BN * ROWB;
+  constexpr int STAGE = 2 * (ABUF + BBUF), PATCH = 8 * 32 * (TN * 32 + 4) * 4;
+  static_assert(STAGE >= PATCH, "epilogue patches must fit the staging LDS");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + 2 * ABUF;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int tilesN = (p.K + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  int tile;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int mt = tile / tilesN, nt = tile - mt * tilesN;
+  const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
+  const int lrow = tid / SLOTS, slot = tid % SLOTS;
+  const int kslot = slot ^ ((lrow >> 1) & 7);  // source-side swizzle: the lane fetches the k-slot that belongs in its physical slot
+  const int ntaps = p.KH * p.KW;
+
+  int aoff[AP], awc[AP];
+  unsigned amask[AP];
+#pragma unroll
+  for (int j = 0; j < AP; ++j) {
+    const int m = m0 + lrow + RPP * j;
+    const bool mv = m < p.M;
+    const int mm = mv ? m : 0;
+    int pb, H, W, ih0, iw0;
+    if constexpr (ML) {
+      int oh, ow;
+      ml_decode16(p.lt, mm, pb, H, W, oh, ow);
+      ih0 = oh - p.pad;
+      iw0 = ow - p.pad;
+    } else {
+      const int hw = p.OH * p.OW;
+      const int n = mm / hw, rem = mm - n * hw;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      ih0 = oh * p.stride - p.pad;
+      iw0 = ow * p.stride - p.pad;
+      pb = n * p.H * p.W;
+      H = p.H;
+      W = p.W;
+    }
+    aoff[j] = (pb + ih0 * W + iw0) * p.xs + kslot * 8;
+    awc[j] = W * p.xs;
+    unsigned mk = 0;
+    for (int kh = 0; kh < p.KH; ++kh)
+      for (int kw = 0; kw < p.KW; ++kw)
+        if (mv && (unsigned)(ih0 + kh) < (unsigned)H && (unsigned)(iw0 + kw) < (unsigned)W) mk |= 1u << (kh * p.KW + kw);
+    amask[j] = mk;
+  }
+  int boff[BP];
+  bool bvalid[BP];
+#pragma unroll
+  for (int j = 0; j < BP; ++j) {
+    const int co = n0 + lrow + RPP * j;
+    bvalid[j] = co < p.K;
+    boff[j] = (bvalid[j] ? co : 0) * p.Kred + kslot * 8;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const __bf16* __restrict__ xb = (const __bf16*)p.x;
+  const int nchunks = ntaps * (p.C / BK);
+  int kh = 0, kw = 0, c0 = 0, tap = 0;
+  constexpr int NP = AP + BP;
+  int ua = 0, ub = 0, ukh = 0, utap = 0;
+  auto cursor_next = [&]() {
+    ua = kw * p.xs + c0;
+    ub = tap * p.C + c0;
+    ukh = kh;
+    utap = tap;
+    ++tap;
+    if (++kw == p.KW) {
+      kw = 0;
+      if (++kh == p.KH) { kh = 0; tap = 0; c0 += BK; }
+    }
+  };
+  const __bf16* zero = (const __bf16*)g_zero64;
+  const int wrow0 = wid * (64 / SLOTS);  // one wave instruction fills 1 KB = 8 consecutive rows of the stage
+  auto issue_piece = [&](int buf, int q) {
+    if (q < AP) {
+      const __bf16* src = ((amask[q] >> utap) & 1u) ? xb + (unsigned)(aoff[q] + ukh * awc[q] + ua) : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * ABUF + (wrow0 + RPP * q) * ROWB), 16, 0, 0);
+    } else {
+      const __bf16* src = bvalid[q - AP] ? p.w + (unsigned)(boff[q - AP] + ub) : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + buf * BBUF + (wrow0 + RPP * (q - AP)) * ROWB), 16, 0, 0);
+    }
+  };
+
+  const int frow = lane & 31, fh = lane >> 5;
+  const int swz = (frow >> 1) & 7;
+  int koff[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) koff[s] = ((2 * s + fh) ^ swz) * 16;
+  const int arow = (wm * 128 + frow) * ROWB, brow = (wn * 64 + frow) * ROWB;
+
+  cursor_next();
+#pragma unroll
+  for (int q = 0; q < NP; ++q) issue_piece(0, q);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  auto iteration = [&](int buf, auto do_load) {
+    constexpr bool LOAD = decltype(do_load)::value;
+    if constexpr (LOAD) cursor_next();
+    const unsigned char* ab = As + buf * ABUF + arow;
+    const unsigned char* bb = Bs + buf * BBUF + brow;
+    bf16x8_t a[2][TM], b[2][TN];  // fragments of k16 step s+1 are read BEFORE the MFMAs of step s are issued
+    auto read_frags = [&](int set, int s) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[set][i] = *(const bf16x8_t*)(ab + i * 32 * ROWB + koff[s]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[set][j] = *(const bf16x8_t*)(bb + j * 32 * ROWB + koff[s]);
+    };
+    read_frags(0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s + 1 < KS) read_frags((s + 1) & 1, s + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
+      if constexpr (LOAD) {
+#pragma unroll
+        for (int q = s * NP / KS; q < (s + 1) * NP / KS; ++q) issue_piece(buf ^ 1, q);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
+  int kc = 0;
+  for (; kc + 1 < nchunks; ++kc) iteration(kc & 1, yes{});
+  iteration(kc & 1, no{});
+
+  // K % 4 == 0 is guaranteed by the launcher
+  float* patch = (float*)smem + wid * (32 * (TN * 32 + 4));
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+    epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[2 * half], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
+                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask);
+}
+
 template <int BN, bool ML>
 static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dtype, hipStream_t stream) {
   const dim3 g(tiles), b(256);
@@ -553,6 +724,32 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
     // wide 1x1 layers) unless the grid is a little over one 512-slot round (tail), not for short HBM-bound ones.
     const bool tail = tiles > 512 && tiles <= 768;
     const bool deep = a.C % 64 == 0 && a.Kred >= 1024 && !tail;
+    const char* w8env = getenv("UTV2_W8");  // "0" keeps every row on the 128 x 128 kernel (A/B runs, tests/test_conv_bf16_gpu.py)
+    const bool w8 = !(w8env && w8env[0] == '0');
+    if (w8 && BN == 128 && a.xs == a.C && a.C % 64 == 0 && a.Kred >= 1024 && a.K >= 256 && (a.K & 3) == 0 && a.m_begin == 0) {
+      // whole rounds of 256 tiles (one per CU) go to the 256 x 256 kernel; the remaining output rows to the 128 x 128 kernel below
+      const int tilesN = cdiv(a.K, 256), tiles_m = a.M / 256;
+      const int main_tiles = (tiles_m * tilesN / 256) * 256;  // a partial round of 256 x 256 tiles loses to the 128 x 128 kernel
+      const int main_m = main_tiles / tilesN;
+      if (main_m > 0) {
+        ConvArgs16 m = a;
+        m.M = main_m * 256;
+        const int smem = 2 * (256 + 256) * 128;
+        static bool attr_done = false;
+        if (!attr_done) {
+          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_w8<ML, __bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_w8<ML, float>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+          attr_done = true;
+        }
+        if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_w8<ML, __bf16>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
+        else hipLaunchKernelGGL((conv_igemm_bf16_w8<ML, float>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
+        if (m.M == a.M) return;
+        ConvArgs16 r = a;
+        r.m_begin = m.M;
+        launch_igemm16<BN, ML>(r, cdiv(a.M - m.M, 128) * cdiv(a.K, 128), x_dtype, y_dtype, stream);
+        return;
+      }
+    }
     if (deep) {
       if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 64, __bf16>), g, b, 0, stream, a);
       else hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 64, float>), g, b, 0, stream, a);
@@ -589,7 +786,7 @@ int utv2_conv2d_nhwc_fwd_bf16(const void* x, int x_dtype, const void* w16, void*
   a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = mask;
   a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.K = K; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
   a.in_dil = in_dil < 1 ? 1 : in_dil; a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.M = N * OH * OW;
-  a.xs = C;
+  a.xs = C; a.m_begin = 0;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   if (small) launch_igemm16<64, false>(a, tiles, x_dtype, y_dtype, stream);
@@ -606,7 +803,7 @@ int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y
   a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
   a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr;
   a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad; a.in_dil = 1;
-  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = C;
+  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = C; a.m_begin = 0;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   if (small) launch_igemm16<64, true>(a, tiles, x_dtype, y_dtype, stream);
@@ -628,7 +825,7 @@ int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int
   a.lt.n = 0;
   a.x = xpad16; a.w = (const __bf16*)w16s; a.y = y; a.scale = scale; a.bias = bias; a.residual = nullptr; a.mask = nullptr;
   a.N = N; a.H = H + 6; a.W = W + 8; a.C = 32; a.OH = OH; a.OW = OW; a.K = K; a.KH = 7; a.KW = 1; a.stride = 2; a.pad = 0;
-  a.in_dil = 1; a.relu = relu; a.accumulate = 0; a.Kred = 7 * 32; a.M = N * OH * OW; a.xs = 4;
+  a.in_dil = 1; a.relu = relu; a.accumulate = 0; a.Kred = 7 * 32; a.M = N * OH * OW; a.xs = 4; a.m_begin = 0;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   const dim3 g(tiles), b(256);
