@@ -554,6 +554,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+#define W8_SP 2  // k16 steps over which the 8 LDS-DMA pieces of the next chunk are issued (1: 951 TF, 2: 968 TF, 4: 933 TF on the tower convs)
 template <bool ML, typename TO>
 __global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
   constexpr int BM = 256, BN = 256, BK = 64, ROWB = BK * 2;
@@ -566,7 +567,8 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
   unsigned char* As = smem;
   unsigned char* Bs = smem + 2 * ABUF;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keeps the LDS-DMA bases (M0) in SGPRs
   const int wm = wid >> 2, wn = wid & 3;
   const int tilesN = (p.K + BN - 1) / BN;
   const int nwg = gridDim.x;
@@ -690,9 +692,11 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
-      if constexpr (LOAD) {
+      if constexpr (LOAD) {  // all 8 pieces go out behind the MFMAs of the first two k16 steps: at least half a chunk to land
+        if (s < W8_SP) {
 #pragma unroll
-        for (int q = s * NP / KS; q < (s + 1) * NP / KS; ++q) issue_piece(buf ^ 1, q);
+          for (int q = s * NP / W8_SP; q < (s + 1) * NP / W8_SP; ++q) issue_piece(buf ^ 1, q);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
