@@ -14,6 +14,7 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/_pw -o ru
 cd $R
 for d in _kt _pf _pw; do f=$(find gpurun_out/$d -name "*.db" | head -1); echo "$d $f"; done
 timeout 120 python tools/rocpd_stats.py "$(find gpurun_out/_kt -name '*.db' | head -1)" > gpurun_out/${TAG}_kernel_stats.txt 2>&1 < /dev/null
-timeout 120 python tools/rocpd_pmc.py "$(find gpurun_out/_pf -name '*.db' | head -1)" 12 > gpurun_out/${TAG}_pmc_fetch.txt 2>&1 < /dev/null
-timeout 120 python tools/rocpd_pmc.py "$(find gpurun_out/_pw -name '*.db' | head -1)" 12 > gpurun_out/${TAG}_pmc_write.txt 2>&1 < /dev/null
+timeout 120 python tools/rocpd_pmc.py "$(find gpurun_out/_pf -name '*.db' | head -1)" 30 > gpurun_out/${TAG}_pmc_fetch.txt 2>&1 < /dev/null
+timeout 120 python tools/rocpd_pmc.py "$(find gpurun_out/_pw -name '*.db' | head -1)" 30 > gpurun_out/${TAG}_pmc_write.txt 2>&1 < /dev/null
+timeout 60 python tools/make_traffic.py gpurun_out/${TAG}_pmc_fetch.txt gpurun_out/${TAG}_pmc_write.txt gpurun_out/${TAG}_traffic.json > /dev/null 2>&1 < /dev/null
 rm -rf gpurun_out/_kt gpurun_out/_pf gpurun_out/_pw
