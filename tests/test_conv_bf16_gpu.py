@@ -343,6 +343,9 @@ def test_w8_tile_kernel_bit_identical_to_128_tile_kernel(monkeypatch):
     msk = torch.randn(8, 100, 100, 512, device="cuda").to(BF)
     both(lambda: hip.conv2d_fwd_bf16(xn, wn, scale=sc, bias=bi, residual=res, stride=1, pad=1, relu=True, kh=3, kw=3, mask=msk))
     both(lambda: hip.conv2d_fwd_bf16(xn, wn, stride=1, pad=1, kh=3, kw=3, out_dtype=torch.float32))
+    x2 = torch.randn(12, 50, 84, 256, device="cuda").to(BF)   # 197 tiles: more than half a round -> all on the big tile, last row tile partial
+    w2 = (torch.randn(256, 9 * 256, device="cuda") * 0.05).to(BF)
+    both(lambda: hip.conv2d_fwd_bf16(x2, w2, stride=1, pad=1, kh=3, kw=3, relu=True))
     x1 = torch.randn(4, 128, 160, 1024, device="cuda").to(BF)
     w1 = (torch.randn(256, 1024, device="cuda") * 0.03).to(BF)
     both(lambda: hip.conv2d_fwd_bf16(x1, w1))

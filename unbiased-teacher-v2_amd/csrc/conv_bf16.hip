@@ -731,13 +731,16 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
     const char* w8env = getenv("UTV2_W8");  // "0" keeps every row on the 128 x 128 kernel (A/B runs, tests/test_conv_bf16_gpu.py)
     const bool w8 = !(w8env && w8env[0] == '0');
     if (w8 && BN == 128 && a.xs == a.C && a.C % 64 == 0 && a.Kred >= 1024 && a.K >= 256 && (a.K & 3) == 0 && a.m_begin == 0) {
-      // whole rounds of 256 tiles (one per CU) go to the 256 x 256 kernel; the remaining output rows to the 128 x 128 kernel below
-      const int tilesN = cdiv(a.K, 256), tiles_m = a.M / 256;
-      const int main_tiles = (tiles_m * tilesN / 256) * 256;  // a partial round of 256 x 256 tiles loses to the 128 x 128 kernel
-      const int main_m = main_tiles / tilesN;
+      // Whole rounds of 256 tiles (one per CU) always pay.  The rest: a partial round costs one 256-tile time (~76 us on the tower
+      // shape) whatever its fill, the 128 x 128 kernel ~35-46 us per round of 512 of its tiles - so the big tile also takes the rest
+      // (including the partial last row tile, masked in the kernel) when it is more than half a round, else the small kernel does.
+      const int tilesN = cdiv(a.K, 256), tiles_m = a.M / 256, tiles_all = cdiv(a.M, 256) * tilesN;
+      int main_tiles = (tiles_m * tilesN / 256) * 256;
+      if (tiles_all - main_tiles > 128) main_tiles = tiles_all;
+      const int main_m = main_tiles == tiles_all ? cdiv(a.M, 256) : main_tiles / tilesN;
       if (main_m > 0) {
         ConvArgs16 m = a;
-        m.M = main_m * 256;
+        m.M = main_tiles == tiles_all ? a.M : main_m * 256;
         const int smem = 2 * (256 + 256) * 128;
         static bool attr_done = false;
         if (!attr_done) {
