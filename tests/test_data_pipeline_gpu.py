@@ -94,3 +94,32 @@ def test_loader_feeds_a_training_step():
     assert torch.isfinite(losses).all()
     rec = tr.flush_metrics()
     assert "loss_fcos_cls" in rec and "loss_fcos_cls_pseudo" in rec
+
+
+def test_mapper_reads_files_handles_empty_annotations_and_eval_mode(tmp_path):
+    """`file_name` dicts are decoded on the host with Pillow (PNG here: lossless, so the pixels are known), images without boxes give
+    empty Instances, and the is_train=False mapper returns one dict with the resized image only (dataset_mapper.py:102-106)."""
+    from PIL import Image
+    from ubteacher.data import DatasetMapperTwoCropSeparate
+    cfg = cfg_for_data("syn_file", 2)
+    cfg.INPUT.MIN_SIZE_TRAIN = (96,)
+    cfg.INPUT.MIN_SIZE_TRAIN_SAMPLING = "choice"
+    cfg.INPUT.RANDOM_FLIP = "none"
+    rgb = np.random.default_rng(0).integers(0, 256, (60, 90, 3), dtype=np.uint8)
+    path = str(tmp_path / "img.png")
+    Image.fromarray(rgb).save(path)
+    d = {"file_name": path, "height": 60, "width": 90, "image_id": 7, "annotations": []}
+    mapper = DatasetMapperTwoCropSeparate(cfg, True)
+    strong, weak = mapper(d)
+    ref = np.asarray(Image.fromarray(np.ascontiguousarray(rgb[:, :, ::-1])).resize((144, 96), Image.BILINEAR))
+    assert np.array_equal(weak["image"].cpu().numpy(), ref.transpose(2, 0, 1))
+    assert len(weak["instances"]) == 0 and strong["image"].shape == weak["image"].shape and weak["image_id"] == 7
+    with pytest.raises(ValueError):
+        mapper({"file_name": path, "height": 61, "width": 90})                      # check_image_size
+    ev = DatasetMapperTwoCropSeparate(cfg, False)
+    cfg.INPUT.MIN_SIZE_TEST = 120
+    ev = DatasetMapperTwoCropSeparate(cfg, False)
+    out = ev({"file_name": path, "height": 60, "width": 90, "annotations": [{"bbox": [1, 2, 30, 40], "category_id": 3}]})
+    assert isinstance(out, dict) and tuple(out["image"].shape) == (3, 120, 180) and "instances" not in out
+    ref = np.asarray(Image.fromarray(np.ascontiguousarray(rgb[:, :, ::-1])).resize((180, 120), Image.BILINEAR))
+    assert np.array_equal(out["image"].cpu().numpy(), ref.transpose(2, 0, 1))
