@@ -65,9 +65,11 @@ int utv2_conv2d_ml_wgrad(const float* x, const float* dy, float* dw, float* ws, 
 #define UTV2_BF16 1
 int utv2_conv2d_bf16_supported(int C, int KH, int KW);
 /* mask (optional, y's type and shape): y = mask > 0 ? conv*scale+bias : 0, before the residual add - the ReLU backward of the
- * layer that produced the input, fused into the dgrad launch that computes its gradient */
+ * layer that produced the input, fused into the dgrad launch that computes its gradient; post_mask (optional, same type and shape):
+ * y = post_mask > 0 ? y : 0 AFTER the residual add - the ReLU whose OUTPUT this gradient flows into (a bottleneck's input), so the
+ * block that produced that output needs no separate mask pass */
 int utv2_conv2d_nhwc_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
-                              const float* bias, const void* residual, const void* mask, int N, int H, int W, int C, int K,
+                              const float* bias, const void* residual, const void* mask, const void* post_mask, int N, int H, int W, int C, int K,
                               int KH, int KW, int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate,
                               utv2_stream_t stream);
 int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
@@ -114,7 +116,7 @@ int utv2_downsample2x_sum_nhwc(const void* g, void* dtop, int N, int TH, int TW,
                                utv2_stream_t stream);
 /* dgrad of a stride-2 1x1 conv (D2 STRIDE_IN_1X1 bottlenecks): dst[n,2i,2j,:] = src[n,i,j,:], zeros elsewhere;
  * src is [N][(H+1)/2][(W+1)/2][C] - the compact gradient comes from a plain GEMM instead of a 4x larger masked one */
-int utv2_zero_interleave2x_nhwc(const void* src, void* dst, int N, int H, int W, int C, int dtype, utv2_stream_t stream);
+int utv2_zero_interleave2x_nhwc(const void* src, const void* mask, void* dst, int N, int H, int W, int C, int dtype, utv2_stream_t stream);
 /* modeling/one_stage_detector.py:88-90 / meta_arch/rcnn.py:18 (preprocess_image + ImageList pad) */
 int utv2_preprocess_image(const void* src, int is_u8, float* dst, int H, int W, int Hp, int Wp,
                           const float* mean3_host, const float* std3_host, utv2_stream_t stream);

@@ -349,3 +349,30 @@ def test_w8_tile_kernel_bit_identical_to_128_tile_kernel(monkeypatch):
     x1 = torch.randn(4, 128, 160, 1024, device="cuda").to(BF)
     w1 = (torch.randn(256, 1024, device="cuda") * 0.03).to(BF)
     both(lambda: hip.conv2d_fwd_bf16(x1, w1))
+
+
+def test_post_mask_epilogue_and_masked_zero_interleave():
+    """post_mask: y = post_mask > 0 ? (conv [* mask] + residual) : 0 - the gradient of a ReLU output masked where it is produced;
+    same operand on the stride-2 zero-interleave."""
+    from ubteacher import hip
+    BF = torch.bfloat16
+    torch.manual_seed(1)
+    N, Hh, Ww, C, K = 2, 20, 24, 64, 128
+    dy = torch.randn(N, Hh, Ww, K, device="cuda").to(BF)
+    wt = (torch.randn(C, K, device="cuda") * 0.1).to(BF)          # 1x1 dgrad weight image [C][K]
+    res = torch.randn(N, Hh, Ww, C, device="cuda").to(BF)
+    mk = torch.randn(N, Hh, Ww, C, device="cuda").to(BF)
+    pm = torch.randn(N, Hh, Ww, C, device="cuda").to(BF)
+    base = hip.conv2d_dgrad_bf16(dy, wt, (N, Hh, Ww, C), 1, 0, 1, 1, out_dtype=torch.float32)
+    got = hip.conv2d_dgrad_bf16(dy, wt, (N, Hh, Ww, C), 1, 0, 1, 1, out_dtype=BF, mask=mk, residual=res, post_mask=pm)
+    want = torch.where(pm.float() > 0, torch.where(mk.float() > 0, base, torch.zeros_like(base)) + res.float(), torch.zeros_like(base)).to(BF)
+    assert torch.equal(got, want)
+    f32 = hip.conv2d_dgrad_bf16(dy, wt, (N, Hh, Ww, C), 1, 0, 1, 1, out_dtype=torch.float32, residual=res.float(), post_mask=pm.float())
+    assert torch.equal(f32, torch.where(pm.float() > 0, base + res.float(), torch.zeros_like(base)))
+    c = torch.randn(N, 10, 12, C, device="cuda").to(BF)
+    full_mask = torch.randn(N, 20, 24, C, device="cuda").to(BF)
+    z = hip.zero_interleave2x(c, 20, 24, mask=full_mask)
+    ref = torch.zeros(N, 20, 24, C, device="cuda", dtype=BF)
+    ref[:, ::2, ::2] = torch.where(full_mask[:, ::2, ::2].float() > 0, c, torch.zeros_like(c))
+    assert torch.equal(z, ref)
+    assert torch.equal(hip.zero_interleave2x(c, 20, 24)[:, ::2, ::2], c)

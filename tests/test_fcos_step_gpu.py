@@ -222,3 +222,44 @@ def test_evaluation_loop_runs_and_rescales():
         if len(p["scores"]):
             assert p["boxes"][:, 2].max() <= 128 * 1.5 + 1e-3 and p["boxes"][:, 3].max() <= 96 * 1.5 + 1e-3
     assert max(p["boxes"][:, 2].max() if len(p["scores"]) else 0 for p in ev._pred.values()) > 128   # beyond the unscaled width
+
+
+def test_premasked_backbone_gradients_bit_identical(monkeypatch):
+    """AMP backward of the fused bottlenecks: masking the gradient that flows into a block's ReLU output in the PRODUCERS' dgrad epilogues
+    (next block's conv1 dgrad incl. the residual branch, stride-2 zero-interleave, FPN lateral dgrad) equals the separate mask pass at the
+    top of the block's backward BIT FOR BIT: two steps from the same state, the parameter gradients of every layer compared."""
+    import hashlib
+    from ubteacher import ops
+    from ubteacher.engine import UBTeacherTrainer
+    cfg = small_fcos_cfg()
+    cfg.SOLVER.AMP.ENABLED = True
+    prod, orac = make_batch(12, 2, 2, H, W, "cuda")
+    digests, calls = [], []
+    try:
+        for flag in ("0", "1"):
+            monkeypatch.setenv("UTV2_PREMASK", flag)
+            torch.manual_seed(0)
+            tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+            sd_s = tune_state_for_pseudo_labels(cpu_state(tr.model), [d["image"] for d in orac[3]])
+            tr.model.load_state_dict(sd_s)
+            tr.model_teacher.load_state_dict(sd_s)
+            from ubteacher import hip
+            n = [0]
+            orig = hip.relu_bwd_scale
+
+            def counting(*a, **k):
+                n[0] += 1
+                return orig(*a, **k)
+            monkeypatch.setattr(hip, "relu_bwd_scale", counting)
+            tr.iter = 1
+            tr.run_step_full_semisup()
+            torch.cuda.synchronize()
+            monkeypatch.setattr(hip, "relu_bwd_scale", orig)
+            calls.append(n[0])
+            state = tr.model.flat_state().detach().float().cpu().numpy()
+            assert np.isfinite(state).all()
+            digests.append(hashlib.sha1(state.tobytes()).hexdigest())
+    finally:
+        ops.set_precision("fp32")
+    assert digests[0] == digests[1]
+    assert calls[1] < calls[0] and calls[0] - calls[1] >= 13   # the 13 trainable bottlenecks of res3-res5 lost their mask pass

@@ -18,11 +18,11 @@ def call(name, *args):
         e0.record(); orig_call(name, *args); e1.record()
         if name in ("utv2_conv2d_nhwc_fwd", "utv2_conv2d_nhwc_fwd_bf16"):
             b16 = "bf16" in name
-            o = 9 if b16 else 6
+            o = 10 if b16 else 6
             N, H, W, C, K, KH, KW, stride, pad, in_dil, OH, OW = args[o:o + 12]
             xb = (2 if args[1] else 4) if b16 else 4
             yb = (2 if args[4] else 4) if b16 else 4
-            res, acc = (args[7], args[22]) if b16 else (args[5], args[19])
+            res, acc = (args[7], args[23]) if b16 else (args[5], args[19])
             key = ("ig16" if "bf16" in name else "ig32", N, H, W, C, K, KH, stride, in_dil, OH, OW)
             fl = 2.0 * N * OH * OW * K * KH * KW * C / (in_dil * in_dil if in_dil > 1 else 1)
             by = xb * N * H * W * C + yb * N * OH * OW * K * (1 + bool(res.value if hasattr(res, "value") else res) + bool(acc)) + 2.0 * K * KH * KW * C

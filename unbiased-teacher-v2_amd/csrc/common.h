@@ -79,9 +79,12 @@ template <int TN, typename TO = float>
 __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float* lds, int lane, TO* __restrict__ y,
                                               const float* __restrict__ scale, const float* __restrict__ bias,
                                               const TO* __restrict__ residual, int relu, int accumulate, int m_base,
-                                              int co_base, int M, int K, const TO* __restrict__ mask = nullptr) {
+                                              int co_base, int M, int K, const TO* __restrict__ mask = nullptr,
+                                              const TO* __restrict__ post_mask = nullptr) {
   // mask (optional, y's type and shape): y = mask > 0 ? value : 0, applied before the residual add - the ReLU backward of
   // the layer that produced this conv's input, fused into the dgrad that computes its gradient
+  // post_mask (optional, same type and shape): y = post_mask > 0 ? value : 0 AFTER the residual add - the ReLU backward of the layer
+  // whose output is this conv's INPUT in the forward pass (a dgrad + residual-branch sum that flows into a ReLU output is masked where it is made)
   constexpr int VEC = sizeof(TO) == 2 ? 8 : 4, NQ = VEC / 4;  // channels per lane, as NQ quads
   constexpr int COLS = TN * 32, LD = COLS + 4, CV = COLS / VEC, RPI = 64 / CV;  // rows per store instruction
   const int frow = lane & 31, fh = lane >> 5;
@@ -133,6 +136,11 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
 #pragma unroll
               for (int q = 0; q < 8; ++q) v[q >> 2][q & 3] += (float)r[q];
             }
+            if (post_mask) {
+              const bf16x8_t mk = *(const bf16x8_t*)(post_mask + off);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q >> 2][q & 3] = (float)mk[q] > 0.f ? v[q >> 2][q & 3] : 0.f;
+            }
             if (relu) {
 #pragma unroll
               for (int q = 0; q < 8; ++q) v[q >> 2][q & 3] = fmaxf(v[q >> 2][q & 3], 0.f);
@@ -159,6 +167,11 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
             for (int q = 0; q < 4; ++q) v[h][q] = mk[q] > 0.f ? v[h][q] : 0.f;
           }
           if (residual) v[h] += ld4(residual, o4);
+          if (post_mask) {
+            const f32x4 mk = ld4(post_mask, o4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[h][q] = mk[q] > 0.f ? v[h][q] : 0.f;
+          }
           if (relu) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[h][q] = fmaxf(v[h][q], 0.f);

@@ -39,6 +39,7 @@ struct ConvArgs16 {
   const float* bias;
   const void* residual;      // element type TO
   const void* mask;          // element type TO (optional): y = mask > 0 ? y : 0 before the residual add
+  const void* post_mask;     // element type TO (optional): y = post_mask > 0 ? y : 0 after the residual add
   int N, H, W, C, OH, OW, K, KH, KW, stride, pad, in_dil, relu, Kred, M, accumulate;
   int xs;                    // elements between consecutive input pixels (= C except for the image stem's overlapping 8-pixel reads)
   int m_begin;               // first output row of this launch (a conv may be split over two kernels by output-row range)
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
     // all MFMAs retired and every wave is past the last barrier of the K loop: the staging LDS is free
     float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
     epilogue_rows<TN, TO>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
-                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask);
+                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask);
     return;
   }
   TO* yo = (TO*)p.y;
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
         float v = acc[i][j][e] * sc + bi;
         if (msk) v = (float)msk[off] > 0.f ? v : 0.f;
         if (res) v += (float)res[off];
+        if (p.post_mask) v = (float)((const TO*)p.post_mask)[off] > 0.f ? v : 0.f;
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.accumulate) v += (float)yo[off];
         yo[off] = (TO)v;
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
     static_assert(sizeof(smem) >= 4 * 32 * ((BN / 2) + 4) * sizeof(float), "epilogue patches must fit the staging LDS");
     float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
     epilogue_rows<TN, TO>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
-                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask);
+                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask);
     return;
   }
   TO* yo = (TO*)p.y;
@@ -536,6 +538,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
         float v = acc[i][j][e] * sc + bi;
         if (msk) v = (float)msk[off] > 0.f ? v : 0.f;
         if (res) v += (float)res[off];
+        if (p.post_mask) v = (float)((const TO*)p.post_mask)[off] > 0.f ? v : 0.f;
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.accumulate) v += (float)yo[off];
         yo[off] = (TO)v;
@@ -714,7 +717,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
 #pragma unroll
   for (int half = 0; half < 2; ++half)
     epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[2 * half], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
-                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask);
+                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask);
 }
 
 template <int BN, bool ML>
@@ -785,12 +788,13 @@ int utv2_conv2d_bf16_supported(int C, int KH, int KW) { return (C % 8 == 0) ? 1 
 // w16: bf16 [K][KH*KW*C].  x is `x_dtype`, y and residual are `y_dtype` (UTV2_F32 / UTV2_BF16).  Otherwise the
 // contract of utv2_conv2d_nhwc_fwd (also serves as dgrad).
 int utv2_conv2d_nhwc_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
-                              const float* bias, const void* residual, const void* mask, int N, int H, int W, int C, int K, int KH,
+                              const float* bias, const void* residual, const void* mask, const void* post_mask, int N, int H, int W, int C,
+                              int K, int KH,
                               int KW, int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate, hipStream_t stream) {
   if (!x || !w16 || !y || (C % 8) || bad_dtype(x_dtype) || bad_dtype(y_dtype)) return UTV2_EARG;
   ConvArgs16 a;
   a.lt.n = 0;
-  a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = mask;
+  a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = mask; a.post_mask = post_mask;
   a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.K = K; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
   a.in_dil = in_dil < 1 ? 1 : in_dil; a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.M = N * OH * OW;
   a.xs = C; a.m_begin = 0;
@@ -808,7 +812,7 @@ int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y
     return UTV2_EARG;
   ConvArgs16 a;
   a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
-  a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr;
+  a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad; a.in_dil = 1;
   a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = C; a.m_begin = 0;
   const bool small = K <= 64;
@@ -830,7 +834,7 @@ int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int
     return UTV2_EARG;
   ConvArgs16 a;
   a.lt.n = 0;
-  a.x = xpad16; a.w = (const __bf16*)w16s; a.y = y; a.scale = scale; a.bias = bias; a.residual = nullptr; a.mask = nullptr;
+  a.x = xpad16; a.w = (const __bf16*)w16s; a.y = y; a.scale = scale; a.bias = bias; a.residual = nullptr; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = H + 6; a.W = W + 8; a.C = 32; a.OH = OH; a.OW = OW; a.K = K; a.KH = 7; a.KW = 1; a.stride = 2; a.pad = 0;
   a.in_dil = 1; a.relu = relu; a.accumulate = 0; a.Kred = 7 * 32; a.M = N * OH * OW; a.xs = 4; a.m_begin = 0;
   const bool small = K <= 64;

@@ -153,8 +153,8 @@ __global__ __launch_bounds__(256) void downsample2x_sum_nhwc_k(const T* __restri
 
 // dgrad of a stride-2 1x1 conv: the compact gradient [N][TH][TW][C] lands on the even pixels of [N][H][W][C], zeros elsewhere
 template <typename T>
-__global__ __launch_bounds__(256) void zero_interleave2x_nhwc_k(const T* __restrict__ src, T* __restrict__ dst, int N, int H, int W,
-                                                              int TH, int TW, int C4) {
+__global__ __launch_bounds__(256) void zero_interleave2x_nhwc_k(const T* __restrict__ src, const T* __restrict__ mask, T* __restrict__ dst,
+                                                              int N, int H, int W, int TH, int TW, int C4) {
   const size_t total = (size_t)N * H * W * C4;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -165,7 +165,14 @@ __global__ __launch_bounds__(256) void zero_interleave2x_nhwc_k(const T* __restr
     const int h = (int)(t % H); t /= H;
     const int n = (int)t;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (!((h | w) & 1)) v = ld4(src, ((size_t)(n * TH + (h >> 1)) * TW + (w >> 1)) * C4 + c);
+    if (!((h | w) & 1)) {
+      v = ld4(src, ((size_t)(n * TH + (h >> 1)) * TW + (w >> 1)) * C4 + c);
+      if (mask) {  // optional [N][H][W][C]: the gradient flows into a ReLU output, masked where it is made
+        const f32x4 mk = ld4(mask, i);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = mk[q] > 0.f ? v[q] : 0.f;
+      }
+    }
     st4(dst, i, v);
   }
 }
@@ -612,14 +619,14 @@ int utv2_downsample2x_sum_nhwc(const void* g, void* dtop, int N, int TH, int TW,
 }
 
 // dst[n,2i,2j,:] = src[n,i,j,:], zero elsewhere.  TH = (H+1)/2, TW = (W+1)/2.
-int utv2_zero_interleave2x_nhwc(const void* src, void* dst, int N, int H, int W, int C, int dtype, hipStream_t stream) {
+int utv2_zero_interleave2x_nhwc(const void* src, const void* mask, void* dst, int N, int H, int W, int C, int dtype, hipStream_t stream) {
   if (!src || !dst || (C & 3)) return UTV2_EARG;
   const int TH = (H + 1) / 2, TW = (W + 1) / 2;
   const dim3 g(grid_for((size_t)N * H * W * C / 4, 256, 1 << 16)), b(256);
   if (dtype == UTV2_BF16)
-    hipLaunchKernelGGL(zero_interleave2x_nhwc_k<__bf16>, g, b, 0, stream, (const __bf16*)src, (__bf16*)dst, N, H, W, TH, TW, C / 4);
+    hipLaunchKernelGGL(zero_interleave2x_nhwc_k<__bf16>, g, b, 0, stream, (const __bf16*)src, (const __bf16*)mask, (__bf16*)dst, N, H, W, TH, TW, C / 4);
   else if (dtype == UTV2_F32)
-    hipLaunchKernelGGL(zero_interleave2x_nhwc_k<float>, g, b, 0, stream, (const float*)src, (float*)dst, N, H, W, TH, TW, C / 4);
+    hipLaunchKernelGGL(zero_interleave2x_nhwc_k<float>, g, b, 0, stream, (const float*)src, (const float*)mask, (float*)dst, N, H, W, TH, TW, C / 4);
   else
     return UTV2_EARG;
   return utv2_launch_status();

@@ -254,12 +254,15 @@ def downsample2x_sum(g, out=None, accumulate=False):
     return out
 
 
-def zero_interleave2x(src, H, W):
-    """[N,(H+1)//2,(W+1)//2,C] -> [N,H,W,C] with src on the even pixels and zeros elsewhere"""
+def zero_interleave2x(src, H, W, mask=None):
+    """[N,(H+1)//2,(W+1)//2,C] -> [N,H,W,C] with src on the even pixels and zeros elsewhere; mask (optional, [N,H,W,C], same dtype):
+    the values are zeroed where mask <= 0"""
     N, TH, TW, C = src.shape
     assert TH == (H + 1) // 2 and TW == (W + 1) // 2
     out = torch.empty((N, H, W, C), dtype=src.dtype, device=src.device)
-    call("utv2_zero_interleave2x_nhwc", _p(src), _p(out), N, H, W, C, _dt(src), _stream())
+    if mask is not None:
+        assert mask.dtype == src.dtype and tuple(mask.shape) == (N, H, W, C)
+    call("utv2_zero_interleave2x_nhwc", _p(src), _p(mask), _p(out), N, H, W, C, _dt(src), _stream())
     return out
 
 
@@ -604,7 +607,7 @@ def weight_flip_transpose_bf16_batched(arena, scales, bank, table, nlayers):
 
 
 def conv2d_fwd_bf16(x, w16, scale=None, bias=None, residual=None, stride=1, pad=0, relu=False, kh=1, kw=1, out=None,
-                    in_dil=1, out_hw=None, accumulate=False, out_dtype=None, mask=None):
+                    in_dil=1, out_hw=None, accumulate=False, out_dtype=None, mask=None, post_mask=None):
     """x: fp32 or bf16 NHWC; the output (and `residual`) element type is out_dtype (default: x's)."""
     N, H, W, C = x.shape
     K = w16.shape[0]
@@ -615,19 +618,20 @@ def conv2d_fwd_bf16(x, w16, scale=None, bias=None, residual=None, stride=1, pad=
         OH, OW = out_hw
     if out is None:
         out = torch.empty((N, OH, OW, K), dtype=_act_dtype(x, out_dtype), device=x.device)
-    call("utv2_conv2d_nhwc_fwd_bf16", _p(x), _dt(x), _p(w16), _p(out), _same_dt(out, residual, mask), _p(scale), _p(bias),
-         _p(residual), _p(mask), N, H, W, C, K, kh, kw, stride, pad, in_dil, OH, OW, int(relu), int(accumulate), _stream())
+    call("utv2_conv2d_nhwc_fwd_bf16", _p(x), _dt(x), _p(w16), _p(out), _same_dt(out, residual, mask, post_mask), _p(scale), _p(bias),
+         _p(residual), _p(mask), _p(post_mask), N, H, W, C, K, kh, kw, stride, pad, in_dil, OH, OW, int(relu), int(accumulate), _stream())
     return out
 
 
-def conv2d_dgrad_bf16(dy, wt16, in_shape, stride, pad, kh, kw, out=None, out_dtype=None, mask=None, residual=None):
-    """dx = dgrad(dy); mask (the forward activation dx is the gradient of): dx = mask > 0 ? dx : 0; residual: dx += residual"""
+def conv2d_dgrad_bf16(dy, wt16, in_shape, stride, pad, kh, kw, out=None, out_dtype=None, mask=None, residual=None, post_mask=None):
+    """dx = dgrad(dy); mask (the forward activation dx is the gradient of): dx = mask > 0 ? dx : 0; residual: dx += residual;
+    post_mask: dx = post_mask > 0 ? dx : 0 after the residual add"""
     N, H, W, C = in_shape
     _, OH, OW, K = dy.shape
     if out is None:
         out = torch.empty((N, H, W, C), dtype=_act_dtype(dy, out_dtype), device=dy.device)
-    call("utv2_conv2d_nhwc_fwd_bf16", _p(dy), _dt(dy), _p(wt16), _p(out), _same_dt(out, residual, mask), c_p(0), c_p(0), _p(residual),
-         _p(mask), N, OH, OW, K, C, kh, kw, 1, kh - 1 - pad, stride, H, W, 0, 0, _stream())
+    call("utv2_conv2d_nhwc_fwd_bf16", _p(dy), _dt(dy), _p(wt16), _p(out), _same_dt(out, residual, mask, post_mask), c_p(0), c_p(0),
+         _p(residual), _p(mask), _p(post_mask), N, OH, OW, K, C, kh, kw, 1, kh - 1 - pad, stride, H, W, 0, 0, _stream())
     return out
 
 

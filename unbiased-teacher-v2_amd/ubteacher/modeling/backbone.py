@@ -99,6 +99,11 @@ class Bottleneck:
         self.shortcut = None
         if cin != cout:
             self.shortcut = _conv_bn(store, folder, prefix + ".shortcut", cin, cout, 1, stride, 0, False, trainable)
+        # backward of the fused AMP node (ops._BottleneckFn): input_relu - the gradient returned for the input is masked by input > 0
+        # in the dgrad epilogue; grad_premasked - every consumer of this block's output does the same, so no mask pass of its own.
+        # Both are switched on by the FPN builder, which knows all consumers of the stage outputs.
+        self.input_relu = False
+        self.grad_premasked = False
 
     def __call__(self, x):
         return ops.bottleneck(self, x)
@@ -179,6 +184,16 @@ class FPN:
             stage = int(math.log2(self.bottom_up.strides[f]))
             self.lateral[f] = _conv_bias(store, "backbone.fpn_lateral%d" % stage, self.bottom_up.channels[f], oc, 1, 1, 0, _xavier_init)
             self.output[f] = _conv_bias(store, "backbone.fpn_output%d" % stage, oc, oc, 3, 1, 1, _xavier_init)
+        # Gradient pre-masking (ops.premask_on): a stage output is consumed by the next block / next stage's first block and by this
+        # stage's lateral only, and all of them mask the gradient they return by (output > 0) in their dgrad epilogue - so the fused
+        # bottlenecks of the trainable stages skip the mask pass at the top of their backward.
+        for name, blocks, trainable in self.bottom_up.stages:
+            if trainable:
+                for blk in blocks:
+                    blk.input_relu = True
+                    blk.grad_premasked = True
+                if name in self.lateral:
+                    self.lateral[name].premask_input = True
         self.top_block_kind = top_block_kind
         self.levels_fp32 = False  # every consumer of the level buffer (tower / RPN convs, RoIAlign) takes bf16 under AMP
         self.top = []

@@ -8,6 +8,8 @@ Design notes (MI355X-first, not a translation of torch.nn):
     runs even when the activation input comes from the frozen stem/res2;
   * FrozenBN is folded into the conv epilogue (scale/shift), ReLU and the residual add too.
 """
+import os
+
 import torch
 
 from . import hip
@@ -157,6 +159,7 @@ class Conv:
         self.kred = kred if kred is not None else k * k * cin
         self.colscale = colscale  # (Handle scalar, ncols): Scale layer on the first ncols output channels
         self.out_fp32 = out_fp32  # AMP: keep this layer's output fp32 (loss-side head outputs, RoIAlign inputs)
+        self.premask_input = False  # set by the model builder: the input is a fused bottleneck's ReLU output (see premask_on)
         self._wt = None
         self._wt_version = -1
 
@@ -303,16 +306,20 @@ class _ConvFn(torch.autograd.Function):
             x4 = x.view(1, x.shape[0], 1, x.shape[1]) if meta is not None else x
             g4 = g.view(1, g.shape[0], 1, g.shape[1]) if meta is not None else g
             if ctx.needs_input_grad[0]:
+                # premask_input: x is the ReLU output of a fused bottleneck that expects its incoming gradient already masked by x > 0
+                pm = x4 if (layer.premask_input and premask_on()) else None
                 if d16 and layer.k == 1 and layer.stride == 2 and layer.pad == 0:
                     # only the even input pixels receive gradient: a plain GEMM on the compact grid + a zero-interleave,
                     # instead of a 4x larger dilated gather that is 3/4 masked
                     dxc = hip.conv2d_fwd_bf16(g4, layer.wt16(wsc), out_dtype=x.dtype)
-                    dx = hip.zero_interleave2x(dxc, x4.shape[1], x4.shape[2])
+                    dx = hip.zero_interleave2x(dxc, x4.shape[1], x4.shape[2], mask=pm)
                 elif d16:
                     dx = hip.conv2d_dgrad_bf16(g4, layer.wt16(wsc), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k,
-                                               out_dtype=x.dtype)
+                                               out_dtype=x.dtype, mask=pm)
                 else:
                     dx = hip.conv2d_dgrad(g4, layer.wt(), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k)
+                    if pm is not None:
+                        dx = hip.relu_bwd_scale(dx, x4, None)
                 if meta is not None:
                     dx = dx.view(x.shape)
             if layer.use_bf16_wgrad():
@@ -342,9 +349,16 @@ def _wgrad16(layer, x4, g4):
                           rowscale=layer.bn.scale)
 
 
-def _dgrad16(layer, g4, in_shape, mask=None, residual=None):
+def _dgrad16(layer, g4, in_shape, mask=None, residual=None, post_mask=None):
     return hip.conv2d_dgrad_bf16(g4, layer.wt16(layer.bn.scale), tuple(in_shape), layer.stride, layer.pad, layer.k, layer.k,
-                                 out_dtype=torch.bfloat16, mask=mask, residual=residual)
+                                 out_dtype=torch.bfloat16, mask=mask, residual=residual, post_mask=post_mask)
+
+
+def premask_on():
+    """Gradients that flow into a bottleneck's ReLU output are masked where they are produced (the next block's conv1 dgrad epilogue,
+    the FPN lateral's dgrad epilogue) instead of by a separate pass at the top of the block's backward.  UTV2_PREMASK=0: the separate
+    pass (A/B runs; identical results - a 0/1 mask distributes over the sum of the contributions)."""
+    return os.environ.get("UTV2_PREMASK", "1") != "0"
 
 
 class _BottleneckFn(torch.autograd.Function):
@@ -368,7 +382,12 @@ class _BottleneckFn(torch.autograd.Function):
         block = ctx.block
         c1, c2, c3, cs = block.conv1, block.conv2, block.conv3, block.shortcut
         x, y1, y2, y3 = ctx.saved_tensors
-        gm = hip.relu_bwd_scale(dy.contiguous(), y3, None)         # gradient at conv3's BN output == at the residual input
+        pre = premask_on()
+        if pre and block.grad_premasked:    # every producer of dy applied this block's output ReLU mask (y3 > 0) already
+            gm = dy.contiguous()
+        else:
+            gm = hip.relu_bwd_scale(dy.contiguous(), y3, None)     # gradient at conv3's BN output == at the residual input
+        pm = x if (pre and block.input_relu) else None              # x is a ReLU output whose producer expects a masked gradient
         _wgrad16(c3, y2, gm)
         g2 = _dgrad16(c3, gm, y2.shape, mask=y2)                    # ... through ReLU(conv2): at conv2's BN output
         _wgrad16(c2, y1, g2)
@@ -379,14 +398,14 @@ class _BottleneckFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if cs is None:
-                dx = _dgrad16(c1, g1, x.shape, residual=gm)         # identity branch added in the epilogue
+                dx = _dgrad16(c1, g1, x.shape, residual=gm, post_mask=pm)   # identity branch added in the epilogue
             elif c1.stride == 2:
                 c = hip.conv2d_fwd_bf16(gm, cs.wt16(cs.bn.scale), out_dtype=torch.bfloat16)       # compact grids: only the
                 c = hip.conv2d_fwd_bf16(g1, c1.wt16(c1.bn.scale), residual=c, out_dtype=torch.bfloat16)   # even pixels get gradient
-                dx = hip.zero_interleave2x(c, x.shape[1], x.shape[2])
+                dx = hip.zero_interleave2x(c, x.shape[1], x.shape[2], mask=pm)
             else:
                 d = _dgrad16(cs, gm, x.shape)
-                dx = _dgrad16(c1, g1, x.shape, residual=d)
+                dx = _dgrad16(c1, g1, x.shape, residual=d, post_mask=pm)
         if GRAD_SYNC[0] is not None:
             for l in (c3, c2, c1, cs):
                 if l is not None:
