@@ -103,6 +103,22 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
     }
   }
   const bool full = cok[NQ - 1] && (K & 7) == 0;  // keeps the 16-byte accesses 16-byte aligned
+  // bf16 residual rows are fetched BEFORE the accumulators bounce through LDS: the loads then overlap the bounce instead of
+  // sitting, one dependent load after another, between it and the stores
+  bf16x8_t rpre[2][32 / RPI];
+  const bool prefetch = NQ == 2 && full && residual != nullptr;
+  if constexpr (NQ == 2) {
+    if (prefetch) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+          const int m = m_base + i * 32 + it * RPI + rsub;
+          const size_t off = (size_t)(m < M ? m : M - 1) * K + co;
+          rpre[i][it] = *(const bf16x8_t*)((const __bf16*)residual + off);
+        }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -132,7 +148,7 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
               for (int q = 0; q < 8; ++q) v[q >> 2][q & 3] = (float)mk[q] > 0.f ? v[q >> 2][q & 3] : 0.f;
             }
             if (residual) {
-              const bf16x8_t r = *(const bf16x8_t*)(residual + off);
+              const bf16x8_t r = rpre[i][it];
 #pragma unroll
               for (int q = 0; q < 8; ++q) v[q >> 2][q & 3] += (float)r[q];
             }
