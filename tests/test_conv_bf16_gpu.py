@@ -376,3 +376,29 @@ def test_post_mask_epilogue_and_masked_zero_interleave():
     ref[:, ::2, ::2] = torch.where(full_mask[:, ::2, ::2].float() > 0, c, torch.zeros_like(c))
     assert torch.equal(z, ref)
     assert torch.equal(hip.zero_interleave2x(c, 20, 24)[:, ::2, ::2], c)
+
+
+def test_batched_weight_flip_equals_per_layer_flip():
+    """one launch for all layers (tiled transpose) == the per-layer element-wise kernel, bit for bit, incl. ragged K / C and scales"""
+    import struct
+    from ubteacher import hip
+    torch.manual_seed(3)
+    layers = [(256, 3, 3, 256, True), (80, 3, 3, 256, False), (72, 1, 1, 40, True), (512, 1, 1, 2048, False), (64, 7, 1, 32, True)]
+    arena, scales, recs, refs = [], [], [], []
+    w_off = dst_off = sc_off = 0
+    for (K, KH, KW, C, has_scale) in layers:
+        w = torch.randn(K, KH, KW, C, device="cuda")
+        sc = (torch.rand(K, device="cuda") + 0.5) if has_scale else None
+        arena.append(w.reshape(-1))
+        if sc is not None:
+            scales.append(sc)
+        recs.append(struct.pack("<qqqiiii", w_off, dst_off, sc_off if has_scale else -1, K, KH, KW, C))
+        refs.append(hip.weight_flip_transpose_bf16(w, K, KH, KW, C, scale=sc).reshape(-1))
+        w_off += w.numel(); dst_off += w.numel(); sc_off += K if has_scale else 0
+    arena = torch.cat(arena).contiguous()
+    scales = torch.cat(scales).contiguous()
+    table = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).cuda()
+    bank = torch.zeros(dst_off, dtype=torch.bfloat16, device="cuda")
+    hip.weight_flip_transpose_bf16_batched(arena, scales, bank, table, len(layers))
+    torch.cuda.synchronize()
+    assert torch.equal(bank, torch.cat(refs))
