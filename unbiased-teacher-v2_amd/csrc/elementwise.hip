@@ -110,6 +110,39 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_k(const TI* __restrict_
   }
 }
 
+// bf16 -> bf16 form with 8 channels (16 bytes) per thread and 32-bit index arithmetic (max is exact: same result as the generic kernel)
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_bf16x8_k(const __bf16* __restrict__ x, __bf16* __restrict__ y, int N, int H, int W,
+                                                                int C8, int OH, int OW) {
+  const unsigned total = (unsigned)N * OH * OW * C8;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    unsigned t = i;
+    const int c = (int)(t % C8); t /= C8;
+    const int ow = (int)(t % OW); t /= OW;
+    const int oh = (int)(t % OH); t /= OH;
+    const int n = (int)t;
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int ih = oh * 2 - 1 + dh;
+      if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int iw = ow * 2 - 1 + dw;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const bf16x8_t v = ((const bf16x8_t*)x)[((size_t)(n * H + ih) * W + iw) * C8 + c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+      }
+    }
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)m[e];
+    ((bf16x8_t*)y)[i] = o;
+  }
+}
+
 // FPN top-down: out[n,h,w,:] = lateral[n,h,w,:] + top[n,h/2,w/2,:]   (nearest x2)
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_add_nhwc_k(const T* __restrict__ lat, const T* __restrict__ top,
@@ -608,6 +641,10 @@ int utv2_maxpool3x3s2_nhwc(const void* x, int x_dtype, void* y, int y_dtype, int
     hipLaunchKernelGGL((maxpool3x3s2_nhwc_k<float, float>), g, b, 0, stream, (const float*)x, (float*)y, N, H, W, C / 4, OH, OW);
   else if (x_dtype == UTV2_F32 && y_dtype == UTV2_BF16)
     hipLaunchKernelGGL((maxpool3x3s2_nhwc_k<float, __bf16>), g, b, 0, stream, (const float*)x, (__bf16*)y, N, H, W, C / 4, OH, OW);
+  else if (x_dtype == UTV2_BF16 && y_dtype == UTV2_BF16 && (C & 7) == 0 && (size_t)N * OH * OW * C / 8 < (1ull << 31) &&
+           (size_t)N * H * W < (1ull << 31))
+    hipLaunchKernelGGL(maxpool3x3s2_nhwc_bf16x8_k, dim3(grid_for((size_t)N * OH * OW * C / 8, 256, 1 << 16)), b, 0, stream,
+                       (const __bf16*)x, (__bf16*)y, N, H, W, C / 8, OH, OW);
   else if (x_dtype == UTV2_BF16 && y_dtype == UTV2_BF16)
     hipLaunchKernelGGL((maxpool3x3s2_nhwc_k<__bf16, __bf16>), g, b, 0, stream, (const __bf16*)x, (__bf16*)y, N, H, W, C / 4, OH, OW);
   else
