@@ -375,9 +375,7 @@ __global__ __launch_bounds__(256) void gn_apply_relu(GnSegs sg, const T* __restr
   const int g = (c4 * 4) / cpg;
   const float m = mean[seg * G + g], r = rstd[seg * G + g];
   const f32x4 ga = ((const f32x4*)gamma)[c4], be = ((const f32x4*)beta)[c4];
-  for (int row = r0 + rl; row < r1; row += RL) {
-    const size_t i = (size_t)row * C4 + c4;
-    const f32x4 v = ld4(x, i);
+  auto apply = [&](const f32x4 v, size_t i) {
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -385,7 +383,16 @@ __global__ __launch_bounds__(256) void gn_apply_relu(GnSegs sg, const T* __restr
       o[e] = relu ? fmaxf(t, 0.f) : t;
     }
     st4(y, i, o);
+  };
+  int row = r0 + rl;
+  for (; row + 3 * RL < r1; row += 4 * RL) {  // four independent row loads in flight per thread
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = ld4(x, (size_t)(row + u * RL) * C4 + c4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) apply(v[u], (size_t)(row + u * RL) * C4 + c4);
   }
+  for (; row < r1; row += RL) apply(ld4(x, (size_t)row * C4 + c4), (size_t)row * C4 + c4);
 }
 
 // backward stage 1: per (chunk, c): A = sum g*xhat, B = sum g   with g = dy * (y > 0)
