@@ -95,6 +95,29 @@ def _worker(rank, world, port, q):
     dist.all_reduce(ref, op=dist.ReduceOp.SUM)
     out["bucketed_equals_flat"] = bool(torch.equal(gflat, ref))
     out["reset"] = (sum(gb.pending), sum(gb.launched), len(gb.works))
+    # (6) the two-crop loader over a registered dataset: the label / unlabel split by the seed table, TrainingSampler streams whose
+    # seed is shared by the ranks (comm.shared_random_seed) and rank-strided, per-rank batch sizes = total // world (host logic only:
+    # an identity mapper stands in for the GPU one)
+    import itertools
+    from ubteacher.data import DatasetCatalog, build_detection_semisup_train_loader_two_crops, register_synthetic
+    if "gloo_ds" in DatasetCatalog:
+        DatasetCatalog.remove("gloo_ds")
+    register_synthetic("gloo_ds", 50, seed=5)
+    cfg2 = get_config("fcos", 1, ["SOLVER.IMG_PER_BATCH_LABEL", 4, "SOLVER.IMG_PER_BATCH_UNLABEL", 2, "MODEL.DEVICE", "cpu"])
+    cfg2.DATASETS.TRAIN = ("gloo_ds",)
+    cfg2.DATASETS.CROSS_DATASET = False
+    cfg2.DATALOADER.SUP_PERCENT = 30.0
+    cfg2.DATALOADER.RANDOM_DATA_SEED = 0
+    cfg2.DATALOADER.RANDOM_DATA_SEED_PATH = os.path.join(ROOT, "tests", "golden", "supervision_small.json")
+    cfg2.DATALOADER.FILTER_EMPTY_ANNOTATIONS = False
+    ident = lambda d: ({"image_id": d["image_id"], "width": d["width"], "height": d["height"], "v": "s"},
+                       {"image_id": d["image_id"], "width": d["width"], "height": d["height"], "v": "w"})
+    loader = build_detection_semisup_train_loader_two_crops(cfg2, mapper=ident)
+    seq = []
+    for lq, lk, uq, uk in itertools.islice(iter(loader), 6):
+        seq.append(([d["image_id"] for d in lq], [d["image_id"] for d in uq], len(lk), len(uk)))
+    out["loader_seq"] = seq
+    out["label_stream"] = list(itertools.islice(iter(loader.label_dataset.sampler), 12))
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -124,6 +147,15 @@ def test_world_size_2_gloo():
     assert m["loss_a"] == pytest.approx(1.5) and m["loss_b"] == pytest.approx(3.0) and m["other"] == pytest.approx(7.0)
     assert m["total_loss"] == pytest.approx(4.5)                    # sum of averaged keys starting with "loss"
     assert res[1]["metrics"] == {}                                  # only the main process aggregates
+    import json
+    labeled = set(json.load(open(os.path.join(ROOT, "tests", "golden", "supervision_small.json")))["30.0"]["0"])
+    for r in range(world):
+        for lids, uids, nlk, nuk in res[r]["loader_seq"]:
+            assert len(lids) == nlk == 2 and len(uids) == nuk == 1           # 4 // 2 labeled, 2 // 2 unlabeled per rank
+            assert set(lids) <= labeled and not (set(uids) & labeled)
+    # one shared permutation stream, rank-strided: interleaving the two ranks' index streams gives a sequence of permutations of range(15)
+    inter = [res[i % 2]["label_stream"][i // 2] for i in range(24)]
+    assert sorted(inter[:15]) == list(range(15)) and res[0]["label_stream"] != res[1]["label_stream"]
     for r in range(world):
         assert res[r]["nbuckets"] >= 3 and res[r]["cover"] == (0, 5000, True)
         assert 0 < res[r]["launched_before_finish"] < res[r]["nbuckets"]     # buckets with a layer still pending wait
