@@ -422,3 +422,23 @@ def test_pseudo_regression_kl_term_vs_reference_golden(case, kl_type):
     cfg.MODEL.FCOS.KL_LOSS = False
     with pytest.raises(ValueError):  # fcos_outputs.py:587-588
         FCOSOutputs(cfg).pseudo_losses(build_head_out(lv)[0], level_hw, gt)
+
+
+def test_two_criteria_in_one_launch_set_equal_two_calls(fc):
+    """predict_proposals with a tuple of ranking criteria (one set of rank-key / top-k / decode / NMS launches over (criterion, image)
+    pairs) returns exactly what the separate calls return - every field, bit for bit."""
+    from ubteacher.modeling.fcos import FCOSOutputs
+    outm = FCOSOutputs(fcos_cfg())
+    outm.training = False
+    head_out, level_hw = build_head_out(fc)
+    N, H, W = int(fc["N"]), int(fc["H"]), int(fc["W"])
+    sizes = [(H, W)] * N
+    both = outm.predict_proposals(head_out, level_hw, sizes, ("cls_n_ctr", "cls_n_loc", "cls"))
+    assert isinstance(both, list) and len(both) == 3
+    for res, m in zip(both, ("cls_n_ctr", "cls_n_loc", "cls")):
+        one = outm.predict_proposals(head_out, level_hw, sizes, m)
+        assert set(res.f) == set(one.f)
+        for k in one.f:
+            assert torch.equal(res[k], one[k]), (m, k)
+    with pytest.raises(ValueError):
+        outm.predict_proposals(head_out, level_hw, sizes, ("cls", "nope"))

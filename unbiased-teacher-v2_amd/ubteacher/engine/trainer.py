@@ -352,6 +352,7 @@ class UBTeacherTrainer(_TrainerBase):
         self.scheduler = self.build_lr_scheduler(cfg, self.optimizer)
         self.pseudo_generator = PseudoGenerator(cfg)
         self.fuse_student_passes = os.environ.get("UTV2_FUSE_STUDENT_PASSES", "1") != "0"
+        self.fuse_teacher_nms = os.environ.get("UTV2_FUSE_TEACHER_NMS", "1") != "0"
         self._common_init(cfg, data_loader)
 
     # pseudo-label dict surgery (trainer.py:161-175)
@@ -395,9 +396,20 @@ class UBTeacherTrainer(_TrainerBase):
             record_dict = {"ema_rate_1000x": ema_keep_rate * 1000}
 
             with torch.no_grad():
-                pred_teacher, raw_pred_teacher = self.model_teacher(
-                    unlabel_data_k, output_raw=True, nms_method=cfg.MODEL.FCOS.NMS_CRITERIA_TRAIN, branch="teacher_weak")
-                pred_teacher_loc = self.pseudo_generator.nms_from_dense(raw_pred_teacher, cfg.MODEL.FCOS.NMS_CRITERIA_REG_TRAIN)
+                fo_t = self.model_teacher.proposal_generator.fcos_outputs     # eval mode: reads the *_TEST thresholds
+                fo_p = self.pseudo_generator.fcos_output                       # never put in eval mode: *_TRAIN
+                same = ((fo_t.pre_nms_thresh_test, fo_t.pre_nms_topk_test, fo_t.post_nms_topk_test, fo_t.nms_thresh) ==
+                        (fo_p.pre_nms_thresh_train, fo_p.pre_nms_topk_train, fo_p.post_nms_topk_train, fo_p.nms_thresh))
+                if self.fuse_teacher_nms and same and not fo_t.training:
+                    # both criteria (classification / regression pseudo sets, trainer.py:232-251) in ONE set of launches over
+                    # (criterion, image) pairs: identical detections, half the latency-bound top-k / NMS kernels
+                    (pred_teacher, pred_teacher_loc), raw_pred_teacher = self.model_teacher(
+                        unlabel_data_k, output_raw=True,
+                        nms_method=(cfg.MODEL.FCOS.NMS_CRITERIA_TRAIN, cfg.MODEL.FCOS.NMS_CRITERIA_REG_TRAIN), branch="teacher_weak")
+                else:
+                    pred_teacher, raw_pred_teacher = self.model_teacher(
+                        unlabel_data_k, output_raw=True, nms_method=cfg.MODEL.FCOS.NMS_CRITERIA_TRAIN, branch="teacher_weak")
+                    pred_teacher_loc = self.pseudo_generator.nms_from_dense(raw_pred_teacher, cfg.MODEL.FCOS.NMS_CRITERIA_REG_TRAIN)
 
             if S.PSEUDO_BBOX_SAMPLE == "thresholding":
                 cur_threshold = S.BBOX_THRESHOLD

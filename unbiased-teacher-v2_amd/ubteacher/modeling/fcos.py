@@ -326,45 +326,53 @@ class FCOSOutputs:
 
     # -- decode + NMS (fcos_outputs.py:1046-1320) ---------------------------------------------------
     def predict_proposals(self, head_out, level_hw, image_sizes, nms_method="cls_n_ctr", max_det=128):
+        """nms_method: one ranking criterion -> PaddedBoxes; a tuple / list of criteria -> a list of PaddedBoxes in that order, computed
+        by ONE set of launches (ranking keys, exact top-k, decode, class-aware NMS) over (criterion, image) pairs - the UTv2 trainer needs
+        the teacher's detections under two criteria every iteration (trainer.py:232-251) and these kernels are latency-bound."""
         if self.training:
             th, pre, post = self.pre_nms_thresh_train, self.pre_nms_topk_train, self.post_nms_topk_train
         else:
             th, pre, post = self.pre_nms_thresh_test, self.pre_nms_topk_test, self.post_nms_topk_test
-        if nms_method not in METHODS:
-            raise ValueError("Undefined nms criteria")
-        method = METHODS[nms_method]
+        single = isinstance(nms_method, str)
+        names = [nms_method] if single else list(nms_method)
+        for nm in names:
+            if nm not in METHODS:
+                raise ValueError("Undefined nms criteria")
+        methods = [METHODS[nm] for nm in names]
+        M = len(methods)
         meta = head_out["meta"]
         logits_all, box_all = head_out["logits"].detach(), head_out["box"].detach()
         N = meta.N
+        NV = M * N  # virtual images: criterion-major
         dev = logits_all.device
         ks = [min(pre, h * w * self.num_classes) for (h, w) in level_hw]
         MAXC = sum(ks)
         outs = dict(
-            boxes=torch.empty((N, MAXC, 4), dtype=torch.float32, device=dev),
-            scores=torch.empty((N, MAXC), dtype=torch.float32, device=dev),
-            classes=torch.empty((N, MAXC), dtype=torch.int32, device=dev),
-            locations=torch.empty((N, MAXC, 2), dtype=torch.float32, device=dev),
-            centerness=torch.empty((N, MAXC), dtype=torch.float32, device=dev),
-            cls_confid=torch.empty((N, MAXC), dtype=torch.float32, device=dev),
-            reg_pred_std=torch.empty((N, MAXC, 4), dtype=torch.float32, device=dev),
-            fpn_levels=torch.empty((N, MAXC), dtype=torch.int32, device=dev),
-            valid=torch.empty((N, MAXC), dtype=torch.uint8, device=dev),
+            boxes=torch.empty((NV, MAXC, 4), dtype=torch.float32, device=dev),
+            scores=torch.empty((NV, MAXC), dtype=torch.float32, device=dev),
+            classes=torch.empty((NV, MAXC), dtype=torch.int32, device=dev),
+            locations=torch.empty((NV, MAXC, 2), dtype=torch.float32, device=dev),
+            centerness=torch.empty((NV, MAXC), dtype=torch.float32, device=dev),
+            cls_confid=torch.empty((NV, MAXC), dtype=torch.float32, device=dev),
+            reg_pred_std=torch.empty((NV, MAXC, 4), dtype=torch.float32, device=dev),
+            fpn_levels=torch.empty((NV, MAXC), dtype=torch.int32, device=dev),
+            valid=torch.empty((NV, MAXC), dtype=torch.uint8, device=dev),
         )
-        # per-level top-k (fcos_outputs.py:1238-1241): the ranking keys of every (level, image) pair are the ragged rows of ONE
-        # flat buffer and one exact radix select (utv2_topk_rows_i64) serves them all - no padding, no per-level launches
+        # per-level top-k (fcos_outputs.py:1238-1241): the ranking keys of every (level, criterion, image) triple are the ragged rows of
+        # ONE flat buffer and one exact radix select (utv2_topk_rows_i64) serves them all - no padding, no per-level launches
         L = len(level_hw)
         C = self.num_classes
         widths = [h * w * C for h, w in level_hw]
         kmax = max(ks)
         if kmax <= 2048:
-            ck = (N, tuple(level_hw), C, str(dev))
+            ck = (NV, tuple(level_hw), C, str(dev))
             cached = getattr(self, "_topk_rows", None)
             if cached is None or cached[0] != ck:
                 offs, o = [], 0
                 for wd in widths:
-                    for n in range(N):
+                    for n in range(NV):
                         offs.append(o + n * wd)
-                    o += N * wd
+                    o += NV * wd
                 offs.append(o)
                 cached = (ck, torch.tensor(offs, dtype=torch.int64, device=dev), o)
                 self._topk_rows = cached
@@ -373,30 +381,35 @@ class FCOSOutputs:
             o = 0
             for l, (h, w) in enumerate(level_hw):
                 r0, r1 = meta.rows[l]
-                hip.fcos_rank_keys(logits_all[r0:r1], box_all[r0:r1], self.reg_max, N, h * w, th, method,
-                                   out=keys[o:o + N * widths[l]].view(N, widths[l]), row_stride=widths[l])
-                o += N * widths[l]
-            top_all = hip.topk_rows(keys, row_off, L * N, max(widths), kmax)
-            tops = {l: top_all[l * N:(l + 1) * N, :ks[l]].contiguous() for l in range(L)}
+                for method in methods:
+                    hip.fcos_rank_keys(logits_all[r0:r1], box_all[r0:r1], self.reg_max, N, h * w, th, method,
+                                       out=keys[o:o + N * widths[l]].view(N, widths[l]), row_stride=widths[l])
+                    o += N * widths[l]
+            top_all = hip.topk_rows(keys, row_off, L * NV, max(widths), kmax)
+            tops = {(l, m): top_all[(l * M + m) * N:(l * M + m + 1) * N, :ks[l]].contiguous() for l in range(L) for m in range(M)}
         else:  # very large PRE_NMS_TOPK: torch's radix select, one padded matrix per group of levels
             groups = [[0], list(range(1, L))] if L > 1 else [[0]]
             tops = {}
-            for grp in groups:
-                width = max(widths[l] for l in grp)
-                keys = torch.full((len(grp) * N, width), -1, dtype=torch.int64, device=dev)
-                for i, l in enumerate(grp):
-                    h, w = level_hw[l]
-                    r0, r1 = meta.rows[l]
-                    hip.fcos_rank_keys(logits_all[r0:r1], box_all[r0:r1], self.reg_max, N, h * w, th, method,
-                                       out=keys[i * N:(i + 1) * N], row_stride=width)
-                top_all = torch.topk(keys, max(ks[l] for l in grp), dim=1, sorted=True).values
-                for i, l in enumerate(grp):
-                    tops[l] = top_all[i * N:(i + 1) * N, :ks[l]].contiguous()
-        slot0 = 0
-        for l, (h, w) in enumerate(level_hw):
-            r0, r1 = meta.rows[l]
-            hip.fcos_decode(tops[l], logits_all[r0:r1], box_all[r0:r1], self.reg_max, N, h * w, w, self.strides[l], l, method, slot0, outs)
-            slot0 += ks[l]
+            for m, method in enumerate(methods):
+                for grp in groups:
+                    width = max(widths[l] for l in grp)
+                    keys = torch.full((len(grp) * N, width), -1, dtype=torch.int64, device=dev)
+                    for i, l in enumerate(grp):
+                        h, w = level_hw[l]
+                        r0, r1 = meta.rows[l]
+                        hip.fcos_rank_keys(logits_all[r0:r1], box_all[r0:r1], self.reg_max, N, h * w, th, method,
+                                           out=keys[i * N:(i + 1) * N], row_stride=width)
+                    top_all = torch.topk(keys, max(ks[l] for l in grp), dim=1, sorted=True).values
+                    for i, l in enumerate(grp):
+                        tops[(l, m)] = top_all[i * N:(i + 1) * N, :ks[l]].contiguous()
+        for m, method in enumerate(methods):
+            outs_m = {k: v[m * N:(m + 1) * N] for k, v in outs.items()}
+            slot0 = 0
+            for l, (h, w) in enumerate(level_hw):
+                r0, r1 = meta.rows[l]
+                hip.fcos_decode(tops[(l, m)], logits_all[r0:r1], box_all[r0:r1], self.reg_max, N, h * w, w, self.strides[l], l, method, slot0,
+                                outs_m)
+                slot0 += ks[l]
         keep, cnt = hip.nms_batched(outs["boxes"], outs["scores"], outs["classes"], outs["valid"], self.nms_thresh,
                                     class_aware=True, post_topk=post, max_out=max_det)
         idx = keep.clamp(min=0).long()
@@ -409,7 +422,8 @@ class FCOSOutputs:
             f[k] = torch.gather(v, 1, ix).contiguous()
         f["valid"] = valid
         f["count"] = cnt
-        return PaddedBoxes(image_sizes, **f)
+        res = [PaddedBoxes(image_sizes, **{k: v[m * N:(m + 1) * N].contiguous() for k, v in f.items()}) for m in range(M)]
+        return res[0] if single else res
 
 
 @PROPOSAL_GENERATOR_REGISTRY.register()
