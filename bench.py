@@ -1,6 +1,7 @@
 """bench.py - images/sec of the UTv2 training step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N>1: spawns its N ranks itself, or joins the world
+                                                            torch.distributed.run started it in)
 
 A "step" is one UBTeacherTrainer.run_step_full_semisup on one synthetic COCO-shaped batch
 (FCOS R50-FPN, 4 labeled + 4 unlabeled 1333x800 images per GPU, post-burn-in: teacher EMA,
@@ -148,7 +149,7 @@ def cpu_baseline(cfg):
             "sample": "1 step, 1 labeled (weak+strong views) + 1 unlabeled 1333x800 image, fp32, torch CPU kernels, %.1f s" % dt}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -158,19 +159,34 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
                     help="conv arithmetic: bf16 = the config's SOLVER.AMP.ENABLED path (bf16 MFMA, fp32 accumulate); f32 = exact-f32 MFMA")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    # dry-run hooks for boxes with ONE GPU (tests of the N > 1 code path): all ranks on device 0 over gloo
-    if os.environ.get("UTV2_BENCH_SINGLE_DEVICE") == "1":
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
+
+def _launcher_name(world):
+    if os.environ.get("TORCHELASTIC_RUN_ID"):
+        return "torch.distributed.run"
+    return "ubteacher.engine.launch" if world > 1 else "single process"
+
+
+def worker(args):
+    """one rank (ubteacher.engine.launch has bound the device and joined the RCCL world)"""
+    from ubteacher.engine.launch import dist_info
+    info = dist_info()
+    rank, local_rank, world = info["rank"], info["local_rank"], info["world_size"]
+    assert world == args.gpus, "bench: %d ranks were requested, this process is in a world of %d" % (args.gpus, world)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # nccl == RCCL over xGMI on ROCm
-        dist.init_process_group(os.environ.get("UTV2_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        assert dist.is_initialized() and dist.get_world_size() == args.gpus
+    device_index = info["device"]
+    if os.environ.get("UTV2_BENCH_LAUNCH_ONLY") == "1":   # tests of the launch contract on boxes without GPUs: report the world, stop
+        ids = [None] * world
+        if world > 1:
+            dist.all_gather_object(ids, rank)
+        else:
+            ids = [0]
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "ranks": {"world_size": world, "backend": info["backend"], "rank_ids": ids,
+                                                         "launcher": _launcher_name(world)}}), flush=True)
+        return
 
     from ubteacher.engine import UBTeacherTrainer
     from ubteacher.presets import get_config
@@ -178,16 +194,14 @@ def main():
     hip.load()
     cfg = get_config("fcos", 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label * world, "SOLVER.IMG_PER_BATCH_UNLABEL",
                                  args.unlabel * world, "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", args.dtype == "bf16",
-                                 "MODEL.DEVICE", "cuda:%d" % local_rank])
+                                 "MODEL.DEVICE", "cuda:%d" % device_index])
     torch.manual_seed(0)
     timer = ConvTimer(args.dtype)
     timer.install()
     tr = UBTeacherTrainer(cfg)
     batch = tr._data_loader.batches[0]
     tune_for_pseudo_labels(tr, batch)
-    if world > 1:  # identical students on every rank (DDP broadcasts rank 0's parameters)
-        dist.broadcast(tr.model.flat_state(), 0)
-        dist.broadcast(tr.model_teacher.flat_state(), 0)
+    tr.sync_replicas()   # identical students / teachers on every rank (DDP broadcasts rank 0's parameters at construction)
     tr.iter = 1
     tr.log_period = 10 ** 9
     for _ in range(args.warmup):
@@ -207,10 +221,14 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    devices = [device_index]
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        devs = [None] * world
+        dist.all_gather_object(devs, device_index)
+        devices = devs
     metrics = tr.flush_metrics()
     conv = timer.summary()
 
@@ -225,6 +243,8 @@ def main():
                                    "post-burn-in semi-supervised step" % (args.label, args.unlabel),
                        "global_batch": per_step_images, "parallelism": "dp%d" % world,
                        "precision": "AMP (config SOLVER.AMP.ENABLED): bf16 MFMA operands, bf16 activations and activation gradients in HBM, fp32 accumulate / losses / weight gradients / master weights" if args.dtype == "bf16" else "fp32 MFMA, fp32 everywhere"},
+            "ranks": {"world_size": world, "backend": info["backend"], "devices": devices,
+                      "launcher": _launcher_name(world)},
             "losses": {k: v for k, v in metrics.items() if k.startswith("loss") or k.startswith("teacher")},
         }
         if conv:
@@ -240,9 +260,17 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(cfg)
             except Exception as e:  # never lose the GPU measurement to a host-side problem
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
+
+
+def main(argv=None):
+    """`python bench.py --gpus N`: N ranks, one per GPU.  Started bare, the ranks are spawned here (ubteacher.engine.launch, the
+    counterpart of the reference's train_net.py:62-73 `launch(...)`); started by `python -m torch.distributed.run --nproc-per-node N
+    bench.py --gpus N` (the driver's form), this process IS one rank and joins that world.  Either way a world that is not exactly
+    N ranks on N distinct GPUs is an error, never a silently smaller measurement."""
+    args = parse_args(argv)
+    from ubteacher.engine.launch import launch
+    launch(worker, args.gpus, args=(args,))
 
 
 if __name__ == "__main__":

@@ -985,8 +985,9 @@ def rcnn_teacher(sd, images, mean, pix_std, pre_topk=2000, post_topk=1000, thr=0
     return out, props
 
 
-def rcnn_student_losses(sd, images, gts, rpn_keys, roi_keys, pseudo, mean, pix_std, pre_topk=2000, post_topk=1000):
-    """meta_arch/rcnn.py:23-37 / :57-72."""
+def rcnn_student_losses(sd, images, gts, rpn_keys, roi_keys, pseudo, mean, pix_std, pre_topk=2000, post_topk=1000, props_override=None):
+    """meta_arch/rcnn.py:23-37 / :57-72.  props_override (mixed-precision tests): RPN proposals to use instead of this forward's
+    own (a discrete top-k + NMS selection, decoupled from rounding noise the same way pseudo_override decouples the teacher)."""
     p, sizes = rcnn_backbone(sd, images, mean, pix_std)
     feats = [p[k] for k in ("p2", "p3", "p4", "p5", "p6")]
     hw = [(f.shape[2], f.shape[3]) for f in feats]
@@ -995,7 +996,11 @@ def rcnn_student_losses(sd, images, gts, rpn_keys, roi_keys, pseudo, mean, pix_s
     rl, _ = rpn_losses(torch.cat(anchors), torch.cat(obj, 1), torch.cat(dl, 1), gts, rpn_keys, pseudo)
     with torch.no_grad():
         props = find_top_rpn_proposals(anchors, obj, dl, sizes, pre_topk, post_topk)
-    sampled = [roi_label_and_sample(q["boxes"], g, k, pseudo) for q, g, k in zip(props, gts, roi_keys)]
+    if props_override is not None:
+        props = props_override
+    # a key entry may be a callable (n_proposals, n_gt) -> keys: the proposal count is only known here
+    sampled = [roi_label_and_sample(q["boxes"], g, k(len(q["boxes"]), len(g["boxes"])) if callable(k) else k, pseudo)
+               for q, g, k in zip(props, gts, roi_keys)]
     pooled = roi_pool(feats[:4], [s["proposal_boxes"] for s in sampled])
     scores, deltas, std = box_head(sd, pooled)
     cls = torch.cat([s["gt_classes"] for s in sampled])
@@ -1013,7 +1018,8 @@ def rcnn_student_losses(sd, images, gts, rpn_keys, roi_keys, pseudo, mean, pix_s
 
 def rcnn_semisup_step(student_sd, teacher_sd, batch, keys, keep_rate=0.9996, lam_u=4.0, lam_r=1.0, thr=0.7, lr=0.01,
                       momentum=0.9, wd=1e-4, mean=None, pix_std=None, pre_topk=2000, post_topk=1000,
-                      frozen_prefixes=("backbone.bottom_up.stem", "backbone.bottom_up.res2")):
+                      frozen_prefixes=("backbone.bottom_up.stem", "backbone.bottom_up.res2"), pseudo_override=None,
+                      props_override=(None, None)):
     """One post-burn-in UBRCNNTeacherTrainer.run_step_full_semisup (engine/trainer.py:814-912).
     keys = dict(rpn_sup [N,R], roi_sup [list], rpn_unsup, roi_unsup): injected sampling keys."""
     mean = mean if mean is not None else torch.tensor([103.53, 116.28, 123.675]).view(3, 1, 1)
@@ -1023,13 +1029,17 @@ def rcnn_semisup_step(student_sd, teacher_sd, batch, keys, keep_rate=0.9996, lam
     rec = {"EMA_rate": keep_rate}
     with torch.no_grad():
         pseudo, _ = rcnn_teacher(teacher_sd, [d["image"] for d in uk], mean, pix_std, pre_topk, post_topk, thr)
+    if pseudo_override is not None:
+        pseudo = pseudo_override
     params = {k: v.clone().requires_grad_(True) for k, v in student_sd.items()
               if v.dtype.is_floating_point and "norm." not in k and not k.startswith(frozen_prefixes)}
     sd = dict(student_sd)
     sd.update(params)
-    sup, _, _ = rcnn_student_losses(sd, [d["image"] for d in lq + lk], [d["gt"] for d in lq + lk], keys["rpn_sup"], keys["roi_sup"], False, mean, pix_std, pre_topk, post_topk)
+    sup, _, _ = rcnn_student_losses(sd, [d["image"] for d in lq + lk], [d["gt"] for d in lq + lk], keys["rpn_sup"], keys["roi_sup"], False, mean, pix_std, pre_topk, post_topk,
+                                     props_override=props_override[0])
     rec.update(sup)
-    uns, _, _ = rcnn_student_losses(sd, [d["image"] for d in uq], pseudo, keys["rpn_unsup"], keys["roi_unsup"], True, mean, pix_std, pre_topk, post_topk)
+    uns, _, _ = rcnn_student_losses(sd, [d["image"] for d in uq], pseudo, keys["rpn_unsup"], keys["roi_unsup"], True, mean, pix_std, pre_topk, post_topk,
+                                     props_override=props_override[1])
     for k, v in uns.items():
         rec[k + "_pseudo"] = v
     total = 0.0

@@ -102,3 +102,20 @@ def test_strong_param_sampling_ranges():
                 assert 0 <= i and i + h <= 600 and 0 <= j and j + w <= 800 and 0.019 * 480000 <= h * w <= 0.21 * 480000
     assert abs(jit / n - 0.8) < 0.07 and abs(gray / n - 0.2) < 0.07 and abs(blur / n - 0.5) < 0.08
     assert abs(er[0] / n - 0.7) < 0.08 and abs(er[1] / n - 0.5) < 0.08 and abs(er[2] / n - 0.3) < 0.08
+
+
+def test_annotation_bbox_mode_is_honoured():
+    """Detectron2-format COCO dicts (load_coco_json: the reference's builtin datasets) carry XYWH_ABS boxes; the reference converts through
+    BoxMode in transform_instance_annotations (data/dataset_mapper.py:118-131)."""
+    import pytest
+    from ubteacher.data.dataset_mapper import XYWH_ABS, XYXY_ABS, to_xyxy_abs
+    assert to_xyxy_abs({"bbox": [10, 20, 30, 40], "bbox_mode": XYWH_ABS}) == [10.0, 20.0, 40.0, 60.0]
+    assert to_xyxy_abs({"bbox": [10, 20, 30, 40], "bbox_mode": "XYWH_ABS"}) == [10.0, 20.0, 40.0, 60.0]
+    assert to_xyxy_abs({"bbox": [10, 20, 30, 40], "bbox_mode": XYXY_ABS}) == [10.0, 20.0, 30.0, 40.0]
+    assert to_xyxy_abs({"bbox": [10, 20, 30, 40]}) == [10.0, 20.0, 30.0, 40.0]
+
+    class Mode:  # an enum member such as detectron2.structures.BoxMode.XYWH_ABS
+        value = 1
+    assert to_xyxy_abs({"bbox": [1, 2, 3, 4], "bbox_mode": Mode()}) == [1.0, 2.0, 4.0, 6.0]
+    with pytest.raises(ValueError):
+        to_xyxy_abs({"bbox": [0, 0, 1, 1], "bbox_mode": 4})   # XYWHA_ABS (rotated): not supported

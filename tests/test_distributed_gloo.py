@@ -95,6 +95,24 @@ def _worker(rank, world, port, q):
     dist.all_reduce(ref, op=dist.ReduceOp.SUM)
     out["bucketed_equals_flat"] = bool(torch.equal(gflat, ref))
     out["reset"] = (sum(gb.pending), sum(gb.launched), len(gb.works))
+    out["order"] = list(gb.last_order)
+    # ranks whose writers differ (rank 1 runs an extra, unfused pass over two layers) and whose backward completes the layers in
+    # different orders must still issue the bucket collectives in the same (static, descending) order
+    g2 = torch.randn(5000, generator=torch.Generator().manual_seed(70 + rank))
+    ref2 = g2.clone()
+    gflat.copy_(g2)
+    gb.on_forward(hs)
+    if rank == 1:
+        gb.on_forward(hs[:2])
+    gb.arm()
+    for h in (list(reversed(hs)) if rank == 0 else hs):
+        gb.on_backward_done([h])
+    if rank == 1:
+        gb.on_backward_done(hs[:2])
+    gb.finish()
+    dist.all_reduce(ref2, op=dist.ReduceOp.SUM)
+    out["order2"] = list(gb.last_order)
+    out["bucketed_equals_flat2"] = bool(torch.equal(gflat, ref2))
     # (6) the two-crop loader over a registered dataset: the label / unlabel split by the seed table, TrainingSampler streams whose
     # seed is shared by the ranks (comm.shared_random_seed) and rank-strided, per-rank batch sizes = total // world (host logic only:
     # an identity mapper stands in for the GPU one)
@@ -161,3 +179,5 @@ def test_world_size_2_gloo():
         assert 0 < res[r]["launched_before_finish"] < res[r]["nbuckets"]     # buckets with a layer still pending wait
         assert res[r]["launched_after_second_pass"] == res[r]["nbuckets"]
         assert res[r]["bucketed_equals_flat"] and res[r]["reset"] == (0, 0, 0)
+        desc = list(range(res[r]["nbuckets"] - 1, -1, -1))
+        assert res[r]["order"] == desc and res[r]["order2"] == desc and res[r]["bucketed_equals_flat2"]   # static launch order

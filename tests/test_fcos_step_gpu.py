@@ -263,3 +263,44 @@ def test_premasked_backbone_gradients_bit_identical(monkeypatch):
         ops.set_precision("fp32")
     assert digests[0] == digests[1]
     assert calls[1] < calls[0] and calls[0] - calls[1] >= 13   # the 13 trainable bottlenecks of res3-res5 lost their mask pass
+
+
+def test_fcos_step_vs_reference_trainer_golden():
+    """One full FCOS UTv2 iteration of the PRODUCT against the golden produced by executing the reference's own
+    UBTeacherTrainer.run_step_full_semisup on its own OneStageDetector / FCOS / PseudoGenerator modules
+    (tests/golden/gen_golden_step.py): every record_dict entry and the logged total within 1e-3, identical pseudo-label sets,
+    teacher after EMA bit exact, student after SGD."""
+    from tests.utv2_testutil import check_state_fingerprints, golden_batches, golden_init_state, golden_record, load_step_golden
+    from ubteacher.engine import UBTeacherTrainer
+    d = load_step_golden("fcos")
+    _, sd0 = golden_init_state("fcos", d)
+    prod, orac = golden_batches(d, "cuda")
+    cfg = small_fcos_cfg()
+    tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+    sd_s = tune_state_for_pseudo_labels(sd0, [x["image"] for x in orac[3]])
+    sd_t = dict(sd_s)
+    sd_t["proposal_generator.fcos_head.bbox_pred_std.bias"] = torch.full((4,), -3.0)
+    tr.model.load_state_dict(sd_s)
+    tr.model_teacher.load_state_dict(sd_t)
+    tr.iter = 1
+    tr.optimizer.param_groups[0]["lr"] = float(d["lr"])
+    tr.run_step_full_semisup()
+    rec = tr.flush_metrics()
+    torch.cuda.synchronize()
+    ref = golden_record(d)
+    for k, v in ref.items():
+        if k == "data_time":
+            continue
+        assert k in rec, k
+        assert abs(rec[k] - v) <= 1e-3 * max(abs(v), 1e-6), (k, rec[k], v)
+    for name, pb in zip(("pcls", "preg"), tr._last_pseudo):
+        for i in range(pb.n):
+            m = pb["valid"][i].bool()
+            assert int(m.sum()) == len(d["%s%d_boxes" % (name, i)]), (name, i)
+            order = torch.argsort(pb["scores"][i][m], descending=True, stable=True).cpu()
+            ref_order = np.argsort(-d["%s%d_scores" % (name, i)], kind="stable")
+            assert np.array_equal(pb["classes"][i][m].long().cpu()[order].numpy(), d["%s%d_classes" % (name, i)][ref_order])
+            np.testing.assert_allclose(pb["boxes"][i][m].cpu()[order].numpy(), d["%s%d_boxes" % (name, i)][ref_order], rtol=0, atol=2e-2)
+            np.testing.assert_allclose(pb["scores"][i][m].cpu()[order].numpy(), d["%s%d_scores" % (name, i)][ref_order], rtol=1e-3)
+    check_state_fingerprints(d, "teacher", cpu_state(tr.model_teacher), 0.0, exact=True)
+    check_state_fingerprints(d, "student", cpu_state(tr.model), 5e-4)

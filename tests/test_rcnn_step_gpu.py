@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import utv2_oracle as O
-from tests.utv2_testutil import FixedLoader, cpu_state, make_batch
+from tests.utv2_testutil import FixedLoader, cpu_state, make_batch, rcnn_tune as tune
 
 pytestmark = pytest.mark.gpu
 H, W = 96, 128
@@ -21,38 +21,6 @@ def rcnn_cfg():
 def relerr(a, b):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
-
-
-def tune(sd, images, mean, pstd, seed=0):
-    """Random-init R50 features are not normalised (no pretrained BN statistics), so the head outputs
-    explode; rescale the prediction layers (data-driven, via the oracle forward) so the detector emits a
-    few confident, well separated, non-degenerate detections."""
-    import torch.nn.functional as F
-    g = torch.Generator().manual_seed(seed)
-    sd = dict(sd)
-    q = "proposal_generator.rpn_head."
-    p = "roi_heads.box_predictor."
-    with torch.no_grad():
-        feats, sizes = O.rcnn_backbone(sd, images, mean, pstd)
-        fl = [feats[k] for k in ("p2", "p3", "p4", "p5", "p6")]
-        t = torch.cat([F.relu(F.conv2d(f, sd[q + "conv.weight"], sd[q + "conv.bias"], 1, 1)).permute(0, 2, 3, 1).reshape(-1, 256) for f in fl])
-        s_t = t.std().item()
-        sd[q + "objectness_logits.weight"] = torch.randn(3, 256, 1, 1, generator=g) * (1.0 / (s_t * 16))
-        sd[q + "anchor_deltas.weight"] = torch.randn(12, 256, 1, 1, generator=g) * (0.1 / (s_t * 16))
-        hw = [(f.shape[2], f.shape[3]) for f in fl]
-        anchors = O.make_anchors(hw, [4, 8, 16, 32, 64])
-        obj, dl = O.rpn_head(sd, fl)
-        props = O.find_top_rpn_proposals(anchors, obj, dl, sizes, 2000, 1000)
-        x = O.roi_pool(fl[:4], [pp["boxes"] for pp in props]).flatten(1)
-        x = F.relu(F.linear(x, sd["roi_heads.box_head.fc1.weight"], sd["roi_heads.box_head.fc1.bias"]))
-        x = F.relu(F.linear(x, sd["roi_heads.box_head.fc2.weight"], sd["roi_heads.box_head.fc2.bias"]))
-        s_x = x.std().item()
-    sd[p + "cls_score.weight"] = torch.randn(81, 1024, generator=g) * (2.5 / (s_x * 32))
-    b = torch.zeros(81); b[80] = 3.0
-    sd[p + "cls_score.bias"] = b
-    sd[p + "bbox_pred.weight"] = torch.randn(4, 1024, generator=g) * (0.5 / (s_x * 32))
-    sd[p + "bbox_pred_std.weight"] = torch.randn(4, 1024, generator=g) * (0.5 / (s_x * 32))
-    return sd
 
 
 def test_rcnn_full_semisup_step_parity():
@@ -222,3 +190,143 @@ def test_rcnn_evaluation_loop_runs_and_rescales():
     assert np.array_equal(np.asarray(mine["classes"]), ocl.numpy())
     assert np.allclose(np.asarray(mine["scores"]), osc.numpy(), rtol=1e-3, atol=1e-5)
     assert np.allclose(np.asarray(mine["boxes"]), ob.numpy(), rtol=1e-3, atol=5e-2)
+
+
+def _golden_setup(amp=False):
+    from tests.utv2_testutil import golden_batches, golden_init_state, load_step_golden
+    from ubteacher.engine import UBRCNNTeacherTrainer
+    d = load_step_golden("rcnn")
+    _, sd0 = golden_init_state("rcnn", d)
+    prod, orac = golden_batches(d, "cuda")
+    cfg = rcnn_cfg()
+    cfg.SOLVER.AMP.ENABLED = amp
+    tr = UBRCNNTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+    mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1)
+    pstd = torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1)
+    sd_s = tune(sd0, [x["image"] for x in orac[3]], mean, pstd)
+    sd_t = dict(sd_s)
+    sd_t["roi_heads.box_predictor.bbox_pred_std.bias"] = torch.full((4,), -3.0)
+    tr.model.load_state_dict(sd_s)
+    tr.model_teacher.load_state_dict(sd_t)
+    tr.iter = 1
+    tr.optimizer.param_groups[0]["lr"] = float(d["lr"])
+    K = {k: torch.from_numpy(d["keys_" + k]) for k in ("rpn_sup", "roi_sup", "rpn_unsup", "roi_unsup")}
+    calls = {"rpn": 0, "roi": 0}
+
+    def rpn_src(n, m, device):
+        k = K["rpn_sup" if calls["rpn"] == 0 else "rpn_unsup"]
+        calls["rpn"] += 1
+        assert tuple(k.shape) == (n, m), (tuple(k.shape), n, m)
+        return k.to(device)
+
+    def roi_src(n, m, device):
+        k = K["roi_sup" if calls["roi"] == 0 else "roi_unsup"]
+        calls["roi"] += 1
+        assert k.shape[0] == n and k.shape[1] >= m
+        return k[:, :m].contiguous().to(device)
+
+    tr.model.proposal_generator.sample_keys = rpn_src
+    tr.model.roi_heads.sample_keys = roi_src
+    return d, cfg, tr, orac, sd_s, sd_t, K, mean, pstd
+
+
+def test_rcnn_step_vs_reference_trainer_golden():
+    """One full Faster-RCNN UTv2 iteration of the PRODUCT against the golden produced by executing the reference's own
+    UBRCNNTeacherTrainer.run_step_full_semisup (tests/golden/gen_golden_step.py): record_dict within 1e-3 (the two pseudo RPN
+    terms as in the oracle test above), the same pseudo-label set, teacher after EMA bit exact, student after SGD."""
+    from tests.utv2_testutil import check_state_fingerprints, golden_record
+    d, cfg, tr, orac, sd_s, sd_t, K, mean, pstd = _golden_setup()
+    tr.run_step_full_semisup()
+    rec = tr.flush_metrics()
+    torch.cuda.synchronize()
+    ref = golden_record(d)
+    for k, v in ref.items():
+        if k in ("data_time", "total_loss"):
+            continue
+        tol = 2e-2 if k == "loss_rpn_loc_pseudo" else (5e-3 if k == "loss_rpn_cls_pseudo" else 1e-3)
+        assert abs(rec[k] - v) <= tol * max(abs(v), 1e-6), (k, rec[k], v)
+    assert abs(rec["total_loss"] - ref["total_loss"]) <= 1e-3 * ref["total_loss"]
+    gl = tr._last_pseudo
+    i = 0
+    while "pseudo%d_boxes" % i in d:
+        m = gl["valid"][i].bool()
+        assert int(m.sum()) == len(d["pseudo%d_boxes" % i])
+        assert np.array_equal(gl["classes"][i][m].long().cpu().numpy(), d["pseudo%d_classes" % i])
+        np.testing.assert_allclose(gl["boxes"][i][m].cpu().numpy(), d["pseudo%d_boxes" % i], rtol=0, atol=2e-2)
+        np.testing.assert_allclose(gl["scores"][i][m].cpu().numpy(), d["pseudo%d_scores" % i], rtol=1e-3)
+        i += 1
+    assert i == 2
+    check_state_fingerprints(d, "teacher", cpu_state(tr.model_teacher), 0.0, exact=True)
+    check_state_fingerprints(d, "student", cpu_state(tr.model), 5e-4)
+
+
+def test_rcnn_step_bf16_vs_rounding_oracle():
+    """BASELINE configs[4] (Faster-RCNN, bf16 MFMA conv path): the full AMP step against the oracle with the same operand rounding
+    emulated in its convs / linears (O.CONV_ROUND).  Discrete selections are decoupled from rounding noise the way the FCOS AMP
+    test does it: the oracle is handed the product's pseudo labels and the product's RPN proposals of the two student passes, and
+    both sides use the same injected sampling keys; then every loss must agree within 1e-2 relative and the teacher after EMA is
+    bit exact.  The product's own teacher detections must mostly coincide with the rounding oracle's."""
+    from ubteacher import ops
+    try:
+        O.CONV_ROUND[0] = "bf16"
+        d, cfg, tr, orac, sd_s, sd_t, K, mean, pstd = _golden_setup(amp=True)
+        assert ops.PRECISION[0] == "bf16"
+        pg = tr.model.proposal_generator
+        calls = []
+        orig_cls_call = type(pg).__call__
+
+        def patched(self, *a, **k):
+            out = orig_cls_call(self, *a, **k)
+            if self is pg:
+                calls.append(out[0])
+            return out
+        type(pg).__call__ = patched
+        try:
+            tr.run_step_full_semisup()
+        finally:
+            type(pg).__call__ = orig_cls_call
+        rec = tr.flush_metrics()
+        torch.cuda.synchronize()
+        assert len(calls) == 2
+        post = int(cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN)
+
+        def props_of(pb):
+            out = []
+            for i in range(pb.n):
+                n = int(pb["count"][i])
+                out.append(dict(boxes=pb["boxes"][i][:n].cpu(), scores=pb["objectness_logits"][i][:n].cpu()))
+            return out
+        props = (props_of(calls[0]), props_of(calls[1]))
+        gl = tr._last_pseudo
+        pseudo = []
+        for i in range(gl.n):
+            m = gl["valid"][i].bool()
+            pseudo.append(dict(boxes=gl["boxes"][i][m].cpu(), classes=gl["classes"][i][m].long().cpu(), scores=gl["scores"][i][m].cpu(),
+                               pred_boxes_std=gl["pred_boxes_std"][i][m].cpu()))
+        assert sum(len(p["boxes"]) for p in pseudo) > 0
+
+        def compact(name):
+            return [(lambda i: lambda nprop, ngt: torch.cat((K[name][i, :nprop], K[name][i, post:post + ngt])))(i)
+                    for i in range(K[name].shape[0])]
+        keys = dict(rpn_sup=K["rpn_sup"], rpn_unsup=K["rpn_unsup"], roi_sup=compact("roi_sup"), roi_unsup=compact("roi_unsup"))
+        S = cfg.SEMISUPNET
+        rec_o, _, new_t, _, _ = O.rcnn_semisup_step(
+            sd_s, sd_t, orac, keys, keep_rate=S.EMA_KEEP_RATE, lam_u=S.UNSUP_LOSS_WEIGHT, lam_r=S.UNSUP_REG_LOSS_WEIGHT,
+            thr=S.BBOX_THRESHOLD, lr=float(d["lr"]), mean=mean, pix_std=pstd, pseudo_override=pseudo, props_override=props)
+        t_sd = O.ema_update(sd_s, sd_t, S.EMA_KEEP_RATE)
+        with torch.no_grad():
+            own, _ = O.rcnn_teacher(t_sd, [x["image"] for x in orac[3]], mean, pstd, thr=S.BBOX_THRESHOLD)
+    finally:
+        O.CONV_ROUND[0] = None
+        ops.set_precision("fp32")
+    tot, hit = 0, 0
+    for p, q in zip(own, pseudo):
+        tot += max(len(p["boxes"]), len(q["boxes"]))
+        if len(p["boxes"]) and len(q["boxes"]):
+            hit += int((O.pairwise_iou(p["boxes"], q["boxes"]).max(dim=1)[0] > 0.9).sum())
+    assert tot > 0 and hit >= 0.6 * tot, (hit, tot)
+    for k, v in rec_o.items():
+        assert abs(rec[k] - v) <= 1e-2 * max(abs(v), 1e-6), (k, rec[k], v)
+    t_after = cpu_state(tr.model_teacher)
+    for k in new_t:
+        assert torch.equal(t_after[k], new_t[k]), k

@@ -1,0 +1,100 @@
+"""The oracle's whole-iteration restatements (`fcos_semisup_step`, `rcnn_semisup_step`) against the goldens produced by EXECUTING
+the reference's own `UBTeacherTrainer.run_step_full_semisup` / `UBRCNNTeacherTrainer.run_step_full_semisup`
+(engine/trainer.py:181-429, :786-912; tests/golden/gen_golden_step.py): every record_dict entry, the weighted loss the
+reference back-propagates, the pseudo-label sets, the teacher after EMA (bit exact) and the student after SGD.
+This pins the orchestration (EMA placement, thresholds, label surgery, loss weights, key renaming) that rows a1 / a2 of
+SURVEY 8(a) own; the GPU product is checked against the same files in tests/test_*_step_gpu.py."""
+import numpy as np
+import torch
+
+from oracle import utv2_oracle as O
+from tests.utv2_testutil import (check_state_fingerprints, golden_batches, golden_init_state, golden_record, load_step_golden,
+                                 rcnn_tune, tune_state_for_pseudo_labels)
+
+
+def _weighted_fcos(rec, lu, lr):
+    tot = 0.0
+    for k, v in rec.items():
+        if k[:4] != "loss":
+            continue
+        if k in ("loss_fcos_loc",):
+            tot += v / (lr + 1.0)
+        elif k == "loss_fcos_loc_pseudo":
+            tot += v * lr / (lr + 1.0)
+        elif k.endswith("_pseudo"):
+            tot += v * lu / (lu + 1.0)
+        else:
+            tot += v / (lu + 1.0)
+    return tot
+
+
+def test_fcos_step_oracle_vs_reference_trainer():
+    d = load_step_golden("fcos")
+    cfg, sd0 = golden_init_state("fcos", d)
+    _, orac = golden_batches(d, "cpu")
+    sd_s = tune_state_for_pseudo_labels(sd0, [x["image"] for x in orac[3]])
+    sd_t = dict(sd_s)
+    sd_t["proposal_generator.fcos_head.bbox_pred_std.bias"] = torch.full((4,), -3.0)
+    S = cfg.SEMISUPNET
+    rec, new_s, new_t, grads, bufs, pseudo = O.fcos_semisup_step(
+        O.FCOSCfg(), sd_s, sd_t, orac, keep_rate=S.EMA_KEEP_RATE, lam_u=S.UNSUP_LOSS_WEIGHT, lam_r=S.UNSUP_REG_LOSS_WEIGHT,
+        thr_cls=S.BBOX_THRESHOLD, thr_reg=S.BBOX_THRESHOLD_REG, lr=float(d["lr"]), momentum=cfg.SOLVER.MOMENTUM,
+        wd=cfg.SOLVER.WEIGHT_DECAY, mean=sd0["pixel_mean"], pix_std=sd0["pixel_std"])
+    ref = golden_record(d)
+    for k, v in ref.items():
+        if k in ("data_time", "total_loss"):
+            continue
+        assert k in rec, k
+        assert abs(rec[k] - v) <= 1e-5 * max(abs(v), 1e-6), (k, rec[k], v)
+    assert set(rec) == set(ref) - {"data_time", "total_loss"}
+    # the reference's logged total (plain sum of the loss entries) and the weighted objective it back-propagates
+    assert abs(sum(v for k, v in rec.items() if k[:4] == "loss") - ref["total_loss"]) <= 1e-5 * ref["total_loss"]
+    assert abs(_weighted_fcos(rec, S.UNSUP_LOSS_WEIGHT, S.UNSUP_REG_LOSS_WEIGHT) - float(d["losses"])) <= 1e-5 * float(d["losses"])
+    for name, sets in zip(("pcls", "preg"), pseudo):
+        for i, p in enumerate(sets):
+            assert np.array_equal(p["classes"].numpy(), d["%s%d_classes" % (name, i)])
+            np.testing.assert_allclose(p["boxes"].numpy(), d["%s%d_boxes" % (name, i)], rtol=0, atol=1e-4)
+            np.testing.assert_allclose(p["scores"].numpy(), d["%s%d_scores" % (name, i)], rtol=2e-5)
+            np.testing.assert_allclose(p["reg_pred_std"].numpy(), d["%s%d_std" % (name, i)], rtol=1e-4, atol=1e-5)
+    check_state_fingerprints(d, "teacher", new_t, 0.0, exact=True)
+    check_state_fingerprints(d, "student", new_s, 2e-6)
+
+
+def test_rcnn_step_oracle_vs_reference_trainer():
+    d = load_step_golden("rcnn")
+    cfg, sd0 = golden_init_state("rcnn", d)
+    _, orac = golden_batches(d, "cpu")
+    mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1)
+    pstd = torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1)
+    sd_s = rcnn_tune(sd0, [x["image"] for x in orac[3]], mean, pstd)
+    sd_t = dict(sd_s)
+    sd_t["roi_heads.box_predictor.bbox_pred_std.bias"] = torch.full((4,), -3.0)
+    post = int(cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN)
+    K = {k: torch.from_numpy(d["keys_" + k]) for k in ("rpn_sup", "roi_sup", "rpn_unsup", "roi_unsup")}
+
+    def compact(name):
+        return [(lambda i: lambda nprop, ngt: torch.cat((K[name][i, :nprop], K[name][i, post:post + ngt])))(i)
+                for i in range(K[name].shape[0])]
+    keys = dict(rpn_sup=K["rpn_sup"], rpn_unsup=K["rpn_unsup"], roi_sup=compact("roi_sup"), roi_unsup=compact("roi_unsup"))
+    S = cfg.SEMISUPNET
+    rec, new_s, new_t, grads, pseudo = O.rcnn_semisup_step(
+        sd_s, sd_t, orac, keys, keep_rate=S.EMA_KEEP_RATE, lam_u=S.UNSUP_LOSS_WEIGHT, lam_r=S.UNSUP_REG_LOSS_WEIGHT,
+        thr=S.BBOX_THRESHOLD, lr=float(d["lr"]), momentum=cfg.SOLVER.MOMENTUM, wd=cfg.SOLVER.WEIGHT_DECAY, mean=mean, pix_std=pstd)
+    ref = golden_record(d)
+    for k, v in ref.items():
+        if k in ("data_time", "total_loss"):
+            continue
+        assert abs(rec[k] - v) <= 1e-5 * max(abs(v), 1e-6), (k, rec[k], v)
+    assert set(rec) == set(ref) - {"data_time", "total_loss"}
+    assert abs(sum(v for k, v in rec.items() if k[:4] == "loss") - ref["total_loss"]) <= 1e-5 * ref["total_loss"]
+    lu, lr_ = S.UNSUP_LOSS_WEIGHT, S.UNSUP_REG_LOSS_WEIGHT
+    tot = sum(v * (0.0 if k == "loss_rpn_loc_pseudo" else lr_ if k == "loss_box_reg_pseudo" else lu if k.endswith("pseudo") else 1.0)
+              for k, v in rec.items() if k[:4] == "loss")
+    assert abs(tot - float(d["losses"])) <= 1e-5 * float(d["losses"])
+    for i, p in enumerate(pseudo):
+        assert np.array_equal(p["classes"].numpy(), d["pseudo%d_classes" % i])
+        np.testing.assert_allclose(p["boxes"].numpy(), d["pseudo%d_boxes" % i], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(p["scores"].numpy(), d["pseudo%d_scores" % i], rtol=2e-5)
+        np.testing.assert_allclose(p["pred_boxes_std"].numpy(), d["pseudo%d_std" % i], rtol=1e-4, atol=1e-5)
+    check_state_fingerprints(d, "teacher", new_t, 0.0, exact=True)
+    check_state_fingerprints(d, "student", new_s, 2e-6)

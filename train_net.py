@@ -1,6 +1,7 @@
-"""Launcher with the reference's CLI shape (train_net.py:15-73): --config-file, --num-gpus, --resume,
-KEY VALUE overrides.  One process per GPU; for --num-gpus > 1 start it under
-`python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 train_net.py ...`."""
+"""Launcher with the reference's CLI shape (train_net.py:15-73): --config-file, --num-gpus, --resume, --eval-only,
+KEY VALUE overrides.  `--num-gpus N` starts N ranks, one per GPU (ubteacher.engine.launch, the counterpart of the
+`launch(main, args.num_gpus, ...)` call at train_net.py:62-73); under `python -m torch.distributed.run --nproc-per-node N`
+the process joins that world instead of spawning."""
 import argparse
 import os
 import sys
@@ -8,12 +9,10 @@ import sys
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "unbiased-teacher-v2_amd"))
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 from ubteacher import add_ubteacher_config  # noqa: E402
 from ubteacher.d2 import get_cfg  # noqa: E402
 from ubteacher.engine import UBRCNNTeacherTrainer, UBTeacherTrainer  # noqa: E402
+from ubteacher.engine.launch import dist_info, launch  # noqa: E402
 
 
 def setup(args):
@@ -21,18 +20,13 @@ def setup(args):
     add_ubteacher_config(cfg)
     cfg.merge_from_file(args.config_file)
     cfg.merge_from_list(args.opts)
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if cfg.MODEL.DEVICE == "cuda":
-        cfg.MODEL.DEVICE = "cuda:%d" % local_rank
+    if cfg.MODEL.DEVICE == "cuda":  # one process per GPU: this rank's device
+        cfg.MODEL.DEVICE = "cuda:%d" % dist_info().get("device", 0)
     cfg.freeze()
     return cfg
 
 
 def main(args):
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    if world > 1:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-        dist.init_process_group("nccl")
     cfg = setup(args)
     if cfg.SEMISUPNET.Trainer == "ubteacher":
         Trainer = UBTeacherTrainer
@@ -40,18 +34,41 @@ def main(args):
         Trainer = UBRCNNTeacherTrainer
     else:
         raise ValueError("Trainer Name is not found.")
+
     if args.eval_only:
-        raise NotImplementedError("--eval-only: COCO evaluation is outside the training-step scope (SURVEY 8f)")
+        # reference train_net.py:37-54: FCOS evaluates the TEACHER of the teacher/student checkpoint, Faster-RCNN a plain model
+        from ubteacher.checkpoint import DetectionTSCheckpointer
+        from ubteacher.modeling.ts_ensemble import EnsembleTSModel
+        model = Trainer.build_model(cfg)
+        if cfg.SEMISUPNET.Trainer == "ubteacher":
+            model_teacher = Trainer.build_model(cfg)
+            ensem_ts_model = EnsembleTSModel(model_teacher, model)
+            DetectionTSCheckpointer(ensem_ts_model, save_dir=cfg.OUTPUT_DIR).resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume)
+            return Trainer.test(cfg, ensem_ts_model.modelTeacher)
+        from ubteacher.checkpoint import DetectionCheckpointer
+        DetectionCheckpointer(model, save_dir=cfg.OUTPUT_DIR).resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume)
+        return Trainer.test(cfg, model)
+
     trainer = Trainer(cfg)
     trainer.resume_or_load(resume=args.resume)
     return trainer.train()
 
 
-if __name__ == "__main__":
+def default_argument_parser():
+    """the arguments of Detectron2's default_argument_parser that the reference launcher uses [D2-recall]"""
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config-file", default=os.path.join(ROOT, "configs", "utv2_fcos_r50.yaml"))
+    ap.add_argument("--config-file", default=os.path.join(ROOT, "configs", "utv2_fcos_r50.yaml"), metavar="FILE")
     ap.add_argument("--resume", action="store_true")
     ap.add_argument("--eval-only", action="store_true")
-    ap.add_argument("--num-gpus", type=int, default=1)
+    ap.add_argument("--num-gpus", type=int, default=1, help="number of gpus *per machine*")
+    ap.add_argument("--num-machines", type=int, default=1)
+    ap.add_argument("--machine-rank", type=int, default=0)
+    ap.add_argument("--dist-url", default="auto")
     ap.add_argument("opts", nargs=argparse.REMAINDER, default=[])
-    main(ap.parse_args())
+    return ap
+
+
+if __name__ == "__main__":
+    args = default_argument_parser().parse_args()
+    print("Command Line Args:", args)
+    launch(main, args.num_gpus, num_machines=args.num_machines, machine_rank=args.machine_rank, dist_url=args.dist_url, args=(args,))

@@ -62,6 +62,24 @@ def align_and_update_state_dicts(model_sd, ckpt_sd, c2_conversion=True):
     return matched, [k for k in ckeys if k not in used]
 
 
+def resolve_path(path):
+    """Local file for a checkpoint path.  `detectron2://X` (the model-zoo URIs every shipped config uses for MODEL.WEIGHTS) maps to
+    the cache location Detectron2's PathManager downloads it to - $FVCORE_CACHE (default ~/.torch/iopath_cache)/detectron2/X
+    [D2-recall]; there is no network here, so the file has to be there already.  Raises FileNotFoundError otherwise."""
+    if path.startswith("detectron2://"):
+        cache = os.environ.get("FVCORE_CACHE", os.path.join(os.path.expanduser("~"), ".torch", "iopath_cache"))
+        local = os.path.join(cache, "detectron2", path[len("detectron2://"):])
+        if not os.path.exists(local):
+            raise FileNotFoundError("{} is not in the local model-zoo cache ({}); place the file there or point MODEL.WEIGHTS at a local "
+                                    "path (set MODEL.WEIGHTS \"\" to train from random initialisation)".format(path, local))
+        return local
+    if "://" in path:
+        raise FileNotFoundError("cannot fetch {!r}: no network access; point MODEL.WEIGHTS at a local file".format(path))
+    if not os.path.exists(path):
+        raise FileNotFoundError("checkpoint {!r} not found".format(path))
+    return path
+
+
 def load_checkpoint_file(path):
     """.pth -> torch.load; .pkl -> Caffe2 / Detectron pickle: {"model": blobs, "__author__": "Caffe2", "matching_heuristics": True}
     (DetectionCheckpointer._load_file [D2-recall])."""
@@ -107,11 +125,27 @@ class DetectionTSCheckpointer:
         with open(self._last_file(), "w") as f:
             f.write(fn)
 
-    def load(self, path):
+    def load(self, path, checkpointables=None):
+        """Detectron2 Checkpointer.load [D2-recall]: the model always; of the other checkpointables (optimizer, scheduler) the ones
+        named in `checkpointables` (None = all that the file holds, [] = none - the non-resume path)."""
         if not path:
             return {}
+        path = resolve_path(path)
         ck = load_checkpoint_file(path)
-        sd = ck.get("model", ck)
+        self._load_model(ck, ck.get("model", ck))
+        want = ("optimizer", "scheduler") if checkpointables is None else tuple(checkpointables)
+        if "optimizer" in want and "optimizer" in ck and self.optimizer is not None:
+            osd = ck["optimizer"]
+            if not (isinstance(osd, dict) and "momentum_buffer" in osd):
+                raise ValueError("checkpoint {!r}: the optimizer state is not an ArenaSGD state (a torch.optim state_dict of the reference "
+                                 "cannot be mapped onto the flat momentum arena); load it without resuming to take the weights only"
+                                 .format(path))
+            self.optimizer.load_state_dict(osd)
+        if "scheduler" in want and "scheduler" in ck and self.scheduler is not None:
+            self.scheduler.load_state_dict(ck["scheduler"])
+        return ck
+
+    def _load_model(self, ck, sd):
         if ck.get("__author__", None) == "Caffe2":
             # pretrained ImageNet backbone: name-matching heuristics, STUDENT only (detection_checkpoint.py:11-37); the
             # teacher receives it at the burn-in boundary through _update_teacher_model(keep_rate=0)
@@ -123,16 +157,31 @@ class DetectionTSCheckpointer:
             self.model.load_state_dict(sd, strict=False)
         else:  # backbone-only weights -> student only (detection_checkpoint.py:21-49)
             self.model.modelStudent.load_state_dict(sd, strict=False)
-        if "optimizer" in ck and self.optimizer is not None:
-            self.optimizer.load_state_dict(ck["optimizer"])
-        if "scheduler" in ck and self.scheduler is not None:
-            self.scheduler.load_state_dict(ck["scheduler"])
-        return ck
 
     def resume_or_load(self, path, resume=True):
+        """Detectron2 Checkpointer.resume_or_load [D2-recall]: resume from the last checkpoint of OUTPUT_DIR if there is one, else
+        load `path` (MODEL.WEIGHTS) WITHOUT optimizer / scheduler / iteration.  A non-empty path that cannot be resolved raises,
+        like the reference's PathManager does: training silently from random, frozen stem / res2 weights is never what was asked."""
         if resume and self.has_checkpoint():
             return self.load(self.get_checkpoint_file())
-        if path and os.path.exists(path):
-            ck = self.load(path)
+        if path:
+            ck = self.load(path, checkpointables=[])
             return {k: v for k, v in ck.items() if k not in ("optimizer", "scheduler", "iteration")}
         return {}
+
+
+class DetectionCheckpointer(DetectionTSCheckpointer):
+    """Detectron2's plain DetectionCheckpointer over ONE model (the reference's Faster-RCNN `--eval-only` path, train_net.py:48-53)."""
+
+    def _load_model(self, ck, sd):
+        if ck.get("__author__", None) == "Caffe2":
+            matched, unmatched = align_and_update_state_dicts(self.model.state_dict(), sd, c2_conversion=True)
+            self.model.load_state_dict(matched, strict=False)
+            self.last_load_report = {"matched": sorted(matched), "unmatched_checkpoint_keys": unmatched}
+            return
+        mine = set(self.model.state_dict())
+        if not any(k in mine for k in sd):
+            # Detectron2 would log every key as missing / unexpected and go on with the initial weights: refuse instead
+            raise ValueError("checkpoint holds no tensor of this model (first keys: {}); a teacher/student checkpoint "
+                             "(modelTeacher.* / modelStudent.*) loads through DetectionTSCheckpointer".format(list(sd)[:3]))
+        self.model.load_state_dict(sd, strict=False)

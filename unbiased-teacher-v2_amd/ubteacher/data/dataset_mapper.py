@@ -42,6 +42,23 @@ def check_image_size(dataset_dict, image):
     dataset_dict.setdefault("height", image.shape[0])
 
 
+# Detectron2 BoxMode values [D2-recall]: the enum members themselves are ints; dataset dicts may carry the int or the name
+XYXY_ABS, XYWH_ABS = 0, 1
+_BOX_MODES = {0: XYXY_ABS, 1: XYWH_ABS, "XYXY_ABS": XYXY_ABS, "XYWH_ABS": XYWH_ABS, "BoxMode.XYXY_ABS": XYXY_ABS, "BoxMode.XYWH_ABS": XYWH_ABS}
+
+
+def to_xyxy_abs(anno):
+    """the annotation's box as XYXY_ABS (Detectron2 transform_instance_annotations converts through BoxMode before the transforms;
+    load_coco_json - the format of the reference's builtin COCO sets - stores XYWH_ABS).  No `bbox_mode` = XYXY_ABS."""
+    mode = anno.get("bbox_mode", XYXY_ABS)
+    mode = getattr(mode, "value", mode)                      # an enum member
+    key = mode if isinstance(mode, int) else str(mode)
+    if key not in _BOX_MODES:
+        raise ValueError("unsupported bbox_mode {!r} (XYXY_ABS and XYWH_ABS are)".format(anno.get("bbox_mode")))
+    x0, y0, a, b = (float(v) for v in anno["bbox"])
+    return [x0, y0, x0 + a, y0 + b] if _BOX_MODES[key] == XYWH_ABS else [x0, y0, a, b]
+
+
 class DatasetMapperTwoCropSeparate:
     def __init__(self, cfg, is_train=True, seed=None, device=None):
         if cfg.INPUT.CROP.ENABLED and is_train:
@@ -73,7 +90,7 @@ class DatasetMapperTwoCropSeparate:
             return dataset_dict
         if annos_in is not None:
             keep = [a for a in annos_in if a.get("iscrowd", 0) == 0]
-            boxes = T.transform_boxes([a["bbox"] for a in keep], h, w, newh, neww, flip) if keep else np.zeros((0, 4), np.float32)
+            boxes = T.transform_boxes([to_xyxy_abs(a) for a in keep], h, w, newh, neww, flip) if keep else np.zeros((0, 4), np.float32)
             classes = np.array([a["category_id"] for a in keep], dtype=np.int64)
             nonempty = ((boxes[:, 2] - boxes[:, 0]) > 1e-5) & ((boxes[:, 3] - boxes[:, 1]) > 1e-5)  # filter_empty_instances
             inst = Instances((newh, neww))

@@ -1,0 +1,96 @@
+"""One process per GPU on one node: the counterpart of Detectron2's `launch` that the reference's train_net.py:62-73 calls
+(`launch(main, num_gpus, num_machines, machine_rank, dist_url, args=(args,))`).
+
+`launch(main_func, num_gpus_per_machine, ...)` spawns `num_gpus_per_machine` workers with torch.multiprocessing (start method
+"spawn": HIP contexts do not survive a fork), each of which binds ITS device, joins the default process group
+(backend "nccl" == RCCL over xGMI on ROCm; `UTV2_DIST_BACKEND=gloo` for CPU / single-GPU dry runs) and calls `main_func(*args)`.
+The worker fails loudly when the group it joined is not the one that was asked for: a silently smaller world would report
+a scaling point that was never measured.
+
+When the process was ALREADY started as one rank of a world (torch.distributed.run exports RANK / WORLD_SIZE / LOCAL_RANK /
+MASTER_*), `launch` does not spawn: it validates the environment against `num_gpus_per_machine`, joins that world and
+calls `main_func` in-process.  So `python X.py --gpus N` and `python -m torch.distributed.run --nproc-per-node N X.py --gpus N`
+run the same N ranks.
+"""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+
+__all__ = ["launch", "find_free_port", "dist_info"]
+
+_INFO = {}
+
+
+def find_free_port():
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(("127.0.0.1", 0))   # the container hostname may not resolve: always the loopback address
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def dist_info():
+    """what the worker actually joined: {world_size, rank, local_rank, backend, device} (filled by launch)"""
+    return dict(_INFO)
+
+
+def _backend():
+    return os.environ.get("UTV2_DIST_BACKEND", "nccl")
+
+
+def _bind_and_join(rank, local_rank, world_size, dist_url, expect_world):
+    single_dev = os.environ.get("UTV2_BENCH_SINGLE_DEVICE") == "1"  # dry runs of the N > 1 path on a box with one GPU
+    dev = 0 if single_dev else local_rank
+    if torch.cuda.is_available():
+        if not single_dev and torch.cuda.device_count() < expect_world:
+            raise RuntimeError("launch: %d ranks requested but only %d GPUs are visible" % (expect_world, torch.cuda.device_count()))
+        torch.cuda.set_device(dev)
+    if world_size > 1:
+        dist.init_process_group(_backend(), init_method=dist_url, rank=rank, world_size=world_size)
+        if dist.get_world_size() != expect_world:
+            raise RuntimeError("launch: joined a world of %d ranks, %d were requested" % (dist.get_world_size(), expect_world))
+    _INFO.update(world_size=world_size, rank=rank, local_rank=local_rank, backend=_backend() if world_size > 1 else None,
+                 device=dev)
+
+
+def _worker(local_rank, main_func, world_size, dist_url, args):
+    os.environ["RANK"] = os.environ["LOCAL_RANK"] = str(local_rank)
+    os.environ["WORLD_SIZE"] = os.environ["LOCAL_WORLD_SIZE"] = str(world_size)
+    _bind_and_join(local_rank, local_rank, world_size, dist_url, world_size)
+    try:
+        main_func(*args)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def launch(main_func, num_gpus_per_machine, num_machines=1, machine_rank=0, dist_url=None, args=()):
+    if num_machines != 1 or machine_rank != 0:
+        raise NotImplementedError("one node (8 x MI355X over xGMI) is the scope of this launcher")
+    n = int(num_gpus_per_machine)
+    if n < 1:
+        raise ValueError("num_gpus_per_machine must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None and "RANK" in os.environ:
+        # already one rank of an externally launched world (torch.distributed.run)
+        world = int(env_world)
+        if world != n:
+            raise RuntimeError("launch: started inside a world of %d ranks (WORLD_SIZE) but %d GPUs were requested" % (world, n))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        url = "env://"
+        _bind_and_join(int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"])), world, url, n)
+        try:
+            return main_func(*args)
+        finally:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+    if n == 1:
+        _bind_and_join(0, 0, 1, None, 1)
+        return main_func(*args)
+    if dist_url in (None, "auto"):
+        dist_url = "tcp://127.0.0.1:%d" % find_free_port()
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, nprocs=n, args=(main_func, n, dist_url, args), join=True)
+    return None

@@ -202,12 +202,26 @@ class _TrainerBase:
         self.ensem_ts_model = ensem
         self.checkpointer = DetectionTSCheckpointer(ensem, cfg.OUTPUT_DIR, optimizer=self.optimizer, scheduler=self.scheduler)
         self._setup_grad_sync()
+        self.sync_replicas()
+
+    def sync_replicas(self):
+        """Data parallel: every rank starts from rank 0's student, teacher and momentum, as DistributedDataParallel does at
+        construction in the reference (trainer.py:59-63).  Only gradients are exchanged afterwards, so replicas that differ here
+        (per-rank seeding such as Detectron2's SEED + rank, a checkpoint only rank 0 can read) would stay different for good."""
+        if self.world_size > 1:
+            for t in (self.model.flat_state(), self.model_teacher.flat_state(), self.model.store.mom):
+                if t is not None:
+                    dist.broadcast(t, 0)
+            self.model.store.touch()
+            self.model_teacher.store.touch()
+            ops.bump_version()
 
     # -- reference API ------------------------------------------------------------------------
     def resume_or_load(self, resume=True):
         checkpoint = self.checkpointer.resume_or_load(self.cfg.MODEL.WEIGHTS, resume=resume)
         if resume and self.checkpointer.has_checkpoint():
             self.start_iter = checkpoint.get("iteration", -1) + 1
+        self.sync_replicas()
 
     def train(self):
         self.train_loop(self.start_iter, self.max_iter)
@@ -226,6 +240,8 @@ class _TrainerBase:
                     period = self.cfg.SOLVER.CHECKPOINT_PERIOD
                     if comm.is_main_process() and period > 0 and (self.iter + 1) % period == 0:
                         self.checkpointer.save("model_{:07d}".format(self.iter), iteration=self.iter)
+                    if comm.is_main_process() and self.iter + 1 >= max_iter and self.cfg.OUTPUT_DIR:
+                        self.checkpointer.save("model_final", iteration=self.iter)   # D2 PeriodicCheckpointer [D2-recall]
             except Exception:
                 logger.exception("Exception during training:")
                 raise

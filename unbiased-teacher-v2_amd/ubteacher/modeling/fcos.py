@@ -325,7 +325,7 @@ class FCOSOutputs:
         return extras, losses
 
     # -- decode + NMS (fcos_outputs.py:1046-1320) ---------------------------------------------------
-    def predict_proposals(self, head_out, level_hw, image_sizes, nms_method="cls_n_ctr", max_det=128):
+    def predict_proposals(self, head_out, level_hw, image_sizes, nms_method="cls_n_ctr", max_det=None):
         """nms_method: one ranking criterion -> PaddedBoxes; a tuple / list of criteria -> a list of PaddedBoxes in that order, computed
         by ONE set of launches (ranking keys, exact top-k, decode, class-aware NMS) over (criterion, image) pairs - the UTv2 trainer needs
         the teacher's detections under two criteria every iteration (trainer.py:232-251) and these kernels are latency-bound."""
@@ -333,6 +333,12 @@ class FCOSOutputs:
             th, pre, post = self.pre_nms_thresh_train, self.pre_nms_topk_train, self.post_nms_topk_train
         else:
             th, pre, post = self.pre_nms_thresh_test, self.pre_nms_topk_test, self.post_nms_topk_test
+        if max_det is None:
+            # detection slots per image: POST_NMS_TOPK plus headroom for the kthvalue ties the reference keeps beyond it
+            # (fcos_outputs.py:1300-1318); 128 for the shipped 100
+            max_det = 128 if post <= 100 else (post + post // 4 + 63) // 64 * 64
+        if post > max_det:
+            raise ValueError("POST_NMS_TOPK %d exceeds the %d detection slots" % (post, max_det))
         single = isinstance(nms_method, str)
         names = [nms_method] if single else list(nms_method)
         for nm in names:

@@ -33,6 +33,9 @@ class GradBuckets:
         self.launched = [False] * nb
         self.works = []
         self.armed = False
+        self.next = nb - 1       # next bucket to launch: strictly descending
+        self.order = []          # launch order of the running step
+        self.last_order = []     # ... of the last finished step (tests)
 
     def bucket_of(self, h):
         return bisect.bisect_right(self.starts, int(h.offset)) - 1
@@ -47,33 +50,47 @@ class GradBuckets:
         for h in handles:
             if h is None or h.g is None:
                 continue
-            b = self.bucket_of(h)
-            self.pending[b] -= 1
-            if self.armed and self.pending[b] == 0 and not self.launched[b]:
-                self._launch(b)
+            self.pending[self.bucket_of(h)] -= 1
+        if self.armed:
+            self._launch_ready()
 
     # -- called by the trainer -----------------------------------------------------------------
     def arm(self):
-        """right before losses.backward(): every writer of this step has registered by now"""
+        """right before losses.backward(): every writer of this step has registered by now.  Buckets nobody will write this step
+        (parameters of branches that did not run) are ready at once."""
         self.armed = True
+        self._launch_ready()
+
+    def _launch_ready(self):
+        """Collectives must be issued in the SAME order on every rank (a mismatch is an RCCL hang).  Which bucket completes first
+        depends on how many writers a rank registered (e.g. one fused student pass on one rank, two passes on another), so the
+        order is made static instead: buckets go strictly from the highest index down - the order backward finishes them in, the
+        arena being laid out in forward order - and a finished bucket waits for every higher one, as DDP's reducer does."""
+        while self.next >= 0 and self.pending[self.next] == 0:
+            self._launch(self.next)
+            self.next -= 1
 
     def _launch(self, b):
         s, e = self.bounds[b]
         self.launched[b] = True
+        self.order.append(b)
         if e > s:
             self.works.append(dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
-        """after backward: reduce the buckets whose writers never all reported (unused layers), wait for everything"""
-        for b in range(len(self.bounds)):
-            if not self.launched[b]:
-                self._launch(b)
+        """after backward: reduce the buckets that are still waiting (in the same static order), wait for everything"""
+        while self.next >= 0:
+            self._launch(self.next)
+            self.next -= 1
         for w in self.works:
             w.wait()
         self.works = []
         self.armed = False
-        self.pending = [0] * len(self.bounds)
-        self.launched = [False] * len(self.bounds)
+        nb = len(self.bounds)
+        self.pending = [0] * nb
+        self.launched = [False] * nb
+        self.next = nb - 1
+        self.last_order, self.order = self.order, []
 
 
 def param_handles(layer):
