@@ -73,10 +73,12 @@ def fingerprint(t):
     return np.concatenate([[a.sum(), np.abs(a).sum()], head])
 
 
-def state_fingerprints(prefix, sd, d):
+def state_fingerprints(prefix, sd, d, before=None):
     keys = [k for k in sd if torch.is_tensor(sd[k]) and sd[k].dtype.is_floating_point]
     d[prefix + "_fp"] = np.stack([fingerprint(sd[k]) for k in keys])
     d[prefix + "_keys"] = np.array(keys)
+    if before is not None:  # size of the step each tensor took: sum |after - before| (scales the tolerance of the product's SGD check)
+        d[prefix + "_upd"] = np.array([float((sd[k].detach().double() - before[k].double()).abs().sum()) if k in before else 0.0 for k in keys])
 
 
 def make_images_and_gts(seed, bl, bu, H, W):
@@ -281,7 +283,7 @@ def gen_step_fcos(structures, tr):
     for k, v in storage.scalars.items():
         d["rec_" + k] = np.float64(v)
     d["losses"] = np.float64(captured["losses"])
-    state_fingerprints("student", full_state(student), d)
+    state_fingerprints("student", full_state(student), d, before=sd_s)
     state_fingerprints("teacher", full_state(teacher), d)
     for k in ("proposal_generator.fcos_head.cls_logits.bias", "proposal_generator.fcos_head.bbox_pred_std.bias",
               "proposal_generator.fcos_head.scales.0.scale", "proposal_generator.fcos_head.ctrness.bias"):
@@ -426,7 +428,7 @@ def gen_step_rcnn(structures, tr):
     for k, v in storage.scalars.items():
         d["rec_" + k] = np.float64(v)
     d["losses"] = np.float64(captured["losses"])
-    state_fingerprints("student", demangle(student.state_dict(), "net."), d)
+    state_fingerprints("student", demangle(student.state_dict(), "net."), d, before=sd_s)
     state_fingerprints("teacher", demangle(teacher.state_dict(), "net."), d)
     np.savez_compressed(os.path.join(HERE, "step_rcnn.npz"), **d)
     print("step_rcnn.npz:", len(d), "arrays;", {k: round(v, 6) for k, v in storage.scalars.items()}, "losses", captured["losses"])

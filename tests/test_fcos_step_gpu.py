@@ -303,4 +303,4 @@ def test_fcos_step_vs_reference_trainer_golden():
             np.testing.assert_allclose(pb["boxes"][i][m].cpu()[order].numpy(), d["%s%d_boxes" % (name, i)][ref_order], rtol=0, atol=2e-2)
             np.testing.assert_allclose(pb["scores"][i][m].cpu()[order].numpy(), d["%s%d_scores" % (name, i)][ref_order], rtol=1e-3)
     check_state_fingerprints(d, "teacher", cpu_state(tr.model_teacher), 0.0, exact=True)
-    check_state_fingerprints(d, "student", cpu_state(tr.model), 5e-4)
+    check_state_fingerprints(d, "student", cpu_state(tr.model), 1e-4, rtol_update=5e-3)

@@ -257,7 +257,7 @@ def test_rcnn_step_vs_reference_trainer_golden():
         i += 1
     assert i == 2
     check_state_fingerprints(d, "teacher", cpu_state(tr.model_teacher), 0.0, exact=True)
-    check_state_fingerprints(d, "student", cpu_state(tr.model), 5e-4)
+    check_state_fingerprints(d, "student", cpu_state(tr.model), 1e-4, rtol_update=5e-2)
 
 
 def test_rcnn_step_bf16_vs_rounding_oracle():

@@ -186,11 +186,13 @@ def golden_record(d):
     return {k[4:]: float(d[k]) for k in d.files if k.startswith("rec_")}
 
 
-def check_state_fingerprints(d, prefix, sd, rtol, exact=False):
-    """per-tensor (sum, |sum|, first 8 values) of `sd` against the golden's; rtol relative to the tensor's mean magnitude"""
+def check_state_fingerprints(d, prefix, sd, rtol, exact=False, rtol_update=0.0):
+    """per-tensor (sum, |sum|, first 8 values) of `sd` against the golden's.  Tolerance per tensor: rtol x its magnitude plus
+    rtol_update x the size of the step it took in the golden (sum |after - before|; zero-initialised biases ARE their update)."""
     keys = [str(k) for k in d[prefix + "_keys"]]
     ref = d[prefix + "_fp"]
-    for k, r in zip(keys, ref):
+    upd = d[prefix + "_upd"] if (prefix + "_upd") in d.files else np.zeros(len(keys))
+    for k, r, u in zip(keys, ref, upd):
         if k not in sd:
             assert "integral" in k, k
             continue
@@ -199,7 +201,7 @@ def check_state_fingerprints(d, prefix, sd, rtol, exact=False):
             assert np.array_equal(f, r), (prefix, k)
             continue
         n = max(sd[k].numel(), 1)
-        scale = r[1] / n + 1e-12                      # mean |value|
-        assert abs(f[0] - r[0]) <= rtol * r[1] + 1e-12, (prefix, k, "sum", f[0], r[0])
-        assert abs(f[1] - r[1]) <= rtol * r[1] + 1e-12, (prefix, k, "abs", f[1], r[1])
-        assert np.all(np.abs(f[2:] - r[2:]) <= rtol * scale * 50 + 1e-9), (prefix, k, "head", f[2:], r[2:])
+        tol = rtol * r[1] + rtol_update * u + 1e-12
+        assert abs(f[0] - r[0]) <= tol, (prefix, k, "sum", f[0], r[0], tol)
+        assert abs(f[1] - r[1]) <= tol, (prefix, k, "abs", f[1], r[1], tol)
+        assert np.all(np.abs(f[2:] - r[2:]) <= 50 * tol / n + 1e-9), (prefix, k, "head", f[2:], r[2:])
