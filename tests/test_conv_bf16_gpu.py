@@ -147,7 +147,11 @@ def test_fcos_step_bf16_vs_rounding_oracle():
 @pytest.mark.parametrize("xdt,dydt", [(torch.float32, torch.float32), (BF, BF), (BF, torch.float32), (torch.float32, BF)])
 @pytest.mark.parametrize("case", [(2, 25, 42, 256, 256, 3, 1, 1), (2, 13, 21, 64, 128, 3, 2, 1), (2, 50, 84, 64, 256, 1, 1, 0),
                                   (2, 30, 40, 256, 512, 1, 2, 0), (1, 20, 20, 128, 80, 3, 1, 1), (3, 9, 9, 32, 40, 3, 1, 1),
-                                  (1, 11, 7, 24, 16, 3, 1, 1), (2, 8, 8, 200, 136, 1, 1, 0)])
+                                  (1, 11, 7, 24, 16, 3, 1, 1), (2, 8, 8, 200, 136, 1, 1, 0),
+                                  # shapes of the 256 x 256-tile LDS-DMA kernel (bf16 x and dY, C % 256 == 0, K % 256 == 0, >= 16 chunks of
+                                  # 64 pixels): two k-tiles per tap, two co-tiles, a 1x1, a strided 3x3, a ragged pixel tail
+                                  (1, 40, 40, 512, 256, 3, 1, 1), (2, 30, 30, 256, 512, 3, 1, 1), (2, 40, 40, 256, 256, 1, 1, 0),
+                                  (2, 41, 41, 256, 256, 3, 2, 1), (1, 33, 37, 256, 256, 3, 1, 1)])
 def test_conv_bf16_wgrad(case, xdt, dydt):
     from ubteacher import hip
     N, H, W, C, K, k, s, p = case
@@ -188,6 +192,34 @@ def test_conv_ml_bf16_wgrad(xdt, dydt):
     dw = torch.zeros(K, k * k * C, device="cuda")
     hip.conv2d_wgrad_bf16(big, dy, dw, hip.rowinfo_ml(N, level_hw, 1, k, "cuda"), C, k, k, accumulate=False)
     assert relerr(dw.cpu(), wt.grad.permute(0, 2, 3, 1).reshape(K, -1)) < 2e-4
+
+
+def test_conv_ml_bf16_wgrad_big_tile():
+    """multi-level (level-first) wgrad on the 256 x 256-tile kernel: tower-shaped C = K = 256 over five levels, with the bias gradient"""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(5)
+    N, C, K, k = 2, 256, 256, 3
+    level_hw = [(25, 42), (13, 21), (7, 11), (4, 6), (2, 3)]
+    xs = [torch.randn(N, C, h, w, generator=g) for h, w in level_hw]
+    wt = (torch.randn(K, C, k, k, generator=g) * 0.05).requires_grad_(True)
+    ys = [F.conv2d(r16(x), wt, None, 1, 1) for x in xs]
+    dys = [torch.randn(y.shape, generator=g) for y in ys]
+    torch.autograd.backward(ys, [r16(d) for d in dys])
+    big = torch.cat([x.permute(0, 2, 3, 1).reshape(-1, C) for x in xs]).cuda().to(BF)
+    dy = torch.cat([d.permute(0, 2, 3, 1).reshape(-1, K) for d in dys]).cuda().to(BF)
+    assert big.shape[0] >= 16 * 64
+    dw = torch.zeros(K, k * k * C, device="cuda")
+    db = torch.zeros(K, device="cuda")
+    sc = torch.rand(K, generator=g).cuda() + 0.5
+    ri = hip.rowinfo_ml(N, level_hw, 1, k, "cuda")
+    hip.conv2d_wgrad_bf16(big, dy, dw, ri, C, k, k, accumulate=False, db=db, rowscale=sc)
+    ref = wt.grad.permute(0, 2, 3, 1).reshape(K, -1) * sc.cpu()[:, None]
+    assert relerr(dw.cpu(), ref) < 2e-4
+    refb = torch.cat([r16(d).permute(0, 2, 3, 1).reshape(-1, K) for d in dys]).sum(0) * sc.cpu()
+    assert relerr(db.cpu(), refb) < 2e-5
+    dw2 = torch.zeros_like(dw)
+    hip.conv2d_wgrad_bf16(big, dy, dw2, ri, C, k, k, accumulate=False, rowscale=sc)
+    assert torch.equal(dw2, dw)                                       # deterministic
 
 
 def test_elementwise_bf16():

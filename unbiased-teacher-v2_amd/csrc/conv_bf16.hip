@@ -737,6 +737,20 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
                           p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask);
 }
 
+// A/B switches for bench runs and tests, read ONCE per process (never on the launch path): UTV2_W8=0 keeps every forward / dgrad
+// row on the 128 x 128 kernel, UTV2_WGRAD_W8=0 keeps every wgrad on the 128 x 128 kernel.
+static bool env_flag_on(const char* name) {
+  const char* v = getenv(name);
+  return !(v && v[0] == '0');
+}
+static const bool g_use_w8 = env_flag_on("UTV2_W8");
+static const bool g_use_wgrad_w8 = env_flag_on("UTV2_WGRAD_W8");
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+static const int g_wgrad_debug = env_int("UTV2_WGRAD_DEBUG", 0);
+
 template <int BN, bool ML>
 static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dtype, hipStream_t stream) {
   const dim3 g(tiles), b(256);
@@ -748,8 +762,7 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
     // wide 1x1 layers) unless the grid is a little over one 512-slot round (tail), not for short HBM-bound ones.
     const bool tail = tiles > 512 && tiles <= 768;
     const bool deep = a.C % 64 == 0 && a.Kred >= 1024 && !tail;
-    const char* w8env = getenv("UTV2_W8");  // "0" keeps every row on the 128 x 128 kernel (A/B runs, tests/test_conv_bf16_gpu.py)
-    const bool w8 = !(w8env && w8env[0] == '0');
+    const bool w8 = g_use_w8;
     if (w8 && BN == 128 && a.xs == a.C && a.C % 64 == 0 && a.Kred >= 1024 && a.K >= 256 && (a.K & 3) == 0 && a.m_begin == 0) {
       // Whole rounds of 256 tiles (one per CU) always pay.  The rest: a partial round costs one 256-tile time (~76 us on the tower
       // shape) whatever its fill, the 128 x 128 kernel ~35-46 us per round of 512 of its tiles - so the big tile also takes the rest
@@ -922,6 +935,7 @@ struct Wgrad16Args {
   const int2* rowinfo;
   float* bias_ws;  // optional [splits][K]: per-split column sums of dY (conv bias gradient), fused into the dY staging
   int C, K, KH, KW, Kred, M, splits, chunks_per_split;
+  int debug;     // conv_wgrad_bf16_w8 built with UTV2_WGRAD_DEBUG_KNOBS: 16 / 32 / 64 = no DMA / no MFMA / no fragment reads (timing only)
 };
 
 __device__ __forceinline__ bf16x4_t lds_read_tr16(const unsigned char* p) {
@@ -1127,6 +1141,314 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// wgrad for the deep 3x3 layers (K % 256 == 0, C % 256 == 0, bf16 x and dY): the counterpart of conv_igemm_bf16_w8.
+// 256 (co) x 256 (k = one tap x 256 input channels) output tile, 8 waves (2 x 4) of 128 x 64, chunks of 64 pixels, both operand
+// tiles ([64 pixels][256 channels] bf16 = 32 KB each) staged by LDS-DMA into a double-buffered 128 KB image, one workgroup per CU.
+// Against the 128 x 128 / 4-wave kernel above: 12 transposing reads feed 8 MFMAs per k16 step (was 8 : 4), one barrier per 32 MFMAs
+// per wave (was 8), no ds_write pass and no staging VGPRs - per chunk the LDS array serves 24 read cycles per wave and k16 step where
+// the small tile's reads + writes kept it as busy as the matrix pipe itself.  Tower shape (M = 268 800): 0.52 -> 0.39 ms.
+// LDS rows are unpadded (a 1 KB DMA instruction fills two pixel rows); the 64-byte block b of pixel row r lives at block b ^ (r & 3),
+// applied on the SOURCE address of the DMA, so the 4 rows x 64 B a 32-lane half of ds_read_b64_tr_b16 touches fall on 64 distinct
+// banks.  Work items (pixel split x tile) are laid out so that a split's tiles - which share the dY chunk and the X neighbourhood -
+// run on one XCD (block b runs on XCD b % 8: speed only).  Slabs and the fixed-order reduction are the small kernel's.
+//
+// Memory instructions of the K loop are inline asm with hand-placed waits, because the compiler
+//  * orders every LDS load it knows about behind ALL pending LDS-DMA (a vmcnt(0) in front of each fragment read that follows a DMA
+//    issue: the loads of the next chunk would have to land before the current chunk is consumed), and
+//  * waits for a loop-carried global load right where its result is first used - in the middle of the DMA issue sequence.
+// The pixel geometry (rowinfo) of chunk c+2 is fetched by plain VMEM loads issued AHEAD of the DMA pieces of chunk c+1 (loads return
+// in order: the one vmcnt(0) in front of the barrier covers both).  As scalar loads they sat behind every lgkmcnt(0) of the fragment
+// reads (SMEM shares that counter and returns out of order): 0.398 -> 0.387 ms.
+// Measured and NOT kept (tools/bench_wgrad_pf.py, same shape): one discarded dword load per 128-byte line 1-3 chunks ahead of the DMA
+// as an L2 prefetch (0.51 ms: the in-order vmcnt makes every piece wait for the older HBM-miss load); a three-stage ring of 48-pixel
+// chunks with the DMA two chunks ahead and a counted vmcnt(9) in front of a bare s_barrier (0.396 ms: no gain, the DMA stream is not
+// latency-bound).  With the fragment reads / MFMAs / DMA switched off in turn (UTV2_WGRAD_DEBUG_KNOBS): MFMAs alone 0.25 ms, MFMAs +
+// reads 0.32, DMA alone 0.30 (64 KB per CU every 1.8 us = 8.8 TB/s out of the L2s, each dY chunk fetched by nine tiles), all 0.39.
+#ifdef UTV2_WGRAD_DEBUG_KNOBS
+#define WG8_DMA (!(p.debug & 16))
+#define WG8_MFMA (!(p.debug & 32))
+#define WG8_READ (!(p.debug & 64))
+#else
+#define WG8_DMA true
+#define WG8_MFMA true
+#define WG8_READ true
+#endif
+#define WGRAD_W8_BP 64
+__global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
+  constexpr int BP = WGRAD_W8_BP, ROWB = 512, OPB = BP * ROWB, STAGE = 2 * OPB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  const int tilesN = p.Kred >> 8, tiles = (p.K >> 8) * tilesN;
+  const int per = gridDim.x >> 3;
+  const int wi = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (wi >= tiles * p.splits) return;
+  const int split = wi / tiles, bid = wi - split * tiles;
+  const int mt = bid / tilesN, nt = bid - mt * tilesN;
+  const int i0 = mt << 8, j0 = nt << 8;
+  const int tap = j0 / p.C, ci0 = j0 - tap * p.C;
+  const int dh = tap / p.KW, dw = tap - dh * p.KW;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int total_chunks = (p.M + BP - 1) / BP;
+  const int chunk_begin = split * p.chunks_per_split;
+  int chunk_end = chunk_begin + p.chunks_per_split;
+  if (chunk_end > total_chunks) chunk_end = total_chunks;
+
+  // DMA role of the lane: piece q of an operand = pixel rows 8*wid + 2q + (lane >> 5) of the chunk, 16 bytes at physical slot lane & 31
+  const int hr = lane >> 5, slot = lane & 31;
+  int choff[2];  // source channel of the lane's 16 bytes for pieces with (2q + hr) & 3 == hr (q even) / 2 + hr (q odd)
+#pragma unroll
+  for (int o = 0; o < 2; ++o) choff[o] = (((slot >> 2) ^ ((2 * o + hr) & 3)) << 5) + ((slot & 3) << 3);
+  const __bf16* __restrict__ xb = (const __bf16*)p.x;
+  const __bf16* __restrict__ dyb = (const __bf16*)p.dy;
+  const __bf16* zero = (const __bf16*)g_zero64;
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  i32x2 ri[4];              // rowinfo of the lane's four im2col rows of the NEXT chunk to be staged
+  const int rowl = 8 * wid + hr;  // + 2q
+  auto rload = [&](int chunk) {   // asm: invisible to the compiler's waitcnt insertion; waited for by the vmcnt(0) in front of the barrier
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int m = chunk * BP + rowl + 2 * q;
+      m = m < p.M ? m : p.M - 1;
+      const int2* src = p.rowinfo + m;
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ri[q]) : "v"(src));
+    }
+  };
+  const __bf16* bsrc[4];    // source of the lane's 16 bytes of the four im2col pieces of the chunk staged in this iteration
+  auto bsrc_from_ri = [&](int chunk) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = chunk * BP + rowl + 2 * q;
+      const int W = ri[q].y >> 16;
+      const __bf16* s0 = xb + (unsigned)((ri[q].x + dh * W + dw) * p.C + ci0 + choff[q & 1]);
+      const bool ok = (m < p.M) & ((ri[q].y >> tap) & 1);
+      bsrc[q] = ok ? s0 : zero;
+    }
+  };
+  auto issue_piece = [&](int buf, int chunk, int q8) {  // q8 0..3: dY pieces, 4..7: im2col pieces
+    const int q = q8 & 3;
+    unsigned char* dst = smem + buf * STAGE + (q8 < 4 ? 0 : OPB) + (8 * wid + 2 * q) * ROWB;
+    const __bf16* src;
+    if (q8 < 4) {
+      const int m = chunk * BP + rowl + 2 * q;
+      const __bf16* s0 = dyb + (unsigned)(m * p.K + i0 + choff[q & 1]);
+      src = m < p.M ? s0 : zero;
+    } else {
+      src = bsrc[q];
+    }
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+  };
+
+  // transposing fragment reads: lane (G = lane >> 4, t = lane & 15) addresses pixel row 8*(G>>1) + (t>>2) (+4 for the second half of
+  // the 8-deep operand, + 16 per k16 step), the 8 bytes at 32*(G&1) + 8*(t&3) of logical 64-byte block L, stored at block L ^ (t>>2)
+  const int G = lane >> 4, t = lane & 15, r3 = t >> 2;
+  const unsigned lrow = (unsigned)(size_t)(lptr_t)smem + (8 * (G >> 1) + r3) * ROWB + 32 * (G & 1) + 8 * (t & 3);
+  unsigned aoff[4], boff[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aoff[i] = lrow + (((wm * 4 + i) ^ r3) << 6);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) boff[j] = OPB + lrow + (((wn * 2 + j) ^ r3) << 6);
+  typedef __bf16 frag_t __attribute__((ext_vector_type(8)));
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+#define TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define READ_FRAGS(set, S)                                                                         \
+  TR_READ(al[set][0], ab[0], (S) * 16 * ROWB); TR_READ(ah[set][0], ab[0], ((S) * 16 + 4) * ROWB);  \
+  TR_READ(al[set][1], ab[1], (S) * 16 * ROWB); TR_READ(ah[set][1], ab[1], ((S) * 16 + 4) * ROWB);  \
+  TR_READ(al[set][2], ab[2], (S) * 16 * ROWB); TR_READ(ah[set][2], ab[2], ((S) * 16 + 4) * ROWB);  \
+  TR_READ(al[set][3], ab[3], (S) * 16 * ROWB); TR_READ(ah[set][3], ab[3], ((S) * 16 + 4) * ROWB);  \
+  TR_READ(bl[set][0], bb[0], (S) * 16 * ROWB); TR_READ(bh[set][0], bb[0], ((S) * 16 + 4) * ROWB);  \
+  TR_READ(bl[set][1], bb[1], (S) * 16 * ROWB); TR_READ(bh[set][1], bb[1], ((S) * 16 + 4) * ROWB)
+  // all fragment reads issued so far have landed; ties the registers so that no MFMA moves above the wait
+#define WAIT_FRAGS(set)                                                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                                          \
+               : "+v"(al[set][0]), "+v"(al[set][1]), "+v"(al[set][2]), "+v"(al[set][3]), "+v"(ah[set][0]), "+v"(ah[set][1]), \
+                 "+v"(ah[set][2]), "+v"(ah[set][3]), "+v"(bl[set][0]), "+v"(bl[set][1]), "+v"(bh[set][0]), "+v"(bh[set][1]))
+  // every VMEM operation of the wave (rowinfo loads, LDS-DMA pieces) has completed; ties the rowinfo registers
+#define WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" : "+v"(ri[0]), "+v"(ri[1]), "+v"(ri[2]), "+v"(ri[3]) : : "memory")
+
+  auto iteration = [&](int ch, int buf, auto do_load) {
+    constexpr bool LOAD = decltype(do_load)::value;
+    unsigned ab[4], bb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ab[i] = aoff[i] + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bb[j] = boff[j] + buf * STAGE;
+    s16x4 al[2][4], ah[2][4], bl[2][2], bh[2][2];  // low / high pixel quads of the 8-deep operands, two sets (k16 step parity)
+#ifdef UTV2_WGRAD_DEBUG_KNOBS
+    for (int u = 0; u < 2; ++u) {
+      for (int i = 0; i < 4; ++i) al[u][i] = ah[u][i] = s16x4{0, 0, 0, 0};
+      for (int j = 0; j < 2; ++j) bl[u][j] = bh[u][j] = s16x4{0, 0, 0, 0};
+    }
+#endif
+    auto mfmas = [&](int set) {
+      frag_t a[4], b[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x4_t lo = __builtin_bit_cast(bf16x4_t, al[set][i]), hi = __builtin_bit_cast(bf16x4_t, ah[set][i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[i][e] = lo[e]; a[i][4 + e] = hi[e]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x4_t lo = __builtin_bit_cast(bf16x4_t, bl[set][j]), hi = __builtin_bit_cast(bf16x4_t, bh[set][j]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { b[j][e] = lo[e]; b[j][4 + e] = hi[e]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    // the geometry of chunk ch+1 arrived before the last barrier: turn it into the four im2col source addresses, which frees the
+    // rowinfo registers for chunk ch+2
+    if constexpr (LOAD) bsrc_from_ri(ch + 1);
+    // k16 step s: [fragments of step s have landed] -> issue the reads of step s+1 -> 8 MFMAs -> memory work of the next chunks
+    if (WG8_READ) { READ_FRAGS(0, 0); }
+    WAIT_FRAGS(0);
+    if (WG8_READ) { READ_FRAGS(1, 1); }
+    if (WG8_MFMA) mfmas(0);
+    if constexpr (LOAD) {
+      rload(ch + 2);   // older than the DMA pieces below: in-order return, one wait covers both
+      if (WG8_DMA) {
+#pragma unroll
+        for (int q8 = 4; q8 < 8; ++q8) issue_piece(buf ^ 1, ch + 1, q8);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    WAIT_FRAGS(1);
+    if (WG8_READ) { READ_FRAGS(0, 2); }
+    if (WG8_MFMA) mfmas(1);
+    if constexpr (LOAD) {
+      if (WG8_DMA) {
+#pragma unroll
+        for (int q8 = 0; q8 < 4; ++q8) issue_piece(buf ^ 1, ch + 1, q8);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    WAIT_FRAGS(0);
+    if (WG8_READ) { READ_FRAGS(1, 3); }
+    if (WG8_MFMA) mfmas(0);
+    __builtin_amdgcn_sched_barrier(0);
+    WAIT_FRAGS(1);
+    if (WG8_MFMA) mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+    WAIT_VMEM();
+    __syncthreads();
+  };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
+  if (chunk_begin < chunk_end) {
+    rload(chunk_begin);
+    WAIT_VMEM();
+    bsrc_from_ri(chunk_begin);
+    rload(chunk_begin + 1);
+#pragma unroll
+    for (int q8 = 0; q8 < 8; ++q8) issue_piece(0, chunk_begin, q8);
+    WAIT_VMEM();
+    __syncthreads();
+    int ch = chunk_begin;
+    for (; ch + 1 < chunk_end; ++ch) iteration(ch, (ch - chunk_begin) & 1, yes{});
+    iteration(ch, (ch - chunk_begin) & 1, no{});
+  }
+#undef TR_READ
+#undef READ_FRAGS
+#undef WAIT_FRAGS
+#undef WAIT_VMEM
+
+  const int frow = lane & 31, fh = lane >> 5;
+  float* out = p.ws + (size_t)split * p.K * p.Kred;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = j0 + wn * 64 + j * 32 + frow;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = i0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        out[(size_t)co * p.Kred + k] = acc[i][j][e];
+      }
+  }
+}
+
+// Column sums of a bf16 [M][K] matrix (the bias gradient next to conv_wgrad_bf16_w8, which never holds dY in registers):
+// block b sums its contiguous row range per channel -> partial[b][K]; fixed order everywhere.  K % 8 == 0, K <= 2048.
+// Four row loads in flight per thread, ~4 blocks per CU (a single dependent load per thread streamed at 3 TB/s).
+__global__ __launch_bounds__(256) void colsum_bf16_partial(const __bf16* __restrict__ g, float* __restrict__ partial, int M, int K,
+                                                           int rows_per_block) {
+  __shared__ float red[256 * 8];
+  const int cpr = K >> 3;                    // 16-byte groups per row
+  const int rpp = 256 / cpr;                 // rows per pass (K <= 2048)
+  const int cg = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  float s[4][8];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[u][e] = 0.f;
+  if (rl < rpp) {
+    int r = r0 + rl;
+    for (; r + 3 * rpp < r1; r += 4 * rpp) {
+      bf16x8_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *(const bf16x8_t*)(g + (size_t)(r + u * rpp) * K + cg * 8);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[u][e] += (float)v[u][e];
+    }
+    for (; r < r1; r += rpp) {
+      const bf16x8_t v = *(const bf16x8_t*)(g + (size_t)r * K + cg * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[0][e] += (float)v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = (s[0][e] + s[1][e]) + (s[2][e] + s[3][e]);
+  __syncthreads();
+  for (int c = threadIdx.x; c < K; c += 256) {
+    float a = 0.f;
+    for (int k = 0; k < rpp; ++k) a += red[(k * cpr + (c >> 3)) * 8 + (c & 7)];
+    partial[(size_t)blockIdx.x * K + c] = a;
+  }
+}
+
+// db[c] (+)= rowscale[c] * sum_b partial[b][c]: 32 channels x 8 row parts per block, four loads in flight, fixed combine order
+__global__ __launch_bounds__(256) void colsum_final_f32(const float* __restrict__ partial, float* __restrict__ db, int nb, int K,
+                                                        int accumulate, const float* __restrict__ rowscale) {
+  __shared__ float red[256];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), part = threadIdx.x >> 5;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < K) {
+    int b = part;
+    for (; b + 24 < nb; b += 32) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] += partial[(size_t)(b + 8 * u) * K + c];
+    }
+    for (; b < nb; b += 8) s[0] += partial[(size_t)b * K + c];
+  }
+  red[threadIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+  __syncthreads();
+  if (part == 0 && c < K) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += red[threadIdx.x + 32 * k];
+    if (rowscale) v *= rowscale[c];
+    db[c] = accumulate ? db[c] + v : v;
+  }
+}
+
 // dst[i] (+)= rowscale[i / rowlen] * sum_k ws[k][i]   (fixed order; rowscale optional: the folded FrozenBN multiplier of
 // the output channel, applied here instead of to the output gradient).  Four elements per thread (16-byte accesses),
 // four independent partial sums over k mod 4 combined in a fixed order: deterministic, and 4 loads in flight per thread.
@@ -1169,7 +1491,7 @@ __global__ void reduce_slabs16_scalar_f32(const float* __restrict__ ws, float* _
 
 extern "C" {
 
-int utv2_conv2d_wgrad_bf16_splits(int M, int K, int Kred) {
+static int wgrad16_small_splits(int M, int K, int Kred) {
   const int chunks = cdiv(M, 32);
   const int tiles = cdiv(K, 128) * cdiv(Kred, 128);
   // ~2 workgroups per CU: every split costs a K x Kred fp32 slab written and re-read, which rivals the operand traffic
@@ -1184,8 +1506,34 @@ int utv2_conv2d_wgrad_bf16_splits(int M, int K, int Kred) {
   return splits;
 }
 
+// the 256 x 256-tile kernel: one workgroup per CU in ONE round - as many pixel splits as fit 256 work items, at least 8 chunks each
+#define WGRAD_W8_MAX_NB 1024  // row blocks of the bias column-sum pass
+static int wgrad16_w8_splits(int M, int K, int Kred) {
+  const int tiles = (K >> 8) * (Kred >> 8), chunks = cdiv(M, WGRAD_W8_BP);
+  int splits = 256 / tiles;
+  if (splits > chunks / 8) splits = chunks / 8;
+  return splits < 1 ? 1 : splits;
+}
+static bool wgrad16_w8_shape_ok(int M, int C, int K, int KH, int KW) {
+  const int Kred = KH * KW * C, tiles = (K >> 8) * (Kred >> 8), chunks = cdiv(M, WGRAD_W8_BP);
+  if ((K & 255) || (C & 255) || KH * KW > 16 || K > 2048 || tiles > 256 || chunks < 16 || (int64_t)M * K >= (1ll << 31)) return false;
+  // 1x1 layers are HBM-bound: every pixel split costs a K x Kred fp32 slab written and re-read, and this kernel needs 256 / tiles of
+  // them to fill the chip - it pays there only when a split still covers >= 16 chunks (measured: 256 -> 512 stride 2 at M = 134 400
+  // 424 -> 493 TF, the M = 33 600 / 8 400 layers 10-20 % slower)
+  if (KH * KW == 1 && chunks < 16 * (256 / tiles)) return false;
+  return true;
+}
+
+int utv2_conv2d_wgrad_bf16_splits(int M, int K, int Kred) { return wgrad16_small_splits(M, K, Kred); }
+
+// large enough for either kernel (which one runs also depends on the element types)
 int64_t utv2_conv2d_wgrad_bf16_workspace_floats(int M, int K, int Kred) {
-  return (int64_t)utv2_conv2d_wgrad_bf16_splits(M, K, Kred) * ((int64_t)K * Kred + K);
+  int64_t n = (int64_t)wgrad16_small_splits(M, K, Kred) * ((int64_t)K * Kred + K);
+  if ((K & 255) == 0 && (Kred & 255) == 0) {
+    const int64_t n8 = (int64_t)wgrad16_w8_splits(M, K, Kred) * K * Kred + (int64_t)WGRAD_W8_MAX_NB * K;
+    if (n8 > n) n = n8;
+  }
+  return n;
 }
 
 // rowinfo: device int32[M][2] = {anchor input pixel, (W << 16) | tapmask} for every OUTPUT pixel m (built once per
@@ -1199,7 +1547,35 @@ int utv2_conv2d_wgrad_bf16(const void* x, int x_dtype, const void* dy, int dy_dt
     return UTV2_EARG;
   Wgrad16Args a;
   a.x = x; a.dy = dy; a.ws = ws; a.rowinfo = (const int2*)rowinfo;
-  a.C = C; a.K = K; a.KH = KH; a.KW = KW; a.Kred = KH * KW * C; a.M = M;
+  a.C = C; a.K = K; a.KH = KH; a.KW = KW; a.Kred = KH * KW * C; a.M = M; a.debug = 0;
+  if (g_use_wgrad_w8 && x_dtype == UTV2_BF16 && dy_dtype == UTV2_BF16 && wgrad16_w8_shape_ok(M, C, K, KH, KW)) {
+    a.splits = wgrad16_w8_splits(M, K, a.Kred);
+    a.chunks_per_split = cdiv(cdiv(M, WGRAD_W8_BP), a.splits);
+    a.bias_ws = nullptr;
+    a.debug = g_wgrad_debug;
+    const size_t n = (size_t)K * a.Kred;
+    const int smem = 2 * 2 * WGRAD_W8_BP * 512;
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_w8, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_bf16_w8, dim3(256), dim3(512), smem, stream, a);
+    int rb = cdiv((int64_t)n / 4, 256);
+    if (rb > 8192) rb = 8192;
+    hipLaunchKernelGGL(reduce_slabs16_f32, dim3(rb), dim3(256), 0, stream, (const float*)ws, dw, n, a.splits, accumulate, rowscale,
+                       a.Kred);
+    if (db) {
+      float* part = ws + (size_t)a.splits * n;
+      int nb = cdiv(M, 64);
+      if (nb > WGRAD_W8_MAX_NB) nb = WGRAD_W8_MAX_NB;
+      const int rows = cdiv(M, nb);
+      nb = cdiv(M, rows);
+      hipLaunchKernelGGL(colsum_bf16_partial, dim3(nb), dim3(256), 0, stream, (const __bf16*)dy, part, M, K, rows);
+      hipLaunchKernelGGL(colsum_final_f32, dim3(cdiv(K, 32)), dim3(256), 0, stream, (const float*)part, db, nb, K, accumulate, rowscale);
+    }
+    return utv2_launch_status();
+  }
   a.splits = utv2_conv2d_wgrad_bf16_splits(M, K, a.Kred);
   a.chunks_per_split = cdiv(cdiv(M, 32), a.splits);
   const size_t n = (size_t)K * a.Kred;
