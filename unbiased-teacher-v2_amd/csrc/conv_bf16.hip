@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
   const int wm = wid >> 2, wn = wid & 3;
   const int tilesN = p.Kred >> 8, tiles = (p.K >> 8) * tilesN;
   const int per = gridDim.x >> 3;
-  const int wi = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int wi = (blockIdx.x & 7) * per + (blockIdx.x >> 3);   // (spreading a split's tiles over the XCDs instead: 0.39 -> 0.42 ms)
   if (wi >= tiles * p.splits) return;
   const int split = wi / tiles, bid = wi - split * tiles;
   const int mt = bid / tilesN, nt = bid - mt * tilesN;
