@@ -106,11 +106,62 @@ class ConvTimer:
                     alg_gbps=by / ms / 1e6)
 
 
+class WgradTimer:
+    """HIP-event timing of the FCOS tower weight-gradient launches (conv_wgrad_bf16_w8 + reduce_slabs16_f32 + the bias column sums:
+    one C-ABI call = one timed launch): the largest single symbol of the round-1 profile."""
+    kernel = "conv_wgrad_bf16_w8+reduce_slabs16_f32+colsum_bf16_* (FCOS tower 3x3 weight gradients)"
+
+    def __init__(self):
+        self.pairs = []
+        self.enabled = False
+
+    def install(self):
+        from ubteacher import hip
+        orig = hip.conv2d_wgrad_bf16
+        timer = self
+
+        def wrapped(x, dy2d, dw, rowinfo, C, kh, kw, *args, **kwargs):
+            M, K = dy2d.shape
+            mine = (timer.enabled and kh == 3 and kw == 3 and C == 256 and K == 256 and x.dtype == torch.bfloat16
+                    and dy2d.dtype == torch.bfloat16 and M >= 65536)
+            if not mine:
+                return orig(x, dy2d, dw, rowinfo, C, kh, kw, *args, **kwargs)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(x, dy2d, dw, rowinfo, C, kh, kw, *args, **kwargs)
+            e1.record()
+            timer.pairs.append((e0, e1, 2.0 * M * K * kh * kw * C, 2.0 * M * (C + K) + 4.0 * K * kh * kw * C))
+            return r
+
+        hip.conv2d_wgrad_bf16 = wrapped
+
+    summary = ConvTimer.summary
+
+
+class CallCounter:
+    """C-ABI calls per step (every HIP kernel of the product is launched through ubteacher.hip.call; one call = 1-3 kernels)"""
+
+    def __init__(self):
+        self.n = 0
+
+    def install(self):
+        from ubteacher import hip
+        orig = hip.call
+        me = self
+
+        def counted(name, *a):
+            me.n += 1
+            return orig(name, *a)
+        hip.call = counted
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
     (profiles/r01_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs; FETCH_SIZE doubled as
     MI355X_MICROARCH.md's HBM section prescribes for 16-byte-per-lane reads on gfx950)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f).get(kernel)
@@ -119,34 +170,69 @@ def pmc_traffic(kernel):
         return None
 
 
-def cpu_baseline(cfg):
-    """The oracle (CPU port of the reference step) timed on the host cores on a bounded sample:
-    ONE step with 1 labeled + 1 unlabeled 1333x800 image."""
+def cpu_baseline_run(label, unlabel, warmup, steps):
+    """The oracle (CPU port of the reference step: its orchestration + restated Detectron2 primitives on stock torch CPU kernels) timed
+    on the host cores: `warmup` + `steps` iterations of the SAME post-burn-in FCOS step on `label` labeled (weak + strong views) +
+    `unlabel` unlabeled 1333x800 images, with the phase split SURVEY 8(d) asks for.  Runs in its own process (see cpu_baseline)."""
     from oracle import utv2_oracle as O
     from ubteacher.data.synthetic import make_gt, make_image, strong_view
     from ubteacher.modeling import build_model
+    from ubteacher.presets import get_config
     import numpy as np
-    ccfg = cfg.clone()
-    ccfg.defrost()
-    ccfg.MODEL.DEVICE = "cuda"
+    cfg = get_config("fcos", 1, ["MODEL.DEVICE", "cpu", "SEMISUPNET.BURN_UP_STEP", 0])
+    # stock torch CPU convolutions stop scaling (and can slow down) far below the thread count of a 128-core host
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 32)))
     rng = np.random.default_rng(0)
-    model = build_model(ccfg)
-    sd = {k: v.detach().cpu().clone().contiguous() for k, v in model.state_dict().items()}
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    sd = {k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}
     del model
-    torch.cuda.empty_cache()
-
-    def im():
-        return make_image(rng, 800, 1333)
-    gt = make_gt(rng, 800, 1333)
-    g = dict(boxes=gt.gt_boxes.tensor, classes=gt.gt_classes)
-    wk = im()
-    batch = ([{"image": strong_view(rng, wk), "gt": g}], [{"image": wk, "gt": g}], [{"image": im()}], [{"image": im()}])
+    lq, lk, uq, uk = [], [], [], []
+    for _ in range(label):
+        wk = make_image(rng, 800, 1333).cpu()
+        gt = make_gt(rng, 800, 1333)
+        g = dict(boxes=gt.gt_boxes.tensor.cpu(), classes=gt.gt_classes.cpu())
+        lq.append({"image": strong_view(rng, wk).cpu(), "gt": g}); lk.append({"image": wk, "gt": g})
+    for _ in range(unlabel):
+        wk = make_image(rng, 800, 1333).cpu()
+        uq.append({"image": strong_view(rng, wk).cpu()}); uk.append({"image": wk})
+    batch = (lq, lk, uq, uk)
     cores = torch.get_num_threads()
-    t0 = time.perf_counter()
-    O.fcos_semisup_step(O.FCOSCfg(), sd, dict(sd), batch, keep_rate=0.9999)
-    dt = time.perf_counter() - t0
-    return {"value": 2.0 / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "1 step, 1 labeled (weak+strong views) + 1 unlabeled 1333x800 image, fp32, torch CPU kernels, %.1f s" % dt}
+    student, teacher, bufs = sd, dict(sd), None
+    phases, times = {}, []
+    for it in range(warmup + steps):
+        ph = {}
+        t0 = time.perf_counter()
+        _, student, teacher, _, bufs, _ = O.fcos_semisup_step(O.FCOSCfg(), student, teacher, batch, keep_rate=0.9999, bufs=bufs,
+                                                              phase_times=ph)
+        dt = time.perf_counter() - t0
+        if it >= warmup:
+            times.append(dt)
+            for k, v in ph.items():
+                phases[k] = phases.get(k, 0.0) + v
+    mean = sum(times) / len(times)
+    return {"value": (label + unlabel) / mean, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d warm-up + %d timed steps of %d labeled (weak+strong views) + %d unlabeled 1333x800 images, fp32, reference "
+                      "orchestration + restated Detectron2 primitives on stock torch CPU kernels; %.1f s per step"
+                      % (warmup, steps, label, unlabel, mean),
+            "step_seconds": times, "phase_seconds_per_step": {k: v / len(times) for k, v in phases.items()}}
+
+
+def cpu_baseline(label=1, unlabel=1, warmup=1, steps=2, timeout=600):
+    """cpu_baseline_run in a child process, BEFORE the GPU phase starts (it cannot disturb the timed region, and a host-side problem
+    cannot lose the GPU measurement)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--label", str(label), "--unlabel", str(unlabel),
+           "--cpu-warmup", str(warmup), "--cpu-steps", str(steps)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        return json.loads(line[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
 
 
 def parse_args(argv=None):
@@ -157,6 +243,11 @@ def parse_args(argv=None):
     ap.add_argument("--label", type=int, default=4, help="labeled images per GPU")
     ap.add_argument("--unlabel", type=int, default=4, help="unlabeled images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU port on --label/--unlabel images and print its record")
+    ap.add_argument("--cpu-warmup", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-images", type=int, default=1, help="labeled and unlabeled images of the CPU baseline sample (SURVEY 8d protocol: 2)")
+    ap.add_argument("--no-f32", action="store_true", help="skip the f32 sub-record / the bf16-vs-f32 one-step loss deviation")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
                     help="conv arithmetic: bf16 = the config's SOLVER.AMP.ENABLED path (bf16 MFMA, fp32 accumulate); f32 = exact-f32 MFMA")
     return ap.parse_args(argv)
@@ -190,22 +281,40 @@ def worker(args):
 
     from ubteacher.engine import UBTeacherTrainer
     from ubteacher.presets import get_config
-    from ubteacher import hip
+    from ubteacher import hip, ops
     hip.load()
-    cfg = get_config("fcos", 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label * world, "SOLVER.IMG_PER_BATCH_UNLABEL",
-                                 args.unlabel * world, "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", args.dtype == "bf16",
-                                 "MODEL.DEVICE", "cuda:%d" % device_index])
-    torch.manual_seed(0)
+    cpu_rec = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # before any GPU work, in its own process
+        cpu_rec = cpu_baseline(args.cpu_images, args.cpu_images, args.cpu_warmup, args.cpu_steps)
+
+    def make_trainer(dtype):
+        cfg = get_config("fcos", 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label * world, "SOLVER.IMG_PER_BATCH_UNLABEL",
+                                     args.unlabel * world, "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", dtype == "bf16",
+                                     "MODEL.DEVICE", "cuda:%d" % device_index])
+        torch.manual_seed(0)
+        t = UBTeacherTrainer(cfg)
+        t.iter = 1
+        t.log_period = 10 ** 9
+        return t
+
     timer = ConvTimer(args.dtype)
     timer.install()
-    tr = UBTeacherTrainer(cfg)
+    wtimer = WgradTimer()
+    wtimer.install()
+    calls = CallCounter()
+    calls.install()
+    tr = make_trainer(args.dtype)
     batch = tr._data_loader.batches[0]
     tune_for_pseudo_labels(tr, batch)
     tr.sync_replicas()   # identical students / teachers on every rank (DDP broadcasts rank 0's parameters at construction)
-    tr.iter = 1
-    tr.log_period = 10 ** 9
-    for _ in range(args.warmup):
+    parity = rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_f32
+    if parity:
+        s0, t0 = tr.model.flat_state().clone(), tr.model_teacher.flat_state().clone()
+    first = None
+    for i in range(args.warmup):
         tr.run_step_full_semisup(); tr.iter += 1
+        if i == 0 and parity:
+            first = dict(tr.flush_metrics())
 
     def sync():
         torch.cuda.synchronize()
@@ -214,13 +323,16 @@ def worker(args):
             torch.cuda.synchronize()
 
     sync()
-    timer.enabled = True
-    t0 = time.perf_counter()
+    timer.enabled = wtimer.enabled = True
+    n0 = calls.n
+    t0_ = time.perf_counter()
     for _ in range(args.steps):
         tr.run_step_full_semisup(); tr.iter += 1
+    t_host = time.perf_counter() - t0_      # the host has enqueued every step (it runs ahead of the GPU)
     sync()
-    dt = time.perf_counter() - t0
-    timer.enabled = False
+    dt = time.perf_counter() - t0_
+    timer.enabled = wtimer.enabled = False
+    calls_per_step = (calls.n - n0) / max(args.steps, 1)
     devices = [device_index]
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -230,10 +342,66 @@ def worker(args):
         dist.all_gather_object(devs, device_index)
         devices = devs
     metrics = tr.flush_metrics()
-    conv = timer.summary()
+    conv, wg = timer.summary(), wtimer.summary()
+
+    host_ms = None
+    if rank == 0 and world == 1:
+        # host cost of one step: the same trainer code on 96 x 128 images, where the GPU work is negligible and the step time IS the
+        # Python / launch overhead (on the 1333 x 800 batch the host runs ahead until the launch queue is full, so its enqueue time
+        # only mirrors the GPU time)
+        from ubteacher.data.synthetic import SyntheticTwoCropLoader
+        cfg_s = get_config("fcos", 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label, "SOLVER.IMG_PER_BATCH_UNLABEL", args.unlabel,
+                                       "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", args.dtype == "bf16",
+                                       "MODEL.DEVICE", "cuda:%d" % device_index])
+        torch.manual_seed(0)
+        ts = UBTeacherTrainer(cfg_s, data_loader=SyntheticTwoCropLoader(cfg_s, height=96, width=128))
+        ts.iter = 1
+        ts.log_period = 10 ** 9
+        tune_for_pseudo_labels(ts, ts._data_loader.batches[0])
+        for _ in range(3):
+            ts.run_step_full_semisup(); ts.iter += 1
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for _ in range(10):
+            ts.run_step_full_semisup(); ts.iter += 1
+        torch.cuda.synchronize()
+        host_ms = 1e3 * (time.perf_counter() - th) / 10
+        del ts
+
+    f32_rec = None
+    if parity and first is not None:
+        # the mode in which the 1e-3 loss parity against the oracle is demonstrated (tests/test_fcos_step_gpu.py), driver-timed here, and
+        # the deviation of ONE bf16 step from the f32 step on the same 1333x800 batch from the same initial weights
+        del tr
+        torch.cuda.empty_cache()
+        tr32 = make_trainer("f32")
+        tr32.model.flat_state().copy_(s0); tr32.model_teacher.flat_state().copy_(t0)
+        tr32.model.store.touch(); tr32.model_teacher.store.touch(); ops.bump_version()
+        tr32.run_step_full_semisup(); tr32.iter += 1
+        first32 = dict(tr32.flush_metrics())
+        tr32.run_step_full_semisup(); tr32.iter += 1
+        torch.cuda.synchronize()
+        k32 = 5
+        t1 = time.perf_counter()
+        for _ in range(k32):
+            tr32.run_step_full_semisup(); tr32.iter += 1
+        torch.cuda.synchronize()
+        d32 = time.perf_counter() - t1
+        keys = [k for k in first32 if k.startswith("loss")]
+        f32_rec = {"value": (args.label + args.unlabel) * k32 / d32, "unit": "images/sec", "ms_per_step": 1e3 * d32 / k32, "steps": k32,
+                   "warmup": 2, "dtype": "f32",
+                   "first_step_losses": {k: first32[k] for k in keys},
+                   "bf16_first_step_losses": {k: first[k] for k in keys},
+                   "bf16_vs_f32_first_step_rel_dev": {k: abs(first[k] - first32[k]) / max(abs(first32[k]), 1e-12) for k in keys},
+                   "pseudo_boxes_per_step": {"f32": first32.get("teacher_better_student_pseudo"),
+                                             "bf16": first.get("teacher_better_student_pseudo"),
+                                             "note": "teacher_better_student count of the regression pseudo set; each mode thresholds its OWN teacher's detections, so the pseudo "
+                                                     "classification loss also moves with which borderline detections pass the score threshold, not only with rounding"}}
+        del tr32
 
     if rank == 0:
         per_step_images = (args.label + args.unlabel) * world
+        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         out = {
             "metric": "images/sec/node (labeled+unlabeled) UTv2 step, R50-FPN 1333x800",
             "value": per_step_images * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -245,21 +413,26 @@ def worker(args):
                        "precision": "AMP (config SOLVER.AMP.ENABLED): bf16 MFMA operands, bf16 activations and activation gradients in HBM, fp32 accumulate / losses / weight gradients / master weights" if args.dtype == "bf16" else "fp32 MFMA, fp32 everywhere"},
             "ranks": {"world_size": world, "backend": info["backend"], "devices": devices,
                       "launcher": _launcher_name(world)},
+            "host": {"ms_per_step_on_96x128_images": host_ms, "enqueue_ms_per_step": 1e3 * t_host / args.steps,
+                     "cabi_calls_per_step": calls_per_step},
             "losses": {k: v for k, v in metrics.items() if k.startswith("loss") or k.startswith("teacher")},
         }
         if conv:
-            peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
             out["roofline"] = {"bound": "mfma", "kernel": timer.kernel + " (FCOS tower 3x3 convs, all fwd+dgrad launches)",
                                "achieved": conv["tflops"], "peak": peak, "unit": "TFLOP/s",
                                "frac": conv["tflops"] / peak, "traffic": pmc_traffic(timer.kernel),
                                "algorithmic_bytes": conv["alg_bytes"], "algorithmic_GBps": conv["alg_gbps"],
                                "launches": conv["launches"], "avg_us": conv["avg_us"],
                                "time_share": conv["total_ms"] / (1e3 * dt)}
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(cfg)
-            except Exception as e:  # never lose the GPU measurement to a host-side problem
-                out["cpu_baseline"] = {"error": repr(e)}
+        if wg:
+            out["roofline_wgrad"] = {"bound": "mfma", "kernel": wtimer.kernel, "achieved": wg["tflops"], "peak": peak, "unit": "TFLOP/s",
+                                     "frac": wg["tflops"] / peak, "traffic": pmc_traffic("conv_wgrad_bf16_w8"),
+                                     "algorithmic_bytes": wg["alg_bytes"], "launches": wg["launches"], "avg_us": wg["avg_us"],
+                                     "time_share": wg["total_ms"] / (1e3 * dt)}
+        if f32_rec is not None:
+            out["f32"] = f32_rec
+        if cpu_rec is not None:
+            out["cpu_baseline"] = cpu_rec
         print(json.dumps(out), flush=True)
 
 
@@ -269,6 +442,9 @@ def main(argv=None):
     bench.py --gpus N` (the driver's form), this process IS one rank and joins that world.  Either way a world that is not exactly
     N ranks on N distinct GPUs is an error, never a silently smaller measurement."""
     args = parse_args(argv)
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline_run(args.label, args.unlabel, args.cpu_warmup, args.cpu_steps)), flush=True)
+        return
     from ubteacher.engine.launch import launch
     launch(worker, args.gpus, args=(args,))
 

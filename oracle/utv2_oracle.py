@@ -603,20 +603,32 @@ def fcos_forward(sd, images, mean, std_pix, trainable_keys=None):
 
 def fcos_semisup_step(cfg, student_sd, teacher_sd, batch, keep_rate, lam_u=3.0, lam_r=0.2, thr_cls=0.5, thr_reg=0.5,
                       lr=0.01, momentum=0.9, wd=1e-4, bufs=None, mean=None, pix_std=None, frozen_prefixes=("backbone.bottom_up.stem", "backbone.bottom_up.res2"),
-                      pseudo_override=None):
+                      pseudo_override=None, phase_times=None):
     """One post-burn-in iteration of UBTeacherTrainer.run_step_full_semisup (engine/trainer.py:212-429),
-    fp32 (no AMP).  batch = (label_q, label_k, unlabel_q, unlabel_k) lists of dicts with 'image' (+ 'gt')."""
+    fp32 (no AMP).  batch = (label_q, label_k, unlabel_q, unlabel_k) lists of dicts with 'image' (+ 'gt').
+    phase_times (optional dict): seconds per phase are ADDED to its entries (bench.py's cpu_baseline phase split)."""
+    import time as _time
+    _t = [_time.perf_counter()]
+
+    def _mark(name):
+        if phase_times is not None:
+            now = _time.perf_counter()
+            phase_times[name] = phase_times.get(name, 0.0) + now - _t[0]
+            _t[0] = now
     mean = mean if mean is not None else torch.tensor([103.53, 116.28, 123.675]).view(3, 1, 1)
     pix_std = pix_std if pix_std is not None else torch.ones(3, 1, 1)
     lq, lk, uq, uk = batch
     teacher_sd = ema_update(student_sd, teacher_sd, keep_rate)
+    _mark("ema")
     rec = {"ema_rate_1000x": keep_rate * 1000}
     with torch.no_grad():
         tl = fcos_forward(teacher_sd, [d["image"] for d in uk], mean, pix_std)
+        _mark("teacher_forward")
         det_cls = fcos_predict(cfg, *tl[:4], tl[4], tl[5], "cls")
         det_loc = fcos_predict(cfg, *tl[:4], tl[4], tl[5], "cls_n_loc")
     pseudo_cls = [threshold_bbox(d, thr_cls) for d in det_cls]
     pseudo_reg = [threshold_bbox(d, thr_reg) for d in det_loc]
+    _mark("decode_nms_threshold")
     if pseudo_override is not None:  # (mixed-precision tests: decouple the student check from teacher selection noise)
         pseudo_cls, pseudo_reg = pseudo_override
     params = {k: v.clone().requires_grad_(True) for k, v in student_sd.items()
@@ -631,6 +643,7 @@ def fcos_semisup_step(cfg, student_sd, teacher_sd, batch, keep_rate, lam_u=3.0, 
     uns, _ = fcos_pseudo_losses(cfg, *out[:4], out[4], {"cls": pseudo_cls, "reg": pseudo_reg})
     for k, v in uns.items():
         rec[k + "_pseudo"] = v
+    _mark("student_forward_losses")
     total = 0.0
     for k, v in rec.items():
         if k[:4] != "loss":
@@ -647,9 +660,11 @@ def fcos_semisup_step(cfg, student_sd, teacher_sd, batch, keep_rate, lam_u=3.0, 
             total = total + v / (lam_u + 1.0)
     grads_l = torch.autograd.grad(total, list(params.values()), allow_unused=True)
     grads = {k: (g if g is not None else torch.zeros_like(params[k])) for k, g in zip(params.keys(), grads_l)}
+    _mark("backward")
     wds = {k: (0.0 if is_norm_param(k) else wd) for k in params}
     bufs = bufs if bufs is not None else {}
     newp, bufs = sgd_step({k: v.detach() for k, v in params.items()}, grads, bufs, lr, momentum, wds)
+    _mark("sgd")
     new_student = OrderedDict(student_sd)
     new_student.update(newp)
     rec = {k: (float(v.detach()) if torch.is_tensor(v) else float(v)) for k, v in rec.items()}

@@ -31,8 +31,10 @@ def test_forward_parity():
         logits, reg, std, ctr, locs, sizes = O.fcos_forward(sd, [d["image"] for d in orac[3]],
                                                             sd["pixel_mean"], sd["pixel_std"])
     for l in range(5):
-        lo = raw["logits_pred"][l].permute(0, 3, 1, 2)
+        lo = raw["logits_pred"][l]                     # the reference's key: NCHW (a strided view of the NHWC buffer)
         bo = raw["box_pred"][l].permute(0, 3, 1, 2)
+        assert torch.equal(raw["reg_pred"][l], bo[:, :68]) and torch.equal(raw["reg_pred_std"][l], bo[:, 68:72])
+        assert torch.equal(raw["ctrness_pred"][l], bo[:, 72:73]) and raw["locations"][l].shape == (lo.shape[2] * lo.shape[3], 2)
         assert relerr(lo, logits[l]) < 1e-4
         assert relerr(bo[:, :68], reg[l]) < 1e-4
         assert relerr(bo[:, 72:73], ctr[l]) < 1e-4
@@ -304,3 +306,80 @@ def test_fcos_step_vs_reference_trainer_golden():
             np.testing.assert_allclose(pb["scores"][i][m].cpu()[order].numpy(), d["%s%d_scores" % (name, i)][ref_order], rtol=1e-3)
     check_state_fingerprints(d, "teacher", cpu_state(tr.model_teacher), 0.0, exact=True)
     check_state_fingerprints(d, "student", cpu_state(tr.model), 1e-4, rtol_update=5e-3)
+
+
+def test_raw_output_contract_and_pseudo_generator_accepts_reference_dict():
+    """The teacher's raw output carries the reference's keys (fcos/fcos.py:110-138) as per-level NCHW tensors, and
+    PseudoGenerator.nms_from_dense accepts a plain reference-style dict of such tensors: same detections as from the fused buffers.
+    process_pseudo_label's result also behaves like the reference's list[Instances]."""
+    from ubteacher.modeling import build_model
+    from ubteacher.modeling.pseudo_generator import PseudoGenerator
+    cfg = small_fcos_cfg()
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    prod, orac = make_batch(13, 2, 2, H, W, "cuda")
+    sd = tune_state_for_pseudo_labels(cpu_state(model), [d["image"] for d in orac[3]])
+    model.load_state_dict(sd)
+    model.eval()
+    with torch.no_grad():
+        dets, raw = model(prod[3], output_raw=True, nms_method="cls", branch="teacher_weak")
+    for k in ("logits_pred", "reg_pred", "reg_pred_std", "top_feats", "bbox_towers", "locations", "ctrness_pred", "image_sizes"):
+        assert k in raw, k
+    assert raw["logits_pred"][0].shape[:2] == (2, 80) and raw["reg_pred"][0].shape[1] == 68 and raw["ctrness_pred"][0].shape[1] == 1
+    pg = PseudoGenerator(cfg)
+    pg.fcos_output.training = False
+    mine = pg.nms_from_dense(raw, "cls_n_loc")
+    plain = {k: [t.clone() for t in raw[k]] for k in ("logits_pred", "reg_pred", "reg_pred_std", "ctrness_pred")}
+    plain.update(top_feats=[], locations=raw["locations"], image_sizes=raw["image_sizes"])
+    ref_style = pg.nms_from_dense(plain, "cls_n_loc")
+    for k in ("boxes", "scores", "classes", "valid"):
+        assert torch.equal(mine[k], ref_style[k]), k
+    pseudo, num = pg.process_pseudo_label(mine, 0.3, "roih", "thresholding")
+    assert len(pseudo) == 2
+    inst = pseudo[0]                                   # reference return type: Instances with gt_boxes / gt_classes / scores
+    m = pseudo["valid"][0].bool()
+    assert len(inst) == int(m.sum()) and torch.equal(inst.gt_boxes.tensor, pseudo["boxes"][0][m])
+    assert torch.equal(inst.scores, pseudo["scores"][0][m]) and inst.has("reg_pred_std")
+    assert [len(x) for x in pseudo] == [int(v.sum()) for v in pseudo["valid"].bool()]
+    assert dets[0].has("pred_boxes") and len(dets) == 2
+
+
+def test_checkpoint_roundtrip_on_device_arena(tmp_path):
+    """SURVEY 8f rank 2 on the GPU: train a step, save the teacher/student checkpoint (arena -> reference-named CPU tensors), resume in a
+    FRESH trainer (CPU tensors -> device arenas, momentum, scheduler, iteration) and take the next step in both: bit-identical
+    students, teachers and losses."""
+    from ubteacher.engine import UBTeacherTrainer
+
+    def fresh(out_dir):
+        cfg = small_fcos_cfg()
+        cfg.OUTPUT_DIR = str(out_dir)
+        torch.manual_seed(0)
+        prod, orac = make_batch(12, 2, 2, H, W, "cuda")
+        tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+        return tr, orac
+    a, orac = fresh(tmp_path / "a")
+    sd_s = tune_state_for_pseudo_labels(cpu_state(a.model), [d["image"] for d in orac[3]])
+    a.model.load_state_dict(sd_s)
+    a.model_teacher.load_state_dict(sd_s)
+    a.iter = 1
+    a.optimizer.param_groups[0]["lr"] = 0.01
+    a.run_step_full_semisup()
+    a.scheduler.step()
+    a.checkpointer.save("model_0000001", iteration=1)
+    a.iter = 2
+    a.run_step_full_semisup()
+    rec_a = a.flush_metrics()
+    b, _ = fresh(tmp_path / "a")          # same OUTPUT_DIR: resume picks the checkpoint up
+    b.resume_or_load(resume=True)
+    assert b.start_iter == 2 and b.scheduler.last_iter == a.scheduler.last_iter
+    b.optimizer.param_groups[0]["lr"] = a.optimizer.param_groups[0]["lr"]
+    b.iter = 2
+    b.run_step_full_semisup()
+    rec_b = b.flush_metrics()
+    torch.cuda.synchronize()
+    assert torch.equal(a.model.flat_state(), b.model.flat_state())
+    assert torch.equal(a.model_teacher.flat_state(), b.model_teacher.flat_state())
+    assert torch.equal(a.model.store.mom, b.model.store.mom)
+    for k, v in rec_a.items():
+        if k != "data_time":
+            assert rec_b[k] == v, k

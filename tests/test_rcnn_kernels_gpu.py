@@ -205,3 +205,23 @@ def test_roi_align_bf16_io():
     hip.roi_align_bwd(d16, scales, 2, rois, batch, valid, dy)
     for a, b in zip(d16, d32):   # fp32 atomics: the summation order differs between launches
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max() + 1e-6)
+
+
+def test_box_iou_and_add_entry_points():
+    """utv2_box_iou (D2 pairwise_iou [D2-recall]) against the oracle's restatement, including degenerate and disjoint boxes;
+    utv2_add bit-exact against a + b."""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(3)
+    xy = torch.rand(37, 2, generator=g) * 100
+    a = torch.cat([xy, xy + torch.rand(37, 2, generator=g) * 60], 1)
+    xy = torch.rand(53, 2, generator=g) * 100
+    b = torch.cat([xy, xy + torch.rand(53, 2, generator=g) * 60], 1)
+    a[0] = torch.tensor([5.0, 5.0, 5.0, 9.0])          # zero area
+    b[1] = torch.tensor([500.0, 500.0, 510.0, 510.0])  # disjoint from everything
+    b[2] = a[3]                                         # identical
+    got = hip.box_iou(a.cuda(), b.cuda()).cpu()
+    ref = O.pairwise_iou(a, b)
+    assert got.shape == ref.shape and float((got - ref).abs().max()) < 1e-6
+    assert float(got[3, 2]) == 1.0 and float(got[:, 1].max()) == 0.0
+    x, y = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    assert torch.equal(hip.add(x.cuda(), y.cuda()).cpu(), x + y)

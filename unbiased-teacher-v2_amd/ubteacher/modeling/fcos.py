@@ -36,10 +36,23 @@ class PaddedBoxes:
         self.f = fields  # boxes [N,M,4], classes [N,M] int32, valid [N,M] uint8, scores, reg_pred_std, ...
 
     def __getitem__(self, k):
+        """field name -> batched padded tensor; image index -> reference-style Instances of that image (the return type of the
+        reference's predict_proposals / process_pseudo_label is list[Instances]: `out[0].gt_boxes` keeps working, at the price of a
+        device sync - the trainers only use the batched form)"""
+        if isinstance(k, int):
+            return self.to_instances(as_gt=self.as_gt)[k]
         return self.f[k]
 
     def __contains__(self, k):
         return k in self.f
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        return iter(self.to_instances(as_gt=self.as_gt))
+
+    as_gt = False   # True once thresholded into pseudo ground truth (gt_boxes / gt_classes instead of pred_boxes / pred_classes)
 
     @property
     def n(self):
@@ -67,7 +80,9 @@ class PaddedBoxes:
             keep = (self.f["cls_confid"] > thr) & (self.f["centerness"] > ctr_thr)
         out = dict(self.f)
         out["valid"] = (self.f["valid"].bool() & keep).to(torch.uint8)
-        return PaddedBoxes(self.image_sizes, **out)
+        res = PaddedBoxes(self.image_sizes, **out)
+        res.as_gt = True
+        return res
 
     def to_instances(self, as_gt=False):
         """Materialise reference-style Instances (forces a device sync; API compatibility only)."""
@@ -122,6 +137,50 @@ def compute_locations(h, w, stride, device):
     sy = torch.arange(0, h * stride, step=stride, dtype=torch.float32, device=device)
     yy, xx = torch.meshgrid(sy, sx, indexing="ij")
     return torch.stack((xx.reshape(-1), yy.reshape(-1)), dim=1) + stride // 2
+
+
+class RawOutput(dict):
+    """The reference's `raw_output` dict (modeling/fcos/fcos.py:110-138): `logits_pred`, `reg_pred`, `reg_pred_std`, `ctrness_pred` as
+    per-level NCHW tensors, `top_feats`, `bbox_towers`, `locations`, `image_sizes`.  The NCHW tensors are zero-copy strided views of
+    the fused level-first NHWC buffers, built on first access (the trainers never touch them: PseudoGenerator.nms_from_dense reads
+    `head_out` / `level_hw`, which ride along as extra keys; `box_pred` = the fused bbox | std | ctrness buffer per level, NHWC)."""
+
+    _LAZY = ("logits_pred", "reg_pred", "reg_pred_std", "ctrness_pred", "top_feats", "bbox_towers", "locations", "box_pred")
+
+    def __init__(self, head_out, level_hw, image_sizes, strides, reg_max):
+        super().__init__(head_out=head_out, level_hw=level_hw, image_sizes=image_sizes)
+        self._strides, self._nreg = list(strides), 4 * (reg_max + 1)
+
+    def __missing__(self, key):
+        if key not in self._LAZY:
+            raise KeyError(key)
+        ho, hw = dict.__getitem__(self, "head_out"), dict.__getitem__(self, "level_hw")
+        meta, L, R = ho["meta"], len(hw), self._nreg
+
+        def nchw(buf, c0, c1):
+            return [meta.level_view(buf, l)[..., c0:c1].permute(0, 3, 1, 2) for l in range(L)]
+        if key == "logits_pred":
+            v = nchw(ho["logits"], 0, ho["logits"].shape[1])
+        elif key == "reg_pred":
+            v = nchw(ho["box"], 0, R)
+        elif key == "reg_pred_std":
+            v = nchw(ho["box"], R, R + 4)
+        elif key == "ctrness_pred":
+            v = nchw(ho["box"], R + 4, R + 5)
+        elif key == "box_pred":
+            v = [meta.level_view(ho["box"], l) for l in range(L)]
+        elif key == "locations":
+            v = [compute_locations(h, w, s, ho["logits"].device) for (h, w), s in zip(hw, self._strides)]
+        else:  # top_feats (no top module), bbox_towers (YIELD_PROPOSAL False in every shipped config)
+            v = []
+        self[key] = v
+        return v
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._LAZY
+
+    def keys(self):
+        return list(dict.keys(self)) + [k for k in self._LAZY if not dict.__contains__(self, k)]
 
 
 class FCOSHead:
@@ -462,9 +521,7 @@ class FCOS:
             meta = ops.LevelMeta(feats[0].shape[0], level_hw)
             big = torch.cat([f.reshape(-1, f.shape[-1]) for f in feats], dim=0)
         head_out = self.fcos_head(big, meta)
-        raw_output = {"head_out": head_out, "level_hw": level_hw, "image_sizes": image_sizes,
-                      "logits_pred": [meta.level_view(head_out["logits"], l) for l in range(len(level_hw))],
-                      "box_pred": [meta.level_view(head_out["box"], l) for l in range(len(level_hw))]}
+        raw_output = RawOutput(head_out, level_hw, image_sizes, self.fpn_strides, self.fcos_outputs.reg_max)
         results = {}
         if self.training:
             if ignore_near:
