@@ -225,3 +225,28 @@ def test_box_iou_and_add_entry_points():
     assert float(got[3, 2]) == 1.0 and float(got[:, 1].max()) == 0.0
     x, y = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
     assert torch.equal(hip.add(x.cuda(), y.cuda()).cpu(), x + y)
+
+
+def test_rpn_pre_nms_topk_radix_select_equals_torch_topk():
+    """PseudoLabRPN._pre_nms_topk (one utv2_topk_rows_i64 call for all levels and images) returns exactly the anchor indices of the
+    per-level torch.topk on (score desc, index asc) keys - negative logits, ties and levels narrower than PRE_NMS_TOPK included."""
+    from ubteacher import ops
+    from ubteacher.modeling.rcnn import RPN_CH, float_order_key
+    from ubteacher.modeling import build_model
+    from ubteacher.presets import get_config
+    cfg = get_config("rcnn", 1, ["MODEL.DEVICE", "cuda"])
+    torch.manual_seed(0)
+    rpn = build_model(cfg).proposal_generator
+    N, hw = 3, [(40, 56), (20, 28), (10, 14), (5, 7), (3, 4)]
+    meta = ops.LevelMeta(N, hw)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    big = torch.randn(meta.P, RPN_CH, device="cuda", generator=g) * 3
+    big[:, :3] = torch.round(big[:, :3] * 4) / 4            # many exact ties
+    top = rpn._pre_nms_topk(big, N, hw)
+    obj, _ = rpn._per_image_views(big, N, hw)
+    pre = rpn.pre_nms_topk[rpn.training]
+    for l, o in enumerate(obj):
+        k = min(pre, o.shape[1])
+        ref = torch.topk(float_order_key(o), k, dim=1, sorted=True).values
+        ref_idx = 4294967295 - (ref & 4294967295)
+        assert torch.equal(top[l], ref_idx), l

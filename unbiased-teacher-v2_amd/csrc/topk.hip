@@ -44,12 +44,23 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const long long* __restr
   const int hi = shift + bits;  // bits >= hi are decided
   for (int i = threadIdx.x; i < TK_BINS; i += blockDim.x) lh[i] = 0u;
   __syncthreads();
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < width; i += (long long)gridDim.x * blockDim.x) {
-    const long long key = keys[base + i];
-    if (key < 0) continue;
-    const unsigned long long u = (unsigned long long)key;
-    if (hi < 64 && (u >> hi) != (prefix >> hi)) continue;
-    atomicAdd(&lh[(u >> shift) & ((1u << bits) - 1u)], 1u);
+  for (long long i0 = (long long)blockIdx.x * blockDim.x; i0 < width; i0 += (long long)gridDim.x * blockDim.x) {
+    const long long i = i0 + threadIdx.x;
+    int bin = -1;
+    if (i < width) {
+      const long long key = keys[base + i];
+      const unsigned long long u = (unsigned long long)key;
+      if (key >= 0 && !(hi < 64 && (u >> hi) != (prefix >> hi))) bin = (int)((u >> shift) & ((1u << bits) - 1u));
+    }
+    // DENSE rows (every anchor of an RPN level is a candidate) put a whole wave into one or two bins of the leading digits: the lanes
+    // that share the first active lane's bin are counted by ONE atomic (64 same-address LDS atomics serialise), the rest one by one
+    const unsigned long long act = __ballot(bin >= 0);
+    if (act) {
+      const int lead = __builtin_amdgcn_readfirstlane(__shfl(bin, __ffsll((long long)act) - 1, 64));
+      const unsigned long long same = __ballot(bin == lead);
+      if ((threadIdx.x & 63) == __ffsll((long long)same) - 1) atomicAdd(&lh[lead], (unsigned)__popcll(same));
+      if (bin >= 0 && bin != lead) atomicAdd(&lh[bin], 1u);
+    }
   }
   __syncthreads();
   unsigned* h = hist + (size_t)row * TK_BINS;

@@ -215,8 +215,44 @@ class PseudoLabRPN:
             losses = {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}  # applied twice
         with torch.no_grad():
             obj, dl = self._per_image_views(big.detach(), N, hw)
-            proposals = self.predict_proposals(anchors, obj, dl, image_sizes)
+            proposals = self.predict_proposals(anchors, obj, dl, image_sizes, top_idx=self._pre_nms_topk(big.detach(), N, hw))
         return proposals, losses
+
+    @torch.no_grad()
+    def _pre_nms_topk(self, big, N, hw):
+        """D2 find_top_rpn_proposals' per-(image, level) `topk(pre_nms_topk)` for all levels and images by ONE exact radix select
+        (utv2_topk_rows_i64; torch.topk per level costs ~70 launches per forward): the objectness of the level-first head output
+        becomes one flat buffer of sortable keys whose ragged rows are the (level, image) pairs.  Returns per level the anchor
+        indices [N, k_l] in (score desc, index asc) order - the order torch.topk on float_order_key gives - or None when
+        PRE_NMS_TOPK exceeds the kernel's 2048."""
+        pre = self.pre_nms_topk[self.training]
+        A = self.A
+        widths = [h * w * A for (h, w) in hw]
+        ks = [min(pre, wd) for wd in widths]
+        if max(ks) > 2048:
+            return None
+        dev = big.device
+        ck = (N, tuple(hw), str(dev))
+        geom = self.__dict__.setdefault("_topk_geom", {})   # one entry per batch geometry (teacher / labeled / unlabeled batches differ)
+        cached = geom.get(ck)
+        if cached is None:
+            offs, idx, o = [], [], 0
+            for wd in widths:
+                for n in range(N):
+                    offs.append(o + n * wd)
+                idx.append(torch.arange(wd, dtype=torch.int64, device=dev).repeat(N))
+                o += N * wd
+            offs.append(o)
+            if len(geom) >= 16:
+                geom.clear()
+            cached = geom[ck] = (torch.tensor(offs, dtype=torch.int64, device=dev), 2147483647 - torch.cat(idx))
+        row_off, inv_idx = cached
+        x = big[:, :A].reshape(-1).contiguous()                       # (level, image, hw, anchor): the rows in memory order
+        i = x.view(torch.int32)
+        mono = (i ^ ((i >> 31) & 0x7FFFFFFF)).long() + 2147483648     # order-preserving, in [0, 2^32)
+        keys = mono * 2147483648 + inv_idx                            # 63-bit non-negative keys (the kernel's negative = empty)
+        top = hip.topk_rows(keys, row_off, len(hw) * N, max(widths), max(ks))
+        return [2147483647 - (top[l * N:(l + 1) * N, :ks[l]] & 2147483647) for l in range(len(hw))]
 
     __call__ = forward
 
@@ -273,15 +309,18 @@ class PseudoLabRPN:
 
     # -- proposals (D2 find_top_rpn_proposals) -----------------------------------------------------------
     @torch.no_grad()
-    def predict_proposals(self, anchors, obj, deltas, image_sizes):
+    def predict_proposals(self, anchors, obj, deltas, image_sizes, top_idx=None):
         N = obj[0].shape[0]
         dev = obj[0].device
         pre, post = self.pre_nms_topk[self.training], self.post_nms_topk[self.training]
         boxes, scores, lvls = [], [], []
         for l, (a, o, d) in enumerate(zip(anchors, obj, deltas)):
             k = min(pre, o.shape[1])
-            top = torch.topk(float_order_key(o), k, dim=1, sorted=True).values
-            idx = 4294967295 - (top & 4294967295)
+            if top_idx is not None:
+                idx = top_idx[l]
+            else:
+                top = torch.topk(float_order_key(o), k, dim=1, sorted=True).values
+                idx = 4294967295 - (top & 4294967295)
             sc = torch.gather(o, 1, idx)
             bx = rpn_apply_deltas(torch.gather(d, 1, idx[:, :, None].expand(-1, -1, 4)), a[idx], self.box_weights)
             boxes.append(bx); scores.append(sc)
