@@ -51,6 +51,27 @@ def tune_for_pseudo_labels(trainer, batch, target_std=1.5, bias=-6.0):
     m.store.touch()  # weights were edited in place: invalidate the bf16 mirror
 
 
+def tune_rcnn_for_pseudo_labels(trainer, batch, target_std=2.5, bg_bias=3.0):
+    """Faster-RCNN counterpart: a random-init R50 has no normalised features, the class scores are flat; rescale the predictor's
+    cls_score (data-driven, with the product's own teacher forward) so the teacher emits some confident detections above
+    BBOX_THRESHOLD and the pseudo-label branch of the step does real work."""
+    m = trainer.model
+    sd = m.state_dict()
+    w, b = sd["roi_heads.box_predictor.cls_score.weight"], sd["roi_heads.box_predictor.cls_score.bias"]
+    g = torch.Generator(device="cpu").manual_seed(0)
+    w.copy_((torch.randn(w.shape, generator=g) * 0.01).to(w.device))
+    b.zero_()
+    m.store.touch()
+    with torch.no_grad():
+        _, _, _, preds = m(batch[3], branch="unsup_data_weak")
+        s = preds[0].float().std()
+    w.mul_(target_std / s.clamp(min=1e-12))
+    b[-1] = bg_bias
+    m.store.touch()
+    trainer._update_teacher_model(keep_rate=0.0)  # teacher := student
+    m.store.touch()
+
+
 class ConvTimer:
     """HIP-event timing (torch events recorded on the stream the kernels are launched on) of every launch of the
     dominant kernel inside the timed region.  Dominant kernel (largest share of GPU time in profiles/): the multi-level
@@ -248,6 +269,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-images", type=int, default=1, help="labeled and unlabeled images of the CPU baseline sample (SURVEY 8d protocol: 2)")
     ap.add_argument("--no-f32", action="store_true", help="skip the f32 sub-record / the bf16-vs-f32 one-step loss deviation")
+    ap.add_argument("--model", choices=["fcos", "rcnn"], default="fcos",
+                    help="fcos: BASELINE configs[1] (the headline workload); rcnn: the Faster-RCNN UTv2 trainer of configs[2] / [4] on the same "
+                         "per-GPU batch (its shipped configs run fp32: --dtype f32; configs[4] is the bf16 MFMA path)")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
                     help="conv arithmetic: bf16 = the config's SOLVER.AMP.ENABLED path (bf16 MFMA, fp32 accumulate); f32 = exact-f32 MFMA")
     return ap.parse_args(argv)
@@ -279,20 +303,21 @@ def worker(args):
                                                          "launcher": _launcher_name(world)}}), flush=True)
         return
 
-    from ubteacher.engine import UBTeacherTrainer
+    from ubteacher.engine import UBRCNNTeacherTrainer, UBTeacherTrainer
     from ubteacher.presets import get_config
     from ubteacher import hip, ops
     hip.load()
+    rcnn = args.model == "rcnn"
     cpu_rec = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # before any GPU work, in its own process
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not rcnn:   # before any GPU work, in its own process
         cpu_rec = cpu_baseline(args.cpu_images, args.cpu_images, args.cpu_warmup, args.cpu_steps)
 
     def make_trainer(dtype):
-        cfg = get_config("fcos", 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label * world, "SOLVER.IMG_PER_BATCH_UNLABEL",
-                                     args.unlabel * world, "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", dtype == "bf16",
-                                     "MODEL.DEVICE", "cuda:%d" % device_index])
+        cfg = get_config(args.model, 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label * world, "SOLVER.IMG_PER_BATCH_UNLABEL",
+                                         args.unlabel * world, "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", dtype == "bf16",
+                                         "MODEL.DEVICE", "cuda:%d" % device_index])
         torch.manual_seed(0)
-        t = UBTeacherTrainer(cfg)
+        t = (UBRCNNTeacherTrainer if rcnn else UBTeacherTrainer)(cfg)
         t.iter = 1
         t.log_period = 10 ** 9
         return t
@@ -305,9 +330,9 @@ def worker(args):
     calls.install()
     tr = make_trainer(args.dtype)
     batch = tr._data_loader.batches[0]
-    tune_for_pseudo_labels(tr, batch)
+    (tune_rcnn_for_pseudo_labels if rcnn else tune_for_pseudo_labels)(tr, batch)
     tr.sync_replicas()   # identical students / teachers on every rank (DDP broadcasts rank 0's parameters at construction)
-    parity = rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_f32
+    parity = rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_f32 and not rcnn
     if parity:
         s0, t0 = tr.model.flat_state().clone(), tr.model_teacher.flat_state().clone()
     first = None
@@ -345,7 +370,7 @@ def worker(args):
     conv, wg = timer.summary(), wtimer.summary()
 
     host_ms = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not rcnn:
         # host cost of one step: the same trainer code on 96 x 128 images, where the GPU work is negligible and the step time IS the
         # Python / launch overhead (on the 1333 x 800 batch the host runs ahead until the launch queue is full, so its enqueue time
         # only mirrors the GPU time)
@@ -407,8 +432,10 @@ def worker(args):
             "value": per_step_images * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "FCOS R50-FPN UTv2 sup1 (configs[1]): %d labeled + %d unlabeled 1333x800 images per GPU, "
-                                   "post-burn-in semi-supervised step" % (args.label, args.unlabel),
+            "config": {"workload": ("Faster-RCNN R50-FPN UTv2 sup1 (the trainer of configs[2] / [4]): %d labeled + %d unlabeled 1333x800 images "
+                                    "per GPU, post-burn-in semi-supervised step" if rcnn else
+                                    "FCOS R50-FPN UTv2 sup1 (configs[1]): %d labeled + %d unlabeled 1333x800 images per GPU, "
+                                    "post-burn-in semi-supervised step") % (args.label, args.unlabel),
                        "global_batch": per_step_images, "parallelism": "dp%d" % world,
                        "precision": "AMP (config SOLVER.AMP.ENABLED): bf16 MFMA operands, bf16 activations and activation gradients in HBM, fp32 accumulate / losses / weight gradients / master weights" if args.dtype == "bf16" else "fp32 MFMA, fp32 everywhere"},
             "ranks": {"world_size": world, "backend": info["backend"], "devices": devices,
@@ -418,7 +445,8 @@ def worker(args):
             "losses": {k: v for k, v in metrics.items() if k.startswith("loss") or k.startswith("teacher")},
         }
         if conv:
-            out["roofline"] = {"bound": "mfma", "kernel": timer.kernel + " (FCOS tower 3x3 convs, all fwd+dgrad launches)",
+            out["roofline"] = {"bound": "mfma", "kernel": timer.kernel + (" (RPN head 3x3 conv over p2-p6, fwd+dgrad launches)" if rcnn else
+                                                                         " (FCOS tower 3x3 convs, all fwd+dgrad launches)"),
                                "achieved": conv["tflops"], "peak": peak, "unit": "TFLOP/s",
                                "frac": conv["tflops"] / peak, "traffic": pmc_traffic(timer.kernel),
                                "algorithmic_bytes": conv["alg_bytes"], "algorithmic_GBps": conv["alg_gbps"],

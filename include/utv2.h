@@ -215,6 +215,12 @@ int utv2_roi_align_fwd(int num_levels, int min_level, const void* const* feats_h
 int utv2_roi_align_bwd(int num_levels, int min_level, float* const* dfeats_host, const int* H_host, const int* W_host,
                        const float* scales_host, const float* rois, const int* roi_batch, const unsigned char* roi_valid,
                        int R, int C, int PH, int PW, const void* dy, int dtype, utv2_stream_t stream);
+/* the same gradient as a deterministic gather over 8 x 8 pixel tiles (no atomics; the backward of the ROIPooler call at
+ * roi_heads/roi_heads.py:118): the ROIs of image n are rois[n*rois_per_image .. (n+1)*rois_per_image), C <= 256, PH, PW <= 7;
+ * every element of every dfeats[l] ([N][H_l][W_l][C], element type out_dtype) is written - no zero-fill, no fp32 staging */
+int utv2_roi_align_bwd_tiled(int num_levels, int min_level, void* const* dfeats_host, const int* H_host, const int* W_host,
+                             const float* scales_host, const float* rois, const unsigned char* roi_valid, int N, int rois_per_image,
+                             int C, int PH, int PW, const void* dy, int dy_dtype, int out_dtype, utv2_stream_t stream);
 /* roi_heads/fast_rcnn.py:925-936 + FocalLoss :1405-1429 (softmax CE focal, gamma 1.5), summed */
 int utv2_softmax_focal_fwd(const float* logits, const int* target, int R, int C, float gamma, float* loss_sum, float* ws,
                            utv2_stream_t stream);

@@ -250,3 +250,54 @@ def test_rpn_pre_nms_topk_radix_select_equals_torch_topk():
         ref = torch.topk(float_order_key(o), k, dim=1, sorted=True).values
         ref_idx = 4294967295 - (ref & 4294967295)
         assert torch.equal(top[l], ref_idx), l
+
+
+def test_roi_align_bwd_tiled_gather_equals_scatter_and_is_deterministic():
+    """utv2_roi_align_bwd_tiled (the deterministic gather over 8 x 8 pixel tiles the ROI heads' backward runs) against the atomic
+    scatter kernel and, through autograd, against the oracle: ROIs image by image (P slots each, some invalid), boxes that stick out of
+    the image, elongated boxes with many samples per bin, all four levels; bit-identical between runs; bf16 in / out forms."""
+    from ubteacher import hip, ops
+    g = torch.Generator().manual_seed(33)
+    N, P, C = 3, 40, 256
+    shapes = [(N, 50, 64, C), (N, 25, 32, C), (N, 13, 16, C), (N, 7, 8, C)]
+    x1 = torch.rand(N * P, generator=g) * 220 - 10; y1 = torch.rand(N * P, generator=g) * 170 - 10
+    wh = torch.exp(torch.rand(N * P, 2, generator=g) * 5.0 + 0.5)
+    rois = torch.stack((x1, y1, x1 + wh[:, 0], y1 + wh[:, 1]), 1)
+    rois[0] = torch.tensor([-300.0, -200.0, 500.0, 460.0])    # far outside on every side, large enough for the coarsest level
+    rois[1] = torch.tensor([5.0, 3.0, 9.0, 190.0])            # tall and thin: many samples per bin row
+    rois[2] = torch.tensor([2.0, 100.0, 250.0, 104.0])        # wide and flat
+    rois[3] = torch.tensor([255.5, 199.5, 256.0, 200.0])      # at the far corner
+    rois[4] = torch.tensor([-40.0, -40.0, 260.0, 240.0])      # sqrt(area) in [224, 448): the third level
+    rois = rois.cuda()
+    valid = (torch.rand(N * P, generator=g) > 0.15).to(torch.uint8).cuda()
+    valid[:5] = 1
+    batch = torch.arange(N, dtype=torch.int32).repeat_interleave(P).cuda()
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    dy = torch.randn(N * P, 7, 7, C, generator=g).cuda()
+    ref = [torch.zeros(s, device="cuda") for s in shapes]
+    hip.roi_align_bwd(ref, scales, 2, rois, batch, valid, dy)
+    got = hip.roi_align_bwd_tiled(shapes, torch.float32, scales, 2, rois, valid, dy, P)
+    again = hip.roi_align_bwd_tiled(shapes, torch.float32, scales, 2, rois, valid, dy, P)
+    for a, b, c in zip(got, ref, again):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max() + 1e-6)
+        assert torch.equal(a, c)                                # deterministic
+    assert all(float(b.abs().max()) > 0 for b in ref)          # every level is exercised
+    # bf16 dy / bf16 gradient maps: the fp32 result of the bf16 dy, rounded once
+    dy16 = dy.to(torch.bfloat16)
+    g32 = hip.roi_align_bwd_tiled(shapes, torch.float32, scales, 2, rois, valid, dy16.float(), P)
+    g16 = hip.roi_align_bwd_tiled(shapes, torch.bfloat16, scales, 2, rois, valid, dy16, P)
+    for a, b in zip(g16, g32):
+        assert a.dtype == torch.bfloat16 and torch.equal(a, b.to(torch.bfloat16))
+    # through autograd (the product's path) against the oracle's autograd
+    feats = [torch.randn(N, C, s[1], s[2], generator=g) * 0.5 for s in shapes]
+    fr = [f.clone().requires_grad_(True) for f in feats]
+    rc, vc = rois.cpu(), valid.cpu().bool()
+    outs = [O.roi_pool([f[n:n + 1] for f in fr], [rc[n * P + i:n * P + i + 1]]) for n in range(N) for i in range(P)]
+    refy = torch.cat(outs)
+    dyc = dy.cpu().permute(0, 3, 1, 2) * vc[:, None, None, None]
+    refy.backward(dyc)
+    fh = [f.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True) for f in feats]
+    y = ops.roi_align(fh, scales, 2, rois, batch, valid, 7, rois_per_image=P)
+    y.backward(dy)
+    for a, b in zip(fh, fr):
+        close(a.grad.permute(0, 3, 1, 2), b.grad, rtol=1e-3, atol=2e-5)

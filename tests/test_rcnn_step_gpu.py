@@ -330,3 +330,21 @@ def test_rcnn_step_bf16_vs_rounding_oracle():
     t_after = cpu_state(tr.model_teacher)
     for k in new_t:
         assert torch.equal(t_after[k], new_t[k]), k
+
+
+def test_rcnn_step_is_bit_deterministic():
+    """Two identical Faster-RCNN UTv2 steps (same weights, batch and sampling keys) end in bit-identical students and teachers: every
+    kernel on the path is deterministic now that the RoIAlign backward is a gather (it was an fp32 atomic scatter) - what data-parallel
+    replicas rely on to stay in lock step."""
+    states = []
+    for _ in range(2):
+        d, cfg, tr, orac, sd_s, sd_t, K, mean, pstd = _golden_setup(amp=True)
+        try:
+            tr.run_step_full_semisup()
+            torch.cuda.synchronize()
+            states.append((tr.model.flat_state().clone(), tr.model_teacher.flat_state().clone(), tr.model.store.grad.clone()))
+        finally:
+            from ubteacher import ops
+            ops.set_precision("fp32")
+    assert torch.equal(states[0][2], states[1][2])      # gradients
+    assert torch.equal(states[0][0], states[1][0]) and torch.equal(states[0][1], states[1][1])

@@ -539,6 +539,19 @@ def roi_align_bwd(dfeats, scales, min_level, rois, roi_batch, roi_valid, dy):
          ctypes.cast(S, c_p), _p(rois), _p(roi_batch), _p(roi_valid), R, C, PH, PW, _p(dy), _dt(dy), _stream())
 
 
+def roi_align_bwd_tiled(shapes, out_dtype, scales, min_level, rois, roi_valid, dy, rois_per_image):
+    """deterministic gather form: returns the per-level gradient maps (every element written by the kernel)"""
+    R, PH, PW, C = dy.shape
+    N = shapes[0][0]
+    assert R == N * rois_per_image
+    dfeats = [torch.empty(s, dtype=out_dtype, device=dy.device) for s in shapes]
+    fp = _ptr_array(dfeats)
+    H = _iarr([s[1] for s in shapes]); W = _iarr([s[2] for s in shapes]); S = _farr(scales)
+    call("utv2_roi_align_bwd_tiled", len(dfeats), min_level, ctypes.cast(fp, c_p), ctypes.cast(H, c_p), ctypes.cast(W, c_p),
+         ctypes.cast(S, c_p), _p(rois), _p(roi_valid), N, rois_per_image, C, PH, PW, _p(dy), _dt(dy), _dt(dfeats[0]), _stream())
+    return dfeats
+
+
 def softmax_focal_fwd(logits, target, gamma):
     R, C = logits.shape
     out = torch.empty(1, dtype=torch.float32, device=logits.device)

@@ -555,7 +555,7 @@ class StandardROIHeadsPseudoLab:
         N, P = valid.shape
         rois = boxes.reshape(-1, 4).contiguous()
         batch = torch.arange(N, device=rois.device, dtype=torch.int32)[:, None].expand(N, P).reshape(-1).contiguous()
-        x = ops.roi_align(feats, self.scales, self.min_level, rois, batch, valid.reshape(-1).contiguous(), self.res)
+        x = ops.roi_align(feats, self.scales, self.min_level, rois, batch, valid.reshape(-1).contiguous(), self.res, rois_per_image=P)
         x = x.view(x.shape[0], 1, 1, -1)
         for fc in self.fcs:
             x = fc(x)

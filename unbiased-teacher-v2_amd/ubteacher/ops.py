@@ -576,8 +576,9 @@ def assemble(big, rows, levels):
 class _RoIAlignFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rois, roi_batch, roi_valid, cfg, *feats):
-        scales, min_level, out_size = cfg
-        ctx.cfg = cfg
+        scales, min_level, out_size, per_image = cfg
+        ctx.cfg = cfg[:3]
+        ctx.per_image = per_image
         ctx.shapes = [tuple(f.shape) for f in feats]
         ctx.fdtype = feats[0].dtype
         ctx.save_for_backward(rois, roi_batch, roi_valid)
@@ -587,6 +588,12 @@ class _RoIAlignFn(torch.autograd.Function):
     def backward(ctx, dy):
         rois, roi_batch, roi_valid = ctx.saved_tensors
         scales, min_level, out_size = ctx.cfg
+        N, C = ctx.shapes[0][0], ctx.shapes[0][3]
+        R = rois.shape[0]
+        if ctx.per_image > 0 and R == N * ctx.per_image and C <= 256 and out_size <= 7:
+            # ROIs laid out image by image (the ROI heads' [N, P] slots): deterministic gather, final dtype written directly
+            dfeats = hip.roi_align_bwd_tiled(ctx.shapes, ctx.fdtype, scales, min_level, rois, roi_valid, dy.contiguous(), ctx.per_image)
+            return (None, None, None, None) + tuple(dfeats)
         dfeats = [torch.zeros(s, dtype=torch.float32, device=dy.device) for s in ctx.shapes]   # fp32: atomics
         hip.roi_align_bwd(dfeats, scales, min_level, rois, roi_batch, roi_valid, dy.contiguous())
         if ctx.fdtype != torch.float32:
@@ -594,9 +601,11 @@ class _RoIAlignFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(dfeats)
 
 
-def roi_align(feats, scales, min_level, rois, roi_batch, roi_valid, out_size):
+def roi_align(feats, scales, min_level, rois, roi_batch, roi_valid, out_size, rois_per_image=0):
+    """rois_per_image > 0: the caller guarantees roi_batch == repeat_interleave(arange(N), rois_per_image) (the backward then runs as
+    the deterministic tiled gather instead of the atomic scatter)"""
     if torch.is_grad_enabled() and any(f.requires_grad for f in feats):
-        return _RoIAlignFn.apply(rois, roi_batch, roi_valid, (tuple(scales), min_level, out_size), *feats)
+        return _RoIAlignFn.apply(rois, roi_batch, roi_valid, (tuple(scales), min_level, out_size, int(rois_per_image)), *feats)
     return hip.roi_align_fwd(list(feats), scales, min_level, rois, roi_batch, roi_valid, out_size)
 
 
