@@ -1,11 +1,15 @@
-"""profiles/<tag>_traffic.json from the FETCH_SIZE / WRITE_SIZE PMC summaries (tools/rocpd_pmc.py output) for the dominant launch of
-bench.py: the FCOS tower conv = conv_igemm_bf16_w8<true,__bf16> (whole rounds of 256x256 tiles) + conv_igemm_bf16_v2<128,true,64,__bf16>
-(remaining rows), one of each per launch.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: 16-byte-per-lane reads are under-counted 2x on
-gfx950).  usage: make_traffic.py FETCH.txt WRITE.txt OUT.json"""
+"""profiles/<tag>_traffic.json from the FETCH_SIZE / WRITE_SIZE PMC summaries (tools/rocpd_pmc.py output) and the kernel-trace summary
+(tools/rocpd_stats.py output) of one command.  FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: 16-byte-per-lane reads are
+counted at half their bytes on gfx950; our own gn_apply_relu, which reads exactly what it writes, shows FETCH = WRITE / 2).  Per kernel:
+HBM bytes per launch = 2 * FETCH + WRITE, GB/s = bytes / the kernel-trace average duration (the PMC passes themselves run slower).
+Two aggregate keys are what bench.py reads: the FCOS tower conv launch (conv_igemm_bf16_w8<true> on whole rounds of 256 x 256 tiles +
+conv_igemm_bf16_v2<128,true,64> on the remaining rows: one of each per launch) and the tower weight gradient (conv_wgrad_bf16_w8).
+usage: make_traffic.py FETCH.txt WRITE.txt KERNEL_STATS.txt OUT.json"""
 import json
 import sys
 
-KERNELS = ("_Z18conv_igemm_bf16_w8ILb1EDF16bEv10ConvArgs16", "_Z18conv_igemm_bf16_v2ILi128ELb1ELi64EDF16bEv10ConvArgs16")
+TOWER = ("_Z18conv_igemm_bf16_w8ILb1EDF16bEv10ConvArgs16", "_Z18conv_igemm_bf16_v2ILi128ELb1ELi64EDF16bEv10ConvArgs16")
+WGRAD = "_Z18conv_wgrad_bf16_w811Wgrad16Args"
 
 
 def per_kernel(path):
@@ -13,16 +17,46 @@ def per_kernel(path):
     for line in open(path):
         f = line.split()
         if len(f) >= 6 and f[1] in ("FETCH_SIZE", "WRITE_SIZE"):
-            out[f[0].replace(".kd", "")] = (int(f[2]), float(f[3]))
+            out[f[0].replace(".kd", "")] = (int(f[2]), float(f[3]))   # calls, sum in KiB
     return out
 
 
-fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
-n = fetch[KERNELS[0]][0]  # launches of the tower conv = dispatches of the w8 kernel
-fk = sum(fetch[k][1] for k in KERNELS if k in fetch) / n
-wk = sum(write[k][1] for k in KERNELS if k in write) / n
-key = "conv_igemm_bf16_w8<true,__bf16>+conv_igemm_bf16_v2<128,true,64,__bf16>"
-json.dump({key: {"fetch_size_kib_per_launch": round(fk, 2), "write_size_kib_per_launch": round(wk, 2), "fetch_correction": 2.0,
-                 "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0, "launches_in_pmc_run": n,
-                 "source": "%s, %s" % (sys.argv[1], sys.argv[2])}}, open(sys.argv[3], "w"), indent=1)
-print(open(sys.argv[3]).read())
+def durations(path):
+    out = {}
+    for line in open(path):
+        f = line.split()
+        if len(f) >= 7 and f[0].startswith("_Z") and f[1].isdigit():
+            out[f[0].replace(".kd", "")] = (int(f[1]), float(f[3]))   # calls, avg_us
+    return out
+
+
+fetch, write, dur = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), durations(sys.argv[3])
+res = {"fetch_correction": 2.0, "source": "%s, %s, %s" % tuple(sys.argv[1:4])}
+if TOWER[0] in fetch:
+    n = fetch[TOWER[0]][0]
+    fk = sum(fetch[k][1] for k in TOWER if k in fetch) / n
+    wk = sum(write[k][1] for k in TOWER if k in write) / n
+    res["conv_igemm_bf16_w8<true,__bf16>+conv_igemm_bf16_v2<128,true,64,__bf16>"] = {
+        "fetch_size_kib_per_launch": round(fk, 2), "write_size_kib_per_launch": round(wk, 2),
+        "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0, "launches_in_pmc_run": n}
+kernels = {}
+for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch.get(k, (1, 0))[1] + write.get(k, (1, 0))[1])):
+    nf, f = fetch.get(k, (0, 0.0))
+    nw, w = write.get(k, (0, 0.0))
+    n = max(nf, nw, 1)
+    b = (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0
+    if b < (1 << 20):
+        continue
+    e = {"launches_in_pmc_run": n, "fetch_size_kib_per_launch": round(f / max(nf, 1), 2), "write_size_kib_per_launch": round(w / max(nw, 1), 2),
+         "hbm_bytes_per_launch": b}
+    if k in dur:
+        e["avg_us_kernel_trace"] = dur[k][1]
+        e["hbm_GBps"] = round(b / dur[k][1] / 1e3, 1)
+    kernels[k] = e
+res["kernels"] = kernels
+if WGRAD in kernels:
+    res["conv_wgrad_bf16_w8"] = dict(kernels[WGRAD])
+json.dump(res, open(sys.argv[4], "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k != "kernels"}, indent=1))
+for k, e in list(kernels.items())[:25]:
+    print("%-80s %8.1f MiB/launch %8s GB/s" % (k[:80], e["hbm_bytes_per_launch"] / 2 ** 20, e.get("hbm_GBps", "-")))

@@ -1,20 +1,38 @@
 #!/bin/bash
-# Round measurement of record (run on the GPU box through gpurun): bench lines, kernel trace, PMC passes.
-# usage: tools/measure_record.sh <tag>     outputs -> gpurun_out/<tag>_*
+# Round measurement of record (run on the GPU box through gpurun): bench lines, kernel traces, PMC passes for the FCOS (headline) and the
+# Faster-RCNN step.  usage: tools/measure_record.sh <tag>     outputs -> gpurun_out/<tag>_*
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$PWD
 mkdir -p gpurun_out
-timeout 600 python bench.py > gpurun_out/${TAG}_bench_bf16.json 2> gpurun_out/${TAG}_bench_bf16.err < /dev/null
-timeout 600 python bench.py --dtype f32 --no-cpu-baseline > gpurun_out/${TAG}_bench_f32.json 2> /dev/null < /dev/null
+timeout 900 python bench.py > gpurun_out/${TAG}_bench_bf16.json 2> gpurun_out/${TAG}_bench_bf16.err < /dev/null
+timeout 600 python bench.py --model rcnn > gpurun_out/${TAG}_bench_rcnn_bf16.json 2> /dev/null < /dev/null
+timeout 600 python bench.py --model rcnn --dtype f32 --steps 5 > gpurun_out/${TAG}_bench_rcnn_f32.json 2> /dev/null < /dev/null
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace -d $R/gpurun_out/_kt -o run -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${TAG}_kt.log 2>&1 < /dev/null
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/_pf -o run -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/_pw -o run -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
+prof() {  # prof <dir> <extra rocprof args> -- <bench args>
+  local d=$1; shift
+  local pmc=()
+  while [ "$1" != "--" ]; do pmc+=("$1"); shift; done
+  shift
+  timeout 600 rocprofv3 --kernel-trace "${pmc[@]}" -d $R/gpurun_out/$d -o run -- python $R/bench.py --no-cpu-baseline --no-f32 "$@" > $R/gpurun_out/${TAG}_$d.log 2>&1 < /dev/null
+}
+prof _kt -- --steps 8 --warmup 2
+prof _pf --pmc FETCH_SIZE -- --steps 3 --warmup 1
+prof _pw --pmc WRITE_SIZE -- --steps 3 --warmup 1
+prof _rkt -- --model rcnn --steps 8 --warmup 2
+prof _rpf --pmc FETCH_SIZE -- --model rcnn --steps 3 --warmup 1
+prof _rpw --pmc WRITE_SIZE -- --model rcnn --steps 3 --warmup 1
 cd $R
-for d in _kt _pf _pw; do f=$(find gpurun_out/$d -name "*.db" | head -1); echo "$d $f"; done
-timeout 120 python tools/rocpd_stats.py "$(find gpurun_out/_kt -name '*.db' | head -1)" > gpurun_out/${TAG}_kernel_stats.txt 2>&1 < /dev/null
-timeout 120 python tools/rocpd_pmc.py "$(find gpurun_out/_pf -name '*.db' | head -1)" 30 > gpurun_out/${TAG}_pmc_fetch.txt 2>&1 < /dev/null
-timeout 120 python tools/rocpd_pmc.py "$(find gpurun_out/_pw -name '*.db' | head -1)" 30 > gpurun_out/${TAG}_pmc_write.txt 2>&1 < /dev/null
-timeout 60 python tools/make_traffic.py gpurun_out/${TAG}_pmc_fetch.txt gpurun_out/${TAG}_pmc_write.txt gpurun_out/${TAG}_traffic.json > /dev/null 2>&1 < /dev/null
-rm -rf gpurun_out/_kt gpurun_out/_pf gpurun_out/_pw
+db() { find gpurun_out/$1 -name '*.db' | head -1; }
+timeout 120 python tools/rocpd_stats.py "$(db _kt)" > gpurun_out/${TAG}_fcos_4p4_bf16_kernel_stats.txt 2>&1 < /dev/null
+timeout 120 python tools/rocpd_pmc.py "$(db _pf)" 40 > gpurun_out/${TAG}_fcos_4p4_bf16_pmc_fetch.txt 2>&1 < /dev/null
+timeout 120 python tools/rocpd_pmc.py "$(db _pw)" 40 > gpurun_out/${TAG}_fcos_4p4_bf16_pmc_write.txt 2>&1 < /dev/null
+timeout 60 python tools/make_traffic.py gpurun_out/${TAG}_fcos_4p4_bf16_pmc_fetch.txt gpurun_out/${TAG}_fcos_4p4_bf16_pmc_write.txt \
+  gpurun_out/${TAG}_fcos_4p4_bf16_kernel_stats.txt gpurun_out/${TAG}_traffic.json > gpurun_out/${TAG}_traffic.log 2>&1 < /dev/null
+timeout 120 python tools/rocpd_stats.py "$(db _rkt)" > gpurun_out/${TAG}_rcnn_4p4_bf16_kernel_stats.txt 2>&1 < /dev/null
+timeout 120 python tools/rocpd_pmc.py "$(db _rpf)" 60 > gpurun_out/${TAG}_rcnn_4p4_bf16_pmc_fetch.txt 2>&1 < /dev/null
+timeout 120 python tools/rocpd_pmc.py "$(db _rpw)" 60 > gpurun_out/${TAG}_rcnn_4p4_bf16_pmc_write.txt 2>&1 < /dev/null
+timeout 60 python tools/make_traffic.py gpurun_out/${TAG}_rcnn_4p4_bf16_pmc_fetch.txt gpurun_out/${TAG}_rcnn_4p4_bf16_pmc_write.txt \
+  gpurun_out/${TAG}_rcnn_4p4_bf16_kernel_stats.txt gpurun_out/${TAG}_rcnn_traffic.json > gpurun_out/${TAG}_rcnn_traffic.log 2>&1 < /dev/null
+rm -rf gpurun_out/_kt gpurun_out/_pf gpurun_out/_pw gpurun_out/_rkt gpurun_out/_rpf gpurun_out/_rpw
+tail -c 600 gpurun_out/${TAG}_bench_bf16.json; echo; tail -c 400 gpurun_out/${TAG}_bench_rcnn_bf16.json; echo; tail -30 gpurun_out/${TAG}_rcnn_traffic.log
