@@ -1157,9 +1157,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
 //  * orders every LDS load it knows about behind ALL pending LDS-DMA (a vmcnt(0) in front of each fragment read that follows a DMA
 //    issue: the loads of the next chunk would have to land before the current chunk is consumed), and
 //  * waits for a loop-carried global load right where its result is first used - in the middle of the DMA issue sequence.
-// The pixel geometry (rowinfo) of chunk c+2 is fetched by plain VMEM loads issued AHEAD of the DMA pieces of chunk c+1 (loads return
-// in order: the one vmcnt(0) in front of the barrier covers both).  As scalar loads they sat behind every lgkmcnt(0) of the fragment
-// reads (SMEM shares that counter and returns out of order): 0.398 -> 0.387 ms.
+// The pixel geometry (rowinfo) is fetched by plain VMEM loads two chunks ahead, issued BEHIND the DMA pieces of the iteration and left
+// in flight by a counted vmcnt(4) in front of a bare s_barrier (loads return in order; __syncthreads() would drain vmcnt).  As scalar
+// loads they sat behind every lgkmcnt(0) of the fragment reads (SMEM shares that counter and returns out of order): 0.398 -> 0.387 ms.
 // Measured and NOT kept (tools/bench_wgrad_pf.py, same shape): one discarded dword load per 128-byte line 1-3 chunks ahead of the DMA
 // as an L2 prefetch (0.51 ms: the in-order vmcnt makes every piece wait for the older HBM-miss load); a three-stage ring of 48-pixel
 // chunks with the DMA two chunks ahead and a counted vmcnt(9) in front of a bare s_barrier (0.396 ms: no gain, the DMA stream is not
@@ -1213,28 +1213,36 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
   const __bf16* __restrict__ dyb = (const __bf16*)p.dy;
   const __bf16* zero = (const __bf16*)g_zero64;
   typedef int i32x2 __attribute__((ext_vector_type(2)));
-  i32x2 ri[4];              // rowinfo of the lane's four im2col rows of the NEXT chunk to be staged
+  i32x2 ri[2][4];           // rowinfo of the lane's four im2col rows, two chunks in flight (set = parity of the chunk it belongs to)
   const int rowl = 8 * wid + hr;  // + 2q
-  auto rload = [&](int chunk) {   // asm: invisible to the compiler's waitcnt insertion; waited for by the vmcnt(0) in front of the barrier
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int m = chunk * BP + rowl + 2 * q;
-      m = m < p.M ? m : p.M - 1;
-      const int2* src = p.rowinfo + m;
-      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ri[q]) : "v"(src));
-    }
-  };
+  // (two explicit copies per helper: `set` must be a compile-time constant - an asm result has to land in its final registers -
+  // and inline asm inside a generic lambda cannot name the captured array)
+#define WG8_RLOAD(SET)                                                                             \
+  [&](int chunk) {                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                \
+      int m = chunk * BP + rowl + 2 * q;                                                           \
+      m = m < p.M ? m : p.M - 1;                                                                   \
+      const int2* src = p.rowinfo + m;                                                             \
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ri[SET][q]) : "v"(src));               \
+    }                                                                                              \
+  }
+  auto rload0 = WG8_RLOAD(0);   // asm: invisible to the compiler's waitcnt insertion; covered by the counted vmcnt waits
+  auto rload1 = WG8_RLOAD(1);
+#undef WG8_RLOAD
   const __bf16* bsrc[4];    // source of the lane's 16 bytes of the four im2col pieces of the chunk staged in this iteration
-  auto bsrc_from_ri = [&](int chunk) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int m = chunk * BP + rowl + 2 * q;
-      const int W = ri[q].y >> 16;
-      const __bf16* s0 = xb + (unsigned)((ri[q].x + dh * W + dw) * p.C + ci0 + choff[q & 1]);
-      const bool ok = (m < p.M) & ((ri[q].y >> tap) & 1);
-      bsrc[q] = ok ? s0 : zero;
-    }
-  };
+#define WG8_BSRC(SET)                                                                                              \
+  [&](int chunk) {                                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                \
+      const int m = chunk * BP + rowl + 2 * q;                                                                     \
+      const int W = ri[SET][q].y >> 16;                                                                            \
+      const __bf16* s0 = xb + (unsigned)((ri[SET][q].x + dh * W + dw) * p.C + ci0 + choff[q & 1]);                 \
+      const bool ok = (m < p.M) & (chunk < chunk_end) & ((ri[SET][q].y >> tap) & 1);                               \
+      bsrc[q] = ok ? s0 : zero;                                                                                    \
+    }                                                                                                              \
+  }
+  auto bsrc0 = WG8_BSRC(0);
+  auto bsrc1 = WG8_BSRC(1);
+#undef WG8_BSRC
   auto issue_piece = [&](int buf, int chunk, int q8) {  // q8 0..3: dY pieces, 4..7: im2col pieces
     const int q = q8 & 3;
     unsigned char* dst = smem + buf * STAGE + (q8 < 4 ? 0 : OPB) + (8 * wid + 2 * q) * ROWB;
@@ -1242,7 +1250,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
     if (q8 < 4) {
       const int m = chunk * BP + rowl + 2 * q;
       const __bf16* s0 = dyb + (unsigned)(m * p.K + i0 + choff[q & 1]);
-      src = m < p.M ? s0 : zero;
+      src = ((m < p.M) & (chunk < chunk_end)) ? s0 : zero;   // past the split's end: zeros (keeps the vmcnt arithmetic uniform)
     } else {
       src = bsrc[q];
     }
@@ -1273,11 +1281,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
   asm volatile("s_waitcnt lgkmcnt(0)"                                                                                          \
                : "+v"(al[set][0]), "+v"(al[set][1]), "+v"(al[set][2]), "+v"(al[set][3]), "+v"(ah[set][0]), "+v"(ah[set][1]), \
                  "+v"(ah[set][2]), "+v"(ah[set][3]), "+v"(bl[set][0]), "+v"(bl[set][1]), "+v"(bh[set][0]), "+v"(bh[set][1]))
-  // every VMEM operation of the wave (rowinfo loads, LDS-DMA pieces) has completed; ties the rowinfo registers
-#define WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" : "+v"(ri[0]), "+v"(ri[1]), "+v"(ri[2]), "+v"(ri[3]) : : "memory")
+  // all but the newest N VMEM operations of the wave (rowinfo loads, LDS-DMA pieces) have completed; ties the rowinfo registers
+#define WAIT_VMEM(N)                                                                                                      \
+  asm volatile("s_waitcnt vmcnt(" #N ")"                                                                                  \
+               : "+v"(ri[0][0]), "+v"(ri[0][1]), "+v"(ri[0][2]), "+v"(ri[0][3]), "+v"(ri[1][0]), "+v"(ri[1][1]), "+v"(ri[1][2]), \
+                 "+v"(ri[1][3]) : : "memory")
 
-  auto iteration = [&](int ch, int buf, auto do_load) {
-    constexpr bool LOAD = decltype(do_load)::value;
+  // Iteration ch consumes chunk ch from stage ch & 1, issues the 8 DMA pieces of chunk ch+1 (their geometry arrived an iteration ago:
+  // set (ch+1) & 1) and, BEHIND them, the 4 geometry loads of chunk ch+3 into the set the pieces just released.  The wait in front of
+  // the barrier leaves those 4 loads in flight (vmcnt(4): loads return in order, so the pieces and the older geometry are in) - they
+  // get a whole further chunk to come back from HBM; the barrier is a bare s_barrier (__syncthreads() would drain vmcnt).
+  auto iteration = [&](int ch, int buf, auto setc) {
+    constexpr bool LOAD = true;
+    constexpr int SET = decltype(setc)::value;
     unsigned ab[4], bb[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) ab[i] = aoff[i] + buf * STAGE;
@@ -1309,16 +1325,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     };
-    // the geometry of chunk ch+1 arrived before the last barrier: turn it into the four im2col source addresses, which frees the
-    // rowinfo registers for chunk ch+2
-    if constexpr (LOAD) bsrc_from_ri(ch + 1);
+    if constexpr (SET == 0) bsrc0(ch + 1); else bsrc1(ch + 1);
     // k16 step s: [fragments of step s have landed] -> issue the reads of step s+1 -> 8 MFMAs -> memory work of the next chunks
     if (WG8_READ) { READ_FRAGS(0, 0); }
     WAIT_FRAGS(0);
     if (WG8_READ) { READ_FRAGS(1, 1); }
     if (WG8_MFMA) mfmas(0);
     if constexpr (LOAD) {
-      rload(ch + 2);   // older than the DMA pieces below: in-order return, one wait covers both
       if (WG8_DMA) {
 #pragma unroll
         for (int q8 = 4; q8 < 8; ++q8) issue_piece(buf ^ 1, ch + 1, q8);
@@ -1333,6 +1346,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
 #pragma unroll
         for (int q8 = 0; q8 < 4; ++q8) issue_piece(buf ^ 1, ch + 1, q8);
       }
+      if constexpr (SET == 0) rload0(ch + 3); else rload1(ch + 3);
     }
     __builtin_amdgcn_sched_barrier(0);
     WAIT_FRAGS(0);
@@ -1342,23 +1356,33 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
     WAIT_FRAGS(1);
     if (WG8_MFMA) mfmas(1);
     __builtin_amdgcn_sched_barrier(0);
-    WAIT_VMEM();
-    __syncthreads();
+#ifdef UTV2_WGRAD_DEBUG_KNOBS
+    if (WG8_DMA) { WAIT_VMEM(4); } else { WAIT_VMEM(0); }
+#else
+    WAIT_VMEM(4);
+#endif
+    __builtin_amdgcn_s_barrier();
   };
-  using yes = std::integral_constant<bool, true>;
-  using no = std::integral_constant<bool, false>;
   if (chunk_begin < chunk_end) {
-    rload(chunk_begin);
-    WAIT_VMEM();
-    bsrc_from_ri(chunk_begin);
-    rload(chunk_begin + 1);
+    using set0 = std::integral_constant<int, 0>;
+    using set1 = std::integral_constant<int, 1>;
+    // chunk k's geometry lives in set (k - chunk_begin) & 1
+    rload0(chunk_begin);
+    rload1(chunk_begin + 1);
+    WAIT_VMEM(0);
+    bsrc0(chunk_begin);
 #pragma unroll
     for (int q8 = 0; q8 < 8; ++q8) issue_piece(0, chunk_begin, q8);
-    WAIT_VMEM();
-    __syncthreads();
-    int ch = chunk_begin;
-    for (; ch + 1 < chunk_end; ++ch) iteration(ch, (ch - chunk_begin) & 1, yes{});
-    iteration(ch, (ch - chunk_begin) & 1, no{});
+    rload0(chunk_begin + 2);
+    WAIT_VMEM(0);
+    __builtin_amdgcn_s_barrier();
+    for (int ch = chunk_begin; ch < chunk_end;) {
+      iteration(ch, 0, set1{});          // stages chunk ch+1 (odd offset): its geometry is in set 1; refills set 1 with chunk ch+3
+      if (++ch >= chunk_end) break;
+      iteration(ch, 1, set0{});
+      ++ch;
+    }
+    WAIT_VMEM(0);   // the trailing (zero-page) pieces must not land in LDS after the workgroup has gone
   }
 #undef TR_READ
 #undef READ_FRAGS
