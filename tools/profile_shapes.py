@@ -36,7 +36,7 @@ def call(name, *args):
             yb = (2 if args[4] else 4) if b16 else 4
             by = N * 29841 * (xb * C + yb * K)
         elif name == "utv2_conv2d_wgrad_bf16":
-            M, C, K, KH, KW = args[8:13]
+            M, C, K, KH, KW = args[9:14]
             key = ("wg16", M, 0, 0, C, K, KH, 1, 1, 0, 0)
             fl = 2.0 * M * K * KH * KW * C
             by = M * ((2 if args[1] else 4) * C + (2 if args[3] else 4) * K)
@@ -52,7 +52,7 @@ def call(name, *args):
         orig_call(name, *args)
 
 hip.call = call
-sys.argv = ["bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+sys.argv = ["bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-f32"]
 # run bench main but toggle recording around the timed region by patching ConvTimer.enabled setter
 class T(bench.ConvTimer):
     def __setattr__(self, k, v):

@@ -369,6 +369,8 @@ class UBTeacherTrainer(_TrainerBase):
         self.pseudo_generator = PseudoGenerator(cfg)
         self.fuse_student_passes = os.environ.get("UTV2_FUSE_STUDENT_PASSES", "1") != "0"
         self.fuse_teacher_nms = os.environ.get("UTV2_FUSE_TEACHER_NMS", "1") != "0"
+        self.overlap_teacher = os.environ.get("UTV2_OVERLAP_TEACHER", "1") != "0"
+        self._side_stream = None
         self._common_init(cfg, data_loader)
 
     # pseudo-label dict surgery (trainer.py:161-175)
@@ -387,6 +389,45 @@ class UBTeacherTrainer(_TrainerBase):
             for d in unlabled_data:
                 d[key] = label
         return unlabled_data
+
+    @torch.no_grad()
+    def _teacher_pseudo_labels(self, unlabel_data_k):
+        """trainer.py:224-292: teacher forward on the weak views, detections under the two ranking criteria, thresholding into the
+        classification and the regression pseudo sets"""
+        cfg = self.cfg
+        S = cfg.SEMISUPNET
+        fo_t = self.model_teacher.proposal_generator.fcos_outputs     # eval mode: reads the *_TEST thresholds
+        fo_p = self.pseudo_generator.fcos_output                       # never put in eval mode: *_TRAIN (SURVEY B10)
+        same = ((fo_t.pre_nms_thresh_test, fo_t.pre_nms_topk_test, fo_t.post_nms_topk_test, fo_t.nms_thresh) ==
+                (fo_p.pre_nms_thresh_train, fo_p.pre_nms_topk_train, fo_p.post_nms_topk_train, fo_p.nms_thresh))
+        if self.fuse_teacher_nms and same and not fo_t.training:
+            # both criteria (classification / regression pseudo sets, trainer.py:232-251) in ONE set of launches over
+            # (criterion, image) pairs: identical detections, half the latency-bound top-k / NMS kernels
+            (pred_teacher, pred_teacher_loc), raw_pred_teacher = self.model_teacher(
+                unlabel_data_k, output_raw=True,
+                nms_method=(cfg.MODEL.FCOS.NMS_CRITERIA_TRAIN, cfg.MODEL.FCOS.NMS_CRITERIA_REG_TRAIN), branch="teacher_weak")
+        else:
+            pred_teacher, raw_pred_teacher = self.model_teacher(
+                unlabel_data_k, output_raw=True, nms_method=cfg.MODEL.FCOS.NMS_CRITERIA_TRAIN, branch="teacher_weak")
+            pred_teacher_loc = self.pseudo_generator.nms_from_dense(raw_pred_teacher, cfg.MODEL.FCOS.NMS_CRITERIA_REG_TRAIN)
+
+        if S.PSEUDO_BBOX_SAMPLE == "thresholding":
+            cur_threshold = S.BBOX_THRESHOLD
+        elif S.PSEUDO_BBOX_SAMPLE == "thresholding_cls_ctr":
+            cur_threshold = (S.BBOX_THRESHOLD, S.BBOX_CTR_THRESHOLD)
+        else:
+            raise ValueError
+        if S.PSEUDO_BBOX_SAMPLE_REG == "thresholding":
+            cur_threshold_reg = S.BBOX_THRESHOLD_REG
+        elif S.PSEUDO_BBOX_SAMPLE_REG == "thresholding_cls_ctr":
+            cur_threshold_reg = (S.BBOX_THRESHOLD_REG, S.BBOX_CTR_THRESHOLD_REG)
+        else:
+            raise ValueError
+
+        pseudo_cls, _ = self.pseudo_generator.process_pseudo_label(pred_teacher, cur_threshold, "roih", S.PSEUDO_BBOX_SAMPLE)
+        pseudo_reg, _ = self.pseudo_generator.process_pseudo_label(pred_teacher_loc, cur_threshold_reg, "roih", S.PSEUDO_BBOX_SAMPLE_REG)
+        self._last_pseudo = (pseudo_cls, pseudo_reg)
+        return pseudo_cls, pseudo_reg
 
     def run_step_full_semisup(self):
         cfg = self.cfg
@@ -411,38 +452,37 @@ class UBTeacherTrainer(_TrainerBase):
                 ema_keep_rate = S.EMA_KEEP_RATE  # guards the reference's unbound-name bug
             record_dict = {"ema_rate_1000x": ema_keep_rate * 1000}
 
-            with torch.no_grad():
-                fo_t = self.model_teacher.proposal_generator.fcos_outputs     # eval mode: reads the *_TEST thresholds
-                fo_p = self.pseudo_generator.fcos_output                       # never put in eval mode: *_TRAIN
-                same = ((fo_t.pre_nms_thresh_test, fo_t.pre_nms_topk_test, fo_t.post_nms_topk_test, fo_t.nms_thresh) ==
-                        (fo_p.pre_nms_thresh_train, fo_p.pre_nms_topk_train, fo_p.post_nms_topk_train, fo_p.nms_thresh))
-                if self.fuse_teacher_nms and same and not fo_t.training:
-                    # both criteria (classification / regression pseudo sets, trainer.py:232-251) in ONE set of launches over
-                    # (criterion, image) pairs: identical detections, half the latency-bound top-k / NMS kernels
-                    (pred_teacher, pred_teacher_loc), raw_pred_teacher = self.model_teacher(
-                        unlabel_data_k, output_raw=True,
-                        nms_method=(cfg.MODEL.FCOS.NMS_CRITERIA_TRAIN, cfg.MODEL.FCOS.NMS_CRITERIA_REG_TRAIN), branch="teacher_weak")
-                else:
-                    pred_teacher, raw_pred_teacher = self.model_teacher(
-                        unlabel_data_k, output_raw=True, nms_method=cfg.MODEL.FCOS.NMS_CRITERIA_TRAIN, branch="teacher_weak")
-                    pred_teacher_loc = self.pseudo_generator.nms_from_dense(raw_pred_teacher, cfg.MODEL.FCOS.NMS_CRITERIA_REG_TRAIN)
-
-            if S.PSEUDO_BBOX_SAMPLE == "thresholding":
-                cur_threshold = S.BBOX_THRESHOLD
-            elif S.PSEUDO_BBOX_SAMPLE == "thresholding_cls_ctr":
-                cur_threshold = (S.BBOX_THRESHOLD, S.BBOX_CTR_THRESHOLD)
-            else:
-                raise ValueError
-            if S.PSEUDO_BBOX_SAMPLE_REG == "thresholding":
-                cur_threshold_reg = S.BBOX_THRESHOLD_REG
-            elif S.PSEUDO_BBOX_SAMPLE_REG == "thresholding_cls_ctr":
-                cur_threshold_reg = (S.BBOX_THRESHOLD_REG, S.BBOX_CTR_THRESHOLD_REG)
-            else:
-                raise ValueError
-
-            pseudo_cls, _ = self.pseudo_generator.process_pseudo_label(pred_teacher, cur_threshold, "roih", S.PSEUDO_BBOX_SAMPLE)
-            pseudo_reg, _ = self.pseudo_generator.process_pseudo_label(pred_teacher_loc, cur_threshold_reg, "roih", S.PSEUDO_BBOX_SAMPLE_REG)
-            self._last_pseudo = (pseudo_cls, pseudo_reg)
+            all_label_data = label_data_q + label_data_k
+            # The reference runs two student forwards (trainer.py:396-411).  Every layer is per-image (FrozenBN, per-image
+            # GroupNorm), so when both lists pad to the same canvas they are ONE batch here: larger GEMMs, one weight
+            # gradient per layer instead of two.  Different canvases (zero padding differs) keep the two passes.
+            fuse = (self.fuse_student_passes and not S.PSEUDO_CLS_IGNORE_NEAR
+                    and self.model.padded_canvas(all_label_data) == self.model.padded_canvas(unlabel_data_q))
+            # The student's forward needs the pseudo labels only in its loss kernels: with one student batch the teacher (forward,
+            # top-k, decode, NMS, thresholding - the last four latency-bound) runs on a side stream NEXT TO the student's backbone /
+            # FPN / towers and fills the partial rounds and tails those leave on the chip.
+            overlap = fuse and self.overlap_teacher and self.model.device.type == "cuda"
+            ctx = None
+            if overlap:
+                main = torch.cuda.current_stream(self.model.device)
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(self.model.device)
+                side = self._side_stream
+                side.wait_stream(main)           # the EMA update above, the loader's copies
+                torch.cuda.set_stream(side)
+            try:
+                pseudo_cls, pseudo_reg = self._teacher_pseudo_labels(unlabel_data_k)
+                if overlap:
+                    for pb in (pseudo_cls, pseudo_reg):      # allocated on the side stream, consumed on the main one
+                        for t in pb.f.values():
+                            if torch.is_tensor(t):
+                                t.record_stream(main)
+            finally:
+                if overlap:
+                    torch.cuda.set_stream(main)
+            if overlap:
+                ctx = self.model.forward_joint_begin(all_label_data, unlabel_data_q)   # concurrent with the teacher
+                main.wait_stream(side)
 
             unlabel_data_q = self.remove_label(unlabel_data_q)
             unlabel_data_k = self.remove_label(unlabel_data_k)
@@ -451,15 +491,11 @@ class UBTeacherTrainer(_TrainerBase):
             unlabel_data_q = self.add_label(unlabel_data_q, pseudo_reg, "reg")
             unlabel_data_k = self.add_label(unlabel_data_k, pseudo_reg, "reg")
 
-            all_label_data = label_data_q + label_data_k
             all_unlabel_data = unlabel_data_q
-
-            # The reference runs two student forwards (trainer.py:396-411).  Every layer is per-image (FrozenBN, per-image
-            # GroupNorm), so when both lists pad to the same canvas they are ONE batch here: larger GEMMs, one weight
-            # gradient per layer instead of two.  Different canvases (zero padding differs) keep the two passes.
-            fuse = (self.fuse_student_passes and not S.PSEUDO_CLS_IGNORE_NEAR
-                    and self.model.padded_canvas(all_label_data) == self.model.padded_canvas(all_unlabel_data))
-            if fuse:
+            if ctx is not None:
+                rec_l, record_unl = self.model.forward_joint_finish(ctx, all_unlabel_data)
+                record_dict.update(rec_l)
+            elif fuse:
                 rec_l, record_unl = self.model.forward_joint(all_label_data, all_unlabel_data)
                 record_dict.update(rec_l)
             else:

@@ -125,8 +125,9 @@ _ws_cache = {}
 
 
 def workspace(nfloats, device, tag="default"):
-    """A reusable fp32 scratch buffer per (device, tag); grows monotonically."""
-    key = (str(device), tag)
+    """A reusable fp32 scratch buffer per (device, stream, tag); grows monotonically.  Per stream: the teacher's forward may run on a
+    side stream next to the student's (engine/trainer.py), and kernels of two streams must not share scratch."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0, tag)
     t = _ws_cache.get(key)
     if t is None or t.numel() < nfloats:
         t = torch.empty(max(int(nfloats), 1024), dtype=torch.float32, device=device)

@@ -549,15 +549,21 @@ class FCOS:
         """Both student passes of one UTv2 iteration on ONE batch: images [0, n_labeled) carry ground truth (branch
         "labeled"), the rest pseudo labels (branch "unlabeled").  Every op of the network is per-image (FrozenBN,
         per-image GroupNorm), so this equals the two separate forwards whenever both groups share one padded canvas."""
+        return self.forward_joint_finish(self.forward_joint_begin(image_sizes, features, n_labeled, gt_labeled), gt_unlabeled)
+
+    def forward_joint_begin(self, image_sizes, features, n_labeled, gt_labeled):
         assert self.training
         feats = [features[f] for f in self.in_features]
         level_hw = [(f.shape[1], f.shape[2]) for f in feats]
         big, meta = features["_levelfirst"]
-        N = meta.N
         head_out = self.fcos_head(big, meta)
-        act = torch.zeros(N, dtype=torch.uint8, device=big.device)
+        return dict(head_out=head_out, level_hw=level_hw, n_labeled=n_labeled, gt_labeled=gt_labeled, N=meta.N, device=big.device)
+
+    def forward_joint_finish(self, ctx, gt_unlabeled):
+        head_out, level_hw, n_labeled, N = ctx["head_out"], ctx["level_hw"], ctx["n_labeled"], ctx["N"]
+        act = torch.zeros(N, dtype=torch.uint8, device=ctx["device"])
         act[:n_labeled] = 1
-        _, l_sup = self.fcos_outputs.losses(head_out, level_hw, gt_labeled.pad_images(0, N - n_labeled), active=act)
+        _, l_sup = self.fcos_outputs.losses(head_out, level_hw, ctx["gt_labeled"].pad_images(0, N - n_labeled), active=act)
         gtu = {k: v.pad_images(n_labeled, 0) for k, v in gt_unlabeled.items()}
         _, l_uns = self.fcos_outputs.pseudo_losses(head_out, level_hw, gtu, active=(1 - act))
         return l_sup, l_uns

@@ -100,6 +100,20 @@ class OneStageDetector(PseudoProposalNetwork):
         gt_u = {"cls": self._gt(unlabeled_inputs, "instances_class"), "reg": self._gt(unlabeled_inputs, "instances_reg")}
         return self.proposal_generator.forward_joint(image_sizes, features, len(labeled_inputs), gt_l, gt_u)
 
+    def forward_joint_begin(self, labeled_inputs, unlabeled_inputs):
+        """first half of forward_joint: everything that does not need the pseudo labels (backbone, FPN, towers, prediction convs of the
+        concatenated batch) - the trainer runs it while the teacher is still producing them on another stream"""
+        assert self.training
+        both = list(labeled_inputs) + list(unlabeled_inputs)
+        features, image_sizes = self._features(both)
+        gt_l = self._gt(labeled_inputs, "instances")
+        return self.proposal_generator.forward_joint_begin(image_sizes, features, len(labeled_inputs), gt_l)
+
+    def forward_joint_finish(self, ctx, unlabeled_inputs):
+        """second half: the loss kernels, given the unlabeled images' pseudo labels"""
+        gt_u = {"cls": self._gt(unlabeled_inputs, "instances_class"), "reg": self._gt(unlabeled_inputs, "instances_reg")}
+        return self.proposal_generator.forward_joint_finish(ctx, gt_u)
+
     def forward(self, batched_inputs, output_raw=False, nms_method="cls_n_ctr", ignore_near=False, branch="labeled"):
         if self.training:
             features, image_sizes = self._features(batched_inputs)
