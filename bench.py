@@ -51,21 +51,40 @@ def tune_for_pseudo_labels(trainer, batch, target_std=1.5, bias=-6.0):
     m.store.touch()  # weights were edited in place: invalidate the bf16 mirror
 
 
-def tune_rcnn_for_pseudo_labels(trainer, batch, target_std=2.5, bg_bias=3.0):
-    """Faster-RCNN counterpart: a random-init R50 has no normalised features, the class scores are flat; rescale the predictor's
-    cls_score (data-driven, with the product's own teacher forward) so the teacher emits some confident detections above
-    BBOX_THRESHOLD and the pseudo-label branch of the step does real work."""
+def tune_rcnn_for_pseudo_labels(trainer, batch, target_std=8.0, bg_bias=0.0):
+    """Faster-RCNN counterpart: a random-init R50 has no normalised features - the RPN's deltas explode (every proposal clamps to the
+    image, NMS keeps a handful) and the class scores are flat.  Rescale the RPN prediction layers and the predictor's cls_score,
+    data-driven with the product's own forward, so that the RPN emits its ~1000 proposals per image and the teacher some confident
+    detections above BBOX_THRESHOLD: the pseudo-label branch of the step then does real work."""
+    from ubteacher import hip, ops
     m = trainer.model
     sd = m.state_dict()
-    w, b = sd["roi_heads.box_predictor.cls_score.weight"], sd["roi_heads.box_predictor.cls_score.bias"]
     g = torch.Generator(device="cpu").manual_seed(0)
-    w.copy_((torch.randn(w.shape, generator=g) * 0.01).to(w.device))
+    wo, wd = sd["proposal_generator.rpn_head.objectness_logits.weight"], sd["proposal_generator.rpn_head.anchor_deltas.weight"]
+    wo.copy_((torch.randn(wo.shape, generator=g) * 0.01).to(wo.device))
+    wd.copy_((torch.randn(wd.shape, generator=g) * 0.01).to(wd.device))
+    m.store.touch()
+    with torch.no_grad():
+        images = [x["image"].to(m.device) for x in batch[3]]
+        x4, _ = hip.preprocess_images(images, m._mean_host, m._std_host, m.backbone.size_divisibility, bf16_stem=ops.PRECISION[0] == "bf16")
+        m.folder.fold()
+        big, _, _ = m.proposal_generator._head(m.backbone(x4))
+        s_obj, s_dl = big[:, :3].float().std(), big[:, 3:15].float().std()
+    wo.mul_(1.0 / s_obj.clamp(min=1e-12))
+    wd.mul_(0.1 / s_dl.clamp(min=1e-12))
+    w, b = sd["roi_heads.box_predictor.cls_score.weight"], sd["roi_heads.box_predictor.cls_score.bias"]
+    wb, ws = sd["roi_heads.box_predictor.bbox_pred.weight"], sd["roi_heads.box_predictor.bbox_pred_std.weight"]
+    for t in (w, wb, ws):
+        t.copy_((torch.randn(t.shape, generator=g) * 0.01).to(t.device))
     b.zero_()
     m.store.touch()
     with torch.no_grad():
-        _, _, _, preds = m(batch[3], branch="unsup_data_weak")
-        s = preds[0].float().std()
+        _, rpn, _, preds = m(batch[3], branch="unsup_data_weak")
+        rows = rpn["valid"].reshape(-1).bool()
+        s, s_d, s_s = (p_.float()[rows].std() for p_ in preds)
     w.mul_(target_std / s.clamp(min=1e-12))
+    wb.mul_(0.5 / s_d.clamp(min=1e-12))
+    ws.mul_(0.5 / s_s.clamp(min=1e-12))
     b[-1] = bg_bias
     m.store.touch()
     trainer._update_teacher_model(keep_rate=0.0)  # teacher := student
@@ -320,6 +339,11 @@ def worker(args):
         t = (UBRCNNTeacherTrainer if rcnn else UBTeacherTrainer)(cfg)
         t.iter = 1
         t.log_period = 10 ** 9
+        if rcnn:
+            # random-init R50 features are not normalised (|x| ~ 1e4 in the box head): at any practical learning rate ONE SGD step moves
+            # the student far enough that the EMA teacher stops emitting pseudo boxes and the pseudo-label branch degenerates.  The step's
+            # work does not depend on the learning rate: a vanishing one keeps the synthetic problem stationary (100 pseudo boxes / image).
+            t.optimizer.param_groups[0]["lr"] = 1e-12
         return t
 
     timer = ConvTimer(args.dtype)
@@ -367,22 +391,29 @@ def worker(args):
         dist.all_gather_object(devs, device_index)
         devices = devs
     metrics = tr.flush_metrics()
+    lp = getattr(tr, "_last_pseudo", None)
+    if lp is None:
+        pseudo_count = None
+    elif isinstance(lp, tuple):
+        pseudo_count = {"cls": int(lp[0]["valid"].sum()), "reg": int(lp[1]["valid"].sum())}
+    else:
+        pseudo_count = int(lp["valid"].sum())
     conv, wg = timer.summary(), wtimer.summary()
 
     host_ms = None
-    if rank == 0 and world == 1 and not rcnn:
+    if rank == 0 and world == 1:
         # host cost of one step: the same trainer code on 96 x 128 images, where the GPU work is negligible and the step time IS the
         # Python / launch overhead (on the 1333 x 800 batch the host runs ahead until the launch queue is full, so its enqueue time
         # only mirrors the GPU time)
         from ubteacher.data.synthetic import SyntheticTwoCropLoader
-        cfg_s = get_config("fcos", 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label, "SOLVER.IMG_PER_BATCH_UNLABEL", args.unlabel,
+        cfg_s = get_config(args.model, 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label, "SOLVER.IMG_PER_BATCH_UNLABEL", args.unlabel,
                                        "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", args.dtype == "bf16",
                                        "MODEL.DEVICE", "cuda:%d" % device_index])
         torch.manual_seed(0)
-        ts = UBTeacherTrainer(cfg_s, data_loader=SyntheticTwoCropLoader(cfg_s, height=96, width=128))
+        ts = (UBRCNNTeacherTrainer if rcnn else UBTeacherTrainer)(cfg_s, data_loader=SyntheticTwoCropLoader(cfg_s, height=96, width=128))
         ts.iter = 1
         ts.log_period = 10 ** 9
-        tune_for_pseudo_labels(ts, ts._data_loader.batches[0])
+        (tune_rcnn_for_pseudo_labels if rcnn else tune_for_pseudo_labels)(ts, ts._data_loader.batches[0])
         for _ in range(3):
             ts.run_step_full_semisup(); ts.iter += 1
         torch.cuda.synchronize()
@@ -443,6 +474,7 @@ def worker(args):
             "host": {"ms_per_step_on_96x128_images": host_ms, "enqueue_ms_per_step": 1e3 * t_host / args.steps,
                      "cabi_calls_per_step": calls_per_step},
             "losses": {k: v for k, v in metrics.items() if k.startswith("loss") or k.startswith("teacher")},
+            "pseudo_boxes_last_step": pseudo_count,
         }
         if conv:
             out["roofline"] = {"bound": "mfma", "kernel": timer.kernel + (" (RPN head 3x3 conv over p2-p6, fwd+dgrad launches)" if rcnn else

@@ -1,4 +1,5 @@
 """Faster-RCNN UTv2 trainer (reference engine/trainer.py:612-1023) on the arena/HIP machinery."""
+import os
 import time
 
 import torch
@@ -62,19 +63,40 @@ def _make(base):
                     self._update_teacher_model(keep_rate=cur_ema_rate)
                 record_dict = {"EMA_rate": cur_ema_rate}
 
-                with torch.no_grad():
-                    _, proposals_rpn_unsup_k, proposals_roih_unsup_k, _ = self.model_teacher(unlabel_data_k, branch="unsup_data_weak")
-                pseudo, _ = self.process_pseudo_label(proposals_roih_unsup_k, S.BBOX_THRESHOLD, "roih", "thresholding")
-                # student ground truth fields
-                gt = PaddedBoxes(pseudo.image_sizes, boxes=pseudo["boxes"], classes=pseudo["classes"], valid=pseudo["valid"],
-                                 scores=pseudo["scores"], pred_boxes_std=pseudo["pred_boxes_std"])
+                # The supervised student pass does not depend on the pseudo labels: the teacher (forward, RPN top-k + NMS, ROI inference
+                # + NMS, thresholding - mostly latency-bound kernels) runs on a side stream next to it (engine/trainer.py does the same
+                # for FCOS); the pseudo-labeled pass follows once both are done.  UTV2_OVERLAP_TEACHER=0: one stream (identical results).
+                overlap = os.environ.get("UTV2_OVERLAP_TEACHER", "1") != "0" and self.model.device.type == "cuda"
+                if overlap:
+                    main = torch.cuda.current_stream(self.model.device)
+                    if getattr(self, "_side_stream", None) is None:
+                        self._side_stream = torch.cuda.Stream(self.model.device)
+                    side = self._side_stream
+                    side.wait_stream(main)           # the EMA update above
+                    torch.cuda.set_stream(side)
+                try:
+                    with torch.no_grad():
+                        _, proposals_rpn_unsup_k, proposals_roih_unsup_k, _ = self.model_teacher(unlabel_data_k, branch="unsup_data_weak")
+                    pseudo, _ = self.process_pseudo_label(proposals_roih_unsup_k, S.BBOX_THRESHOLD, "roih", "thresholding")
+                    # student ground truth fields
+                    gt = PaddedBoxes(pseudo.image_sizes, boxes=pseudo["boxes"], classes=pseudo["classes"], valid=pseudo["valid"],
+                                     scores=pseudo["scores"], pred_boxes_std=pseudo["pred_boxes_std"])
+                    if overlap:
+                        for t in gt.f.values():          # allocated on the side stream, consumed on the main one
+                            if torch.is_tensor(t):
+                                t.record_stream(main)
+                finally:
+                    if overlap:
+                        torch.cuda.set_stream(main)
                 self._last_pseudo = gt
-                unlabel_data_q = self.add_label(self.remove_label(unlabel_data_q), gt)
-                unlabel_data_k = self.add_label(self.remove_label(unlabel_data_k), gt)
 
                 all_label_data = label_data_q + label_data_k if S.USE_SUP_STRONG == "both" else label_data_k
                 rec_l, _, _, _ = self.model(all_label_data, branch="supervised")
                 record_dict.update(rec_l)
+                if overlap:
+                    main.wait_stream(side)
+                unlabel_data_q = self.add_label(self.remove_label(unlabel_data_q), gt)
+                unlabel_data_k = self.add_label(self.remove_label(unlabel_data_k), gt)
                 rec_u, _, _, _ = self.model(unlabel_data_q, branch="unsup_data_train")
                 for k, v in rec_u.items():
                     record_dict[k + "_pseudo"] = v
