@@ -199,6 +199,7 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
 // of busy waves (5 FPN levels for the RPN, 80 categories for FCOS / the ROI head).  The per-wave early exit is the same rule
 // as above applied to the wave's own kept list (a sub-list of the global one, so its k-th score bounds the global k-th).
 #define NMS_PW 8
+#define NMS_SYNC 8   // chunks between the global kept-count checks (power of two)
 __global__ __launch_bounds__(64 * NMS_PW) void nms_scan_par_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ sidx,
                                                                    const int* __restrict__ scls, const int* __restrict__ nvalid,
                                                                    const float* __restrict__ scores, int M, int Mpad, int post_topk,
@@ -218,16 +219,30 @@ __global__ __launch_bounds__(64 * NMS_PW) void nms_scan_par_kernel(const unsigne
 #pragma unroll
   for (int s = 0; s < NMS_MAXW; ++s) removed[s] = 0ull;
   int count = 0;
-  bool have_kth = false;
+  bool have_kth = false, done = false;
   float kth = 0.f;
+  __shared__ int wkept[NMS_PW];
   for (int c = 0; c < nchunks; ++c) {
+    // Without a post_topk tie rule only the first max_out kept candidates (in global score order) are emitted: every NMS_SYNC chunks
+    // the waves add up what they have kept in the chunks so far (all of them final: every wave is past them) and the whole block
+    // stops once that reaches max_out - the RPN keeps 1000 of 10 000 candidates and would otherwise walk all of them.
+    if (post_topk <= 0 && c > 0 && (c & (NMS_SYNC - 1)) == 0) {
+      if (lane == 0) wkept[wv] = count;
+      __syncthreads();
+      int total = 0;
+#pragma unroll
+      for (int w = 0; w < NMS_PW; ++w) total += wkept[w];
+      __syncthreads();
+      if (total >= max_out) break;   // block-uniform
+    }
+    if (done) continue;
     const int row = c * 64 + lane;
     const bool mine = row < nv && (int)((unsigned)cl[row] % NMS_PW) == wv;
     const unsigned long long cm = __ballot(mine);
     if (cm == 0ull) continue;  // wave-uniform
     if (have_kth) {            // post_topk already kept by this wave: stop once its candidates fall below that score
       const int first = c * 64 + (__ffsll((long long)cm) - 1);
-      if (sc[si[first]] < kth) break;
+      if (sc[si[first]] < kth) { done = true; continue; }
     }
     unsigned long long rw = 0ull;
 #pragma unroll
