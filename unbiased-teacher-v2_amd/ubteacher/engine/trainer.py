@@ -277,7 +277,12 @@ class _TrainerBase:
         gs = getattr(self, "_grad_sync", None)
         if gs is not None:
             gs.arm()
-        losses.backward()
+        ops.wgrad_side_stream(True)      # weight gradients on a side stream, next to the dgrad chain (ops._wgrad_launch)
+        try:
+            losses.backward()
+        finally:
+            ops.wgrad_side_stream(False)
+            ops.join_wgrad_stream()      # the optimizer step (and whatever reads the gradient arena) follows on the main stream
 
     def _allreduce_grads(self):
         if self.world_size > 1:

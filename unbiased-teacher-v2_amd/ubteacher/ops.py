@@ -32,6 +32,40 @@ _VERSION = [0]  # bumped by the optimizer step: invalidates cached dgrad weight 
 GRAD_SYNC = [None]  # utils.grad_sync.GradBuckets when data parallel: backward-overlapped all-reduce of the gradient arena
 
 
+# Weight gradients are off the backward's critical path (nothing consumes them before the optimizer step): while the trainer's
+# backward runs (`wgrad_side_stream(True)`), every wgrad launch goes to a side stream and overlaps the dgrad chain of the main one -
+# the backbone's res4 / res5 layers fill 40-80 % of the chip per launch in either direction.  The arguments are recorded on the side
+# stream (the caching allocator must not hand their blocks out again while it still reads them); `join_wgrad_stream()` makes the main
+# stream wait (before the optimizer step / before a gradient bucket is all-reduced).
+_WGRAD = {"on": False, "streams": {}, "pending": set()}
+
+
+def wgrad_side_stream(on):
+    _WGRAD["on"] = bool(on) and os.environ.get("UTV2_WGRAD_STREAM", "1") != "0"
+
+
+def _wgrad_launch(fn, *tensors):
+    dev = tensors[0].device
+    if not _WGRAD["on"] or dev.type != "cuda":
+        return fn()
+    side = _WGRAD["streams"].get(dev)
+    if side is None:
+        side = _WGRAD["streams"][dev] = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))   # the operands (and the zeroed gradient arena) are ready
+    with torch.cuda.stream(side):
+        fn()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    _WGRAD["pending"].add(dev)
+
+
+def join_wgrad_stream():
+    for dev in list(_WGRAD["pending"]):
+        torch.cuda.current_stream(dev).wait_stream(_WGRAD["streams"][dev])
+    _WGRAD["pending"].clear()
+
+
 def _sync_handles(layer, cs=None):
     from .utils.grad_sync import param_handles
     hs = param_handles(layer)
@@ -296,12 +330,12 @@ class _ConvFn(torch.autograd.Function):
                 else:
                     dx = hip.conv2d_ml_dgrad(g, layer.wt(), meta.level_hw, meta.N, layer.k, layer.pad)
             if layer.use_bf16_wgrad():
-                hip.conv2d_wgrad_bf16(x, g, layer.w.g, hip.rowinfo_ml(meta.N, meta.level_hw, layer.pad, layer.k, x.device), layer.cin,
-                                      layer.k, layer.k, accumulate=True, db=layer.bias.g if layer.bias is not None else None,
-                                      rowscale=wsc)
+                _wgrad_launch(lambda: hip.conv2d_wgrad_bf16(
+                    x, g, layer.w.g, hip.rowinfo_ml(meta.N, meta.level_hw, layer.pad, layer.k, x.device), layer.cin, layer.k, layer.k,
+                    accumulate=True, db=layer.bias.g if layer.bias is not None else None, rowscale=wsc), x, g)
                 bias_done = True
             else:
-                hip.conv2d_ml_wgrad(x, g, layer.w.g, meta.level_hw, meta.N, layer.k, layer.pad, accumulate=True)
+                _wgrad_launch(lambda: hip.conv2d_ml_wgrad(x, g, layer.w.g, meta.level_hw, meta.N, layer.k, layer.pad, accumulate=True), x, g)
         else:
             x4 = x.view(1, x.shape[0], 1, x.shape[1]) if meta is not None else x
             g4 = g.view(1, g.shape[0], 1, g.shape[1]) if meta is not None else g
@@ -325,13 +359,14 @@ class _ConvFn(torch.autograd.Function):
             if layer.use_bf16_wgrad():
                 n_, h_, w_, _ = x4.shape
                 ri = hip.rowinfo_nhwc(n_, h_, w_, g4.shape[1], g4.shape[2], layer.stride, layer.pad, layer.k, layer.k, x.device)
-                hip.conv2d_wgrad_bf16(x4, g4.reshape(-1, layer.cout), layer.w.g, ri, layer.cin, layer.k, layer.k, accumulate=True,
-                                      db=layer.bias.g if layer.bias is not None else None, rowscale=wsc)
+                _wgrad_launch(lambda: hip.conv2d_wgrad_bf16(
+                    x4, g4.reshape(-1, layer.cout), layer.w.g, ri, layer.cin, layer.k, layer.k, accumulate=True,
+                    db=layer.bias.g if layer.bias is not None else None, rowscale=wsc), x4, g4)
                 bias_done = True
             else:
-                hip.conv2d_wgrad(x4, g4, layer.w.g, layer.stride, layer.pad, layer.k, layer.k, accumulate=True)
+                _wgrad_launch(lambda: hip.conv2d_wgrad(x4, g4, layer.w.g, layer.stride, layer.pad, layer.k, layer.k, accumulate=True), x4, g4)
         if layer.bias is not None and not bias_done:
-            hip.colsum(g.view(-1, layer.cout), layer.bias.g, accumulate=True)
+            _wgrad_launch(lambda: hip.colsum(g.view(-1, layer.cout), layer.bias.g, accumulate=True), g)
         if GRAD_SYNC[0] is not None:
             GRAD_SYNC[0].on_backward_done(_sync_handles(layer, ctx.cs))
         return dx, gres, None, None, None, None, None
@@ -345,8 +380,8 @@ class _ConvFn(torch.autograd.Function):
 def _wgrad16(layer, x4, g4):
     n_, h_, w_, _ = x4.shape
     ri = hip.rowinfo_nhwc(n_, h_, w_, g4.shape[1], g4.shape[2], layer.stride, layer.pad, layer.k, layer.k, x4.device)
-    hip.conv2d_wgrad_bf16(x4, g4.reshape(-1, layer.cout), layer.w.g, ri, layer.cin, layer.k, layer.k, accumulate=True,
-                          rowscale=layer.bn.scale)
+    _wgrad_launch(lambda: hip.conv2d_wgrad_bf16(x4, g4.reshape(-1, layer.cout), layer.w.g, ri, layer.cin, layer.k, layer.k, accumulate=True,
+                                                rowscale=layer.bn.scale), x4, g4)
 
 
 def _dgrad16(layer, g4, in_shape, mask=None, residual=None, post_mask=None):

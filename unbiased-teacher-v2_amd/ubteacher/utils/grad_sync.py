@@ -75,6 +75,8 @@ class GradBuckets:
         self.launched[b] = True
         self.order.append(b)
         if e > s:
+            from .. import ops
+            ops.join_wgrad_stream()   # this bucket's weight gradients may still be running on the wgrad side stream
             self.works.append(dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
