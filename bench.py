@@ -400,6 +400,30 @@ def worker(args):
         pseudo_count = int(lp["valid"].sum())
     conv, wg = timer.summary(), wtimer.summary()
 
+    # the same launches with the step's side streams off (teacher pass / weight gradients back on the main stream): the dominant kernels
+    # alone on the GPU.  Not part of the timed region - reported beside the in-step figures as `exclusive`.
+    conv_x = wg_x = None
+    if rank == 0 and world == 1 and args.dtype == "bf16":
+        saved = {k: os.environ.get(k) for k in ("UTV2_OVERLAP_TEACHER", "UTV2_WGRAD_STREAM")}
+        os.environ["UTV2_OVERLAP_TEACHER"] = os.environ["UTV2_WGRAD_STREAM"] = "0"
+        ot = getattr(tr, "overlap_teacher", None)
+        if ot is not None:
+            tr.overlap_teacher = False
+        timer.pairs, wtimer.pairs = [], []
+        timer.enabled = wtimer.enabled = True
+        for _ in range(min(args.steps, 5)):
+            tr.run_step_full_semisup(); tr.iter += 1
+        torch.cuda.synchronize()
+        timer.enabled = wtimer.enabled = False
+        conv_x, wg_x = timer.summary(), wtimer.summary()
+        if ot is not None:
+            tr.overlap_teacher = ot
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
     host_ms = None
     if rank == 0 and world == 1:
         # host cost of one step: the same trainer code on 96 x 128 images, where the GPU work is negligible and the step time IS the
@@ -484,11 +508,19 @@ def worker(args):
                                "algorithmic_bytes": conv["alg_bytes"], "algorithmic_GBps": conv["alg_gbps"],
                                "launches": conv["launches"], "avg_us": conv["avg_us"],
                                "time_share": conv["total_ms"] / (1e3 * dt)}
+            if conv_x:
+                out["roofline"]["exclusive"] = {"achieved": conv_x["tflops"], "frac": conv_x["tflops"] / peak, "avg_us": conv_x["avg_us"],
+                                                "launches": conv_x["launches"],
+                                                "note": "same launches, side streams off (UTV2_OVERLAP_TEACHER=0 UTV2_WGRAD_STREAM=0), outside the timed region: "
+                                                        "in the timed region the teacher pass / weight gradients share the CUs with this kernel"}
         if wg:
             out["roofline_wgrad"] = {"bound": "mfma", "kernel": wtimer.kernel, "achieved": wg["tflops"], "peak": peak, "unit": "TFLOP/s",
                                      "frac": wg["tflops"] / peak, "traffic": pmc_traffic("conv_wgrad_bf16_w8"),
                                      "algorithmic_bytes": wg["alg_bytes"], "launches": wg["launches"], "avg_us": wg["avg_us"],
                                      "time_share": wg["total_ms"] / (1e3 * dt)}
+            if wg_x:
+                out["roofline_wgrad"]["exclusive"] = {"achieved": wg_x["tflops"], "frac": wg_x["tflops"] / peak, "avg_us": wg_x["avg_us"],
+                                                      "launches": wg_x["launches"]}
         if f32_rec is not None:
             out["f32"] = f32_rec
         if cpu_rec is not None:

@@ -18,7 +18,19 @@ __global__ __launch_bounds__(512) void k(const unsigned char* src, int iters, in
   f32x4 acc = {0, 0, 0, 0};
   for (int it = 0; it < iters; ++it) {
     const int buf = it & 1;
-    if (MODE == 0 || MODE == 1) {
+    if (MODE >= 5) {
+      // strided pieces as the conv kernels fetch them: MODE 5: 8 rows x 128 B, MODE 6: 16 rows x 64 B, MODE 7: 32 rows x 32 B; row pitch 512 B
+      constexpr int RB = MODE == 5 ? 128 : MODE == 6 ? 64 : 32, LPR = RB / 16, RPP = 64 / LPR;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int piece = q * 8 + wid;                       // 64 pieces of 1 KB = 64 KB, laid out as 512 rows x 128 B in a 512-B-pitch image
+        const int row = (piece * RPP + lane / LPR) % 128, col = (piece * RPP + lane / LPR) / 128;
+        const unsigned char* s = base + (size_t)row * 512 + col * RB + (lane % LPR) * 16;
+        __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(smem + buf * 65536 + piece * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else if (MODE == 0 || MODE == 1) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const unsigned char* s = base + (size_t)((q * 8 + wid) * 1024 + lane * 16);
@@ -86,5 +98,8 @@ int main() {
   run<2>("global_load x4 -> VGPR, drained", d, sink, nwg, iters);
   run<3>("global_load x4 -> VGPR -> ds_write_b128", d, sink, nwg, iters);
   run<4>("half LDS-DMA + half VGPR/ds_write", d, sink, nwg, iters);
+  run<5>("LDS-DMA, pieces of 8 rows x 128 B, pitch 512", d, sink, nwg, iters);
+  run<6>("LDS-DMA, pieces of 16 rows x 64 B, pitch 512", d, sink, nwg, iters);
+  run<7>("LDS-DMA, pieces of 32 rows x 32 B, pitch 512", d, sink, nwg, iters);
   return 0;
 }

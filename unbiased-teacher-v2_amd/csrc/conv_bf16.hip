@@ -737,6 +737,329 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
                           p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Same 256 x 256 tile, 8 waves, 128 x 64 per wave, LDS-DMA staging - scheduled as a PING-PONG: the two waves that share a SIMD never
+// do the same thing at the same time.  In conv_igemm_bf16_w8 all 8 waves run one stream (reads, MFMAs, DMA issue) in loose lockstep,
+// so the matrix pipe idles whenever both waves of a SIMD are in their non-MFMA part (s_memtime trace: ~4200 cycles per 64-deep chunk
+// against the 2048 the 64 MFMAs of a SIMD need).  Here a chunk is cut into two 32-channel SEGMENTS; waves 0-3 (one per SIMD) and waves
+// 4-7 run   LOAD(s) | COMPUTE(s)   one slot apart, slots separated by s_barrier:
+//     slot        4c         4c+1        4c+2        4c+3        4c+4
+//     waves 0-3   LOAD(2c)   COMP(2c)    LOAD(2c+1)  COMP(2c+1)  LOAD(2c+2)
+//     waves 4-7   COMP(2c-1) LOAD(2c)    COMP(2c)    LOAD(2c+1)  COMP(2c+1)
+// LOAD(s): 12 ds_read_b128 (all fragments of the segment: 48 VGPRs) and, in their shadow, the source addresses of the wave's next 4
+// LDS-DMA pieces; COMPUTE(s): 16 MFMAs with those 4 pieces (segment s+3) issued bare behind the 3rd, 7th, 11th and 15th MFMA.  Measured
+// placement costs (tools/probe/pp_trace.hip): a piece issued with its address arithmetic in a LOAD slot stalls the wave 100-200 cycles
+// (all four waves of a half queue on the CU's one address unit), a bare piece between MFMAs ~40.
+// The LDS image is a ring of four 32 KB segment slots ([stage][operand][segment][256 rows][64 B]), a piece = 16 rows x 64 B, the
+// 16-byte slot XOR-swizzled with (row >> 2) & 3 on the source side (conflict-free ds_read_b128).  DMA bookkeeping: segment s+3 goes
+// into the slot of segment s-1, whose last readers finished two barriers earlier, and is first read >= 4 slots after its issue; at the
+// end of every odd slot each wave waits for everything but the batches younger than the segment the next LOAD slot reads (vmcnt(8) /
+// vmcnt(4), loads return in order).  Fragment reads are asm (the compiler would put vmcnt(0) in front of any LDS load it can see while
+// DMA is in flight), their waits tied to the registers.  Same accumulation order as the other kernels: bit-identical outputs.
+#ifdef UTV2_PP_TRACE
+// tools/probe/pp_trace.hip: s_memtime at both ends of every slot of chunks 8..15 of workgroup 0, kept in the unused LDS above the ring
+__device__ unsigned g_pp_trace[8 * 128];
+#define PP_STAMP                                                                                         \
+  if (blockIdx.x == 0 && c >= 8 && c < 16) {                                                             \
+    const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime();                                          \
+    asm volatile("ds_write_b32 %0, %1" : : "v"(tr_addr + 4 * tn), "v"(t_) : "memory");                   \
+    ++tn;                                                                                                \
+  }
+#else
+#define PP_STAMP
+#endif
+#if defined(UTV2_PP_TRACE) && defined(PP_NO_DMA)
+#define PP_DMA(cond) false
+#else
+#define PP_DMA(cond) (cond)
+#endif
+template <bool ML, typename TO>
+__global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
+  constexpr int BM = 256, BN = 256, BK = 64, SEGB = 64;
+  constexpr int OPSEG = 256 * SEGB, OPB = 2 * OPSEG, STAGE = 2 * OPB;  // 16 KB, 32 KB, 64 KB
+  constexpr int TM = 4, TN = 2;
+  constexpr int PATCH = 8 * 32 * (TN * 32 + 4) * 4;
+  static_assert(2 * STAGE >= PATCH, "epilogue patches must fit the staging LDS");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  const int tilesN = (p.K + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  int tile;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int mt = tile / tilesN, nt = tile - mt * tilesN;
+  const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
+  // DMA role of the lane: rows 32 * wid + 16 * j + (lane >> 2) of either operand, the k-slot that belongs in physical slot lane & 3
+  const int prow = lane >> 2;
+  const int kslot = (lane & 3) ^ ((lane >> 4) & 3);
+  const int ntaps = p.KH * p.KW;
+
+  int aoff[2], awc[2];
+  unsigned amask[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + wid * 32 + j * 16 + prow;
+    const bool mv = m < p.M;
+    const int mm = mv ? m : 0;
+    int pb, H, W, ih0, iw0;
+    if constexpr (ML) {
+      int oh, ow;
+      ml_decode16(p.lt, mm, pb, H, W, oh, ow);
+      ih0 = oh - p.pad;
+      iw0 = ow - p.pad;
+    } else {
+      const int hw = p.OH * p.OW;
+      const int n = mm / hw, rem = mm - n * hw;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      ih0 = oh * p.stride - p.pad;
+      iw0 = ow * p.stride - p.pad;
+      pb = n * p.H * p.W;
+      H = p.H;
+      W = p.W;
+    }
+    aoff[j] = (pb + ih0 * W + iw0) * p.xs + kslot * 8;
+    awc[j] = W * p.xs;
+    unsigned mk = 0;
+    for (int kh = 0; kh < p.KH; ++kh)
+      for (int kw = 0; kw < p.KW; ++kw)
+        if (mv && (unsigned)(ih0 + kh) < (unsigned)H && (unsigned)(iw0 + kw) < (unsigned)W) mk |= 1u << (kh * p.KW + kw);
+    amask[j] = mk;
+  }
+  int boff[2];
+  bool bvalid[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int co = n0 + wid * 32 + j * 16 + prow;
+    bvalid[j] = co < p.K;
+    boff[j] = (bvalid[j] ? co : 0) * p.Kred + kslot * 8;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const __bf16* __restrict__ xb = (const __bf16*)p.x;
+  const int nchunks = ntaps * (p.C / BK);
+  int kh = 0, kw = 0, c0 = 0, tap = 0;
+  int ua = 0, ub = 0, ukh = 0, utap = 0;
+  auto cursor_next = [&]() {
+    ua = kw * p.xs + c0;
+    ub = tap * p.C + c0;
+    ukh = kh;
+    utap = tap;
+    ++tap;
+    if (++kw == p.KW) {
+      kw = 0;
+      if (++kh == p.KH) { kh = 0; tap = 0; c0 += BK; }
+    }
+  };
+  const __bf16* zero = (const __bf16*)g_zero64;
+  unsigned char* const dma_row = smem + (wid * 32) * SEGB;  // wave-uniform (M0)
+#ifdef UTV2_PP_TRACE
+  const unsigned tr_addr = (unsigned)(size_t)(lptr_t)smem + 2 * STAGE + wid * 512;
+  int tn = 0;
+  int c = 0;
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  const __bf16* psrc[4];  // sources of the wave's next 4 pieces (0,1: im2col, 2,3: weights), computed in the LOAD slot, issued from the COMPUTE slot
+  auto prep_pieces = [&](int sg) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      psrc[j] = ((amask[j] >> utap) & 1u) ? xb + (unsigned)(aoff[j] + ukh * awc[j] + ua + sg * 32) : zero;
+      psrc[2 + j] = bvalid[j] ? p.w + (unsigned)(boff[j] + ub + sg * 32) : zero;
+    }
+  };
+  auto issue_piece = [&](int stage, int sg, int q) {
+    unsigned char* d = dma_row + stage * STAGE + sg * OPSEG + (q >> 1) * OPB + (q & 1) * 16 * SEGB;
+    __builtin_amdgcn_global_load_lds((gptr_t)psrc[q], (lptr_t)d, 16, 0, 0);
+  };
+
+  const int frow = lane & 31, fh = lane >> 5, fx = (frow >> 2) & 3;
+  const unsigned lbase = (unsigned)(size_t)(lptr_t)smem;
+  unsigned a_addr[2], b_addr[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    a_addr[ks] = lbase + (wm * 128 + frow) * SEGB + (((ks * 2 + fh) ^ fx) << 4);
+    b_addr[ks] = lbase + OPB + (wn * 64 + frow) * SEGB + (((ks * 2 + fh) ^ fx) << 4);
+  }
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  i32x4 fa[2][TM], fb[2][TN];
+#if defined(UTV2_PP_TRACE) && defined(PP_NO_READ)
+  for (int ks = 0; ks < 2; ++ks) {
+    for (int i = 0; i < TM; ++i) fa[ks][i] = i32x4{lane, 1, 2, 3};
+    for (int j = 0; j < TN; ++j) fb[ks][j] = i32x4{lane, 1, 2, 3};
+  }
+#endif
+  unsigned aa0, aa1, bb0, bb1;
+#define PP_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#if defined(UTV2_PP_TRACE) && defined(PP_NO_READ)
+#define PP_LOAD_SEG(SG)
+#else
+#define PP_LOAD_SEG(SG)                                                                                        \
+  PP_READ(fa[0][0], aa0, (SG) * OPSEG); PP_READ(fa[0][1], aa0, (SG) * OPSEG + 2048);                           \
+  PP_READ(fa[0][2], aa0, (SG) * OPSEG + 4096); PP_READ(fa[0][3], aa0, (SG) * OPSEG + 6144);                    \
+  PP_READ(fb[0][0], bb0, (SG) * OPSEG); PP_READ(fb[0][1], bb0, (SG) * OPSEG + 2048);                           \
+  PP_READ(fa[1][0], aa1, (SG) * OPSEG); PP_READ(fa[1][1], aa1, (SG) * OPSEG + 2048);                           \
+  PP_READ(fa[1][2], aa1, (SG) * OPSEG + 4096); PP_READ(fa[1][3], aa1, (SG) * OPSEG + 6144);                    \
+  PP_READ(fb[1][0], bb1, (SG) * OPSEG); PP_READ(fb[1][1], bb1, (SG) * OPSEG + 2048)
+#endif
+#define PP_WAIT_FRAGS                                                                                                         \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                                         \
+               : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), \
+                 "+v"(fa[1][3]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]))
+#define PP_VMWAIT(last, N)                                          \
+  if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        \
+  else asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define PP_BARRIER                          \
+  __builtin_amdgcn_sched_barrier(0);        \
+  __builtin_amdgcn_s_barrier();             \
+  __builtin_amdgcn_sched_barrier(0)
+  auto compute = [&](bool with_dma, int stage, int sg) {  // 16 MFMAs; the wave's 4 pieces of a later segment go out behind the 3rd, 7th, 11th, 15th
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[ks][i]), __builtin_bit_cast(bf16x8_t, fb[ks][j]),
+                                                              acc[i][j], 0, 0, 0);
+          const int n = (ks * TM + i) * TN + j;
+          if ((n & 3) == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (with_dma) issue_piece(stage, sg, n >> 2);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+  };
+
+  // prologue: segments 0, 1 (chunk 0) and 2 (chunk 1); the cursor stays on chunk 1
+  cursor_next();
+#pragma unroll
+  for (int sg = 0; sg < 2; ++sg) {
+    prep_pieces(sg);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_piece(0, sg, q);
+  }
+  if (nchunks > 1) {
+    cursor_next();
+    prep_pieces(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_piece(1, 0, q);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PP_BARRIER;
+  // C(2c) sends segment 2c+3 = (chunk c+1, segment 1), C(2c+1) segment 2c+4 = (chunk c+2, segment 0) - into the ring slot whose last
+  // readers finished two barriers earlier.  Waits (end of every odd slot): everything but the batches younger than the segment the
+  // next LOAD slot reads.
+  if (wm == 0) {
+#ifdef UTV2_PP_TRACE
+    for (c = 0; c < nchunks; ++c) {
+#else
+    for (int c = 0; c < nchunks; ++c) {
+#endif
+      const int st = c & 1;
+      const bool more1 = c + 1 < nchunks, more2 = c + 2 < nchunks;
+      aa0 = a_addr[0] + st * STAGE; aa1 = a_addr[1] + st * STAGE; bb0 = b_addr[0] + st * STAGE; bb1 = b_addr[1] + st * STAGE;
+      PP_STAMP;
+      PP_LOAD_SEG(0);
+      if (more1) prep_pieces(1);
+      PP_WAIT_FRAGS;
+      PP_STAMP;
+      PP_BARRIER;
+      PP_STAMP;
+      compute(PP_DMA(more1), st ^ 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PP_STAMP;
+      PP_BARRIER;
+      PP_STAMP;
+      PP_LOAD_SEG(1);
+      if (more2) { cursor_next(); prep_pieces(0); }
+      PP_WAIT_FRAGS;
+      PP_STAMP;
+      PP_BARRIER;
+      PP_STAMP;
+      compute(PP_DMA(more2), st, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (more1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PP_STAMP;
+      PP_BARRIER;
+    }
+    PP_BARRIER;
+  } else {
+    PP_BARRIER;
+#ifdef UTV2_PP_TRACE
+    for (c = 0; c < nchunks; ++c) {
+#else
+    for (int c = 0; c < nchunks; ++c) {
+#endif
+      const int st = c & 1;
+      const bool more1 = c + 1 < nchunks, more2 = c + 2 < nchunks;
+      aa0 = a_addr[0] + st * STAGE; aa1 = a_addr[1] + st * STAGE; bb0 = b_addr[0] + st * STAGE; bb1 = b_addr[1] + st * STAGE;
+      PP_STAMP;
+      PP_LOAD_SEG(0);
+      if (more1) prep_pieces(1);
+      PP_WAIT_FRAGS;
+      if (more1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PP_STAMP;
+      PP_BARRIER;
+      PP_STAMP;
+      compute(PP_DMA(more1), st ^ 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      PP_STAMP;
+      PP_BARRIER;
+      PP_STAMP;
+      PP_LOAD_SEG(1);
+      if (more2) { cursor_next(); prep_pieces(0); }
+      PP_WAIT_FRAGS;
+      if (more1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PP_STAMP;
+      PP_BARRIER;
+      PP_STAMP;
+      compute(PP_DMA(more2), st, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      PP_STAMP;
+      PP_BARRIER;
+    }
+  }
+#undef PP_READ
+#undef PP_LOAD_SEG
+#undef PP_WAIT_FRAGS
+#undef PP_VMWAIT
+#undef PP_BARRIER
+  __syncthreads();
+#ifdef UTV2_PP_TRACE
+  if (blockIdx.x == 0) {
+    for (int i = tid; i < 8 * 128; i += 512) g_pp_trace[i] = ((const unsigned*)(smem + 2 * STAGE))[i];
+    __syncthreads();
+    if (tid == 0) {  // shader clock: s_memtime ticks per 100 MHz s_memrealtime tick over the main loop
+      g_pp_trace[126] = (unsigned)(__builtin_amdgcn_s_memtime() - clk0);
+      g_pp_trace[127] = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt0);
+    }
+  }
+#endif
+
+  float* patch = (float*)smem + wid * (32 * (TN * 32 + 4));
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+    epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[2 * half], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
+                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask);
+}
+
 // A/B switches for bench runs and tests, read ONCE per process (never on the launch path): UTV2_W8=0 keeps every forward / dgrad
 // row on the 128 x 128 kernel, UTV2_WGRAD_W8=0 keeps every wgrad on the 128 x 128 kernel.
 static bool env_flag_on(const char* name) {
@@ -750,6 +1073,7 @@ static int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 static const int g_wgrad_debug = env_int("UTV2_WGRAD_DEBUG", 0);
+static const int g_use_pp = env_int("UTV2_PP", 1);  // 256 x 256 forward tile: 1 = ping-pong schedule, 0 = conv_igemm_bf16_w8
 
 template <int BN, bool ML>
 static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dtype, hipStream_t stream) {
@@ -779,9 +1103,14 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
         if (!attr_done) {
           (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_w8<ML, __bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
           (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_w8<ML, float>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_pp<ML, __bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_pp<ML, float>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
           attr_done = true;
         }
-        if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_w8<ML, __bf16>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
+        if (g_use_pp) {
+          if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, __bf16>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
+          else hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, float>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
+        } else if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_w8<ML, __bf16>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
         else hipLaunchKernelGGL((conv_igemm_bf16_w8<ML, float>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
         if (m.M == a.M) return;
         ConvArgs16 r = a;

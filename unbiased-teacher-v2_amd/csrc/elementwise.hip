@@ -470,18 +470,29 @@ __global__ __launch_bounds__(256) void gn_bwd_partial(GnSegs sg, const T* __rest
 
 // backward stage 2 (one block per segment): AB[seg][c][2] = sum over the segment's chunks; s1 = sum_c gamma*A,
 // s2 = sum_c gamma*B per group.
-__global__ __launch_bounds__(256) void gn_bwd_reduce(GnSegs sg, const float* __restrict__ part, const float* __restrict__ gamma,
-                                                   float* __restrict__ AB, float* __restrict__ s12, int C, int G) {
+__global__ __launch_bounds__(1024) void gn_bwd_reduce(GnSegs sg, const float* __restrict__ part, const float* __restrict__ gamma,
+                                                    float* __restrict__ AB, float* __restrict__ s12, int C, int G) {
   const int seg = blockIdx.x;
   const int cpg = C / G;
-  extern __shared__ float sh[];  // [C][2]
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  extern __shared__ float sh[];  // [C][2] then 4 x [C][2] partial sums
+  float* ps = sh + 2 * C;
+  const int k0 = sg.chunk0[seg], k1 = sg.chunk0[seg + 1];
+  // 4 interleaved chunk walks per channel (the largest level has 50 chunks per image), combined in a fixed order
+  for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) {
+    const int c = i % C, q = i / C;
     float a = 0.f, b = 0.f;
-    for (int k = sg.chunk0[seg]; k < sg.chunk0[seg + 1]; ++k) {
-      const float* p = part + ((size_t)k * C + c) * 2;
-      a += p[0];
-      b += p[1];
+    for (int k = k0 + q; k < k1; k += 4) {
+      const float2 v = *(const float2*)(part + ((size_t)k * C + c) * 2);
+      a += v.x;
+      b += v.y;
     }
+    ps[(q * C + c) * 2] = a;
+    ps[(q * C + c) * 2 + 1] = b;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float a = (ps[c * 2] + ps[(C + c) * 2]) + (ps[(2 * C + c) * 2] + ps[(3 * C + c) * 2]);
+    const float b = (ps[c * 2 + 1] + ps[(C + c) * 2 + 1]) + (ps[(2 * C + c) * 2 + 1] + ps[(3 * C + c) * 2 + 1]);
     AB[((size_t)seg * C + c) * 2] = a;
     AB[((size_t)seg * C + c) * 2 + 1] = b;
     sh[c * 2] = a * gamma[c];
@@ -499,16 +510,26 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce(GnSegs sg, const float* __r
   }
 }
 
-__global__ void gn_bwd_param(const float* __restrict__ AB, float* __restrict__ dgamma, float* __restrict__ dbeta, int S, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void gn_bwd_param(const float* __restrict__ AB, float* __restrict__ dgamma, float* __restrict__ dbeta, int S,
+                                                     int C) {
+  // 64 channels x 4 segment parts per block (one thread per channel walked the S segments alone: 16 us of pure load latency);
+  // the parts are combined in a fixed order
+  __shared__ float ra[256], rb[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
   float a = 0.f, b = 0.f;
-  for (int n = 0; n < S; ++n) {
-    a += AB[((size_t)n * C + c) * 2];
-    b += AB[((size_t)n * C + c) * 2 + 1];
+  if (c < C)
+    for (int n = part; n < S; n += 4) {
+      const float2 v = *(const float2*)(AB + ((size_t)n * C + c) * 2);
+      a += v.x;
+      b += v.y;
+    }
+  ra[threadIdx.x] = a;
+  rb[threadIdx.x] = b;
+  __syncthreads();
+  if (part == 0 && c < C) {
+    dgamma[c] += (ra[threadIdx.x] + ra[threadIdx.x + 64]) + (ra[threadIdx.x + 128] + ra[threadIdx.x + 192]);
+    dbeta[c] += (rb[threadIdx.x] + rb[threadIdx.x + 64]) + (rb[threadIdx.x + 128] + rb[threadIdx.x + 192]);
   }
-  dgamma[c] += a;
-  dbeta[c] += b;
 }
 
 // backward stage 3: dx = rstd * (g*gamma - (s2 + xhat*s1)/cnt)
@@ -590,8 +611,8 @@ static void gn_bwd_launch(const GnSegs& sg, int chunks, int nseg, const void* dy
   float* s12 = AB + (size_t)nseg * C * 2;
   hipLaunchKernelGGL(gn_bwd_partial<T>, dim3(chunks), dim3(256), 0, stream, sg, (const T*)dy, (const T*)y, (const T*)x, mean, rstd,
                      gamma, beta, part, C, G, relu);
-  hipLaunchKernelGGL(gn_bwd_reduce, dim3(nseg), dim3(256), 2 * C * sizeof(float), stream, sg, (const float*)part, gamma, AB, s12, C, G);
-  hipLaunchKernelGGL(gn_bwd_param, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)AB, dgamma, dbeta, nseg, C);
+  hipLaunchKernelGGL(gn_bwd_reduce, dim3(nseg), dim3(1024), 10 * C * sizeof(float), stream, sg, (const float*)part, gamma, AB, s12, C, G);
+  hipLaunchKernelGGL(gn_bwd_param, dim3(cdiv(C, 64)), dim3(256), 0, stream, (const float*)AB, dgamma, dbeta, nseg, C);
   hipLaunchKernelGGL(gn_bwd_apply<T>, dim3(chunks), dim3(256), 0, stream, sg, (const T*)dy, (const T*)y, (const T*)x, mean, rstd,
                      gamma, beta, (const float*)s12, (T*)dx, C, G, relu);
 }
