@@ -287,6 +287,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-warmup", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-images", type=int, default=1, help="labeled and unlabeled images of the CPU baseline sample (SURVEY 8d protocol: 2)")
+    ap.add_argument("--timed-only", action="store_true", help="only the warmup and the timed steps (profiling runs): no exclusive pass, no host probe")
     ap.add_argument("--no-f32", action="store_true", help="skip the f32 sub-record / the bf16-vs-f32 one-step loss deviation")
     ap.add_argument("--model", choices=["fcos", "rcnn"], default="fcos",
                     help="fcos: BASELINE configs[1] (the headline workload); rcnn: the Faster-RCNN UTv2 trainer of configs[2] / [4] on the same "
@@ -403,7 +404,7 @@ def worker(args):
     # the same launches with the step's side streams off (teacher pass / weight gradients back on the main stream): the dominant kernels
     # alone on the GPU.  Not part of the timed region - reported beside the in-step figures as `exclusive`.
     conv_x = wg_x = None
-    if rank == 0 and world == 1 and args.dtype == "bf16":
+    if rank == 0 and world == 1 and args.dtype == "bf16" and not args.timed_only:
         saved = {k: os.environ.get(k) for k in ("UTV2_OVERLAP_TEACHER", "UTV2_WGRAD_STREAM")}
         os.environ["UTV2_OVERLAP_TEACHER"] = os.environ["UTV2_WGRAD_STREAM"] = "0"
         ot = getattr(tr, "overlap_teacher", None)
@@ -425,7 +426,7 @@ def worker(args):
                 os.environ[k] = v
 
     host_ms = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.timed_only:
         # host cost of one step: the same trainer code on 96 x 128 images, where the GPU work is negligible and the step time IS the
         # Python / launch overhead (on the 1333 x 800 batch the host runs ahead until the launch queue is full, so its enqueue time
         # only mirrors the GPU time)

@@ -221,6 +221,18 @@ int utv2_roi_align_bwd(int num_levels, int min_level, float* const* dfeats_host,
 int utv2_roi_align_bwd_tiled(int num_levels, int min_level, void* const* dfeats_host, const int* H_host, const int* W_host,
                              const float* scales_host, const float* rois, const unsigned char* roi_valid, int N, int rois_per_image,
                              int C, int PH, int PW, const void* dy, int dy_dtype, int out_dtype, utv2_stream_t stream);
+/* RPN proposal decoding, the part of detectron2's RPN.predict_proposals / find_top_rpn_proposals in front of the NMS that
+ * proposal_generator/rpn.py:60-76 inherits.  head: level-first RPN head output, rows (level, image, pixel) x ch floats = A objectness
+ * logits then 4A anchor-major deltas; hw_host[l] = pixels of level l.
+ * rank_keys: keys[t] for every logit in memory order (rows x A), 63-bit, descending key order == (logit desc, anchor index asc) within
+ * the logit's (level, image) row - the input of utv2_topk_rows_i64.
+ * decode: top = [num_levels * N][maxk] selected keys (-1 = empty), k_host[l] candidates kept per image on level l; writes, per image,
+ * the K = sum k_l candidates in level order: boxes [N][K][4] (apply_deltas with weights_host[4], clipped to image_hw[n] = (h, w)),
+ * scores (0 where non-finite), lvls, keep (finite and both sides > min_size). */
+int utv2_rpn_rank_keys(const float* head, int num_levels, const int* hw_host, int N, int A, int ch, int64_t* keys, utv2_stream_t stream);
+int utv2_rpn_decode(const int64_t* top, int maxk, const float* head, const float* anchors, const float* image_hw, int num_levels,
+                    const int* hw_host, const int* k_host, int N, int A, int ch, const float* weights_host, float scale_clamp,
+                    float min_size, float* boxes, float* scores, int* lvls, unsigned char* keep, utv2_stream_t stream);
 /* roi_heads/fast_rcnn.py:925-936 + FocalLoss :1405-1429 (softmax CE focal, gamma 1.5), summed */
 int utv2_softmax_focal_fwd(const float* logits, const int* target, int R, int C, float gamma, float* loss_sum, float* ws,
                            utv2_stream_t stream);

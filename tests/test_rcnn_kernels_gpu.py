@@ -242,14 +242,59 @@ def test_rpn_pre_nms_topk_radix_select_equals_torch_topk():
     g = torch.Generator(device="cuda").manual_seed(1)
     big = torch.randn(meta.P, RPN_CH, device="cuda", generator=g) * 3
     big[:, :3] = torch.round(big[:, :3] * 4) / 4            # many exact ties
-    top = rpn._pre_nms_topk(big, N, hw)
+    top, ks = rpn._pre_nms_topk(big, N, hw)
     obj, _ = rpn._per_image_views(big, N, hw)
     pre = rpn.pre_nms_topk[rpn.training]
     for l, o in enumerate(obj):
         k = min(pre, o.shape[1])
+        assert ks[l] == k
         ref = torch.topk(float_order_key(o), k, dim=1, sorted=True).values
         ref_idx = 4294967295 - (ref & 4294967295)
-        assert torch.equal(top[l], ref_idx), l
+        got = 2147483647 - (top[l * N:(l + 1) * N, :k] & 2147483647)
+        assert torch.equal(got, ref_idx), l
+
+
+def test_rpn_fused_decode_equals_elementwise_chain():
+    """utv2_rpn_rank_keys + utv2_rpn_decode (one launch for gather / apply_deltas / clip / keep over all levels) against
+    PseudoLabRPN.predict_proposals' per-level ATen chain on the same head output: identical candidate boxes, scores, levels and keep
+    masks, hence identical proposals after the NMS.  Includes deltas beyond SCALE_CLAMP, boxes pushed outside the image, boxes
+    that shrink below MIN_SIZE after clipping, a NaN and an inf logit / delta, and ragged image sizes."""
+    from ubteacher import hip, ops
+    from ubteacher.modeling.rcnn import RPN_CH, SCALE_CLAMP
+    from ubteacher.modeling import build_model
+    from ubteacher.presets import get_config
+    cfg = get_config("rcnn", 1, ["MODEL.DEVICE", "cuda"])
+    torch.manual_seed(0)
+    rpn = build_model(cfg).proposal_generator
+    N, hw = 3, [(40, 56), (20, 28), (10, 14), (5, 7), (3, 4)]
+    sizes = [(160, 224), (150, 200), (97, 131)]
+    meta = ops.LevelMeta(N, hw)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    big = torch.randn(meta.P, RPN_CH, device="cuda", generator=g)
+    big[:, 3:15] *= 1.5                                       # some dw / dh beyond log(1000 / 16) after the next line
+    big[::37, 5] = 9.0
+    big[::41, 3] = -40.0                                      # pushed far outside: clipped to zero width
+    big[11, 0] = float("nan"); big[13, 4] = float("inf"); big[17, 1] = float("-inf")
+    anchors = rpn.anchor_generator(hw, big.device)
+    for training in (True, False):
+        rpn.train(training)
+        obj, dl = rpn._per_image_views(big, N, hw)
+        ref = rpn.predict_proposals(anchors, obj, dl, sizes)
+        sel = rpn._pre_nms_topk(big, N, hw)
+        got = rpn._proposals_fused(big, anchors, sel, hw, N, sizes)
+        assert torch.equal(got["count"], ref["count"])
+        assert torch.equal(got["valid"], ref["valid"])
+        m = ref["valid"].bool()
+        assert torch.equal(got["boxes"][m], ref["boxes"][m])
+        assert torch.equal(got["objectness_logits"][m], ref["objectness_logits"][m])
+        # the candidate tensors themselves
+        top, ks = sel
+        boxes, scores, lvls, keep = hip.rpn_decode(top, big, torch.cat(anchors).contiguous(),
+                                                   torch.tensor([[s[0], s[1]] for s in sizes], dtype=torch.float32, device="cuda"),
+                                                   [h * w for h, w in hw], ks, N, rpn.A, rpn.box_weights, SCALE_CLAMP, rpn.min_box_size)
+        assert int(keep.sum()) > 0 and int((keep == 0).sum()) > 0
+        assert torch.equal(lvls[0].cpu(), torch.repeat_interleave(torch.arange(len(hw), dtype=torch.int32), torch.tensor(ks)))
+    rpn.train(True)
 
 
 def test_roi_align_bwd_tiled_gather_equals_scatter_and_is_deterministic():

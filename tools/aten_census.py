@@ -18,31 +18,37 @@ tr.iter = 1; tr.log_period = 10 ** 9
 for _ in range(3):
     tr.run_step_full_semisup(); tr.iter += 1
 torch.cuda.synchronize()
-from torch.profiler import profile, ProfilerActivity
+import traceback
+from torch.utils._python_dispatch import TorchDispatchMode
 K = 2
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+agg = collections.Counter()
+
+
+class Census(TorchDispatchMode):
+    """every ATen op that reaches the dispatcher with a CUDA tensor, keyed by the innermost frame inside the package"""
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        flat = [a for a in list(args) + list((kwargs or {}).values()) + ([out] if isinstance(out, torch.Tensor) else list(out) if isinstance(out, (tuple, list)) else [])
+                if isinstance(a, torch.Tensor)]
+        if any(t.is_cuda for t in flat):
+            name = str(func).replace("aten.", "")
+            if not any(name.startswith(v) for v in ("view", "_unsafe_view", "reshape", "permute", "transpose", "slice", "select", "expand", "as_strided",
+                                                    "unsqueeze", "squeeze", "detach", "alias", "t.", "empty", "unbind", "split", "_local_scalar", "narrow", "new_empty")):
+                where = "?"
+                for fr in reversed(traceback.extract_stack()):
+                    if "unbiased-teacher-v2_amd" in fr.filename and "torch" not in fr.filename.split("unbiased-teacher-v2_amd")[-1]:
+                        where = "%s:%d %s" % (fr.filename.split("unbiased-teacher-v2_amd/")[-1], fr.lineno, fr.name)
+                        break
+                agg[(name, where)] += 1
+        return out
+
+
+with Census():
     for _ in range(K):
         tr.run_step_full_semisup(); tr.iter += 1
     torch.cuda.synchronize()
-agg = collections.Counter()
-kern = collections.Counter()
-for ev in prof.events():
-    if ev.device_type == torch.autograd.DeviceType.CUDA if hasattr(torch.autograd, "DeviceType") else False:
-        continue
-for ev in prof.events():
-    name = ev.name
-    if not name.startswith("aten::"):
-        continue
-    # only leaf-ish ops that launch kernels
-    if not ev.kernels:
-        continue
-    where = "?"
-    for fr in (ev.stack or []):
-        if "unbiased-teacher-v2_amd" in fr or "bench.py" in fr:
-            where = fr.split("unbiased-teacher-v2_amd/")[-1]
-            break
-    agg[(name, where)] += len(ev.kernels)
 tot = sum(agg.values())
-print("ATen kernel launches per step: %.1f" % (tot / K))
-for (name, where), n in agg.most_common(70):
+print("ATen ops on CUDA tensors per step (views excluded): %.1f" % (tot / K))
+for (name, where), n in agg.most_common(90):
     print("%6.1f  %-28s %s" % (n / K, name, where))

@@ -493,6 +493,83 @@ __global__ void sum_partials_f32(const float* __restrict__ partial, int n, float
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// RPN proposal decoding (D2 find_top_rpn_proposals up to the NMS [D2-recall]; proposal_generator/rpn.py runs it through
+// detectron2's RPN.predict_proposals).  The head output is level-first: rows (level, image, pixel) x ch floats, the A objectness
+// logits first, then the 4A deltas (anchor-major).
+#define RPN_MAX_LEVELS 8
+struct RpnLevels {
+  int n;
+  int row0[RPN_MAX_LEVELS];     // first head-output row of the level (N * hw rows per level)
+  int hw[RPN_MAX_LEVELS];
+  int anchor0[RPN_MAX_LEVELS];  // first anchor of the level in the concatenated anchor table
+  int out0[RPN_MAX_LEVELS + 1]; // first candidate slot of the level in the per-image output (k_l = out0[l+1] - out0[l])
+};
+
+// sortable keys of every objectness logit, in memory order: descending key order == (logit desc, anchor index asc) inside the
+// (level, image) row the logit belongs to; 63-bit non-negative (the select kernel's negative = empty)
+__global__ __launch_bounds__(256) void rpn_rank_keys_kernel(RpnLevels L, const float* __restrict__ head, int N, int A, int ch,
+                                                          long long total, long long* __restrict__ keys) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int r = (int)(t / A), a = (int)(t - (long long)r * A);
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < RPN_MAX_LEVELS; ++i)
+    if (i < L.n && r >= L.row0[i]) l = i;
+  const int p = (r - L.row0[l]) % L.hw[l];
+  const int bits = __float_as_int(head[(size_t)r * ch + a]);
+  const long long mono = (long long)(bits ^ ((bits >> 31) & 0x7FFFFFFF)) + 2147483648ll;
+  keys[t] = mono * 2147483648ll + (2147483647ll - ((long long)p * A + a));
+}
+
+// one thread per (image, candidate): anchor index from the selected key, Box2BoxTransform.apply_deltas (separately rounded mul / add
+// as the elementwise reference chain), clip to the image, the finite / min-size keep mask
+__global__ __launch_bounds__(256) void rpn_decode_kernel(RpnLevels L, const long long* __restrict__ top, int maxk, const float* __restrict__ head,
+                                                       const float* __restrict__ anchors, const float* __restrict__ image_hw, int N, int A,
+                                                       int ch, float wx, float wy, float ww, float wh, float scale_clamp, float min_size,
+                                                       float* __restrict__ boxes, float* __restrict__ scores, int* __restrict__ lvls,
+                                                       unsigned char* __restrict__ keep) {
+  const int K = L.out0[L.n];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (j >= K) return;
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < RPN_MAX_LEVELS; ++i)
+    if (i < L.n && j >= L.out0[i]) l = i;
+  const size_t o = (size_t)n * K + j;
+  const long long key = top[((size_t)l * N + n) * maxk + (j - L.out0[l])];
+  lvls[o] = l;
+  if (key < 0) {
+    *(float4*)(boxes + o * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    scores[o] = 0.f;
+    keep[o] = 0;
+    return;
+  }
+  const int idx = (int)(2147483647ll - (key & 2147483647ll));
+  const int p = idx / A, a = idx - p * A;
+  const float* hrow = head + ((size_t)L.row0[l] + (size_t)n * L.hw[l] + p) * ch;
+  const float sc = hrow[a];
+  const float4 an = *(const float4*)(anchors + ((size_t)L.anchor0[l] + idx) * 4);
+  const float d0 = hrow[A + a * 4], d1 = hrow[A + a * 4 + 1], d2 = hrow[A + a * 4 + 2], d3 = hrow[A + a * 4 + 3];
+  const float w = an.z - an.x, h = an.w - an.y;
+  const float cx = an.x + 0.5f * w, cy = an.y + 0.5f * h;
+  const float dx = d0 / wx, dy = d1 / wy;
+  float dw = d2 / ww, dh = d3 / wh;
+  dw = dw > scale_clamp ? scale_clamp : dw;   // torch.clamp(max=): NaN stays NaN
+  dh = dh > scale_clamp ? scale_clamp : dh;
+  const float pcx = dx * w + cx, pcy = dy * h + cy;
+  const float pw = expf(dw) * w, ph = expf(dh) * h;
+  float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+  const bool finite = isfinite(x1) && isfinite(y1) && isfinite(x2) && isfinite(y2) && isfinite(sc);
+  const float H = image_hw[n * 2], W = image_hw[n * 2 + 1];
+  x1 = x1 < 0.f ? 0.f : x1; y1 = y1 < 0.f ? 0.f : y1; x2 = x2 < 0.f ? 0.f : x2; y2 = y2 < 0.f ? 0.f : y2;
+  x1 = x1 > W ? W : x1; y1 = y1 > H ? H : y1; x2 = x2 > W ? W : x2; y2 = y2 > H ? H : y2;
+  *(float4*)(boxes + o * 4) = make_float4(x1, y1, x2, y2);
+  scores[o] = finite ? sc : 0.f;
+  keep[o] = (finite && (x2 - x1) > min_size && (y2 - y1) > min_size) ? 1 : 0;
+}
+
 extern "C" {
 
 // boxes: [N][P][4] (box_img_stride = P*4) or shared anchors [P][4] (box_img_stride = 0).
@@ -621,6 +698,50 @@ int utv2_softmax_focal_bwd(const float* logits, const int* target, int R, int C,
   if (R == 0) return UTV2_OK;
   hipLaunchKernelGGL(softmax_focal_bwd_kernel, dim3(cdiv(R, 4) > 4096 ? 4096 : cdiv(R, 4)), dim3(256), 0, stream, logits, target,
                      R, C, gamma, coef, dlogits);
+  return utv2_launch_status();
+}
+
+static int fill_rpn_levels(RpnLevels& L, int num_levels, int N, const int* hw_host, const int* k_host, int A) {
+  if (num_levels < 1 || num_levels > RPN_MAX_LEVELS || !hw_host) return UTV2_EARG;
+  L.n = num_levels;
+  int row = 0, anc = 0, out = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    if (hw_host[l] < 1) return UTV2_EARG;
+    L.row0[l] = row; L.hw[l] = hw_host[l]; L.anchor0[l] = anc; L.out0[l] = out;
+    row += N * hw_host[l];
+    anc += hw_host[l] * A;
+    out += k_host ? k_host[l] : 0;
+  }
+  L.out0[num_levels] = out;
+  return UTV2_OK;
+}
+
+int utv2_rpn_rank_keys(const float* head, int num_levels, const int* hw_host, int N, int A, int ch, int64_t* keys, hipStream_t stream) {
+  RpnLevels L;
+  if (!head || !keys || N < 1 || A < 1 || ch < 5 * A) return UTV2_EARG;
+  if (int e = fill_rpn_levels(L, num_levels, N, hw_host, nullptr, A)) return e;
+  long long rows = 0;
+  for (int l = 0; l < num_levels; ++l) rows += (long long)N * hw_host[l];
+  const long long total = rows * A;
+  hipLaunchKernelGGL(rpn_rank_keys_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, L, head, N, A, ch, total, (long long*)keys);
+  return utv2_launch_status();
+}
+
+int utv2_rpn_decode(const int64_t* top, int maxk, const float* head, const float* anchors, const float* image_hw, int num_levels,
+                    const int* hw_host, const int* k_host, int N, int A, int ch, const float* weights_host, float scale_clamp,
+                    float min_size, float* boxes, float* scores, int* lvls, unsigned char* keep, hipStream_t stream) {
+  RpnLevels L;
+  if (!top || !head || !anchors || !image_hw || !k_host || !weights_host || !boxes || !scores || !lvls || !keep || N < 1 || A < 1 ||
+      ch < 5 * A)
+    return UTV2_EARG;
+  if (int e = fill_rpn_levels(L, num_levels, N, hw_host, k_host, A)) return e;
+  for (int l = 0; l < num_levels; ++l)
+    if (k_host[l] < 0 || k_host[l] > maxk) return UTV2_EARG;
+  const int K = L.out0[num_levels];
+  if (K == 0) return UTV2_OK;
+  hipLaunchKernelGGL(rpn_decode_kernel, dim3(cdiv(K, 256), N), dim3(256), 0, stream, L, (const long long*)top, maxk, head, anchors, image_hw,
+                     N, A, ch, weights_host[0], weights_host[1], weights_host[2], weights_host[3], scale_clamp, min_size, boxes, scores,
+                     lvls, keep);
   return utv2_launch_status();
 }
 

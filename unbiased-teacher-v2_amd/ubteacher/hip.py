@@ -553,6 +553,30 @@ def roi_align_bwd_tiled(shapes, out_dtype, scales, min_level, rois, roi_valid, d
     return dfeats
 
 
+def rpn_rank_keys(head, hw, N, A):
+    """sortable int64 keys of every objectness logit of the level-first RPN head output, in memory order (the rows of utv2_topk_rows_i64)"""
+    rows, ch = head.shape
+    assert head.dtype == torch.float32 and rows == N * sum(hw)
+    keys = torch.empty(rows * A, dtype=torch.int64, device=head.device)
+    call("utv2_rpn_rank_keys", _p(head), len(hw), ctypes.cast(_iarr(hw), c_p), N, A, ch, _p(keys), _stream())
+    return keys
+
+
+def rpn_decode(top, head, anchors, image_hw, hw, ks, N, A, weights, scale_clamp, min_size):
+    """selected keys [L*N, maxk] -> per image the sum(ks) candidates in level order: boxes [N,K,4], scores [N,K], lvls int32, keep uint8"""
+    K = int(sum(ks))
+    dev = head.device
+    boxes = torch.empty((N, K, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((N, K), dtype=torch.float32, device=dev)
+    lvls = torch.empty((N, K), dtype=torch.int32, device=dev)
+    keep = torch.empty((N, K), dtype=torch.uint8, device=dev)
+    assert top.dtype == torch.int64 and top.shape[0] == len(hw) * N and anchors.dtype == torch.float32 and image_hw.dtype == torch.float32
+    call("utv2_rpn_decode", _p(top), top.shape[1], _p(head), _p(anchors), _p(image_hw), len(hw), ctypes.cast(_iarr(hw), c_p),
+         ctypes.cast(_iarr(ks), c_p), N, A, head.shape[1], ctypes.cast(_farr(weights), c_p), float(scale_clamp),
+         float(min_size), _p(boxes), _p(scores), _p(lvls), _p(keep), _stream())
+    return boxes, scores, lvls, keep
+
+
 def softmax_focal_fwd(logits, target, gamma):
     R, C = logits.shape
     out = torch.empty(1, dtype=torch.float32, device=logits.device)

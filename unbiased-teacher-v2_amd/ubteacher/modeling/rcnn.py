@@ -214,17 +214,21 @@ class PseudoLabRPN:
             losses = self.losses(torch.cat(anchors), torch.cat(obj, 1), torch.cat(dl, 1), gt)
             losses = {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}  # applied twice
         with torch.no_grad():
-            obj, dl = self._per_image_views(big.detach(), N, hw)
-            proposals = self.predict_proposals(anchors, obj, dl, image_sizes, top_idx=self._pre_nms_topk(big.detach(), N, hw))
+            sel = self._pre_nms_topk(big.detach(), N, hw)
+            if sel is not None:
+                proposals = self._proposals_fused(big.detach(), anchors, sel, hw, N, image_sizes)
+            else:
+                obj, dl = self._per_image_views(big.detach(), N, hw)
+                proposals = self.predict_proposals(anchors, obj, dl, image_sizes)
         return proposals, losses
 
     @torch.no_grad()
     def _pre_nms_topk(self, big, N, hw):
         """D2 find_top_rpn_proposals' per-(image, level) `topk(pre_nms_topk)` for all levels and images by ONE exact radix select
-        (utv2_topk_rows_i64; torch.topk per level costs ~70 launches per forward): the objectness of the level-first head output
-        becomes one flat buffer of sortable keys whose ragged rows are the (level, image) pairs.  Returns per level the anchor
-        indices [N, k_l] in (score desc, index asc) order - the order torch.topk on float_order_key gives - or None when
-        PRE_NMS_TOPK exceeds the kernel's 2048."""
+        (utv2_topk_rows_i64; torch.topk per level costs ~70 launches per forward): utv2_rpn_rank_keys turns the objectness of the
+        level-first head output into one flat buffer of sortable keys whose ragged rows are the (level, image) pairs.  Returns
+        (selected keys [L*N, max k], k per level) - row l*N+n in (score desc, anchor index asc) order, the order torch.topk on
+        float_order_key gives - or None when PRE_NMS_TOPK exceeds the kernel's 2048."""
         pre = self.pre_nms_topk[self.training]
         A = self.A
         widths = [h * w * A for (h, w) in hw]
@@ -234,25 +238,45 @@ class PseudoLabRPN:
         dev = big.device
         ck = (N, tuple(hw), str(dev))
         geom = self.__dict__.setdefault("_topk_geom", {})   # one entry per batch geometry (teacher / labeled / unlabeled batches differ)
-        cached = geom.get(ck)
-        if cached is None:
-            offs, idx, o = [], [], 0
+        row_off = geom.get(ck)
+        if row_off is None:
+            offs, o = [], 0
             for wd in widths:
-                for n in range(N):
-                    offs.append(o + n * wd)
-                idx.append(torch.arange(wd, dtype=torch.int64, device=dev).repeat(N))
+                offs.extend(o + n * wd for n in range(N))
                 o += N * wd
             offs.append(o)
             if len(geom) >= 16:
                 geom.clear()
-            cached = geom[ck] = (torch.tensor(offs, dtype=torch.int64, device=dev), 2147483647 - torch.cat(idx))
-        row_off, inv_idx = cached
-        x = big[:, :A].reshape(-1).contiguous()                       # (level, image, hw, anchor): the rows in memory order
-        i = x.view(torch.int32)
-        mono = (i ^ ((i >> 31) & 0x7FFFFFFF)).long() + 2147483648     # order-preserving, in [0, 2^32)
-        keys = mono * 2147483648 + inv_idx                            # 63-bit non-negative keys (the kernel's negative = empty)
-        top = hip.topk_rows(keys, row_off, len(hw) * N, max(widths), max(ks))
-        return [2147483647 - (top[l * N:(l + 1) * N, :ks[l]] & 2147483647) for l in range(len(hw))]
+            row_off = geom[ck] = torch.tensor(offs, dtype=torch.int64, device=dev)
+        keys = hip.rpn_rank_keys(big, [h * w for (h, w) in hw], N, A)
+        return hip.topk_rows(keys, row_off, len(hw) * N, max(widths), max(ks)), ks
+
+    @torch.no_grad()
+    def _proposals_fused(self, big, anchors, sel, hw, N, image_sizes):
+        """predict_proposals with the gather / apply_deltas / clip / keep chain of all levels in one launch (utv2_rpn_decode)"""
+        top, ks = sel
+        dev = big.device
+        post = self.post_nms_topk[self.training]
+        cache = self.__dict__.setdefault("_decode_cache", {})
+        ck = (tuple(hw), tuple(image_sizes), str(dev))
+        ent = cache.get(ck)
+        if ent is None:
+            if len(cache) >= 16:
+                cache.clear()
+            ent = cache[ck] = (torch.cat(anchors).contiguous(),
+                               torch.tensor([[s[0], s[1]] for s in image_sizes], dtype=torch.float32, device=dev))
+        anchors_cat, image_hw = ent
+        boxes, scores, lvls, keep = hip.rpn_decode(top, big, anchors_cat, image_hw, [h * w for (h, w) in hw], ks, N, self.A,
+                                                   self.box_weights, SCALE_CLAMP, self.min_box_size)
+        return self._nms_and_pack(boxes, scores, lvls, keep, image_sizes, post)
+
+    def _nms_and_pack(self, boxes, scores, lvls, keep, image_sizes, post):
+        dev = boxes.device
+        kidx, cnt = hip.nms_batched(boxes, scores, lvls, keep, self.nms_thresh, class_aware=True, post_topk=-1, max_out=post)
+        ix = kidx.clamp(min=0).long()
+        valid = (torch.arange(post, device=dev)[None, :] < cnt[:, None]).to(torch.uint8)
+        return PaddedBoxes(image_sizes, boxes=torch.gather(boxes, 1, ix[:, :, None].expand(-1, -1, 4)).contiguous(),
+                           objectness_logits=torch.gather(scores, 1, ix).contiguous(), valid=valid, count=cnt)
 
     __call__ = forward
 
@@ -332,12 +356,7 @@ class PseudoLabRPN:
         keep = finite & ((boxes[..., 2] - boxes[..., 0]) > self.min_box_size) & ((boxes[..., 3] - boxes[..., 1]) > self.min_box_size)
         boxes = boxes.contiguous()
         scores = torch.where(finite, scores, torch.zeros_like(scores)).contiguous()
-        kidx, cnt = hip.nms_batched(boxes, scores, lvls.contiguous(), keep.to(torch.uint8).contiguous(), self.nms_thresh,
-                                    class_aware=True, post_topk=-1, max_out=post)
-        ix = kidx.clamp(min=0).long()
-        valid = (torch.arange(post, device=dev)[None, :] < cnt[:, None]).to(torch.uint8)
-        return PaddedBoxes(image_sizes, boxes=torch.gather(boxes, 1, ix[:, :, None].expand(-1, -1, 4)).contiguous(),
-                           objectness_logits=torch.gather(scores, 1, ix).contiguous(), valid=valid, count=cnt)
+        return self._nms_and_pack(boxes, scores, lvls.contiguous(), keep.to(torch.uint8).contiguous(), image_sizes, post)
 
 
 # ---------------------------------------------------------------------------------------------------
