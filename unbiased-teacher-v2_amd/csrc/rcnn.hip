@@ -18,6 +18,21 @@ __device__ __forceinline__ float iou_d2(const float4& a, const float4& b) {
   return inter > 0.f ? inter / (aa + ab - inter) : 0.f;
 }
 
+// valid gts of image n, compacted in their original order (256 threads, G <= MB_MAXG): sidx[k] = k-th valid slot; returns their number
+__device__ __forceinline__ int compact_valid_gts(const unsigned char* __restrict__ gt_valid, int n, int G, int* sidx, int* wcnt) {
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const bool v = t < G && gt_valid[n * G + t];
+  const unsigned long long b = __ballot(v);
+  if (lane == 0) wcnt[w] = __popcll(b);
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < w; ++i) base += wcnt[i];
+  if (v) sidx[base + __popcll(b & ((1ull << lane) - 1ull))] = t;
+  const int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+  __syncthreads();
+  return total;
+}
+
 __global__ __launch_bounds__(256) void match_boxes_kernel(const float* __restrict__ boxes, long long box_img_stride, int P,
                                                         const float* __restrict__ gt_boxes, const unsigned char* __restrict__ gt_valid,
                                                         int G, float* __restrict__ max_iou, int* __restrict__ arg,
@@ -25,16 +40,9 @@ __global__ __launch_bounds__(256) void match_boxes_kernel(const float* __restric
   __shared__ float4 sg[MB_MAXG];
   __shared__ int sidx[MB_MAXG];
   __shared__ unsigned smax[MB_MAXG];
-  __shared__ int scount;
+  __shared__ int wcnt[4];
   const int n = blockIdx.y;
-  if (threadIdx.x == 0) {
-    int c = 0;
-    for (int g = 0; g < G; ++g)
-      if (gt_valid[n * G + g]) sidx[c++] = g;
-    scount = c;
-  }
-  __syncthreads();
-  const int Gv = scount;
+  const int Gv = compact_valid_gts(gt_valid, n, G, sidx, wcnt);
   for (int k = threadIdx.x; k < Gv; k += blockDim.x) {
     sg[k] = ((const float4*)gt_boxes)[(size_t)n * G + sidx[k]];
     smax[k] = 0u;
@@ -48,7 +56,8 @@ __global__ __launch_bounds__(256) void match_boxes_kernel(const float* __restric
     for (int k = 0; k < Gv; ++k) {
       const float v = iou_d2(sg[k], b);
       if (v > best) { best = v; bi = k; }
-      if (gt_max_bits) atomicMax(&smax[k], __float_as_uint(v));
+      // most pairs are disjoint and the maximum settles quickly: the LDS atomic only when this pair can still raise it
+      if (gt_max_bits && v > 0.f && __float_as_uint(v) > ((volatile unsigned*)smax)[k]) atomicMax(&smax[k], __float_as_uint(v));
     }
     max_iou[(size_t)n * P + p] = best;
     arg[(size_t)n * P + p] = Gv > 0 ? sidx[bi] : 0;
@@ -65,19 +74,13 @@ __global__ __launch_bounds__(256) void match_lowq_kernel(const float* __restrict
                                                        unsigned char* __restrict__ lowq) {
   __shared__ float4 sg[MB_MAXG];
   __shared__ float smax[MB_MAXG];
-  __shared__ int scount;
+  __shared__ int sidx[MB_MAXG];
+  __shared__ int wcnt[4];
   const int n = blockIdx.y;
-  if (threadIdx.x == 0) scount = 0;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int c = 0;
-    for (int g = 0; g < G; ++g)
-      if (gt_valid[n * G + g]) {
-        sg[c] = ((const float4*)gt_boxes)[(size_t)n * G + g];
-        smax[c] = __uint_as_float(gt_max_bits[(size_t)n * G + g]);
-        ++c;
-      }
-    scount = c;
+  const int scount = compact_valid_gts(gt_valid, n, G, sidx, wcnt);
+  for (int k = threadIdx.x; k < scount; k += blockDim.x) {
+    sg[k] = ((const float4*)gt_boxes)[(size_t)n * G + sidx[k]];
+    smax[k] = __uint_as_float(gt_max_bits[(size_t)n * G + sidx[k]]);
   }
   __syncthreads();
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
