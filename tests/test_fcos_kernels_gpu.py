@@ -317,6 +317,35 @@ def test_nms_class_parallel_scan_post_topk():
             assert torch.equal(keep[n, : len(ref)].long(), ref)
 
 
+def test_nms_bucketed_max_out_truncation_and_sparse_class_ids():
+    """the bucketed class-aware pipeline (per-bucket IoU matrices and scans, global-order emit) when only the first max_out kept
+    candidates are wanted (the RPN: 1000 of ~9000, a bucket stops once it has kept max_out on its own), with class ids far apart
+    that collide in a bucket (ids 3, 35, 67 share bucket 3), an empty image and a single-candidate image: bit-exact vs the oracle."""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(19)
+    for (N, M, thr, ids, max_out) in [(2, 9000, 0.7, [0, 1, 2, 3, 4], 1000), (2, 3000, 0.5, [3, 35, 67, 1000, 64], 300),
+                                      (3, 500, 0.6, [7], 64)]:
+        ctr = torch.rand(N, M, 2, generator=g) * 500
+        wh = torch.rand(N, M, 2, generator=g) * 100 + 4
+        boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], dim=2)
+        scores = torch.rand(N, M, generator=g)
+        scores[:, ::9] = 0.25
+        cls = torch.tensor(ids, dtype=torch.int32)[torch.randint(0, len(ids), (N, M), generator=g)]
+        valid = (torch.rand(N, M, generator=g) > 0.05).to(torch.uint8)
+        if N == 3:
+            valid[1] = 0                       # no candidates at all
+            valid[2] = 0; valid[2, 17] = 1     # exactly one
+        keep, cnt = hip.nms_batched(boxes.to(DEV), scores.to(DEV), cls.to(DEV), valid.to(DEV), thr, class_aware=True, post_topk=-1,
+                                    max_out=max_out)
+        keep, cnt = keep.cpu(), cnt.cpu()
+        for n in range(N):
+            vi = valid[n].bool().nonzero().squeeze(1)
+            ref = vi[O.batched_nms(boxes[n][vi], scores[n][vi], cls[n][vi].long(), thr)][:max_out] if len(vi) else vi
+            assert int(cnt[n]) == len(ref), (N, M, int(cnt[n]), len(ref))
+            assert torch.equal(keep[n, : len(ref)].long(), ref)
+            assert bool((keep[n, len(ref):] == -1).all())
+
+
 def test_center_sample_variant_vs_reference_golden():
     """MODEL.FCOS.CENTER_SAMPLE True through the product (target kernel with the radius*stride centre region): labels, regression
     targets, losses and head gradients vs the reference's own outputs (fcos_center_sample.npz); also the first-box-centre quirk."""
