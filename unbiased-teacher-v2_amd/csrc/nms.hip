@@ -55,13 +55,12 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
   // bitonic sort ascending
   for (int k = 2; k <= Mpad; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < Mpad; i += blockDim.x) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long a = keys[i], c = keys[ixj];
-          const bool up = ((i & k) == 0);
-          if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
-        }
+      for (int t = threadIdx.x; t < (Mpad >> 1); t += blockDim.x) {  // pair t: (i, i + j) with bit j of i clear
+        const int i = 2 * t - (t & (j - 1));
+        const int ixj = i + j;
+        const unsigned long long a = keys[i], c = keys[ixj];
+        const bool up = ((i & k) == 0);
+        if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
       }
       __syncthreads();
     }
@@ -370,16 +369,27 @@ __global__ __launch_bounds__(64) void nms_scan_bucket_kernel(const unsigned long
       have_kth = true;
     }
     count += __popcll(keepbits);
+    // OR the kept rows into the removed set, 8 rows' loads in flight at a time (one row per round trip left the wave waiting ~0.5 us
+    // per kept candidate: 1000 kept = the whole kernel)
     unsigned long long kb = keepbits;
     while (kb) {
-      const int j = __ffsll((long long)kb) - 1;
-      kb &= kb - 1ull;
-      const unsigned long long* r = mrow + (size_t)(c * 64 + j) * wb;
+      unsigned long long v[8][NMS_MAXW];
 #pragma unroll
-      for (int s = 0; s < NMS_MAXW; ++s) {
-        const int w = s * 64 + lane;
-        if (w < wb && w > c) removed[s] |= r[w];
+      for (int u = 0; u < 8; ++u) {
+        const bool on = kb != 0ull;
+        const int j = on ? __ffsll((long long)kb) - 1 : 0;
+        kb &= kb - 1ull;   // 0 stays 0
+        const unsigned long long* r = mrow + (size_t)(c * 64 + j) * wb;
+#pragma unroll
+        for (int s = 0; s < NMS_MAXW; ++s) {
+          const int w = s * 64 + lane;
+          v[u][s] = (on && w < wb && w > c) ? r[w] : 0ull;
+        }
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int s = 0; s < NMS_MAXW; ++s) removed[s] |= v[u][s];
     }
   }
 }
