@@ -96,7 +96,7 @@ class ConvTimer:
     dominant kernel inside the timed region.  Dominant kernel (largest share of GPU time in profiles/): the multi-level
     3x3 implicit-GEMM conv of the shared FCOS towers - forward AND dgrad launches, 256 -> 256 channels over all five FPN
     levels of the student batch in one launch:
-        bf16: conv_igemm_bf16_w8<true,__bf16> on the whole rounds of 256 x 256 tiles + conv_igemm_bf16_v2<128,true,64,__bf16> on the
+        bf16: conv_igemm_bf16_pp<true,__bf16> on the whole rounds of 256 x 256 tiles + conv_igemm_bf16_v2<128,true,64,__bf16> on the
               remaining output rows (two kernels, one C-ABI call = one timed launch)      f32: conv_igemm_f32<128,0,true>"""
 
     def __init__(self, dtype):
@@ -104,7 +104,7 @@ class ConvTimer:
         self.enabled = False
         self.bf16 = dtype == "bf16"
         self.entry = "conv2d_ml_fwd_bf16" if self.bf16 else "conv2d_ml_fwd"
-        self.kernel = "conv_igemm_bf16_w8<true,__bf16>+conv_igemm_bf16_v2<128,true,64,__bf16>" if self.bf16 else "conv_igemm_f32<128,0,true>"
+        self.kernel = "conv_igemm_bf16_pp<true,__bf16>+conv_igemm_bf16_v2<128,true,64,__bf16>" if self.bf16 else "conv_igemm_f32<128,0,true>"
 
     def install(self):
         from ubteacher import hip

@@ -2,13 +2,13 @@
 (tools/rocpd_stats.py output) of one command.  FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: 16-byte-per-lane reads are
 counted at half their bytes on gfx950; our own gn_apply_relu, which reads exactly what it writes, shows FETCH = WRITE / 2).  Per kernel:
 HBM bytes per launch = 2 * FETCH + WRITE, GB/s = bytes / the kernel-trace average duration (the PMC passes themselves run slower).
-Two aggregate keys are what bench.py reads: the FCOS tower conv launch (conv_igemm_bf16_w8<true> on whole rounds of 256 x 256 tiles +
+Two aggregate keys are what bench.py reads: the FCOS tower conv launch (conv_igemm_bf16_pp<true> on whole rounds of 256 x 256 tiles +
 conv_igemm_bf16_v2<128,true,64> on the remaining rows: one of each per launch) and the tower weight gradient (conv_wgrad_bf16_w8).
 usage: make_traffic.py FETCH.txt WRITE.txt KERNEL_STATS.txt OUT.json"""
 import json
 import sys
 
-TOWER = ("_Z18conv_igemm_bf16_w8ILb1EDF16bEv10ConvArgs16", "_Z18conv_igemm_bf16_v2ILi128ELb1ELi64EDF16bEv10ConvArgs16")
+TOWER = ("_Z18conv_igemm_bf16_ppILb1EDF16bEv10ConvArgs16", "_Z18conv_igemm_bf16_v2ILi128ELb1ELi64EDF16bEv10ConvArgs16")
 WGRAD = "_Z18conv_wgrad_bf16_w811Wgrad16Args"
 
 
@@ -33,16 +33,16 @@ def durations(path):
 fetch, write, dur = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), durations(sys.argv[3])
 res = {"fetch_correction": 2.0, "source": "%s, %s, %s" % tuple(sys.argv[1:4])}
 if TOWER[0] in fetch:
-    # the w8 kernel's share of the launch (whole rounds of 256 x 256 tiles: 97.5 % of the student's rows, 73 % of the teacher's); the
+    # the 256-tile kernel's share of the launch (whole rounds of 256 x 256 tiles: 97.5 % of the student's rows, 73 % of the teacher's); the
     # remaining rows run on conv_igemm_bf16_v2<128,true,64>, whose PMC row cannot be split from the head prediction convs that use
     # the same instance, so it is left out here (r01 added ALL of that kernel's bytes to this figure)
     n = fetch[TOWER[0]][0]
     fk = fetch[TOWER[0]][1] / n
     wk = write[TOWER[0]][1] / n
-    res["conv_igemm_bf16_w8<true,__bf16>+conv_igemm_bf16_v2<128,true,64,__bf16>"] = {
+    res["conv_igemm_bf16_pp<true,__bf16>+conv_igemm_bf16_v2<128,true,64,__bf16>"] = {
         "fetch_size_kib_per_launch": round(fk, 2), "write_size_kib_per_launch": round(wk, 2),
         "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0, "launches_in_pmc_run": n,
-        "covers": "conv_igemm_bf16_w8<true,__bf16> only (the whole rounds of 256x256 tiles of each launch)"}
+        "covers": "conv_igemm_bf16_pp<true,__bf16> only (the whole rounds of 256x256 tiles of each launch)"}
 kernels = {}
 for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch.get(k, (1, 0))[1] + write.get(k, (1, 0))[1])):
     nf, f = fetch.get(k, (0, 0.0))

@@ -14,7 +14,7 @@ prof() {  # prof <dir> <extra rocprof args> -- <bench args>
   local pmc=()
   while [ "$1" != "--" ]; do pmc+=("$1"); shift; done
   shift
-  timeout 600 rocprofv3 --kernel-trace "${pmc[@]}" -d $R/gpurun_out/$d -o run -- python $R/bench.py --no-cpu-baseline --no-f32 "$@" > $R/gpurun_out/${TAG}_$d.log 2>&1 < /dev/null
+  timeout 600 rocprofv3 --kernel-trace "${pmc[@]}" -d $R/gpurun_out/$d -o run -- python $R/bench.py --no-cpu-baseline --no-f32 --timed-only "$@" > $R/gpurun_out/${TAG}_$d.log 2>&1 < /dev/null
 }
 prof _kt -- --steps 8 --warmup 2
 prof _pf --pmc FETCH_SIZE -- --steps 3 --warmup 1
@@ -29,6 +29,8 @@ timeout 120 python tools/rocpd_pmc.py "$(db _pf)" 40 > gpurun_out/${TAG}_fcos_4p
 timeout 120 python tools/rocpd_pmc.py "$(db _pw)" 40 > gpurun_out/${TAG}_fcos_4p4_bf16_pmc_write.txt 2>&1 < /dev/null
 timeout 60 python tools/make_traffic.py gpurun_out/${TAG}_fcos_4p4_bf16_pmc_fetch.txt gpurun_out/${TAG}_fcos_4p4_bf16_pmc_write.txt \
   gpurun_out/${TAG}_fcos_4p4_bf16_kernel_stats.txt gpurun_out/${TAG}_traffic.json > gpurun_out/${TAG}_traffic.log 2>&1 < /dev/null
+timeout 120 python tools/rocpd_timeline.py "$(db _kt)" steps 10 6 > gpurun_out/${TAG}_fcos_4p4_bf16_timeline.txt 2>&1 < /dev/null
+timeout 120 python tools/rocpd_timeline.py "$(db _rkt)" steps 10 6 > gpurun_out/${TAG}_rcnn_4p4_bf16_timeline.txt 2>&1 < /dev/null
 timeout 120 python tools/rocpd_stats.py "$(db _rkt)" > gpurun_out/${TAG}_rcnn_4p4_bf16_kernel_stats.txt 2>&1 < /dev/null
 timeout 120 python tools/rocpd_pmc.py "$(db _rpf)" 60 > gpurun_out/${TAG}_rcnn_4p4_bf16_pmc_fetch.txt 2>&1 < /dev/null
 timeout 120 python tools/rocpd_pmc.py "$(db _rpw)" 60 > gpurun_out/${TAG}_rcnn_4p4_bf16_pmc_write.txt 2>&1 < /dev/null

@@ -470,33 +470,31 @@ __global__ __launch_bounds__(256) void gn_bwd_partial(GnSegs sg, const T* __rest
 
 // backward stage 2 (one block per segment): AB[seg][c][2] = sum over the segment's chunks; s1 = sum_c gamma*A,
 // s2 = sum_c gamma*B per group.
-__global__ __launch_bounds__(1024) void gn_bwd_reduce(GnSegs sg, const float* __restrict__ part, const float* __restrict__ gamma,
-                                                    float* __restrict__ AB, float* __restrict__ s12, int C, int G) {
+__global__ __launch_bounds__(256) void gn_bwd_reduce(GnSegs sg, const float* __restrict__ part, const float* __restrict__ gamma,
+                                                   float* __restrict__ AB, float* __restrict__ s12, int C, int G) {
   const int seg = blockIdx.x;
   const int cpg = C / G;
-  extern __shared__ float sh[];  // [C][2] then 4 x [C][2] partial sums
-  float* ps = sh + 2 * C;
+  extern __shared__ float sh[];  // [C][2]
   const int k0 = sg.chunk0[seg], k1 = sg.chunk0[seg + 1];
-  // 4 interleaved chunk walks per channel (the largest level has 50 chunks per image), combined in a fixed order
-  for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) {
-    const int c = i % C, q = i / C;
-    float a = 0.f, b = 0.f;
-    for (int k = k0 + q; k < k1; k += 4) {
-      const float2 v = *(const float2*)(part + ((size_t)k * C + c) * 2);
-      a += v.x;
-      b += v.y;
-    }
-    ps[(q * C + c) * 2] = a;
-    ps[(q * C + c) * 2 + 1] = b;
-  }
-  __syncthreads();
+  // 4 interleaved chunk walks per channel, their loads in flight together (the largest level has 50 chunks per image; one dependent
+  // walk per thread was pure load latency), combined in a fixed order.  256 threads: a 1024-thread workgroup waits for a whole free CU
+  // while the side-stream convolutions hold every CU's registers (measured 267 us per launch inside the step against 7 us alone).
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const float a = (ps[c * 2] + ps[(C + c) * 2]) + (ps[(2 * C + c) * 2] + ps[(3 * C + c) * 2]);
-    const float b = (ps[c * 2 + 1] + ps[(C + c) * 2 + 1]) + (ps[(2 * C + c) * 2 + 1] + ps[(3 * C + c) * 2 + 1]);
-    AB[((size_t)seg * C + c) * 2] = a;
-    AB[((size_t)seg * C + c) * 2 + 1] = b;
-    sh[c * 2] = a * gamma[c];
-    sh[c * 2 + 1] = b * gamma[c];
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = k0; k < k1; k += 4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (k + q < k1) {
+          const float2 v = *(const float2*)(part + ((size_t)(k + q) * C + c) * 2);
+          a[q] += v.x;
+          b[q] += v.y;
+        }
+    }
+    const float sa = (a[0] + a[1]) + (a[2] + a[3]), sb = (b[0] + b[1]) + (b[2] + b[3]);
+    AB[((size_t)seg * C + c) * 2] = sa;
+    AB[((size_t)seg * C + c) * 2 + 1] = sb;
+    sh[c * 2] = sa * gamma[c];
+    sh[c * 2 + 1] = sb * gamma[c];
   }
   __syncthreads();
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
@@ -611,7 +609,7 @@ static void gn_bwd_launch(const GnSegs& sg, int chunks, int nseg, const void* dy
   float* s12 = AB + (size_t)nseg * C * 2;
   hipLaunchKernelGGL(gn_bwd_partial<T>, dim3(chunks), dim3(256), 0, stream, sg, (const T*)dy, (const T*)y, (const T*)x, mean, rstd,
                      gamma, beta, part, C, G, relu);
-  hipLaunchKernelGGL(gn_bwd_reduce, dim3(nseg), dim3(1024), 10 * C * sizeof(float), stream, sg, (const float*)part, gamma, AB, s12, C, G);
+  hipLaunchKernelGGL(gn_bwd_reduce, dim3(nseg), dim3(256), 2 * C * sizeof(float), stream, sg, (const float*)part, gamma, AB, s12, C, G);
   hipLaunchKernelGGL(gn_bwd_param, dim3(cdiv(C, 64)), dim3(256), 0, stream, (const float*)AB, dgamma, dbeta, nseg, C);
   hipLaunchKernelGGL(gn_bwd_apply<T>, dim3(chunks), dim3(256), 0, stream, sg, (const T*)dy, (const T*)y, (const T*)x, mean, rstd,
                      gamma, beta, (const float*)s12, (T*)dx, C, G, relu);
