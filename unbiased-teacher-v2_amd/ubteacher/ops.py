@@ -60,6 +60,19 @@ def _wgrad_launch(fn, *tensors):
     _WGRAD["pending"].add(dev)
 
 
+def wgrad_stream_behind_main(dev):
+    """the wgrad side stream of `dev`, made to wait for everything the main stream has enqueued so far - or None when the weight
+    gradients are not on a side stream.  A consumer of parameter gradients that runs on its own stream (a bucket all-reduce) is issued
+    from this stream: it then waits for the gradient kernels of BOTH streams while the main stream's dgrad chain keeps running."""
+    if not _WGRAD["on"] or dev.type != "cuda":
+        return None
+    side = _WGRAD["streams"].get(dev)
+    if side is None:
+        return None
+    side.wait_stream(torch.cuda.current_stream(dev))
+    return side
+
+
 def join_wgrad_stream():
     for dev in list(_WGRAD["pending"]):
         torch.cuda.current_stream(dev).wait_stream(_WGRAD["streams"][dev])

@@ -76,8 +76,15 @@ class GradBuckets:
         self.order.append(b)
         if e > s:
             from .. import ops
-            ops.join_wgrad_stream()   # this bucket's weight gradients may still be running on the wgrad side stream
-            self.works.append(dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
+            # this bucket's weight gradients may still be running on the wgrad side stream: the collective is issued from THAT stream
+            # (made to wait for the main one), so RCCL's stream waits for both and the main stream's dgrad chain is never held up
+            side = ops.wgrad_stream_behind_main(self.grad.device)
+            if side is not None:
+                with torch.cuda.stream(side):
+                    self.works.append(dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
+            else:
+                ops.join_wgrad_stream()
+                self.works.append(dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
         """after backward: reduce the buckets that are still waiting (in the same static order), wait for everything"""
