@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(ROOT, "unbiased-teacher-v2_amd"))
 import torch
 from ubteacher import hip
 BF = torch.bfloat16
-N = 8
+N = int(os.environ.get("TOWER_N", "8"))
 level_hw = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
 P = N * sum(h * w for h, w in level_hw)
 C = K = 256
