@@ -233,6 +233,30 @@ int utv2_rpn_rank_keys(const float* head, int num_levels, const int* hw_host, in
 int utv2_rpn_decode(const int64_t* top, int maxk, const float* head, const float* anchors, const float* image_hw, int num_levels,
                     const int* hw_host, const int* k_host, int N, int A, int ch, const float* weights_host, float scale_clamp,
                     float min_size, float* boxes, float* scores, int* lvls, unsigned char* keep, utv2_stream_t stream);
+/* PseudoLabRPN.losses on the sampled anchors (proposal_generator/rpn.py:153-225): sums[0] = sum of BCE-with-logits over the sampled
+ * positives (pos_idx [N][npos], int64 anchor indices, pos_valid) and negatives (neg_idx [N][nneg]) - every term times the score of the
+ * anchor's matched pseudo box when gt_scores is given, zero when the image has no gt (has_gt [N]) -, sums[1] = sum over the valid
+ * positives of |delta - Box2BoxTransform.get_deltas(anchor, matched gt, weights_host[4])|; gobj [N][npos+nneg] / gdl [N][npos][4] =
+ * the derivatives of the two sums.  head = 0: obj [N][R], deltas [N][R][4]; head = 1: obj = deltas = the level-first RPN head output
+ * (utv2_rpn_decode's layout).  matched [N][R] int32 (utv2_match_boxes' argmax), gt_boxes [N][G][4], gt_scores [N][G] or NULL.
+ * bwd: scatters gout_cls[0] * gobj and gout_loc[0] * gdl (device scalars) to the sampled anchors of zero-filled grad_obj / grad_deltas
+ * (same layouts; head = 1: both = the head-output gradient). */
+int utv2_rpn_loss_fwd(const float* obj, const float* deltas, int head, int num_levels, const int* hw_host, int N, int A, int ch, int R,
+                      const float* anchors, const int64_t* pos_idx, const unsigned char* pos_valid, int npos, const int64_t* neg_idx,
+                      const unsigned char* neg_valid, int nneg, const int* matched, const unsigned char* has_gt, const float* gt_boxes,
+                      const float* gt_scores, int G, const float* weights_host, float* sums, float* gobj, float* gdl, utv2_stream_t stream);
+int utv2_rpn_loss_bwd(const float* gobj, const float* gdl, const float* gout_cls, const float* gout_loc, int head, int num_levels,
+                      const int* hw_host, int N, int A, int ch, int R, const int64_t* pos_idx, const unsigned char* pos_valid, int npos,
+                      const int64_t* neg_idx, const unsigned char* neg_valid, int nneg, float* grad_obj, float* grad_deltas,
+                      utv2_stream_t stream);
+/* box_reg_loss / box_reg_pseudo_loss of the boundary-variance predictor (roi_heads/fast_rcnn.py:938-1090) on R sampled ROIs, summed:
+ * deltas / stdl = the predicted boundary deltas and std logits (row pitch ld floats), cls [R] int64 (-1 = empty slot, foreground =
+ * [0, num_classes)), prop / gtb [R][4] proposal and matched gt boxes, gstd [R][4] the pseudo boxes' std logits or NULL.
+ * mode 0: nlloss (L1 + 0.05 sum NLL * IoU, gradient through the IoU), 1: smooth_l1 at beta 0, 2: tsbetter, 3: pseudo smooth_l1.
+ * Writes sum[0] and the derivatives gdeltas / gstd_out [R][4] (Box2BoxXYXYTransform weights wx, wy and clamp). */
+int utv2_roi_box_loss(const float* deltas, const float* stdl, int64_t ld, const int64_t* cls, const float* prop, const float* gtb,
+                      const float* gstd, int R, int num_classes, int mode, float wx, float wy, float scale_clamp, float ts_better,
+                      float t_cert, float* sum, float* gdeltas, float* gstd_out, utv2_stream_t stream);
 /* roi_heads/fast_rcnn.py:925-936 + FocalLoss :1405-1429 (softmax CE focal, gamma 1.5), summed */
 int utv2_softmax_focal_fwd(const float* logits, const int* target, int R, int C, float gamma, float* loss_sum, float* ws,
                            utv2_stream_t stream);

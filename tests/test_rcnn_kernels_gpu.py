@@ -157,6 +157,47 @@ def test_rpn_pseudo_losses_vs_reference_golden(rc):
     close(dl.grad[:, :n0], rc["rpn_gdl0"], rtol=1e-4, atol=1e-8); close(dl.grad[:, n0:], rc["rpn_gdl1"], rtol=1e-4, atol=1e-8)
 
 
+def test_rpn_losses_from_head_output_equal_dense_form():
+    """PseudoLabRPN.losses reading logits / deltas straight from the level-first head output (the product path: no per-image copies)
+    against the same fused kernel on the dense per-image tensors the reference-golden test above pins: identical sums, and the
+    gradient scattered into the head buffer equals autograd through the per-image views.  Pseudo-label weights, an image without gt."""
+    from ubteacher import ops
+    from ubteacher.modeling.fcos import PaddedBoxes
+    from ubteacher.modeling.rcnn import RPN_CH
+    from ubteacher.modeling import build_model
+    from ubteacher.presets import get_config
+    cfg = get_config("rcnn", 1, ["MODEL.DEVICE", "cuda"])
+    torch.manual_seed(0)
+    rpn = build_model(cfg).proposal_generator
+    N, hw = 3, [(40, 56), (20, 28), (10, 14), (5, 7), (3, 4)]
+    meta = ops.LevelMeta(N, hw)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    big0 = torch.randn(meta.P, RPN_CH, device="cuda", generator=g)
+    anchors = rpn.anchor_generator(hw, big0.device)
+    gb = torch.zeros(N, 8, 4, device="cuda"); gv = torch.zeros(N, 8, dtype=torch.uint8, device="cuda")
+    gb[0, :3] = torch.tensor([[10., 12., 90., 70.], [100., 40., 180., 150.], [30., 60., 60., 100.]], device="cuda"); gv[0, :3] = 1
+    gb[2, :1] = torch.tensor([[50., 20., 200., 140.]], device="cuda"); gv[2, :1] = 1          # image 1 has no gt
+    gs = torch.rand(N, 8, device="cuda", generator=g)
+    keys = torch.rand(N, torch.cat(anchors).shape[0], device="cuda", generator=g)
+    for pseudo in (False, True):
+        f = dict(boxes=gb, valid=gv, classes=torch.zeros(N, 8, dtype=torch.int32, device="cuda"))
+        if pseudo:
+            f["scores"] = gs
+        gt = PaddedBoxes([(160, 224)] * N, **f)
+        rpn.sample_keys = keys
+        big_a = big0.clone().requires_grad_(True)
+        la = rpn.losses(torch.cat(anchors), big_a, None, gt, head_hw=hw)
+        (la["loss_rpn_cls"] * 1.7 + la["loss_rpn_loc"] * 0.6).backward()
+        big_b = big0.clone().requires_grad_(True)
+        obj, dl = rpn._per_image_views(big_b, N, hw)
+        lb = rpn.losses(torch.cat(anchors), torch.cat(obj, 1), torch.cat(dl, 1), gt)
+        (lb["loss_rpn_cls"] * 1.7 + lb["loss_rpn_loc"] * 0.6).backward()
+        assert la["loss_rpn_cls"].item() > 0 and la["loss_rpn_loc"].item() > 0
+        assert torch.equal(la["loss_rpn_cls"], lb["loss_rpn_cls"]) and torch.equal(la["loss_rpn_loc"], lb["loss_rpn_loc"])
+        assert torch.equal(big_a.grad, big_b.grad) and float(big_a.grad.abs().sum()) > 0
+    rpn.sample_keys = None
+
+
 def test_roi_sampling_vs_reference_golden(rc):
     from ubteacher.modeling.fcos import PaddedBoxes
     from ubteacher.modeling.rcnn import StandardROIHeadsPseudoLab

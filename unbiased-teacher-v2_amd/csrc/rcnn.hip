@@ -573,6 +573,228 @@ __global__ __launch_bounds__(256) void rpn_decode_kernel(RpnLevels L, const long
   keep[o] = (finite && (x2 - x1) > min_size && (y2 - y1) > min_size) ? 1 : 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// RPN losses on the sampled anchors (proposal_generator/rpn.py:153-225): sum of BCE-with-logits over the sampled positives and
+// negatives (weighted by the matched pseudo box's score when gt_scores is given - negatives too) and sum of |delta - target|
+// over the positives, plus d(sum)/d(logit) per slot and d(sum)/d(delta) per positive slot.  The logits / deltas are read either from
+// dense [N][R] / [N][R][4] tensors or straight from the level-first head output (rows (level, image, pixel) x ch: A logits, then 4A
+// anchor-major deltas).  One workgroup, fixed summation order: deterministic.
+struct RpnLossArgs {
+  RpnLevels L;
+  int head, N, A, ch, R, npos, nneg, G;
+  const float* obj;
+  const float* deltas;
+  const float* anchors;
+  const long long* pos_idx;
+  const unsigned char* pos_valid;
+  const long long* neg_idx;
+  const unsigned char* neg_valid;
+  const int* matched;
+  const unsigned char* has_gt;
+  const float* gt_boxes;
+  const float* gt_scores;
+  float wx, wy, ww, wh;
+};
+
+// element offsets of anchor r's logit and of its first delta for image n
+__device__ __forceinline__ void rpn_locate(const RpnLevels& L, int head, int n, int r, int A, int ch, int R, size_t& o_obj, size_t& o_dl) {
+  if (!head) {
+    o_obj = (size_t)n * R + r;
+    o_dl = ((size_t)n * R + r) * 4;
+    return;
+  }
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < RPN_MAX_LEVELS; ++i)
+    if (i < L.n && r >= L.anchor0[i]) l = i;
+  const int q = r - L.anchor0[l], p = q / A, a = q - p * A;
+  const size_t row = (size_t)L.row0[l] + (size_t)n * L.hw[l] + p;
+  o_obj = row * ch + a;
+  o_dl = row * ch + A + a * 4;
+}
+
+__global__ __launch_bounds__(256) void rpn_loss_fwd_kernel(RpnLossArgs p, float* __restrict__ sums, float* __restrict__ gobj,
+                                                         float* __restrict__ gdl) {
+  __shared__ float red[2][256];
+  const int S = p.npos + p.nneg;
+  float cls = 0.f, loc = 0.f;
+  for (int slot = threadIdx.x; slot < p.N * S; slot += blockDim.x) {
+    const int n = slot / S, j = slot - n * S;
+    const bool pos = j < p.npos;
+    const long long idx = pos ? p.pos_idx[(size_t)n * p.npos + j] : p.neg_idx[(size_t)n * p.nneg + (j - p.npos)];
+    const bool valid = pos ? p.pos_valid[(size_t)n * p.npos + j] : p.neg_valid[(size_t)n * p.nneg + (j - p.npos)];
+    size_t oo, od;
+    rpn_locate(p.L, p.head, n, (int)idx, p.A, p.ch, p.R, oo, od);
+    const float x = p.obj[oo], t = pos ? 1.f : 0.f;
+    const bool hg = p.has_gt[n] != 0;
+    const int g = p.matched[(size_t)n * p.R + idx];
+    float w = valid ? 1.f : 0.f;
+    if (p.gt_scores) w = w * (hg ? p.gt_scores[(size_t)n * p.G + g] : 0.f);
+    const float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+    cls += bce * w;
+    gobj[slot] = (1.f / (1.f + expf(-x)) - t) * w;
+    if (pos) {
+      const bool pv = valid && hg;
+      float4 a = make_float4(0.f, 0.f, 1.f, 1.f), b = a;
+      if (pv) {
+        a = *(const float4*)(p.anchors + (size_t)idx * 4);
+        b = *(const float4*)(p.gt_boxes + ((size_t)n * p.G + g) * 4);
+      }
+      const float sw = a.z - a.x, sh = a.w - a.y, sx = a.x + 0.5f * sw, sy = a.y + 0.5f * sh;
+      const float tw = b.z - b.x, th = b.w - b.y, tx = b.x + 0.5f * tw, ty = b.y + 0.5f * th;
+      const float tgt[4] = {p.wx * (tx - sx) / sw, p.wy * (ty - sy) / sh, p.ww * logf(tw / sw), p.wh * logf(th / sh)};
+      const float m = pv ? 1.f : 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float d = p.deltas[od + c] - tgt[c];
+        loc += fabsf(d) * m;
+        gdl[((size_t)n * p.npos + j) * 4 + c] = (d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f) * m;
+      }
+    }
+  }
+  red[0][threadIdx.x] = cls;
+  red[1][threadIdx.x] = loc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { sums[0] = red[0][0]; sums[1] = red[1][0]; }
+}
+
+// gradient of (gout[0] * cls_sum + gout[1] * loc_sum) scattered to the sampled anchors' logits / deltas (the caller zero-fills the
+// gradient buffers; the valid slots of an image are distinct anchors, invalid slots carry no gradient and are skipped)
+__global__ __launch_bounds__(256) void rpn_loss_bwd_kernel(RpnLossArgs p, const float* __restrict__ gobj, const float* __restrict__ gdl,
+                                                         const float* __restrict__ gout_cls, const float* __restrict__ gout_loc,
+                                                         float* __restrict__ grad_obj, float* __restrict__ grad_deltas) {
+  const int S = p.npos + p.nneg;
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= p.N * S) return;
+  const int n = slot / S, j = slot - n * S;
+  const bool pos = j < p.npos;
+  const bool valid = pos ? p.pos_valid[(size_t)n * p.npos + j] : p.neg_valid[(size_t)n * p.nneg + (j - p.npos)];
+  if (!valid) return;
+  const long long idx = pos ? p.pos_idx[(size_t)n * p.npos + j] : p.neg_idx[(size_t)n * p.nneg + (j - p.npos)];
+  size_t oo, od;
+  rpn_locate(p.L, p.head, n, (int)idx, p.A, p.ch, p.R, oo, od);
+  grad_obj[oo] = gobj[slot] * gout_cls[0];
+  if (pos) {
+    const float g1 = gout_loc[0];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) grad_deltas[od + c] = gdl[((size_t)n * p.npos + j) * 4 + c] * g1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Box regression losses of the boundary-variance predictor on the sampled ROIs (roi_heads/fast_rcnn.py:938-1090: `box_reg_loss`
+// nlloss / smooth_l1(beta 0) and `box_reg_pseudo_loss` tsbetter / smooth_l1), summed, with the derivatives w.r.t. the predicted
+// deltas and std logits.  mode 0: L1 + 0.05 * sum(NLL * IoU(gt, decoded box)) with the gradient flowing through the IoU;
+// 1: L1; 2: L1 on the boundaries where the teacher is more certain than the student by ts_better and above t_cert; 3: L1.
+// Box2BoxXYXYTransform (box_regression.py:11-129): get_deltas divides by (side + 1), apply_deltas multiplies by the side (B3 kept).
+// One workgroup, fixed summation order.
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void roi_box_loss_kernel(const float* __restrict__ deltas, const float* __restrict__ stdl, long long ld,
+                                                         const long long* __restrict__ cls, const float* __restrict__ prop,
+                                                         const float* __restrict__ gtb, const float* __restrict__ gstd, int R,
+                                                         int num_classes, int mode, float wx, float wy, float clampv, float ts_better,
+                                                         float t_cert, float* __restrict__ sum, float* __restrict__ gd,
+                                                         float* __restrict__ gs) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+    const long long c = cls[r];
+    const bool fg = c >= 0 && c < num_classes;
+    float4 pb = make_float4(0.f, 0.f, 1.f, 1.f), gb = pb;
+    if (fg) {
+      pb = *(const float4*)(prop + (size_t)r * 4);
+      gb = *(const float4*)(gtb + (size_t)r * 4);
+    }
+    const float d[4] = {deltas[(size_t)r * ld], deltas[(size_t)r * ld + 1], deltas[(size_t)r * ld + 2], deltas[(size_t)r * ld + 3]};
+    const float sl[4] = {stdl[(size_t)r * ld], stdl[(size_t)r * ld + 1], stdl[(size_t)r * ld + 2], stdl[(size_t)r * ld + 3]};
+    const float sw = pb.z - pb.x + 1.f, sh = pb.w - pb.y + 1.f;
+    const float t[4] = {wx * (gb.x - pb.x) / sw, wx * (gb.z - pb.z) / sw, wy * (gb.y - pb.y) / sh, wy * (gb.w - pb.w) / sh};
+    float g_d[4] = {0.f, 0.f, 0.f, 0.f}, g_s[4] = {0.f, 0.f, 0.f, 0.f};
+    const float fgf = fg ? 1.f : 0.f;
+    if (mode == 2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float ct = 1.f - sigmoidf_(gstd ? gstd[(size_t)r * 4 + k] : 0.f), cs = 1.f - sigmoidf_(sl[k]);
+        const float m = (ct > cs + ts_better && ct > t_cert && fg) ? 1.f : 0.f;
+        const float df = d[k] - t[k];
+        acc += fabsf(df) * m;
+        g_d[k] = (df > 0.f ? 1.f : df < 0.f ? -1.f : 0.f) * m;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float df = d[k] - t[k];
+        acc += fabsf(df) * fgf;
+        g_d[k] = (df > 0.f ? 1.f : df < 0.f ? -1.f : 0.f) * fgf;
+      }
+      if (mode == 0) {
+        const float w = pb.z - pb.x, h = pb.w - pb.y;
+        const float wd[4] = {wx, wx, wy, wy};
+        const float side[4] = {w, w, h, h};
+        float q[4], dq[4];   // clamped delta / weight and its derivative w.r.t. the delta
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float v = d[k] / wd[k];
+          q[k] = v > clampv ? clampv : v < -clampv ? -clampv : v;   // NaN stays NaN like torch.clamp
+          dq[k] = (v >= -clampv && v <= clampv) ? side[k] / wd[k] : 0.f;
+        }
+        const float px1 = q[0] * w + pb.x, px2 = q[1] * w + pb.z, py1 = q[2] * h + pb.y, py2 = q[3] * h + pb.w;
+        const float a1 = (gb.z - gb.x) * (gb.w - gb.y), a2 = (px2 - px1) * (py2 - py1);
+        const float ltx = fmaxf(gb.x, px1), lty = fmaxf(gb.y, py1), rbx = fminf(gb.z, px2), rby = fminf(gb.w, py2);
+        const float whx = fmaxf(rbx - ltx, 0.f), why = fmaxf(rby - lty, 0.f);
+        const float I = whx * why, U = a1 + a2 - I;
+        const float iou = fg ? I / U : 0.f;
+        float nll = 0.f, sig[4], sq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          sig[k] = sigmoidf_(sl[k]);
+          sq[k] = sig[k] * sig[k];
+          const float df = t[k] - d[k];
+          nll += df * df / (2.f * sq[k]) + 0.5f * logf(sq[k]);
+        }
+        nll += 2.f * 1.8378770664093453f;  // 2 log(2 pi)
+        acc += 0.05f * (nll * iou * fgf);
+        if (fg) {
+          // torch.max / torch.min send the gradient to the selected operand (half on a tie), clamp(min=0) passes it where its input >= 0
+          const float cx = (rbx - ltx) >= 0.f ? 1.f : 0.f, cy = (rby - lty) >= 0.f ? 1.f : 0.f;
+          const float mx1 = px1 > gb.x ? 1.f : px1 == gb.x ? 0.5f : 0.f, mx2 = px2 < gb.z ? 1.f : px2 == gb.z ? 0.5f : 0.f;
+          const float my1 = py1 > gb.y ? 1.f : py1 == gb.y ? 0.5f : 0.f, my2 = py2 < gb.w ? 1.f : py2 == gb.w ? 0.5f : 0.f;
+          // order of the deltas: x1, x2, y1, y2
+          const float dI[4] = {-why * cx * mx1, why * cx * mx2, -whx * cy * my1, whx * cy * my2};
+          const float dA[4] = {-(py2 - py1), (py2 - py1), -(px2 - px1), (px2 - px1)};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float diou = (dI[k] * (U + I) - I * dA[k]) / (U * U) * dq[k];
+            const float df = d[k] - t[k];
+            g_d[k] += 0.05f * (iou * df / sq[k] + nll * diou);
+            g_s[k] = 0.05f * iou * (1.f - sig[k]) * (1.f - df * df / sq[k]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gd[(size_t)r * 4 + k] = g_d[k];
+      gs[(size_t)r * 4 + k] = g_s[k];
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sum[0] = red[0];
+}
+
 extern "C" {
 
 // boxes: [N][P][4] (box_img_stride = P*4) or shared anchors [P][4] (box_img_stride = 0).
@@ -745,6 +967,62 @@ int utv2_rpn_decode(const int64_t* top, int maxk, const float* head, const float
   hipLaunchKernelGGL(rpn_decode_kernel, dim3(cdiv(K, 256), N), dim3(256), 0, stream, L, (const long long*)top, maxk, head, anchors, image_hw,
                      N, A, ch, weights_host[0], weights_host[1], weights_host[2], weights_host[3], scale_clamp, min_size, boxes, scores,
                      lvls, keep);
+  return utv2_launch_status();
+}
+
+static int fill_rpn_loss_args(RpnLossArgs& a, const float* obj, const float* deltas, int head, int num_levels, const int* hw_host, int N,
+                              int A, int ch, int R, const float* anchors, const int64_t* pos_idx, const unsigned char* pos_valid, int npos,
+                              const int64_t* neg_idx, const unsigned char* neg_valid, int nneg, const int* matched,
+                              const unsigned char* has_gt, const float* gt_boxes, const float* gt_scores, int G, const float* weights_host) {
+  if (!obj || !deltas || !pos_idx || !pos_valid || !neg_idx || !neg_valid || N < 1 || R < 1 || npos < 0 || nneg < 0) return UTV2_EARG;
+  a.L.n = 0;
+  if (head) {
+    if (A < 1 || ch < 5 * A) return UTV2_EARG;
+    if (int e = fill_rpn_levels(a.L, num_levels, N, hw_host, nullptr, A)) return e;
+  }
+  a.head = head; a.N = N; a.A = A; a.ch = ch; a.R = R; a.npos = npos; a.nneg = nneg; a.G = G;
+  a.obj = obj; a.deltas = deltas; a.anchors = anchors;
+  a.pos_idx = (const long long*)pos_idx; a.pos_valid = pos_valid; a.neg_idx = (const long long*)neg_idx; a.neg_valid = neg_valid;
+  a.matched = matched; a.has_gt = has_gt; a.gt_boxes = gt_boxes; a.gt_scores = gt_scores;
+  a.wx = weights_host ? weights_host[0] : 1.f; a.wy = weights_host ? weights_host[1] : 1.f;
+  a.ww = weights_host ? weights_host[2] : 1.f; a.wh = weights_host ? weights_host[3] : 1.f;
+  return UTV2_OK;
+}
+
+int utv2_rpn_loss_fwd(const float* obj, const float* deltas, int head, int num_levels, const int* hw_host, int N, int A, int ch, int R,
+                      const float* anchors, const int64_t* pos_idx, const unsigned char* pos_valid, int npos, const int64_t* neg_idx,
+                      const unsigned char* neg_valid, int nneg, const int* matched, const unsigned char* has_gt, const float* gt_boxes,
+                      const float* gt_scores, int G, const float* weights_host, float* sums, float* gobj, float* gdl, hipStream_t stream) {
+  RpnLossArgs a;
+  if (!anchors || !matched || !has_gt || !gt_boxes || !weights_host || !sums || !gobj || !gdl || G < 1) return UTV2_EARG;
+  if (int e = fill_rpn_loss_args(a, obj, deltas, head, num_levels, hw_host, N, A, ch, R, anchors, pos_idx, pos_valid, npos, neg_idx,
+                                 neg_valid, nneg, matched, has_gt, gt_boxes, gt_scores, G, weights_host))
+    return e;
+  hipLaunchKernelGGL(rpn_loss_fwd_kernel, dim3(1), dim3(256), 0, stream, a, sums, gobj, gdl);
+  return utv2_launch_status();
+}
+
+int utv2_rpn_loss_bwd(const float* gobj, const float* gdl, const float* gout_cls, const float* gout_loc, int head, int num_levels,
+                      const int* hw_host, int N, int A, int ch, int R, const int64_t* pos_idx, const unsigned char* pos_valid, int npos,
+                      const int64_t* neg_idx, const unsigned char* neg_valid, int nneg, float* grad_obj, float* grad_deltas,
+                      hipStream_t stream) {
+  RpnLossArgs a;
+  if (!gobj || !gdl || !gout_cls || !gout_loc) return UTV2_EARG;
+  if (int e = fill_rpn_loss_args(a, grad_obj, grad_deltas, head, num_levels, hw_host, N, A, ch, R, nullptr, pos_idx, pos_valid, npos, neg_idx,
+                                 neg_valid, nneg, nullptr, nullptr, nullptr, nullptr, 1, nullptr))
+    return e;
+  const int total = N * (npos + nneg);
+  if (total == 0) return UTV2_OK;
+  hipLaunchKernelGGL(rpn_loss_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a, gobj, gdl, gout_cls, gout_loc, grad_obj, grad_deltas);
+  return utv2_launch_status();
+}
+
+int utv2_roi_box_loss(const float* deltas, const float* stdl, int64_t ld, const int64_t* cls, const float* prop, const float* gtb,
+                      const float* gstd, int R, int num_classes, int mode, float wx, float wy, float scale_clamp, float ts_better,
+                      float t_cert, float* sum, float* gdeltas, float* gstd_out, hipStream_t stream) {
+  if (!deltas || !stdl || !cls || !prop || !gtb || !sum || !gdeltas || !gstd_out || R < 0 || ld < 4 || mode < 0 || mode > 3) return UTV2_EARG;
+  hipLaunchKernelGGL(roi_box_loss_kernel, dim3(1), dim3(256), 0, stream, deltas, stdl, (long long)ld, (const long long*)cls, prop, gtb, gstd, R,
+                     num_classes, mode, wx, wy, scale_clamp, ts_better, t_cert, sum, gdeltas, gstd_out);
   return utv2_launch_status();
 }
 

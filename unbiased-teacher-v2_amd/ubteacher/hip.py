@@ -577,6 +577,51 @@ def rpn_decode(top, head, anchors, image_hw, hw, ks, N, A, weights, scale_clamp,
     return boxes, scores, lvls, keep
 
 
+def _u8(t):
+    """bool / uint8 tensor as a contiguous uint8 tensor (same bytes)"""
+    t = t.contiguous()
+    return t.view(torch.uint8) if t.dtype == torch.bool else t
+
+
+def rpn_loss_fwd(obj, deltas, head_hw, N, A, R, anchors, s, gt_boxes, gt_scores, weights):
+    """(sums [2], gobj [N, npos+nneg], gdl [N, npos, 4]); head_hw = None: dense obj [N,R] / deltas [N,R,4]; else obj is deltas is the
+    level-first head output and head_hw the pixels per level.  s: the sampler's dict (pos_idx, pos_valid, neg_idx, neg_valid, matched32, has_gt)."""
+    dev = obj.device
+    npos, nneg = s["pos_idx"].shape[1], s["neg_idx"].shape[1]
+    sums = torch.empty(2, dtype=torch.float32, device=dev)
+    gobj = torch.empty((N, npos + nneg), dtype=torch.float32, device=dev)
+    gdl = torch.empty((N, npos, 4), dtype=torch.float32, device=dev)
+    head = head_hw is not None
+    hw = _iarr(head_hw if head else [1])
+    G = gt_boxes.shape[1]
+    call("utv2_rpn_loss_fwd", _p(obj), _p(deltas), int(head), len(head_hw) if head else 1, ctypes.cast(hw, c_p), N, A, obj.shape[-1] if head else 0, R,
+         _p(anchors), _p(s["pos_idx"]), _p(_u8(s["pos_valid"])), npos, _p(s["neg_idx"]), _p(_u8(s["neg_valid"])), nneg, _p(s["matched32"]),
+         _p(_u8(s["has_gt"])), _p(gt_boxes), _p(gt_scores), G, ctypes.cast(_farr(weights), c_p), _p(sums), _p(gobj), _p(gdl), _stream())
+    return sums, gobj, gdl
+
+
+def rpn_loss_bwd(gobj, gdl, gout_cls, gout_loc, head_hw, N, A, ch, R, s, grad_obj, grad_deltas):
+    head = head_hw is not None
+    hw = _iarr(head_hw if head else [1])
+    npos, nneg = s["pos_idx"].shape[1], s["neg_idx"].shape[1]
+    call("utv2_rpn_loss_bwd", _p(gobj), _p(gdl), _p(gout_cls), _p(gout_loc), int(head), len(head_hw) if head else 1, ctypes.cast(hw, c_p), N, A, ch, R,
+         _p(s["pos_idx"]), _p(_u8(s["pos_valid"])), npos, _p(s["neg_idx"]), _p(_u8(s["neg_valid"])), nneg, _p(grad_obj), _p(grad_deltas), _stream())
+
+
+def roi_box_loss(deltas, std, cls, prop, gtb, gstd, num_classes, mode, wx, wy, scale_clamp, ts_better, t_cert):
+    """(sum [1], d sum / d deltas [R,4], d sum / d std [R,4]); deltas / std may be column slices of the predictor output (row pitch = stride(0))"""
+    R = deltas.shape[0]
+    assert deltas.dtype == torch.float32 and std.dtype == torch.float32 and deltas.stride(1) == 1 and std.stride(1) == 1
+    assert deltas.stride(0) == std.stride(0) and cls.dtype == torch.int64
+    dev = deltas.device
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    gd = torch.empty((R, 4), dtype=torch.float32, device=dev)
+    gs = torch.empty((R, 4), dtype=torch.float32, device=dev)
+    call("utv2_roi_box_loss", c_p(deltas.data_ptr()), c_p(std.data_ptr()), deltas.stride(0), _p(cls), _p(prop), _p(gtb), _p(gstd), R, num_classes,
+         mode, float(wx), float(wy), float(scale_clamp), float(ts_better), float(t_cert), _p(out), _p(gd), _p(gs), _stream())
+    return out, gd, gs
+
+
 def softmax_focal_fwd(logits, target, gamma):
     R, C = logits.shape
     out = torch.empty(1, dtype=torch.float32, device=logits.device)

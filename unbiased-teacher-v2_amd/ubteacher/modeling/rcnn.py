@@ -104,6 +104,49 @@ def sample_k_smallest(keys, mask, k):
     return idx, v < 2.0
 
 
+class _RpnLossFn(torch.autograd.Function):
+    """[sum BCE, sum L1] of PseudoLabRPN.losses as one node: forward = utv2_rpn_loss_fwd (which also leaves the per-slot derivatives),
+    backward = zero-fill + utv2_rpn_loss_bwd scatter."""
+
+    @staticmethod
+    def forward(ctx, obj, deltas, rpn, anchors, s, gt, head_hw, N):
+        R = anchors.shape[0]
+        hw = [h * w for (h, w) in head_hw] if head_hw is not None else None
+        sums, gobj, gdl = hip.rpn_loss_fwd(obj.detach(), deltas.detach(), hw, N, rpn.A, R, anchors, s, gt["boxes"],
+                                           gt["scores"] if "scores" in gt else None, rpn.box_weights)
+        ctx.meta = (hw, N, rpn.A, R, s, tuple(obj.shape), tuple(deltas.shape), head_hw is not None)
+        ctx.save_for_backward(gobj, gdl)
+        return sums
+
+    @staticmethod
+    def backward(ctx, g):
+        gobj, gdl = ctx.saved_tensors
+        hw, N, A, R, s, oshape, dshape, head = ctx.meta
+        g = g.contiguous()
+        grad_obj = torch.zeros(oshape, dtype=torch.float32, device=g.device)
+        grad_dl = grad_obj if head else torch.zeros(dshape, dtype=torch.float32, device=g.device)
+        hip.rpn_loss_bwd(gobj, gdl, g[0:1], g[1:2], hw, N, A, oshape[-1] if head else 0, R, s, grad_obj, grad_dl)
+        return grad_obj, (None if head else grad_dl), None, None, None, None, None, None
+
+
+class _RoiBoxLossFn(torch.autograd.Function):
+    """box_reg_loss / box_reg_pseudo_loss (fast_rcnn.py:938-1090) as one node: utv2_roi_box_loss computes the sum and its derivatives
+    w.r.t. the deltas and std logits in the forward launch; the backward scales them."""
+
+    @staticmethod
+    def forward(ctx, deltas, std, cls, prop, gtb, gstd, pred, mode):
+        t = pred.box2box_transform
+        out, gd, gs = hip.roi_box_loss(deltas.detach(), std.detach(), cls, prop, gtb, gstd, pred.num_classes, mode, t.weights[0], t.weights[1],
+                                       t.scale_clamp, pred.ts_better, pred.t_cert)
+        ctx.save_for_backward(gd, gs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gd, gs = ctx.saved_tensors
+        return gd * g, gs * g, None, None, None, None, None, None
+
+
 # ---------------------------------------------------------------------------------------------------
 class AnchorGenerator:
     """D2 DefaultAnchorGenerator [D2-recall]: sizes per level x aspect ratios, offset 0, order (H, W, A)."""
@@ -210,8 +253,7 @@ class PseudoLabRPN:
         anchors = self.anchor_generator(hw, big.device)
         losses = {}
         if (self.training and compute_loss) or compute_val_loss:
-            obj, dl = self._per_image_views(big, N, hw)
-            losses = self.losses(torch.cat(anchors), torch.cat(obj, 1), torch.cat(dl, 1), gt)
+            losses = self.losses(self._anchors_cat(anchors, hw, big.device), big, None, gt, head_hw=hw)
             losses = {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}  # applied twice
         with torch.no_grad():
             sel = self._pre_nms_topk(big.detach(), N, hw)
@@ -221,6 +263,16 @@ class PseudoLabRPN:
                 obj, dl = self._per_image_views(big.detach(), N, hw)
                 proposals = self.predict_proposals(anchors, obj, dl, image_sizes)
         return proposals, losses
+
+    def _anchors_cat(self, anchors, hw, dev):
+        cache = self.__dict__.setdefault("_anchor_cat_cache", {})
+        ck = (tuple(hw), str(dev))
+        a = cache.get(ck)
+        if a is None:
+            if len(cache) >= 16:
+                cache.clear()
+            a = cache[ck] = torch.cat(anchors).contiguous()
+        return a
 
     @torch.no_grad()
     def _pre_nms_topk(self, big, N, hw):
@@ -300,34 +352,18 @@ class PseudoLabRPN:
         npos = pval.sum(1, keepdim=True)
         nidx, nval = sample_k_smallest(keys, labels == 0, self.batch_size_per_image)
         nval = nval & (torch.arange(nidx.shape[1], device=anchors.device)[None, :] < (self.batch_size_per_image - npos))
-        return dict(pos_idx=pidx, pos_valid=pval, neg_idx=nidx, neg_valid=nval, matched=arg.long(), has_gt=has_gt)
+        return dict(pos_idx=pidx, pos_valid=pval, neg_idx=nidx, neg_valid=nval, matched=arg.long(), matched32=arg, has_gt=has_gt)
 
-    def losses(self, anchors, obj, deltas, gt):
+    def losses(self, anchors, obj, deltas, gt, head_hw=None):
         """rpn.py:153-225: BCE(sum) over sampled anchors (optionally weighted by the matched pseudo-box score,
-        negatives too - SURVEY B4) + L1 on positives, both / (batch_size_per_image * N), weights applied here too."""
-        N = obj.shape[0]
+        negatives too - SURVEY B4) + L1 on positives, both / (batch_size_per_image * N), weights applied here too.
+        One fused forward launch and one backward launch (utv2_rpn_loss_fwd / _bwd).  obj [N,R] + deltas [N,R,4], or - head_hw given -
+        obj = the level-first head output [P, RPN_CH] (deltas ignored): no per-image copies of the logits / deltas are made."""
+        N = gt.n
         s = self.label_and_sample(anchors, gt)
-        pseudo = "scores" in gt
-        idx = torch.cat((s["pos_idx"], s["neg_idx"]), dim=1)
-        valid = torch.cat((s["pos_valid"], s["neg_valid"]), dim=1)
-        target = torch.cat((torch.ones_like(s["pos_idx"]), torch.zeros_like(s["neg_idx"])), dim=1).float()
-        logit = torch.gather(obj, 1, idx)
-        w = valid.float()
-        if pseudo:
-            conf = torch.gather(gt["scores"], 1, torch.gather(s["matched"], 1, idx))
-            w = w * torch.where(s["has_gt"], conf, torch.zeros_like(conf))
-        cls = (F.binary_cross_entropy_with_logits(logit, target, reduction="none") * w).sum()
-        pa = anchors[s["pos_idx"]]
-        pg = torch.gather(gt["boxes"], 1, torch.gather(s["matched"], 1, s["pos_idx"])[:, :, None].expand(-1, -1, 4))
-        pv = s["pos_valid"] & s["has_gt"]
-        safe = torch.tensor([0.0, 0.0, 1.0, 1.0], device=pa.device)
-        pg = torch.where(pv[:, :, None], pg, safe)
-        pa_s = torch.where(pv[:, :, None], pa, safe)
-        tgt = rpn_get_deltas(pa_s, pg, self.box_weights)
-        pd = torch.gather(deltas, 1, s["pos_idx"][:, :, None].expand(-1, -1, 4))
-        loc = ((pd - tgt).abs() * pv[:, :, None].float()).sum()
+        sums = _RpnLossFn.apply(obj, obj if head_hw is not None else deltas, self, anchors, s, gt, head_hw, N)
         norm = self.batch_size_per_image * N
-        out = {"loss_rpn_cls": cls / norm, "loss_rpn_loc": loc / norm}
+        out = {"loss_rpn_cls": sums[0] / norm, "loss_rpn_loc": sums[1] / norm}
         self._last_sample = s
         return {k: v * self.loss_weight.get(k, 1.0) for k, v in out.items()}
 
@@ -411,41 +447,11 @@ class FastRCNNFocaltLossBoundaryVarOutputLayers:
         Rn = (cls >= 0).sum().clamp(min=1).float()        # gt_classes.numel() of the reference
         tgt = cls.to(torch.int32).contiguous()
         loss_cls = ops.softmax_focal_sum(scores, tgt, self.focal_gamma)[0] / Rn
-        fg = (cls >= 0) & (cls < self.num_classes)
-        pb = sampled["proposal_boxes"].reshape(-1, 4)
-        gb = sampled["gt_boxes"].reshape(-1, 4)
-        safe = torch.tensor([0.0, 0.0, 1.0, 1.0], device=pb.device)
-        pb = torch.where(fg[:, None], pb, safe)
-        gb = torch.where(fg[:, None], gb, safe)
-        fgf = fg.float()
-        gt_d = self.box2box_transform.get_deltas(pb, gb)
-        if branch == "unsup_data_train":
-            if self.box_pseudo_reg_loss_type == "tsbetter":
-                gstd = sampled["gt_loc_std"].reshape(-1, 4) if "gt_loc_std" in sampled else torch.zeros_like(std)
-                ct = 1 - gstd.sigmoid()
-                cs = 1 - std.sigmoid()
-                sel = (ct > cs + self.ts_better) & (ct > self.t_cert) & fg[:, None]
-                box = ((deltas - gt_d).abs() * sel.float()).sum()
-            else:
-                box = ((deltas - gt_d).abs() * fgf[:, None]).sum()
-        else:
-            l1 = ((deltas - gt_d).abs() * fgf[:, None]).sum()
-            if self.box_reg_loss_type == "nlloss":
-                pred = self.box2box_transform.apply_deltas(deltas, pb)
-                a1 = (gb[:, 2] - gb[:, 0]) * (gb[:, 3] - gb[:, 1])
-                a2 = (pred[:, 2] - pred[:, 0]) * (pred[:, 3] - pred[:, 1])
-                lt = torch.max(gb[:, :2], pred[:, :2])
-                rb = torch.min(gb[:, 2:], pred[:, 2:])
-                wh = (rb - lt).clamp(min=0)
-                inter = wh[:, 0] * wh[:, 1]
-                iou = inter / (a1 + a2 - inter)            # fast_rcnn.py:20-44, gradient flows
-                iou = torch.where(fg, iou, torch.zeros_like(iou))
-                sig = std.sigmoid()
-                sq = sig * sig
-                nll = ((gt_d - deltas) ** 2 / (2 * sq) + 0.5 * torch.log(sq)).sum(1) + 2 * math.log(2 * math.pi)
-                box = l1 + 0.05 * (nll * iou * fgf).sum()
-            else:
-                box = l1
+        pseudo = branch == "unsup_data_train"
+        mode = (2 if self.box_pseudo_reg_loss_type == "tsbetter" else 3) if pseudo else (0 if self.box_reg_loss_type == "nlloss" else 1)
+        gstd = sampled["gt_loc_std"].reshape(-1, 4).contiguous() if (mode == 2 and "gt_loc_std" in sampled) else None
+        box = _RoiBoxLossFn.apply(deltas, std, cls.long().contiguous(), sampled["proposal_boxes"].reshape(-1, 4).contiguous(),
+                                  sampled["gt_boxes"].reshape(-1, 4).contiguous(), gstd, self, mode)[0]
         out = {"loss_cls": loss_cls, "loss_box_reg": box / Rn}
         return {k: v * self.loss_weight.get(k, 1.0) for k, v in out.items()}
 
