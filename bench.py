@@ -210,6 +210,21 @@ def pmc_traffic(kernel):
         return None
 
 
+def dispatches_per_step(model):
+    """GPU dispatches (kernels + copies) per step, from the committed kernel trace of THIS command
+    (profiles/r02_<model>_4p4_bf16_timeline.txt, tools/rocpd_timeline.py over the last 6 of `bench.py --timed-only` steps)"""
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_%s_4p4_bf16_timeline.txt" % model)
+    try:
+        with open(path) as f:
+            m = re.search(r"window [0-9.]+ ms \(([0-9.]+) ms / step\), (\d+) dispatches", f.read())
+        if not m:
+            return None
+        return {"dispatches_per_step": int(m.group(2)) / 6.0, "ms_per_step_under_rocprofv3": float(m.group(1)), "source": os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))}
+    except OSError:
+        return None
+
+
 def cpu_baseline_run(label, unlabel, warmup, steps):
     """The oracle (CPU port of the reference step: its orchestration + restated Detectron2 primitives on stock torch CPU kernels) timed
     on the host cores: `warmup` + `steps` iterations of the SAME post-burn-in FCOS step on `label` labeled (weak + strong views) +
@@ -497,7 +512,7 @@ def worker(args):
             "ranks": {"world_size": world, "backend": info["backend"], "devices": devices,
                       "launcher": _launcher_name(world)},
             "host": {"ms_per_step_on_96x128_images": host_ms, "enqueue_ms_per_step": 1e3 * t_host / args.steps,
-                     "cabi_calls_per_step": calls_per_step},
+                     "cabi_calls_per_step": calls_per_step, "gpu_dispatches": dispatches_per_step(args.model) if args.dtype == "bf16" else None},
             "losses": {k: v for k, v in metrics.items() if k.startswith("loss") or k.startswith("teacher")},
             "pseudo_boxes_last_step": pseudo_count,
         }
