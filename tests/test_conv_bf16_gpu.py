@@ -434,3 +434,27 @@ def test_batched_weight_flip_equals_per_layer_flip():
     hip.weight_flip_transpose_bf16_batched(arena, scales, bank, table, len(layers))
     torch.cuda.synchronize()
     assert torch.equal(bank, torch.cat(refs))
+
+
+def test_big_tile_kernels_bit_identical_across_schedules(tmp_path):
+    """The three kernels a deep bf16 conv can run on - the 128 x 128 tile (UTV2_W8=0), the 256 x 256 lock-step tile (UTV2_PP=0) and
+    the 256 x 256 ping-pong tile (default) - accumulate every output element in the same order: bit-identical outputs on a multi-level
+    tower conv, a 3x3 with mask + residual + ReLU epilogue, an fp32-output conv and a wide 1x1 (tools/check_w8.py; the switches are
+    read once per process, hence the subprocesses)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = str(tmp_path / "ref.pt")
+
+    def run(env, *args):
+        e = dict(os.environ); e.update(env)
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_w8.py")] + list(args), env=e, capture_output=True, text=True,
+                             timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return out.stdout
+
+    run({"UTV2_W8": "0"}, "save", ref)
+    for env in ({"UTV2_PP": "0"}, {}):
+        lines = [ln for ln in run(env, "cmp", ref).splitlines() if ln.strip()]
+        assert len(lines) == 4 and all("bit-identical" in ln and "nan" not in ln for ln in lines), lines
