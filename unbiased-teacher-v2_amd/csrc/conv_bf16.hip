@@ -406,6 +406,12 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
       ih0 = oh - p.pad;
       iw0 = ow - p.pad;
     } else {
+      if (p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0) {  // pointwise: output pixel m reads input pixel m, no geometry to decode
+        aoff[j] = mm * p.xs + slot * 8;
+        awc[j] = 0;
+        amask[j] = mv ? 1u : 0u;
+        continue;
+      }
       const int hw = p.OH * p.OW;
       const int n = mm / hw, rem = mm - n * hw;
       const int oh = rem / p.OW, ow = rem - oh * p.OW;
