@@ -168,6 +168,16 @@ int utv2_fcos_loc_terms_fwd(const int* labels, const float* box, int box_stride,
 int utv2_fcos_loc_terms_bwd(const int* labels, const float* box, int box_stride, const float* reg_targets,
                             const float* bvars, int64_t P, int num_classes, int reg_max, float ts_better, float ts_cert,
                             int flags, const float* coef, float* dbox, utv2_stream_t stream);
+/* scalar tail of the FCOS losses of a fused student pass (normalisation fcos_outputs.py:317-321,361-362,381-416; pseudo branch
+ * :504-585; loss weighting engine/trainer.py:396-417): the raw sums of utv2_sigmoid_focal_fwd / utv2_fcos_loc_terms_fwd of the
+ * supervised, pseudo-cls and pseudo-reg target sets -> rec[8] = {cls, loc, ctr, cls_pseudo, ctr_pseudo, loc_pseudo,
+ * teacher_better_student, weighted total} and coef[26] = d total / d {focal_sup[1], sums_sup[8], focal_cls[1], sums_cls[8], sums_reg[8]}.
+ * norm: optional [6] all-reduced (n_pos, sum ctrness) per branch (NULL: the local sums); world = data-parallel world size;
+ * flags 1 KL_LOSS, 2 KL type "klloss", 4 UNIFY_CTRCLS, 8 tsbetter; loss k (order cls, loc, ctr, cls_p, ctr_p, loc_p) enters the total
+ * as value * wmul_host[k] / wdiv_host[k]. */
+int utv2_fcos_loss_combine(const float* focal_sup, const float* sums_sup, const float* focal_cls, const float* sums_cls,
+                           const float* sums_reg, const float* norm, float world, int flags, float kl_weight, const float* wmul_host,
+                           const float* wdiv_host, float* rec, float* coef, utv2_stream_t stream);
 /* :1146-1195 ranking score -> sortable int64 key (method 0 cls, 1 cls_n_ctr, 2 ctr, 3 cls_n_loc); image n's HW*C keys
  * start at keys + n*key_row_stride (>= HW*C: rows of a wider matrix shared by all FPN levels) */
 int utv2_fcos_rank_keys(const float* logits, const float* box, int box_stride, int reg_max, int N, int HW, int C,

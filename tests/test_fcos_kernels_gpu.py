@@ -133,6 +133,40 @@ def test_pseudo_losses(fc):
     level_grads(fc, "pseudo", head_out)
 
 
+def test_joint_losses_fused_tail_equals_op_chain(fc):
+    """FCOSOutputs.joint_losses (raw kernel sums -> normalised losses, the trainer's weighting and the backward coefficients in ONE
+    utv2_fcos_loss_combine launch) against losses() + pseudo_losses() + the trainer's per-key arithmetic as ATen ops: every loss, the
+    weighted total and the gradients of both head buffers.  The two branches own different images of the batch (`active`)."""
+    from ubteacher.modeling.fcos import FCOSOutputs
+    outm = FCOSOutputs(fcos_cfg())
+    N = int(fc["N"])
+    gtl = padded_gt(fc, "sup_gt", N)
+    gtu = {"cls": padded_gt(fc, "pcls_gt", N), "reg": padded_gt(fc, "preg_gt", N)}
+    act = torch.zeros(N, dtype=torch.uint8, device=DEV); act[:max(N // 2, 1)] = 1
+    lu, lr = 4.0, 1.5
+    lw = {"loss_fcos_cls": (1.0, lu + 1.0), "loss_fcos_ctr": (1.0, lu + 1.0), "loss_fcos_loc": (1.0, lr + 1.0),
+          "loss_fcos_cls_pseudo": (lu, lu + 1.0), "loss_fcos_ctr_pseudo": (lu, lu + 1.0), "loss_fcos_loc_pseudo": (lr, lr + 1.0)}
+    ha, level_hw = build_head_out(fc, True)
+    ls, lun, total = outm.joint_losses(ha, level_hw, gtl, gtu, act, lw)
+    total.backward()
+    hb, _ = build_head_out(fc, True)
+    _, rs = outm.losses(hb, level_hw, gtl, active=act)
+    _, ru = outm.pseudo_losses(hb, level_hw, gtu, active=(1 - act))
+    ref = (rs["loss_fcos_cls"] / (lu + 1.0) + rs["loss_fcos_loc"] / (lr + 1.0) + rs["loss_fcos_ctr"] / (lu + 1.0)
+           + ru["loss_fcos_cls"] * lu / (lu + 1.0) + ru["loss_fcos_ctr"] * lu / (lu + 1.0) + ru["loss_fcos_loc"] * lr / (lr + 1.0))
+    ref.backward()
+    for k in ("loss_fcos_cls", "loss_fcos_loc", "loss_fcos_ctr"):
+        close(ls[k], rs[k].detach(), rtol=1e-6)
+        close(lun[k], ru[k].detach(), rtol=1e-6)
+        assert not ls[k].requires_grad
+    close(lun["teacher_better_student"], ru["teacher_better_student"], rtol=0)
+    close(total.detach(), ref.detach(), rtol=1e-6)
+    for key in ("logits", "box"):
+        ga, gb = ha[key].grad, hb[key].grad
+        assert float(gb.abs().max()) > 0
+        assert float((ga - gb).abs().max()) <= 1e-6 * float(gb.abs().max())
+
+
 @pytest.mark.parametrize("method", ["cls", "cls_n_ctr", "cls_n_loc"])
 def test_decode_nms(fc, method):
     from ubteacher.modeling.fcos import FCOSOutputs

@@ -582,6 +582,71 @@ static LevelTable make_table(int num_levels, const int* H, const int* W, const i
   return t;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Scalar tail of the FCOS losses of one fused student pass (fcos_outputs.py:317-321,340-416 supervised; :447-631 pseudo; the loss
+// weighting of engine/trainer.py:396-417): from the raw sums of the loss kernels to the six normalised losses, their weighted total and
+// d(total)/d(every raw sum) in ONE single-thread launch (as ATen scalar ops this was ~60 forward + ~70 backward launches per step, with
+// the GPU idle between them).  Normalisers carry no gradient (they are counts / target sums).
+//   flags: 1 = KL_LOSS on the supervised branch, 2 = KL type "klloss" (mean over positives x 4), 4 = UNIFY_CTRCLS, 8 = tsbetter pseudo loc
+//   wmul / wdiv [6]: the weighted loss k enters the total as value * wmul[k] / wdiv[k]; k = cls, loc, ctr, cls_pseudo, ctr_pseudo, loc_pseudo
+//   rec [8] = {cls, loc, ctr, cls_pseudo, ctr_pseudo, loc_pseudo, teacher_better_student, total}
+//   coef [26] = d total / d {focal_sup[1], sums_sup[8], focal_cls[1], sums_cls[8], sums_reg[8]}
+struct FcosCombineArgs {
+  const float* focal_sup;
+  const float* sums_sup;
+  const float* focal_cls;
+  const float* sums_cls;
+  const float* sums_reg;
+  const float* norm;   // optional [6]: all-reduced (n_pos, sum ctr) of the sup / cls / reg branches
+  float world, kl_weight;
+  int flags;
+  float wmul[6], wdiv[6];
+};
+
+__global__ void fcos_loss_combine_kernel(FcosCombineArgs a, float* __restrict__ rec, float* __restrict__ coef) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < 26; ++i) coef[i] = 0.f;
+  const bool kl = a.flags & 1, kl4 = a.flags & 2, unify = a.flags & 4, tsb = a.flags & 8;
+  float g[6];
+  for (int k = 0; k < 6; ++k) g[k] = a.wmul[k] / a.wdiv[k];
+  const float* S = a.sums_sup;
+  const float npa_s = fmaxf((a.norm ? a.norm[0] : S[0]) / a.world, 1.f), den_s = fmaxf((a.norm ? a.norm[1] : S[1]) / a.world, 1e-6f);
+  const float cls = a.focal_sup[0] / npa_s, ctr = S[2] / npa_s;
+  float loc = S[3] / den_s;
+  coef[0] = g[0] / npa_s;
+  coef[1 + 2] = g[2] / npa_s;
+  coef[1 + 3] = g[1] / den_s;
+  if (kl) {
+    const float n = fmaxf(S[0], 1.f), dn = kl4 ? 4.f * n : n, w = a.kl_weight;
+    loc = w * (w * (S[4] / dn)) + loc;
+    coef[1 + 4] = g[1] * (w * w) / dn;
+  }
+  const float* C = a.sums_cls;
+  const float npa_c = fmaxf((a.norm ? a.norm[2] : C[0]) / a.world, 1.f);
+  const float cls_p = a.focal_cls[0] / npa_c;
+  float ctr_p = C[2] / npa_c;
+  coef[9] = g[3] / npa_c;
+  if (unify) ctr_p = ctr_p * 0.f;
+  else coef[10 + 2] = g[4] / npa_c;
+  const float* R = a.sums_reg;
+  float loc_p, tbs = 0.f;
+  if (tsb) {
+    const float d = fmaxf(R[5], 1.f);
+    loc_p = R[6] / d;
+    tbs = R[5];
+    coef[18 + 6] = g[5] / d;
+  } else {
+    const float n = fmaxf(R[0], 1.f), dn = kl4 ? 4.f * n : n;
+    loc_p = a.kl_weight * (R[4] / dn);
+    coef[18 + 4] = g[5] * a.kl_weight / dn;
+  }
+  rec[0] = cls; rec[1] = loc; rec[2] = ctr; rec[3] = cls_p; rec[4] = ctr_p; rec[5] = loc_p; rec[6] = tbs;
+  const float v[6] = {cls, loc, ctr, cls_p, ctr_p, loc_p};
+  float total = 0.f;
+  for (int k = 0; k < 6; ++k) total += v[k] * a.wmul[k] / a.wdiv[k];   // the trainer's `record * lambda / (lambda + 1)`, summed in key order
+  rec[7] = total;
+}
+
 extern "C" {
 
 // H,W,strides: host int[num_levels]; soi: host float[2*num_levels] (lo,hi per level).
@@ -675,6 +740,19 @@ int utv2_scale_cols_bwd(float* g, const float* ypost, int64_t rows, int row_stri
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(scale_cols_bwd_kernel, dim3(nb), dim3(256), 0, stream, g, ypost, (size_t)rows, row_stride, ncols, s, ws);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, nb, 1, dsum);
+  return utv2_launch_status();
+}
+
+int utv2_fcos_loss_combine(const float* focal_sup, const float* sums_sup, const float* focal_cls, const float* sums_cls,
+                           const float* sums_reg, const float* norm, float world, int flags, float kl_weight, const float* wmul_host,
+                           const float* wdiv_host, float* rec, float* coef, hipStream_t stream) {
+  if (!focal_sup || !sums_sup || !focal_cls || !sums_cls || !sums_reg || !wmul_host || !wdiv_host || !rec || !coef || !(world >= 1.f))
+    return UTV2_EARG;
+  FcosCombineArgs a;
+  a.focal_sup = focal_sup; a.sums_sup = sums_sup; a.focal_cls = focal_cls; a.sums_cls = sums_cls; a.sums_reg = sums_reg; a.norm = norm;
+  a.world = world; a.kl_weight = kl_weight; a.flags = flags;
+  for (int k = 0; k < 6; ++k) { a.wmul[k] = wmul_host[k]; a.wdiv[k] = wdiv_host[k]; }
+  hipLaunchKernelGGL(fcos_loss_combine_kernel, dim3(1), dim3(64), 0, stream, a, rec, coef);
   return utv2_launch_status();
 }
 

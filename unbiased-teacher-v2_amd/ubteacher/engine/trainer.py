@@ -497,11 +497,17 @@ class UBTeacherTrainer(_TrainerBase):
             unlabel_data_k = self.add_label(unlabel_data_k, pseudo_reg, "reg")
 
             all_unlabel_data = unlabel_data_q
+            lu, lr = S.UNSUP_LOSS_WEIGHT, S.UNSUP_REG_LOSS_WEIGHT
+            # the weighting below as (mul, div) per key: the fused pass folds it into its single scalar-tail launch
+            lw = {"loss_fcos_cls": (1.0, lu + 1.0), "loss_fcos_ctr": (1.0, lu + 1.0), "loss_fcos_loc": (1.0, lr + 1.0),
+                  "loss_fcos_cls_pseudo": (lu, lu + 1.0), "loss_fcos_ctr_pseudo": (lu, lu + 1.0), "loss_fcos_loc_pseudo": (lr, lr + 1.0)}
+            if os.environ.get("UTV2_FUSE_LOSS_TAIL", "1") == "0":
+                lw = None
             if ctx is not None:
-                rec_l, record_unl = self.model.forward_joint_finish(ctx, all_unlabel_data)
+                rec_l, record_unl = self.model.forward_joint_finish(ctx, all_unlabel_data, loss_weights=lw)
                 record_dict.update(rec_l)
             elif fuse:
-                rec_l, record_unl = self.model.forward_joint(all_label_data, all_unlabel_data)
+                rec_l, record_unl = self.model.forward_joint(all_label_data, all_unlabel_data, loss_weights=lw)
                 record_dict.update(rec_l)
             else:
                 record_dict.update(self.model(all_label_data, branch="labeled"))
@@ -510,9 +516,9 @@ class UBTeacherTrainer(_TrainerBase):
             for k, v in record_unl.items():
                 record_dict[k + "_pseudo"] = v
 
-            lu, lr = S.UNSUP_LOSS_WEIGHT, S.UNSUP_REG_LOSS_WEIGHT
+            fused_total = record_dict.pop("weighted_total", None)
             loss_dict = {}
-            for key in record_dict.keys():
+            for key in ([] if fused_total is not None else record_dict.keys()):
                 if key[:4] != "loss":
                     continue
                 if key in ("loss_fcos_ctr", "loss_fcos_cls"):
@@ -525,7 +531,7 @@ class UBTeacherTrainer(_TrainerBase):
                     loss_dict[key] = record_dict[key] * lr / (lr + 1.0)
                 else:
                     loss_dict[key] = record_dict[key] / (lu + 1.0)
-            losses = sum(loss_dict.values())
+            losses = fused_total if fused_total is not None else sum(loss_dict.values())
 
         metrics_dict = record_dict
         metrics_dict["data_time"] = data_time

@@ -412,6 +412,16 @@ def fcos_loc_terms_fwd(labels, box, reg_targets, bvars, num_classes, reg_max, ts
     return sums
 
 
+def fcos_loss_combine(focal_sup, sums_sup, focal_cls, sums_cls, sums_reg, norm, world, flags, kl_weight, wmul, wdiv):
+    """(rec [8], coef [26]) - see utv2_fcos_loss_combine"""
+    dev = sums_sup.device
+    rec = torch.empty(8, dtype=torch.float32, device=dev)
+    coef = torch.empty(26, dtype=torch.float32, device=dev)
+    call("utv2_fcos_loss_combine", _p(focal_sup), _p(sums_sup), _p(focal_cls), _p(sums_cls), _p(sums_reg), _p(norm), float(world), int(flags),
+         float(kl_weight), ctypes.cast(_farr(wmul), c_p), ctypes.cast(_farr(wdiv), c_p), _p(rec), _p(coef), _stream())
+    return rec, coef
+
+
 def fcos_loc_terms_bwd(labels, box, reg_targets, bvars, num_classes, reg_max, ts_better, ts_cert, coef, out=None, flags=0):
     P, BS = box.shape
     if out is None:

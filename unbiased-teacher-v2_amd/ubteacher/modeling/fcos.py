@@ -381,6 +381,43 @@ class FCOSOutputs:
             extras["sums_" + labeltype] = sums
         return extras, losses
 
+    # -- both branches of a fused student pass, scalar tail in one launch -------------------------------
+    LOSS_KEYS = ("loss_fcos_cls", "loss_fcos_loc", "loss_fcos_ctr", "loss_fcos_cls_pseudo", "loss_fcos_ctr_pseudo", "loss_fcos_loc_pseudo")
+
+    def joint_losses(self, head_out, level_hw, gt_labeled, gt_unlabeled, act, loss_weights):
+        """losses(labeled) + pseudo_losses(unlabeled) + the trainer's loss weighting: the same target / focal / positive-location kernels,
+        but everything between their raw sums and the weighted total - normalisers, KL means, weights (about 60 scalar launches forward
+        and 70 backward, the GPU idle in between) - is ONE utv2_fcos_loss_combine launch whose backward hands the kernels their
+        coefficients.  loss_weights: key -> (mul, div), the loss enters the total as value * mul / div.  Returns (supervised dict,
+        pseudo dict (keys without the suffix), weighted total); the dict entries are detached (metrics)."""
+        logits_all, box_all = head_out["logits"], head_out["box"]
+        nc, rm = self.num_classes, self.reg_max
+        labels, reg_t, _, _ = self._targets(level_hw, gt_labeled, drop_empty=1, active=act)
+        focal_s = ops.focal_loss_sum(logits_all, labels, self.focal_loss_alpha, self.focal_loss_gamma)
+        flags_s = self.loc_flags | (hip.LT_QUALITY_IOU if self.quality_iou else 0)
+        sums_s = ops.fcos_loc_terms(box_all, labels, reg_t, None, (nc, rm, 0.0, 0.0, flags_s))
+        inact = 1 - act
+        labels, reg_t, _, _ = self._targets(level_hw, gt_unlabeled["cls"], drop_empty=0, active=inact)
+        focal_c = ops.focal_loss_sum(logits_all, labels, self.focal_loss_alpha, self.focal_loss_gamma)
+        sums_c = ops.fcos_loc_terms(box_all, labels, reg_t, None, (nc, rm, 0.0, 0.0, self.loc_flags))
+        tsbetter = self.reg_unsup_loss == "ts_locvar_better_nms_nll_l1"
+        labels, reg_t, bvars, _ = self._targets(level_hw, gt_unlabeled["reg"], drop_empty=0, active=inact)
+        sums_r = ops.fcos_loc_terms(box_all, labels, reg_t, bvars if tsbetter else None,
+                                    (nc, rm, self.tsbetter_reg, self.tsbetter_reg_cert, self.loc_flags))
+        ws = comm.get_world_size()
+        norm = None
+        if ws > 1:   # ONE fused all-reduce of the three branches' (n_pos, sum ctrness) pairs
+            norm = comm.reduce_sum(torch.cat((sums_s[0:2], sums_c[0:2], sums_r[0:2])).detach())
+        flags = (1 if self.kl_loss else 0) | (2 if self.kl_loss_type == "klloss" else 0) | (4 if self.unify_ctrcls else 0) | (8 if tsbetter else 0)
+        wmul = [loss_weights[k][0] for k in self.LOSS_KEYS]
+        wdiv = [loss_weights[k][1] for k in self.LOSS_KEYS]
+        total, rec = ops.fcos_loss_combine(focal_s, sums_s, focal_c, sums_c, sums_r, norm, float(ws), flags, self.kl_loss_weight, wmul, wdiv)
+        l_sup = {"loss_fcos_cls": rec[0], "loss_fcos_loc": rec[1], "loss_fcos_ctr": rec[2]}
+        l_uns = {"loss_fcos_cls": rec[3], "loss_fcos_ctr": rec[4], "loss_fcos_loc": rec[5]}
+        if tsbetter:
+            l_uns["teacher_better_student"] = rec[6]
+        return l_sup, l_uns, total
+
     # -- decode + NMS (fcos_outputs.py:1046-1320) ---------------------------------------------------
     def predict_proposals(self, head_out, level_hw, image_sizes, nms_method="cls_n_ctr", max_det=None):
         """nms_method: one ranking criterion -> PaddedBoxes; a tuple / list of criteria -> a list of PaddedBoxes in that order, computed
@@ -543,11 +580,11 @@ class FCOS:
             return results, {}, raw_output
         return results, {}
 
-    def forward_joint(self, image_sizes, features, n_labeled, gt_labeled, gt_unlabeled):
+    def forward_joint(self, image_sizes, features, n_labeled, gt_labeled, gt_unlabeled, loss_weights=None):
         """Both student passes of one UTv2 iteration on ONE batch: images [0, n_labeled) carry ground truth (branch
         "labeled"), the rest pseudo labels (branch "unlabeled").  Every op of the network is per-image (FrozenBN,
         per-image GroupNorm), so this equals the two separate forwards whenever both groups share one padded canvas."""
-        return self.forward_joint_finish(self.forward_joint_begin(image_sizes, features, n_labeled, gt_labeled), gt_unlabeled)
+        return self.forward_joint_finish(self.forward_joint_begin(image_sizes, features, n_labeled, gt_labeled), gt_unlabeled, loss_weights)
 
     def forward_joint_begin(self, image_sizes, features, n_labeled, gt_labeled):
         assert self.training
@@ -557,13 +594,21 @@ class FCOS:
         head_out = self.fcos_head(big, meta)
         return dict(head_out=head_out, level_hw=level_hw, n_labeled=n_labeled, gt_labeled=gt_labeled, N=meta.N, device=big.device)
 
-    def forward_joint_finish(self, ctx, gt_unlabeled):
+    def forward_joint_finish(self, ctx, gt_unlabeled, loss_weights=None):
+        """loss_weights (key -> (mul, div), the trainer's weighting of the loss dict): when given and both pseudo label sets are there,
+        the scalar tail runs fused (FCOSOutputs.joint_losses) and the weighted total rides along as l_sup["weighted_total"]."""
         head_out, level_hw, n_labeled, N = ctx["head_out"], ctx["level_hw"], ctx["n_labeled"], ctx["N"]
         act = torch.zeros(N, dtype=torch.uint8, device=ctx["device"])
         act[:n_labeled] = 1
-        _, l_sup = self.fcos_outputs.losses(head_out, level_hw, ctx["gt_labeled"].pad_images(0, N - n_labeled), active=act)
+        gtl = ctx["gt_labeled"].pad_images(0, N - n_labeled)
         gtu = {k: v.pad_images(n_labeled, 0) for k, v in gt_unlabeled.items()}
-        _, l_uns = self.fcos_outputs.pseudo_losses(head_out, level_hw, gtu, active=(1 - act))
+        fo = self.fcos_outputs
+        if loss_weights is not None and set(gtu) == {"cls", "reg"} and fo.kl_loss and all(k in loss_weights for k in fo.LOSS_KEYS):
+            l_sup, l_uns, total = fo.joint_losses(head_out, level_hw, gtl, gtu, act, loss_weights)
+            l_sup["weighted_total"] = total
+            return l_sup, l_uns
+        _, l_sup = fo.losses(head_out, level_hw, gtl, active=act)
+        _, l_uns = fo.pseudo_losses(head_out, level_hw, gtu, active=(1 - act))
         return l_sup, l_uns
 
     __call__ = forward

@@ -89,7 +89,7 @@ class PseudoProposalNetwork(ArenaModel):
 
 @META_ARCH_REGISTRY.register()
 class OneStageDetector(PseudoProposalNetwork):
-    def forward_joint(self, labeled_inputs, unlabeled_inputs):
+    def forward_joint(self, labeled_inputs, unlabeled_inputs, loss_weights=None):
         """model(labeled, branch="labeled") and model(unlabeled, branch="unlabeled") of one iteration
         (reference trainer.py:396-411) as ONE forward over the concatenated batch; returns the two loss dicts.
         Only valid when padded_canvas() of the two lists coincide (the caller checks)."""
@@ -98,7 +98,7 @@ class OneStageDetector(PseudoProposalNetwork):
         features, image_sizes = self._features(both)
         gt_l = self._gt(labeled_inputs, "instances")
         gt_u = {"cls": self._gt(unlabeled_inputs, "instances_class"), "reg": self._gt(unlabeled_inputs, "instances_reg")}
-        return self.proposal_generator.forward_joint(image_sizes, features, len(labeled_inputs), gt_l, gt_u)
+        return self.proposal_generator.forward_joint(image_sizes, features, len(labeled_inputs), gt_l, gt_u, loss_weights)
 
     def forward_joint_begin(self, labeled_inputs, unlabeled_inputs):
         """first half of forward_joint: everything that does not need the pseudo labels (backbone, FPN, towers, prediction convs of the
@@ -109,10 +109,10 @@ class OneStageDetector(PseudoProposalNetwork):
         gt_l = self._gt(labeled_inputs, "instances")
         return self.proposal_generator.forward_joint_begin(image_sizes, features, len(labeled_inputs), gt_l)
 
-    def forward_joint_finish(self, ctx, unlabeled_inputs):
+    def forward_joint_finish(self, ctx, unlabeled_inputs, loss_weights=None):
         """second half: the loss kernels, given the unlabeled images' pseudo labels"""
         gt_u = {"cls": self._gt(unlabeled_inputs, "instances_class"), "reg": self._gt(unlabeled_inputs, "instances_reg")}
-        return self.proposal_generator.forward_joint_finish(ctx, gt_u)
+        return self.proposal_generator.forward_joint_finish(ctx, gt_u, loss_weights)
 
     def forward(self, batched_inputs, output_raw=False, nms_method="cls_n_ctr", ignore_near=False, branch="labeled"):
         if self.training:

@@ -596,6 +596,28 @@ class _LocTermsFn(torch.autograd.Function):
         return d, None, None, None, None
 
 
+class _FcosCombineFn(torch.autograd.Function):
+    """The scalar tail of the FCOS losses of a fused student pass as one node (utv2_fcos_loss_combine): raw kernel sums -> (weighted
+    total, the individual losses for the metrics); backward = the stored d total / d sums, scaled."""
+
+    @staticmethod
+    def forward(ctx, focal_sup, sums_sup, focal_cls, sums_cls, sums_reg, norm, world, flags, kl_weight, wmul, wdiv):
+        rec, coef = hip.fcos_loss_combine(focal_sup.detach(), sums_sup.detach(), focal_cls.detach(), sums_cls.detach(), sums_reg.detach(),
+                                          norm, world, flags, kl_weight, wmul, wdiv)
+        ctx.save_for_backward(coef)
+        ctx.mark_non_differentiable(rec)
+        return rec[7].clone(), rec
+
+    @staticmethod
+    def backward(ctx, g, _):
+        c = ctx.saved_tensors[0] * g
+        return (c[0:1], c[1:9], c[9:10], c[10:18], c[18:26]) + (None,) * 6
+
+
+def fcos_loss_combine(focal_sup, sums_sup, focal_cls, sums_cls, sums_reg, norm, world, flags, kl_weight, wmul, wdiv):
+    return _FcosCombineFn.apply(focal_sup, sums_sup, focal_cls, sums_cls, sums_reg, norm, world, flags, kl_weight, wmul, wdiv)
+
+
 def fcos_loc_terms(box, labels, reg_targets, bvars, args):
     return _LocTermsFn.apply(box, labels, reg_targets, bvars, args)
 
