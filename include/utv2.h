@@ -153,6 +153,13 @@ int utv2_fcos_targets(int num_levels, const int* H_host, const int* W_host, cons
                       const unsigned char* gt_valid, const float* gt_std, int num_classes, int drop_empty,
                       float center_radius, const unsigned char* img_active, int* labels, float* reg_targets, float* bvars,
                       int* gt_inds, utv2_stream_t stream);
+/* the same for a batch of N images of which only [gt_img0, gt_img0 + gt_imgs) carry this loss branch's ground truth (the gt arrays
+ * hold gt_imgs images); every other image gets label -1 - no padded copies of the gt arrays, no activity mask */
+int utv2_fcos_targets_range(int num_levels, const int* H_host, const int* W_host, const int* strides_host, const float* soi_host, int N,
+                            int MAXG, const float* gt_boxes, const int* gt_classes, const unsigned char* gt_valid, const float* gt_std,
+                            int gt_img0, int gt_imgs, int num_classes, int drop_empty, float center_radius,
+                            const unsigned char* img_active, int* labels, float* reg_targets, float* bvars, int* gt_inds,
+                            utv2_stream_t stream);
 /* fvcore sigmoid_focal_loss_jit at :329-338,:619-628 with on-the-fly one-hot.  ws >= 1024 floats */
 int utv2_sigmoid_focal_fwd(const float* logits, const int* labels, int64_t P, int C, float alpha, float gamma,
                            float* loss_sum, float* ws, utv2_stream_t stream);

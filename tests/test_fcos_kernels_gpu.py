@@ -134,24 +134,32 @@ def test_pseudo_losses(fc):
 
 
 def test_joint_losses_fused_tail_equals_op_chain(fc):
-    """FCOSOutputs.joint_losses (raw kernel sums -> normalised losses, the trainer's weighting and the backward coefficients in ONE
-    utv2_fcos_loss_combine launch) against losses() + pseudo_losses() + the trainer's per-key arithmetic as ATen ops: every loss, the
-    weighted total and the gradients of both head buffers.  The two branches own different images of the batch (`active`)."""
-    from ubteacher.modeling.fcos import FCOSOutputs
+    """FCOSOutputs.joint_losses (range form of the target kernel: no padded ground-truth copies, no activity mask; raw kernel sums ->
+    normalised losses, the trainer's weighting and the backward coefficients in ONE utv2_fcos_loss_combine launch) against losses() +
+    pseudo_losses() on padded ground truth with activity masks + the trainer's per-key arithmetic as ATen ops: every loss, the weighted
+    total and the gradients of both head buffers.  The first image(s) of the batch are the labeled branch, the rest the pseudo branch."""
+    from ubteacher.modeling.fcos import FCOSOutputs, PaddedBoxes
     outm = FCOSOutputs(fcos_cfg())
     N = int(fc["N"])
-    gtl = padded_gt(fc, "sup_gt", N)
-    gtu = {"cls": padded_gt(fc, "pcls_gt", N), "reg": padded_gt(fc, "preg_gt", N)}
-    act = torch.zeros(N, dtype=torch.uint8, device=DEV); act[:max(N // 2, 1)] = 1
+    nl = max(N // 2, 1)
+
+    def rows(pb, a, b):
+        return PaddedBoxes(list(pb.image_sizes)[a:b], **{k: v[a:b].contiguous() for k, v in pb.f.items() if k != "count"})
+
+    gtl_full = padded_gt(fc, "sup_gt", N)
+    gtu_full = {"cls": padded_gt(fc, "pcls_gt", N), "reg": padded_gt(fc, "preg_gt", N)}
+    gtl = rows(gtl_full, 0, nl)                                  # what the fused pass hands over: each branch's own images only
+    gtu = {k: rows(v, nl, N) for k, v in gtu_full.items()}
+    act = torch.zeros(N, dtype=torch.uint8, device=DEV); act[:nl] = 1
     lu, lr = 4.0, 1.5
     lw = {"loss_fcos_cls": (1.0, lu + 1.0), "loss_fcos_ctr": (1.0, lu + 1.0), "loss_fcos_loc": (1.0, lr + 1.0),
           "loss_fcos_cls_pseudo": (lu, lu + 1.0), "loss_fcos_ctr_pseudo": (lu, lu + 1.0), "loss_fcos_loc_pseudo": (lr, lr + 1.0)}
     ha, level_hw = build_head_out(fc, True)
-    ls, lun, total = outm.joint_losses(ha, level_hw, gtl, gtu, act, lw)
+    ls, lun, total = outm.joint_losses(ha, level_hw, gtl, gtu, nl, N, lw)
     total.backward()
     hb, _ = build_head_out(fc, True)
-    _, rs = outm.losses(hb, level_hw, gtl, active=act)
-    _, ru = outm.pseudo_losses(hb, level_hw, gtu, active=(1 - act))
+    _, rs = outm.losses(hb, level_hw, gtl.pad_images(0, N - nl), active=act)
+    _, ru = outm.pseudo_losses(hb, level_hw, {k: v.pad_images(nl, 0) for k, v in gtu.items()}, active=(1 - act))
     ref = (rs["loss_fcos_cls"] / (lu + 1.0) + rs["loss_fcos_loc"] / (lr + 1.0) + rs["loss_fcos_ctr"] / (lu + 1.0)
            + ru["loss_fcos_cls"] * lu / (lu + 1.0) + ru["loss_fcos_ctr"] * lu / (lu + 1.0) + ru["loss_fcos_loc"] * lr / (lr + 1.0))
     ref.backward()

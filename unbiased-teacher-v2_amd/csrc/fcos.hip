@@ -43,25 +43,30 @@ __global__ __launch_bounds__(256) void fcos_targets_kernel(LevelTable lt, int N,
                                                          const unsigned char* __restrict__ gt_valid,
                                                          const float* __restrict__ gt_std, int num_classes, int drop_empty,
                                                          float center_radius, const unsigned char* __restrict__ img_active,
-                                                         int* __restrict__ labels, float* __restrict__ reg_targets,
-                                                         float* __restrict__ bvars, int* __restrict__ gt_inds) {
+                                                         int gt_img0, int gt_imgs, int* __restrict__ labels,
+                                                         float* __restrict__ reg_targets, float* __restrict__ bvars,
+                                                         int* __restrict__ gt_inds) {
   __shared__ float sb[TG_MAXG][4];
   __shared__ float sarea[TG_MAXG];
   __shared__ int sidx[TG_MAXG];
   __shared__ int scount;
   const int n = blockIdx.y;
   const int L = lt.off[lt.num_levels];
+  // the gt arrays describe images [gt_img0, gt_img0 + gt_imgs) of the batch; the others belong to another loss branch
+  const int gi = n - gt_img0;
+  const bool in_range = gi >= 0 && gi < gt_imgs;
   if (threadIdx.x == 0) {
     // ordered compaction of the valid gts (serial: MAXG <= 256)
     int c = 0;
-    for (int g = 0; g < MAXG; ++g)
-      if (gt_valid[n * MAXG + g]) sidx[c++] = g;
+    if (in_range)
+      for (int g = 0; g < MAXG; ++g)
+        if (gt_valid[gi * MAXG + g]) sidx[c++] = g;
     scount = c;
   }
   __syncthreads();
   const int G = scount;
   for (int k = threadIdx.x; k < G; k += blockDim.x) {
-    const float* b = gt_boxes + ((size_t)n * MAXG + sidx[k]) * 4;
+    const float* b = gt_boxes + ((size_t)gi * MAXG + sidx[k]) * 4;
     sb[k][0] = b[0]; sb[k][1] = b[1]; sb[k][2] = b[2]; sb[k][3] = b[3];
     sarea[k] = (b[2] - b[0]) * (b[3] - b[1]);
   }
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(256) void fcos_targets_kernel(LevelTable lt, int N,
   const float ys = (float)(y * lt.stride[l]) + (float)(lt.stride[l] / 2);
   const size_t p = (size_t)N * lt.off[l] + (size_t)n * HWl + hw;
   // an inactive image (it belongs to the other loss branch of a fused student pass) is ignored like a dropped one
-  const bool inactive = img_active != nullptr && !img_active[n];
+  const bool inactive = !in_range || (img_active != nullptr && !img_active[n]);
   if (G == 0 || inactive) {
     labels[p] = (drop_empty || inactive) ? -1 : num_classes;
     gt_inds[p] = -1;
@@ -111,14 +116,14 @@ __global__ __launch_bounds__(256) void fcos_targets_kernel(LevelTable lt, int N,
   }
   const bool bg = (best == INF);
   const int g = sidx[bi];
-  labels[p] = bg ? num_classes : gt_classes[n * MAXG + g];
+  labels[p] = bg ? num_classes : gt_classes[gi * MAXG + g];
   gt_inds[p] = g;
   reg_targets[p * 4 + 0] = (xs - sb[bi][0]) / s;
   reg_targets[p * 4 + 1] = (ys - sb[bi][1]) / s;
   reg_targets[p * 4 + 2] = (sb[bi][2] - xs) / s;
   reg_targets[p * 4 + 3] = (sb[bi][3] - ys) / s;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) bvars[p * 4 + e] = bg ? 99999.0f : (gt_std ? gt_std[((size_t)n * MAXG + g) * 4 + e] : 0.f);
+  for (int e = 0; e < 4; ++e) bvars[p * 4 + e] = bg ? 99999.0f : (gt_std ? gt_std[((size_t)gi * MAXG + g) * 4 + e] : 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -650,18 +655,28 @@ __global__ void fcos_loss_combine_kernel(FcosCombineArgs a, float* __restrict__ 
 extern "C" {
 
 // H,W,strides: host int[num_levels]; soi: host float[2*num_levels] (lo,hi per level).
-int utv2_fcos_targets(int num_levels, const int* H, const int* W, const int* strides, const float* soi, int N, int MAXG,
-                      const float* gt_boxes, const int* gt_classes, const unsigned char* gt_valid, const float* gt_std,
-                      int num_classes, int drop_empty, float center_radius, const unsigned char* img_active, int* labels,
-                      float* reg_targets, float* bvars, int* gt_inds, hipStream_t stream) {
+int utv2_fcos_targets_range(int num_levels, const int* H, const int* W, const int* strides, const float* soi, int N, int MAXG,
+                            const float* gt_boxes, const int* gt_classes, const unsigned char* gt_valid, const float* gt_std,
+                            int gt_img0, int gt_imgs, int num_classes, int drop_empty, float center_radius,
+                            const unsigned char* img_active, int* labels, float* reg_targets, float* bvars, int* gt_inds,
+                            hipStream_t stream) {
   if (num_levels < 1 || num_levels > MAX_LEVELS || MAXG > TG_MAXG || MAXG < 1 || !gt_boxes || !gt_classes || !gt_valid ||
-      !labels || !reg_targets || !bvars || !gt_inds)
+      !labels || !reg_targets || !bvars || !gt_inds || gt_img0 < 0 || gt_imgs < 0 || gt_img0 + gt_imgs > N)
     return UTV2_EARG;
   LevelTable t = make_table(num_levels, H, W, strides, soi);
   const int L = t.off[num_levels];
   hipLaunchKernelGGL(fcos_targets_kernel, dim3(cdiv(L, 256), N), dim3(256), 0, stream, t, N, MAXG, gt_boxes, gt_classes,
-                     gt_valid, gt_std, num_classes, drop_empty, center_radius, img_active, labels, reg_targets, bvars, gt_inds);
+                     gt_valid, gt_std, num_classes, drop_empty, center_radius, img_active, gt_img0, gt_imgs, labels, reg_targets, bvars,
+                     gt_inds);
   return utv2_launch_status();
+}
+
+int utv2_fcos_targets(int num_levels, const int* H, const int* W, const int* strides, const float* soi, int N, int MAXG,
+                      const float* gt_boxes, const int* gt_classes, const unsigned char* gt_valid, const float* gt_std,
+                      int num_classes, int drop_empty, float center_radius, const unsigned char* img_active, int* labels,
+                      float* reg_targets, float* bvars, int* gt_inds, hipStream_t stream) {
+  return utv2_fcos_targets_range(num_levels, H, W, strides, soi, N, MAXG, gt_boxes, gt_classes, gt_valid, gt_std, 0, N, num_classes,
+                                 drop_empty, center_radius, img_active, labels, reg_targets, bvars, gt_inds, stream);
 }
 
 #define FOCAL_BLOCKS 1024

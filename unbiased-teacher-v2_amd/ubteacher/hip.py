@@ -361,9 +361,11 @@ def _farr(vals):
 
 
 def fcos_targets(level_hw, strides, soi, gt_boxes, gt_classes, gt_valid, gt_std, num_classes, drop_empty, active=None,
-                 center_radius=0.0):
-    """gt_* padded [N,MAXG,...]; returns labels[int32 P], reg_targets[P,4], bvars[P,4], gt_inds[P]."""
-    N, MAXG = gt_classes.shape
+                 center_radius=0.0, batch=None, img0=0):
+    """gt_* padded [n,MAXG,...]; returns labels[int32 P], reg_targets[P,4], bvars[P,4], gt_inds[P].
+    batch / img0: the gt arrays belong to images [img0, img0 + n) of a batch of `batch` images (default: n = the whole batch)."""
+    n_gt, MAXG = gt_classes.shape
+    N = n_gt if batch is None else int(batch)
     L = sum(h * w for h, w in level_hw)
     P = N * L
     dev = gt_boxes.device
@@ -378,8 +380,8 @@ def fcos_targets(level_hw, strides, soi, gt_boxes, gt_classes, gt_valid, gt_std,
     for lo, hi in soi:
         flat += [lo, hi]
     so = _farr(flat)
-    call("utv2_fcos_targets", len(level_hw), ctypes.cast(H, c_p), ctypes.cast(W, c_p), ctypes.cast(S, c_p),
-         ctypes.cast(so, c_p), N, MAXG, _p(gt_boxes), _p(gt_classes), _p(gt_valid), _p(gt_std), num_classes,
+    call("utv2_fcos_targets_range", len(level_hw), ctypes.cast(H, c_p), ctypes.cast(W, c_p), ctypes.cast(S, c_p),
+         ctypes.cast(so, c_p), N, MAXG, _p(gt_boxes), _p(gt_classes), _p(gt_valid), _p(gt_std), int(img0), n_gt, num_classes,
          int(drop_empty), float(center_radius), _p(active), _p(labels), _p(reg), _p(bv), _p(gi), _stream())
     return labels, reg, bv, gi
 

@@ -308,10 +308,10 @@ class FCOSOutputs:
         self.training = True
 
     # -- targets --------------------------------------------------------------------------------
-    def _targets(self, level_hw, gt, drop_empty, active=None):
+    def _targets(self, level_hw, gt, drop_empty, active=None, batch=None, img0=0):
         std = gt["reg_pred_std"] if "reg_pred_std" in gt else None
         return hip.fcos_targets(level_hw, self.strides, self.sizes_of_interest, gt["boxes"], gt["classes"],
-                                gt["valid"], std, self.num_classes, drop_empty, active, center_radius=self.center_radius)
+                                gt["valid"], std, self.num_classes, drop_empty, active, center_radius=self.center_radius, batch=batch, img0=img0)
 
     @staticmethod
     def _normalisers(sums):
@@ -384,7 +384,7 @@ class FCOSOutputs:
     # -- both branches of a fused student pass, scalar tail in one launch -------------------------------
     LOSS_KEYS = ("loss_fcos_cls", "loss_fcos_loc", "loss_fcos_ctr", "loss_fcos_cls_pseudo", "loss_fcos_ctr_pseudo", "loss_fcos_loc_pseudo")
 
-    def joint_losses(self, head_out, level_hw, gt_labeled, gt_unlabeled, act, loss_weights):
+    def joint_losses(self, head_out, level_hw, gt_labeled, gt_unlabeled, n_labeled, N, loss_weights):
         """losses(labeled) + pseudo_losses(unlabeled) + the trainer's loss weighting: the same target / focal / positive-location kernels,
         but everything between their raw sums and the weighted total - normalisers, KL means, weights (about 60 scalar launches forward
         and 70 backward, the GPU idle in between) - is ONE utv2_fcos_loss_combine launch whose backward hands the kernels their
@@ -392,16 +392,16 @@ class FCOSOutputs:
         pseudo dict (keys without the suffix), weighted total); the dict entries are detached (metrics)."""
         logits_all, box_all = head_out["logits"], head_out["box"]
         nc, rm = self.num_classes, self.reg_max
-        labels, reg_t, _, _ = self._targets(level_hw, gt_labeled, drop_empty=1, active=act)
+        # images [0, n_labeled) of the batch carry ground truth, [n_labeled, N) the pseudo labels: the target kernel takes the range
+        labels, reg_t, _, _ = self._targets(level_hw, gt_labeled, drop_empty=1, batch=N, img0=0)
         focal_s = ops.focal_loss_sum(logits_all, labels, self.focal_loss_alpha, self.focal_loss_gamma)
         flags_s = self.loc_flags | (hip.LT_QUALITY_IOU if self.quality_iou else 0)
         sums_s = ops.fcos_loc_terms(box_all, labels, reg_t, None, (nc, rm, 0.0, 0.0, flags_s))
-        inact = 1 - act
-        labels, reg_t, _, _ = self._targets(level_hw, gt_unlabeled["cls"], drop_empty=0, active=inact)
+        labels, reg_t, _, _ = self._targets(level_hw, gt_unlabeled["cls"], drop_empty=0, batch=N, img0=n_labeled)
         focal_c = ops.focal_loss_sum(logits_all, labels, self.focal_loss_alpha, self.focal_loss_gamma)
         sums_c = ops.fcos_loc_terms(box_all, labels, reg_t, None, (nc, rm, 0.0, 0.0, self.loc_flags))
         tsbetter = self.reg_unsup_loss == "ts_locvar_better_nms_nll_l1"
-        labels, reg_t, bvars, _ = self._targets(level_hw, gt_unlabeled["reg"], drop_empty=0, active=inact)
+        labels, reg_t, bvars, _ = self._targets(level_hw, gt_unlabeled["reg"], drop_empty=0, batch=N, img0=n_labeled)
         sums_r = ops.fcos_loc_terms(box_all, labels, reg_t, bvars if tsbetter else None,
                                     (nc, rm, self.tsbetter_reg, self.tsbetter_reg_cert, self.loc_flags))
         ws = comm.get_world_size()
@@ -598,15 +598,16 @@ class FCOS:
         """loss_weights (key -> (mul, div), the trainer's weighting of the loss dict): when given and both pseudo label sets are there,
         the scalar tail runs fused (FCOSOutputs.joint_losses) and the weighted total rides along as l_sup["weighted_total"]."""
         head_out, level_hw, n_labeled, N = ctx["head_out"], ctx["level_hw"], ctx["n_labeled"], ctx["N"]
+        fo = self.fcos_outputs
+        if (loss_weights is not None and set(gt_unlabeled) == {"cls", "reg"} and fo.kl_loss and all(k in loss_weights for k in fo.LOSS_KEYS)
+                and ctx["gt_labeled"].n == n_labeled and all(v.n == N - n_labeled for v in gt_unlabeled.values())):
+            l_sup, l_uns, total = fo.joint_losses(head_out, level_hw, ctx["gt_labeled"], gt_unlabeled, n_labeled, N, loss_weights)
+            l_sup["weighted_total"] = total
+            return l_sup, l_uns
         act = torch.zeros(N, dtype=torch.uint8, device=ctx["device"])
         act[:n_labeled] = 1
         gtl = ctx["gt_labeled"].pad_images(0, N - n_labeled)
         gtu = {k: v.pad_images(n_labeled, 0) for k, v in gt_unlabeled.items()}
-        fo = self.fcos_outputs
-        if loss_weights is not None and set(gtu) == {"cls", "reg"} and fo.kl_loss and all(k in loss_weights for k in fo.LOSS_KEYS):
-            l_sup, l_uns, total = fo.joint_losses(head_out, level_hw, gtl, gtu, act, loss_weights)
-            l_sup["weighted_total"] = total
-            return l_sup, l_uns
         _, l_sup = fo.losses(head_out, level_hw, gtl, active=act)
         _, l_uns = fo.pseudo_losses(head_out, level_hw, gtu, active=(1 - act))
         return l_sup, l_uns
