@@ -296,24 +296,27 @@ class _TrainerBase:
 
     # -- metrics (trainer.py:431-466 / :914-948), device resident until flushed -------------------------
     def _write_metrics(self, metrics_dict):
-        keys, vals = [], []
+        # host scalars (EMA rate, data time) stay on the host: a `torch.tensor(x, device=cuda)` here is a pageable host-to-device copy,
+        # which PyTorch follows with a stream synchronize - the whole forward drained right before backward starts
+        keys, vals, host_items = [], [], []
         for k, v in metrics_dict.items():
-            keys.append(k)
             if isinstance(v, torch.Tensor):
+                keys.append(k)
                 vals.append(v.detach().reshape(()).float())
             else:
-                vals.append(torch.tensor(float(v), device=self.model.device))
-        self._pending_metrics = (keys, torch.stack(vals))
+                host_items.append((k, float(v)))
+        self._pending_metrics = (keys, torch.stack(vals) if vals else None, host_items)
         if (self.iter + 1) % self.log_period == 0:
             self.flush_metrics()
 
     def flush_metrics(self):
         if self._pending_metrics is None:
             return self._last_metrics
-        keys, vals = self._pending_metrics
+        keys, vals, host_items = self._pending_metrics
         self._pending_metrics = None
-        host = vals.cpu().tolist()  # the one host sync
+        host = vals.cpu().tolist() if vals is not None else []  # the one host sync
         md = dict(zip(keys, host))
+        md.update(host_items)
         all_md = comm.gather(md)
         if comm.is_main_process():
             if "data_time" in all_md[0]:

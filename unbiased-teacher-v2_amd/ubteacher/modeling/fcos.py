@@ -107,11 +107,33 @@ class PaddedBoxes:
         g = max([len(x) for x in instances] + [1])
         M = max(min_slots, (g + 15) // 16 * 16)
         assert M <= 256, "more than 256 ground-truth boxes per image is not supported by utv2_fcos_targets"
+        has_std = any(x.has("reg_pred_std") for x in instances if len(x))
+        dev = torch.device(device)
+        on_dev = dev.type == "cuda" and all(x.gt_boxes.tensor.device.type == "cuda" and x.gt_classes.device.type == "cuda" for x in instances if len(x))
+        if on_dev:
+            # ground truth that already lives on the device (GPU data pipeline, synthetic loaders) is padded there: the host round trip
+            # below is a device-to-host sync per image plus pageable host-to-device copies, each of which drains the stream
+            boxes = torch.zeros((n, M, 4), dtype=torch.float32, device=dev)
+            classes = torch.zeros((n, M), dtype=torch.int32, device=dev)
+            valid = torch.zeros((n, M), dtype=torch.uint8, device=dev)
+            std = torch.zeros((n, M, 4), dtype=torch.float32, device=dev) if has_std else None
+            for i, x in enumerate(instances):
+                k = len(x)
+                if k == 0:
+                    continue
+                boxes[i, :k] = x.gt_boxes.tensor.detach().float()
+                classes[i, :k] = x.gt_classes.detach().to(torch.int32)
+                valid[i, :k] = 1
+                if has_std and x.has("reg_pred_std"):
+                    std[i, :k] = x.reg_pred_std.detach().float().to(dev)
+            f = dict(boxes=boxes, classes=classes, valid=valid)
+            if std is not None:
+                f["reg_pred_std"] = std
+            return PaddedBoxes([x.image_size for x in instances], **f)
         boxes = torch.zeros((n, M, 4), dtype=torch.float32)
         classes = torch.zeros((n, M), dtype=torch.int32)
         valid = torch.zeros((n, M), dtype=torch.uint8)
         std = None
-        has_std = any(x.has("reg_pred_std") for x in instances if len(x))
         if has_std:
             std = torch.zeros((n, M, 4), dtype=torch.float32)
         for i, x in enumerate(instances):
