@@ -130,12 +130,22 @@ class PaddedBoxes:
             if std is not None:
                 f["reg_pred_std"] = std
             return PaddedBoxes([x.image_size for x in instances], **f)
-        boxes = torch.zeros((n, M, 4), dtype=torch.float32)
-        classes = torch.zeros((n, M), dtype=torch.int32)
-        valid = torch.zeros((n, M), dtype=torch.uint8)
-        std = None
-        if has_std:
-            std = torch.zeros((n, M, 4), dtype=torch.float32)
+        if dev.type == "cuda":
+            # host ground truth: all arrays packed into ONE pinned staging buffer and copied with non_blocking=True - a `.to(device)` of
+            # pageable memory is followed by a stream synchronize (three of them drained the stream at the start of every step)
+            nb, nc = n * M * 16, n * M * 4
+            total = nb * (2 if has_std else 1) + nc + n * M
+            stage = PaddedBoxes._stage(dev, total)
+            boxes = stage[:nb].view(torch.float32).view(n, M, 4).zero_()
+            std = stage[nb:2 * nb].view(torch.float32).view(n, M, 4).zero_() if has_std else None
+            o = nb * (2 if has_std else 1)
+            classes = stage[o:o + nc].view(torch.int32).view(n, M).zero_()
+            valid = stage[o + nc:o + nc + n * M].view(n, M).zero_()
+        else:
+            boxes = torch.zeros((n, M, 4), dtype=torch.float32)
+            classes = torch.zeros((n, M), dtype=torch.int32)
+            valid = torch.zeros((n, M), dtype=torch.uint8)
+            std = torch.zeros((n, M, 4), dtype=torch.float32) if has_std else None
         for i, x in enumerate(instances):
             k = len(x)
             if k == 0:
@@ -145,10 +155,40 @@ class PaddedBoxes:
             valid[i, :k] = 1
             if has_std and x.has("reg_pred_std"):
                 std[i, :k] = x.reg_pred_std.detach().float().cpu()
+        if dev.type == "cuda":
+            d = stage[:total].to(dev, non_blocking=True)
+            PaddedBoxes._stage_done(dev)
+            f = dict(boxes=d[:nb].view(torch.float32).view(n, M, 4), classes=d[o:o + nc].view(torch.int32).view(n, M),
+                     valid=d[o + nc:o + nc + n * M].view(n, M))
+            if has_std:
+                f["reg_pred_std"] = d[nb:2 * nb].view(torch.float32).view(n, M, 4)
+            return PaddedBoxes([x.image_size for x in instances], **f)
         f = dict(boxes=boxes.to(device), classes=classes.to(device), valid=valid.to(device))
         if std is not None:
             f["reg_pred_std"] = std.to(device)
         return PaddedBoxes([x.image_size for x in instances], **f)
+
+    _STAGE = {}
+
+    @staticmethod
+    def _stage(dev, nbytes):
+        """two pinned uint8 staging buffers per device, used alternately; a buffer is reused only after the copy issued from it has finished"""
+        st = PaddedBoxes._STAGE.setdefault(str(dev), {"bufs": [None, None], "events": [None, None], "next": 0})
+        i = st["next"]
+        if st["events"][i] is not None:
+            st["events"][i].synchronize()
+        if st["bufs"][i] is None or st["bufs"][i].numel() < nbytes:
+            st["bufs"][i] = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8).pin_memory()
+        return st["bufs"][i]
+
+    @staticmethod
+    def _stage_done(dev):
+        st = PaddedBoxes._STAGE[str(dev)]
+        i = st["next"]
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        st["events"][i] = ev
+        st["next"] = i ^ 1
 
 
 def compute_locations(h, w, stride, device):

@@ -463,7 +463,13 @@ class FastRCNNFocaltLossBoundaryVarOutputLayers:
         K = self.K
         pb = proposals["boxes"]
         boxes = self.box2box_transform.apply_deltas(deltas.view(N, P, 4), pb)
-        hwt = torch.tensor([[s[1], s[0], s[1], s[0]] for s in proposals.image_sizes], dtype=torch.float32, device=pb.device)[:, None, :]
+        cache = self.__dict__.setdefault("_hwt_cache", {})   # a fresh torch.tensor(..., device=cuda) is a synchronizing pageable copy
+        ck = (tuple(proposals.image_sizes), str(pb.device))
+        hwt = cache.get(ck)
+        if hwt is None:
+            if len(cache) >= 16:
+                cache.clear()
+            hwt = cache[ck] = torch.tensor([[s[1], s[0], s[1], s[0]] for s in proposals.image_sizes], dtype=torch.float32, device=pb.device)[:, None, :]
         probs = F.softmax(scores, dim=-1).view(N, P, K + 1)[:, :, :K]
         ok = proposals["valid"].bool() & torch.isfinite(boxes).all(dim=2) & torch.isfinite(probs).all(dim=2)
         boxes = torch.minimum(boxes.clamp(min=0), hwt)
