@@ -1,10 +1,10 @@
 """The largest all-queues-idle gaps of a rocprofv3 kernel trace (last K of TOTAL identical bench steps): what ran before and after each.
-usage: rocpd_gaps.py DB TOTAL_STEPS K [TOP=40]"""
+usage: rocpd_gaps.py DB TOTAL_STEPS K [TOP=40] [QUEUE]      QUEUE: only the dispatches of that queue id (its own idle time)"""
 import sqlite3
 import sys
 
 
-def main(path, total_steps, k, top=40):
+def main(path, total_steps, k, top=40, queue=None):
     db = sqlite3.connect(path)
     cur = db.cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
@@ -17,6 +17,10 @@ def main(path, total_steps, k, top=40):
     cps = len(marks) // total_steps
     w0, w1 = marks[-k * cps - 1], marks[-1]
     rows = [r for r in rows if r[0] >= w0 and r[1] <= w1]
+    if queue is not None:
+        qs = sorted(set(r[3] for r in rows))
+        print("queues:", qs)
+        rows = [r for r in rows if str(r[3]) == str(queue)]
     gaps = []
     cur_end, last = rows[0][1], rows[0]
     for r in rows[1:]:
@@ -35,4 +39,4 @@ def main(path, total_steps, k, top=40):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 40)
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 40, sys.argv[5] if len(sys.argv) > 5 else None)

@@ -468,8 +468,11 @@ class FCOSOutputs:
                                     (nc, rm, self.tsbetter_reg, self.tsbetter_reg_cert, self.loc_flags))
         ws = comm.get_world_size()
         norm = None
-        if ws > 1:   # ONE fused all-reduce of the three branches' (n_pos, sum ctrness) pairs
-            norm = comm.reduce_sum(torch.cat((sums_s[0:2], sums_c[0:2], sums_r[0:2])).detach())
+        if ws > 1:
+            # the (n_pos, sum ctrness) pairs of the three target sets, all-reduced one by one in the order losses() / pseudo_losses()
+            # do it: a rank whose two student passes could not be fused (different padded canvases) runs those, and every rank must
+            # issue the same sequence of collectives
+            norm = torch.cat([comm.reduce_sum(x[0:2].detach().clone()) for x in (sums_s, sums_c, sums_r)])
         flags = (1 if self.kl_loss else 0) | (2 if self.kl_loss_type == "klloss" else 0) | (4 if self.unify_ctrcls else 0) | (8 if tsbetter else 0)
         wmul = [loss_weights[k][0] for k in self.LOSS_KEYS]
         wdiv = [loss_weights[k][1] for k in self.LOSS_KEYS]
