@@ -266,6 +266,18 @@ int utv2_rpn_loss_bwd(const float* gobj, const float* gdl, const float* gout_cls
                       const int* hw_host, int N, int A, int ch, int R, const int64_t* pos_idx, const unsigned char* pos_valid, int npos,
                       const int64_t* neg_idx, const unsigned char* neg_valid, int nneg, float* grad_obj, float* grad_deltas,
                       utv2_stream_t stream);
+/* _range (head = 1 only): the head output holds `batch` images per level and the N images of this call - the sampler arrays, gt and
+ * has_gt are theirs alone - are images [img0, img0 + N) of it: one loss branch of a student pass that ran the labeled and the
+ * pseudo-labeled images (reference trainer.py:838-866) as one batch.  The plain entries are batch = N, img0 = 0. */
+int utv2_rpn_loss_fwd_range(const float* obj, const float* deltas, int head, int num_levels, const int* hw_host, int N, int batch, int img0,
+                            int A, int ch, int R, const float* anchors, const int64_t* pos_idx, const unsigned char* pos_valid, int npos,
+                            const int64_t* neg_idx, const unsigned char* neg_valid, int nneg, const int* matched,
+                            const unsigned char* has_gt, const float* gt_boxes, const float* gt_scores, int G, const float* weights_host,
+                            float* sums, float* gobj, float* gdl, utv2_stream_t stream);
+int utv2_rpn_loss_bwd_range(const float* gobj, const float* gdl, const float* gout_cls, const float* gout_loc, int head, int num_levels,
+                            const int* hw_host, int N, int batch, int img0, int A, int ch, int R, const int64_t* pos_idx,
+                            const unsigned char* pos_valid, int npos, const int64_t* neg_idx, const unsigned char* neg_valid, int nneg,
+                            float* grad_obj, float* grad_deltas, utv2_stream_t stream);
 /* box_reg_loss / box_reg_pseudo_loss of the boundary-variance predictor (roi_heads/fast_rcnn.py:938-1090) on R sampled ROIs, summed:
  * deltas / stdl = the predicted boundary deltas and std logits (row pitch ld floats), cls [R] int64 (-1 = empty slot, foreground =
  * [0, num_classes)), prop / gtb [R][4] proposal and matched gt boxes, gstd [R][4] the pseudo boxes' std logits or NULL.

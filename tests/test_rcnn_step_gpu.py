@@ -147,6 +147,59 @@ def test_rcnn_step_amp_close_to_fp32():
         assert np.isfinite(a) and abs(a - b) <= 5e-2 * max(abs(b), 1e-6), (k, a, b)
 
 
+def test_rcnn_fused_student_pass_equals_two_passes():
+    """The fused student pass (labeled + pseudo-labeled images as ONE backbone / RPN head / RoIAlign / box head batch, losses per branch on
+    their own image range) against the two passes of the reference trainer (trainer.py:838-866) on the same weights, batch and sampling
+    keys: every loss to 1e-5 (per-image layers: only the summation order of sums over the batch differs), the same pseudo labels, the
+    student after SGD to the accumulation-order bound of the weight gradients."""
+    from ubteacher.engine import UBRCNNTeacherTrainer
+    outs = {}
+    for fuse in (True, False):
+        cfg = rcnn_cfg()
+        torch.manual_seed(0)
+        prod, orac = make_batch(31, 2, 2, H, W, "cuda")
+        tr = UBRCNNTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+        tr.fuse_student_passes = fuse
+        mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1)
+        pstd = torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1)
+        sd_s = tune(cpu_state(tr.model), [d["image"] for d in orac[3]], mean, pstd)
+        sd_t = dict(sd_s)
+        sd_t["roi_heads.box_predictor.bbox_pred_std.bias"] = torch.full((4,), -3.0)
+        tr.model.load_state_dict(sd_s)
+        tr.model_teacher.load_state_dict(sd_t)
+        tr.iter = 1
+        tr.optimizer.param_groups[0]["lr"] = 0.01
+        calls = []
+
+        def src(n, m, device, calls=calls):   # keys depend on the shape only: both schedules draw the same ones whatever their call order
+            calls.append((n, m))
+            return torch.rand(n, m, generator=torch.Generator().manual_seed(1000 * n + m)).to(device)
+
+        tr.model.proposal_generator.sample_keys = src
+        tr.model.roi_heads.sample_keys = src
+        seen = []
+        if fuse:
+            orig = tr.model.forward_joint_begin
+            tr.model.forward_joint_begin = lambda *a, **k: (seen.append(1), orig(*a, **k))[1]
+        tr.run_step_full_semisup()
+        torch.cuda.synchronize()
+        assert bool(seen) == fuse and len(calls) == 4
+        outs[fuse] = (tr.flush_metrics(), cpu_state(tr.model), sd_s, tr._last_pseudo)
+    ra, rb = outs[True][0], outs[False][0]
+    assert set(ra) == set(rb)
+    for k in rb:
+        if k.startswith("loss") or k == "total_loss":
+            assert abs(ra[k] - rb[k]) <= 1e-5 * max(abs(rb[k]), 1e-6), (k, ra[k], rb[k])
+    assert rb["loss_box_reg_pseudo"] > 0 and rb["loss_rpn_cls_pseudo"] > 0 and rb["loss_rpn_loc"] > 0
+    for f in ("boxes", "classes", "valid", "scores"):
+        assert torch.equal(outs[True][3][f], outs[False][3][f]), f
+    sa, sb, s0 = outs[True][1], outs[False][1], outs[True][2]
+    for k in sb:
+        upd = float((sb[k].double() - s0[k].double()).abs().max())
+        err = float((sa[k].double() - sb[k].double()).abs().max())
+        assert err <= 1e-6 * float(sb[k].abs().max()) + 1e-3 * upd + 1e-12, (k, err, upd)
+
+
 def test_rcnn_evaluation_loop_runs_and_rescales():
     """UBRCNNTeacherTrainer.test(): the eval-mode model runs `inference` (RPN test top-k -> box head -> fast_rcnn_inference) over a
     fixed-length loader, detections are rescaled to the ORIGINAL image size and the COCO box-AP dict comes back; the inference
@@ -281,6 +334,13 @@ def test_rcnn_step_bf16_vs_rounding_oracle():
                 calls.append(out[0])
             return out
         type(pg).__call__ = patched
+        orig_joint = pg.forward_joint_begin
+
+        def joint(image_sizes, features, n_labeled, gt_labeled):   # the fused student pass: one RPN call for both image sets
+            out = orig_joint(image_sizes, features, n_labeled, gt_labeled)
+            calls.extend((out[1].images(0, n_labeled), out[1].images(n_labeled, out[1].n)))
+            return out
+        pg.forward_joint_begin = joint
         try:
             tr.run_step_full_semisup()
         finally:

@@ -971,14 +971,19 @@ int utv2_rpn_decode(const int64_t* top, int maxk, const float* head, const float
 }
 
 static int fill_rpn_loss_args(RpnLossArgs& a, const float* obj, const float* deltas, int head, int num_levels, const int* hw_host, int N,
-                              int A, int ch, int R, const float* anchors, const int64_t* pos_idx, const unsigned char* pos_valid, int npos,
+                              int batch, int img0, int A, int ch, int R, const float* anchors, const int64_t* pos_idx, const unsigned char* pos_valid, int npos,
                               const int64_t* neg_idx, const unsigned char* neg_valid, int nneg, const int* matched,
                               const unsigned char* has_gt, const float* gt_boxes, const float* gt_scores, int G, const float* weights_host) {
   if (!obj || !deltas || !pos_idx || !pos_valid || !neg_idx || !neg_valid || N < 1 || R < 1 || npos < 0 || nneg < 0) return UTV2_EARG;
   a.L.n = 0;
   if (head) {
     if (A < 1 || ch < 5 * A) return UTV2_EARG;
-    if (int e = fill_rpn_levels(a.L, num_levels, N, hw_host, nullptr, A)) return e;
+    // the head output holds `batch` images per level; this call's N images are [img0, img0 + N) of them
+    if (batch < N || img0 < 0 || img0 + N > batch) return UTV2_EARG;
+    if (int e = fill_rpn_levels(a.L, num_levels, batch, hw_host, nullptr, A)) return e;
+    for (int l = 0; l < num_levels; ++l) a.L.row0[l] += img0 * hw_host[l];
+  } else if (batch != N || img0 != 0) {
+    return UTV2_EARG;
   }
   a.head = head; a.N = N; a.A = A; a.ch = ch; a.R = R; a.npos = npos; a.nneg = nneg; a.G = G;
   a.obj = obj; a.deltas = deltas; a.anchors = anchors;
@@ -989,16 +994,40 @@ static int fill_rpn_loss_args(RpnLossArgs& a, const float* obj, const float* del
   return UTV2_OK;
 }
 
+int utv2_rpn_loss_fwd_range(const float* obj, const float* deltas, int head, int num_levels, const int* hw_host, int N, int batch, int img0,
+                            int A, int ch, int R, const float* anchors, const int64_t* pos_idx, const unsigned char* pos_valid, int npos,
+                            const int64_t* neg_idx, const unsigned char* neg_valid, int nneg, const int* matched, const unsigned char* has_gt,
+                            const float* gt_boxes, const float* gt_scores, int G, const float* weights_host, float* sums, float* gobj,
+                            float* gdl, hipStream_t stream) {
+  RpnLossArgs a;
+  if (!anchors || !matched || !has_gt || !gt_boxes || !weights_host || !sums || !gobj || !gdl || G < 1) return UTV2_EARG;
+  if (int e = fill_rpn_loss_args(a, obj, deltas, head, num_levels, hw_host, N, batch, img0, A, ch, R, anchors, pos_idx, pos_valid, npos, neg_idx,
+                                 neg_valid, nneg, matched, has_gt, gt_boxes, gt_scores, G, weights_host))
+    return e;
+  hipLaunchKernelGGL(rpn_loss_fwd_kernel, dim3(1), dim3(256), 0, stream, a, sums, gobj, gdl);
+  return utv2_launch_status();
+}
+
 int utv2_rpn_loss_fwd(const float* obj, const float* deltas, int head, int num_levels, const int* hw_host, int N, int A, int ch, int R,
                       const float* anchors, const int64_t* pos_idx, const unsigned char* pos_valid, int npos, const int64_t* neg_idx,
                       const unsigned char* neg_valid, int nneg, const int* matched, const unsigned char* has_gt, const float* gt_boxes,
                       const float* gt_scores, int G, const float* weights_host, float* sums, float* gobj, float* gdl, hipStream_t stream) {
+  return utv2_rpn_loss_fwd_range(obj, deltas, head, num_levels, hw_host, N, N, 0, A, ch, R, anchors, pos_idx, pos_valid, npos, neg_idx, neg_valid,
+                                 nneg, matched, has_gt, gt_boxes, gt_scores, G, weights_host, sums, gobj, gdl, stream);
+}
+
+int utv2_rpn_loss_bwd_range(const float* gobj, const float* gdl, const float* gout_cls, const float* gout_loc, int head, int num_levels,
+                            const int* hw_host, int N, int batch, int img0, int A, int ch, int R, const int64_t* pos_idx,
+                            const unsigned char* pos_valid, int npos, const int64_t* neg_idx, const unsigned char* neg_valid, int nneg,
+                            float* grad_obj, float* grad_deltas, hipStream_t stream) {
   RpnLossArgs a;
-  if (!anchors || !matched || !has_gt || !gt_boxes || !weights_host || !sums || !gobj || !gdl || G < 1) return UTV2_EARG;
-  if (int e = fill_rpn_loss_args(a, obj, deltas, head, num_levels, hw_host, N, A, ch, R, anchors, pos_idx, pos_valid, npos, neg_idx,
-                                 neg_valid, nneg, matched, has_gt, gt_boxes, gt_scores, G, weights_host))
+  if (!gobj || !gdl || !gout_cls || !gout_loc) return UTV2_EARG;
+  if (int e = fill_rpn_loss_args(a, grad_obj, grad_deltas, head, num_levels, hw_host, N, batch, img0, A, ch, R, nullptr, pos_idx, pos_valid, npos, neg_idx,
+                                 neg_valid, nneg, nullptr, nullptr, nullptr, nullptr, 1, nullptr))
     return e;
-  hipLaunchKernelGGL(rpn_loss_fwd_kernel, dim3(1), dim3(256), 0, stream, a, sums, gobj, gdl);
+  const int total = N * (npos + nneg);
+  if (total == 0) return UTV2_OK;
+  hipLaunchKernelGGL(rpn_loss_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a, gobj, gdl, gout_cls, gout_loc, grad_obj, grad_deltas);
   return utv2_launch_status();
 }
 
@@ -1006,15 +1035,8 @@ int utv2_rpn_loss_bwd(const float* gobj, const float* gdl, const float* gout_cls
                       const int* hw_host, int N, int A, int ch, int R, const int64_t* pos_idx, const unsigned char* pos_valid, int npos,
                       const int64_t* neg_idx, const unsigned char* neg_valid, int nneg, float* grad_obj, float* grad_deltas,
                       hipStream_t stream) {
-  RpnLossArgs a;
-  if (!gobj || !gdl || !gout_cls || !gout_loc) return UTV2_EARG;
-  if (int e = fill_rpn_loss_args(a, grad_obj, grad_deltas, head, num_levels, hw_host, N, A, ch, R, nullptr, pos_idx, pos_valid, npos, neg_idx,
-                                 neg_valid, nneg, nullptr, nullptr, nullptr, nullptr, 1, nullptr))
-    return e;
-  const int total = N * (npos + nneg);
-  if (total == 0) return UTV2_OK;
-  hipLaunchKernelGGL(rpn_loss_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a, gobj, gdl, gout_cls, gout_loc, grad_obj, grad_deltas);
-  return utv2_launch_status();
+  return utv2_rpn_loss_bwd_range(gobj, gdl, gout_cls, gout_loc, head, num_levels, hw_host, N, N, 0, A, ch, R, pos_idx, pos_valid, npos, neg_idx,
+                                 neg_valid, nneg, grad_obj, grad_deltas, stream);
 }
 
 int utv2_roi_box_loss(const float* deltas, const float* stdl, int64_t ld, const int64_t* cls, const float* prop, const float* gtb,

@@ -14,6 +14,7 @@ def _make(base):
             self.optimizer = self.build_optimizer(cfg, self.model)
             self.model_teacher = self.build_model(cfg)  # stays in train mode
             self.scheduler = self.build_lr_scheduler(cfg, self.optimizer)
+            self.fuse_student_passes = os.environ.get("UTV2_FUSE_STUDENT_PASSES", "1") != "0"
             self._common_init(cfg, data_loader)
 
         # -- pseudo-labelling (trainer.py:727-780) ----------------------------------------------------
@@ -66,6 +67,10 @@ def _make(base):
                 # The supervised student pass does not depend on the pseudo labels: the teacher (forward, RPN top-k + NMS, ROI inference
                 # + NMS, thresholding - mostly latency-bound kernels) runs on a side stream next to it (engine/trainer.py does the same
                 # for FCOS); the pseudo-labeled pass follows once both are done.  UTV2_OVERLAP_TEACHER=0: one stream (identical results).
+                # When the labeled and the unlabeled images pad to the same canvas the two student passes (trainer.py:838-866) are ONE
+                # batch (model.forward_joint_*): the part that needs no pseudo labels runs next to the teacher, the rest after it.
+                all_label_data = label_data_q + label_data_k if S.USE_SUP_STRONG == "both" else label_data_k
+                fuse = self.fuse_student_passes and self.model.padded_canvas(all_label_data) == self.model.padded_canvas(unlabel_data_q)
                 overlap = os.environ.get("UTV2_OVERLAP_TEACHER", "1") != "0" and self.model.device.type == "cuda"
                 if overlap:
                     main = torch.cuda.current_stream(self.model.device)
@@ -90,14 +95,19 @@ def _make(base):
                         torch.cuda.set_stream(main)
                 self._last_pseudo = gt
 
-                all_label_data = label_data_q + label_data_k if S.USE_SUP_STRONG == "both" else label_data_k
-                rec_l, _, _, _ = self.model(all_label_data, branch="supervised")
-                record_dict.update(rec_l)
+                if fuse:
+                    ctx = self.model.forward_joint_begin(all_label_data, unlabel_data_q)
+                else:
+                    rec_l, _, _, _ = self.model(all_label_data, branch="supervised")
                 if overlap:
                     main.wait_stream(side)
                 unlabel_data_q = self.add_label(self.remove_label(unlabel_data_q), gt)
                 unlabel_data_k = self.add_label(self.remove_label(unlabel_data_k), gt)
-                rec_u, _, _, _ = self.model(unlabel_data_q, branch="unsup_data_train")
+                if fuse:
+                    rec_l, rec_u = self.model.forward_joint_finish(ctx, gt)
+                else:
+                    rec_u, _, _, _ = self.model(unlabel_data_q, branch="unsup_data_train")
+                record_dict.update(rec_l)
                 for k, v in rec_u.items():
                     record_dict[k + "_pseudo"] = v
 

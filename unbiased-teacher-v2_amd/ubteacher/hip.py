@@ -595,7 +595,7 @@ def _u8(t):
     return t.view(torch.uint8) if t.dtype == torch.bool else t
 
 
-def rpn_loss_fwd(obj, deltas, head_hw, N, A, R, anchors, s, gt_boxes, gt_scores, weights):
+def rpn_loss_fwd(obj, deltas, head_hw, N, A, R, anchors, s, gt_boxes, gt_scores, weights, batch=None, img0=0):
     """(sums [2], gobj [N, npos+nneg], gdl [N, npos, 4]); head_hw = None: dense obj [N,R] / deltas [N,R,4]; else obj is deltas is the
     level-first head output and head_hw the pixels per level.  s: the sampler's dict (pos_idx, pos_valid, neg_idx, neg_valid, matched32, has_gt)."""
     dev = obj.device
@@ -606,17 +606,19 @@ def rpn_loss_fwd(obj, deltas, head_hw, N, A, R, anchors, s, gt_boxes, gt_scores,
     head = head_hw is not None
     hw = _iarr(head_hw if head else [1])
     G = gt_boxes.shape[1]
-    call("utv2_rpn_loss_fwd", _p(obj), _p(deltas), int(head), len(head_hw) if head else 1, ctypes.cast(hw, c_p), N, A, obj.shape[-1] if head else 0, R,
+    call("utv2_rpn_loss_fwd_range", _p(obj), _p(deltas), int(head), len(head_hw) if head else 1, ctypes.cast(hw, c_p), N,
+         N if batch is None else batch, img0, A, obj.shape[-1] if head else 0, R,
          _p(anchors), _p(s["pos_idx"]), _p(_u8(s["pos_valid"])), npos, _p(s["neg_idx"]), _p(_u8(s["neg_valid"])), nneg, _p(s["matched32"]),
          _p(_u8(s["has_gt"])), _p(gt_boxes), _p(gt_scores), G, ctypes.cast(_farr(weights), c_p), _p(sums), _p(gobj), _p(gdl), _stream())
     return sums, gobj, gdl
 
 
-def rpn_loss_bwd(gobj, gdl, gout_cls, gout_loc, head_hw, N, A, ch, R, s, grad_obj, grad_deltas):
+def rpn_loss_bwd(gobj, gdl, gout_cls, gout_loc, head_hw, N, A, ch, R, s, grad_obj, grad_deltas, batch=None, img0=0):
     head = head_hw is not None
     hw = _iarr(head_hw if head else [1])
     npos, nneg = s["pos_idx"].shape[1], s["neg_idx"].shape[1]
-    call("utv2_rpn_loss_bwd", _p(gobj), _p(gdl), _p(gout_cls), _p(gout_loc), int(head), len(head_hw) if head else 1, ctypes.cast(hw, c_p), N, A, ch, R,
+    call("utv2_rpn_loss_bwd_range", _p(gobj), _p(gdl), _p(gout_cls), _p(gout_loc), int(head), len(head_hw) if head else 1, ctypes.cast(hw, c_p), N,
+         N if batch is None else batch, img0, A, ch, R,
          _p(s["pos_idx"]), _p(_u8(s["pos_valid"])), npos, _p(s["neg_idx"]), _p(_u8(s["neg_valid"])), nneg, _p(grad_obj), _p(grad_deltas), _stream())
 
 

@@ -58,6 +58,12 @@ class PaddedBoxes:
     def n(self):
         return self.f["valid"].shape[0]
 
+    def images(self, a, b):
+        """images [a, b) of the batch (views)"""
+        out = PaddedBoxes(list(self.image_sizes[a:b]), **{k: v[a:b] for k, v in self.f.items()})
+        out.as_gt = self.as_gt
+        return out
+
     def pad_images(self, before, after):
         """The same boxes inside a longer batch: `before` / `after` empty images are added around them (device-side cat, no
         sync) - the ground truth of one loss branch of a fused student pass."""

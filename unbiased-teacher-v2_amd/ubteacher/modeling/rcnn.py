@@ -109,24 +109,24 @@ class _RpnLossFn(torch.autograd.Function):
     backward = zero-fill + utv2_rpn_loss_bwd scatter."""
 
     @staticmethod
-    def forward(ctx, obj, deltas, rpn, anchors, s, gt, head_hw, N):
+    def forward(ctx, obj, deltas, rpn, anchors, s, gt, head_hw, N, batch=None, img0=0):
         R = anchors.shape[0]
         hw = [h * w for (h, w) in head_hw] if head_hw is not None else None
         sums, gobj, gdl = hip.rpn_loss_fwd(obj.detach(), deltas.detach(), hw, N, rpn.A, R, anchors, s, gt["boxes"],
-                                           gt["scores"] if "scores" in gt else None, rpn.box_weights)
-        ctx.meta = (hw, N, rpn.A, R, s, tuple(obj.shape), tuple(deltas.shape), head_hw is not None)
+                                           gt["scores"] if "scores" in gt else None, rpn.box_weights, batch=batch, img0=img0)
+        ctx.meta = (hw, N, rpn.A, R, s, tuple(obj.shape), tuple(deltas.shape), head_hw is not None, batch, img0)
         ctx.save_for_backward(gobj, gdl)
         return sums
 
     @staticmethod
     def backward(ctx, g):
         gobj, gdl = ctx.saved_tensors
-        hw, N, A, R, s, oshape, dshape, head = ctx.meta
+        hw, N, A, R, s, oshape, dshape, head, batch, img0 = ctx.meta
         g = g.contiguous()
         grad_obj = torch.zeros(oshape, dtype=torch.float32, device=g.device)
         grad_dl = grad_obj if head else torch.zeros(dshape, dtype=torch.float32, device=g.device)
-        hip.rpn_loss_bwd(gobj, gdl, g[0:1], g[1:2], hw, N, A, oshape[-1] if head else 0, R, s, grad_obj, grad_dl)
-        return grad_obj, (None if head else grad_dl), None, None, None, None, None, None
+        hip.rpn_loss_bwd(gobj, gdl, g[0:1], g[1:2], hw, N, A, oshape[-1] if head else 0, R, s, grad_obj, grad_dl, batch=batch, img0=img0)
+        return grad_obj, (None if head else grad_dl), None, None, None, None, None, None, None, None
 
 
 class _RoiBoxLossFn(torch.autograd.Function):
@@ -264,6 +264,29 @@ class PseudoLabRPN:
                 proposals = self.predict_proposals(anchors, obj, dl, image_sizes)
         return proposals, losses
 
+    def forward_joint_begin(self, image_sizes, features, n_labeled, gt_labeled):
+        """The labeled and the pseudo-labeled images of one iteration as ONE batch (images [0, n_labeled) carry ground truth): head,
+        proposals of every image, and the labeled images' losses - everything that does not need the pseudo labels."""
+        big, hw, N = self._head(features)
+        anchors = self.anchor_generator(hw, big.device)
+        acat = self._anchors_cat(anchors, hw, big.device)
+        losses = self.losses(acat, big, None, gt_labeled, head_hw=hw, batch=N, img0=0)
+        losses = {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}  # applied twice (SURVEY B2), as in forward()
+        sample_l = self._last_sample
+        with torch.no_grad():
+            sel = self._pre_nms_topk(big.detach(), N, hw)
+            if sel is not None:
+                proposals = self._proposals_fused(big.detach(), anchors, sel, hw, N, image_sizes)
+            else:
+                obj, dl = self._per_image_views(big.detach(), N, hw)
+                proposals = self.predict_proposals(anchors, obj, dl, image_sizes)
+        return dict(big=big, hw=hw, N=N, acat=acat, n_labeled=n_labeled, sample_l=sample_l), proposals, losses
+
+    def forward_joint_finish(self, ctx, gt_unlabeled):
+        """the pseudo-labeled images' losses of a forward_joint_begin batch"""
+        losses = self.losses(ctx["acat"], ctx["big"], None, gt_unlabeled, head_hw=ctx["hw"], batch=ctx["N"], img0=ctx["n_labeled"])
+        return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
+
     def _anchors_cat(self, anchors, hw, dev):
         cache = self.__dict__.setdefault("_anchor_cat_cache", {})
         ck = (tuple(hw), str(dev))
@@ -354,14 +377,15 @@ class PseudoLabRPN:
         nval = nval & (torch.arange(nidx.shape[1], device=anchors.device)[None, :] < (self.batch_size_per_image - npos))
         return dict(pos_idx=pidx, pos_valid=pval, neg_idx=nidx, neg_valid=nval, matched=arg.long(), matched32=arg, has_gt=has_gt)
 
-    def losses(self, anchors, obj, deltas, gt, head_hw=None):
+    def losses(self, anchors, obj, deltas, gt, head_hw=None, batch=None, img0=0):
         """rpn.py:153-225: BCE(sum) over sampled anchors (optionally weighted by the matched pseudo-box score,
         negatives too - SURVEY B4) + L1 on positives, both / (batch_size_per_image * N), weights applied here too.
         One fused forward launch and one backward launch (utv2_rpn_loss_fwd / _bwd).  obj [N,R] + deltas [N,R,4], or - head_hw given -
-        obj = the level-first head output [P, RPN_CH] (deltas ignored): no per-image copies of the logits / deltas are made."""
+        obj = the level-first head output [P, RPN_CH] (deltas ignored): no per-image copies of the logits / deltas are made.
+        batch / img0 (head form): the head output covers `batch` images and gt's are images [img0, img0 + gt.n) of it."""
         N = gt.n
         s = self.label_and_sample(anchors, gt)
-        sums = _RpnLossFn.apply(obj, obj if head_hw is not None else deltas, self, anchors, s, gt, head_hw, N)
+        sums = _RpnLossFn.apply(obj, obj if head_hw is not None else deltas, self, anchors, s, gt, head_hw, N, batch, img0)
         norm = self.batch_size_per_image * N
         out = {"loss_rpn_cls": sums[0] / norm, "loss_rpn_loc": sums[1] / norm}
         self._last_sample = s
@@ -608,6 +632,24 @@ class StandardROIHeadsPseudoLab:
 
     __call__ = forward
 
+    def forward_joint(self, features, proposals, n_labeled, gt_labeled, gt_unlabeled):
+        """forward(..., branch="supervised") on images [0, n_labeled) and forward(..., branch="unsup_data_train") on the rest as one
+        RoIAlign / box head / predictor pass over all sampled ROIs; sampling and the losses stay per branch (the predictor output's rows
+        are image-major, so each branch owns a contiguous row range).  Returns the two loss dicts."""
+        assert self.training
+        feats = [features[f] for f in self.in_features]
+        nl = n_labeled
+        s_l = self.label_and_sample_proposals(proposals.images(0, nl), gt_labeled, "supervised")
+        s_u = self.label_and_sample_proposals(proposals.images(nl, proposals.n), gt_unlabeled, "unsup_data_train")
+        self._last_sampled = s_u
+        boxes = torch.cat((s_l["proposal_boxes"], s_u["proposal_boxes"]), dim=0)
+        valid = torch.cat((s_l["valid"], s_u["valid"]), dim=0)
+        scores, deltas, std = self.box_predictor(self._box_features(feats, boxes, valid))
+        r = nl * boxes.shape[1]
+        l_l = self.box_predictor.losses((scores[:r], deltas[:r], std[:r]), s_l, "supervised")
+        l_u = self.box_predictor.losses((scores[r:], deltas[r:], std[r:]), s_u, "unsup_data_train")
+        return l_l, l_u
+
 
 @META_ARCH_REGISTRY.register()
 class TwoStagePseudoLabGeneralizedRCNN(ArenaModel):
@@ -643,6 +685,40 @@ class TwoStagePseudoLabGeneralizedRCNN(ArenaModel):
             if insts[0].has("pred_boxes_std"):
                 gt.f["pred_boxes_std"] = st.to(self.device)
         return gt
+
+    def padded_canvas(self, batched_inputs):
+        """(H, W) the batch is zero-padded to by preprocess_image (ImageList.from_tensors with size_divisibility)."""
+        d = self.backbone.size_divisibility
+        h = max(int(x["image"].shape[1]) for x in batched_inputs)
+        w = max(int(x["image"].shape[2]) for x in batched_inputs)
+        return ((h + d - 1) // d * d, (w + d - 1) // d * d) if d > 1 else (h, w)
+
+    def forward_joint_begin(self, labeled_inputs, unlabeled_inputs):
+        """model(labeled, branch="supervised") and model(unlabeled, branch="unsup_data_train") of one iteration (reference
+        trainer.py:838-866) as ONE pass over the concatenated batch - every layer is per-image (FrozenBN; RPN / ROI heads work per image),
+        so when both lists pad to the same canvas (the caller checks) the results are those of the two passes, with larger GEMMs, half
+        the launches and one weight gradient per layer.  This first half runs everything that does not need the pseudo labels (backbone,
+        RPN head, the proposals of all images, the labeled images' RPN losses) - the trainer runs it next to the teacher."""
+        assert self.training
+        both = list(labeled_inputs) + list(unlabeled_inputs)
+        images = [x["image"].to(self.device) for x in both]
+        x4, image_sizes = hip.preprocess_images(images, self._mean_host, self._std_host, self.backbone.size_divisibility,
+                                                 bf16_stem=ops.PRECISION[0] == "bf16")
+        gt_l = self._gt(labeled_inputs)
+        self.folder.fold()
+        features = self.backbone(x4)
+        rctx, proposals, rpn_l = self.proposal_generator.forward_joint_begin(image_sizes, features, len(labeled_inputs), gt_l)
+        return dict(features=features, rpn=rctx, proposals=proposals, rpn_l=rpn_l, gt_l=gt_l, n_labeled=len(labeled_inputs))
+
+    def forward_joint_finish(self, ctx, gt_unlabeled):
+        """second half: the pseudo-labeled images' RPN losses and the ROI heads of both branches, given the pseudo ground truth
+        (a PaddedBoxes of the unlabeled images).  Returns (supervised loss dict, pseudo loss dict)."""
+        rpn_u = self.proposal_generator.forward_joint_finish(ctx["rpn"], gt_unlabeled)
+        roi_l, roi_u = self.roi_heads.forward_joint(ctx["features"], ctx["proposals"], ctx["n_labeled"], ctx["gt_l"], gt_unlabeled)
+        l_l, l_u = {}, {}
+        l_l.update(roi_l); l_l.update(ctx["rpn_l"])
+        l_u.update(roi_u); l_u.update(rpn_u)
+        return l_l, l_u
 
     def forward(self, batched_inputs, branch="supervised", given_proposals=None, val_mode=False):
         if (not self.training) and (not val_mode):
