@@ -278,6 +278,26 @@ int utv2_rpn_loss_bwd_range(const float* gobj, const float* gdl, const float* go
                             const int* hw_host, int N, int batch, int img0, int A, int ch, int R, const int64_t* pos_idx,
                             const unsigned char* pos_valid, int npos, const int64_t* neg_idx, const unsigned char* neg_valid, int nneg,
                             float* grad_obj, float* grad_deltas, utv2_stream_t stream);
+/* Labelling + random subsampling of anchors / proposals (rpn.py:112-148 -> D2 label_and_sample_anchors + subsample_labels;
+ * roi_heads.py:141-270 -> D2 Matcher + _sample_proposals).  Random choice = the k smallest of one uniform key in [0, 1) per slot (keys
+ * from the caller); equal keys are taken in slot order.
+ * rpn_sample_keys: max_iou / lowq [N][R] (utv2_match_boxes / utv2_match_lowq), labels: IoU < lo negative, >= hi or lowq positive, image
+ * without gt all negative; out [2N][R]: row n = positives of image n, row N + n its negatives, -1 = not a candidate, else a sortable key
+ * (input of utv2_topk_rows_i64 with k = max(npos_max, nneg_max)).  rpn_sample_unpack: top [2N][k] selected keys -> pos_idx [N][npos_max]
+ * / neg_idx [N][nneg_max] (ascending key order) and their valid flags; negatives are valid up to nneg_max - #positives; has_gt [N].
+ * roi_sample: boxes [N][P][4] (proposals ++ gt, P <= 4096), valid [N][P], max_iou / argmax [N][P] against gt_* [N][G]; foreground = matched
+ * IoU >= iou_thr in an image with gt; per image <= nfg_max foreground then background up to `batch` slots: out_boxes [N][batch][4],
+ * out_classes (int64: gt class, num_classes = background, -1 = empty slot), out_gt_boxes, out_valid, out_idx (slot in [0, P)), and - when
+ * gt_scores / gt_std [N][G] / [N][G][4] and the outputs are given - the matched pseudo box's score and std logits. */
+int utv2_rpn_sample_keys(const float* max_iou, const unsigned char* lowq, const unsigned char* gt_valid, int G, const float* keys, int N,
+                         int R, float lo, float hi, int64_t* out, utv2_stream_t stream);
+int utv2_rpn_sample_unpack(const int64_t* top, int k, int N, int npos_max, int nneg_max, const unsigned char* gt_valid, int G,
+                           int64_t* pos_idx, unsigned char* pos_valid, int64_t* neg_idx, unsigned char* neg_valid, unsigned char* has_gt,
+                           utv2_stream_t stream);
+int utv2_roi_sample(const float* boxes, const unsigned char* valid, const float* max_iou, const int* argmax, const float* keys, int N, int P,
+                    const float* gt_boxes, const int* gt_classes, const unsigned char* gt_valid, const float* gt_scores, const float* gt_std,
+                    int G, float iou_thr, int num_classes, int batch, int nfg_max, float* out_boxes, int64_t* out_classes,
+                    float* out_gt_boxes, unsigned char* out_valid, int64_t* out_idx, float* out_conf, float* out_std, utv2_stream_t stream);
 /* box_reg_loss / box_reg_pseudo_loss of the boundary-variance predictor (roi_heads/fast_rcnn.py:938-1090) on R sampled ROIs, summed:
  * deltas / stdl = the predicted boundary deltas and std logits (row pitch ld floats), cls [R] int64 (-1 = empty slot, foreground =
  * [0, num_classes)), prop / gtb [R][4] proposal and matched gt boxes, gstd [R][4] the pseudo boxes' std logits or NULL.

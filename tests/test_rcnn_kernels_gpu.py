@@ -387,3 +387,70 @@ def test_roi_align_bwd_tiled_gather_equals_scatter_and_is_deterministic():
     y.backward(dy)
     for a, b in zip(fh, fr):
         close(a.grad.permute(0, 3, 1, 2), b.grad, rtol=1e-3, atol=2e-5)
+
+
+def test_fused_samplers_equal_the_elementwise_chains(monkeypatch):
+    """utv2_rpn_sample_keys + radix select + utv2_rpn_sample_unpack, and utv2_roi_sample, against the chains of elementwise / topk /
+    sort / gather launches they replace (UTV2_FUSED_SAMPLERS=0, the form the reference goldens above pin): identical sampled sets in
+    identical order on every valid slot - images with many, few and no ground-truth boxes, more candidates than slots and fewer."""
+    from ubteacher.modeling.fcos import PaddedBoxes
+    from ubteacher.modeling.rcnn import PseudoLabRPN, StandardROIHeadsPseudoLab
+    from ubteacher.params import ParamStore
+    cfg = rcnn_cfg()
+    g = torch.Generator().manual_seed(5)
+    N, M = 4, 16
+    sizes = [(160, 224)] * N
+    gb = torch.zeros(N, M, 4); gv = torch.zeros(N, M, dtype=torch.uint8)
+    for n, k in enumerate((9, 2, 0, 16)):
+        xy = torch.rand(k, 2, generator=g) * torch.tensor([150.0, 100.0])
+        wh = torch.rand(k, 2, generator=g) * 60 + 8
+        gb[n, :k] = torch.cat((xy, xy + wh), 1); gv[n, :k] = 1
+    gt = PaddedBoxes(sizes, boxes=gb.to(DEV), classes=torch.randint(0, 80, (N, M), generator=g).to(torch.int32).to(DEV), valid=gv.to(DEV),
+                     scores=torch.rand(N, M, generator=g).to(DEV), pred_boxes_std=torch.randn(N, M, 4, generator=g).to(DEV))
+    rpn = PseudoLabRPN(cfg, ParamStore(), 256)
+    hw = [(40, 56), (20, 28), (10, 14), (5, 7), (3, 4)]
+    anchors = torch.cat(rpn.anchor_generator(hw, torch.device(DEV)))
+    R = anchors.shape[0]
+    rkeys = torch.rand(N, R, generator=g).to(DEV)
+    rpn.sample_keys = rkeys
+    heads = StandardROIHeadsPseudoLab(cfg, ParamStore(), 256)
+    P = 300
+    xy = torch.rand(N, P, 2, generator=g) * torch.tensor([150.0, 100.0])
+    wh = torch.rand(N, P, 2, generator=g) * 60 + 8
+    pbx = torch.cat((xy, xy + wh), 2)
+    pbx[:, :40] = gb[:, torch.arange(40) % M] + torch.randn(N, 40, 4, generator=g) * 2     # proposals near the gt boxes: foreground
+    pvalid = (torch.rand(N, P, generator=g) > 0.1).to(torch.uint8)
+    props = PaddedBoxes(sizes, boxes=pbx.to(DEV).contiguous(), valid=pvalid.to(DEV))
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("UTV2_FUSED_SAMPLERS", fused)
+        for bs in (256, 32):
+            rpn.batch_size_per_image = bs
+            outs[("rpn", bs, fused)] = rpn.label_and_sample(anchors, gt)
+        for bs in (512, 64):
+            heads.batch_size_per_image = bs
+            heads.sample_keys = torch.rand(N, P + M, generator=torch.Generator().manual_seed(bs)).to(DEV)
+            outs[("roi", bs, fused)] = heads.label_and_sample_proposals(props, gt, "unsup_data_train")
+    for bs in (256, 32):
+        a, b = outs[("rpn", bs, "1")], outs[("rpn", bs, "0")]
+        assert torch.equal(a["has_gt"].bool(), b["has_gt"]) and torch.equal(a["matched32"], b["matched32"])
+        for part in ("pos", "neg"):
+            va, vb = a[part + "_valid"].bool(), b[part + "_valid"].bool()
+            assert torch.equal(va, vb), (bs, part)
+            assert torch.equal(a[part + "_idx"][va], b[part + "_idx"][vb]), (bs, part)
+        assert int(a["pos_valid"].sum()) > 0 and int(a["neg_valid"].sum()) > 0
+        assert int(a["pos_valid"][2].sum()) == 0 and int(a["neg_valid"][2].sum()) == bs      # image without gt: negatives only
+    for bs in (512, 64):
+        a, b = outs[("roi", bs, "1")], outs[("roi", bs, "0")]
+        w = b["valid"].shape[1]      # the chain's width is min(batch, nfg_max + #slots) (here 128 + 316 < 512); the kernel always pads to batch
+        assert not bool(a["valid"][:, w:].any())
+        va = a["valid"].bool()[:, :w]
+        assert torch.equal(va, b["valid"].bool()) and int(va.sum()) > 0
+        assert set(a) == set(b)
+        for k in b:
+            if k != "valid":
+                assert torch.equal(a[k][:, :w][va], b[k][va]), (bs, k)
+        va = a["valid"].bool()
+        assert bool((a["gt_classes"][~va] == -1).all())
+        fg = (a["gt_classes"] >= 0) & (a["gt_classes"] < 80)
+        assert int(fg.sum()) > 0 and int(fg[2].sum()) == 0

@@ -689,6 +689,143 @@ __global__ __launch_bounds__(256) void rpn_loss_bwd_kernel(RpnLossArgs p, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Anchor / proposal labelling and random subsampling (proposal_generator/rpn.py:112-148 -> D2 label_and_sample_anchors +
+// subsample_labels; roi_heads/roi_heads.py:141-270 -> D2 add_ground_truth_to_proposals, Matcher, _sample_proposals) without the
+// chain of elementwise / topk / gather launches.  Random choice = "the k smallest of one uniform key per slot" (the keys come from
+// the caller: device RNG in training, injected in the parity tests); equal keys are taken in slot order.
+//
+// RPN, R ~ 2e5 anchors per image: rpn_sample_keys_kernel labels every anchor (IoU < lo: negative, >= hi or low-quality match: positive,
+// image without gt: all negative) and writes one sortable 63-bit key per anchor into a row of positives and a row of negatives
+// (-1 = not a candidate; descending key order == ascending random key, then ascending anchor index) - the input of the exact radix
+// select utv2_topk_rows_i64; rpn_sample_unpack_kernel turns the selected keys into the sampler's index / valid arrays.
+__global__ __launch_bounds__(256) void rpn_sample_keys_kernel(const float* __restrict__ mx, const unsigned char* __restrict__ lowq,
+                                                            const unsigned char* __restrict__ gt_valid, int G,
+                                                            const float* __restrict__ keys, int N, int R, float lo, float hi,
+                                                            long long* __restrict__ out) {
+  const int n = blockIdx.y;
+  int any = 0;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) any |= gt_valid[(size_t)n * G + g];
+  const int has_gt = __syncthreads_or(any);
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const size_t o = (size_t)n * R + r;
+  const float v = mx[o];
+  int label = v < lo ? 0 : -1;
+  if (v >= hi) label = 1;
+  if (lowq[o]) label = 1;
+  if (!has_gt) label = 0;
+  const long long k = ((long long)(0x7fffffff - (__float_as_int(keys[o]) & 0x7fffffff)) << 32) | (long long)(0xffffffffu - (unsigned)r);
+  out[o] = label == 1 ? k : -1;
+  out[(size_t)N * R + o] = label == 0 ? k : -1;
+}
+
+__global__ __launch_bounds__(256) void rpn_sample_unpack_kernel(const long long* __restrict__ top, int k, int N, int npos_max, int nneg_max,
+                                                              const unsigned char* __restrict__ gt_valid, int G,
+                                                              long long* __restrict__ pos_idx, unsigned char* __restrict__ pos_valid,
+                                                              long long* __restrict__ neg_idx, unsigned char* __restrict__ neg_valid,
+                                                              unsigned char* __restrict__ has_gt) {
+  const int n = blockIdx.x;
+  int any = 0, cnt = 0;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) any |= gt_valid[(size_t)n * G + g];
+  for (int j = threadIdx.x; j < npos_max; j += blockDim.x) {
+    const long long key = j < k ? top[(size_t)n * k + j] : -1;
+    const bool ok = key >= 0;
+    pos_idx[(size_t)n * npos_max + j] = ok ? (long long)(0xffffffffu - (unsigned)(key & 0xffffffffll)) : 0;
+    pos_valid[(size_t)n * npos_max + j] = ok;
+    cnt += ok;
+  }
+  any = __syncthreads_or(any);
+  __shared__ int npos;
+  if (threadIdx.x == 0) npos = 0;
+  __syncthreads();
+  if (cnt) atomicAdd(&npos, cnt);
+  __syncthreads();
+  if (threadIdx.x == 0) has_gt[n] = any != 0;
+  const int room = nneg_max - npos;   // negatives fill what the positives leave of the per-image batch
+  for (int j = threadIdx.x; j < nneg_max; j += blockDim.x) {
+    const long long key = j < k ? top[(size_t)(N + n) * k + j] : -1;
+    const bool ok = key >= 0 && j < room;
+    neg_idx[(size_t)n * nneg_max + j] = key >= 0 ? (long long)(0xffffffffu - (unsigned)(key & 0xffffffffll)) : 0;
+    neg_valid[(size_t)n * nneg_max + j] = ok;
+  }
+}
+
+// ROI heads, P <= 4096 proposals (+ appended gt boxes) per image: one workgroup per image sorts (group, key, slot) in LDS - group 0
+// foreground (matched IoU >= thr), 1 background, 2 not a candidate - takes the first <= nfg_max foreground and fills the batch with
+// background, and gathers everything the losses need for the B sampled slots (foreground first, each part in ascending key order -
+// the order D2's cat + the reference's stable valid-first packing give).
+#define ROI_SAMPLE_MAX 4096
+__global__ __launch_bounds__(512) void roi_sample_kernel(const float* __restrict__ pb, const unsigned char* __restrict__ pv,
+                                                       const float* __restrict__ mx, const int* __restrict__ arg,
+                                                       const float* __restrict__ keys, int P, const float* __restrict__ gt_boxes,
+                                                       const int* __restrict__ gt_classes, const unsigned char* __restrict__ gt_valid,
+                                                       const float* __restrict__ gt_scores, const float* __restrict__ gt_std, int G,
+                                                       float iou_thr, int num_classes, int B, int nfg_max, int npow2,
+                                                       float* __restrict__ out_prop, long long* __restrict__ out_cls,
+                                                       float* __restrict__ out_gtb, unsigned char* __restrict__ out_valid,
+                                                       long long* __restrict__ out_idx, float* __restrict__ out_conf,
+                                                       float* __restrict__ out_std) {
+  __shared__ unsigned long long sk[ROI_SAMPLE_MAX];
+  __shared__ int cnt[2];
+  const int n = blockIdx.x, t = threadIdx.x;
+  int any = 0;
+  for (int g = t; g < G; g += blockDim.x) any |= gt_valid[(size_t)n * G + g];
+  if (t < 2) cnt[t] = 0;
+  const int has_gt = __syncthreads_or(any);
+  for (int i = t; i < npow2; i += blockDim.x) {
+    unsigned long long grp = 2, kb = 0;
+    if (i < P && pv[(size_t)n * P + i]) {
+      const bool fgm = has_gt && mx[(size_t)n * P + i] >= iou_thr;
+      const int cls = fgm ? gt_classes[(size_t)n * G + arg[(size_t)n * P + i]] : num_classes;
+      grp = cls != num_classes ? 0 : 1;
+      kb = (unsigned)__float_as_int(keys[(size_t)n * P + i]) & 0x7fffffffu;
+      atomicAdd(&cnt[grp], 1);
+    }
+    sk[i] = (grp << 60) | (kb << 20) | (unsigned long long)i;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npow2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int q = t; q < (npow2 >> 1); q += blockDim.x) {
+        const int i = 2 * q - (q & (j - 1)), l = i + j;   // i has bit j clear, l = i | j
+        const unsigned long long a = sk[i], b = sk[l];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) { sk[i] = b; sk[l] = a; }
+      }
+      __syncthreads();
+    }
+  const int nfg = cnt[0], nbg = cnt[1];
+  const int fsel = nfg < nfg_max ? nfg : nfg_max;
+  const int bsel = nbg < B - fsel ? nbg : B - fsel;
+  for (int j = t; j < B; j += blockDim.x) {
+    const int src = j < fsel ? j : (j < fsel + bsel ? nfg + (j - fsel) : -1);
+    const size_t o = (size_t)n * B + j;
+    float4 box = make_float4(0.f, 0.f, 0.f, 0.f), gb = box, gs = box;
+    long long cls = -1, idx = 0;
+    float conf = 0.f;
+    if (src >= 0) {
+      const int i = (int)(sk[src] & 0xfffffull);
+      idx = i;
+      box = *(const float4*)(pb + ((size_t)n * P + i) * 4);
+      cls = j < fsel ? (long long)gt_classes[(size_t)n * G + arg[(size_t)n * P + i]] : (long long)num_classes;
+      if (has_gt) {
+        const size_t g = (size_t)n * G + arg[(size_t)n * P + i];
+        gb = *(const float4*)(gt_boxes + g * 4);
+        if (gt_scores) conf = gt_scores[g];
+        if (gt_std) gs = *(const float4*)(gt_std + g * 4);
+      }
+    }
+    *(float4*)(out_prop + o * 4) = box;
+    out_cls[o] = cls;
+    *(float4*)(out_gtb + o * 4) = gb;
+    out_valid[o] = src >= 0;
+    out_idx[o] = idx;
+    if (out_conf) out_conf[o] = conf;
+    if (out_std) *(float4*)(out_std + o * 4) = gs;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Box regression losses of the boundary-variance predictor on the sampled ROIs (roi_heads/fast_rcnn.py:938-1090: `box_reg_loss`
 // nlloss / smooth_l1(beta 0) and `box_reg_pseudo_loss` tsbetter / smooth_l1), summed, with the derivatives w.r.t. the predicted
 // deltas and std logits.  mode 0: L1 + 0.05 * sum(NLL * IoU(gt, decoded box)) with the gradient flowing through the IoU;
@@ -1037,6 +1174,40 @@ int utv2_rpn_loss_bwd(const float* gobj, const float* gdl, const float* gout_cls
                       hipStream_t stream) {
   return utv2_rpn_loss_bwd_range(gobj, gdl, gout_cls, gout_loc, head, num_levels, hw_host, N, N, 0, A, ch, R, pos_idx, pos_valid, npos, neg_idx,
                                  neg_valid, nneg, grad_obj, grad_deltas, stream);
+}
+
+int utv2_rpn_sample_keys(const float* max_iou, const unsigned char* lowq, const unsigned char* gt_valid, int G, const float* keys, int N,
+                         int R, float lo, float hi, int64_t* out, hipStream_t stream) {
+  if (!max_iou || !lowq || !gt_valid || !keys || !out || N < 1 || R < 1 || G < 1) return UTV2_EARG;
+  hipLaunchKernelGGL(rpn_sample_keys_kernel, dim3(cdiv(R, 256), N), dim3(256), 0, stream, max_iou, lowq, gt_valid, G, keys, N, R, lo, hi,
+                     (long long*)out);
+  return utv2_launch_status();
+}
+
+int utv2_rpn_sample_unpack(const int64_t* top, int k, int N, int npos_max, int nneg_max, const unsigned char* gt_valid, int G,
+                           int64_t* pos_idx, unsigned char* pos_valid, int64_t* neg_idx, unsigned char* neg_valid, unsigned char* has_gt,
+                           hipStream_t stream) {
+  if (!top || !gt_valid || !pos_idx || !pos_valid || !neg_idx || !neg_valid || !has_gt || N < 1 || k < 1 || npos_max < 0 || nneg_max < 0 ||
+      G < 1)
+    return UTV2_EARG;
+  hipLaunchKernelGGL(rpn_sample_unpack_kernel, dim3(N), dim3(256), 0, stream, (const long long*)top, k, N, npos_max, nneg_max, gt_valid, G,
+                     (long long*)pos_idx, pos_valid, (long long*)neg_idx, neg_valid, has_gt);
+  return utv2_launch_status();
+}
+
+int utv2_roi_sample(const float* boxes, const unsigned char* valid, const float* max_iou, const int* argmax, const float* keys, int N, int P,
+                    const float* gt_boxes, const int* gt_classes, const unsigned char* gt_valid, const float* gt_scores, const float* gt_std,
+                    int G, float iou_thr, int num_classes, int batch, int nfg_max, float* out_boxes, int64_t* out_classes,
+                    float* out_gt_boxes, unsigned char* out_valid, int64_t* out_idx, float* out_conf, float* out_std, hipStream_t stream) {
+  if (!boxes || !valid || !max_iou || !argmax || !keys || !gt_boxes || !gt_classes || !gt_valid || !out_boxes || !out_classes ||
+      !out_gt_boxes || !out_valid || !out_idx || N < 1 || P < 1 || P > ROI_SAMPLE_MAX || G < 1 || batch < 1 || nfg_max < 0 || nfg_max > batch)
+    return UTV2_EARG;
+  int npow2 = 2;
+  while (npow2 < P) npow2 <<= 1;
+  hipLaunchKernelGGL(roi_sample_kernel, dim3(N), dim3(512), 0, stream, boxes, valid, max_iou, argmax, keys, P, gt_boxes, gt_classes, gt_valid,
+                     gt_scores, gt_std, G, iou_thr, num_classes, batch, nfg_max, npow2, out_boxes, (long long*)out_classes, out_gt_boxes,
+                     out_valid, (long long*)out_idx, out_conf, out_std);
+  return utv2_launch_status();
 }
 
 int utv2_roi_box_loss(const float* deltas, const float* stdl, int64_t ld, const int64_t* cls, const float* prop, const float* gtb,

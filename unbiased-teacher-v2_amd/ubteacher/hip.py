@@ -622,6 +622,58 @@ def rpn_loss_bwd(gobj, gdl, gout_cls, gout_loc, head_hw, N, A, ch, R, s, grad_ob
          _p(s["pos_idx"]), _p(_u8(s["pos_valid"])), npos, _p(s["neg_idx"]), _p(_u8(s["neg_valid"])), nneg, _p(grad_obj), _p(grad_deltas), _stream())
 
 
+def rpn_sample(mx, lowq, gt_valid, keys, lo, hi, npos_max, batch):
+    """PseudoLabRPN.label_and_sample after the matching: labels + "k smallest keys" subsampling of positives / negatives as three
+    launches (sortable keys, exact radix select, unpack).  -> pos_idx [N,npos_max] int64, pos_valid uint8, neg_idx [N,batch], neg_valid,
+    has_gt [N,1] uint8."""
+    N, R = mx.shape
+    dev = mx.device
+    G = gt_valid.shape[1]
+    k = max(npos_max, batch)
+    assert k <= 2048 and keys.dtype == torch.float32 and tuple(keys.shape) == (N, R)
+    skeys = torch.empty((2 * N, R), dtype=torch.int64, device=dev)
+    call("utv2_rpn_sample_keys", _p(mx), _p(_u8(lowq)), _p(gt_valid), G, _p(keys.contiguous()), N, R, float(lo), float(hi), _p(skeys), _stream())
+    ck = (N, R, str(dev))
+    row_off = _rpn_sample_rows.get(ck)
+    if row_off is None:
+        if len(_rpn_sample_rows) >= 16:
+            _rpn_sample_rows.clear()
+        row_off = _rpn_sample_rows[ck] = torch.arange(2 * N + 1, dtype=torch.int64, device=dev) * R
+    top = topk_rows(skeys, row_off, 2 * N, R, k)
+    pos_idx = torch.empty((N, npos_max), dtype=torch.int64, device=dev)
+    pos_valid = torch.empty((N, npos_max), dtype=torch.uint8, device=dev)
+    neg_idx = torch.empty((N, batch), dtype=torch.int64, device=dev)
+    neg_valid = torch.empty((N, batch), dtype=torch.uint8, device=dev)
+    has_gt = torch.empty((N, 1), dtype=torch.uint8, device=dev)
+    call("utv2_rpn_sample_unpack", _p(top), k, N, npos_max, batch, _p(gt_valid), G, _p(pos_idx), _p(pos_valid), _p(neg_idx), _p(neg_valid),
+         _p(has_gt), _stream())
+    return pos_idx, pos_valid, neg_idx, neg_valid, has_gt
+
+
+_rpn_sample_rows = {}
+
+
+def roi_sample(boxes, valid, mx, arg, keys, gt_boxes, gt_classes, gt_valid, gt_scores, gt_std, iou_thr, num_classes, batch, nfg_max):
+    """StandardROIHeadsPseudoLab.label_and_sample_proposals after the matching, one launch (one workgroup per image)"""
+    N, P = mx.shape
+    dev = mx.device
+    G = gt_valid.shape[1]
+    out = dict(proposal_boxes=torch.empty((N, batch, 4), dtype=torch.float32, device=dev),
+               gt_classes=torch.empty((N, batch), dtype=torch.int64, device=dev),
+               gt_boxes=torch.empty((N, batch, 4), dtype=torch.float32, device=dev),
+               valid=torch.empty((N, batch), dtype=torch.uint8, device=dev),
+               sampled_idx=torch.empty((N, batch), dtype=torch.int64, device=dev))
+    if gt_scores is not None:
+        out["gt_confid"] = torch.empty((N, batch), dtype=torch.float32, device=dev)
+        if gt_std is not None:
+            out["gt_loc_std"] = torch.empty((N, batch, 4), dtype=torch.float32, device=dev)
+    call("utv2_roi_sample", _p(boxes), _p(_u8(valid)), _p(mx), _p(arg), _p(keys.contiguous()), N, P, _p(gt_boxes), _p(gt_classes), _p(gt_valid),
+         _p(gt_scores), _p(gt_std if gt_scores is not None else None), G, float(iou_thr), int(num_classes), int(batch), int(nfg_max),
+         _p(out["proposal_boxes"]), _p(out["gt_classes"]), _p(out["gt_boxes"]), _p(out["valid"]), _p(out["sampled_idx"]),
+         _p(out.get("gt_confid")), _p(out.get("gt_loc_std")), _stream())
+    return out
+
+
 def roi_box_loss(deltas, std, cls, prop, gtb, gstd, num_classes, mode, wx, wy, scale_clamp, ts_better, t_cert):
     """(sum [1], d sum / d deltas [R,4], d sum / d std [R,4]); deltas / std may be column slices of the predictor output (row pitch = stride(0))"""
     R = deltas.shape[0]

@@ -13,6 +13,7 @@ and the Detectron2 pieces they inherit from [D2-recall, SURVEY appendix C], re-l
     MFMA implicit-GEMM kernel as the convs; fc1 consumes the NHWC RoIAlign output directly.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -363,19 +364,23 @@ class PseudoLabRPN:
         mx, arg, gmax = hip.match_boxes(anchors, gt["boxes"], gt["valid"], want_gt_max=True)
         lowq = hip.match_lowq(anchors, gt["boxes"], gt["valid"], gmax)
         lo, hi = self.iou_thresholds
+        keys = _keys(self.sample_keys, N, R, anchors.device)
+        npos_max = int(self.batch_size_per_image * self.positive_fraction)
+        if max(npos_max, self.batch_size_per_image) <= 2048 and os.environ.get("UTV2_FUSED_SAMPLERS", "1") != "0":
+            # labels (IoU thresholds, allow_low_quality_matches, images without gt) and both "k smallest keys" draws in three launches
+            pidx, pval, nidx, nval, has_gt = hip.rpn_sample(mx, lowq, gt["valid"], keys, lo, hi, npos_max, self.batch_size_per_image)
+            return dict(pos_idx=pidx, pos_valid=pval, neg_idx=nidx, neg_valid=nval, matched32=arg, has_gt=has_gt)
         has_gt = gt["valid"].bool().any(dim=1, keepdim=True)
         one = torch.ones((), dtype=torch.int8, device=anchors.device)
         labels = torch.where(mx < lo, one * 0, one * -1)
         labels = torch.where(mx >= hi, one, labels)
         labels = torch.where(lowq.bool(), one, labels)   # allow_low_quality_matches
         labels = torch.where(has_gt, labels, torch.zeros_like(labels))
-        keys = _keys(self.sample_keys, N, R, anchors.device)
-        npos_max = int(self.batch_size_per_image * self.positive_fraction)
         pidx, pval = sample_k_smallest(keys, labels == 1, npos_max)
         npos = pval.sum(1, keepdim=True)
         nidx, nval = sample_k_smallest(keys, labels == 0, self.batch_size_per_image)
         nval = nval & (torch.arange(nidx.shape[1], device=anchors.device)[None, :] < (self.batch_size_per_image - npos))
-        return dict(pos_idx=pidx, pos_valid=pval, neg_idx=nidx, neg_valid=nval, matched=arg.long(), matched32=arg, has_gt=has_gt)
+        return dict(pos_idx=pidx, pos_valid=pval, neg_idx=nidx, neg_valid=nval, matched32=arg, has_gt=has_gt)
 
     def losses(self, anchors, obj, deltas, gt, head_hw=None, batch=None, img0=0):
         """rpn.py:153-225: BCE(sum) over sampled anchors (optionally weighted by the matched pseudo-box score,
@@ -578,6 +583,12 @@ class StandardROIHeadsPseudoLab:
             pv = torch.cat((pv, gt["valid"].bool()), dim=1)
         N, P = pv.shape
         mx, arg, _ = hip.match_boxes(pb, gt["boxes"], gt["valid"])
+        if P <= 4096 and os.environ.get("UTV2_FUSED_SAMPLERS", "1") != "0":
+            # classes, foreground / background draws, valid-first packing and the gathers of the sampled slots in one launch
+            keys = _keys(self.sample_keys, N, P, pb.device)
+            return hip.roi_sample(pb, pv, mx, arg, keys, gt["boxes"], gt["classes"], gt["valid"], gt["scores"] if "scores" in gt else None,
+                                  gt["pred_boxes_std"] if "pred_boxes_std" in gt else None, self.iou_threshold, self.num_classes,
+                                  self.batch_size_per_image, int(self.batch_size_per_image * self.positive_fraction))
         arg = arg.long()
         has_gt = gt["valid"].bool().any(dim=1, keepdim=True)
         fgm = (mx >= self.iou_threshold) & has_gt
