@@ -360,6 +360,13 @@ class _ConvFn(torch.autograd.Function):
                     # instead of a 4x larger dilated gather that is 3/4 masked
                     dxc = hip.conv2d_fwd_bf16(g4, layer.wt16(wsc), out_dtype=x.dtype)
                     dx = hip.zero_interleave2x(dxc, x4.shape[1], x4.shape[2], mask=pm)
+                elif (d16 and layer.k == 3 and layer.stride == 2 and layer.pad == 1 and g4.shape[-1] % 32 == 0
+                      and x4.shape[0] * x4.shape[1] * x4.shape[2] <= 65536):
+                    # small stride-2 3x3 layers (FPN p6 / p7): the dilated-gather dgrad only exists in the generic kernel, whose long K loop
+                    # on a 52-workgroup grid sat on the backward's critical path (78 us alone, ~250 us in the step; -0.12 ms / step); the gradient
+                    # zero-interleaved to the input grid is a plain stride-1 conv for the LDS-DMA kernel (4x the MACs of a tiny layer)
+                    gd = hip.zero_interleave2x(g4.contiguous(), x4.shape[1], x4.shape[2])
+                    dx = hip.conv2d_fwd_bf16(gd, layer.wt16(wsc), pad=1, kh=3, kw=3, out_dtype=x.dtype, mask=pm)
                 elif d16:
                     dx = hip.conv2d_dgrad_bf16(g4, layer.wt16(wsc), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k,
                                                out_dtype=x.dtype, mask=pm)
