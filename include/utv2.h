@@ -91,8 +91,13 @@ int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int
 int utv2_f32_to_bf16(const float* src, void* dst16, int64_t n, utv2_stream_t stream);
 int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, const float* scale, int K, int KH, int KW, int C,
                                     utv2_stream_t stream);
-/* every dgrad weight image of a model in one launch; table = device array of nlayers 40-byte records
- * {int64 w_off (elements into arena), int64 dst_off (into bank), int64 scale_off (into scales, -1 = none), int32 K, KH, KW, C} */
+/* dst16 bf16 [rows][cpad] = src [rows][c] (UTV2_F32 / UTV2_BF16) rounded to nearest even, columns [c, cpad) zero; c, cpad % 8 == 0.
+ * The output gradient of a layer whose channel count is no multiple of 32 (the 80-channel FCOS prediction convs, fcos.py:283-307),
+ * padded for the LDS-DMA dgrad kernel. */
+int utv2_pad_cols_bf16(const void* src, int src_dtype, void* dst16, int64_t rows, int c, int cpad, utv2_stream_t stream);
+/* every dgrad weight image of a model in one launch; table = device array of nlayers 48-byte records
+ * {int64 w_off (elements into arena), int64 dst_off (into bank), int64 scale_off (into scales, -1 = none), int32 K, KH, KW, C,
+ *  int32 Kpad (>= K: pitch of the image's output-channel axis, channels [K, Kpad) zero), int32 0} */
 int utv2_weight_flip_transpose_bf16_batched(const float* arena, const float* scales, void* bank, const void* table, int nlayers,
                                             utv2_stream_t stream);
 

@@ -411,7 +411,8 @@ def test_post_mask_epilogue_and_masked_zero_interleave():
 
 
 def test_batched_weight_flip_equals_per_layer_flip():
-    """one launch for all layers (tiled transpose) == the per-layer element-wise kernel, bit for bit, incl. ragged K / C and scales"""
+    """one launch for all layers (tiled transpose) == the per-layer element-wise kernel, bit for bit, incl. ragged K / C, scales and a
+    zero-padded output-channel axis"""
     import struct
     from ubteacher import hip
     torch.manual_seed(3)
@@ -424,9 +425,11 @@ def test_batched_weight_flip_equals_per_layer_flip():
         arena.append(w.reshape(-1))
         if sc is not None:
             scales.append(sc)
-        recs.append(struct.pack("<qqqiiii", w_off, dst_off, sc_off if has_scale else -1, K, KH, KW, C))
-        refs.append(hip.weight_flip_transpose_bf16(w, K, KH, KW, C, scale=sc).reshape(-1))
-        w_off += w.numel(); dst_off += w.numel(); sc_off += K if has_scale else 0
+        Kpad = 96 if K == 80 else K          # the 80-channel prediction convs: image zero-padded to 96 output channels
+        recs.append(struct.pack("<qqqiiiiii", w_off, dst_off, sc_off if has_scale else -1, K, KH, KW, C, Kpad, 0))
+        ref = hip.weight_flip_transpose_bf16(w, K, KH, KW, C, scale=sc)
+        refs.append(torch.nn.functional.pad(ref.view(C, KH * KW, K), (0, Kpad - K)).reshape(-1))
+        w_off += w.numel(); dst_off += C * KH * KW * Kpad; sc_off += K if has_scale else 0
     arena = torch.cat(arena).contiguous()
     scales = torch.cat(scales).contiguous()
     table = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).cuda()

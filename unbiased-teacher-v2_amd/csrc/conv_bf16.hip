@@ -271,6 +271,27 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
   }
 }
 
+// dst bf16 [rows][cpad] = RNE(src [rows][c]) with zeros in columns [c, cpad)   (c, cpad multiples of 8)
+template <typename T>
+__global__ __launch_bounds__(256) void pad_cols_bf16_kernel(const T* __restrict__ src, __bf16* __restrict__ dst, size_t rows, int c, int cpad) {
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  const int per_row = cpad / 8;
+  const size_t total = rows * per_row, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t r = i / per_row;
+    const int j = (int)(i - r * per_row) * 8;
+    bf16x8_t o;
+    if (j < c) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)(float)src[r * c + j + e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)0.f;
+    }
+    *(bf16x8_t*)(dst + r * cpad + j) = o;
+  }
+}
+
 // wt16[ci][KH-1-kh][KW-1-kw][co] = bf16(w[co][kh][kw][ci] * scale[co])   (scale optional: the folded FrozenBN multiplier,
 // so dgrad consumes the UNscaled output gradient and no "dy * scale" pass is ever materialised)
 __global__ void weight_flip_transpose_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, const float* __restrict__ scale,
@@ -296,6 +317,8 @@ struct FlipDesc {
   long long dst_off;    // element offset of its [C][KH][KW][K] bf16 image in the bank buffer
   long long scale_off;  // element offset of its per-output-channel multiplier in `scales`, or -1
   int K, KH, KW, C;
+  int Kpad;             // pitch of the image's innermost (output-channel) axis, >= K: channels [K, Kpad) are written as zeros
+  int reserved;
 };
 
 __global__ __launch_bounds__(256) void weight_flip_transpose_bf16_batched_kernel(const float* __restrict__ arena, const float* __restrict__ scales,
@@ -307,7 +330,7 @@ __global__ __launch_bounds__(256) void weight_flip_transpose_bf16_batched_kernel
   const float* w = arena + d.w_off;
   const float* scale = d.scale_off >= 0 ? scales + d.scale_off : nullptr;
   __bf16* wt = bank + d.dst_off;
-  const int T = d.KH * d.KW, tk = (d.K + 31) / 32, tc = (d.C + 31) / 32;
+  const int T = d.KH * d.KW, tk = (d.Kpad + 31) / 32, tc = (d.C + 31) / 32;
   const int ntiles = T * tk * tc;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -329,7 +352,7 @@ __global__ __launch_bounds__(256) void weight_flip_transpose_bf16_batched_kernel
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ci = ci0 + ty + 8 * i, co = co0 + tx;
-      if (ci < d.C && co < d.K) wt[((size_t)ci * T + ftap) * d.K + co] = (__bf16)tile[tx][ty + 8 * i];
+      if (ci < d.C && co < d.Kpad) wt[((size_t)ci * T + ftap) * d.Kpad + co] = (__bf16)tile[tx][ty + 8 * i];
     }
     __syncthreads();
   }
@@ -1225,6 +1248,18 @@ int utv2_f32_to_bf16(const float* src, void* dst16, int64_t n, hipStream_t strea
   return utv2_launch_status();
 }
 
+int utv2_pad_cols_bf16(const void* src, int src_dtype, void* dst16, int64_t rows, int c, int cpad, hipStream_t stream) {
+  if (!src || !dst16 || rows < 0 || c < 8 || (c & 7) || (cpad & 7) || cpad < c || bad_dtype(src_dtype)) return UTV2_EARG;
+  if (rows == 0) return UTV2_OK;
+  size_t nb = ((size_t)rows * (cpad / 8) + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  if (src_dtype == UTV2_BF16)
+    hipLaunchKernelGGL(pad_cols_bf16_kernel<__bf16>, dim3((int)nb), dim3(256), 0, stream, (const __bf16*)src, (__bf16*)dst16, (size_t)rows, c, cpad);
+  else
+    hipLaunchKernelGGL(pad_cols_bf16_kernel<float>, dim3((int)nb), dim3(256), 0, stream, (const float*)src, (__bf16*)dst16, (size_t)rows, c, cpad);
+  return utv2_launch_status();
+}
+
 int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, const float* scale, int K, int KH, int KW, int C,
                                     hipStream_t stream) {
   if (!w || !wt16) return UTV2_EARG;
@@ -1235,12 +1270,13 @@ int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, const float* sca
   return utv2_launch_status();
 }
 
-// table: device array of nlayers records {int64 w_off, dst_off, scale_off; int32 K, KH, KW, C} (40 bytes each, see FlipDesc):
-// bank[dst_off ..] = bf16 flip/transpose of arena[w_off ..] (* scales[scale_off + co] when scale_off >= 0) for every layer.
+// table: device array of nlayers records {int64 w_off, dst_off, scale_off; int32 K, KH, KW, C, Kpad, 0} (48 bytes each, see FlipDesc):
+// bank[dst_off ..] = bf16 flip/transpose of arena[w_off ..] (* scales[scale_off + co] when scale_off >= 0) for every layer, the
+// output-channel axis zero-padded from K to Kpad (the dgrad of a layer whose K is no multiple of 32 runs on a padded gradient).
 int utv2_weight_flip_transpose_bf16_batched(const float* arena, const float* scales, void* bank, const void* table, int nlayers,
                                             hipStream_t stream) {
   if (!arena || !bank || !table || nlayers < 1) return UTV2_EARG;
-  static_assert(sizeof(FlipDesc) == 40, "table record layout is part of the ABI");
+  static_assert(sizeof(FlipDesc) == 48, "table record layout is part of the ABI");
   hipLaunchKernelGGL(weight_flip_transpose_bf16_batched_kernel, dim3(128, nlayers), dim3(256), 0, stream, arena, scales, (__bf16*)bank,
                      (const FlipDesc*)table);
   return utv2_launch_status();

@@ -750,6 +750,14 @@ def _act_dtype(x, out_dtype):
     return out_dtype if out_dtype is not None else x.dtype
 
 
+def pad_cols_bf16(src2d, cpad):
+    """[rows, c] fp32 / bf16 -> bf16 [rows, cpad], zero padded columns"""
+    rows, c = src2d.shape
+    out = torch.empty((rows, cpad), dtype=torch.bfloat16, device=src2d.device)
+    call("utv2_pad_cols_bf16", _p(src2d), _dt(src2d), _p(out), rows, c, cpad, _stream())
+    return out
+
+
 def weight_flip_transpose_bf16_batched(arena, scales, bank, table, nlayers):
     call("utv2_weight_flip_transpose_bf16_batched", _p(arena), c_p(scales.data_ptr()) if scales is not None else c_p(0), _p(bank),
          _p(table), int(nlayers), _stream())

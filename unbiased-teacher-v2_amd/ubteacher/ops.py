@@ -152,7 +152,7 @@ class FlipBank:
         offs, total = [], 0
         for layer, _ in self.layers:
             offs.append(total)
-            total += (layer.cout * layer.k * layer.k * layer.cin + 7) // 8 * 8
+            total += (layer.dgrad_cout() * layer.k * layer.k * layer.cin + 7) // 8 * 8
         self.bank = torch.empty(total, dtype=torch.bfloat16, device=dev)
         self.scales = None
         rec = bytearray()
@@ -163,9 +163,10 @@ class FlipBank:
                     self.scales = torch.empty(0, dtype=torch.float32, device=dev).set_(sc.untyped_storage())
                 assert sc.untyped_storage().data_ptr() == self.scales.untyped_storage().data_ptr()
                 so = sc.storage_offset()
-            rec += struct.pack("<qqqiiii", layer.w.offset, o, so, layer.cout, layer.k, layer.k, layer.cin)
+            rec += struct.pack("<qqqiiiiii", layer.w.offset, o, so, layer.cout, layer.k, layer.k, layer.cin, layer.dgrad_cout(), 0)
         self.table = torch.frombuffer(rec, dtype=torch.uint8).clone().to(dev)
-        self.views = [self.bank[o:o + l.cout * l.k * l.k * l.cin].view(l.cin, l.k * l.k * l.cout) for (l, _), o in zip(self.layers, offs)]
+        self.views = [self.bank[o:o + l.dgrad_cout() * l.k * l.k * l.cin].view(l.cin, l.k * l.k * l.dgrad_cout())
+                      for (l, _), o in zip(self.layers, offs)]
         self.dirty = False
         self.single.clear()
 
@@ -187,7 +188,11 @@ class FlipBank:
             return self.views[self.slot[id(layer)]]
         ent = self.single.get(id(layer))
         if ent is None or ent[0] != cur:
-            ent = (cur, hip.weight_flip_transpose_bf16(layer.w.t, layer.cout, layer.k, layer.k, layer.cin, scale))
+            img = hip.weight_flip_transpose_bf16(layer.w.t, layer.cout, layer.k, layer.k, layer.cin, scale)
+            if layer.dgrad_cout() != layer.cout:   # first request of a padded layer only: later ones come from the batched launch
+                img = torch.nn.functional.pad(img.view(layer.cin, layer.k * layer.k, layer.cout), (0, layer.dgrad_cout() - layer.cout)) \
+                    .reshape(layer.cin, -1).contiguous()
+            ent = (cur, img)
             self.single[id(layer)] = ent
         return ent[1]
 
@@ -230,6 +235,14 @@ class Conv:
         if bank is None:
             bank = self.w.store._flipbank = FlipBank(self.w.store)
         return bank.get(self, scale)
+
+    def dgrad_cout(self):
+        """output channels of the bf16 dgrad weight image: the multi-level 3x3 layers whose cout is no multiple of 32 (the 80-channel
+        prediction convs) run their dgrad on a zero-padded bf16 copy of the gradient - the LDS-DMA kernel stages 32-channel chunks; the
+        generic kernel took 318 us per launch on them against ~100"""
+        if self.k == 3 and self.stride == 1 and self.cout % 32 and self.cout % 8 == 0 and self.cout > 32:
+            return (self.cout + 31) // 32 * 32
+        return self.cout
 
     def use_bf16(self):
         return PRECISION[0] == "bf16" and self.cin % 8 == 0 and self.kred == self.k * self.k * self.cin
@@ -338,7 +351,8 @@ class _ConvFn(torch.autograd.Function):
         if meta is not None and layer.k > 1:
             if ctx.needs_input_grad[0]:
                 if d16:
-                    dx = hip.conv2d_ml_fwd_bf16(g, layer.wt16(wsc), meta.level_hw, meta.N, k=layer.k, pad=layer.k - 1 - layer.pad,
+                    gp = g if layer.dgrad_cout() == layer.cout else hip.pad_cols_bf16(g, layer.dgrad_cout())
+                    dx = hip.conv2d_ml_fwd_bf16(gp, layer.wt16(wsc), meta.level_hw, meta.N, k=layer.k, pad=layer.k - 1 - layer.pad,
                                                 out_dtype=x.dtype)
                 else:
                     dx = hip.conv2d_ml_dgrad(g, layer.wt(), meta.level_hw, meta.N, layer.k, layer.pad)
@@ -368,7 +382,10 @@ class _ConvFn(torch.autograd.Function):
                     gd = hip.zero_interleave2x(g4.contiguous(), x4.shape[1], x4.shape[2])
                     dx = hip.conv2d_fwd_bf16(gd, layer.wt16(wsc), pad=1, kh=3, kw=3, out_dtype=x.dtype, mask=pm)
                 elif d16:
-                    dx = hip.conv2d_dgrad_bf16(g4, layer.wt16(wsc), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k,
+                    gd = g4
+                    if layer.dgrad_cout() != layer.cout:
+                        gd = hip.pad_cols_bf16(g4.reshape(-1, layer.cout), layer.dgrad_cout()).view(g4.shape[:-1] + (layer.dgrad_cout(),))
+                    dx = hip.conv2d_dgrad_bf16(gd, layer.wt16(wsc), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k,
                                                out_dtype=x.dtype, mask=pm)
                 else:
                     dx = hip.conv2d_dgrad(g4, layer.wt(), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k)
