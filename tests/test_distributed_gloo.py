@@ -55,6 +55,14 @@ def _worker(rank, world, port, q):
     sums0 = torch.zeros(8)
     npa0, den0 = FCOSOutputs._normalisers(sums0)
     out["npa0"], out["den0"] = float(npa0), float(den0)
+    # (2b) a rank running the fused student pass next to a rank running the two passes (their image lists pad to different canvases):
+    # the fused path's normaliser reduction must be the same three collectives the per-pass path issues, in the same order
+    trio = [torch.tensor([1.0 + rank + 10 * i, 0.5 * (rank + 1) + i, 0, 0, 0, 0, 0, 0]) for i in range(3)]
+    if rank == 0:
+        out["joint"] = FCOSOutputs._joint_normaliser_sums(*trio).tolist()
+    else:
+        pairs = [FCOSOutputs._normalisers(t) for t in trio]
+        out["joint"] = [float(v) * 2 for pr in pairs for v in pr]      # _normalisers returns world means (clamps inactive here)
     # (3) loader sharding
     cfg = get_config("fcos", 1, ["SOLVER.IMG_PER_BATCH_LABEL", 4, "SOLVER.IMG_PER_BATCH_UNLABEL", 2, "MODEL.DEVICE", "cpu"])
     ld = SyntheticTwoCropLoader(cfg, height=32, width=48, device="cpu")
@@ -159,6 +167,9 @@ def test_world_size_2_gloo():
         assert res[r]["npa"] == pytest.approx((3.0 + 4.0) / 2)      # == single-process value on the concatenated batch / world
         assert res[r]["den"] == pytest.approx((1.5 + 3.0) / 2)
         assert res[r]["npa0"] == 1.0 and res[r]["den0"] == pytest.approx(1e-6)   # clamps (fcos_outputs.py:321,362)
+        # mixed fused / per-pass ranks: the same three collectives met each other (no hang, no mismatched sizes) and both see the world sums
+        want = [v for i in range(3) for v in ((1.0 + 10 * i) + (2.0 + 10 * i), (0.5 + i) + (1.0 + i))]
+        assert res[r]["joint"] == pytest.approx(want)
         assert res[r]["sizes"] == (2, 2, 1, 1)                      # IMG_PER_BATCH_* // world (data/build.py:240-241)
     assert not torch.equal(res[0]["img0"], res[1]["img0"])          # ranks see different images
     m = res[0]["metrics"]

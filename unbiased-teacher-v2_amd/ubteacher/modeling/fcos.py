@@ -392,6 +392,16 @@ class FCOSOutputs:
         den = (pair[1] / ws).clamp(min=1e-6)
         return npa, den
 
+    @staticmethod
+    def _joint_normaliser_sums(sums_s, sums_c, sums_r):
+        """world sums of the (n_pos, sum ctrness) pairs of the three target sets of a fused student pass -> [6] (None in a world of 1).
+        Three 2-float all-reduces in the order losses() / pseudo_losses() issue theirs through _normalisers(): a rank whose two student
+        passes could not be fused (its lists pad to different canvases) runs those instead, and every rank must issue the same sequence
+        of collectives."""
+        if comm.get_world_size() == 1:
+            return None
+        return torch.cat([comm.reduce_sum(x[0:2].detach().clone()) for x in (sums_s, sums_c, sums_r)])
+
     def _kl_mean(self, sums):
         """LOC_FUN_ALL "mean" of the KL-type term: NLLoss averages over positives (kl_loss.py:93-105), KLLoss over positives x 4
         boundaries (kl_loss.py:59-60)."""
@@ -473,12 +483,7 @@ class FCOSOutputs:
         sums_r = ops.fcos_loc_terms(box_all, labels, reg_t, bvars if tsbetter else None,
                                     (nc, rm, self.tsbetter_reg, self.tsbetter_reg_cert, self.loc_flags))
         ws = comm.get_world_size()
-        norm = None
-        if ws > 1:
-            # the (n_pos, sum ctrness) pairs of the three target sets, all-reduced one by one in the order losses() / pseudo_losses()
-            # do it: a rank whose two student passes could not be fused (different padded canvases) runs those, and every rank must
-            # issue the same sequence of collectives
-            norm = torch.cat([comm.reduce_sum(x[0:2].detach().clone()) for x in (sums_s, sums_c, sums_r)])
+        norm = self._joint_normaliser_sums(sums_s, sums_c, sums_r)
         flags = (1 if self.kl_loss else 0) | (2 if self.kl_loss_type == "klloss" else 0) | (4 if self.unify_ctrcls else 0) | (8 if tsbetter else 0)
         wmul = [loss_weights[k][0] for k in self.LOSS_KEYS]
         wdiv = [loss_weights[k][1] for k in self.LOSS_KEYS]
