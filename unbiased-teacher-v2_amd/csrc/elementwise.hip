@@ -508,12 +508,14 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce(GnSegs sg, const float* __r
   }
 }
 
-__global__ __launch_bounds__(256) void gn_bwd_param(const float* __restrict__ AB, float* __restrict__ dgamma, float* __restrict__ dbeta, int S,
-                                                     int C) {
+// dgamma / dbeta += sums of AB over the segments.  Runs as the prologue of the first cdiv(C, 64) workgroups of gn_bwd_apply: a launch of
+// its own sat, with its gap, between gn_bwd_reduce and gn_bwd_apply on the backward's critical path although only the optimizer reads it.
+__device__ __forceinline__ void gn_bwd_param(const float* __restrict__ AB, float* __restrict__ dgamma, float* __restrict__ dbeta, int S, int C,
+                                             int block) {
   // 64 channels x 4 segment parts per block (one thread per channel walked the S segments alone: 16 us of pure load latency);
   // the parts are combined in a fixed order
   __shared__ float ra[256], rb[256];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const int c = block * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
   float a = 0.f, b = 0.f;
   if (c < C)
     for (int n = part; n < S; n += 4) {
@@ -536,7 +538,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(GnSegs sg, const T* __restri
                                                   const T* __restrict__ x, const float* __restrict__ mean,
                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, const float* __restrict__ s12,
-                                                  T* __restrict__ dx, int C, int G, int relu) {
+                                                  T* __restrict__ dx, int C, int G, int relu, const float* __restrict__ AB,
+                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int param_blocks) {
+  if ((int)blockIdx.x < param_blocks) gn_bwd_param(AB, dgamma, dbeta, sg.nseg, C, blockIdx.x);
   int seg, r0, r1;
   gn_locate(sg, blockIdx.x, seg, r0, r1);
   const int C4 = C >> 2, cpg = C / G;
@@ -610,9 +614,9 @@ static void gn_bwd_launch(const GnSegs& sg, int chunks, int nseg, const void* dy
   hipLaunchKernelGGL(gn_bwd_partial<T>, dim3(chunks), dim3(256), 0, stream, sg, (const T*)dy, (const T*)y, (const T*)x, mean, rstd,
                      gamma, beta, part, C, G, relu);
   hipLaunchKernelGGL(gn_bwd_reduce, dim3(nseg), dim3(256), 2 * C * sizeof(float), stream, sg, (const float*)part, gamma, AB, s12, C, G);
-  hipLaunchKernelGGL(gn_bwd_param, dim3(cdiv(C, 64)), dim3(256), 0, stream, (const float*)AB, dgamma, dbeta, nseg, C);
-  hipLaunchKernelGGL(gn_bwd_apply<T>, dim3(chunks), dim3(256), 0, stream, sg, (const T*)dy, (const T*)y, (const T*)x, mean, rstd,
-                     gamma, beta, (const float*)s12, (T*)dx, C, G, relu);
+  const int pb = cdiv(C, 64);   // workgroups that also run gn_bwd_param (a workgroup past the last chunk finds no rows)
+  hipLaunchKernelGGL(gn_bwd_apply<T>, dim3(chunks > pb ? chunks : pb), dim3(256), 0, stream, sg, (const T*)dy, (const T*)y, (const T*)x, mean,
+                     rstd, gamma, beta, (const float*)s12, (T*)dx, C, G, relu, (const float*)AB, dgamma, dbeta, pb);
 }
 
 extern "C" {
