@@ -141,6 +141,14 @@ int utv2_groupnorm_relu_seg_fwd(const void* x, const float* gamma, const float* 
 int utv2_groupnorm_relu_seg_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
                                 const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, float* ws,
                                 int nseg, const int* seg_rows_host, int C, int G, int relu, int dtype, utv2_stream_t stream);
+/* the same with colsum_part (optional, fp32 [utv2_groupnorm_seg_chunks(...)][C]) = per-chunk column sums of dx as stored: summed over
+ * the chunks (utv2_colsum) they are the bias gradient of the convolution in front of the GroupNorm (fcos.py:263: conv -> GN -> ReLU), whose
+ * dY is this dx - no separate pass over dY */
+int64_t utv2_groupnorm_seg_chunks(int nseg, const int* seg_rows_host);
+int utv2_groupnorm_relu_seg_bwd_colsum(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
+                                       const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, float* ws,
+                                       int nseg, const int* seg_rows_host, int C, int G, int relu, int dtype, float* colsum_part,
+                                       utv2_stream_t stream);
 int64_t utv2_groupnorm_workspace_floats(int N, int HW, int C);
 int utv2_groupnorm_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                             float* ws, int N, int HW, int C, int G, float eps, int relu, utv2_stream_t stream);

@@ -273,6 +273,33 @@ def test_groupnorm_relu_fwd_bwd():
     close(dbe, ber.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_groupnorm_bwd_column_sums_of_dx(dtype):
+    """utv2_groupnorm_relu_seg_bwd_colsum: the per-chunk column sums written next to dx add up to the column sums of dx AS STORED (the
+    bias gradient of the conv in front of the GroupNorm: what the separate colsum pass over its dY computed), dx / dgamma / dbeta are those
+    of the plain entry; ragged (image, level) segments, chunks that end mid-way."""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(8)
+    C, seg_rows = 256, [700, 256, 1, 513, 90]
+    rows = sum(seg_rows)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.3).to(dtype).to(DEV)
+    dy = torch.randn(rows, C, generator=g).to(dtype).to(DEV)
+    ga = (torch.rand(C, generator=g) + 0.5).to(DEV); be = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    y, mean, rstd = hip.groupnorm_relu_seg_fwd(x, seg_rows, ga, be)
+    d0 = [torch.zeros(C, device=DEV) for _ in range(2)]
+    d1 = [torch.zeros(C, device=DEV) for _ in range(2)]
+    dx0 = hip.groupnorm_relu_seg_bwd(dy, y, x, seg_rows, mean, rstd, ga, d0[0], d0[1], beta=be)
+    dx1, part = hip.groupnorm_relu_seg_bwd(dy, y, x, seg_rows, mean, rstd, ga, d1[0], d1[1], beta=be, want_colsum=True)
+    assert torch.equal(dx0, dx1) and torch.equal(d0[0], d1[0]) and torch.equal(d0[1], d1[1])
+    assert part.shape == (sum((r + 255) // 256 for r in seg_rows), C)
+    ref = dx1.double().sum(0)
+    got = part.double().sum(0)
+    assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    db = torch.full((C,), 0.5, device=DEV)
+    hip.colsum(part, db, accumulate=True)
+    assert float((db.double() - 0.5 - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
 def test_pool_upsample_preprocess_fold():
     from ubteacher import hip
     g = torch.Generator().manual_seed(6)

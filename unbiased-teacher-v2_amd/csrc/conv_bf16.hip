@@ -1903,15 +1903,26 @@ static int wgrad16_small_splits(int M, int K, int Kred) {
 
 // the 256 x 256-tile kernel: one workgroup per CU in ONE round - as many pixel splits as fit 256 work items, at least 8 chunks each
 #define WGRAD_W8_MAX_NB 1024  // row blocks of the bias column-sum pass
+// Workgroups (= CUs: one 8-wave, 512-VGPR workgroup fills a CU) a launch may occupy.  Fewer than 256 leaves CUs free for the main
+// stream while the weight gradients run on their side stream (UTV2_WGRAD_W8_WGS, a multiple of 8, read once).
+static int wgrad16_w8_budget() {
+  static const int w = [] {
+    int v = env_int("UTV2_WGRAD_W8_WGS", 256);
+    v = (v / 8) * 8;
+    return v < 8 ? 8 : (v > 256 ? 256 : v);
+  }();
+  return w;
+}
 static int wgrad16_w8_splits(int M, int K, int Kred) {
   const int tiles = (K >> 8) * (Kred >> 8), chunks = cdiv(M, WGRAD_W8_BP);
-  int splits = 256 / tiles;
+  int splits = wgrad16_w8_budget() / tiles;
   if (splits > chunks / 8) splits = chunks / 8;
   return splits < 1 ? 1 : splits;
 }
 static bool wgrad16_w8_shape_ok(int M, int C, int K, int KH, int KW) {
   const int Kred = KH * KW * C, tiles = (K >> 8) * (Kred >> 8), chunks = cdiv(M, WGRAD_W8_BP);
-  if ((K & 255) || (C & 255) || KH * KW > 16 || K > 2048 || tiles > 256 || chunks < 16 || (int64_t)M * K >= (1ll << 31)) return false;
+  if ((K & 255) || (C & 255) || KH * KW > 16 || K > 2048 || tiles > wgrad16_w8_budget() || chunks < 16 || (int64_t)M * K >= (1ll << 31))
+    return false;
   // 1x1 layers are HBM-bound: every pixel split costs a K x Kred fp32 slab written and re-read, and this kernel needs 256 / tiles of
   // them to fill the chip - it pays there only when a split still covers >= 16 chunks (measured: 256 -> 512 stride 2 at M = 134 400
   // 424 -> 493 TF, the M = 33 600 / 8 400 layers 10-20 % slower)
@@ -1955,7 +1966,7 @@ int utv2_conv2d_wgrad_bf16(const void* x, int x_dtype, const void* dy, int dy_dt
       (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_w8, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       attr_done = true;
     }
-    hipLaunchKernelGGL(conv_wgrad_bf16_w8, dim3(256), dim3(512), smem, stream, a);
+    hipLaunchKernelGGL(conv_wgrad_bf16_w8, dim3(wgrad16_w8_budget()), dim3(512), smem, stream, a);
     int rb = cdiv((int64_t)n / 4, 256);
     if (rb > 8192) rb = 8192;
     hipLaunchKernelGGL(reduce_slabs16_f32, dim3(rb), dim3(256), 0, stream, (const float*)ws, dw, n, a.splits, accumulate, rowscale,

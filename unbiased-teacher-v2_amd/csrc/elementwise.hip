@@ -539,7 +539,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(GnSegs sg, const T* __restri
                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, const float* __restrict__ s12,
                                                   T* __restrict__ dx, int C, int G, int relu, const float* __restrict__ AB,
-                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int param_blocks) {
+                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int param_blocks,
+                                                  float* __restrict__ colpart) {
   if ((int)blockIdx.x < param_blocks) gn_bwd_param(AB, dgamma, dbeta, sg.nseg, C, blockIdx.x);
   int seg, r0, r1;
   gn_locate(sg, blockIdx.x, seg, r0, r1);
@@ -553,10 +554,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(GnSegs sg, const T* __restri
   const bool remask = relu && beta != nullptr;
   f32x4 be = {0.f, 0.f, 0.f, 0.f};
   if (remask) be = ((const f32x4*)beta)[c4];
-  for (int row = r0 + rl; row < r1; row += RL) {
-    const size_t i = (size_t)row * C4 + c4;
-    f32x4 gg = ld4(dy, i);
-    const f32x4 xx = ld4(x, i);
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};   // colpart: column sums of the rows this thread writes
+  auto apply = [&](f32x4 gg, const f32x4 xx, size_t i) {
     if (remask) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) gg[e] = ((xx[e] - m) * r * ga[e] + be[e]) > 0.f ? gg[e] : 0.f;
@@ -572,6 +571,40 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(GnSegs sg, const T* __restri
       o[e] = r * (gg[e] * ga[e] - (s2 + xh * s1) * inv_cnt);
     }
     st4(dx, i, o);
+    if (colpart) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) csum[e] += (float)(T)o[e];   // the value as stored (rounded to T)
+    }
+  };
+  // 8 independent loads in flight per thread: inside the step this kernel shares the chip with the weight-gradient stream and gets a
+  // fraction of the CUs, so the bandwidth one CU sustains decides its time (324 us per launch in the step against ~100 alone)
+  int row = r0 + rl;
+  for (; row + 3 * RL < r1; row += 4 * RL) {
+    f32x4 gv[4], xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t i = (size_t)(row + u * RL) * C4 + c4;
+      gv[u] = ld4(dy, i);
+      xv[u] = ld4(x, i);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) apply(gv[u], xv[u], (size_t)(row + u * RL) * C4 + c4);
+  }
+  for (; row < r1; row += RL) {
+    const size_t i = (size_t)row * C4 + c4;
+    apply(ld4(dy, i), ld4(x, i), i);
+  }
+  if (colpart) {   // colpart[chunk][c] = column sums of this chunk of dx, row lanes combined in a fixed order
+    __shared__ float cred[256 * 4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cred[threadIdx.x * 4 + e] = csum[e];
+    __syncthreads();
+    if (rl == 0 && (int)blockIdx.x < sg.chunk0[sg.nseg]) {
+      for (int k = 1; k < RL; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) csum[e] += cred[(k * C4 + c4) * 4 + e];
+      *(f32x4*)(colpart + (size_t)blockIdx.x * C + c4 * 4) = csum;
+    }
   }
 }
 
@@ -607,7 +640,7 @@ static void gn_fwd_launch(const GnSegs& sg, int chunks, int nseg, const void* x,
 template <typename T>
 static void gn_bwd_launch(const GnSegs& sg, int chunks, int nseg, const void* dy, const void* y, const void* x, const float* mean,
                           const float* rstd, const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta,
-                          float* ws, int C, int G, int relu, hipStream_t stream) {
+                          float* ws, int C, int G, int relu, float* colpart, hipStream_t stream) {
   float* part = ws;
   float* AB = ws + (size_t)chunks * C * 2;
   float* s12 = AB + (size_t)nseg * C * 2;
@@ -616,7 +649,7 @@ static void gn_bwd_launch(const GnSegs& sg, int chunks, int nseg, const void* dy
   hipLaunchKernelGGL(gn_bwd_reduce, dim3(nseg), dim3(256), 2 * C * sizeof(float), stream, sg, (const float*)part, gamma, AB, s12, C, G);
   const int pb = cdiv(C, 64);   // workgroups that also run gn_bwd_param (a workgroup past the last chunk finds no rows)
   hipLaunchKernelGGL(gn_bwd_apply<T>, dim3(chunks > pb ? chunks : pb), dim3(256), 0, stream, sg, (const T*)dy, (const T*)y, (const T*)x, mean,
-                     rstd, gamma, beta, (const float*)s12, (T*)dx, C, G, relu, (const float*)AB, dgamma, dbeta, pb);
+                     rstd, gamma, beta, (const float*)s12, (T*)dx, C, G, relu, (const float*)AB, dgamma, dbeta, pb, colpart);
 }
 
 extern "C" {
@@ -790,16 +823,33 @@ int utv2_groupnorm_relu_seg_fwd(const void* x, const float* gamma, const float* 
 
 // dx written (`dtype`, like dy / y / x); dgamma/dbeta (fp32) accumulated (+=).  The ReLU mask comes from y, or - when
 // beta is given - is recomputed from x (y may then be null).
-int utv2_groupnorm_relu_seg_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
-                                const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, float* ws,
-                                int nseg, const int* seg_rows_host, int C, int G, int relu, int dtype, hipStream_t stream) {
+int64_t utv2_groupnorm_seg_chunks(int nseg, const int* seg_rows_host) {
+  int64_t chunks = 0;
+  for (int s = 0; s < nseg; ++s) chunks += (seg_rows_host[s] + GN_ROWS - 1) / GN_ROWS;
+  return chunks;
+}
+
+// colsum_part (optional, fp32 [utv2_groupnorm_seg_chunks()][C]): per-chunk column sums of dx as stored - the partial sums of the bias
+// gradient of the convolution that produced x (its dY is this dx), for free while dx is in registers.
+int utv2_groupnorm_relu_seg_bwd_colsum(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
+                                       const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, float* ws,
+                                       int nseg, const int* seg_rows_host, int C, int G, int relu, int dtype, float* colsum_part,
+                                       hipStream_t stream) {
   if (!dy || !x || !dx || !ws || !gn_check(nseg, C, G) || (dtype != UTV2_F32 && dtype != UTV2_BF16) || (relu && !y && !beta))
     return UTV2_EARG;
   GnSegs sg;
   const int chunks = gn_fill(sg, nseg, seg_rows_host);
-  if (dtype == UTV2_BF16) gn_bwd_launch<__bf16>(sg, chunks, nseg, dy, y, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, ws, C, G, relu, stream);
-  else gn_bwd_launch<float>(sg, chunks, nseg, dy, y, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, ws, C, G, relu, stream);
+  if (dtype == UTV2_BF16)
+    gn_bwd_launch<__bf16>(sg, chunks, nseg, dy, y, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, ws, C, G, relu, colsum_part, stream);
+  else gn_bwd_launch<float>(sg, chunks, nseg, dy, y, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, ws, C, G, relu, colsum_part, stream);
   return utv2_launch_status();
+}
+
+int utv2_groupnorm_relu_seg_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
+                                const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, float* ws,
+                                int nseg, const int* seg_rows_host, int C, int G, int relu, int dtype, hipStream_t stream) {
+  return utv2_groupnorm_relu_seg_bwd_colsum(dy, y, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, ws, nseg, seg_rows_host, C, G, relu, dtype,
+                                            nullptr, stream);
 }
 
 // Dense [N][HW][C] convenience forms (one segment per image).

@@ -53,7 +53,7 @@ def _parse_header(path):
 
 
 _SIGS = _parse_header(HEADER_PATH)
-_PLAIN = {"utv2_aug_resize_workspace_bytes", "utv2_topk_rows_workspace_bytes", "utv2_groupnorm_seg_workspace_floats", "utv2_conv2d_wgrad_bf16_splits", "utv2_conv2d_wgrad_bf16_workspace_floats", "utv2_conv2d_bf16_supported", "utv2_conv2d_wgrad_splits", "utv2_conv2d_wgrad_workspace_floats", "utv2_groupnorm_workspace_floats",
+_PLAIN = {"utv2_aug_resize_workspace_bytes", "utv2_topk_rows_workspace_bytes", "utv2_groupnorm_seg_workspace_floats", "utv2_groupnorm_seg_chunks", "utv2_conv2d_wgrad_bf16_splits", "utv2_conv2d_wgrad_bf16_workspace_floats", "utv2_conv2d_bf16_supported", "utv2_conv2d_wgrad_splits", "utv2_conv2d_wgrad_workspace_floats", "utv2_groupnorm_workspace_floats",
           "utv2_nms_mpad", "utv2_nms_workspace_bytes"}  # return a value, not a status
 
 
@@ -872,15 +872,19 @@ def groupnorm_relu_seg_fwd(x2d, seg_rows, gamma, beta, G=32, eps=1e-5, relu=True
     return y, mean, rstd
 
 
-def groupnorm_relu_seg_bwd(dy, y, x2d, seg_rows, mean, rstd, gamma, dgamma, dbeta, G=32, relu=True, beta=None):
+def groupnorm_relu_seg_bwd(dy, y, x2d, seg_rows, mean, rstd, gamma, dgamma, dbeta, G=32, relu=True, beta=None, want_colsum=False):
+    """-> dx, or (dx, colsum_part [chunks, C] fp32: per-chunk column sums of dx as stored) with want_colsum"""
     rows, C = x2d.shape
     S = len(seg_rows)
     dx = torch.empty_like(x2d)
     sr = _iarr(seg_rows)
     ws = workspace(load().utv2_groupnorm_seg_workspace_floats(S, ctypes.cast(sr, c_p), C), x2d.device, "gn")
-    call("utv2_groupnorm_relu_seg_bwd", _p(dy), _p(y), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx), _p(dgamma), _p(dbeta),
-         _p(ws), S, ctypes.cast(sr, c_p), C, G, int(relu), _same_dt(dy, y, x2d), _stream())
-    return dx
+    part = None
+    if want_colsum:
+        part = torch.empty((load().utv2_groupnorm_seg_chunks(S, ctypes.cast(sr, c_p)), C), dtype=torch.float32, device=x2d.device)
+    call("utv2_groupnorm_relu_seg_bwd_colsum", _p(dy), _p(y), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx), _p(dgamma), _p(dbeta),
+         _p(ws), S, ctypes.cast(sr, c_p), C, G, int(relu), _same_dt(dy, y, x2d), _p(part), _stream())
+    return (dx, part) if want_colsum else dx
 
 
 # ---- two-crop data path: Pillow-exact image arithmetic on uint8 [H][W][3] device tensors (csrc/augment.hip) ----------------------------

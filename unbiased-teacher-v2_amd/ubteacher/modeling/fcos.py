@@ -273,7 +273,7 @@ class FCOSHead:
                 pg = "%s.%s_tower.%d" % (prefix, name, 3 * i + 1)
                 ga = store.new((C,), "nodecay", lambda t: t.fill_(1.0)).export(pg + ".weight")
                 be = store.new((C,), "nodecay", lambda t: t.zero_()).export(pg + ".bias")
-                layers.append((conv, ops.GroupNormReLU(ga, be, 32, 1e-5, True)))
+                layers.append(ops.pair_conv_gn(conv, ops.GroupNormReLU(ga, be, 32, 1e-5, True)))
             self.towers[name] = layers
         nc = self.num_classes
         prior = fc.PRIOR_PROB

@@ -212,6 +212,7 @@ class Conv:
         self.colscale = colscale  # (Handle scalar, ncols): Scale layer on the first ncols output channels
         self.out_fp32 = out_fp32  # AMP: keep this layer's output fp32 (loss-side head outputs, RoIAlign inputs)
         self.premask_input = False  # set by the model builder: the input is a fused bottleneck's ReLU output (see premask_on)
+        self.bias_by_gn = False     # set by pair_conv_gn(): the GroupNorm that consumes this conv's output produces its bias gradient
         self._wt = None
         self._wt_version = -1
 
@@ -250,6 +251,13 @@ class Conv:
     def use_bf16_wgrad(self):
         return (PRECISION[0] == "bf16" and self.cin % 8 == 0 and self.cout % 8 == 0 and self.k * self.k <= 16
                 and self.kred == self.k * self.k * self.cin)
+
+    def bias_grad_from_gn(self):
+        """the bias gradient = column sums of this conv's dY, and dY is the dx the following GroupNorm's backward writes: its last pass
+        sums the columns while it has them in registers (utv2_groupnorm_relu_seg_bwd_colsum) instead of a separate pass over dY next
+        to the weight-gradient kernel"""
+        return self.bias_by_gn and self.bias is not None and self.trainable and self.use_bf16_wgrad() and self.use_bf16_dgrad() \
+            and os.environ.get("UTV2_GN_BIAS_GRAD", "1") != "0"
 
     def use_bf16_dgrad(self):
         return PRECISION[0] == "bf16" and self.cout % 8 == 0
@@ -359,7 +367,7 @@ class _ConvFn(torch.autograd.Function):
             if layer.use_bf16_wgrad():
                 _wgrad_launch(lambda: hip.conv2d_wgrad_bf16(
                     x, g, layer.w.g, hip.rowinfo_ml(meta.N, meta.level_hw, layer.pad, layer.k, x.device), layer.cin, layer.k, layer.k,
-                    accumulate=True, db=layer.bias.g if layer.bias is not None else None, rowscale=wsc), x, g)
+                    accumulate=True, db=layer.bias.g if (layer.bias is not None and not layer.bias_grad_from_gn()) else None, rowscale=wsc), x, g)
                 bias_done = True
             else:
                 _wgrad_launch(lambda: hip.conv2d_ml_wgrad(x, g, layer.w.g, meta.level_hw, meta.N, layer.k, layer.pad, accumulate=True), x, g)
@@ -398,7 +406,7 @@ class _ConvFn(torch.autograd.Function):
                 ri = hip.rowinfo_nhwc(n_, h_, w_, g4.shape[1], g4.shape[2], layer.stride, layer.pad, layer.k, layer.k, x.device)
                 _wgrad_launch(lambda: hip.conv2d_wgrad_bf16(
                     x4, g4.reshape(-1, layer.cout), layer.w.g, ri, layer.cin, layer.k, layer.k, accumulate=True,
-                    db=layer.bias.g if layer.bias is not None else None, rowscale=wsc), x4, g4)
+                    db=layer.bias.g if (layer.bias is not None and not layer.bias_grad_from_gn()) else None, rowscale=wsc), x4, g4)
                 bias_done = True
             else:
                 _wgrad_launch(lambda: hip.conv2d_wgrad(x4, g4, layer.w.g, layer.stride, layer.pad, layer.k, layer.k, accumulate=True), x4, g4)
@@ -500,9 +508,18 @@ def bottleneck(block, x):
     return block.conv3(out, residual=sc)
 
 
+def pair_conv_gn(conv, gn):
+    """declare that `gn` normalises exactly the output of `conv` (conv -> GN -> ReLU, fcos.py:263-264): the GroupNorm's backward then
+    also produces the conv's bias gradient (Conv.bias_grad_from_gn)"""
+    conv.bias_by_gn = True
+    gn.bias_conv = conv
+    return conv, gn
+
+
 class GroupNormReLU:
     def __init__(self, gamma, beta, groups=32, eps=1e-5, relu=True):
         self.gamma, self.beta, self.groups, self.eps, self.relu = gamma, beta, groups, eps, relu
+        self.bias_conv = None   # see pair_conv_gn
 
     def __call__(self, x, meta=None):
         if torch.is_grad_enabled():
@@ -535,13 +552,21 @@ class _GNFn(torch.autograd.Function):
         layer, meta = ctx.layer, ctx.meta
         x, y, mean, rstd = ctx.saved_tensors
         dy = dy.contiguous()
+        conv = layer.bias_conv
+        cs = conv is not None and conv.bias_grad_from_gn() and x.dtype == torch.bfloat16
         if meta is None:
             N, H, W, C = x.shape
             dx = hip.groupnorm_relu_seg_bwd(dy.view(-1, C), y.view(-1, C), x.view(-1, C), [H * W] * N, mean, rstd, layer.gamma.t,
-                                            layer.gamma.g, layer.beta.g, layer.groups, layer.relu, beta=layer.beta.t).view(x.shape)
+                                            layer.gamma.g, layer.beta.g, layer.groups, layer.relu, beta=layer.beta.t, want_colsum=cs)
         else:
             dx = hip.groupnorm_relu_seg_bwd(dy, y, x, meta.seg_rows, mean, rstd, layer.gamma.t, layer.gamma.g, layer.beta.g,
-                                            layer.groups, layer.relu, beta=layer.beta.t)
+                                            layer.groups, layer.relu, beta=layer.beta.t, want_colsum=cs)
+        if cs:
+            dx, part = dx
+            # the few-hundred-row reduction of the per-chunk sums is nobody's dependency before the optimizer: weight-gradient stream
+            _wgrad_launch(lambda: hip.colsum(part, conv.bias.g, accumulate=True), part)
+        if meta is None:
+            dx = dx.view(x.shape)
         if GRAD_SYNC[0] is not None:
             GRAD_SYNC[0].on_backward_done(_sync_handles(layer))
         return dx, None, None, None
