@@ -41,3 +41,49 @@ def test_ml_conv_fwd_dgrad_wgrad(k, C, K):
     dw = torch.zeros_like(w2)
     hip.conv2d_ml_wgrad(big, dy, dw, level_hw, N, k, (k - 1) // 2, accumulate=True)
     assert relerr(dw.cpu(), wr.grad.permute(0, 2, 3, 1).reshape(K, -1)) < 2e-4
+
+
+def test_padded_dgrad_of_an_80_channel_head_conv():
+    """A multi-level 3x3 conv with 80 output channels and an fp32 output (the FCOS prediction convs, fcos.py:283-307) under AMP: its
+    backward pads the gradient to 96 bf16 channels (utv2_pad_cols_bf16) and runs the LDS-DMA kernel on a zero-padded weight image
+    (Conv.dgrad_cout) - the same dx, to one bf16 rounding of the accumulation-order difference, as the generic kernel on the fp32
+    gradient; the image from the batched flip launch equals the per-layer one padded; weight / bias gradients are untouched."""
+    from ubteacher import hip, ops
+    from ubteacher.params import ParamStore
+    g = torch.Generator().manual_seed(3)
+    N, C, K = 2, 256, 80
+    level_hw = [(20, 24), (10, 12), (5, 6)]
+    meta = ops.LevelMeta(N, level_hw)
+    try:
+        ops.set_precision("bf16")
+        store = ParamStore()
+        w = store.new((K, 9 * C), "decay", lambda t: t.normal_(0.0, 0.05))
+        b = store.new((K,), "decay", lambda t: t.normal_(0.0, 0.1))
+        conv = ops.Conv(w, C, K, 3, 1, 1, bias=b, out_fp32=True)
+        store.finalize("cuda")
+        assert conv.dgrad_cout() == 96
+        x = (torch.randn(meta.P, C, generator=g) * 0.5).to(torch.bfloat16).cuda().requires_grad_(True)
+        dy = torch.randn(meta.P, K, generator=g).cuda()
+        dxs, imgs = [], []
+        for _ in range(2):      # first backward: per-layer image (registers the layer); second: the batched launch
+            x.grad = None
+            store.grad.zero_()
+            y = conv(x, meta=meta)
+            assert y.dtype == torch.float32
+            y.backward(dy)
+            torch.cuda.synchronize()
+            dxs.append(x.grad.clone())
+            imgs.append(conv.wt16(None).clone())
+            ops.bump_version()
+        assert torch.equal(dxs[0], dxs[1]) and torch.equal(imgs[0], imgs[1])
+        img = imgs[0].view(C, 9, 96)
+        plain = hip.weight_flip_transpose_bf16(w.t, K, 3, 3, C).view(C, 9, K)
+        assert torch.equal(img[:, :, :K], plain) and float(img[:, :, K:].abs().max()) == 0.0
+        ref = hip.conv2d_ml_fwd_bf16(dy, plain.reshape(C, -1).contiguous(), level_hw, N, k=3, pad=1, out_dtype=torch.bfloat16)
+        err = (dxs[0].float() - ref.float()).abs().max().item()
+        assert err <= 2 ** -7 * ref.float().abs().max().item(), err
+        assert float(w.g.abs().sum()) > 0 and float(b.g.abs().sum()) > 0
+        # the bias gradient is summed next to the wgrad's dY staging, from the operands as the MFMA sees them (bf16-rounded)
+        assert relerr(b.g.cpu(), dy.to(torch.bfloat16).float().sum(0).cpu()) < 1e-4
+    finally:
+        ops.set_precision("fp32")
