@@ -553,7 +553,7 @@ class _GNFn(torch.autograd.Function):
         x, y, mean, rstd = ctx.saved_tensors
         dy = dy.contiguous()
         conv = layer.bias_conv
-        cs = conv is not None and conv.bias_grad_from_gn() and x.dtype == torch.bfloat16
+        cs = conv is not None and conv.bias_grad_from_gn()   # the SAME predicate makes the conv's backward skip its own bias sum
         if meta is None:
             N, H, W, C = x.shape
             dx = hip.groupnorm_relu_seg_bwd(dy.view(-1, C), y.view(-1, C), x.view(-1, C), [H * W] * N, mean, rstd, layer.gamma.t,
