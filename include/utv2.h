@@ -128,6 +128,10 @@ int utv2_preprocess_image(const void* src, int is_u8, float* dst, int H, int W, 
 /* same, as bf16 at pixel offset (3,3) of one [Hp+6][Wp+8][4] slot of the zero-bordered bf16 stem input */
 int utv2_preprocess_image_bf16pad(const void* src, int is_u8, void* dst16, int H, int W, int Hp, int Wp,
                                   const float* mean3_host, const float* std3_host, utv2_stream_t stream);
+/* the whole batch in one launch: src_host = host array of N <= 32 device pointers ([3][H_i][W_i] images, all uint8 or all fp32),
+ * dst16 = the N slots bf16 [N][Hp+6][Wp+8][4] */
+int utv2_preprocess_images_bf16pad(const void* const* src_host, int is_u8, void* dst16, const int* H_host, const int* W_host, int N,
+                                   int Hp, int Wp, const float* mean3_host, const float* std3_host, utv2_stream_t stream);
 /* D2 FrozenBatchNorm2d.forward: scale = w*rsqrt(var+eps), shift = b - mean*scale, all layers at once */
 int utv2_frozenbn_fold(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift,
                        int n, float eps, utv2_stream_t stream);

@@ -255,6 +255,35 @@ __global__ __launch_bounds__(256) void preprocess_chw_to_nhwc4_bf16pad(const T* 
   }
 }
 
+// the same for a whole batch in ONE launch (blockIdx.y = image): a training step preprocesses 12 + 4 images and each launch, with its
+// gap, sat at the very start of the step's critical path
+#define PRE_MAX_IMGS 32
+struct PreBatch {
+  const void* src[PRE_MAX_IMGS];
+  int H[PRE_MAX_IMGS], W[PRE_MAX_IMGS];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void preprocess_batch_bf16pad(PreBatch b, __bf16* __restrict__ dst, int Hp, int Wp, float m0, float m1,
+                                                              float m2, float s0, float s1, float s2) {
+  const int n = blockIdx.y, H = b.H[n], W = b.W[n];
+  const T* __restrict__ src = (const T*)b.src[n];
+  __bf16* out = dst + (size_t)n * (Hp + 6) * (Wp + 8) * 4;
+  const size_t total = (size_t)Hp * Wp;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int h = (int)(i / Wp), w = (int)(i % Wp);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (h < H && w < W) {
+      const size_t o = (size_t)h * W + w, hw = (size_t)H * W;
+      v[0] = ((float)src[o] - m0) / s0;
+      v[1] = ((float)src[hw + o] - m1) / s1;
+      v[2] = ((float)src[2 * hw + o] - m2) / s2;
+    }
+    st4(out, (size_t)(h + 3) * (Wp + 8) + (w + 3), v);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // FrozenBatchNorm fold for every BN layer at once (D2 FrozenBatchNorm2d.forward [D2-recall]):
 //   scale = w * rsqrt(var + eps);  shift = b - mean * scale
@@ -787,6 +816,28 @@ int utv2_preprocess_image_bf16pad(const void* src, int is_u8, void* dst16, int H
   else
     hipLaunchKernelGGL((preprocess_chw_to_nhwc4_bf16pad<float>), dim3(g), dim3(256), 0, stream, (const float*)src, (__bf16*)dst16,
                        H, W, Hp, Wp, m0, m1, m2, s0, s1, s2);
+  return utv2_launch_status();
+}
+
+// N <= 32 images (device pointers in src_host, sizes in H_host / W_host) into the N slots of dst16 = bf16 [N][Hp+6][Wp+8][4]
+int utv2_preprocess_images_bf16pad(const void* const* src_host, int is_u8, void* dst16, const int* H_host, const int* W_host, int N,
+                                   int Hp, int Wp, const float* mean3_host, const float* std3_host, hipStream_t stream) {
+  if (!src_host || !dst16 || !H_host || !W_host || !mean3_host || !std3_host || N < 1 || N > PRE_MAX_IMGS) return UTV2_EARG;
+  PreBatch b;
+  for (int i = 0; i < PRE_MAX_IMGS; ++i) {
+    b.src[i] = i < N ? src_host[i] : nullptr;
+    b.H[i] = i < N ? H_host[i] : 0;
+    b.W[i] = i < N ? W_host[i] : 0;
+    if (i < N && (!src_host[i] || H_host[i] > Hp || W_host[i] > Wp || H_host[i] < 0 || W_host[i] < 0)) return UTV2_EARG;
+  }
+  const float m0 = mean3_host[0], m1 = mean3_host[1], m2 = mean3_host[2];
+  const float s0 = std3_host[0], s1 = std3_host[1], s2 = std3_host[2];
+  const int g = grid_for((size_t)Hp * Wp, 256, 1 << 12);
+  if (is_u8)
+    hipLaunchKernelGGL((preprocess_batch_bf16pad<unsigned char>), dim3(g, N), dim3(256), 0, stream, b, (__bf16*)dst16, Hp, Wp, m0, m1, m2, s0,
+                       s1, s2);
+  else
+    hipLaunchKernelGGL((preprocess_batch_bf16pad<float>), dim3(g, N), dim3(256), 0, stream, b, (__bf16*)dst16, Hp, Wp, m0, m1, m2, s0, s1, s2);
   return utv2_launch_status();
 }
 

@@ -291,10 +291,19 @@ def preprocess_images(images, mean, std, size_divisibility, bf16_stem=False):
                 _stem_in_cache.clear()
             out = torch.zeros((len(images), Hm + 6, Wm + 8, 4), dtype=torch.bfloat16, device=dev)
             _stem_in_cache[key] = out
-        for i, im in enumerate(images):
-            assert im.is_contiguous() and im.dtype in (torch.uint8, torch.float32)
-            call("utv2_preprocess_image_bf16pad", _p(im), int(im.dtype == torch.uint8), c_p(out[i].data_ptr()), sizes[i][0],
-                 sizes[i][1], Hm, Wm, ctypes.cast(m, c_p), ctypes.cast(s, c_p), _stream())
+        n = len(images)
+        dt = images[0].dtype
+        if n <= 32 and all(im.dtype == dt for im in images):      # the whole batch in one launch
+            for im in images:
+                assert im.is_cuda and im.is_contiguous() and im.dtype in (torch.uint8, torch.float32)
+            ptrs = (ctypes.c_void_p * n)(*[im.data_ptr() for im in images])
+            call("utv2_preprocess_images_bf16pad", ctypes.cast(ptrs, c_p), int(dt == torch.uint8), _p(out), ctypes.cast(_iarr([a for a, _ in sizes]), c_p),
+                 ctypes.cast(_iarr([b for _, b in sizes]), c_p), n, Hm, Wm, ctypes.cast(m, c_p), ctypes.cast(s, c_p), _stream())
+        else:
+            for i, im in enumerate(images):
+                assert im.is_contiguous() and im.dtype in (torch.uint8, torch.float32)
+                call("utv2_preprocess_image_bf16pad", _p(im), int(im.dtype == torch.uint8), c_p(out[i].data_ptr()), sizes[i][0],
+                     sizes[i][1], Hm, Wm, ctypes.cast(m, c_p), ctypes.cast(s, c_p), _stream())
         out.canvas = (Hm, Wm)
         return out, sizes
     out = torch.empty((len(images), Hm, Wm, 4), dtype=torch.float32, device=dev)
