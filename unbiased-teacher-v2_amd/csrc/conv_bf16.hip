@@ -1277,7 +1277,9 @@ int utv2_weight_flip_transpose_bf16_batched(const float* arena, const float* sca
                                             hipStream_t stream) {
   if (!arena || !bank || !table || nlayers < 1) return UTV2_EARG;
   static_assert(sizeof(FlipDesc) == 48, "table record layout is part of the ABI");
-  hipLaunchKernelGGL(weight_flip_transpose_bf16_batched_kernel, dim3(128, nlayers), dim3(256), 0, stream, arena, scales, (__bf16*)bank,
+  // blocks of a layer stride over its 32 x 32 tiles: 512 per layer keep the one big layer of a model (the box head's 1024 x 12544 fc1:
+  // 12544 tiles; 239 us per step at 128 blocks) from serialising on a few CUs, the surplus blocks of small layers exit at once
+  hipLaunchKernelGGL(weight_flip_transpose_bf16_batched_kernel, dim3(512, nlayers), dim3(256), 0, stream, arena, scales, (__bf16*)bank,
                      (const FlipDesc*)table);
   return utv2_launch_status();
 }
