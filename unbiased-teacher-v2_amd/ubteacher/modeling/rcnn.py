@@ -208,6 +208,10 @@ class PseudoLabRPN:
         bp.export(prefix + ".rpn_head.objectness_logits.bias", lambda t: t[0:A])
         bp.export(prefix + ".rpn_head.anchor_deltas.bias", lambda t: t[A:5 * A])
         self.pred = ops.Conv(wp, C, RPN_CH, 1, 1, 0, bias=bp, out_fp32=True)
+        # the 3x3 conv's ReLU output has one consumer, the prediction conv: its dgrad epilogue applies the mask (ops.premask_on) instead of
+        # a pass over the [all levels x images, 256] gradient at the top of the 3x3 conv's backward (450 us per step)
+        self.pred.premask_input = True
+        self.conv.grad_premasked = True
         self.batch_size_per_image = r.BATCH_SIZE_PER_IMAGE
         self.positive_fraction = r.POSITIVE_FRACTION
         self.iou_thresholds = list(r.IOU_THRESHOLDS)

@@ -213,6 +213,8 @@ class Conv:
         self.out_fp32 = out_fp32  # AMP: keep this layer's output fp32 (loss-side head outputs, RoIAlign inputs)
         self.premask_input = False  # set by the model builder: the input is a fused bottleneck's ReLU output (see premask_on)
         self.bias_by_gn = False     # set by pair_conv_gn(): the GroupNorm that consumes this conv's output produces its bias gradient
+        self.grad_premasked = False  # set by the model builder: every consumer of this conv's ReLU output has premask_input, i.e. applies
+        #                              the mask (output > 0) in its own dgrad epilogue - no mask pass at the top of this conv's backward
         self._wt = None
         self._wt_version = -1
 
@@ -342,16 +344,17 @@ class _ConvFn(torch.autograd.Function):
         # only elementwise backward pass left is the ReLU mask (none at all for the ReLU-less shortcut convs)
         fold = sc is not None and d16 and layer.use_bf16_wgrad() and layer.bias is None
         wsc = sc if fold else None
+        relu = layer.relu and not (layer.grad_premasked and premask_on())   # premasked: dy arrives with the ReLU mask applied
         if fold:
-            g = hip.relu_bwd_scale(dy, y, None) if layer.relu else dy
+            g = hip.relu_bwd_scale(dy, y, None) if relu else dy
             gres = g if ctx.has_res else None
         elif ctx.has_res:
-            gm = hip.relu_bwd_scale(dy, y if layer.relu else None, None) if layer.relu else dy
+            gm = hip.relu_bwd_scale(dy, y if relu else None, None) if relu else dy
             gres = gm
             g = hip.relu_bwd_scale(gm, None, sc) if sc is not None else gm
         else:
-            if layer.relu or sc is not None:
-                g = hip.relu_bwd_scale(dy, y if layer.relu else None, sc)
+            if relu or sc is not None:
+                g = hip.relu_bwd_scale(dy, y if relu else None, sc)
             else:
                 g = dy
         dx = None
