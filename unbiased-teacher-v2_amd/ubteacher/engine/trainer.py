@@ -280,6 +280,7 @@ class _TrainerBase:
         ops.wgrad_side_stream(True)      # weight gradients on a side stream, next to the dgrad chain (ops._wgrad_launch)
         try:
             losses.backward()
+            ops.FanIn.check()            # a gradient handed from one producer to another's epilogue must have been picked up
         finally:
             ops.wgrad_side_stream(False)
             ops.join_wgrad_stream()      # the optimizer step (and whatever reads the gradient arena) follows on the main stream

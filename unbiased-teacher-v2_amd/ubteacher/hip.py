@@ -561,12 +561,17 @@ def roi_align_bwd(dfeats, scales, min_level, rois, roi_batch, roi_valid, dy):
          ctypes.cast(S, c_p), _p(rois), _p(roi_batch), _p(roi_valid), R, C, PH, PW, _p(dy), _dt(dy), _stream())
 
 
-def roi_align_bwd_tiled(shapes, out_dtype, scales, min_level, rois, roi_valid, dy, rois_per_image):
-    """deterministic gather form: returns the per-level gradient maps (every element written by the kernel)"""
+def roi_align_bwd_tiled(shapes, out_dtype, scales, min_level, rois, roi_valid, dy, rois_per_image, outs=None):
+    """deterministic gather form: returns the per-level gradient maps (every element written by the kernel); outs: preallocated
+    contiguous destinations of these shapes / dtype (e.g. the levels' row ranges of one level-first buffer)"""
     R, PH, PW, C = dy.shape
     N = shapes[0][0]
     assert R == N * rois_per_image
-    dfeats = [torch.empty(s, dtype=out_dtype, device=dy.device) for s in shapes]
+    if outs is None:
+        dfeats = [torch.empty(s, dtype=out_dtype, device=dy.device) for s in shapes]
+    else:
+        dfeats = list(outs)
+        assert all(tuple(d.shape) == tuple(s) and d.dtype == out_dtype and d.is_contiguous() for d, s in zip(dfeats, shapes))
     fp = _ptr_array(dfeats)
     H = _iarr([s[1] for s in shapes]); W = _iarr([s[2] for s in shapes]); S = _farr(scales)
     call("utv2_roi_align_bwd_tiled", len(dfeats), min_level, ctypes.cast(fp, c_p), ctypes.cast(H, c_p), ctypes.cast(W, c_p),

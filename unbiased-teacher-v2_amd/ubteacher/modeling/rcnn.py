@@ -621,11 +621,12 @@ class StandardROIHeadsPseudoLab:
                                                 torch.zeros((), device=pb.device))
         return out
 
-    def _box_features(self, feats, boxes, valid):
+    def _box_features(self, feats, boxes, valid, fanin=None):
         N, P = valid.shape
         rois = boxes.reshape(-1, 4).contiguous()
         batch = torch.arange(N, device=rois.device, dtype=torch.int32)[:, None].expand(N, P).reshape(-1).contiguous()
-        x = ops.roi_align(feats, self.scales, self.min_level, rois, batch, valid.reshape(-1).contiguous(), self.res, rois_per_image=P)
+        x = ops.roi_align(feats, self.scales, self.min_level, rois, batch, valid.reshape(-1).contiguous(), self.res, rois_per_image=P,
+                          fanin=fanin)
         x = x.view(x.shape[0], 1, 1, -1)
         for fc in self.fcs:
             x = fc(x)
@@ -637,7 +638,7 @@ class StandardROIHeadsPseudoLab:
             assert targets is not None
             sampled = self.label_and_sample_proposals(proposals, targets, branch)
             self._last_sampled = sampled
-            x = self._box_features(feats, sampled["proposal_boxes"], sampled["valid"])
+            x = self._box_features(feats, sampled["proposal_boxes"], sampled["valid"], fanin=features.get("_fanin"))
             predictions = self.box_predictor(x)
             return sampled, self.box_predictor.losses(predictions, sampled, branch)
         x = self._box_features(feats, proposals["boxes"], proposals["valid"])
@@ -659,7 +660,7 @@ class StandardROIHeadsPseudoLab:
         self._last_sampled = s_u
         boxes = torch.cat((s_l["proposal_boxes"], s_u["proposal_boxes"]), dim=0)
         valid = torch.cat((s_l["valid"], s_u["valid"]), dim=0)
-        scores, deltas, std = self.box_predictor(self._box_features(feats, boxes, valid))
+        scores, deltas, std = self.box_predictor(self._box_features(feats, boxes, valid, fanin=features.get("_fanin")))
         r = nl * boxes.shape[1]
         l_l = self.box_predictor.losses((scores[:r], deltas[:r], std[:r]), s_l, "supervised")
         l_u = self.box_predictor.losses((scores[r:], deltas[r:], std[r:]), s_u, "unsup_data_train")
@@ -701,6 +702,18 @@ class TwoStagePseudoLabGeneralizedRCNN(ArenaModel):
                 gt.f["pred_boxes_std"] = st.to(self.device)
         return gt
 
+    def _fan_in(self, features):
+        """one gradient hand-over per training pass: RoIAlign's level gradients go into the RPN conv's dgrad epilogue (ops.FanIn)"""
+        lf = features.get("_levelfirst")
+        rpn, roi = self.proposal_generator, self.roi_heads
+        if (lf is None or not ops.fanin_enabled() or not torch.is_grad_enabled() or not lf[0].requires_grad
+                or roi.in_features != rpn.in_features[:len(roi.in_features)]
+                or lf[1].level_hw != [tuple(features[f].shape[1:3]) for f in rpn.in_features]):
+            return
+        fan = ops.FanIn(lf[1], len(roi.in_features))
+        lf[0]._utv2_fanin = fan
+        features["_fanin"] = fan
+
     def padded_canvas(self, batched_inputs):
         """(H, W) the batch is zero-padded to by preprocess_image (ImageList.from_tensors with size_divisibility)."""
         d = self.backbone.size_divisibility
@@ -722,6 +735,7 @@ class TwoStagePseudoLabGeneralizedRCNN(ArenaModel):
         gt_l = self._gt(labeled_inputs)
         self.folder.fold()
         features = self.backbone(x4)
+        self._fan_in(features)
         rctx, proposals, rpn_l = self.proposal_generator.forward_joint_begin(image_sizes, features, len(labeled_inputs), gt_l)
         return dict(features=features, rpn=rctx, proposals=proposals, rpn_l=rpn_l, gt_l=gt_l, n_labeled=len(labeled_inputs))
 
@@ -745,6 +759,7 @@ class TwoStagePseudoLabGeneralizedRCNN(ArenaModel):
         self.folder.fold()
         features = self.backbone(x4)
         if branch in ("supervised", "unsup_data_train"):
+            self._fan_in(features)
             proposals_rpn, proposal_losses = self.proposal_generator(image_sizes, features, gt)
             _, detector_losses = self.roi_heads(features, proposals_rpn, gt, branch=branch)
             losses = {}

@@ -268,7 +268,7 @@ class Conv:
         """x: NHWC tensor, or a level-first [P, C] matrix with `meta` (one launch for all levels; k x k
         'same' convs only).  colscale_handle: a Handle, or one Handle per level when `meta` is given."""
         if torch.is_grad_enabled() and self.trainable:
-            return _ConvFn.apply(x, residual, hook(x.device), self, (out,), colscale_handle, meta)
+            return _ConvFn.apply(x, residual, hook(x.device), self, (out, getattr(x, "_utv2_fanin", None)), colscale_handle, meta)
         return self._forward(x, residual, out, colscale_handle, meta)
 
     def _forward(self, x, residual, out, cs, meta):
@@ -318,6 +318,7 @@ class _ConvFn(torch.autograd.Function):
             GRAD_SYNC[0].on_forward(_sync_handles(layer, cs))
         ctx.save_for_backward(x, y if (layer.relu or cs is not None) else None)
         ctx.xshape = tuple(x.shape)
+        ctx.fanin = out_holder[1] if len(out_holder) > 1 else None   # FanIn: another consumer's gradient of x, added in this dgrad's epilogue
         return y
 
     @staticmethod
@@ -363,8 +364,11 @@ class _ConvFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 if d16:
                     gp = g if layer.dgrad_cout() == layer.cout else hip.pad_cols_bf16(g, layer.dgrad_cout())
+                    other = ctx.fanin.take() if ctx.fanin is not None else None
+                    if other is not None and (other.dtype != x.dtype or tuple(other.shape) != tuple(x.shape)):
+                        raise RuntimeError("FanIn: stored gradient does not match the conv input")
                     dx = hip.conv2d_ml_fwd_bf16(gp, layer.wt16(wsc), meta.level_hw, meta.N, k=layer.k, pad=layer.k - 1 - layer.pad,
-                                                out_dtype=x.dtype)
+                                                residual=other, out_dtype=x.dtype)
                 else:
                     dx = hip.conv2d_ml_dgrad(g, layer.wt(), meta.level_hw, meta.N, layer.k, layer.pad)
             if layer.use_bf16_wgrad():
@@ -676,6 +680,54 @@ def fcos_loc_terms(box, labels, reg_targets, bvars, args):
 
 # ------------------------------------------------------------------------------------------------
 # Faster-RCNN helpers
+class FanIn:
+    """Gradient fan-in of the FPN levels of a Faster-RCNN pass without the add kernels: the levels feed the RPN head (as rows of the
+    level-first buffer) and RoIAlign (as level tensors), and autograd would sum the two gradients of every level with one elementwise
+    pass each (3 tensor passes over [N, H, W, 256]; 0.67 ms per step).  The ROI heads were built last, so their backward runs first:
+    RoIAlign's backward writes its level gradients into the row ranges of ONE level-first buffer kept here and reports no gradient;
+    the RPN 3x3 conv's dgrad - whose output is the gradient of that same level-first buffer - adds it in its epilogue (`residual`).
+    Either side falls back to the plain path when the other has not / has already run; check() after backward() fails loudly if a stored
+    gradient was never picked up."""
+    _live = []
+
+    def __init__(self, meta, levels):
+        self.meta, self.levels = meta, levels     # levels: how many leading levels of meta RoIAlign reads
+        self.buf = None
+        self.closed = False                       # the consumer (RPN dgrad) has run
+        if len(FanIn._live) >= 64:                # forwards whose backward never ran through a trainer (tests): keep the list short
+            del FanIn._live[:32]
+        FanIn._live.append(self)
+
+    def store(self, C, dtype, device):
+        """-> (level-first buffer, its per-level destination views), or None when the consumer already ran"""
+        if self.closed or self.buf is not None:
+            return None
+        m = self.meta
+        buf = torch.empty((m.P, C), dtype=dtype, device=device)
+        outs = [m.alias_view(buf, l) for l in range(self.levels)]
+        r0 = m.rows[self.levels][0] if self.levels < len(m.rows) else m.P
+        if r0 < m.P:
+            buf[r0:].zero_()                      # levels RoIAlign does not read (p6)
+        self.buf = buf
+        return buf, outs
+
+    def take(self):
+        self.closed = True
+        b, self.buf = self.buf, None
+        return b
+
+    @staticmethod
+    def check():
+        live, FanIn._live = FanIn._live, []
+        for f in live:
+            if f.buf is not None:
+                raise RuntimeError("FanIn: a RoIAlign gradient was stored but the RPN dgrad that adds it never ran")
+
+
+def fanin_enabled():
+    return PRECISION[0] == "bf16" and os.environ.get("UTV2_FANIN", "1") != "0"
+
+
 class _AssembleFn(torch.autograd.Function):
     """Makes the level-first buffer the convs wrote into (`big`) visible to autograd as one tensor:
     output aliases `big`; backward hands each level its row range of the incoming gradient."""
@@ -698,9 +750,10 @@ def assemble(big, rows, levels):
 class _RoIAlignFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rois, roi_batch, roi_valid, cfg, *feats):
-        scales, min_level, out_size, per_image = cfg
+        scales, min_level, out_size, per_image, fanin = cfg
         ctx.cfg = cfg[:3]
         ctx.per_image = per_image
+        ctx.fanin = fanin
         ctx.shapes = [tuple(f.shape) for f in feats]
         ctx.fdtype = feats[0].dtype
         ctx.save_for_backward(rois, roi_batch, roi_valid)
@@ -714,6 +767,13 @@ class _RoIAlignFn(torch.autograd.Function):
         R = rois.shape[0]
         if ctx.per_image > 0 and R == N * ctx.per_image and C <= 256 and out_size <= 7:
             # ROIs laid out image by image (the ROI heads' [N, P] slots): deterministic gather, final dtype written directly
+            st = ctx.fanin.store(C, ctx.fdtype, dy.device) if (ctx.fanin is not None and ctx.fdtype == torch.bfloat16) else None
+            if st is not None and [tuple(o.shape) for o in st[1]] == [tuple(x) for x in ctx.shapes]:
+                # the RPN conv's dgrad adds these level gradients in its epilogue (FanIn): no gradient reported from here
+                hip.roi_align_bwd_tiled(ctx.shapes, ctx.fdtype, scales, min_level, rois, roi_valid, dy.contiguous(), ctx.per_image, outs=st[1])
+                return (None, None, None, None) + (None,) * len(ctx.shapes)
+            if st is not None:
+                ctx.fanin.take(); ctx.fanin.closed = False
             dfeats = hip.roi_align_bwd_tiled(ctx.shapes, ctx.fdtype, scales, min_level, rois, roi_valid, dy.contiguous(), ctx.per_image)
             return (None, None, None, None) + tuple(dfeats)
         dfeats = [torch.zeros(s, dtype=torch.float32, device=dy.device) for s in ctx.shapes]   # fp32: atomics
@@ -723,11 +783,11 @@ class _RoIAlignFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(dfeats)
 
 
-def roi_align(feats, scales, min_level, rois, roi_batch, roi_valid, out_size, rois_per_image=0):
+def roi_align(feats, scales, min_level, rois, roi_batch, roi_valid, out_size, rois_per_image=0, fanin=None):
     """rois_per_image > 0: the caller guarantees roi_batch == repeat_interleave(arange(N), rois_per_image) (the backward then runs as
-    the deterministic tiled gather instead of the atomic scatter)"""
+    the deterministic tiled gather instead of the atomic scatter); fanin: see FanIn"""
     if torch.is_grad_enabled() and any(f.requires_grad for f in feats):
-        return _RoIAlignFn.apply(rois, roi_batch, roi_valid, (tuple(scales), min_level, out_size, int(rois_per_image)), *feats)
+        return _RoIAlignFn.apply(rois, roi_batch, roi_valid, (tuple(scales), min_level, out_size, int(rois_per_image), fanin), *feats)
     return hip.roi_align_fwd(list(feats), scales, min_level, rois, roi_batch, roi_valid, out_size)
 
 
