@@ -153,6 +153,8 @@ int utv2_groupnorm_relu_seg_bwd_colsum(const void* dy, const void* y, const void
                                        const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, float* ws,
                                        int nseg, const int* seg_rows_host, int C, int G, int relu, int dtype, float* colsum_part,
                                        utv2_stream_t stream);
+/* db[c] (+)= sum_b partial[b][c], partial fp32 [nb][K] (the colsum_part above; fixed summation order) */
+int utv2_colsum_partials(const float* partial, float* db, int nb, int K, int accumulate, utv2_stream_t stream);
 int64_t utv2_groupnorm_workspace_floats(int N, int HW, int C);
 int utv2_groupnorm_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                             float* ws, int N, int HW, int C, int G, float eps, int relu, utv2_stream_t stream);

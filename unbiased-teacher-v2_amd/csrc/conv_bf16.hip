@@ -1935,6 +1935,14 @@ static bool wgrad16_w8_shape_ok(int M, int C, int K, int KH, int KW) {
 int utv2_conv2d_wgrad_bf16_splits(int M, int K, int Kred) { return wgrad16_small_splits(M, K, Kred); }
 
 // large enough for either kernel (which one runs also depends on the element types)
+// db[c] (+)= sum_b partial[b][c] for a [nb][K] matrix of per-block column sums (e.g. utv2_groupnorm_relu_seg_bwd_colsum's): 32 channels x
+// 8 row parts per workgroup, fixed combine order
+int utv2_colsum_partials(const float* partial, float* db, int nb, int K, int accumulate, hipStream_t stream) {
+  if (!partial || !db || nb < 1 || K < 1) return UTV2_EARG;
+  hipLaunchKernelGGL(colsum_final_f32, dim3(cdiv(K, 32)), dim3(256), 0, stream, partial, db, nb, K, accumulate, (const float*)nullptr);
+  return utv2_launch_status();
+}
+
 int64_t utv2_conv2d_wgrad_bf16_workspace_floats(int M, int K, int Kred) {
   int64_t n = (int64_t)wgrad16_small_splits(M, K, Kred) * ((int64_t)K * Kred + K);
   if ((K & 255) == 0 && (Kred & 255) == 0) {

@@ -196,6 +196,13 @@ def conv2d_wgrad(x, dy, dw, stride, pad, kh, kw, accumulate=True):
     return dw
 
 
+def colsum_partials(part, db, accumulate=True):
+    """db (+)= column sums of a small fp32 [nb, K] matrix of per-block partial sums"""
+    nb, K = part.shape
+    call("utv2_colsum_partials", _p(part), _p(db), nb, K, int(accumulate), _stream())
+    return db
+
+
 def colsum(g2d, db, accumulate=True):
     M, C = g2d.shape
     ws = workspace(1024 * C, g2d.device, "colsum")

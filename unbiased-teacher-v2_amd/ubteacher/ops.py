@@ -571,7 +571,7 @@ class _GNFn(torch.autograd.Function):
         if cs:
             dx, part = dx
             # the few-hundred-row reduction of the per-chunk sums is nobody's dependency before the optimizer: weight-gradient stream
-            _wgrad_launch(lambda: hip.colsum(part, conv.bias.g, accumulate=True), part)
+            _wgrad_launch(lambda: hip.colsum_partials(part, conv.bias.g, accumulate=True), part)
         if meta is None:
             dx = dx.view(x.shape)
         if GRAD_SYNC[0] is not None:
