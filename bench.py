@@ -195,26 +195,34 @@ class CallCounter:
         hip.call = counted
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
-    (profiles/r01_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md's HBM section prescribes for 16-byte-per-lane reads on gfx950)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f).get(kernel)
-        return None if t is None else float(t["hbm_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
-        return None
+def pmc_traffic(kernel, model="fcos"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command and THIS model
+    (profiles/rNN_traffic.json for the FCOS step, profiles/rNN_rcnn_traffic.json for the Faster-RCNN step: FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs; FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM section prescribes for
+    16-byte-per-lane reads on gfx950).  The newest round's file wins."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    stem = "traffic.json" if model == "fcos" else "%s_traffic.json" % model
+    for rnd in ("r03", "r02", "r01"):
+        path = os.path.join(here, "%s_%s" % (rnd, stem))
+        if not os.path.exists(path):
+            continue
+        try:
+            with open(path) as f:
+                t = json.load(f).get(kernel)
+            if t is not None:
+                return float(t["hbm_bytes_per_launch"])
+        except (OSError, ValueError, KeyError):
+            pass
+    return None
 
 
 def dispatches_per_step(model):
     """GPU dispatches (kernels + copies) per step, from the committed kernel trace of THIS command
-    (profiles/r02_<model>_4p4_bf16_timeline.txt, tools/rocpd_timeline.py over the last 6 of `bench.py --timed-only` steps)"""
+    (profiles/rNN_<model>_4p4_bf16_timeline.txt, newest round, tools/rocpd_timeline.py over the last 6 of `bench.py --timed-only` steps)"""
     import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_%s_4p4_bf16_timeline.txt" % model)
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    path = next((q for q in (os.path.join(here, "%s_%s_4p4_bf16_timeline.txt" % (r, model)) for r in ("r03", "r02")) if os.path.exists(q)),
+                os.path.join(here, "r02_%s_4p4_bf16_timeline.txt" % model))
     try:
         with open(path) as f:
             m = re.search(r"window [0-9.]+ ms \(([0-9.]+) ms / step\), (\d+) dispatches", f.read())
@@ -225,23 +233,16 @@ def dispatches_per_step(model):
         return None
 
 
-def cpu_baseline_run(label, unlabel, warmup, steps):
-    """The oracle (CPU port of the reference step: its orchestration + restated Detectron2 primitives on stock torch CPU kernels) timed
-    on the host cores: `warmup` + `steps` iterations of the SAME post-burn-in FCOS step on `label` labeled (weak + strong views) +
-    `unlabel` unlabeled 1333x800 images, with the phase split SURVEY 8(d) asks for.  Runs in its own process (see cpu_baseline)."""
-    from oracle import utv2_oracle as O
-    from ubteacher.data.synthetic import make_gt, make_image, strong_view
-    from ubteacher.modeling import build_model
-    from ubteacher.presets import get_config
-    import numpy as np
-    cfg = get_config("fcos", 1, ["MODEL.DEVICE", "cpu", "SEMISUPNET.BURN_UP_STEP", 0])
+def _cpu_threads():
     # stock torch CPU convolutions stop scaling (and can slow down) far below the thread count of a 128-core host
-    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 32)))
+    return max(1, min(os.cpu_count() or 1, 32))
+
+
+def _synthetic_cpu_batch(label, unlabel):
+    """SURVEY 8(d) synthetic inputs on the host: `label` labeled (weak + strong view) and `unlabel` unlabeled 1333x800 uint8 images"""
+    import numpy as np
+    from ubteacher.data.synthetic import make_gt, make_image, strong_view
     rng = np.random.default_rng(0)
-    torch.manual_seed(0)
-    model = build_model(cfg)
-    sd = {k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}
-    del model
     lq, lk, uq, uk = [], [], [], []
     for _ in range(label):
         wk = make_image(rng, 800, 1333).cpu()
@@ -251,34 +252,115 @@ def cpu_baseline_run(label, unlabel, warmup, steps):
     for _ in range(unlabel):
         wk = make_image(rng, 800, 1333).cpu()
         uq.append({"image": strong_view(rng, wk).cpu()}); uk.append({"image": wk})
-    batch = (lq, lk, uq, uk)
+    return lq, lk, uq, uk
+
+
+def cpu_baseline_run(model_kind, label, unlabel, warmup, steps, dump=None):
+    """The oracle (CPU port of the reference step: its orchestration + restated Detectron2 primitives on stock torch CPU kernels) timed
+    on the host cores: `warmup` + `steps` iterations of the SAME post-burn-in step on `label` labeled (weak + strong views) +
+    `unlabel` unlabeled 1333x800 images, with the phase split SURVEY 8(d) asks for.  Runs in its own process (see cpu_baseline).
+    model_kind "fcos": BASELINE configs[1]'s step; "rcnn": configs[0] (Faster-RCNN UTv2, MODEL.DEVICE=cpu, 1 process).
+    The teacher / student heads are rescaled (tests.utv2_testutil: data-driven, with the oracle's forward) so the teacher emits pseudo
+    boxes and the pseudo-label branch does real work.  dump: path of a torch file that receives the initial student / teacher
+    state, the batch, and the record_dict of the FIRST step - the parent process runs the product's f32 step on exactly that and
+    reports the deviation (`parity_fullsize`): the oracle is the checker here, never the thing shipped."""
+    from oracle import utv2_oracle as O
+    from tests.utv2_testutil import rcnn_tune
+    from ubteacher.modeling import build_model
+    from ubteacher.presets import get_config
+    cfg = get_config(model_kind, 1, ["MODEL.DEVICE", "cpu", "SEMISUPNET.BURN_UP_STEP", 0])
+    O.FAST_ROI_ALIGN[0] = True   # same arithmetic, a backward without the per-ROI full-map zero fills (see oracle/utv2_oracle.py)
+    torch.set_num_threads(_cpu_threads())
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    sd = {k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}
+    del model
+    batch = _synthetic_cpu_batch(label, unlabel)
     cores = torch.get_num_threads()
-    student, teacher, bufs = sd, dict(sd), None
-    phases, times = {}, []
+    S = cfg.SEMISUPNET
+    mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1)
+    pstd = torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1)
+    weak = [d["image"] for d in batch[3]]
+    if model_kind == "fcos":
+        # cls_logits rescaled to std 1.5 (as tests.utv2_testutil.tune_state_for_pseudo_labels), the bias placed so that ~40 logits per
+        # weak image clear p = 0.6: both pseudo-label sets (criteria "cls" and "cls_n_loc", threshold 0.5) are non-empty
+        q = "proposal_generator.fcos_head.cls_logits"
+        g = torch.Generator().manual_seed(0)
+        student = dict(sd)
+        student[q + ".weight"] = torch.randn(sd[q + ".weight"].shape, generator=g) * 0.01
+        student[q + ".bias"] = torch.zeros_like(sd[q + ".bias"])
+        with torch.no_grad():
+            lg = torch.cat([x.reshape(-1) for x in O.fcos_forward(student, weak, mean, pstd)[0]])
+        scale = 1.5 / max(float(lg.std()), 1e-12)
+        kth = float(torch.topk(lg, 40 * len(weak)).values[-1]) * scale
+        student[q + ".weight"] = student[q + ".weight"] * scale
+        student[q + ".bias"] = torch.full_like(sd[q + ".bias"], 0.405 - kth)
+        teacher = dict(student)
+        teacher["proposal_generator.fcos_head.bbox_pred_std.bias"] = torch.full((4,), -3.0)   # confident teacher boundaries
+        keys = None
+    else:
+        student = rcnn_tune(sd, weak, mean, pstd)
+        # as tune_rcnn_for_pseudo_labels does for the product: class scores wide enough (std 8, no background bias) that the teacher
+        # emits detections above BBOX_THRESHOLD on noise images
+        q = "roi_heads.box_predictor.cls_score"
+        student[q + ".weight"] = student[q + ".weight"] * (8.0 / 2.5)
+        student[q + ".bias"] = torch.zeros_like(student[q + ".bias"])
+        teacher = dict(student)
+        teacher["roi_heads.box_predictor.bbox_pred_std.bias"] = torch.full((4,), -3.0)
+        g = torch.Generator().manual_seed(99)
+        R = 3 * sum(-(-800 // s) * -(-1344 // s) for s in (4, 8, 16, 32, 64))
+
+        def roi_k(nprop, ngt):
+            return torch.rand(nprop + ngt, generator=g)
+        keys = dict(rpn_sup=torch.rand(2 * label, R, generator=g), rpn_unsup=torch.rand(unlabel, R, generator=g),
+                    roi_sup=[roi_k] * (2 * label), roi_unsup=[roi_k] * unlabel)
+    init = (student, teacher)
+    bufs = None
+    phases, times, first, pseudo_n = {}, [], None, None
     for it in range(warmup + steps):
         ph = {}
         t0 = time.perf_counter()
-        _, student, teacher, _, bufs, _ = O.fcos_semisup_step(O.FCOSCfg(), student, teacher, batch, keep_rate=0.9999, bufs=bufs,
-                                                              phase_times=ph)
+        if model_kind == "fcos":
+            rec, student, teacher, _, bufs, pseudo = O.fcos_semisup_step(
+                O.FCOSCfg(), student, teacher, batch, keep_rate=S.EMA_KEEP_RATE, lam_u=S.UNSUP_LOSS_WEIGHT, lam_r=S.UNSUP_REG_LOSS_WEIGHT,
+                bufs=bufs, mean=mean, pix_std=pstd, phase_times=ph)
+            npseudo = {"cls": sum(len(p["boxes"]) for p in pseudo[0]), "reg": sum(len(p["boxes"]) for p in pseudo[1])}
+        else:
+            rec, student, teacher, _, pseudo = O.rcnn_semisup_step(
+                student, teacher, batch, keys, keep_rate=S.EMA_KEEP_RATE, lam_u=S.UNSUP_LOSS_WEIGHT, lam_r=S.UNSUP_REG_LOSS_WEIGHT,
+                thr=S.BBOX_THRESHOLD, lr=1e-12, mean=mean, pix_std=pstd)
+            npseudo = sum(len(p["boxes"]) for p in pseudo)
         dt = time.perf_counter() - t0
+        if it == 0:
+            first, pseudo_n = rec, npseudo
+            if dump:
+                torch.save({"student": init[0], "teacher": init[1], "batch": batch, "record": rec, "pseudo": npseudo,
+                            "keep_rate": S.EMA_KEEP_RATE}, dump)
         if it >= warmup:
             times.append(dt)
             for k, v in ph.items():
                 phases[k] = phases.get(k, 0.0) + v
-    mean = sum(times) / len(times)
-    return {"value": (label + unlabel) / mean, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d warm-up + %d timed steps of %d labeled (weak+strong views) + %d unlabeled 1333x800 images, fp32, reference "
-                      "orchestration + restated Detectron2 primitives on stock torch CPU kernels; %.1f s per step"
-                      % (warmup, steps, label, unlabel, mean),
-            "step_seconds": times, "phase_seconds_per_step": {k: v / len(times) for k, v in phases.items()}}
+    mean_t = sum(times) / len(times)
+    what = ("FCOS R50-FPN UTv2 (configs[1]'s step)" if model_kind == "fcos" else
+            "Faster-RCNN R50-FPN UTv2 (configs[0]: MODEL.DEVICE=cpu, 1 process)")
+    out = {"value": (label + unlabel) / mean_t, "unit": "images/sec", "cores": cores, "kind": "port", "model": model_kind,
+           "sample": "%s: %d warm-up + %d timed steps of %d labeled (weak+strong views) + %d unlabeled 1333x800 images, fp32, reference "
+                     "orchestration + restated Detectron2 primitives on stock torch CPU kernels; %.1f s per step"
+                     % (what, warmup, steps, label, unlabel, mean_t),
+           "step_seconds": times, "first_step_record": first, "pseudo_boxes_first_step": pseudo_n}
+    if phases:
+        out["phase_seconds_per_step"] = {k: v / len(times) for k, v in phases.items()}
+    return out
 
 
-def cpu_baseline(label=1, unlabel=1, warmup=1, steps=2, timeout=600):
+def cpu_baseline(model_kind="fcos", label=2, unlabel=2, warmup=2, steps=5, timeout=900, dump=None):
     """cpu_baseline_run in a child process, BEFORE the GPU phase starts (it cannot disturb the timed region, and a host-side problem
     cannot lose the GPU measurement)."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--label", str(label), "--unlabel", str(unlabel),
-           "--cpu-warmup", str(warmup), "--cpu-steps", str(steps)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--model", model_kind, "--label", str(label),
+           "--unlabel", str(unlabel), "--cpu-warmup", str(warmup), "--cpu-steps", str(steps)]
+    if dump:
+        cmd += ["--cpu-dump", dump]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
@@ -290,6 +372,106 @@ def cpu_baseline(label=1, unlabel=1, warmup=1, steps=2, timeout=600):
         return {"error": repr(e)}
 
 
+def parity_fullsize(dump, device_index):
+    """The product's exact-f32 step on the SAME 1333x800 batch and the SAME initial student / teacher the cpu_baseline child ran its
+    first oracle step on: per-loss relative deviation of the two record_dicts (north-star tolerance 1e-3).  Every 256-tile / ping-pong /
+    multi-round top-k / 1000-candidate NMS path that the 96x128 parity tests cannot reach is exercised here at benchmark resolution."""
+    from ubteacher.d2.structures import Boxes, Instances
+    from ubteacher.engine import UBTeacherTrainer
+    from ubteacher.presets import get_config
+    from ubteacher import ops
+    d = torch.load(dump, weights_only=False)
+    lq, lk, uq, uk = d["batch"]
+    dev = "cuda:%d" % device_index
+
+    def conv(part):
+        out = []
+        for x in part:
+            e = {"image": x["image"].to(dev), "height": int(x["image"].shape[1]), "width": int(x["image"].shape[2])}
+            if "gt" in x:
+                inst = Instances((e["height"], e["width"]))
+                inst.gt_boxes = Boxes(x["gt"]["boxes"].clone().to(dev))
+                inst.gt_classes = x["gt"]["classes"].clone().to(dev)
+                e["instances"] = inst
+            out.append(e)
+        return out
+    batch = tuple(conv(p) for p in (lq, lk, uq, uk))
+
+    class Fixed:
+        def __iter__(self):
+            return self
+
+        def __next__(self):
+            return tuple([dict(x) for x in part] for part in batch)
+    cfg = get_config("fcos", 1, ["SOLVER.IMG_PER_BATCH_LABEL", len(lq), "SOLVER.IMG_PER_BATCH_UNLABEL", len(uq), "SEMISUPNET.BURN_UP_STEP", 0,
+                                 "SOLVER.AMP.ENABLED", False, "MODEL.DEVICE", dev])
+    torch.manual_seed(0)
+    tr = UBTeacherTrainer(cfg, data_loader=Fixed())
+    tr.model.load_state_dict(d["student"]); tr.model_teacher.load_state_dict(d["teacher"])
+    tr.model.store.touch(); tr.model_teacher.store.touch(); ops.bump_version()
+    tr.iter = 1
+    tr.log_period = 10 ** 9
+    tr.run_step_full_semisup()
+    rec = dict(tr.flush_metrics())
+    torch.cuda.synchronize()
+    pc, pr = tr._last_pseudo
+    ref = d["record"]
+    dev_ = {k: abs(rec[k] - v) / max(abs(v), 1e-12) for k, v in ref.items() if k.startswith("loss") and k in rec}
+    out = {"mode": "f32", "images": "%d labeled (weak+strong) + %d unlabeled 1333x800" % (len(lq), len(uq)), "tolerance": 1e-3,
+           "rel_dev": dev_, "max_rel_dev": max(dev_.values()) if dev_ else None,
+           "within_tolerance": bool(dev_) and max(dev_.values()) <= 1e-3,
+           "oracle_losses": {k: ref[k] for k in dev_}, "product_losses": {k: rec[k] for k in dev_},
+           "pseudo_boxes": {"oracle": d["pseudo"], "product": {"cls": int(pc["valid"].sum()), "reg": int(pr["valid"].sum())}},
+           "teacher_better_student_pseudo": {"oracle": ref.get("teacher_better_student_pseudo"), "product": rec.get("teacher_better_student_pseudo")}}
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
+def rcnn_subrecord(args, device_index, timer, steps=10, warmup=3):
+    """images/sec of UBRCNNTeacherTrainer.run_step_full_semisup (BASELINE configs[2] / [4]: Faster-RCNN R50-FPN UTv2, bf16 MFMA conv
+    path) on the same per-GPU batch as the headline, timed by the same rule (barrier-free at world 1: synchronize on both sides);
+    its dominant kernel = the RPN head 3x3 conv over p2-p6 (the same multi-level implicit-GEMM kernel), timed by HIP events."""
+    from ubteacher.engine import UBRCNNTeacherTrainer
+    from ubteacher.presets import get_config
+    cfg = get_config("rcnn", 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label, "SOLVER.IMG_PER_BATCH_UNLABEL", args.unlabel,
+                                 "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", True, "MODEL.DEVICE", "cuda:%d" % device_index])
+    torch.manual_seed(0)
+    tr = UBRCNNTeacherTrainer(cfg)
+    tr.iter = 1
+    tr.log_period = 10 ** 9
+    tr.optimizer.param_groups[0]["lr"] = 1e-12   # see make_trainer: keeps the synthetic problem stationary
+    tune_rcnn_for_pseudo_labels(tr, tr._data_loader.batches[0])
+    for _ in range(warmup):
+        tr.run_step_full_semisup(); tr.iter += 1
+    torch.cuda.synchronize()
+    timer.pairs = []
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.run_step_full_semisup(); tr.iter += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    conv = timer.summary()
+    metrics = tr.flush_metrics()
+    lp = getattr(tr, "_last_pseudo", None)
+    out = {"value": (args.label + args.unlabel) * steps / dt, "unit": "images/sec", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+           "warmup": warmup, "dtype": "bf16",
+           "workload": "Faster-RCNN R50-FPN UTv2 sup1 (the trainer of configs[2] / [4]): %d labeled + %d unlabeled 1333x800 images per GPU, "
+                       "post-burn-in semi-supervised step" % (args.label, args.unlabel),
+           "losses": {k: v for k, v in metrics.items() if k.startswith("loss")},
+           "pseudo_boxes_last_step": None if lp is None else int(lp["valid"].sum())}
+    if conv:
+        out["roofline"] = {"bound": "mfma", "kernel": timer.kernel + " (RPN head 3x3 conv over p2-p6, fwd+dgrad launches)",
+                           "achieved": conv["tflops"], "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": conv["tflops"] / PEAK_BF16_MFMA_TFLOPS, "traffic": pmc_traffic(timer.kernel, "rcnn"),
+                           "algorithmic_bytes": conv["alg_bytes"], "launches": conv["launches"], "avg_us": conv["avg_us"]}
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -299,9 +481,11 @@ def parse_args(argv=None):
     ap.add_argument("--unlabel", type=int, default=4, help="unlabeled images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU port on --label/--unlabel images and print its record")
-    ap.add_argument("--cpu-warmup", type=int, default=1)
-    ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--cpu-images", type=int, default=1, help="labeled and unlabeled images of the CPU baseline sample (SURVEY 8d protocol: 2)")
+    ap.add_argument("--cpu-warmup", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-images", type=int, default=2, help="labeled and unlabeled images of the CPU baseline sample (SURVEY 8d protocol: 2)")
+    ap.add_argument("--cpu-dump", default=None, help="(internal) file that receives the first oracle step's inputs / record_dict")
+    ap.add_argument("--no-rcnn", action="store_true", help="skip the Faster-RCNN sub-records (GPU step of configs[2]/[4], CPU step of configs[0])")
     ap.add_argument("--timed-only", action="store_true", help="only the warmup and the timed steps (profiling runs): no exclusive pass, no host probe")
     ap.add_argument("--no-f32", action="store_true", help="skip the f32 sub-record / the bf16-vs-f32 one-step loss deviation")
     ap.add_argument("--model", choices=["fcos", "rcnn"], default="fcos",
@@ -343,9 +527,17 @@ def worker(args):
     from ubteacher import hip, ops
     hip.load()
     rcnn = args.model == "rcnn"
-    cpu_rec = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not rcnn:   # before any GPU work, in its own process
-        cpu_rec = cpu_baseline(args.cpu_images, args.cpu_images, args.cpu_warmup, args.cpu_steps)
+    cpu_rec = cpu_rcnn = dump = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # before any GPU work, in its own process
+        import tempfile
+        if not rcnn:
+            dump = os.path.join(tempfile.gettempdir(), "utv2_bench_parity_%d.pt" % os.getpid())
+            cpu_rec = cpu_baseline("fcos", args.cpu_images, args.cpu_images, args.cpu_warmup, args.cpu_steps, dump=dump)
+        if rcnn or not args.no_rcnn:
+            # BASELINE configs[0]: Faster-RCNN 2+2, MODEL.DEVICE=cpu, 1 process (a step costs ~2x the FCOS one: fewer repetitions)
+            cpu_rcnn = cpu_baseline("rcnn", 2, 2, 1, 2)
+        if rcnn:
+            cpu_rec = cpu_rcnn
 
     def make_trainer(dtype):
         cfg = get_config(args.model, 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label * world, "SOLVER.IMG_PER_BATCH_UNLABEL",
@@ -495,6 +687,30 @@ def worker(args):
                                                      "classification loss also moves with which borderline detections pass the score threshold, not only with rounding"}}
         del tr32
 
+    parity_full = None
+    if dump is not None and os.path.exists(dump):
+        try:
+            try:
+                del tr
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
+            parity_full = parity_fullsize(dump, device_index)
+        except Exception as e:  # noqa: BLE001  (a failed check is reported, it must not lose the measurement)
+            parity_full = {"error": repr(e)}
+        finally:
+            os.remove(dump)
+
+    rcnn_rec = None
+    if rank == 0 and world == 1 and not rcnn and not args.no_rcnn and not args.timed_only and args.dtype == "bf16":
+        # the Faster-RCNN UTv2 trainer (BASELINE configs[2] / [4]: bf16 MFMA conv path) on the same per-GPU batch, as a sub-record
+        try:
+            torch.cuda.empty_cache()
+            args_r = argparse.Namespace(**vars(args)); args_r.model = "rcnn"
+            rcnn_rec = rcnn_subrecord(args_r, device_index, timer)
+        except Exception as e:  # noqa: BLE001
+            rcnn_rec = {"error": repr(e)}
+
     if rank == 0:
         per_step_images = (args.label + args.unlabel) * world
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
@@ -520,7 +736,7 @@ def worker(args):
             out["roofline"] = {"bound": "mfma", "kernel": timer.kernel + (" (RPN head 3x3 conv over p2-p6, fwd+dgrad launches)" if rcnn else
                                                                          " (FCOS tower 3x3 convs, all fwd+dgrad launches)"),
                                "achieved": conv["tflops"], "peak": peak, "unit": "TFLOP/s",
-                               "frac": conv["tflops"] / peak, "traffic": pmc_traffic(timer.kernel),
+                               "frac": conv["tflops"] / peak, "traffic": pmc_traffic(timer.kernel, args.model),
                                "algorithmic_bytes": conv["alg_bytes"], "algorithmic_GBps": conv["alg_gbps"],
                                "launches": conv["launches"], "avg_us": conv["avg_us"],
                                "time_share": conv["total_ms"] / (1e3 * dt)}
@@ -531,7 +747,7 @@ def worker(args):
                                                         "in the timed region the teacher pass / weight gradients share the CUs with this kernel"}
         if wg:
             out["roofline_wgrad"] = {"bound": "mfma", "kernel": wtimer.kernel, "achieved": wg["tflops"], "peak": peak, "unit": "TFLOP/s",
-                                     "frac": wg["tflops"] / peak, "traffic": pmc_traffic("conv_wgrad_bf16_w8"),
+                                     "frac": wg["tflops"] / peak, "traffic": pmc_traffic("conv_wgrad_bf16_w8", args.model),
                                      "algorithmic_bytes": wg["alg_bytes"], "launches": wg["launches"], "avg_us": wg["avg_us"],
                                      "time_share": wg["total_ms"] / (1e3 * dt)}
             if wg_x:
@@ -541,6 +757,12 @@ def worker(args):
             out["f32"] = f32_rec
         if cpu_rec is not None:
             out["cpu_baseline"] = cpu_rec
+        if parity_full is not None:
+            out["parity_fullsize"] = parity_full
+        if rcnn_rec is not None:
+            out["rcnn"] = rcnn_rec
+        if cpu_rcnn is not None and not rcnn:
+            out["cpu_baseline_rcnn"] = cpu_rcnn
         print(json.dumps(out), flush=True)
 
 
@@ -551,7 +773,7 @@ def main(argv=None):
     N ranks on N distinct GPUs is an error, never a silently smaller measurement."""
     args = parse_args(argv)
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline_run(args.label, args.unlabel, args.cpu_warmup, args.cpu_steps)), flush=True)
+        print(json.dumps(cpu_baseline_run(args.model, args.label, args.unlabel, args.cpu_warmup, args.cpu_steps, dump=args.cpu_dump)), flush=True)
         return
     from ubteacher.engine.launch import launch
     launch(worker, args.gpus, args=(args,))

@@ -858,8 +858,66 @@ def roi_align(feat, rois, scale, out=7):
     return res
 
 
+# bench.py's cpu_baseline leg sets this: the per-sample form above is the pinned restatement (known-answer tests, step goldens) but
+# its autograd backward materialises a full [C,H,W] zero map per ROI and per tap (45 s of a 60 s CPU step at 1333x800) - a cost the
+# reference's CPU path (torchvision's C++ roi_align) does not have.  The separable form below is the same arithmetic regrouped
+# (tests/test_oracle_golden_rcnn.py::test_fast_roi_align_equals_pinned_form), with a backward that touches each ROI's window once.
+FAST_ROI_ALIGN = [False]
+
+
+def _roi_axis_weights(start, bin_sz, g, out, L):
+    """[out, window] weights of one axis: mean over the g samples of a bin of the bilinear taps, torchvision's rules
+    (sample skipped outside [-1, L], clamped at 0, last-pixel clamp); returns (P, first pixel, one past the last pixel)."""
+    v = (start + (torch.arange(out)[:, None] * bin_sz + (torch.arange(g)[None, :] + 0.5) * bin_sz / g).reshape(-1)).float()
+    ok = ((v >= -1.0) & (v <= L)).float()
+    v = v.clamp(min=0)
+    lo = v.floor().long()
+    edge = lo >= L - 1
+    lo = torch.where(edge, torch.full_like(lo, L - 1), lo)
+    hi = torch.where(edge, lo, lo + 1)
+    v = torch.where(edge, lo.to(v.dtype), v)
+    frac = v - lo.to(v.dtype)
+    a, b = int(lo.min()), int(hi.max()) + 1
+    A = torch.zeros(out * g, b - a)
+    rows = torch.arange(out * g)
+    A[rows, lo - a] += (1 - frac) * ok
+    A[rows, hi - a] += frac * ok
+    return A.view(out, g, b - a).sum(1) / g, a, b
+
+
+class _RoiAlignSeparable(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois, scale, out):
+        C, H, W = feat.shape
+        res = feat.new_zeros((rois.shape[0], C, out, out))
+        saved = []
+        for r in range(rois.shape[0]):
+            x1, y1, x2, y2 = [float(v) * scale - 0.5 for v in rois[r]]
+            rw, rh = x2 - x1, y2 - y1
+            gh, gw = int(math.ceil(rh / out)), int(math.ceil(rw / out))
+            if gh <= 0 or gw <= 0:
+                saved.append(None)
+                continue
+            Py, ya, yb = _roi_axis_weights(y1, rh / out, gh, out, H)
+            Px, xa, xb = _roi_axis_weights(x1, rw / out, gw, out, W)
+            res[r] = torch.einsum("oy,cyx,px->cop", Py, feat[:, ya:yb, xa:xb], Px)
+            saved.append((Py, Px, ya, yb, xa, xb))
+        ctx.saved, ctx.shape = saved, feat.shape
+        return res
+
+    @staticmethod
+    def backward(ctx, g):
+        gf = g.new_zeros(ctx.shape)
+        for r, s in enumerate(ctx.saved):
+            if s is not None:
+                Py, Px, ya, yb, xa, xb = s
+                gf[:, ya:yb, xa:xb] += torch.einsum("oy,cop,px->cyx", Py, g[r], Px)
+        return gf, None, None, None
+
+
 def roi_pool(feats, boxes_per_im, out=7):
     """D2 ROIPooler (levels 2..5, canonical 224 @ level 4) [D2-recall]; feats NCHW list p2..p5."""
+    roi_align_ = (lambda f, b, s, o: _RoiAlignSeparable.apply(f, b, s, o)) if FAST_ROI_ALIGN[0] else roi_align
     outs = []
     for n, boxes in enumerate(boxes_per_im):
         area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
@@ -868,7 +926,7 @@ def roi_pool(feats, boxes_per_im, out=7):
         for l in range(4):
             m = torch.nonzero(lv == l).squeeze(1)
             if len(m):
-                o[m] = roi_align(feats[l][n], boxes[m], 1.0 / (4 * 2 ** l), out)
+                o[m] = roi_align_(feats[l][n], boxes[m], 1.0 / (4 * 2 ** l), out)
         outs.append(o)
     return torch.cat(outs) if outs else feats[0].new_zeros((0, feats[0].shape[1], out, out))
 

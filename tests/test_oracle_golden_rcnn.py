@@ -107,3 +107,22 @@ def test_known_answers_d2_primitives():
     a = O.make_anchors([(1, 2)], [16], sizes=(32,))[0]
     assert torch.allclose(a[0], torch.tensor([-22.6274, -11.3137, 22.6274, 11.3137]), atol=1e-3)
     assert torch.allclose(a[3], a[0] + torch.tensor([16.0, 0, 16.0, 0]))
+
+
+def test_fast_roi_align_equals_pinned_form():
+    """bench.py's cpu_baseline leg switches the oracle's RoIAlign to its separable form (same arithmetic regrouped, a backward that
+    touches each ROI's window once): forward and the gradient w.r.t. the feature map equal the pinned per-sample form."""
+    g = torch.Generator().manual_seed(5)
+    feat = torch.randn(6, 23, 31, generator=g)
+    rois = torch.tensor([[3.0, 4.0, 60.0, 50.0], [-20.0, -8.0, 30.0, 200.0], [100.0, 70.0, 124.0, 92.0], [5.0, 5.0, 5.5, 5.2],
+                         [110.0, 80.0, 140.0, 100.0], [0.0, 0.0, 124.0, 92.0], [40.0, 40.0, 40.0, 40.0]])
+    w = torch.randn(len(rois), 6, 7, 7, generator=g)
+    fa = feat.clone().requires_grad_(True)
+    ya = O.roi_align(fa, rois, 0.25)
+    (ya * w).sum().backward()
+    fb = feat.clone().requires_grad_(True)
+    yb = O._RoiAlignSeparable.apply(fb, rois, 0.25, 7)
+    (yb * w).sum().backward()
+    assert torch.allclose(ya, yb, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(fa.grad, fb.grad, rtol=1e-5, atol=1e-5)
+    assert float(ya.abs().sum()) > 0
