@@ -485,6 +485,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--cpu-images", type=int, default=2, help="labeled and unlabeled images of the CPU baseline sample (SURVEY 8d protocol: 2)")
     ap.add_argument("--cpu-dump", default=None, help="(internal) file that receives the first oracle step's inputs / record_dict")
+    ap.add_argument("--dry-nccl", action="store_true",
+                    help="join the world, run the RCCL self-check (one tiny all-reduce per rank, a device-bound barrier, an object "
+                         "all-gather), print {n_gpus, rccl_ranks, ...} on rank 0 and stop: first contact with the backend in seconds")
     ap.add_argument("--no-rcnn", action="store_true", help="skip the Faster-RCNN sub-records (GPU step of configs[2]/[4], CPU step of configs[0])")
     ap.add_argument("--timed-only", action="store_true", help="only the warmup and the timed steps (profiling runs): no exclusive pass, no host probe")
     ap.add_argument("--no-f32", action="store_true", help="skip the f32 sub-record / the bf16-vs-f32 one-step loss deviation")
@@ -511,6 +514,19 @@ def worker(args):
     if world > 1:
         assert dist.is_initialized() and dist.get_world_size() == args.gpus
     device_index = info["device"]
+    from ubteacher.utils import comm
+    rccl = None
+    if dist.is_initialized() and os.environ.get("UTV2_BENCH_LAUNCH_ONLY") != "1":
+        # first contact with the backend, before any model is built: a wrong device binding / IPC mode / missing rank shows here
+        rccl = comm.rccl_selfcheck()
+        comm.barrier()
+        rccl["devices"] = comm.all_gather_object(device_index)
+        assert rccl["ok"] and rccl["ranks"] == world, "RCCL self-check failed: %r" % (rccl,)
+    if args.dry_nccl:
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "rccl_ranks": None if rccl is None else rccl["ranks"], "rccl": rccl,
+                              "ranks": {"world_size": world, "backend": info["backend"], "launcher": _launcher_name(world)}}), flush=True)
+        return
     if os.environ.get("UTV2_BENCH_LAUNCH_ONLY") == "1":   # tests of the launch contract on boxes without GPUs: report the world, stop
         ids = [None] * world
         if world > 1:
@@ -576,7 +592,7 @@ def worker(args):
     def sync():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            comm.barrier()     # device_ids = this rank's device under nccl
             torch.cuda.synchronize()
 
     sync()
@@ -595,9 +611,7 @@ def worker(args):
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        devs = [None] * world
-        dist.all_gather_object(devs, device_index)
-        devices = devs
+        devices = comm.all_gather_object(device_index)
     metrics = tr.flush_metrics()
     lp = getattr(tr, "_last_pseudo", None)
     if lp is None:
@@ -726,7 +740,7 @@ def worker(args):
                        "global_batch": per_step_images, "parallelism": "dp%d" % world,
                        "precision": "AMP (config SOLVER.AMP.ENABLED): bf16 MFMA operands, bf16 activations and activation gradients in HBM, fp32 accumulate / losses / weight gradients / master weights" if args.dtype == "bf16" else "fp32 MFMA, fp32 everywhere"},
             "ranks": {"world_size": world, "backend": info["backend"], "devices": devices,
-                      "launcher": _launcher_name(world)},
+                      "launcher": _launcher_name(world), "rccl_selfcheck": rccl},
             "host": {"ms_per_step_on_96x128_images": host_ms, "enqueue_ms_per_step": 1e3 * t_host / args.steps,
                      "cabi_calls_per_step": calls_per_step, "gpu_dispatches": dispatches_per_step(args.model) if args.dtype == "bf16" else None},
             "losses": {k: v for k, v in metrics.items() if k.startswith("loss") or k.startswith("teacher")},

@@ -154,12 +154,18 @@ def test_weights_path_resolution_and_non_resume_semantics(tmp_path, monkeypatch)
     ck2 = DetectionTSCheckpointer(b, str(src), optimizer=ob, scheduler=sb)
     out = ck2.resume_or_load("", resume=True)
     assert out["iteration"] == 76 and ob.lr == 0.01 and sb.last_iter == 77 and float(ob.mom[0]) == 5.0
-    # a reference-produced checkpoint carries a torch.optim state_dict: refused with a clear message when resuming
+    # a reference-produced checkpoint carries a torch.optim state_dict: resuming takes weights / scheduler / iteration and warns that the
+    # momentum restarts (strict_optimizer = True refuses with a clear message instead)
     data = torch.load(weights)
     data["optimizer"] = {"state": {0: {"momentum_buffer": torch.zeros(3)}}, "param_groups": [{"lr": 0.01}]}
     torch.save(data, weights)
+    ck2.strict_optimizer = True
     with pytest.raises(ValueError, match="ArenaSGD"):
         ck2.resume_or_load("", resume=True)
+    ck2.strict_optimizer = False
+    sb.last_iter = 0
+    out = ck2.resume_or_load("", resume=True)
+    assert out["iteration"] == 76 and sb.last_iter == 77 and ck2.last_optimizer_skipped
     ck.resume_or_load(weights, resume=False)                                                # ... and simply skipped otherwise
     # model-zoo cache mapping
     monkeypatch.setenv("FVCORE_CACHE", str(tmp_path / "cache"))

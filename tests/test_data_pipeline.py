@@ -119,3 +119,17 @@ def test_annotation_bbox_mode_is_honoured():
     assert to_xyxy_abs({"bbox": [1, 2, 3, 4], "bbox_mode": Mode()}) == [1.0, 2.0, 4.0, 6.0]
     with pytest.raises(ValueError):
         to_xyxy_abs({"bbox": [0, 0, 1, 1], "bbox_mode": 4})   # XYWHA_ABS (rotated): not supported
+
+
+def test_bbox_mode_accepts_numpy_integers_and_names():
+    """dataset dicts built from numpy / pandas carry numpy integer bbox_mode values: any Integral is a BoxMode value"""
+    import numpy as np
+    from ubteacher.data.dataset_mapper import to_xyxy_abs
+    for mode in (1, np.int64(1), np.int32(1), "XYWH_ABS", "BoxMode.XYWH_ABS"):
+        assert to_xyxy_abs({"bbox": [10, 20, 5, 6], "bbox_mode": mode}) == [10.0, 20.0, 15.0, 26.0]
+    for mode in (0, np.int64(0), "XYXY_ABS"):
+        assert to_xyxy_abs({"bbox": [10, 20, 15, 26], "bbox_mode": mode}) == [10.0, 20.0, 15.0, 26.0]
+    assert to_xyxy_abs({"bbox": [1, 2, 3, 4]}) == [1.0, 2.0, 3.0, 4.0]      # no field: XYXY_ABS (with one warning)
+    import pytest
+    with pytest.raises(ValueError):
+        to_xyxy_abs({"bbox": [1, 2, 3, 4], "bbox_mode": np.int64(7)})

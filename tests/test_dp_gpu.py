@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, overlap, q):
+def _worker(rank, world, port, overlap, q, kind="fcos"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "unbiased-teacher-v2_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -33,15 +33,26 @@ def _worker(rank, world, port, overlap, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from tests.utv2_testutil import FixedLoader, make_batch, small_fcos_cfg
-    from ubteacher.engine import UBTeacherTrainer
-    cfg = small_fcos_cfg(bl=2 * world, bu=2 * world)   # global batch; each rank takes 2 + 2
+    from ubteacher.engine import UBRCNNTeacherTrainer, UBTeacherTrainer
+    import bench
     torch.manual_seed(0)                               # identical initial weights on every rank
     prod, _ = make_batch(50 + rank, 2, 2, 96, 128, "cuda")   # different data per rank
-    tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+    if kind == "fcos":
+        cfg = small_fcos_cfg(bl=2 * world, bu=2 * world)   # global batch; each rank takes 2 + 2
+        tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+        bench.tune_for_pseudo_labels(tr, prod)   # make the teacher emit pseudo boxes (same recipe as bench.py, on the device)
+    else:
+        # the trainer of BASELINE configs[0] / [2] / [4] (reference engine/trainer.py:631-635 wraps THAT student in DDP)
+        from ubteacher.presets import get_config
+        cfg = get_config("rcnn", 1, ["SOLVER.IMG_PER_BATCH_LABEL", 2 * world, "SOLVER.IMG_PER_BATCH_UNLABEL", 2 * world,
+                                     "SEMISUPNET.BURN_UP_STEP", 0, "MODEL.DEVICE", "cuda"])
+        tr = UBRCNNTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+        bench.tune_rcnn_for_pseudo_labels(tr, prod)
+        # per-rank sampling keys (each rank samples its own anchors / proposals, as each DDP rank draws its own randperm)
+        g = torch.Generator().manual_seed(500 + rank)
+        tr.model.proposal_generator.sample_keys = lambda n, m, device: torch.rand(n, m, generator=g).to(device)
+        tr.model.roi_heads.sample_keys = lambda n, m, device: torch.rand(n, m, generator=g).to(device)
     assert tr.world_size == world
-    # make the teacher emit pseudo boxes (same recipe as bench.py, on the device)
-    import bench
-    bench.tune_for_pseudo_labels(tr, prod)
     dist.broadcast(tr.model.flat_state(), 0)
     dist.broadcast(tr.model_teacher.flat_state(), 0)
     tr.iter = 1
@@ -68,12 +79,12 @@ def _worker(rank, world, port, overlap, q):
     dist.destroy_process_group()
 
 
-def _run(overlap):
+def _run(overlap, kind="fcos"):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, overlap, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, overlap, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -95,3 +106,42 @@ def test_two_rank_step_overlapped_allreduce():
     launched, nb = a[0][2]
     assert nb >= 4 and launched >= nb - 1, (launched, nb)                    # the hooks fired during backward
     assert b[0][2] is None
+
+
+def test_two_rank_rcnn_step_overlapped_allreduce():
+    """the same for UBRCNNTeacherTrainer (three of the five BASELINE configs are data-parallel Faster-RCNN): RPN + ROI-head losses on
+    per-rank samples, RoIAlign backward as a deterministic gather, the bucketed all-reduce driven by the real backward"""
+    a = _run(True, "rcnn")
+    b = _run(False, "rcnn")
+    assert a[0][0] == a[1][0] and a[0][1] == a[1][1]
+    assert a[0][0] == b[0][0]
+    assert a[0][0][1] and a[0][1][1]
+    launched, nb = a[0][2]
+    assert nb >= 4 and launched >= nb - 1, (launched, nb)
+    assert b[0][2] is None
+
+
+def _bench(env, args, timeout=900):
+    import subprocess
+    e = dict(os.environ, **env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_rccl_world_of_one_rank_dry_run_and_step():
+    """The real backend (nccl == RCCL) on the one GPU this box has: a process group of ONE rank, through every call the N-rank
+    bench makes - init bound to the device, the tiny self-check all-reduce, barrier(device_ids), the object all-gather, the replica
+    broadcast, and the gradient buckets all-reduced asynchronously from the weight-gradient side stream during backward."""
+    import json
+    r = _bench({"UTV2_DP_SINGLE_RANK": "1"}, ["--gpus", "1", "--dry-nccl"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rep["rccl_ranks"] == 1 and rep["ranks"]["backend"] == "nccl" and rep["rccl"]["ok"]
+    r = _bench({"UTV2_DP_SINGLE_RANK": "1", "UTV2_GRAD_SYNC_DEBUG": "1"},
+               ["--gpus", "1", "--steps", "2", "--warmup", "1", "--label", "1", "--unlabel", "1", "--no-cpu-baseline", "--no-f32",
+                "--no-rcnn", "--timed-only"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rep["ranks"]["backend"] == "nccl" and rep["ranks"]["rccl_selfcheck"]["ok"] and rep["value"] > 0
+    assert all(v == v for v in rep["losses"].values())   # finite (no NaN)

@@ -79,3 +79,17 @@ def test_bench_under_torchrun_joins_that_world_and_checks_its_size():
     tr[-1] = str(port)
     r = _run_bench({}, ["--gpus", "4"], launcher=tr)
     assert r.returncode != 0 and "world of 2 ranks" in (r.stderr + r.stdout)
+
+
+def test_bench_dry_nccl_selfcheck_two_ranks():
+    """`bench.py --gpus 2 --dry-nccl`: each rank joins the world, one tiny all-reduce + a barrier + an object all-gather, rank 0 prints
+    how many ranks answered (gloo here; the same code path is first contact with RCCL on a GPU node)"""
+    env = dict(os.environ, UTV2_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "UTV2_BENCH_LAUNCH_ONLY"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-nccl"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rep["n_gpus"] == 2 and rep["rccl_ranks"] == 2 and rep["rccl"]["ok"] and rep["rccl"]["sum"] == 1.0
+    assert sorted(rep["rccl"]["devices"]) == [0, 1]

@@ -101,6 +101,9 @@ class DetectionTSCheckpointer:
         self.save_dir = save_dir
         self.optimizer = optimizer
         self.scheduler = scheduler
+        # resuming from a checkpoint whose optimizer entry is a torch.optim state (every reference-produced teacher/student checkpoint):
+        # False = warn and resume weights / scheduler / iteration with zero momentum; True = refuse
+        self.strict_optimizer = False
 
     def _last_file(self):
         return os.path.join(self.save_dir, "last_checkpoint")
@@ -136,11 +139,19 @@ class DetectionTSCheckpointer:
         want = ("optimizer", "scheduler") if checkpointables is None else tuple(checkpointables)
         if "optimizer" in want and "optimizer" in ck and self.optimizer is not None:
             osd = ck["optimizer"]
-            if not (isinstance(osd, dict) and "momentum_buffer" in osd):
+            if isinstance(osd, dict) and "momentum_buffer" in osd:
+                self.optimizer.load_state_dict(osd)
+            elif self.strict_optimizer:
                 raise ValueError("checkpoint {!r}: the optimizer state is not an ArenaSGD state (a torch.optim state_dict of the reference "
                                  "cannot be mapped onto the flat momentum arena); load it without resuming to take the weights only"
                                  .format(path))
-            self.optimizer.load_state_dict(osd)
+            else:
+                # a reference (torch.optim.SGD) checkpoint: weights, scheduler and iteration resume, the momentum restarts from zero
+                import logging
+                logging.getLogger(__name__).warning(
+                    "checkpoint %r holds a torch.optim optimizer state that cannot be mapped onto the flat momentum arena: resuming "
+                    "model / scheduler / iteration WITHOUT momentum (set checkpointer.strict_optimizer = True to make this an error)", path)
+                self.last_optimizer_skipped = True
         if "scheduler" in want and "scheduler" in ck and self.scheduler is not None:
             self.scheduler.load_state_dict(ck["scheduler"])
         return ck

@@ -7,6 +7,7 @@ Host work: JPEG decode (Pillow) when the dict has `file_name`, the random decisi
 csrc/augment.hip, bit-exact to the Pillow arithmetic of the reference pipeline (tests/test_aug_gpu.py, tests/test_data_pipeline_gpu.py).
 Reference quirk kept: the strong augmentation is applied to the image in cfg.INPUT.FORMAT order (BGR) labelled "RGB"
 (dataset_mapper.py:139), so the grey weights / hue act on swapped channels."""
+import numbers
 import copy
 
 import numpy as np
@@ -44,15 +45,26 @@ def check_image_size(dataset_dict, image):
 
 # Detectron2 BoxMode values [D2-recall]: the enum members themselves are ints; dataset dicts may carry the int or the name
 XYXY_ABS, XYWH_ABS = 0, 1
+_WARNED_NO_MODE = False
 _BOX_MODES = {0: XYXY_ABS, 1: XYWH_ABS, "XYXY_ABS": XYXY_ABS, "XYWH_ABS": XYWH_ABS, "BoxMode.XYXY_ABS": XYXY_ABS, "BoxMode.XYWH_ABS": XYWH_ABS}
 
 
 def to_xyxy_abs(anno):
     """the annotation's box as XYXY_ABS (Detectron2 transform_instance_annotations converts through BoxMode before the transforms;
-    load_coco_json - the format of the reference's builtin COCO sets - stores XYWH_ABS).  No `bbox_mode` = XYXY_ABS."""
+    load_coco_json - the format of the reference's builtin COCO sets - stores XYWH_ABS).  Detectron2 requires `bbox_mode`; a dict
+    without it is read as XYXY_ABS with ONE warning (a COCO-style XYWH dict that lost the field would otherwise be silently wrong)."""
+    if "bbox_mode" not in anno:
+        global _WARNED_NO_MODE
+        if not _WARNED_NO_MODE:
+            _WARNED_NO_MODE = True
+            import logging
+            logging.getLogger(__name__).warning("annotation without `bbox_mode`: assuming XYXY_ABS (Detectron2 requires the field)")
     mode = anno.get("bbox_mode", XYXY_ABS)
     mode = getattr(mode, "value", mode)                      # an enum member
-    key = mode if isinstance(mode, int) else str(mode)
+    if isinstance(mode, numbers.Integral) and not isinstance(mode, bool):
+        key = int(mode)                                      # python int, numpy.int32 / int64 (dicts built from numpy / pandas)
+    else:
+        key = str(mode)
     if key not in _BOX_MODES:
         raise ValueError("unsupported bbox_mode {!r} (XYXY_ABS and XYWH_ABS are)".format(anno.get("bbox_mode")))
     x0, y0, a, b = (float(v) for v in anno["bbox"])

@@ -44,14 +44,22 @@ def _bind_and_join(rank, local_rank, world_size, dist_url, expect_world):
     single_dev = os.environ.get("UTV2_BENCH_SINGLE_DEVICE") == "1"  # dry runs of the N > 1 path on a box with one GPU
     dev = 0 if single_dev else local_rank
     if torch.cuda.is_available():
-        if not single_dev and torch.cuda.device_count() < expect_world:
-            raise RuntimeError("launch: %d ranks requested but only %d GPUs are visible" % (expect_world, torch.cuda.device_count()))
+        nvis = torch.cuda.device_count()
+        if not single_dev and nvis == 1 and local_rank > 0:
+            dev = 0   # started with one visible device per process (CUDA/HIP_VISIBLE_DEVICES set by the external launcher)
+        elif not single_dev and nvis <= dev:
+            # the device THIS rank binds must exist; the world size is not a device count (ranks may see one device each)
+            raise RuntimeError("launch: rank %d (local rank %d) binds device %d but only %d GPUs are visible"
+                               % (rank, local_rank, dev, nvis))
         torch.cuda.set_device(dev)
-    if world_size > 1:
-        dist.init_process_group(_backend(), init_method=dist_url, rank=rank, world_size=world_size)
+    if world_size > 1 or os.environ.get("UTV2_DP_SINGLE_RANK") == "1":
+        kw = {}
+        if torch.cuda.is_available() and _backend() == "nccl":
+            kw["device_id"] = torch.device("cuda", dev)   # RCCL communicator bound to this rank's device at init (eager, no lazy guess)
+        dist.init_process_group(_backend(), init_method=dist_url, rank=rank, world_size=world_size, **kw)
         if dist.get_world_size() != expect_world:
             raise RuntimeError("launch: joined a world of %d ranks, %d were requested" % (dist.get_world_size(), expect_world))
-    _INFO.update(world_size=world_size, rank=rank, local_rank=local_rank, backend=_backend() if world_size > 1 else None,
+    _INFO.update(world_size=world_size, rank=rank, local_rank=local_rank, backend=_backend() if dist.is_initialized() else None,
                  device=dev)
 
 
@@ -87,10 +95,27 @@ def launch(main_func, num_gpus_per_machine, num_machines=1, machine_rank=0, dist
             if dist.is_initialized():
                 dist.destroy_process_group()
     if n == 1:
-        _bind_and_join(0, 0, 1, None, 1)
-        return main_func(*args)
-    if dist_url in (None, "auto"):
-        dist_url = "tcp://127.0.0.1:%d" % find_free_port()
+        # UTV2_DP_SINGLE_RANK=1: a process group of ONE rank (the real backend on a one-GPU box; see trainer.data_parallel)
+        url = "tcp://127.0.0.1:%d" % find_free_port() if os.environ.get("UTV2_DP_SINGLE_RANK") == "1" else None
+        _bind_and_join(0, 0, 1, url, 1)
+        try:
+            return main_func(*args)
+        finally:
+            if dist.is_initialized():
+                dist.destroy_process_group()
     import torch.multiprocessing as mp
-    mp.spawn(_worker, nprocs=n, args=(main_func, n, dist_url, args), join=True)
+    if dist_url not in (None, "auto"):
+        mp.spawn(_worker, nprocs=n, args=(main_func, n, dist_url, args), join=True)
+        return None
+    # find_free_port closes its probe socket before the workers bind: another process can take the port in between.  A rendezvous
+    # that dies on EADDRINUSE is retried on a fresh port (anything else propagates).
+    for attempt in range(4):
+        dist_url = "tcp://127.0.0.1:%d" % find_free_port()
+        try:
+            mp.spawn(_worker, nprocs=n, args=(main_func, n, dist_url, args), join=True)
+            return None
+        except Exception as e:  # noqa: BLE001
+            msg = str(e)
+            if attempt == 3 or not ("EADDRINUSE" in msg or "Address already in use" in msg or "address already in use" in msg):
+                raise
     return None

@@ -193,6 +193,9 @@ class _TrainerBase:
         self.max_iter = cfg.SOLVER.MAX_ITER
         self.iter = 0
         self.world_size = comm.get_world_size()
+        # the data-parallel machinery (replica broadcast, bucketed all-reduce from the wgrad stream) also runs in a world of ONE
+        # rank when asked to: a single-GPU box can then drive the real RCCL backend through every call the N-rank step makes
+        self._dp_single_rank = comm.is_dist() and os.environ.get("UTV2_DP_SINGLE_RANK") == "1"
         self._data_loader = data_loader if data_loader is not None else self.build_train_loader(cfg)
         self._data_loader_iter = iter(self._data_loader)
         self.storage = None
@@ -204,11 +207,17 @@ class _TrainerBase:
         self._setup_grad_sync()
         self.sync_replicas()
 
+    _dp_single_rank = False
+
+    @property
+    def data_parallel(self):
+        return self.world_size > 1 or self._dp_single_rank
+
     def sync_replicas(self):
         """Data parallel: every rank starts from rank 0's student, teacher and momentum, as DistributedDataParallel does at
         construction in the reference (trainer.py:59-63).  Only gradients are exchanged afterwards, so replicas that differ here
         (per-rank seeding such as Detectron2's SEED + rank, a checkpoint only rank 0 can read) would stay different for good."""
-        if self.world_size > 1:
+        if self.data_parallel:
             for t in (self.model.flat_state(), self.model_teacher.flat_state(), self.model.store.mom):
                 if t is not None:
                     dist.broadcast(t, 0)
@@ -266,7 +275,7 @@ class _TrainerBase:
     def _setup_grad_sync(self):
         """data parallel: cut the gradient arena into buckets that are all-reduced while backward is still running"""
         self._grad_sync = None
-        if self.world_size > 1 and os.environ.get("UTV2_OVERLAP_ALLREDUCE", "1") != "0":
+        if self.data_parallel and os.environ.get("UTV2_OVERLAP_ALLREDUCE", "1") != "0":
             from ..utils.grad_sync import GradBuckets
             st = self.model.store
             hs = [h for h in st.handles if h.g is not None]
@@ -286,7 +295,7 @@ class _TrainerBase:
             ops.join_wgrad_stream()      # the optimizer step (and whatever reads the gradient arena) follows on the main stream
 
     def _allreduce_grads(self):
-        if self.world_size > 1:
+        if self.data_parallel:
             gs = getattr(self, "_grad_sync", None)
             if gs is not None:
                 gs.finish()

@@ -291,10 +291,12 @@ def preprocess_images(images, mean, std, size_divisibility, bf16_stem=False):
     m = (ctypes.c_float * 3)(*[float(v) for v in mean])
     s = (ctypes.c_float * 3)(*[float(v) for v in std])
     if bf16_stem and Wm % 2 == 0:
-        key = (len(images), Hm, Wm, str(dev))
+        # keyed by stream too (as workspace() is): the teacher's pass on its side stream and a student pass on the main stream may
+        # preprocess batches of the same shape concurrently
+        key = (len(images), Hm, Wm, str(dev), int(torch.cuda.current_stream(dev).cuda_stream))
         out = _stem_in_cache.get(key)
         if out is None:
-            if len(_stem_in_cache) > 8:
+            if len(_stem_in_cache) > 16:
                 _stem_in_cache.clear()
             out = torch.zeros((len(images), Hm + 6, Wm + 8, 4), dtype=torch.bfloat16, device=dev)
             _stem_in_cache[key] = out

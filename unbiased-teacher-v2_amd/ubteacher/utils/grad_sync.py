@@ -10,9 +10,12 @@ own stream, overlapping the rest of backward over xGMI).  `finish()` launches wh
 The 1/world scale stays folded into the SGD kernel.  With world_size 1 nothing is registered or launched.
 """
 import bisect
+import os
 
 import torch
 import torch.distributed as dist
+
+_DEBUG = os.environ.get("UTV2_GRAD_SYNC_DEBUG", "0") == "1"
 
 
 class GradBuckets:
@@ -36,6 +39,8 @@ class GradBuckets:
         self.next = nb - 1       # next bucket to launch: strictly descending
         self.order = []          # launch order of the running step
         self.last_order = []     # ... of the last finished step (tests)
+        self.prelaunched = []    # buckets reduced at arm() (no registered writer): UTV2_GRAD_SYNC_DEBUG=1 re-checks them in finish()
+        self._ops = None
 
     def bucket_of(self, h):
         return bisect.bisect_right(self.starts, int(h.offset)) - 1
@@ -59,7 +64,15 @@ class GradBuckets:
         """right before losses.backward(): every writer of this step has registered by now.  Buckets nobody will write this step
         (parameters of branches that did not run) are ready at once."""
         self.armed = True
+        before = len(self.order)
         self._launch_ready()
+        self.prelaunched = list(self.order[before:])
+        if _DEBUG:
+            # a bucket reduced before backward must not be written by it: a layer that accumulates into handle.g without registering
+            # through on_forward would have its gradient reduced before it exists, and the ranks would diverge silently
+            for w in self.works:
+                w.wait()
+            self._pre_sums = [float(self.grad[s:e].double().abs().sum()) for s, e in (self.bounds[b] for b in self.prelaunched)]
 
     def _launch_ready(self):
         """Collectives must be issued in the SAME order on every rank (a mismatch is an RCCL hang).  Which bucket completes first
@@ -75,7 +88,10 @@ class GradBuckets:
         self.launched[b] = True
         self.order.append(b)
         if e > s:
-            from .. import ops
+            if self._ops is None:
+                from .. import ops as _ops
+                self._ops = _ops
+            ops = self._ops
             # this bucket's weight gradients may still be running on the wgrad side stream: the collective is issued from THAT stream
             # (made to wait for the main one), so RCCL's stream waits for both and the main stream's dgrad chain is never held up
             side = ops.wgrad_stream_behind_main(self.grad.device)
@@ -94,6 +110,12 @@ class GradBuckets:
         for w in self.works:
             w.wait()
         self.works = []
+        if _DEBUG and self.prelaunched:
+            now = [float(self.grad[s:e].double().abs().sum()) for s, e in (self.bounds[b] for b in self.prelaunched)]
+            bad = [b for b, x, y in zip(self.prelaunched, self._pre_sums, now) if x != y]
+            if bad:
+                raise RuntimeError("grad_sync: buckets %s were all-reduced at arm() (no registered writer) but backward wrote them: "
+                                   "a layer accumulates into its gradient handle without on_forward()" % bad)
         self.armed = False
         nb = len(self.bounds)
         self.pending = [0] * nb
