@@ -178,7 +178,8 @@ def bind(duck, cls, names):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def gen_step_fcos(structures, tr):
+def load_ref_fcos_modules():
+    """the reference's own FCOS module, OneStageDetector and PseudoGenerator, imported in place (Detectron2 names stubbed)"""
     sys.modules["detectron2.data.detection_utils"] = G._Stub("detectron2.data.detection_utils")
     for n in ("detectron2.modeling.backbone", "detectron2.modeling.postprocessing"):
         m = G._Stub(n)
@@ -188,6 +189,40 @@ def gen_step_fcos(structures, tr):
     fcos_mod = G._load("ubteacher.modeling.fcos.fcos", REF + "/ubteacher/modeling/fcos/fcos.py")
     osd = G._load("ubteacher.modeling.one_stage_detector", REF + "/ubteacher/modeling/one_stage_detector.py")
     pg = sys.modules["ubteacher.modeling.pseudo_generator"]
+    return fcos_mod, osd, pg
+
+
+class OracleBackbone(torch.nn.Module):
+    """Detectron2 build_fcos_resnet_fpn_backbone stand-in: ResNet-50 (FrozenBN, stride in 1x1) + FPN p3-p5 + LastLevelP6P7"""
+    size_divisibility = 32
+
+    def __init__(self, sd):
+        super().__init__()
+        self.net = ParamNet(OrderedDict((k, v) for k, v in sd.items() if k.startswith("backbone.")), FROZEN)
+
+    def forward(self, x):
+        v = self.net.view()
+        c = O.resnet50(v, x, "backbone.bottom_up", ("res3", "res4", "res5"))
+        return O.fpn(v, c, ["res3", "res4", "res5"], "p6p7")
+
+
+def build_ref_one_stage(cfg, sd, fcos_mod, osd):
+    """the reference's OneStageDetector (one_stage_detector.py:155-240) over its own FCOS module, with state `sd`"""
+    m = osd.OneStageDetector.__new__(osd.OneStageDetector)
+    torch.nn.Module.__init__(m)
+    m.backbone = OracleBackbone(sd)
+    shapes = {f: types.SimpleNamespace(channels=256, stride=s) for f, s in zip(cfg.MODEL.FCOS.IN_FEATURES, cfg.MODEL.FCOS.FPN_STRIDES)}
+    m.proposal_generator = fcos_mod.FCOS(cfg, shapes)
+    m.register_buffer("pixel_mean", sd["pixel_mean"].clone().view(-1, 1, 1))
+    m.register_buffer("pixel_std", sd["pixel_std"].clone().view(-1, 1, 1))
+    head = {k[len("proposal_generator."):]: v for k, v in sd.items() if k.startswith("proposal_generator.")}
+    missing, unexpected = m.proposal_generator.load_state_dict(head, strict=False)
+    assert not unexpected and all("integral" in k for k in missing), (missing, unexpected)
+    return m
+
+
+def gen_step_fcos(structures, tr):
+    fcos_mod, osd, pg = load_ref_fcos_modules()
 
     cfg, sd0 = product_cfg_and_state("fcos", seed=0)
     H, W = 96, 128
@@ -208,31 +243,8 @@ def gen_step_fcos(structures, tr):
     sd_t = OrderedDict(sd_s)
     sd_t["proposal_generator.fcos_head.bbox_pred_std.bias"] = torch.full((4,), -3.0)
 
-    class OracleBackbone(torch.nn.Module):
-        """Detectron2 build_fcos_resnet_fpn_backbone stand-in: ResNet-50 (FrozenBN, stride in 1x1) + FPN p3-p5 + LastLevelP6P7"""
-        size_divisibility = 32
-
-        def __init__(self, sd):
-            super().__init__()
-            self.net = ParamNet(OrderedDict((k, v) for k, v in sd.items() if k.startswith("backbone.")), FROZEN)
-
-        def forward(self, x):
-            v = self.net.view()
-            c = O.resnet50(v, x, "backbone.bottom_up", ("res3", "res4", "res5"))
-            return O.fpn(v, c, ["res3", "res4", "res5"], "p6p7")
-
     def build(sd):
-        m = osd.OneStageDetector.__new__(osd.OneStageDetector)
-        torch.nn.Module.__init__(m)
-        m.backbone = OracleBackbone(sd)
-        shapes = {f: types.SimpleNamespace(channels=256, stride=s) for f, s in zip(cfg.MODEL.FCOS.IN_FEATURES, cfg.MODEL.FCOS.FPN_STRIDES)}
-        m.proposal_generator = fcos_mod.FCOS(cfg, shapes)
-        m.register_buffer("pixel_mean", sd["pixel_mean"].clone().view(-1, 1, 1))
-        m.register_buffer("pixel_std", sd["pixel_std"].clone().view(-1, 1, 1))
-        head = {k[len("proposal_generator."):]: v for k, v in sd.items() if k.startswith("proposal_generator.")}
-        missing, unexpected = m.proposal_generator.load_state_dict(head, strict=False)
-        assert not unexpected and all("integral" in k for k in missing), (missing, unexpected)
-        return m
+        return build_ref_one_stage(cfg, sd, fcos_mod, osd)
 
     def full_state(m):
         out = demangle(m.state_dict())

@@ -226,6 +226,56 @@ def test_evaluation_loop_runs_and_rescales():
     assert max(p["boxes"][:, 2].max() if len(p["scores"]) else 0 for p in ev._pred.values()) > 128   # beyond the unscaled width
 
 
+@pytest.mark.parametrize("variant", ["default", "testth"])
+def test_fcos_eval_detections_vs_reference_golden(variant):
+    """FCOS test-mode inference of the PRODUCT (Trainer.test -> inference_on_dataset -> eval-mode OneStageDetector with
+    NMS_CRITERIA_TEST and the *_TEST thresholds -> detector_postprocess) against the golden produced by executing the reference's own
+    eval-mode OneStageDetector.forward (tests/golden/gen_golden_eval.py; one_stage_detector.py:16-43,136-145,230-240,
+    evaluation/evaluator.py:14-104): a two-image ragged batch rescaled to original sizes; kept detections identical (classes and
+    order exact), scores 1e-3, boxes 1e-3 of the image size.  `testth`: *_TEST thresholds that differ from the *_TRAIN ones."""
+    from tests.test_step_golden import EVAL_VARIANTS, _eval_golden, eval_golden_state
+    from ubteacher.engine import UBTeacherTrainer
+    from ubteacher.evaluation import inference_on_dataset
+    d = _eval_golden()
+    _, sd = eval_golden_state(d)
+    over = [str(x) for x in d[variant + "_overrides"]]
+    cfg = small_fcos_cfg()
+    typed = []
+    for k, v in zip(over[0::2], over[1::2]):
+        typed += [k, v if k.endswith("CRITERIA_TEST") else (float(v) if "." in v else int(v))]
+    cfg.merge_from_list(typed)
+    torch.manual_seed(0)
+    prod, _ = make_batch(12, 2, 2, H, W, "cuda")
+    tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+    tr.model_teacher.load_state_dict(sd)
+    batch = []
+    for i in range(2):
+        oh, ow = [int(x) for x in d["orig%d" % i]]
+        batch.append({"image": torch.from_numpy(d["img%d" % i]).cuda(), "height": oh, "width": ow, "image_id": i})
+
+    class Capture:
+        def reset(self):
+            self.out = []
+
+        def process(self, inputs, outputs):
+            self.out.extend(outputs)
+
+        def evaluate(self):
+            return {}
+    ev = Capture()
+    inference_on_dataset(tr.model_teacher, [batch], ev, cfg)
+    assert len(ev.out) == 2
+    for i, r in enumerate(ev.out):
+        x = r["instances"]
+        oh, ow = [int(v) for v in d["orig%d" % i]]
+        assert tuple(x.image_size) == (oh, ow)
+        cls, sc, bx = d["%s_classes%d" % (variant, i)], d["%s_scores%d" % (variant, i)], d["%s_boxes%d" % (variant, i)]
+        assert len(x) == len(cls) and len(cls) > 0, (len(x), len(cls))
+        assert np.array_equal(x.pred_classes.long().cpu().numpy(), cls)
+        np.testing.assert_allclose(x.scores.cpu().numpy(), sc, rtol=1e-3)
+        np.testing.assert_allclose(x.pred_boxes.tensor.cpu().numpy(), bx, rtol=0, atol=1e-3 * max(oh, ow))
+
+
 def test_premasked_backbone_gradients_bit_identical(monkeypatch):
     """AMP backward of the fused bottlenecks: masking the gradient that flows into a block's ReLU output in the PRODUCERS' dgrad epilogues
     (next block's conv1 dgrad incl. the residual branch, stride-2 zero-interleave, FPN lateral dgrad) equals the separate mask pass at the

@@ -98,3 +98,48 @@ def test_rcnn_step_oracle_vs_reference_trainer():
         np.testing.assert_allclose(p["pred_boxes_std"].numpy(), d["pseudo%d_std" % i], rtol=1e-4, atol=1e-5)
     check_state_fingerprints(d, "teacher", new_t, 0.0, exact=True)
     check_state_fingerprints(d, "student", new_s, 2e-6)
+
+
+def _eval_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fcos_eval.npz"), allow_pickle=False)
+
+
+def eval_golden_state(d):
+    """the weights the eval golden ran on: product CPU init (fingerprint-checked) + the stored cls_logits rescale"""
+    from tests.utv2_testutil import golden_init_state
+    cfg, sd = golden_init_state("fcos", d)
+    p = "proposal_generator.fcos_head.cls_logits"
+    g = torch.Generator().manual_seed(0)
+    sd = dict(sd)
+    sd[p + ".weight"] = torch.randn(sd[p + ".weight"].shape, generator=g) * 0.01 * float(d["cls_scale"])
+    sd[p + ".bias"] = torch.full_like(sd[p + ".bias"], float(d["cls_bias"]))
+    return cfg, sd
+
+
+EVAL_VARIANTS = {"default": dict(nms="cls_n_ctr"), "testth": dict(nms="cls_n_loc", pre_nms_thresh=0.2, pre_nms_topk=60, post_nms_topk=12)}
+
+
+def test_fcos_eval_oracle_vs_reference_golden():
+    """FCOS test-mode inference (tests/golden/gen_golden_eval.py: the reference's eval-mode OneStageDetector.forward +
+    detector_postprocess, one_stage_detector.py:16-43,136-145,230-240): the oracle's forward + predict at the *_TEST thresholds +
+    rescale reproduces the kept detections (classes exact, scores 1e-5, boxes 1e-4)."""
+    d = _eval_golden()
+    _, sd = eval_golden_state(d)
+    images = [torch.from_numpy(d["img%d" % i]) for i in range(2)]
+    with torch.no_grad():
+        out = O.fcos_forward(sd, images, sd["pixel_mean"], sd["pixel_std"])
+    for name, v in EVAL_VARIANTS.items():
+        v = dict(v)
+        nms = v.pop("nms")
+        dets = O.fcos_predict(O.FCOSCfg(**v), *out[:4], out[4], out[5], nms)
+        for i, det in enumerate(dets):
+            oh, ow = [int(x) for x in d["orig%d" % i]]
+            h, w = det["image_size"]
+            b = det["boxes"].clone()
+            b[:, 0::2] = (b[:, 0::2] * (ow / w)).clamp(0, ow)
+            b[:, 1::2] = (b[:, 1::2] * (oh / h)).clamp(0, oh)
+            keep = ((b[:, 2] - b[:, 0]) > 0) & ((b[:, 3] - b[:, 1]) > 0)
+            assert np.array_equal(det["classes"][keep].numpy(), d["%s_classes%d" % (name, i)]), (name, i)
+            np.testing.assert_allclose(det["scores"][keep].numpy(), d["%s_scores%d" % (name, i)], rtol=1e-5)
+            np.testing.assert_allclose(b[keep].numpy(), d["%s_boxes%d" % (name, i)], rtol=1e-4, atol=1e-3)
