@@ -162,7 +162,8 @@ class WgradTimer:
 
         def wrapped(x, dy2d, dw, rowinfo, C, kh, kw, *args, **kwargs):
             M, K = dy2d.shape
-            mine = (timer.enabled and kh == 3 and kw == 3 and C == 256 and K == 256 and x.dtype == torch.bfloat16
+            G = kwargs.get("groups", 1)      # paired towers: K = 512 (cls | bbox), C = 256 input channels per group
+            mine = (timer.enabled and kh == 3 and kw == 3 and C == 256 and K in (256, 512) and x.dtype == torch.bfloat16
                     and dy2d.dtype == torch.bfloat16 and M >= 65536)
             if not mine:
                 return orig(x, dy2d, dw, rowinfo, C, kh, kw, *args, **kwargs)
@@ -170,7 +171,7 @@ class WgradTimer:
             e0.record()
             r = orig(x, dy2d, dw, rowinfo, C, kh, kw, *args, **kwargs)
             e1.record()
-            timer.pairs.append((e0, e1, 2.0 * M * K * kh * kw * C, 2.0 * M * (C + K) + 4.0 * K * kh * kw * C))
+            timer.pairs.append((e0, e1, 2.0 * M * K * kh * kw * C, 2.0 * M * (G * C + K) + 4.0 * K * kh * kw * C))
             return r
 
         hip.conv2d_wgrad_bf16 = wrapped

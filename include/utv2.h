@@ -75,6 +75,14 @@ int utv2_conv2d_nhwc_fwd_bf16(const void* x, int x_dtype, const void* w16, void*
 int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
                             const float* bias, const void* residual, int nlev, const int* H_host, const int* W_host, int N,
                             int C, int K, int KH, int KW, int pad, int relu, int accumulate, utv2_stream_t stream);
+/* The same over column slices and / or GROUPED (the paired FCOS towers - cls | bbox, two independent 256 -> 256 chains of
+ * fcos/fcos.py:252-304 - run as ONE launch per depth): x has row pitch x_pitch elements and group g reads its channels
+ * [g*C, (g+1)*C) (C = input channels PER GROUP), w16 = bf16 [K][KH*KW*C], y / residual have row pitch y_pitch >= K.
+ * Anything but (groups 1, x_pitch C, y_pitch K) needs bf16 x, C % 32 == 0, K % 4 == 0, pitches % 8 == 0, (K / groups) % 128 == 0. */
+int utv2_conv2d_ml_fwd_bf16_g(const void* x, int x_dtype, int x_pitch, const void* w16, void* y, int y_dtype, int y_pitch,
+                              const float* scale, const float* bias, const void* residual, int nlev, const int* H_host,
+                              const int* W_host, int N, int C, int K, int KH, int KW, int pad, int relu, int accumulate, int groups,
+                              utv2_stream_t stream);
 /* bf16 wgrad (+ fused bias gradient); rowinfo = device int32[M][2] per OUTPUT pixel:
  * {input pixel index of tap (0,0), (W << 16) | mask of the taps that fall inside the image}; KH*KW <= 16 */
 int utv2_conv2d_wgrad_bf16_splits(int M, int K, int Kred);
@@ -84,6 +92,12 @@ int64_t utv2_conv2d_wgrad_bf16_workspace_floats(int M, int K, int Kred);
 int utv2_conv2d_wgrad_bf16(const void* x, int x_dtype, const void* dy, int dy_dtype, float* dw, float* db, float* ws,
                            const int* rowinfo, const float* rowscale, int M, int C, int K, int KH, int KW, int accumulate,
                            utv2_stream_t stream);
+/* x with pixel pitch x_pitch (a channel slice of a wider matrix), dy with row pitch dy_pitch >= K (the first K columns of a
+ * zero-padded matrix) and / or grouped: dw rows [g*K/groups, (g+1)*K/groups) correlate dy with input channels [g*C, (g+1)*C)
+ * (C per group; dw = [K][KH*KW*C]); (K / groups) % 128 == 0, x_pitch >= groups * C */
+int utv2_conv2d_wgrad_bf16_g(const void* x, int x_dtype, int x_pitch, const void* dy, int dy_dtype, int dy_pitch, float* dw, float* db,
+                             float* ws, const int* rowinfo, const float* rowscale, int M, int C, int K, int KH, int KW, int accumulate,
+                             int groups, utv2_stream_t stream);
 /* D2 BasicStem conv1 on bf16 MFMA: xpad16 = bf16 [N][H+6][W+8][4], the normalised NHWC4 image inside a zero border
  * (written by utv2_preprocess_image_bf16pad); w16s = bf16 [K][7][32] (7 taps x 4 channels + 4 zeros per kernel row) */
 int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int y_dtype, const float* scale,

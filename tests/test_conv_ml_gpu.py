@@ -87,3 +87,57 @@ def test_padded_dgrad_of_an_80_channel_head_conv():
         assert relerr(b.g.cpu(), dy.to(torch.bfloat16).float().sum(0).cpu()) < 1e-4
     finally:
         ops.set_precision("fp32")
+
+
+@pytest.mark.parametrize("level_hw,N", [([(20, 24), (10, 12), (5, 6)], 2), ([(128, 160), (64, 80)], 2)])
+def test_grouped_and_pitched_ml_conv_bf16(level_hw, N):
+    """The paired FCOS towers (cls | bbox: two independent 256 -> 256 chains, fcos/fcos.py:252-304) run as ONE grouped launch per depth:
+    utv2_conv2d_ml_fwd_bf16_g with groups = 2 on a [P, 512] matrix == the two 256 -> 256 convs on its column halves, BIT-identical
+    (same tiles, same accumulation order) - on the 128-tile kernel (small case) and on whole rounds of the 256-tile ping-pong kernel
+    + its 128-tile remainder (large case); a conv reading a column SLICE (row pitch 512) and one writing into a column slice equal the
+    convs on contiguous copies; the grouped weight gradient equals the two separate ones (fp32 accumulation, different split counts)."""
+    from ubteacher import hip
+    from ubteacher.ops import LevelMeta
+    g = torch.Generator().manual_seed(7)
+    C = 256
+    meta = LevelMeta(N, level_hw)
+    P = meta.P
+    x = (torch.randn(P, 2 * C, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    w = (torch.randn(2 * C, 9 * C, generator=g) * 0.02).to(torch.bfloat16).cuda()
+    b = torch.randn(2 * C, generator=g).cuda()
+    y = hip.conv2d_ml_fwd_bf16(x, w, level_hw, N, bias=b, k=3, pad=1, groups=2)
+    xa, xb = x[:, :C].contiguous(), x[:, C:].contiguous()
+    ya = hip.conv2d_ml_fwd_bf16(xa, w[:C].contiguous(), level_hw, N, bias=b[:C].contiguous(), k=3, pad=1)
+    yb = hip.conv2d_ml_fwd_bf16(xb, w[C:].contiguous(), level_hw, N, bias=b[C:].contiguous(), k=3, pad=1)
+    assert y.shape == (P, 2 * C) and torch.equal(y[:, :C], ya) and torch.equal(y[:, C:], yb)
+    # against torch on the same bf16-rounded operands (one level, group 1)
+    h0, w0 = level_hw[0]
+    xr = meta.level_view(xb, 0).float().permute(0, 3, 1, 2).cpu()
+    ref = F.conv2d(xr, w[C:].float().view(C, 3, 3, C).permute(0, 3, 1, 2).cpu(), b[C:].cpu(), 1, 1)
+    got = meta.level_view(yb, 0).float().permute(0, 3, 1, 2).cpu()
+    assert relerr(got, ref) < 2e-2
+    # column slices: input with row pitch 512, output written into the right half of a [P, 512] buffer
+    ys = hip.conv2d_ml_fwd_bf16(x[:, C:], w[C:].contiguous(), level_hw, N, bias=b[C:].contiguous(), k=3, pad=1)
+    assert torch.equal(ys, yb)
+    out = torch.zeros(P, 2 * C, dtype=torch.bfloat16, device="cuda")
+    hip.conv2d_ml_fwd_bf16(xa, w[:C].contiguous(), level_hw, N, bias=b[:C].contiguous(), k=3, pad=1, out=out[:, C:])
+    assert torch.equal(out[:, C:], ya) and float(out[:, :C].float().abs().max()) == 0.0
+    # a narrow (80-channel, fp32-output) conv reading a slice: the prediction convs behind the paired towers
+    w80 = (torch.randn(80, 9 * C, generator=g) * 0.02).to(torch.bfloat16).cuda()
+    p_slice = hip.conv2d_ml_fwd_bf16(x[:, :C], w80, level_hw, N, k=3, pad=1, out_dtype=torch.float32)
+    p_copy = hip.conv2d_ml_fwd_bf16(xa, w80, level_hw, N, k=3, pad=1, out_dtype=torch.float32)
+    assert torch.equal(p_slice, p_copy)
+    # weight gradients: grouped == per group; sliced x == contiguous x
+    dy = (torch.randn(P, 2 * C, generator=g) * 0.1).to(torch.bfloat16).cuda()
+    ri = hip.rowinfo_ml(N, level_hw, 1, 3, "cuda")
+    dwg = torch.zeros(2 * C, 9 * C, device="cuda")
+    hip.conv2d_wgrad_bf16(x, dy, dwg, ri, C, 3, 3, accumulate=True, groups=2)
+    dwa, dwb = torch.zeros(C, 9 * C, device="cuda"), torch.zeros(C, 9 * C, device="cuda")
+    hip.conv2d_wgrad_bf16(xa, dy[:, :C].contiguous(), dwa, ri, C, 3, 3, accumulate=True)
+    hip.conv2d_wgrad_bf16(xb, dy[:, C:].contiguous(), dwb, ri, C, 3, 3, accumulate=True)
+    assert relerr(dwg[:C].cpu(), dwa.cpu()) < 1e-5 and relerr(dwg[C:].cpu(), dwb.cpu()) < 1e-5
+    dy80 = torch.randn(P, 80, generator=g).cuda()
+    d1, d2 = torch.zeros(80, 9 * C, device="cuda"), torch.zeros(80, 9 * C, device="cuda")
+    hip.conv2d_wgrad_bf16(x[:, C:], dy80, d1, ri, C, 3, 3, accumulate=True, x_pitch=2 * C)
+    hip.conv2d_wgrad_bf16(xb, dy80, d2, ri, C, 3, 3, accumulate=True)
+    assert torch.equal(d1, d2)

@@ -55,7 +55,7 @@ def call(name, *args):
         orig_call(name, *args)
 
 hip.call = call
-sys.argv = ["bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-f32"]
+sys.argv = ["bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-f32", "--no-rcnn", "--timed-only"]
 # run bench main but toggle recording around the timed region by patching ConvTimer.enabled setter
 class T(bench.ConvTimer):
     def __setattr__(self, k, v):

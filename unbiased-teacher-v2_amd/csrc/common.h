@@ -80,7 +80,10 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
                                               const float* __restrict__ scale, const float* __restrict__ bias,
                                               const TO* __restrict__ residual, int relu, int accumulate, int m_base,
                                               int co_base, int M, int K, const TO* __restrict__ mask = nullptr,
-                                              const TO* __restrict__ post_mask = nullptr) {
+                                              const TO* __restrict__ post_mask = nullptr, int ldy = 0) {
+  // ldy (optional): elements between consecutive rows of y / residual / mask / post_mask (0 = K); y may be a column slice of a wider
+  // matrix (the operands that share y's shape share its pitch)
+  const int LDY = ldy > 0 ? ldy : K;
   // mask (optional, y's type and shape): y = mask > 0 ? value : 0, applied before the residual add - the ReLU backward of
   // the layer that produced this conv's input, fused into the dgrad that computes its gradient
   // post_mask (optional, same type and shape): y = post_mask > 0 ? value : 0 AFTER the residual add - the ReLU backward of the layer
@@ -102,7 +105,7 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
       if (bias) bi[h] = *(const f32x4*)(bias + co + 4 * h);
     }
   }
-  const bool full = cok[NQ - 1] && (K & 7) == 0;  // keeps the 16-byte accesses 16-byte aligned
+  const bool full = cok[NQ - 1] && (K & 7) == 0 && (LDY & 7) == 0;  // keeps the 16-byte accesses 16-byte aligned
   // bf16 residual rows are fetched BEFORE the accumulators bounce through LDS: the loads then overlap the bounce instead of
   // sitting, one dependent load after another, between it and the stores
   bf16x8_t rpre[2][32 / RPI];
@@ -114,7 +117,7 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
 #pragma unroll
         for (int it = 0; it < 32 / RPI; ++it) {
           const int m = m_base + i * 32 + it * RPI + rsub;
-          const size_t off = (size_t)(m < M ? m : M - 1) * K + co;
+          const size_t off = (size_t)(m < M ? m : M - 1) * LDY + co;
           rpre[i][it] = *(const bf16x8_t*)((const __bf16*)residual + off);
         }
     }
@@ -132,7 +135,7 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
       const int row = it * RPI + rsub;
       const int m = m_base + i * 32 + row;
       if (m < M && cok[0]) {
-        const size_t off = (size_t)m * K + co;
+        const size_t off = (size_t)m * LDY + co;
         f32x4 v[NQ];
 #pragma unroll
         for (int h = 0; h < NQ; ++h) {

@@ -41,8 +41,13 @@ struct ConvArgs16 {
   const void* mask;          // element type TO (optional): y = mask > 0 ? y : 0 before the residual add
   const void* post_mask;     // element type TO (optional): y = post_mask > 0 ? y : 0 after the residual add
   int N, H, W, C, OH, OW, K, KH, KW, stride, pad, in_dil, relu, Kred, M, accumulate;
-  int xs;                    // elements between consecutive input pixels (= C except for the image stem's overlapping 8-pixel reads)
+  int xs;                    // elements between consecutive input pixels (= C except for the image stem's overlapping 8-pixel reads, a
+                             // channel slice of a wider matrix, or a grouped conv: groups * C)
   int m_begin;               // first output row of this launch (a conv may be split over two kernels by output-row range)
+  int groups;                // grouped conv: output channels [g*K/groups, (g+1)*K/groups) read input channels [g*C, (g+1)*C) of a pixel
+                             // (C = channels PER GROUP, Kred = KH*KW*C, xs >= groups*C); the tile width divides K/groups.  The paired
+                             // FCOS towers (cls | bbox, two independent 256 -> 256 chains) run as ONE launch per depth this way.
+  int ldy;                   // elements between consecutive rows of y / residual / mask / post_mask (>= K: y may be a column slice)
 };
 
 __device__ __forceinline__ void ml_decode16(const LevelTab& lt, int m, int& pixbase, int& H, int& W, int& oh, int& ow) {
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
     // all MFMAs retired and every wave is past the last barrier of the K loop: the staging LDS is free
     float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
     epilogue_rows<TN, TO>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
-                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask);
+                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy);
     return;
   }
   TO* yo = (TO*)p.y;
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         if (m >= p.M) continue;
-        const size_t off = (size_t)m * p.K + co;
+        const size_t off = (size_t)m * p.ldy + co;
         float v = acc[i][j][e] * sc + bi;
         if (msk) v = (float)msk[off] > 0.f ? v : 0.f;
         if (res) v += (float)res[off];
@@ -414,6 +419,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
   const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
   const int lrow = tid / SLOTS, slot = tid % SLOTS;  // staged rows lrow + RPP*j, channels slot*8 .. +7 of the chunk
   const int ntaps = p.KH * p.KW;
+  const int goff = p.groups > 1 ? (n0 / (p.K / p.groups)) * p.C : 0;  // first input channel of this tile's group
 
   int aoff[AP], awc[AP];
   unsigned amask[AP];
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
       iw0 = ow - p.pad;
     } else {
       if (p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0) {  // pointwise: output pixel m reads input pixel m, no geometry to decode
-        aoff[j] = mm * p.xs + slot * 8;
+        aoff[j] = mm * p.xs + slot * 8 + goff;
         awc[j] = 0;
         amask[j] = mv ? 1u : 0u;
         continue;
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
       H = p.H;
       W = p.W;
     }
-    aoff[j] = (pb + ih0 * W + iw0) * p.xs + slot * 8;
+    aoff[j] = (pb + ih0 * W + iw0) * p.xs + slot * 8 + goff;
     awc[j] = W * p.xs;
     unsigned mk = 0;
     for (int kh = 0; kh < p.KH; ++kh)
@@ -562,7 +568,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
     static_assert(sizeof(smem) >= 4 * 32 * ((BN / 2) + 4) * sizeof(float), "epilogue patches must fit the staging LDS");
     float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
     epilogue_rows<TN, TO>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
-                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask);
+                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy);
     return;
   }
   TO* yo = (TO*)p.y;
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         if (m >= p.M) continue;
-        const size_t off = (size_t)m * p.K + co;
+        const size_t off = (size_t)m * p.ldy + co;
         float v = acc[i][j][e] * sc + bi;
         if (msk) v = (float)msk[off] > 0.f ? v : 0.f;
         if (res) v += (float)res[off];
@@ -631,6 +637,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
   const int lrow = tid / SLOTS, slot = tid % SLOTS;
   const int kslot = slot ^ ((lrow >> 1) & 7);  // source-side swizzle: the lane fetches the k-slot that belongs in its physical slot
   const int ntaps = p.KH * p.KW;
+  const int goff = p.groups > 1 ? (n0 / (p.K / p.groups)) * p.C : 0;
 
   int aoff[AP], awc[AP];
   unsigned amask[AP];
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
       H = p.H;
       W = p.W;
     }
-    aoff[j] = (pb + ih0 * W + iw0) * p.xs + kslot * 8;
+    aoff[j] = (pb + ih0 * W + iw0) * p.xs + kslot * 8 + goff;
     awc[j] = W * p.xs;
     unsigned mk = 0;
     for (int kh = 0; kh < p.KH; ++kh)
@@ -763,7 +770,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
 #pragma unroll
   for (int half = 0; half < 2; ++half)
     epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[2 * half], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
-                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask);
+                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -827,6 +834,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
   const int prow = lane >> 2;
   const int kslot = (lane & 3) ^ ((lane >> 4) & 3);
   const int ntaps = p.KH * p.KW;
+  const int goff = p.groups > 1 ? (n0 / (p.K / p.groups)) * p.C : 0;
 
   int aoff[2], awc[2];
   unsigned amask[2];
@@ -851,7 +859,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
       H = p.H;
       W = p.W;
     }
-    aoff[j] = (pb + ih0 * W + iw0) * p.xs + kslot * 8;
+    aoff[j] = (pb + ih0 * W + iw0) * p.xs + kslot * 8 + goff;
     awc[j] = W * p.xs;
     unsigned mk = 0;
     for (int kh = 0; kh < p.KH; ++kh)
@@ -1086,7 +1094,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
 #pragma unroll
   for (int half = 0; half < 2; ++half)
     epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[2 * half], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
-                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask);
+                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy);
 }
 
 // A/B switches for bench runs and tests, read ONCE per process (never on the launch path): UTV2_W8=0 keeps every forward / dgrad
@@ -1108,7 +1116,7 @@ template <int BN, bool ML>
 static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dtype, hipStream_t stream) {
   const dim3 g(tiles), b(256);
   // v2 kernels: bf16 input, 32-bit element offsets, plain (non-dilated) gather, <= 16 taps
-  const int64_t xelems = ML ? (int64_t)a.M * a.C : (int64_t)a.N * a.H * a.W * a.C;
+  const int64_t xelems = ML ? (int64_t)a.M * a.xs : (int64_t)a.N * a.H * a.W * a.xs;
   if (x_dtype == UTV2_BF16 && a.C % 32 == 0 && a.in_dil == 1 && a.KH * a.KW <= 16 && xelems < (1ll << 31) &&
       (int64_t)a.K * a.Kred < (1ll << 31)) {
     // BK = 64 holds 2 workgroups per CU (64 KB LDS) against 4 for BK = 32: worth it for long K loops (MFMA-bound 3x3 /
@@ -1116,7 +1124,8 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
     const bool tail = tiles > 512 && tiles <= 768;
     const bool deep = a.C % 64 == 0 && a.Kred >= 1024 && !tail;
     const bool w8 = g_use_w8;
-    if (w8 && BN == 128 && a.xs == a.C && a.C % 64 == 0 && a.Kred >= 1024 && a.K >= 256 && (a.K & 3) == 0 && a.m_begin == 0) {
+    if (w8 && BN == 128 && a.xs >= a.groups * a.C && (a.xs & 7) == 0 && a.C % 64 == 0 && a.Kred >= 1024 && a.K >= 256 && (a.K & 3) == 0 &&
+        a.m_begin == 0 && (a.groups == 1 || (a.K / a.groups) % 256 == 0)) {
       // Whole rounds of 256 tiles (one per CU) always pay.  The rest: a partial round costs one 256-tile time (~76 us on the tower
       // shape) whatever its fill, the 128 x 128 kernel ~35-46 us per round of 512 of its tiles - so the big tile also takes the rest
       // (including the partial last row tile, masked in the kernel) when it is more than half a round, else the small kernel does.
@@ -1185,11 +1194,39 @@ int utv2_conv2d_nhwc_fwd_bf16(const void* x, int x_dtype, const void* w16, void*
   a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = mask; a.post_mask = post_mask;
   a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.K = K; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
   a.in_dil = in_dil < 1 ? 1 : in_dil; a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.M = N * OH * OW;
-  a.xs = C; a.m_begin = 0;
+  a.xs = C; a.m_begin = 0; a.groups = 1; a.ldy = K;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   if (small) launch_igemm16<64, false>(a, tiles, x_dtype, y_dtype, stream);
   else launch_igemm16<128, false>(a, tiles, x_dtype, y_dtype, stream);
+  return utv2_launch_status();
+}
+
+// Multi-level k x k 'same' conv over a level-first [P][x_pitch] matrix, optionally GROUPED and on column slices:
+//   x: row pitch x_pitch elements, the conv reads channels [g*C, (g+1)*C) of a row for group g (C = input channels PER GROUP);
+//   w16: bf16 [K][KH*KW*C]; y (and residual): row pitch y_pitch >= K.  x_pitch != C, y_pitch != K or groups > 1 need bf16 x with
+//   C % 32 == 0, K % 4 == 0 and (K / groups) % 128 == 0.
+int utv2_conv2d_ml_fwd_bf16_g(const void* x, int x_dtype, int x_pitch, const void* w16, void* y, int y_dtype, int y_pitch,
+                              const float* scale, const float* bias, const void* residual, int nlev, const int* H_host,
+                              const int* W_host, int N, int C, int K, int KH, int KW, int pad, int relu, int accumulate, int groups,
+                              hipStream_t stream) {
+  if (!x || !w16 || !y || nlev < 1 || nlev > CONV_MAX_LEVELS || (C % 8) || N <= 0 || bad_dtype(x_dtype) || bad_dtype(y_dtype) || groups < 1 ||
+      K % groups || x_pitch < groups * C || y_pitch < K)
+    return UTV2_EARG;
+  const bool plain = groups == 1 && x_pitch == C && y_pitch == K;
+  if (!plain && (x_dtype != UTV2_BF16 || (C % 32) || (K & 3) || KH * KW > 16 || (x_pitch & 7) || (y_pitch & 7) ||
+                 (groups > 1 && (K / groups) % 128)))
+    return UTV2_EARG;
+  ConvArgs16 a;
+  a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
+  if (!plain && ((int64_t)a.M * x_pitch >= (1ll << 31) || (int64_t)K * KH * KW * C >= (1ll << 31))) return UTV2_EARG;
+  a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
+  a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad; a.in_dil = 1;
+  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = x_pitch; a.m_begin = 0; a.groups = groups; a.ldy = y_pitch;
+  const bool small = K <= 64 && plain;
+  const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
+  if (small) launch_igemm16<64, true>(a, tiles, x_dtype, y_dtype, stream);
+  else launch_igemm16<128, true>(a, tiles, x_dtype, y_dtype, stream);
   return utv2_launch_status();
 }
 
@@ -1202,7 +1239,7 @@ int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y
   a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
   a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad; a.in_dil = 1;
-  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = C; a.m_begin = 0;
+  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = C; a.m_begin = 0; a.groups = 1; a.ldy = K;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   if (small) launch_igemm16<64, true>(a, tiles, x_dtype, y_dtype, stream);
@@ -1224,7 +1261,7 @@ int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int
   a.lt.n = 0;
   a.x = xpad16; a.w = (const __bf16*)w16s; a.y = y; a.scale = scale; a.bias = bias; a.residual = nullptr; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = H + 6; a.W = W + 8; a.C = 32; a.OH = OH; a.OW = OW; a.K = K; a.KH = 7; a.KW = 1; a.stride = 2; a.pad = 0;
-  a.in_dil = 1; a.relu = relu; a.accumulate = 0; a.Kred = 7 * 32; a.M = N * OH * OW; a.xs = 4; a.m_begin = 0;
+  a.in_dil = 1; a.relu = relu; a.accumulate = 0; a.Kred = 7 * 32; a.M = N * OH * OW; a.xs = 4; a.m_begin = 0; a.groups = 1; a.ldy = K;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   const dim3 g(tiles), b(256);
@@ -1308,6 +1345,9 @@ struct Wgrad16Args {
   const int2* rowinfo;
   float* bias_ws;  // optional [splits][K]: per-split column sums of dY (conv bias gradient), fused into the dY staging
   int C, K, KH, KW, Kred, M, splits, chunks_per_split;
+  int xs;        // elements between consecutive pixels of x (>= groups * C: x may be a channel slice of a wider matrix)
+  int groups;    // grouped conv: dW rows [g*K/groups, (g+1)*K/groups) correlate dY with input channels [g*C, (g+1)*C); C, Kred per group
+  int dys;       // elements between consecutive rows of dy (>= K: dy may be the first K columns of a zero-padded matrix)
   int debug;     // conv_wgrad_bf16_w8 built with UTV2_WGRAD_DEBUG_KNOBS: 16 / 32 / 64 = no DMA / no MFMA / no fragment reads (timing only)
 };
 
@@ -1340,6 +1380,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
   }
   const int mt = bid / tilesN, nt = bid - mt * tilesN;
   const int i0 = mt * 128, j0 = nt * 128;
+  const int goff = p.groups > 1 ? (i0 / (p.K / p.groups)) * p.C : 0;  // first input channel of this tile's group
 
   // staging: thread -> 8-channel group cg of pixel rows pl0 and pl0 + 16 of BOTH operand tiles
   const int cg = tid & 15, pl0 = tid >> 4;
@@ -1404,11 +1445,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
     const int m = chunk * BK + pl0 + 16 * r;
     const bool mok = m < p.M;
     if (q < 2) {
-      ra[r] = load8(p.dy, (size_t)m * p.K + co8, DY16, mok && aok);
+      ra[r] = load8(p.dy, (size_t)m * p.dys + co8, DY16, mok && aok);
     } else {
       const int W = ri[r].y >> 16;
       const bool ok = mok && bok && ((ri[r].y >> tap) & 1);
-      rb[r] = load8(p.x, (size_t)(ri[r].x + dh * W + dw) * p.C + ci, X16, ok);
+      rb[r] = load8(p.x, (size_t)(ri[r].x + dh * W + dw) * p.xs + goff + ci, X16, ok);
     }
   };
   auto store_piece = [&](int buf, int q) {
@@ -1561,7 +1602,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
   const int split = wi / tiles, bid = wi - split * tiles;
   const int mt = bid / tilesN, nt = bid - mt * tilesN;
   const int i0 = mt << 8, j0 = nt << 8;
-  const int tap = j0 / p.C, ci0 = j0 - tap * p.C;
+  const int tap = j0 / p.C, ci0 = j0 - tap * p.C + (p.groups > 1 ? (i0 / (p.K / p.groups)) * p.C : 0);
   const int dh = tap / p.KW, dw = tap - dh * p.KW;
 
   f32x16 acc[4][2];
@@ -1608,7 +1649,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                \
       const int m = chunk * BP + rowl + 2 * q;                                                                     \
       const int W = ri[SET][q].y >> 16;                                                                            \
-      const __bf16* s0 = xb + (unsigned)((ri[SET][q].x + dh * W + dw) * p.C + ci0 + choff[q & 1]);                 \
+      const __bf16* s0 = xb + (unsigned)((ri[SET][q].x + dh * W + dw) * p.xs + ci0 + choff[q & 1]);                \
       const bool ok = (m < p.M) & (chunk < chunk_end) & ((ri[SET][q].y >> tap) & 1);                               \
       bsrc[q] = ok ? s0 : zero;                                                                                    \
     }                                                                                                              \
@@ -1921,9 +1962,10 @@ static int wgrad16_w8_splits(int M, int K, int Kred) {
   if (splits > chunks / 8) splits = chunks / 8;
   return splits < 1 ? 1 : splits;
 }
-static bool wgrad16_w8_shape_ok(int M, int C, int K, int KH, int KW) {
+static bool wgrad16_w8_shape_ok(int M, int C, int K, int KH, int KW, int xs, int groups) {
   const int Kred = KH * KW * C, tiles = (K >> 8) * (Kred >> 8), chunks = cdiv(M, WGRAD_W8_BP);
-  if ((K & 255) || (C & 255) || KH * KW > 16 || K > 2048 || tiles > wgrad16_w8_budget() || chunks < 16 || (int64_t)M * K >= (1ll << 31))
+  if ((K & 255) || (C & 255) || KH * KW > 16 || K > 2048 || tiles > wgrad16_w8_budget() || chunks < 16 || (int64_t)M * K >= (1ll << 31) ||
+      (int64_t)M * xs >= (1ll << 31) || (xs & 7) || ((K / groups) & 255))
     return false;
   // 1x1 layers are HBM-bound: every pixel split costs a K x Kred fp32 slab written and re-read, and this kernel needs 256 / tiles of
   // them to fill the chip - it pays there only when a split still covers >= 16 chunks (measured: 256 -> 512 stride 2 at M = 134 400
@@ -1953,18 +1995,38 @@ int64_t utv2_conv2d_wgrad_bf16_workspace_floats(int M, int K, int Kred) {
 }
 
 // rowinfo: device int32[M][2] = {anchor input pixel, (W << 16) | tapmask} for every OUTPUT pixel m (built once per
-// geometry by the host).  x is `x_dtype` with C channels per pixel, dy is `dy_dtype` [M][K].  C % 8 == 0, K % 8 == 0,
-// KH*KW <= 16.  dw (+)= rowscale[co] * result; db (optional, [K]) (+)= rowscale[co] * column sums of dy; rowscale optional.
+// geometry by the host).  x is `x_dtype` with pixel pitch x_pitch elements, dy is `dy_dtype` [M][K].  C % 8 == 0, K % 8 == 0,
+// KH*KW <= 16.  dw [K][KH*KW*C] (+)= rowscale[co] * result; db (optional, [K]) (+)= rowscale[co] * column sums of dy; rowscale optional.
+// groups > 1: grouped conv - output channels [g*K/groups, ...) correlate with input channels [g*C, (g+1)*C) (C per group),
+// (K / groups) % 128 == 0, x_pitch >= groups * C.
+static int wgrad_bf16_impl(const void* x, int x_dtype, int x_pitch, const void* dy, int dy_dtype, int dy_pitch, float* dw, float* db,
+                           float* ws, const int* rowinfo, const float* rowscale, int M, int C, int K, int KH, int KW, int accumulate,
+                           int groups, hipStream_t stream);
+
 int utv2_conv2d_wgrad_bf16(const void* x, int x_dtype, const void* dy, int dy_dtype, float* dw, float* db, float* ws,
                            const int* rowinfo, const float* rowscale, int M, int C, int K, int KH, int KW, int accumulate,
                            hipStream_t stream) {
+  return wgrad_bf16_impl(x, x_dtype, C, dy, dy_dtype, K, dw, db, ws, rowinfo, rowscale, M, C, K, KH, KW, accumulate, 1, stream);
+}
+
+int utv2_conv2d_wgrad_bf16_g(const void* x, int x_dtype, int x_pitch, const void* dy, int dy_dtype, int dy_pitch, float* dw, float* db,
+                             float* ws, const int* rowinfo, const float* rowscale, int M, int C, int K, int KH, int KW, int accumulate,
+                             int groups, hipStream_t stream) {
+  return wgrad_bf16_impl(x, x_dtype, x_pitch, dy, dy_dtype, dy_pitch, dw, db, ws, rowinfo, rowscale, M, C, K, KH, KW, accumulate, groups,
+                         stream);
+}
+
+static int wgrad_bf16_impl(const void* x, int x_dtype, int x_pitch, const void* dy, int dy_dtype, int dy_pitch, float* dw, float* db,
+                           float* ws, const int* rowinfo, const float* rowscale, int M, int C, int K, int KH, int KW, int accumulate,
+                           int groups, hipStream_t stream) {
   if (!x || !dy || !dw || !ws || !rowinfo || (C & 7) || (K & 7) || M <= 0 || KH * KW > 16 || bad_dtype(x_dtype) ||
-      bad_dtype(dy_dtype))
+      bad_dtype(dy_dtype) || groups < 1 || K % groups || x_pitch < groups * C || (groups > 1 && (K / groups) % 128) ||
+      (x_pitch != C && (x_pitch & (x_dtype == UTV2_BF16 ? 7 : 3))) || dy_pitch < K || (dy_pitch != K && (dy_pitch & (dy_dtype == UTV2_BF16 ? 7 : 3))))
     return UTV2_EARG;
   Wgrad16Args a;
   a.x = x; a.dy = dy; a.ws = ws; a.rowinfo = (const int2*)rowinfo;
-  a.C = C; a.K = K; a.KH = KH; a.KW = KW; a.Kred = KH * KW * C; a.M = M; a.debug = 0;
-  if (g_use_wgrad_w8 && x_dtype == UTV2_BF16 && dy_dtype == UTV2_BF16 && wgrad16_w8_shape_ok(M, C, K, KH, KW)) {
+  a.C = C; a.K = K; a.KH = KH; a.KW = KW; a.Kred = KH * KW * C; a.M = M; a.debug = 0; a.xs = x_pitch; a.groups = groups; a.dys = dy_pitch;
+  if (g_use_wgrad_w8 && x_dtype == UTV2_BF16 && dy_dtype == UTV2_BF16 && dy_pitch == K && wgrad16_w8_shape_ok(M, C, K, KH, KW, x_pitch, groups)) {
     a.splits = wgrad16_w8_splits(M, K, a.Kred);
     a.chunks_per_split = cdiv(cdiv(M, WGRAD_W8_BP), a.splits);
     a.bias_ws = nullptr;

@@ -815,15 +815,33 @@ def conv2d_dgrad_bf16(dy, wt16, in_shape, stride, pad, kh, kw, out=None, out_dty
     return out
 
 
+def _rows_ptr(t):
+    """pointer + row pitch of a [rows, cols] matrix whose rows are contiguous runs (a column slice of a wider matrix is fine)"""
+    assert t.is_cuda and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1], "row-major matrix (or a column slice of one) expected"
+    return c_p(t.data_ptr()), int(t.stride(0))
+
+
 def conv2d_ml_fwd_bf16(x2d, w16, level_hw, N, scale=None, bias=None, residual=None, k=3, pad=1, relu=False, out=None,
-                       out_dtype=None):
-    P, C = x2d.shape
+                       out_dtype=None, groups=1):
+    """x2d [P, groups*C] (may be a column slice of a wider matrix); groups > 1: grouped conv, w16 [K, k*k*C] with K/groups output
+    channels per group; out (optional) may be a column slice too (then residual must be None)."""
+    P = x2d.shape[0]
+    C = x2d.shape[1] // groups
     K = w16.shape[0]
+    assert w16.shape[1] == k * k * C, (tuple(w16.shape), k, C)
     if out is None:
         out = torch.empty((P, K), dtype=_act_dtype(x2d, out_dtype), device=x2d.device)
     H = _iarr([h for h, _ in level_hw]); W = _iarr([w_ for _, w_ in level_hw])
-    call("utv2_conv2d_ml_fwd_bf16", _p(x2d), _dt(x2d), _p(w16), _p(out), _same_dt(out, residual), _p(scale), _p(bias), _p(residual),
-         len(level_hw), ctypes.cast(H, c_p), ctypes.cast(W, c_p), N, C, K, k, k, pad, int(relu), 0, _stream())
+    xp, xpitch = _rows_ptr(x2d)
+    yp, ypitch = _rows_ptr(out)
+    if groups == 1 and xpitch == C and ypitch == K:
+        call("utv2_conv2d_ml_fwd_bf16", xp, _dt(x2d), _p(w16), yp, _same_dt(out, residual), _p(scale), _p(bias), _p(residual),
+             len(level_hw), ctypes.cast(H, c_p), ctypes.cast(W, c_p), N, C, K, k, k, pad, int(relu), 0, _stream())
+    else:
+        assert residual is None or (residual.stride(0) == ypitch and residual.stride(1) == 1)
+        call("utv2_conv2d_ml_fwd_bf16_g", xp, _dt(x2d), xpitch, _p(w16), yp, _same_dt(out, residual), ypitch, _p(scale), _p(bias),
+             c_p(residual.data_ptr()) if residual is not None else c_p(0), len(level_hw), ctypes.cast(H, c_p), ctypes.cast(W, c_p), N, C, K,
+             k, k, pad, int(relu), 0, int(groups), _stream())
     return out
 
 
@@ -869,14 +887,23 @@ def rowinfo_ml(N, level_hw, pad, k, device):
     return t
 
 
-def conv2d_wgrad_bf16(x, dy2d, dw, rowinfo, C, kh, kw, accumulate=True, db=None, rowscale=None):
-    """x: fp32/bf16 activations (any layout consistent with rowinfo), dy2d [M,K] fp32/bf16; dw [K, kh*kw*C] (+)= wgrad;
-    db [K] (optional) (+)= column sums of dy (bias gradient, fused into the dY staging)."""
+def conv2d_wgrad_bf16(x, dy2d, dw, rowinfo, C, kh, kw, accumulate=True, db=None, rowscale=None, groups=1, x_pitch=None):
+    """x: fp32/bf16 activations (any layout consistent with rowinfo; x_pitch = elements between consecutive pixels when x is a channel
+    slice of a wider matrix), dy2d [M,K] fp32/bf16 (may be the leading K columns of a wider, zero-padded matrix); dw [K, kh*kw*C] (+)=
+    wgrad (C = input channels per group); db [K] (optional) (+)= column sums of dy (bias gradient, fused into the dY staging)."""
     M, K = dy2d.shape
+    assert dy2d.stride(1) == 1
+    dy_pitch = int(dy2d.stride(0))
     nws = load().utv2_conv2d_wgrad_bf16_workspace_floats(M, K, kh * kw * C)
     ws = workspace(nws, dy2d.device, "wgrad")
-    call("utv2_conv2d_wgrad_bf16", _p(x), _dt(x), _p(dy2d), _dt(dy2d), _p(dw), _p(db), _p(ws), _p(rowinfo), _p(rowscale), M, C, K, kh,
-         kw, int(accumulate), _stream())
+    if groups == 1 and (x_pitch is None or x_pitch == C) and dy_pitch == K:
+        call("utv2_conv2d_wgrad_bf16", _p(x), _dt(x), _p(dy2d), _dt(dy2d), _p(dw), _p(db), _p(ws), _p(rowinfo), _p(rowscale), M, C, K, kh,
+             kw, int(accumulate), _stream())
+    else:
+        xp = c_p(x.data_ptr())
+        pitch = int(x_pitch) if x_pitch is not None else groups * C
+        call("utv2_conv2d_wgrad_bf16_g", xp, _dt(x), pitch, c_p(dy2d.data_ptr()), _dt(dy2d), dy_pitch, _p(dw), _p(db), _p(ws), _p(rowinfo),
+             _p(rowscale), M, C, K, kh, kw, int(accumulate), int(groups), _stream())
     return dw
 
 

@@ -263,7 +263,54 @@ class FCOSHead:
         C = in_channels
         self.C = C
         self.towers = {}
+        # The cls and the bbox tower are two independent chains of identical 3x3 256 -> 256 convs + GroupNorm(32) + ReLU
+        # (fcos/fcos.py:252-304).  Equal depth, no shared tower (every shipped config): they are built PAIRED - depth i of both is one
+        # [2C, 9C] weight (rows [0, C) = cls_tower.{3i}, rows [C, 2C) = bbox_tower.{3i}; state_dict() exposes the reference's tensors),
+        # one conv launch over a [P, 2C] activation (depth 0: a plain C -> 2C conv of the shared FPN feature, deeper: a grouped conv,
+        # groups = 2) and one GroupNorm(64) launch set.  Against two chains: half the launches, ONE tile-quantisation remainder per
+        # depth instead of two (the 256-tile kernel runs whole rounds of 256 tiles; 2 x 1050 tiles = 8 rounds + 52 instead of
+        # 2 x (4 rounds + 26)), half the split-K slabs of the weight gradients (18 tiles x 14 pixel splits instead of 2 x 9 x 28), and the
+        # two gradients of the FPN feature are summed inside depth 0's dgrad K loop instead of by an add pass.
+        self.paired = fc.NUM_CLS_CONVS == fc.NUM_BOX_CONVS and fc.NUM_SHARE_CONVS == 0 and fc.NUM_CLS_CONVS > 0
+        if self.paired:
+            n = fc.NUM_CLS_CONVS
+            ws = []
+            layers = []
+            for i in range(n):
+                pc, pb = "%s.cls_tower.%d" % (prefix, 3 * i), "%s.bbox_tower.%d" % (prefix, 3 * i)
+                w = store.new((2 * C, 9 * C), "decay", None)
+                w.export(pc + ".weight", lambda t: t[:C].view(C, 3, 3, C).permute(0, 3, 1, 2))
+                w.export(pb + ".weight", lambda t: t[C:].view(C, 3, 3, C).permute(0, 3, 1, 2))
+                ws.append(w)
+                b = store.new((2 * C,), "decay", lambda t: t.zero_())
+                b.export(pc + ".bias", lambda t: t[:C]).export(pb + ".bias", lambda t: t[C:])
+                conv = ops.Conv(w, C, 2 * C, 3, 1, 1, bias=b, groups=1 if i == 0 else 2)
+                gc, gb = "%s.cls_tower.%d" % (prefix, 3 * i + 1), "%s.bbox_tower.%d" % (prefix, 3 * i + 1)
+                ga = store.new((2 * C,), "nodecay", lambda t: t.fill_(1.0))
+                ga.export(gc + ".weight", lambda t: t[:C]).export(gb + ".weight", lambda t: t[C:])
+                be = store.new((2 * C,), "nodecay", lambda t: t.zero_())
+                be.export(gc + ".bias", lambda t: t[:C]).export(gb + ".bias", lambda t: t[C:])
+                layers.append(ops.pair_conv_gn(conv, ops.GroupNormReLU(ga, be, 64, 1e-5, True)))
+
+            def init_all(_t):
+                # the reference's module order (cls tower first, then the bbox tower): the random stream of the initialisation - and with
+                # it every seeded golden - is the one of two separate towers
+                for half in (0, 1):
+                    for w in ws:
+                        w.t[half * C:(half + 1) * C].normal_(0.0, 0.01)
+            ws[0].init = init_all
+            self.towers["pair"] = layers
+            order = []
+            for name in ("cls", "bbox"):
+                for i in range(n):
+                    order += ["%s.%s_tower.%d.weight" % (prefix, name, 3 * i), "%s.%s_tower.%d.bias" % (prefix, name, 3 * i),
+                              "%s.%s_tower.%d.weight" % (prefix, name, 3 * i + 1), "%s.%s_tower.%d.bias" % (prefix, name, 3 * i + 1)]
+            store.order_keys(order)
         for name, nconv in (("cls", fc.NUM_CLS_CONVS), ("bbox", fc.NUM_BOX_CONVS), ("share", fc.NUM_SHARE_CONVS)):
+            if self.paired:
+                self.towers[name] = []
+                continue
+
             layers = []
             for i in range(nconv):
                 p = "%s.%s_tower.%d" % (prefix, name, 3 * i)
@@ -314,14 +361,19 @@ class FCOSHead:
         """big: level-first [P, C] features of all levels; ONE launch per conv for all levels.
         Returns dict(logits [P,80], box [P,80], meta)."""
         t = big
-        for conv, gn in self.towers["share"]:
-            t = gn(conv(t, meta=meta), meta)
-        tc = t
-        for conv, gn in self.towers["cls"]:
-            tc = gn(conv(tc, meta=meta), meta)
-        tb = t
-        for conv, gn in self.towers["bbox"]:
-            tb = gn(conv(tb, meta=meta), meta)
+        if self.paired:
+            for conv, gn in self.towers["pair"]:
+                t = gn(conv(t, meta=meta), meta)          # [P, 2C]: cls | bbox
+            tc, tb = ops.split_cols(t)                    # column-half views (row pitch 2C): the prediction convs read them in place
+        else:
+            for conv, gn in self.towers["share"]:
+                t = gn(conv(t, meta=meta), meta)
+            tc = t
+            for conv, gn in self.towers["cls"]:
+                tc = gn(conv(tc, meta=meta), meta)
+            tb = t
+            for conv, gn in self.towers["bbox"]:
+                tb = gn(conv(tb, meta=meta), meta)
         logits = self.cls_logits(tc, meta=meta)
         box = self.box_head(tb, meta=meta, colscale_handle=self.scales)
         return {"logits": logits, "box": box, "meta": meta}

@@ -156,6 +156,7 @@ class FlipBank:
         self.bank = torch.empty(total, dtype=torch.bfloat16, device=dev)
         self.scales = None
         rec = bytearray()
+        self.nrec = 0
         for (layer, sc), o in zip(self.layers, offs):
             so = -1
             if sc is not None:
@@ -163,9 +164,21 @@ class FlipBank:
                     self.scales = torch.empty(0, dtype=torch.float32, device=dev).set_(sc.untyped_storage())
                 assert sc.untyped_storage().data_ptr() == self.scales.untyped_storage().data_ptr()
                 so = sc.storage_offset()
-            rec += struct.pack("<qqqiiiiii", layer.w.offset, o, so, layer.cout, layer.k, layer.k, layer.cin, layer.dgrad_cout(), 0)
+            G = layer.groups
+            if G == 1:
+                rec += struct.pack("<qqqiiiiii", layer.w.offset, o, so, layer.cout, layer.k, layer.k, layer.cin, layer.dgrad_cout(), 0)
+                self.nrec += 1
+            else:
+                # a grouped layer is `groups` independent [Kg][k][k][cin] blocks of consecutive weight rows; their images are stacked:
+                # row (g * cin + ci) of the [groups * cin][k * k * Kg] image serves input channel ci of group g
+                assert sc is None and layer.dgrad_cout() == layer.cout
+                Kg = layer.cout // G
+                for gi in range(G):
+                    rec += struct.pack("<qqqiiiiii", layer.w.offset + gi * Kg * layer.kred, o + gi * layer.cin * layer.k * layer.k * Kg, -1,
+                                       Kg, layer.k, layer.k, layer.cin, Kg, 0)
+                    self.nrec += 1
         self.table = torch.frombuffer(rec, dtype=torch.uint8).clone().to(dev)
-        self.views = [self.bank[o:o + l.dgrad_cout() * l.k * l.k * l.cin].view(l.cin, l.k * l.k * l.dgrad_cout())
+        self.views = [self.bank[o:o + l.dgrad_cout() * l.k * l.k * l.cin].view(l.groups * l.cin, l.k * l.k * l.dgrad_cout() // l.groups)
                       for (l, _), o in zip(self.layers, offs)]
         self.dirty = False
         self.single.clear()
@@ -183,12 +196,17 @@ class FlipBank:
             # first request after the arena changed: refresh every registered layer in one launch
             if self.dirty or self.bank is None:
                 self._rebuild()
-            hip.weight_flip_transpose_bf16_batched(self.store.flat, self.scales, self.bank, self.table, len(self.layers))
+            hip.weight_flip_transpose_bf16_batched(self.store.flat, self.scales, self.bank, self.table, self.nrec)
             self.version = cur
             return self.views[self.slot[id(layer)]]
         ent = self.single.get(id(layer))
         if ent is None or ent[0] != cur:
-            img = hip.weight_flip_transpose_bf16(layer.w.t, layer.cout, layer.k, layer.k, layer.cin, scale)
+            if layer.groups > 1:
+                Kg = layer.cout // layer.groups
+                img = torch.cat([hip.weight_flip_transpose_bf16(layer.w.t[gi * Kg:(gi + 1) * Kg], Kg, layer.k, layer.k, layer.cin, None)
+                                 for gi in range(layer.groups)])
+            else:
+                img = hip.weight_flip_transpose_bf16(layer.w.t, layer.cout, layer.k, layer.k, layer.cin, scale)
             if layer.dgrad_cout() != layer.cout:   # first request of a padded layer only: later ones come from the batched launch
                 img = torch.nn.functional.pad(img.view(layer.cin, layer.k * layer.k, layer.cout), (0, layer.dgrad_cout() - layer.cout)) \
                     .reshape(layer.cin, -1).contiguous()
@@ -201,9 +219,14 @@ class Conv:
     """One convolution (+ optional folded FrozenBN or bias, ReLU, residual) bound to arena handles."""
 
     def __init__(self, w, cin, cout, k, stride=1, pad=0, bias=None, bn=None, relu=False, trainable=True,
-                 kred=None, colscale=None, out_fp32=False):
+                 kred=None, colscale=None, out_fp32=False, groups=1):
         self.w = w  # Handle, shape [cout, kred]
         self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
+        # groups > 1 (level-first k x k convs only): output channels [g*cout/groups, ...) read input channels [g*cin, (g+1)*cin) of a
+        # [P, groups*cin] matrix; cin / kred are PER GROUP.  Two independent same-shape chains (the FCOS cls / bbox towers) run as ONE
+        # launch per depth this way - half the launches, tile-quantisation remainders and split-K slabs of two separate convs.
+        self.groups = groups
+        assert groups == 1 or (bn is None and colscale is None and cout % groups == 0)
         self.bias = bias  # Handle [cout] or None
         self.bn = bn  # FrozenBN or None
         self.relu = relu
@@ -268,7 +291,8 @@ class Conv:
         """x: NHWC tensor, or a level-first [P, C] matrix with `meta` (one launch for all levels; k x k
         'same' convs only).  colscale_handle: a Handle, or one Handle per level when `meta` is given."""
         if torch.is_grad_enabled() and self.trainable:
-            return _ConvFn.apply(x, residual, hook(x.device), self, (out, getattr(x, "_utv2_fanin", None)), colscale_handle, meta)
+            return _ConvFn.apply(x, residual, hook(x.device), self, (out, getattr(x, "_utv2_fanin", None), getattr(x, "_utv2_pair", None)),
+                                 colscale_handle, meta)
         return self._forward(x, residual, out, colscale_handle, meta)
 
     def _forward(self, x, residual, out, cs, meta):
@@ -280,11 +304,23 @@ class Conv:
             kw["out_dtype"] = out.dtype if out is not None else (torch.float32 if self.out_fp32 else torch.bfloat16)
         else:
             assert x.dtype == torch.float32, "the fp32 conv kernels take fp32 activations (layer cin=%d)" % self.cin
+        if not b16 and not x.is_contiguous():
+            x = x.contiguous()      # a column slice of a paired tower's output: the fp32 kernels take dense matrices
+        if self.groups > 1:
+            assert meta is not None and self.k > 1 and residual is None and out is None and cs is None
         if meta is not None and self.k > 1:
             assert self.stride == 1 and self.pad == (self.k - 1) // 2
-            fn = hip.conv2d_ml_fwd_bf16 if b16 else hip.conv2d_ml_fwd
-            y = fn(x, w, meta.level_hw, meta.N, scale=sc, bias=sh, residual=residual, k=self.k, pad=self.pad, relu=self.relu, out=out,
-                   **kw)
+            if b16:
+                y = hip.conv2d_ml_fwd_bf16(x, w, meta.level_hw, meta.N, scale=sc, bias=sh, residual=residual, k=self.k, pad=self.pad,
+                                           relu=self.relu, out=out, groups=self.groups, **kw)
+            elif self.groups > 1:   # exact-f32 mode: one dense conv per group (the fp32 kernel has no grouped form)
+                Kg = self.cout // self.groups
+                y = torch.cat([hip.conv2d_ml_fwd(x[:, gi * self.cin:(gi + 1) * self.cin].contiguous(), w[gi * Kg:(gi + 1) * Kg], meta.level_hw,
+                                                 meta.N, scale=None, bias=None if sh is None else sh[gi * Kg:(gi + 1) * Kg], k=self.k,
+                                                 pad=self.pad, relu=self.relu) for gi in range(self.groups)], dim=1)
+            else:
+                y = hip.conv2d_ml_fwd(x, w, meta.level_hw, meta.N, scale=sc, bias=sh, residual=residual, k=self.k, pad=self.pad,
+                                      relu=self.relu, out=out, **kw)
         elif meta is not None:  # 1x1 on a level-first matrix: plain GEMM rows
             fn = hip.conv2d_fwd_bf16 if b16 else hip.conv2d_fwd
             y = fn(x.view(1, x.shape[0], 1, x.shape[1]), w, scale=sc, bias=sh,
@@ -319,6 +355,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, y if (layer.relu or cs is not None) else None)
         ctx.xshape = tuple(x.shape)
         ctx.fanin = out_holder[1] if len(out_holder) > 1 else None   # FanIn: another consumer's gradient of x, added in this dgrad's epilogue
+        ctx.pair = out_holder[2] if len(out_holder) > 2 else None    # (ColPair, half): x is a column half of a paired tower's output
         return y
 
     @staticmethod
@@ -326,6 +363,8 @@ class _ConvFn(torch.autograd.Function):
         layer = ctx.layer
         x, y = ctx.saved_tensors
         dy = dy.contiguous()
+        if not x.is_contiguous() and not (layer.use_bf16_wgrad() and layer.use_bf16_dgrad()):
+            x = x.contiguous()   # a column slice (paired towers) in exact-f32 mode: the fp32 kernels take dense matrices
         sc, _ = layer.scale_shift()
         meta = ctx.meta
         if ctx.cs is not None:
@@ -361,21 +400,40 @@ class _ConvFn(torch.autograd.Function):
         dx = None
         bias_done = False
         if meta is not None and layer.k > 1:
+            G = layer.groups
+            Kg = layer.cout // G
             if ctx.needs_input_grad[0]:
                 if d16:
                     gp = g if layer.dgrad_cout() == layer.cout else hip.pad_cols_bf16(g, layer.dgrad_cout())
                     other = ctx.fanin.take() if ctx.fanin is not None else None
                     if other is not None and (other.dtype != x.dtype or tuple(other.shape) != tuple(x.shape)):
                         raise RuntimeError("FanIn: stored gradient does not match the conv input")
+                    # x a column half of a paired tower's output: the gradient is written straight into its half of ONE [P, 2C] buffer
+                    # (row pitch 2C), which ColPair's backward hands on as the gradient of the whole matrix - no cat pass
+                    dest = ctx.pair[0].grad_half(ctx.pair[1], x) if (ctx.pair is not None and other is None) else None
                     dx = hip.conv2d_ml_fwd_bf16(gp, layer.wt16(wsc), meta.level_hw, meta.N, k=layer.k, pad=layer.k - 1 - layer.pad,
-                                                residual=other, out_dtype=x.dtype)
+                                                residual=other, out_dtype=x.dtype, out=dest, groups=G)
+                elif G > 1:
+                    dx = torch.cat([hip.conv2d_ml_dgrad(g[:, gi * Kg:(gi + 1) * Kg].contiguous(),
+                                                        hip.weight_flip_transpose(layer.w.t[gi * Kg:(gi + 1) * Kg], Kg, layer.k, layer.k, layer.cin),
+                                                        meta.level_hw, meta.N, layer.k, layer.pad) for gi in range(G)], dim=1)
                 else:
                     dx = hip.conv2d_ml_dgrad(g, layer.wt(), meta.level_hw, meta.N, layer.k, layer.pad)
             if layer.use_bf16_wgrad():
+                # the 80-channel prediction convs: the weight gradient reads the zero-padded bf16 copy of the gradient the dgrad was given
+                # (its leading `cout` columns; the same RNE-rounded values the kernel would make of the fp32 gradient while staging it -
+                # identical results from 60 % of the bytes and no conversion work in the staging loop)
+                gw = gp[:, :layer.cout] if (d16 and ctx.needs_input_grad[0] and gp is not g) else g
                 _wgrad_launch(lambda: hip.conv2d_wgrad_bf16(
-                    x, g, layer.w.g, hip.rowinfo_ml(meta.N, meta.level_hw, layer.pad, layer.k, x.device), layer.cin, layer.k, layer.k,
-                    accumulate=True, db=layer.bias.g if (layer.bias is not None and not layer.bias_grad_from_gn()) else None, rowscale=wsc), x, g)
+                    x, gw, layer.w.g, hip.rowinfo_ml(meta.N, meta.level_hw, layer.pad, layer.k, x.device), layer.cin, layer.k, layer.k,
+                    accumulate=True, db=layer.bias.g if (layer.bias is not None and not layer.bias_grad_from_gn()) else None, rowscale=wsc,
+                    groups=G, x_pitch=x.stride(0)), x, gw)
                 bias_done = True
+            elif G > 1:
+                for gi in range(G):
+                    xg, gg = x[:, gi * layer.cin:(gi + 1) * layer.cin].contiguous(), g[:, gi * Kg:(gi + 1) * Kg].contiguous()
+                    _wgrad_launch(lambda xg=xg, gg=gg, gi=gi: hip.conv2d_ml_wgrad(xg, gg, layer.w.g[gi * Kg:(gi + 1) * Kg], meta.level_hw, meta.N,
+                                                                                   layer.k, layer.pad, accumulate=True), xg, gg)
             else:
                 _wgrad_launch(lambda: hip.conv2d_ml_wgrad(x, g, layer.w.g, meta.level_hw, meta.N, layer.k, layer.pad, accumulate=True), x, g)
         else:
@@ -513,6 +571,60 @@ def bottleneck(block, x):
     out = block.conv1(x)
     out = block.conv2(out)
     return block.conv3(out, residual=sc)
+
+
+class ColPair:
+    """The two column halves of a [P, 2C] matrix (the paired towers' output: cls | bbox) as separate autograd tensors for their two
+    consumers, without a cat pass in the backward: each consumer's dgrad writes its half of ONE [P, 2C] gradient buffer (row pitch 2C,
+    `Conv` asks grad_half() for the destination) and the split's backward recognises the two halves and returns the buffer itself."""
+
+    def __init__(self):
+        self.buf = None
+
+    def grad_half(self, idx, x):
+        if self.buf is None:
+            self.buf = torch.empty((x.shape[0], 2 * x.shape[1]), dtype=x.dtype, device=x.device)
+        C = x.shape[1]
+        return self.buf[:, idx * C:(idx + 1) * C]
+
+    def take(self, g0, g1):
+        b, self.buf = self.buf, None
+        if (b is not None and g0 is not None and g1 is not None and g0.dtype == b.dtype and g0.data_ptr() == b.data_ptr()
+                and g1.data_ptr() == b.data_ptr() + g0.shape[1] * b.element_size() and g0.stride(0) == b.stride(0) == g1.stride(0)):
+            return b
+        return None
+
+
+class _SplitColsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, pair):
+        C = t.shape[1] // 2
+        ctx.pair, ctx.C = pair, C
+        ctx.meta_ = (t.dtype, t.device, t.shape[0])
+        return t[:, :C], t[:, C:]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        b = ctx.pair.take(g0, g1)
+        if b is not None:
+            return b, None
+        dt, dev, P = ctx.meta_
+        z = None
+        if g0 is None or g1 is None:
+            z = torch.zeros((P, ctx.C), dtype=dt, device=dev)
+        return torch.cat((g0 if g0 is not None else z, g1 if g1 is not None else z), dim=1), None
+
+
+def split_cols(t):
+    """(left half, right half) column views of t [P, 2C]; under autograd the halves carry `_utv2_pair` so that the level-first convs that
+    consume them write their input gradients into one shared buffer (ColPair)"""
+    C = t.shape[1] // 2
+    if not (torch.is_grad_enabled() and t.requires_grad):
+        return t[:, :C], t[:, C:]
+    pair = ColPair()
+    a, b = _SplitColsFn.apply(t, pair)
+    a._utv2_pair, b._utv2_pair = (pair, 0), (pair, 1)
+    return a, b
 
 
 def pair_conv_gn(conv, gn):

@@ -51,6 +51,14 @@ class ParamStore:
     def __init__(self):
         self.handles = []
         self.finalized = False
+        self.key_orders = []   # lists of state_dict keys whose RELATIVE order is fixed (see order_keys)
+
+    def order_keys(self, keys):
+        """state_dict() lists keys in handle-creation order; handles that fuse tensors of several reference modules (the paired FCOS
+        towers: cls_tower.* and bbox_tower.* rows of one matrix) would interleave their keys.  `keys` = those keys in the reference's
+        module order: state_dict() keeps the slots they occupy and fills them in this order (checkpoints and the step goldens'
+        fingerprint tables list keys in the reference's order)."""
+        self.key_orders.append(list(keys))
 
     def new(self, shape, kind, init=None):
         assert not self.finalized
@@ -115,11 +123,17 @@ class ParamStore:
 
     # ---- state_dict surface ------------------------------------------------------------
     def state_dict(self):
-        sd = OrderedDict()
+        items = []
         for h in self.handles:
             for key, fn in h.exports:
-                sd[key] = h.t if fn is None else fn(h.t)
-        return sd
+                items.append((key, h.t if fn is None else fn(h.t)))
+        for order in self.key_orders:
+            pos = {k: i for i, (k, _) in enumerate(items)}
+            slots = sorted(pos[k] for k in order)
+            vals = [items[pos[k]] for k in order]
+            for i, v in zip(slots, vals):
+                items[i] = v
+        return OrderedDict(items)
 
     def trainable_named(self):
         out = OrderedDict()
