@@ -78,11 +78,13 @@ int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y
 /* The same over column slices and / or GROUPED (the paired FCOS towers - cls | bbox, two independent 256 -> 256 chains of
  * fcos/fcos.py:252-304 - run as ONE launch per depth): x has row pitch x_pitch elements and group g reads its channels
  * [g*C, (g+1)*C) (C = input channels PER GROUP), w16 = bf16 [K][KH*KW*C], y / residual have row pitch y_pitch >= K.
- * Anything but (groups 1, x_pitch C, y_pitch K) needs bf16 x, C % 32 == 0, K % 4 == 0, pitches % 8 == 0, (K / groups) % 128 == 0. */
+ * Anything but (groups 1, x_pitch C, y_pitch K) needs bf16 x, C % 32 == 0, K % 4 == 0, pitches % 8 == 0, (K / groups) % 128 == 0.
+ * gn_part (optional; bf16 y, K % 8 == 0): fp32 [ceil(P / 32)][K / 8][2] - per 32-row block and 8-channel group the sum and the sum of
+ * squares of y as stored: the statistics pass of the GroupNorm that consumes y (fcos/fcos.py:263-264), see ..._seg_fwd_p32. */
 int utv2_conv2d_ml_fwd_bf16_g(const void* x, int x_dtype, int x_pitch, const void* w16, void* y, int y_dtype, int y_pitch,
                               const float* scale, const float* bias, const void* residual, int nlev, const int* H_host,
                               const int* W_host, int N, int C, int K, int KH, int KW, int pad, int relu, int accumulate, int groups,
-                              utv2_stream_t stream);
+                              float* gn_part, utv2_stream_t stream);
 /* bf16 wgrad (+ fused bias gradient); rowinfo = device int32[M][2] per OUTPUT pixel:
  * {input pixel index of tap (0,0), (W << 16) | mask of the taps that fall inside the image}; KH*KW <= 16 */
 int utv2_conv2d_wgrad_bf16_splits(int M, int K, int Kred);
@@ -155,6 +157,11 @@ int64_t utv2_groupnorm_seg_workspace_floats(int nseg, const int* seg_rows_host, 
 int utv2_groupnorm_relu_seg_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                 float* ws, int nseg, const int* seg_rows_host, int C, int G, float eps, int relu, int dtype,
                                 utv2_stream_t stream);
+/* the same for bf16 x with 8 channels per group when the conv that produced x left the statistics partials in part32
+ * (utv2_conv2d_ml_fwd_bf16_g gn_part: fp32 [ceil(rows / 32)][G][2]): one tensor pass less */
+int utv2_groupnorm_relu_seg_fwd_p32(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                    const float* part32, int nseg, const int* seg_rows_host, int C, int G, float eps, int relu,
+                                    utv2_stream_t stream);
 /* beta (optional): the ReLU mask is recomputed from x with the forward expression instead of read from y (y may be null) */
 int utv2_groupnorm_relu_seg_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
                                 const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, float* ws,

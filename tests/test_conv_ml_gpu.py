@@ -141,3 +141,41 @@ def test_grouped_and_pitched_ml_conv_bf16(level_hw, N):
     hip.conv2d_wgrad_bf16(x[:, C:], dy80, d1, ri, C, 3, 3, accumulate=True, x_pitch=2 * C)
     hip.conv2d_wgrad_bf16(xb, dy80, d2, ri, C, 3, 3, accumulate=True)
     assert torch.equal(d1, d2)
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_groupnorm_statistics_from_the_conv_epilogue(groups):
+    """A tower conv under AMP leaves per-(32-row block, 8-channel group) sum / sum of squares of its stored bf16 output
+    (utv2_conv2d_ml_fwd_bf16_g gn_part); the GroupNorm that follows (fcos/fcos.py:263-264) takes mean / rstd from them plus the few
+    segment-edge rows (utv2_groupnorm_relu_seg_fwd_p32) instead of a statistics pass over the tensor: same mean / rstd to fp32
+    summation order, same normalised output to one bf16 rounding - with segments that start off the 32-row grid, on the 128-tile
+    kernel and on the 256-tile kernel + its remainder."""
+    from ubteacher import hip
+    from ubteacher.ops import LevelMeta
+    g = torch.Generator().manual_seed(11)
+    C = 256
+    for level_hw, N in (([(20, 24), (10, 12), (5, 6), (3, 3), (2, 2)], 3), ([(128, 160), (64, 80), (7, 11)], 2)):
+        meta = LevelMeta(N, level_hw)
+        P, K = meta.P, 2 * C
+        x = (torch.randn(P, groups * C, generator=g) * 0.5).to(torch.bfloat16).cuda()
+        w = (torch.randn(K, 9 * C, generator=g) * 0.02).to(torch.bfloat16).cuda()
+        b = torch.randn(K, generator=g).cuda()
+        ga, be = (torch.rand(K, generator=g) + 0.5).cuda(), torch.randn(K, generator=g).cuda()
+        part = hip.gn_part_buffer(P, K, "cuda")
+        part.fill_(float("nan"))
+        y = hip.conv2d_ml_fwd_bf16(x, w, level_hw, N, bias=b, k=3, pad=1, groups=groups, gn_part=part)
+        y0 = hip.conv2d_ml_fwd_bf16(x, w, level_hw, N, bias=b, k=3, pad=1, groups=groups)
+        assert torch.equal(y, y0)
+        # every block that holds a row was written, and equals the sums of the stored tensor
+        yf = y.float()
+        nb = (P + 31) // 32
+        pad = torch.zeros(nb * 32 - P, K, device="cuda")
+        blk = torch.cat((yf, pad)).view(nb, 32, K // 8, 8)
+        ref_s, ref_q = blk.sum(dim=(1, 3)), (blk * blk).sum(dim=(1, 3))
+        assert torch.isfinite(part).all()
+        assert torch.allclose(part[:, :, 0], ref_s, rtol=1e-5, atol=1e-3) and torch.allclose(part[:, :, 1], ref_q, rtol=1e-5, atol=1e-3)
+        z1, m1, r1 = hip.groupnorm_relu_seg_fwd_p32(y, meta.seg_rows, ga, be, part, K // 8)
+        z0, m0, r0 = hip.groupnorm_relu_seg_fwd(y, meta.seg_rows, ga, be, K // 8)
+        assert torch.allclose(m1, m0, rtol=1e-5, atol=1e-6) and torch.allclose(r1, r0, rtol=1e-5)
+        d = (z1.float() - z0.float()).abs()
+        assert float(d.max()) <= 2 ** -7 * float(z0.float().abs().max()) and float((d > 0).float().mean()) < 1e-3

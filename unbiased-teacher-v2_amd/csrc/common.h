@@ -80,7 +80,12 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
                                               const float* __restrict__ scale, const float* __restrict__ bias,
                                               const TO* __restrict__ residual, int relu, int accumulate, int m_base,
                                               int co_base, int M, int K, const TO* __restrict__ mask = nullptr,
-                                              const TO* __restrict__ post_mask = nullptr, int ldy = 0) {
+                                              const TO* __restrict__ post_mask = nullptr, int ldy = 0,
+                                              float* __restrict__ gn_part = nullptr) {
+  // gn_part (optional, bf16 outputs with K % 8 == 0): fp32 [ceil(M / 32)][K / 8][2] - per 32-row block and 8-channel group the sum and
+  // the sum of squares of the values AS STORED (after the bf16 rounding): the statistics pass of the GroupNorm(8 channels per group)
+  // that consumes this conv's output (fcos/fcos.py:263-264), taken while the rows are in registers.  m_base is a multiple of 32; rows
+  // >= M contribute nothing; fixed reduction order (deterministic).
   // ldy (optional): elements between consecutive rows of y / residual / mask / post_mask (0 = K); y may be a column slice of a wider
   // matrix (the operands that share y's shape share its pitch)
   const int LDY = ldy > 0 ? ldy : K;
@@ -124,6 +129,7 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    float gs = 0.f, gq = 0.f;   // this lane's share of the block's group statistics (gn_part)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -173,6 +179,13 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
 #pragma unroll
             for (int q = 0; q < 8; ++q) o[q] = (__bf16)v[q >> 2][q & 3];
             *(bf16x8_t*)(y + off) = o;
+            if (gn_part) {
+              float f[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) f[q] = (float)o[q];
+              gs += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+              gq += ((f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3])) + ((f[4] * f[4] + f[5] * f[5]) + (f[6] * f[6] + f[7] * f[7]));
+            }
             continue;
           }
         }
@@ -197,6 +210,21 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
           }
           if (accumulate) v[h] += ld4(y, o4);
           st4(y, o4, v[h]);
+        }
+      }
+    }
+    if constexpr (NQ == 2) {
+      if (gn_part && full) {   // lanes cv, cv + CV, ... hold the row parts of channel group co / 8: fixed-order butterfly, lane rsub == 0 writes
+#pragma unroll
+        for (int d = CV; d < 64; d <<= 1) {
+          gs += __shfl_xor(gs, d, 64);
+          gq += __shfl_xor(gq, d, 64);
+        }
+        const int mb = m_base + i * 32;
+        if (rsub == 0 && mb < M) {
+          float* dst = gn_part + ((size_t)(mb >> 5) * (K >> 3) + (co >> 3)) * 2;
+          dst[0] = gs;
+          dst[1] = gq;
         }
       }
     }

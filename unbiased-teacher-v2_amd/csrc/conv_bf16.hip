@@ -48,6 +48,7 @@ struct ConvArgs16 {
                              // (C = channels PER GROUP, Kred = KH*KW*C, xs >= groups*C); the tile width divides K/groups.  The paired
                              // FCOS towers (cls | bbox, two independent 256 -> 256 chains) run as ONE launch per depth this way.
   int ldy;                   // elements between consecutive rows of y / residual / mask / post_mask (>= K: y may be a column slice)
+  float* gn_part;            // optional: per (32-row block, 8-channel group) sum / sum of squares of the stored output (see epilogue_rows)
 };
 
 __device__ __forceinline__ void ml_decode16(const LevelTab& lt, int m, int& pixbase, int& H, int& W, int& oh, int& ow) {
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
     // all MFMAs retired and every wave is past the last barrier of the K loop: the staging LDS is free
     float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
     epilogue_rows<TN, TO>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
-                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy);
+                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part);
     return;
   }
   TO* yo = (TO*)p.y;
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
     static_assert(sizeof(smem) >= 4 * 32 * ((BN / 2) + 4) * sizeof(float), "epilogue patches must fit the staging LDS");
     float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
     epilogue_rows<TN, TO>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
-                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy);
+                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part);
     return;
   }
   TO* yo = (TO*)p.y;
@@ -770,7 +771,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
 #pragma unroll
   for (int half = 0; half < 2; ++half)
     epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[2 * half], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
-                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy);
+                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1094,7 +1095,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
 #pragma unroll
   for (int half = 0; half < 2; ++half)
     epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[2 * half], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
-                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy);
+                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part);
 }
 
 // A/B switches for bench runs and tests, read ONCE per process (never on the launch path): UTV2_W8=0 keeps every forward / dgrad
@@ -1194,7 +1195,7 @@ int utv2_conv2d_nhwc_fwd_bf16(const void* x, int x_dtype, const void* w16, void*
   a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = mask; a.post_mask = post_mask;
   a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.K = K; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
   a.in_dil = in_dil < 1 ? 1 : in_dil; a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.M = N * OH * OW;
-  a.xs = C; a.m_begin = 0; a.groups = 1; a.ldy = K;
+  a.xs = C; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   if (small) launch_igemm16<64, false>(a, tiles, x_dtype, y_dtype, stream);
@@ -1206,14 +1207,17 @@ int utv2_conv2d_nhwc_fwd_bf16(const void* x, int x_dtype, const void* w16, void*
 //   x: row pitch x_pitch elements, the conv reads channels [g*C, (g+1)*C) of a row for group g (C = input channels PER GROUP);
 //   w16: bf16 [K][KH*KW*C]; y (and residual): row pitch y_pitch >= K.  x_pitch != C, y_pitch != K or groups > 1 need bf16 x with
 //   C % 32 == 0, K % 4 == 0 and (K / groups) % 128 == 0.
+//   gn_part (optional; bf16 y, K % 8 == 0): fp32 [ceil(P / 32)][K / 8][2], per 32-row block and 8-channel group the sum / sum of squares
+//   of y as stored - the statistics pass of the GroupNorm that follows (utv2_groupnorm_relu_seg_fwd_p32).
 int utv2_conv2d_ml_fwd_bf16_g(const void* x, int x_dtype, int x_pitch, const void* w16, void* y, int y_dtype, int y_pitch,
                               const float* scale, const float* bias, const void* residual, int nlev, const int* H_host,
                               const int* W_host, int N, int C, int K, int KH, int KW, int pad, int relu, int accumulate, int groups,
-                              hipStream_t stream) {
+                              float* gn_part, hipStream_t stream) {
+  if (gn_part && (y_dtype != UTV2_BF16 || (K & 7) || (y_pitch & 7) || x_dtype != UTV2_BF16 || (C % 32) || accumulate)) return UTV2_EARG;
   if (!x || !w16 || !y || nlev < 1 || nlev > CONV_MAX_LEVELS || (C % 8) || N <= 0 || bad_dtype(x_dtype) || bad_dtype(y_dtype) || groups < 1 ||
       K % groups || x_pitch < groups * C || y_pitch < K)
     return UTV2_EARG;
-  const bool plain = groups == 1 && x_pitch == C && y_pitch == K;
+  const bool plain = groups == 1 && x_pitch == C && y_pitch == K && !gn_part;
   if (!plain && (x_dtype != UTV2_BF16 || (C % 32) || (K & 3) || KH * KW > 16 || (x_pitch & 7) || (y_pitch & 7) ||
                  (groups > 1 && (K / groups) % 128)))
     return UTV2_EARG;
@@ -1222,7 +1226,7 @@ int utv2_conv2d_ml_fwd_bf16_g(const void* x, int x_dtype, int x_pitch, const voi
   if (!plain && ((int64_t)a.M * x_pitch >= (1ll << 31) || (int64_t)K * KH * KW * C >= (1ll << 31))) return UTV2_EARG;
   a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad; a.in_dil = 1;
-  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = x_pitch; a.m_begin = 0; a.groups = groups; a.ldy = y_pitch;
+  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = x_pitch; a.m_begin = 0; a.groups = groups; a.ldy = y_pitch; a.gn_part = gn_part;
   const bool small = K <= 64 && plain;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   if (small) launch_igemm16<64, true>(a, tiles, x_dtype, y_dtype, stream);
@@ -1239,7 +1243,7 @@ int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y
   a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
   a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad; a.in_dil = 1;
-  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = C; a.m_begin = 0; a.groups = 1; a.ldy = K;
+  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = C; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   if (small) launch_igemm16<64, true>(a, tiles, x_dtype, y_dtype, stream);
@@ -1261,7 +1265,7 @@ int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int
   a.lt.n = 0;
   a.x = xpad16; a.w = (const __bf16*)w16s; a.y = y; a.scale = scale; a.bias = bias; a.residual = nullptr; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = H + 6; a.W = W + 8; a.C = 32; a.OH = OH; a.OW = OW; a.K = K; a.KH = 7; a.KW = 1; a.stride = 2; a.pad = 0;
-  a.in_dil = 1; a.relu = relu; a.accumulate = 0; a.Kred = 7 * 32; a.M = N * OH * OW; a.xs = 4; a.m_begin = 0; a.groups = 1; a.ldy = K;
+  a.in_dil = 1; a.relu = relu; a.accumulate = 0; a.Kred = 7 * 32; a.M = N * OH * OW; a.xs = 4; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   const dim3 g(tiles), b(256);

@@ -393,6 +393,52 @@ __global__ __launch_bounds__(256) void gn_stats_final(GnSegs sg, const float* __
   }
 }
 
+// The same from the conv epilogue's partials (epilogue_rows gn_part: fp32 [ceil(rows / 32)][G][2] per 32-row block and group; 8 channels
+// per group): one block per segment; the 32-row blocks that lie inside the segment come from `part32`, the (< 32) rows in front of
+// the first and behind the last whole block - segments start at arbitrary rows - are summed here from x itself.  Thread (g = t % G,
+// lane = t / G); double accumulation, fixed order.
+__global__ __launch_bounds__(256) void gn_stats_final_p32(GnSegs sg, const float* __restrict__ part32, const __bf16* __restrict__ x,
+                                                        float* __restrict__ mean, float* __restrict__ rstd, int G, int C, float eps) {
+  __shared__ double red[2][256];
+  const int seg = blockIdx.x;
+  const int g = threadIdx.x % G, ln = threadIdx.x / G, L = blockDim.x / G;
+  const int r0 = sg.row0[seg], r1 = sg.row0[seg + 1];
+  int b0 = (r0 + 31) >> 5, b1 = r1 >> 5;      // whole blocks [b0, b1)
+  if (b1 < b0) b1 = b0;                        // the segment lies inside one block
+  double s = 0.0, q = 0.0;
+  for (int b = b0 + ln; b < b1; b += L) {
+    const float* p = part32 + ((size_t)b * G + g) * 2;
+    s += (double)p[0];
+    q += (double)p[1];
+  }
+  // edge rows: [r0, min(b0 * 32, r1)) and [max(b1 * 32, head end), r1)
+  const int h1 = (b0 << 5) < r1 ? (b0 << 5) : r1;
+  const int t0 = (b1 << 5) > h1 ? (b1 << 5) : h1;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int e0 = pass == 0 ? r0 : t0, e1 = pass == 0 ? h1 : r1;
+    for (int r = e0 + ln; r < e1; r += L) {
+      const bf16x8_t v = *(const bf16x8_t*)(x + (size_t)r * C + g * 8);
+      float fs = 0.f, fq = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; fs += f; fq += f * f; }
+      s += (double)fs;
+      q += (double)fq;
+    }
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  if (ln == 0) {
+    for (int k = 1; k < L; ++k) { s += red[0][k * G + g]; q += red[1][k * G + g]; }
+    const double cnt = (double)(r1 - r0) * 8.0;
+    const double m = s / cnt;
+    double var = q / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[seg * G + g] = (float)m;
+    rstd[seg * G + g] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_relu(GnSegs sg, const T* __restrict__ x, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -869,6 +915,21 @@ int utv2_groupnorm_relu_seg_fwd(const void* x, const float* gamma, const float* 
   const int chunks = gn_fill(sg, nseg, seg_rows_host);
   if (dtype == UTV2_BF16) gn_fwd_launch<__bf16>(sg, chunks, nseg, x, gamma, beta, y, mean, rstd, ws, C, G, eps, relu, stream);
   else gn_fwd_launch<float>(sg, chunks, nseg, x, gamma, beta, y, mean, rstd, ws, C, G, eps, relu, stream);
+  return utv2_launch_status();
+}
+
+// bf16 x with 8 channels per group whose statistics partials the producing conv left in part32 (utv2_conv2d_ml_fwd_bf16_g gn_part:
+// fp32 [ceil(rows / 32)][G][2]): statistics from the partials (+ the segment-edge rows read from x), then the apply pass - one tensor
+// pass less than utv2_groupnorm_relu_seg_fwd.
+int utv2_groupnorm_relu_seg_fwd_p32(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                    const float* part32, int nseg, const int* seg_rows_host, int C, int G, float eps, int relu,
+                                    hipStream_t stream) {
+  if (!x || !y || !mean || !rstd || !part32 || !gn_check(nseg, C, G) || C != 8 * G) return UTV2_EARG;
+  GnSegs sg;
+  const int chunks = gn_fill(sg, nseg, seg_rows_host);
+  hipLaunchKernelGGL(gn_stats_final_p32, dim3(nseg), dim3(256), 0, stream, sg, part32, (const __bf16*)x, mean, rstd, G, C, eps);
+  hipLaunchKernelGGL(gn_apply_relu<__bf16>, dim3(chunks), dim3(256), 0, stream, sg, (const __bf16*)x, (const float*)mean, (const float*)rstd,
+                     gamma, beta, (__bf16*)y, C, G, relu);
   return utv2_launch_status();
 }
 

@@ -822,7 +822,7 @@ def _rows_ptr(t):
 
 
 def conv2d_ml_fwd_bf16(x2d, w16, level_hw, N, scale=None, bias=None, residual=None, k=3, pad=1, relu=False, out=None,
-                       out_dtype=None, groups=1):
+                       out_dtype=None, groups=1, gn_part=None):
     """x2d [P, groups*C] (may be a column slice of a wider matrix); groups > 1: grouped conv, w16 [K, k*k*C] with K/groups output
     channels per group; out (optional) may be a column slice too (then residual must be None)."""
     P = x2d.shape[0]
@@ -834,15 +834,34 @@ def conv2d_ml_fwd_bf16(x2d, w16, level_hw, N, scale=None, bias=None, residual=No
     H = _iarr([h for h, _ in level_hw]); W = _iarr([w_ for _, w_ in level_hw])
     xp, xpitch = _rows_ptr(x2d)
     yp, ypitch = _rows_ptr(out)
-    if groups == 1 and xpitch == C and ypitch == K:
+    if groups == 1 and xpitch == C and ypitch == K and gn_part is None:
         call("utv2_conv2d_ml_fwd_bf16", xp, _dt(x2d), _p(w16), yp, _same_dt(out, residual), _p(scale), _p(bias), _p(residual),
              len(level_hw), ctypes.cast(H, c_p), ctypes.cast(W, c_p), N, C, K, k, k, pad, int(relu), 0, _stream())
     else:
         assert residual is None or (residual.stride(0) == ypitch and residual.stride(1) == 1)
         call("utv2_conv2d_ml_fwd_bf16_g", xp, _dt(x2d), xpitch, _p(w16), yp, _same_dt(out, residual), ypitch, _p(scale), _p(bias),
              c_p(residual.data_ptr()) if residual is not None else c_p(0), len(level_hw), ctypes.cast(H, c_p), ctypes.cast(W, c_p), N, C, K,
-             k, k, pad, int(relu), 0, int(groups), _stream())
+             k, k, pad, int(relu), 0, int(groups), _p(gn_part), _stream())
     return out
+
+
+def gn_part_buffer(P, K, device):
+    """destination of the conv epilogue's GroupNorm statistics partials: fp32 [ceil(P / 32), K / 8, 2]"""
+    return torch.empty(((P + 31) // 32, K // 8, 2), dtype=torch.float32, device=device)
+
+
+def groupnorm_relu_seg_fwd_p32(x2d, seg_rows, gamma, beta, part32, G, eps=1e-5, relu=True):
+    """groupnorm_relu_seg_fwd for bf16 x2d with 8 channels per group whose producer left the statistics partials in part32"""
+    rows, C = x2d.shape
+    assert sum(seg_rows) == rows and x2d.dtype == torch.bfloat16 and C == 8 * G
+    y = torch.empty_like(x2d)
+    S = len(seg_rows)
+    mean = torch.empty((S, G), dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty((S, G), dtype=torch.float32, device=x2d.device)
+    sr = _iarr(seg_rows)
+    call("utv2_groupnorm_relu_seg_fwd_p32", _p(x2d), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(part32), S, ctypes.cast(sr, c_p), C, G,
+         float(eps), int(relu), _stream())
+    return y, mean, rstd
 
 
 _rowinfo_cache = {}

@@ -236,6 +236,8 @@ class Conv:
         self.out_fp32 = out_fp32  # AMP: keep this layer's output fp32 (loss-side head outputs, RoIAlign inputs)
         self.premask_input = False  # set by the model builder: the input is a fused bottleneck's ReLU output (see premask_on)
         self.bias_by_gn = False     # set by pair_conv_gn(): the GroupNorm that consumes this conv's output produces its bias gradient
+        self.gn_cpg = 0             # set by pair_conv_gn(): channels per group of that GroupNorm
+        self._gn_part = None        # (data_ptr of the last output, its statistics partials): picked up by that GroupNorm
         self.grad_premasked = False  # set by the model builder: every consumer of this conv's ReLU output has premask_input, i.e. applies
         #                              the mask (output > 0) in its own dgrad epilogue - no mask pass at the top of this conv's backward
         self._wt = None
@@ -277,6 +279,11 @@ class Conv:
         return (PRECISION[0] == "bf16" and self.cin % 8 == 0 and self.cout % 8 == 0 and self.k * self.k <= 16
                 and self.kred == self.k * self.k * self.cin)
 
+    def gn_stats_fused(self):
+        """the GroupNorm (8 channels per group) that consumes this conv's bf16 output takes its statistics from partial sums this conv's
+        epilogue leaves behind (utv2_conv2d_ml_fwd_bf16_g gn_part) instead of a pass over the tensor; UTV2_GN_STATS_FUSED=0: the pass"""
+        return self.gn_cpg == 8 and self.cout % 8 == 0 and not self.relu and os.environ.get("UTV2_GN_STATS_FUSED", "1") != "0"
+
     def bias_grad_from_gn(self):
         """the bias gradient = column sums of this conv's dY, and dY is the dx the following GroupNorm's backward writes: its last pass
         sums the columns while it has them in registers (utv2_groupnorm_relu_seg_bwd_colsum) instead of a separate pass over dY next
@@ -311,8 +318,12 @@ class Conv:
         if meta is not None and self.k > 1:
             assert self.stride == 1 and self.pad == (self.k - 1) // 2
             if b16:
+                part = None
+                if self.gn_stats_fused() and out is None and residual is None and kw["out_dtype"] == torch.bfloat16 and self.cin % 32 == 0:
+                    part = hip.gn_part_buffer(x.shape[0], self.cout, x.device)
                 y = hip.conv2d_ml_fwd_bf16(x, w, meta.level_hw, meta.N, scale=sc, bias=sh, residual=residual, k=self.k, pad=self.pad,
-                                           relu=self.relu, out=out, groups=self.groups, **kw)
+                                           relu=self.relu, out=out, groups=self.groups, gn_part=part, **kw)
+                self._gn_part = (y.data_ptr(), part) if part is not None else None
             elif self.groups > 1:   # exact-f32 mode: one dense conv per group (the fp32 kernel has no grouped form)
                 Kg = self.cout // self.groups
                 y = torch.cat([hip.conv2d_ml_fwd(x[:, gi * self.cin:(gi + 1) * self.cin].contiguous(), w[gi * Kg:(gi + 1) * Kg], meta.level_hw,
@@ -631,6 +642,7 @@ def pair_conv_gn(conv, gn):
     """declare that `gn` normalises exactly the output of `conv` (conv -> GN -> ReLU, fcos.py:263-264): the GroupNorm's backward then
     also produces the conv's bias gradient (Conv.bias_grad_from_gn)"""
     conv.bias_by_gn = True
+    conv.gn_cpg = conv.cout // gn.groups
     gn.bias_conv = conv
     return conv, gn
 
@@ -652,6 +664,12 @@ class GroupNormReLU:
                                                        self.relu)
             return y.view(x.shape), mean, rstd
         # statistics are per (image, level, group): ONE launch over all (level, image) segments
+        conv = self.bias_conv
+        gp = conv._gn_part if conv is not None else None
+        if gp is not None:
+            conv._gn_part = None
+            if gp[0] == x.data_ptr() and x.dtype == torch.bfloat16:   # x is the output that conv just wrote: its epilogue left the statistics
+                return hip.groupnorm_relu_seg_fwd_p32(x, meta.seg_rows, self.gamma.t, self.beta.t, gp[1], self.groups, self.eps, self.relu)
         return hip.groupnorm_relu_seg_fwd(x, meta.seg_rows, self.gamma.t, self.beta.t, self.groups, self.eps, self.relu)
 
 
