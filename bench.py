@@ -66,7 +66,7 @@ def tune_rcnn_for_pseudo_labels(trainer, batch, target_std=8.0, bg_bias=0.0):
     m.store.touch()
     with torch.no_grad():
         images = [x["image"].to(m.device) for x in batch[3]]
-        x4, _ = hip.preprocess_images(images, m._mean_host, m._std_host, m.backbone.size_divisibility, bf16_stem=ops.PRECISION[0] == "bf16")
+        x4, _ = hip.preprocess_images(images, m._mean_host, m._std_host, m.backbone.size_divisibility, bf16_stem=ops.amp())
         m.folder.fold()
         big, _, _ = m.proposal_generator._head(m.backbone(x4))
         s_obj, s_dl = big[:, :3].float().std(), big[:, 3:15].float().std()
@@ -117,7 +117,7 @@ class ConvTimer:
             tiles = -(-P // 128) * -(-K // 128)
             if timer.bf16:  # the dispatch rule of launch_igemm16 (csrc/conv_bf16.hip) for this template instance
                 out_dt = kw["out"].dtype if kw.get("out") is not None else kw.get("out_dtype", x2d.dtype)
-                mine = (x2d.dtype == torch.bfloat16 and out_dt == torch.bfloat16 and K >= 256 and C % 64 == 0 and Kred >= 1024
+                mine = (x2d.dtype == hip.h16_dtype() and out_dt == hip.h16_dtype() and K >= 256 and C % 64 == 0 and Kred >= 1024
                         and (P // 256) * -(-K // 256) >= 256)
             else:
                 mine = K > 64 and C % 16 == 0
@@ -163,8 +163,8 @@ class WgradTimer:
         def wrapped(x, dy2d, dw, rowinfo, C, kh, kw, *args, **kwargs):
             M, K = dy2d.shape
             G = kwargs.get("groups", 1)      # paired towers: K = 512 (cls | bbox), C = 256 input channels per group
-            mine = (timer.enabled and kh == 3 and kw == 3 and C == 256 and K in (256, 512) and x.dtype == torch.bfloat16
-                    and dy2d.dtype == torch.bfloat16 and M >= 65536)
+            mine = (timer.enabled and kh == 3 and kw == 3 and C == 256 and K in (256, 512) and x.dtype == hip.h16_dtype()
+                    and dy2d.dtype == hip.h16_dtype() and M >= 65536)
             if not mine:
                 return orig(x, dy2d, dw, rowinfo, C, kh, kw, *args, **kwargs)
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -495,8 +495,9 @@ def parse_args(argv=None):
     ap.add_argument("--model", choices=["fcos", "rcnn"], default="fcos",
                     help="fcos: BASELINE configs[1] (the headline workload); rcnn: the Faster-RCNN UTv2 trainer of configs[2] / [4] on the same "
                          "per-GPU batch (its shipped configs run fp32: --dtype f32; configs[4] is the bf16 MFMA path)")
-    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
-                    help="conv arithmetic: bf16 = the config's SOLVER.AMP.ENABLED path (bf16 MFMA, fp32 accumulate); f32 = exact-f32 MFMA")
+    ap.add_argument("--dtype", choices=["bf16", "f32", "f16"], default="bf16",
+                    help="conv arithmetic: bf16 = the config's SOLVER.AMP.ENABLED path (bf16 MFMA, fp32 accumulate); f16 = the same path on the "
+                         "fp16 build of the kernels (the reference's own autocast type) with GradScaler-style dynamic loss scaling; f32 = exact-f32 MFMA")
     return ap.parse_args(argv)
 
 
@@ -558,9 +559,13 @@ def worker(args):
 
     def make_trainer(dtype):
         cfg = get_config(args.model, 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label * world, "SOLVER.IMG_PER_BATCH_UNLABEL",
-                                         args.unlabel * world, "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", dtype == "bf16",
+                                         args.unlabel * world, "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", dtype != "f32",
                                          "MODEL.DEVICE", "cuda:%d" % device_index])
         torch.manual_seed(0)
+        if dtype == "f16":
+            os.environ["UTV2_PRECISION"] = "fp16"     # the 16-bit type is an environment choice (the config surface stays the reference's)
+        else:
+            os.environ.pop("UTV2_PRECISION", None)
         t = (UBRCNNTeacherTrainer if rcnn else UBTeacherTrainer)(cfg)
         t.iter = 1
         t.log_period = 10 ** 9
@@ -626,7 +631,7 @@ def worker(args):
     # the same launches with the step's side streams off (teacher pass / weight gradients back on the main stream): the dominant kernels
     # alone on the GPU.  Not part of the timed region - reported beside the in-step figures as `exclusive`.
     conv_x = wg_x = None
-    if rank == 0 and world == 1 and args.dtype == "bf16" and not args.timed_only:
+    if rank == 0 and world == 1 and args.dtype != "f32" and not args.timed_only:
         saved = {k: os.environ.get(k) for k in ("UTV2_OVERLAP_TEACHER", "UTV2_WGRAD_STREAM")}
         os.environ["UTV2_OVERLAP_TEACHER"] = os.environ["UTV2_WGRAD_STREAM"] = "0"
         ot = getattr(tr, "overlap_teacher", None)
@@ -654,7 +659,7 @@ def worker(args):
         # only mirrors the GPU time)
         from ubteacher.data.synthetic import SyntheticTwoCropLoader
         cfg_s = get_config(args.model, 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label, "SOLVER.IMG_PER_BATCH_UNLABEL", args.unlabel,
-                                       "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", args.dtype == "bf16",
+                                       "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", args.dtype != "f32",
                                        "MODEL.DEVICE", "cuda:%d" % device_index])
         torch.manual_seed(0)
         ts = (UBRCNNTeacherTrainer if rcnn else UBTeacherTrainer)(cfg_s, data_loader=SyntheticTwoCropLoader(cfg_s, height=96, width=128))
@@ -728,7 +733,7 @@ def worker(args):
 
     if rank == 0:
         per_step_images = (args.label + args.unlabel) * world
-        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS   # f16 MFMA: the bf16 rate
         out = {
             "metric": "images/sec/node (labeled+unlabeled) UTv2 step, R50-FPN 1333x800",
             "value": per_step_images * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -739,7 +744,12 @@ def worker(args):
                                     "FCOS R50-FPN UTv2 sup1 (configs[1]): %d labeled + %d unlabeled 1333x800 images per GPU, "
                                     "post-burn-in semi-supervised step") % (args.label, args.unlabel),
                        "global_batch": per_step_images, "parallelism": "dp%d" % world,
-                       "precision": "AMP (config SOLVER.AMP.ENABLED): bf16 MFMA operands, bf16 activations and activation gradients in HBM, fp32 accumulate / losses / weight gradients / master weights" if args.dtype == "bf16" else "fp32 MFMA, fp32 everywhere"},
+                       "precision": {"bf16": "AMP (config SOLVER.AMP.ENABLED): bf16 MFMA operands, bf16 activations and activation gradients in HBM, fp32 "
+                                             "accumulate / losses / weight gradients / master weights",
+                                     "f16": "AMP (config SOLVER.AMP.ENABLED) on the fp16 build of the kernels: IEEE fp16 MFMA operands / activations / "
+                                            "activation gradients, dynamic loss scale with GradScaler's semantics kept on the device, fp32 accumulate / "
+                                            "losses / weight gradients / master weights",
+                                     "f32": "fp32 MFMA, fp32 everywhere"}[args.dtype]},
             "ranks": {"world_size": world, "backend": info["backend"], "devices": devices,
                       "launcher": _launcher_name(world), "rccl_selfcheck": rccl},
             "host": {"ms_per_step_on_96x128_images": host_ms, "enqueue_ms_per_step": 1e3 * t_host / args.steps,

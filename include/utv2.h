@@ -62,7 +62,8 @@ int utv2_conv2d_ml_wgrad(const float* x, const float* dy, float* dw, float* ws, 
  * their gradients, RoIAlign output - enter and leave without a cast pass.  `residual` has y's type.
  * Same contracts as the fp32 entry points otherwise. */
 #define UTV2_F32 0
-#define UTV2_BF16 1
+#define UTV2_BF16 1   /* the library's 16-bit float type: bfloat16 in libutv2_hip.so, IEEE fp16 in libutv2_hip_f16.so (the same sources built
+                       * with -DUTV2_H16=_Float16; csrc/common.h h16_t) - "bf16" in the names below reads "the 16-bit type" there */
 int utv2_conv2d_bf16_supported(int C, int KH, int KW);
 /* mask (optional, y's type and shape): y = mask > 0 ? conv*scale+bias : 0, before the residual add - the ReLU backward of the
  * layer that produced the input, fused into the dgrad launch that computes its gradient; post_mask (optional, same type and shape):
@@ -124,6 +125,15 @@ int utv2_ema_axpby(float* teacher, const float* student, int64_t n, double keep_
  * (engine/trainer.py:50,625; optimizer.step at :425-429,:912). */
 int utv2_sgd_momentum(float* param, float* grad, float* mom_buf, int64_t n, float lr, float momentum, float weight_decay,
                       float grad_scale, int zero_grad, utv2_stream_t stream);
+/* Dynamic loss scaling of the fp16 AMP mode with torch.cuda.amp.GradScaler's semantics (reference engine/trainer.py:207,424-426),
+ * on the device: state = fp32 {loss scale, found_inf flag, growth tracker}.  utv2_amp_found_inf sets the flag when the (scaled)
+ * gradient arena holds a non-finite value; utv2_sgd_momentum_amp applies the SGD step to grad / scale (* grad_scale), or nothing at
+ * all when the flag is set; utv2_amp_update_scale: flag ? scale *= backoff : (every growth_interval clean steps scale *= growth),
+ * then clears the flag. */
+int utv2_amp_found_inf(const float* grad, int64_t n, float* state, utv2_stream_t stream);
+int utv2_sgd_momentum_amp(float* param, const float* grad, float* mom_buf, int64_t n, float lr, float momentum, float weight_decay,
+                          float grad_scale, const float* state, utv2_stream_t stream);
+int utv2_amp_update_scale(float* state, float growth_factor, float backoff_factor, int growth_interval, utv2_stream_t stream);
 
 /* ---- elementwise pieces of ResNet / FPN ([D2-recall]) ------------------ */
 int utv2_relu_bwd_scale(const void* dy, const void* y, const float* scale, void* out, int64_t M, int C, int dtype,

@@ -34,17 +34,18 @@ CONV_ROUND = [None]
 
 
 def _r16(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+    """round to the emulated 16-bit type (CONV_ROUND "bf16": bfloat16, "fp16": IEEE half - the product's second kernel build)"""
+    return t.to(torch.float16 if CONV_ROUND[0] == "fp16" else torch.bfloat16).to(torch.float32)
 
 
 def _conv2d(x, w, b=None, stride=1, padding=0):
-    if CONV_ROUND[0] == "bf16" and x.shape[1] % 8 == 0:
+    if CONV_ROUND[0] in ("bf16", "fp16") and x.shape[1] % 8 == 0:
         x, w = _r16(x), _r16(w)
     return F.conv2d(x, w, b, stride, padding)
 
 
 def _linear(x, w, b=None):
-    if CONV_ROUND[0] == "bf16" and x.shape[1] % 8 == 0:
+    if CONV_ROUND[0] in ("bf16", "fp16") and x.shape[1] % 8 == 0:
         x, w = _r16(x), _r16(w)
     return F.linear(x, w, b)
 

@@ -91,24 +91,28 @@ def _to_oracle_pseudo(pb):
     return out
 
 
-def test_fcos_step_bf16_vs_rounding_oracle():
-    """Full UTv2 FCOS step in AMP mode (bf16 MFMA operands) vs the oracle with the same operand rounding
-    emulated in its convs.  The two agree to ~1e-3 on activations (measured: 7e-4 mean, 4e-3 max on the
+@pytest.mark.parametrize("kind,tol", [("bf16", 1e-2), ("fp16", 2e-3)])
+def test_fcos_step_bf16_vs_rounding_oracle(kind, tol, monkeypatch):
+    """Full UTv2 FCOS step in AMP mode (16-bit MFMA operands) vs the oracle with the same operand rounding
+    emulated in its convs.  bf16: the two agree to ~1e-3 on activations (measured: 7e-4 mean, 4e-3 max on the
     logits: a 1e-6 accumulation-order difference that lands on a bf16 rounding boundary becomes a 4e-3 one),
     so: teacher detections must overlap (IoU-matched) and, given the SAME pseudo labels, every loss must
-    be within 1e-2 relative; EMA stays bit exact."""
+    be within 1e-2 relative; EMA stays bit exact.  fp16 (UTV2_PRECISION=fp16: the second build of the kernel library, the reference's
+    own autocast element type, 3 more mantissa bits; loss scale 65536 on the backward): 2e-3."""
     from oracle import utv2_oracle as O
     from tests.utv2_testutil import FixedLoader, cpu_state, make_batch, small_fcos_cfg, tune_state_for_pseudo_labels
     from ubteacher.engine import UBTeacherTrainer
     from ubteacher import ops
     cfg = small_fcos_cfg()
     cfg.SOLVER.AMP.ENABLED = True
+    if kind == "fp16":
+        monkeypatch.setenv("UTV2_PRECISION", "fp16")
     torch.manual_seed(0)
     prod, orac = make_batch(12, 2, 2, 96, 128, "cuda")
     try:
-        O.CONV_ROUND[0] = "bf16"
+        O.CONV_ROUND[0] = kind
         tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
-        assert ops.PRECISION[0] == "bf16"
+        assert ops.PRECISION[0] == kind and (tr._amp_state is not None) == (kind == "fp16")
         sd_s = tune_state_for_pseudo_labels(cpu_state(tr.model), [d["image"] for d in orac[3]])
         sd_t = dict(sd_s)
         sd_t["proposal_generator.fcos_head.bbox_pred_std.bias"] = torch.full((4,), -3.0)
@@ -138,10 +142,80 @@ def test_fcos_step_bf16_vs_rounding_oracle():
             hit += int((O.pairwise_iou(p["boxes"], mine).max(dim=1)[0] > 0.9).sum())
     assert tot > 0 and hit >= 0.6 * tot, (hit, tot)
     for k, v in rec_o.items():
-        assert abs(rec[k] - v) <= 1e-2 * max(abs(v), 1e-6), (k, rec[k], v)
+        assert abs(rec[k] - v) <= tol * max(abs(v), 1e-6), (k, rec[k], v)
     t_after = cpu_state(tr.model_teacher)
     for k in new_t:
         assert torch.equal(t_after[k], new_t[k]), k
+    if kind == "fp16":
+        st = tr._amp_state.cpu().tolist()
+        assert st == [65536.0, 0.0, 1.0], st       # finite gradients: the step was applied, one clean step counted, flag cleared
+        torch.cuda.synchronize()
+
+
+def test_amp_loss_scaler_matches_gradscaler_semantics():
+    """utv2_amp_found_inf / utv2_sgd_momentum_amp / utv2_amp_update_scale against torch.cuda.amp.GradScaler's rules (the reference:
+    engine/trainer.py:207,424-426): a non-finite gradient skips the whole step and halves the scale; `growth_interval` clean steps
+    double it; the applied step equals plain SGD on grad / scale."""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(1)
+    n = 10007
+    p0 = torch.randn(n, generator=g).cuda()
+    m0 = torch.randn(n, generator=g).cuda() * 0.1
+    gr = torch.randn(n, generator=g).cuda()
+    st = torch.tensor([1024.0, 0.0, 0.0], device="cuda")
+    # clean step == sgd on the unscaled gradient
+    p, m = p0.clone(), m0.clone()
+    hip.amp_found_inf(gr * 1024.0, st)
+    hip.sgd_momentum_amp(p, gr * 1024.0, m, 0.01, 0.9, 1e-4, 0.5, st)
+    hip.amp_update_scale(st, 2.0, 0.5, 3)
+    pr, mr, gz = p0.clone(), m0.clone(), gr.clone()
+    hip.sgd_momentum(pr, gz, mr, 0.01, 0.9, 1e-4, 0.5, zero_grad=False)
+    assert torch.equal(p, pr) and torch.equal(m, mr) and st.cpu().tolist() == [1024.0, 0.0, 1.0]
+    # two more clean steps: the third one grows the scale
+    for want in ([1024.0, 0.0, 2.0], [2048.0, 0.0, 0.0]):
+        hip.amp_found_inf(gr, st)
+        hip.amp_update_scale(st, 2.0, 0.5, 3)
+        assert st.cpu().tolist() == want
+    # an inf (or a NaN) anywhere - including the tail past the last full quad - skips the step and backs the scale off
+    for pos, val in ((5, float("inf")), (n - 1, float("nan")), (n - 3, float("-inf"))):
+        bad = gr.clone()
+        bad[pos] = val
+        p, m = p0.clone(), m0.clone()
+        hip.amp_found_inf(bad, st)
+        assert float(st[1]) == 1.0
+        hip.sgd_momentum_amp(p, bad, m, 0.01, 0.9, 1e-4, 1.0, st)
+        before = float(st[0])
+        hip.amp_update_scale(st, 2.0, 0.5, 3)
+        assert torch.equal(p, p0) and torch.equal(m, m0) and st.cpu().tolist() == [before * 0.5, 0.0, 0.0]
+
+
+def test_fp16_library_conv_matches_fp32_conv_on_rounded_operands():
+    """libutv2_hip_f16.so (the same sources with h16_t = _Float16): forward, dgrad-as-conv and wgrad of a 3x3 256 -> 256 conv equal an
+    fp32 conv on the fp16-rounded operands to accumulation order - the only change against the bf16 build is the operand rounding."""
+    from ubteacher import hip, ops
+    g = torch.Generator().manual_seed(2)
+    N, H, W, C, K = 2, 25, 42, 256, 256
+    try:
+        ops.set_precision("fp16")
+        assert hip.h16_dtype() == torch.float16
+        x = (torch.randn(N, H, W, C, generator=g)).half().cuda()
+        w = (torch.randn(K, 9 * C, generator=g) * 0.02).half().cuda()
+        b = torch.randn(K, generator=g).cuda()
+        y = hip.conv2d_fwd_bf16(x, w, bias=b, pad=1, kh=3, kw=3, out_dtype=torch.float32)
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2).cpu(), w.float().view(K, 3, 3, C).permute(0, 3, 1, 2).cpu(), b.cpu(), 1, 1)
+        assert relerr(y.permute(0, 3, 1, 2).cpu(), ref) < 2e-4
+        y16 = hip.conv2d_fwd_bf16(x, w, bias=b, pad=1, kh=3, kw=3)
+        assert y16.dtype == torch.float16 and relerr(y16.float().permute(0, 3, 1, 2).cpu(), ref) < 2e-3
+        dy = (torch.randn(N * H * W, K, generator=g) * 0.1).half().cuda()
+        dw = torch.zeros(K, 9 * C, device="cuda")
+        ri = hip.rowinfo_nhwc(N, H, W, H, W, 1, 1, 3, 3, "cuda")
+        hip.conv2d_wgrad_bf16(x, dy, dw, ri, C, 3, 3, accumulate=True)
+        xr = x.float().permute(0, 3, 1, 2).cpu().requires_grad_(False)
+        wr = w.float().view(K, 3, 3, C).permute(0, 3, 1, 2).cpu().clone().requires_grad_(True)
+        F.conv2d(xr, wr, None, 1, 1).backward(dy.float().view(N, H, W, K).permute(0, 3, 1, 2).cpu())
+        assert relerr(dw.cpu(), wr.grad.permute(0, 2, 3, 1).reshape(K, -1)) < 2e-4
+    finally:
+        ops.set_precision("fp32")
 
 
 @pytest.mark.parametrize("xdt,dydt", [(torch.float32, torch.float32), (BF, BF), (BF, torch.float32), (torch.float32, BF)])

@@ -15,9 +15,29 @@ static inline int utv2_launch_status() {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// The 16-bit float type of THIS build of the library.  Every "bf16" kernel, entry point and dtype code (UTV2_BF16) is written against
+// h16_t: the default build (libutv2_hip.so) makes it bfloat16, the second build of the same sources (libutv2_hip_f16.so, compiled with
+// -DUTV2_H16=_Float16) makes it IEEE fp16 - the element type of the reference's own AMP mode (torch.cuda.amp.autocast,
+// engine/trainer.py:195,319).  Nothing below depends on which one it is: conversions are plain casts (round-to-nearest-even either way),
+// the matrix instruction is picked by overload (mfma_32x32x16), LDS / DMA / transposing-read traffic is 16-bit data either way.
+#ifndef UTV2_H16
+#define UTV2_H16 __bf16
+#endif
+typedef UTV2_H16 h16_t;
+typedef h16_t bf16x4_t __attribute__((ext_vector_type(4)));
+typedef h16_t bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 mfma_f16x8 __attribute__((ext_vector_type(8)));
+
+// v_mfma_f32_32x32x16_{bf16,f16}: same shape, same rate (2.5 PFLOP/s dense), fp32 accumulate
+__device__ __forceinline__ float __attribute__((ext_vector_type(16))) mfma_32x32x16(mfma_bf16x8 a, mfma_bf16x8 b,
+                                                                                 float __attribute__((ext_vector_type(16))) c) {
+  return mfma_32x32x16(a, b, c);
+}
+__device__ __forceinline__ float __attribute__((ext_vector_type(16))) mfma_32x32x16(mfma_f16x8 a, mfma_f16x8 b,
+                                                                                 float __attribute__((ext_vector_type(16))) c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
 // activation element types of the C-ABI (`*_dtype` arguments)
 #define UTV2_F32 0
@@ -25,7 +45,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 // quad (4 consecutive elements) load / store of an activation tensor, arithmetic always in fp32
 __device__ __forceinline__ f32x4 ld4(const float* p, size_t i4) { return ((const f32x4*)p)[i4]; }
-__device__ __forceinline__ f32x4 ld4(const __bf16* p, size_t i4) {
+__device__ __forceinline__ f32x4 ld4(const h16_t* p, size_t i4) {
   const bf16x4_t v = ((const bf16x4_t*)p)[i4];
   f32x4 o;
 #pragma unroll
@@ -33,10 +53,10 @@ __device__ __forceinline__ f32x4 ld4(const __bf16* p, size_t i4) {
   return o;
 }
 __device__ __forceinline__ void st4(float* p, size_t i4, f32x4 v) { ((f32x4*)p)[i4] = v; }
-__device__ __forceinline__ void st4(__bf16* p, size_t i4, f32x4 v) {
+__device__ __forceinline__ void st4(h16_t* p, size_t i4, f32x4 v) {
   bf16x4_t o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];  // round-to-nearest-even
+  for (int e = 0; e < 4; ++e) o[e] = (h16_t)v[e];  // round-to-nearest-even
   ((bf16x4_t*)p)[i4] = o;
 }
 
@@ -123,7 +143,7 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
         for (int it = 0; it < 32 / RPI; ++it) {
           const int m = m_base + i * 32 + it * RPI + rsub;
           const size_t off = (size_t)(m < M ? m : M - 1) * LDY + co;
-          rpre[i][it] = *(const bf16x8_t*)((const __bf16*)residual + off);
+          rpre[i][it] = *(const bf16x8_t*)((const h16_t*)residual + off);
         }
     }
   }
@@ -177,7 +197,7 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
             }
             bf16x8_t o;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) o[q] = (__bf16)v[q >> 2][q & 3];
+            for (int q = 0; q < 8; ++q) o[q] = (h16_t)v[q >> 2][q & 3];
             *(bf16x8_t*)(y + off) = o;
             if (gn_part) {
               float f[8];

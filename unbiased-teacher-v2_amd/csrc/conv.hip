@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
     float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
     if constexpr (MODE == 1) {
       if (p.y_bf16) {  // no residual / accumulate on this path
-        epilogue_rows<TN, __bf16>(acc, patch, lane, (__bf16*)p.y, p.scale, p.bias, (const __bf16*)nullptr, p.relu, 0, m0 + wm * 64,
+        epilogue_rows<TN, h16_t>(acc, patch, lane, (h16_t*)p.y, p.scale, p.bias, (const h16_t*)nullptr, p.relu, 0, m0 + wm * 64,
                                   n0 + wn * (BN / 2), p.M, p.K);
         return;
       }

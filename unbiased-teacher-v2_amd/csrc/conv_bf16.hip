@@ -33,7 +33,7 @@ struct LevelTab {
 struct ConvArgs16 {
   LevelTab lt;
   const void* x;             // NHWC activations, element type TI
-  const __bf16* w;           // bf16 [K][Kred]
+  const h16_t* w;           // bf16 [K][Kred]
   void* y;                   // element type TO
   const float* scale;
   const float* bias;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
     }
   }
   bool bvalid[BROWS];
-  const __bf16* wrow[BROWS];
+  const h16_t* wrow[BROWS];
 #pragma unroll
   for (int r = 0; r < BROWS; ++r) {
     const int co = n0 + lrow + 64 * r;
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
       if constexpr (IN16) {
         bf16x8_t v;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
-        if (ok) v = *(const bf16x8_t*)((const __bf16*)p.x + eoff);
+        for (int e = 0; e < 8; ++e) v[e] = (h16_t)0.f;
+        if (ok) v = *(const bf16x8_t*)((const h16_t*)p.x + eoff);
         ra16[r] = v;
       } else {
         f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
     for (int r = 0; r < BROWS; ++r) {
       bf16x8_t v;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+      for (int e = 0; e < 8; ++e) v[e] = (h16_t)0.f;
       if (bvalid[r] && (c0 + kg * 8 < p.C)) v = *(const bf16x8_t*)(wrow[r] + (kh * p.KW + kw) * p.C + c0 + kg * 8);
       rb[r] = v;
     }
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = (__bf16)ra[r][0][e];
-          v[4 + e] = (__bf16)ra[r][1][e];
+          v[e] = (h16_t)ra[r][0][e];
+          v[4 + e] = (h16_t)ra[r][1][e];
         }
       }
       *(bf16x8_t*)(As + buf * BM * LDB + (lrow + 64 * r) * LDB + kg * 16) = v;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x16(a[i][s], b[j][s], acc[i][j]);
     if (kc + 1 < nchunks) lds_store(buf ^ 1);
     __syncthreads();
   }
@@ -264,23 +264,23 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
 }
 
 // dst bf16 = RNE(src fp32)
-__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n4) {
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, h16_t* __restrict__ dst, size_t n4) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < n4; i += stride) {
     const f32x4 v = ((const f32x4*)src)[i];
-    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    typedef h16_t bf16x4_t __attribute__((ext_vector_type(4)));
     bf16x4_t o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+    for (int e = 0; e < 4; ++e) o[e] = (h16_t)v[e];
     ((bf16x4_t*)dst)[i] = o;
   }
 }
 
 // dst bf16 [rows][cpad] = RNE(src [rows][c]) with zeros in columns [c, cpad)   (c, cpad multiples of 8)
 template <typename T>
-__global__ __launch_bounds__(256) void pad_cols_bf16_kernel(const T* __restrict__ src, __bf16* __restrict__ dst, size_t rows, int c, int cpad) {
-  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void pad_cols_bf16_kernel(const T* __restrict__ src, h16_t* __restrict__ dst, size_t rows, int c, int cpad) {
+  typedef h16_t bf16x8_t __attribute__((ext_vector_type(8)));
   const int per_row = cpad / 8;
   const size_t total = rows * per_row, stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -289,10 +289,10 @@ __global__ __launch_bounds__(256) void pad_cols_bf16_kernel(const T* __restrict_
     bf16x8_t o;
     if (j < c) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (__bf16)(float)src[r * c + j + e];
+      for (int e = 0; e < 8; ++e) o[e] = (h16_t)(float)src[r * c + j + e];
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (__bf16)0.f;
+      for (int e = 0; e < 8; ++e) o[e] = (h16_t)0.f;
     }
     *(bf16x8_t*)(dst + r * cpad + j) = o;
   }
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void pad_cols_bf16_kernel(const T* __restrict_
 
 // wt16[ci][KH-1-kh][KW-1-kw][co] = bf16(w[co][kh][kw][ci] * scale[co])   (scale optional: the folded FrozenBN multiplier,
 // so dgrad consumes the UNscaled output gradient and no "dy * scale" pass is ever materialised)
-__global__ void weight_flip_transpose_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, const float* __restrict__ scale,
+__global__ void weight_flip_transpose_bf16_kernel(const float* __restrict__ w, h16_t* __restrict__ wt, const float* __restrict__ scale,
                                                   int K, int KH, int KW, int C) {
   const size_t n = (size_t)K * KH * KW * C;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -313,7 +313,7 @@ __global__ void weight_flip_transpose_bf16_kernel(const float* __restrict__ w, _
     const int ci = (int)t;
     float v = w[(((size_t)co * KH + (KH - 1 - khp)) * KW + (KW - 1 - kwp)) * C + ci];
     if (scale) v *= scale[co];
-    wt[i] = (__bf16)v;
+    wt[i] = (h16_t)v;
   }
 }
 
@@ -328,14 +328,14 @@ struct FlipDesc {
 };
 
 __global__ __launch_bounds__(256) void weight_flip_transpose_bf16_batched_kernel(const float* __restrict__ arena, const float* __restrict__ scales,
-                                                                               __bf16* __restrict__ bank, const FlipDesc* __restrict__ table) {
+                                                                               h16_t* __restrict__ bank, const FlipDesc* __restrict__ table) {
   // per tap a (K x C) -> (C x K) transpose: 32 x 32 tiles through LDS so that both the fp32 reads (along ci) and the bf16 writes (along
   // co) are coalesced (the element-wise gather ran at 0.75 TB/s)
   __shared__ float tile[32][33];
   const FlipDesc d = table[blockIdx.y];
   const float* w = arena + d.w_off;
   const float* scale = d.scale_off >= 0 ? scales + d.scale_off : nullptr;
-  __bf16* wt = bank + d.dst_off;
+  h16_t* wt = bank + d.dst_off;
   const int T = d.KH * d.KW, tk = (d.Kpad + 31) / 32, tc = (d.C + 31) / 32;
   const int ntiles = T * tk * tc;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void weight_flip_transpose_bf16_batched_kernel
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ci = ci0 + ty + 8 * i, co = co0 + tx;
-      if (ci < d.C && co < d.Kpad) wt[((size_t)ci * T + ftap) * d.Kpad + co] = (__bf16)tile[tx][ty + 8 * i];
+      if (ci < d.C && co < d.Kpad) wt[((size_t)ci * T + ftap) * d.Kpad + co] = (h16_t)tile[tx][ty + 8 * i];
     }
     __syncthreads();
   }
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const __bf16* __restrict__ xb = (const __bf16*)p.x;
+  const h16_t* __restrict__ xb = (const h16_t*)p.x;
   const int nchunks = ntaps * (p.C / BK);
   int kh = 0, kw = 0, c0 = 0, tap = 0;
   bf16x8_t ra[AP], rb[BP];
@@ -494,13 +494,13 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
       if (++kh == p.KH) { kh = 0; tap = 0; c0 += BK; }
     }
   };
-  const __bf16* zero = (const __bf16*)g_zero64;  // halo / out-of-range pieces read zeros: no branches, no data masking
+  const h16_t* zero = (const h16_t*)g_zero64;  // halo / out-of-range pieces read zeros: no branches, no data masking
   auto load_piece = [&](int q) {
     if (q < AP) {
-      const __bf16* src = ((amask[q] >> utap) & 1u) ? xb + (unsigned)(aoff[q] + ukh * awc[q] + ua) : zero;
+      const h16_t* src = ((amask[q] >> utap) & 1u) ? xb + (unsigned)(aoff[q] + ukh * awc[q] + ua) : zero;
       ra[q] = *(const bf16x8_t*)src;
     } else {
-      const __bf16* src = bvalid[q - AP] ? p.w + (unsigned)(boff[q - AP] + ub) : zero;
+      const h16_t* src = bvalid[q - AP] ? p.w + (unsigned)(boff[q - AP] + ub) : zero;
       rb[q - AP] = *(const bf16x8_t*)src;
     }
   };
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x16(a[i], b[j], acc[i][j]);
 #pragma unroll
       for (int q = s * NP / KS; q < (s + 1) * NP / KS; ++q) {
         if constexpr (STORE) store_piece(buf ^ 1, q);
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const __bf16* __restrict__ xb = (const __bf16*)p.x;
+  const h16_t* __restrict__ xb = (const h16_t*)p.x;
   const int nchunks = ntaps * (p.C / BK);
   int kh = 0, kw = 0, c0 = 0, tap = 0;
   constexpr int NP = AP + BP;
@@ -704,14 +704,14 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
       if (++kh == p.KH) { kh = 0; tap = 0; c0 += BK; }
     }
   };
-  const __bf16* zero = (const __bf16*)g_zero64;
+  const h16_t* zero = (const h16_t*)g_zero64;
   const int wrow0 = wid * (64 / SLOTS);  // one wave instruction fills 1 KB = 8 consecutive rows of the stage
   auto issue_piece = [&](int buf, int q) {
     if (q < AP) {
-      const __bf16* src = ((amask[q] >> utap) & 1u) ? xb + (unsigned)(aoff[q] + ukh * awc[q] + ua) : zero;
+      const h16_t* src = ((amask[q] >> utap) & 1u) ? xb + (unsigned)(aoff[q] + ukh * awc[q] + ua) : zero;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * ABUF + (wrow0 + RPP * q) * ROWB), 16, 0, 0);
     } else {
-      const __bf16* src = bvalid[q - AP] ? p.w + (unsigned)(boff[q - AP] + ub) : zero;
+      const h16_t* src = bvalid[q - AP] ? p.w + (unsigned)(boff[q - AP] + ub) : zero;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + buf * BBUF + (wrow0 + RPP * (q - AP)) * ROWB), 16, 0, 0);
     }
   };
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x16(a[s & 1][i], b[s & 1][j], acc[i][j]);
       if constexpr (LOAD) {  // all 8 pieces go out behind the MFMAs of the first two k16 steps: at least half a chunk to land
         if (s < W8_SP) {
 #pragma unroll
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const __bf16* __restrict__ xb = (const __bf16*)p.x;
+  const h16_t* __restrict__ xb = (const h16_t*)p.x;
   const int nchunks = ntaps * (p.C / BK);
   int kh = 0, kw = 0, c0 = 0, tap = 0;
   int ua = 0, ub = 0, ukh = 0, utap = 0;
@@ -900,7 +900,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
       if (++kh == p.KH) { kh = 0; tap = 0; c0 += BK; }
     }
   };
-  const __bf16* zero = (const __bf16*)g_zero64;
+  const h16_t* zero = (const h16_t*)g_zero64;
   unsigned char* const dma_row = smem + (wid * 32) * SEGB;  // wave-uniform (M0)
 #ifdef UTV2_PP_TRACE
   const unsigned tr_addr = (unsigned)(size_t)(lptr_t)smem + 2 * STAGE + wid * 512;
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
   int c = 0;
   const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  const __bf16* psrc[4];  // sources of the wave's next 4 pieces (0,1: im2col, 2,3: weights), computed in the LOAD slot, issued from the COMPUTE slot
+  const h16_t* psrc[4];  // sources of the wave's next 4 pieces (0,1: im2col, 2,3: weights), computed in the LOAD slot, issued from the COMPUTE slot
   auto prep_pieces = [&](int sg) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -968,8 +968,8 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[ks][i]), __builtin_bit_cast(bf16x8_t, fb[ks][j]),
-                                                              acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_32x32x16(__builtin_bit_cast(bf16x8_t, fa[ks][i]), __builtin_bit_cast(bf16x8_t, fb[ks][j]),
+                                                              acc[i][j]);
           const int n = (ks * TM + i) * TN + j;
           if ((n & 3) == 2) {
             __builtin_amdgcn_sched_barrier(0);
@@ -1140,16 +1140,16 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
         const int smem = 2 * (256 + 256) * 128;
         static bool attr_done = false;
         if (!attr_done) {
-          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_w8<ML, __bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_w8<ML, h16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
           (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_w8<ML, float>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_pp<ML, __bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_pp<ML, h16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
           (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_pp<ML, float>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
           attr_done = true;
         }
         if (g_use_pp) {
-          if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, __bf16>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
+          if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, h16_t>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
           else hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, float>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
-        } else if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_w8<ML, __bf16>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
+        } else if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_w8<ML, h16_t>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
         else hipLaunchKernelGGL((conv_igemm_bf16_w8<ML, float>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
         if (m.M == a.M) return;
         ConvArgs16 r = a;
@@ -1159,19 +1159,19 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
       }
     }
     if (deep) {
-      if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 64, __bf16>), g, b, 0, stream, a);
+      if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 64, h16_t>), g, b, 0, stream, a);
       else hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 64, float>), g, b, 0, stream, a);
     } else {
-      if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 32, __bf16>), g, b, 0, stream, a);
+      if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 32, h16_t>), g, b, 0, stream, a);
       else hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 32, float>), g, b, 0, stream, a);
     }
     return;
   }
   if (x_dtype == UTV2_BF16) {
-    if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, __bf16, __bf16>), g, b, 0, stream, a);
-    else hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, __bf16, float>), g, b, 0, stream, a);
+    if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, h16_t, h16_t>), g, b, 0, stream, a);
+    else hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, h16_t, float>), g, b, 0, stream, a);
   } else {
-    if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, float, __bf16>), g, b, 0, stream, a);
+    if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, float, h16_t>), g, b, 0, stream, a);
     else hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, float, float>), g, b, 0, stream, a);
   }
 }
@@ -1192,7 +1192,7 @@ int utv2_conv2d_nhwc_fwd_bf16(const void* x, int x_dtype, const void* w16, void*
   if (!x || !w16 || !y || (C % 8) || bad_dtype(x_dtype) || bad_dtype(y_dtype)) return UTV2_EARG;
   ConvArgs16 a;
   a.lt.n = 0;
-  a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = mask; a.post_mask = post_mask;
+  a.x = x; a.w = (const h16_t*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = mask; a.post_mask = post_mask;
   a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.K = K; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
   a.in_dil = in_dil < 1 ? 1 : in_dil; a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.M = N * OH * OW;
   a.xs = C; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr;
@@ -1224,7 +1224,7 @@ int utv2_conv2d_ml_fwd_bf16_g(const void* x, int x_dtype, int x_pitch, const voi
   ConvArgs16 a;
   a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
   if (!plain && ((int64_t)a.M * x_pitch >= (1ll << 31) || (int64_t)K * KH * KW * C >= (1ll << 31))) return UTV2_EARG;
-  a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
+  a.x = x; a.w = (const h16_t*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad; a.in_dil = 1;
   a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = x_pitch; a.m_begin = 0; a.groups = groups; a.ldy = y_pitch; a.gn_part = gn_part;
   const bool small = K <= 64 && plain;
@@ -1241,7 +1241,7 @@ int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y
     return UTV2_EARG;
   ConvArgs16 a;
   a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
-  a.x = x; a.w = (const __bf16*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
+  a.x = x; a.w = (const h16_t*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad; a.in_dil = 1;
   a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = C; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr;
   const bool small = K <= 64;
@@ -1263,17 +1263,17 @@ int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int
     return UTV2_EARG;
   ConvArgs16 a;
   a.lt.n = 0;
-  a.x = xpad16; a.w = (const __bf16*)w16s; a.y = y; a.scale = scale; a.bias = bias; a.residual = nullptr; a.mask = nullptr; a.post_mask = nullptr;
+  a.x = xpad16; a.w = (const h16_t*)w16s; a.y = y; a.scale = scale; a.bias = bias; a.residual = nullptr; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = H + 6; a.W = W + 8; a.C = 32; a.OH = OH; a.OW = OW; a.K = K; a.KH = 7; a.KW = 1; a.stride = 2; a.pad = 0;
   a.in_dil = 1; a.relu = relu; a.accumulate = 0; a.Kred = 7 * 32; a.M = N * OH * OW; a.xs = 4; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   const dim3 g(tiles), b(256);
   if (small) {
-    if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<64, false, 32, __bf16>), g, b, 0, stream, a);
+    if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<64, false, 32, h16_t>), g, b, 0, stream, a);
     else hipLaunchKernelGGL((conv_igemm_bf16_v2<64, false, 32, float>), g, b, 0, stream, a);
   } else {
-    if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<128, false, 32, __bf16>), g, b, 0, stream, a);
+    if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<128, false, 32, h16_t>), g, b, 0, stream, a);
     else hipLaunchKernelGGL((conv_igemm_bf16_v2<128, false, 32, float>), g, b, 0, stream, a);
   }
   return utv2_launch_status();
@@ -1285,7 +1285,7 @@ int utv2_f32_to_bf16(const float* src, void* dst16, int64_t n, hipStream_t strea
   if (n == 0) return UTV2_OK;
   size_t nb = ((size_t)n / 4 + 255) / 256;
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((int)nb), dim3(256), 0, stream, src, (__bf16*)dst16, (size_t)n / 4);
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((int)nb), dim3(256), 0, stream, src, (h16_t*)dst16, (size_t)n / 4);
   return utv2_launch_status();
 }
 
@@ -1295,9 +1295,9 @@ int utv2_pad_cols_bf16(const void* src, int src_dtype, void* dst16, int64_t rows
   size_t nb = ((size_t)rows * (cpad / 8) + 255) / 256;
   if (nb > 8192) nb = 8192;
   if (src_dtype == UTV2_BF16)
-    hipLaunchKernelGGL(pad_cols_bf16_kernel<__bf16>, dim3((int)nb), dim3(256), 0, stream, (const __bf16*)src, (__bf16*)dst16, (size_t)rows, c, cpad);
+    hipLaunchKernelGGL(pad_cols_bf16_kernel<h16_t>, dim3((int)nb), dim3(256), 0, stream, (const h16_t*)src, (h16_t*)dst16, (size_t)rows, c, cpad);
   else
-    hipLaunchKernelGGL(pad_cols_bf16_kernel<float>, dim3((int)nb), dim3(256), 0, stream, (const float*)src, (__bf16*)dst16, (size_t)rows, c, cpad);
+    hipLaunchKernelGGL(pad_cols_bf16_kernel<float>, dim3((int)nb), dim3(256), 0, stream, (const float*)src, (h16_t*)dst16, (size_t)rows, c, cpad);
   return utv2_launch_status();
 }
 
@@ -1307,7 +1307,7 @@ int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, const float* sca
   const size_t n = (size_t)K * KH * KW * C;
   int nb = cdiv((int64_t)n, 256);
   if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(weight_flip_transpose_bf16_kernel, dim3(nb), dim3(256), 0, stream, w, (__bf16*)wt16, scale, K, KH, KW, C);
+  hipLaunchKernelGGL(weight_flip_transpose_bf16_kernel, dim3(nb), dim3(256), 0, stream, w, (h16_t*)wt16, scale, K, KH, KW, C);
   return utv2_launch_status();
 }
 
@@ -1320,7 +1320,7 @@ int utv2_weight_flip_transpose_bf16_batched(const float* arena, const float* sca
   static_assert(sizeof(FlipDesc) == 48, "table record layout is part of the ABI");
   // blocks of a layer stride over its 32 x 32 tiles: 512 per layer keep the one big layer of a model (the box head's 1024 x 12544 fc1:
   // 12544 tiles; 239 us per step at 128 blocks) from serialising on a few CUs, the surplus blocks of small layers exit at once
-  hipLaunchKernelGGL(weight_flip_transpose_bf16_batched_kernel, dim3(512, nlayers), dim3(256), 0, stream, arena, scales, (__bf16*)bank,
+  hipLaunchKernelGGL(weight_flip_transpose_bf16_batched_kernel, dim3(512, nlayers), dim3(256), 0, stream, arena, scales, (h16_t*)bank,
                      (const FlipDesc*)table);
   return utv2_launch_status();
 }
@@ -1431,15 +1431,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
   auto load8 = [&](const void* base, size_t eoff, bool is16, bool ok) -> bf16x8_t {
     bf16x8_t v;
     if (is16) {
-      const __bf16* src = ok ? (const __bf16*)base + eoff : (const __bf16*)g_zero64;
+      const h16_t* src = ok ? (const h16_t*)base + eoff : (const h16_t*)g_zero64;
       v = *(const bf16x8_t*)src;
     } else {
       const float* src = ok ? (const float*)base + eoff : (const float*)g_zero64;
       const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[e] = (__bf16)v0[e];
-        v[4 + e] = (__bf16)v1[e];
+        v[e] = (h16_t)v0[e];
+        v[4 + e] = (h16_t)v1[e];
       }
     }
     return v;
@@ -1496,7 +1496,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16(a[i], b[j], acc[i][j]);
       // s = 0: the im2col pieces (they consume the rowinfo registers), s = 1: the dY pieces, then the next geometry
 #pragma unroll
       for (int q = (s == 0 ? 2 : 0); q < (s == 0 ? 4 : 2); ++q) {
@@ -1627,9 +1627,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
   int choff[2];  // source channel of the lane's 16 bytes for pieces with (2q + hr) & 3 == hr (q even) / 2 + hr (q odd)
 #pragma unroll
   for (int o = 0; o < 2; ++o) choff[o] = (((slot >> 2) ^ ((2 * o + hr) & 3)) << 5) + ((slot & 3) << 3);
-  const __bf16* __restrict__ xb = (const __bf16*)p.x;
-  const __bf16* __restrict__ dyb = (const __bf16*)p.dy;
-  const __bf16* zero = (const __bf16*)g_zero64;
+  const h16_t* __restrict__ xb = (const h16_t*)p.x;
+  const h16_t* __restrict__ dyb = (const h16_t*)p.dy;
+  const h16_t* zero = (const h16_t*)g_zero64;
   typedef int i32x2 __attribute__((ext_vector_type(2)));
   i32x2 ri[2][4];           // rowinfo of the lane's four im2col rows, two chunks in flight (set = parity of the chunk it belongs to)
   const int rowl = 8 * wid + hr;  // + 2q
@@ -1647,13 +1647,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
   auto rload0 = WG8_RLOAD(0);   // asm: invisible to the compiler's waitcnt insertion; covered by the counted vmcnt waits
   auto rload1 = WG8_RLOAD(1);
 #undef WG8_RLOAD
-  const __bf16* bsrc[4];    // source of the lane's 16 bytes of the four im2col pieces of the chunk staged in this iteration
+  const h16_t* bsrc[4];    // source of the lane's 16 bytes of the four im2col pieces of the chunk staged in this iteration
 #define WG8_BSRC(SET)                                                                                              \
   [&](int chunk) {                                                                                                 \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                \
       const int m = chunk * BP + rowl + 2 * q;                                                                     \
       const int W = ri[SET][q].y >> 16;                                                                            \
-      const __bf16* s0 = xb + (unsigned)((ri[SET][q].x + dh * W + dw) * p.xs + ci0 + choff[q & 1]);                \
+      const h16_t* s0 = xb + (unsigned)((ri[SET][q].x + dh * W + dw) * p.xs + ci0 + choff[q & 1]);                \
       const bool ok = (m < p.M) & (chunk < chunk_end) & ((ri[SET][q].y >> tap) & 1);                               \
       bsrc[q] = ok ? s0 : zero;                                                                                    \
     }                                                                                                              \
@@ -1664,10 +1664,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
   auto issue_piece = [&](int buf, int chunk, int q8) {  // q8 0..3: dY pieces, 4..7: im2col pieces
     const int q = q8 & 3;
     unsigned char* dst = smem + buf * STAGE + (q8 < 4 ? 0 : OPB) + (8 * wid + 2 * q) * ROWB;
-    const __bf16* src;
+    const h16_t* src;
     if (q8 < 4) {
       const int m = chunk * BP + rowl + 2 * q;
-      const __bf16* s0 = dyb + (unsigned)(m * p.K + i0 + choff[q & 1]);
+      const h16_t* s0 = dyb + (unsigned)(m * p.K + i0 + choff[q & 1]);
       src = ((m < p.M) & (chunk < chunk_end)) ? s0 : zero;   // past the split's end: zeros (keeps the vmcnt arithmetic uniform)
     } else {
       src = bsrc[q];
@@ -1684,7 +1684,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
   for (int i = 0; i < 4; ++i) aoff[i] = lrow + (((wm * 4 + i) ^ r3) << 6);
 #pragma unroll
   for (int j = 0; j < 2; ++j) boff[j] = OPB + lrow + (((wn * 2 + j) ^ r3) << 6);
-  typedef __bf16 frag_t __attribute__((ext_vector_type(8)));
+  typedef h16_t frag_t __attribute__((ext_vector_type(8)));
   typedef short s16x4 __attribute__((ext_vector_type(4)));
 #define TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define READ_FRAGS(set, S)                                                                         \
@@ -1741,7 +1741,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16(a[i], b[j], acc[i][j]);
     };
     if constexpr (SET == 0) bsrc0(ch + 1); else bsrc1(ch + 1);
     // k16 step s: [fragments of step s have landed] -> issue the reads of step s+1 -> 8 MFMAs -> memory work of the next chunks
@@ -1825,7 +1825,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
 // Column sums of a bf16 [M][K] matrix (the bias gradient next to conv_wgrad_bf16_w8, which never holds dY in registers):
 // block b sums its contiguous row range per channel -> partial[b][K]; fixed order everywhere.  K % 8 == 0, K <= 2048.
 // Four row loads in flight per thread, ~4 blocks per CU (a single dependent load per thread streamed at 3 TB/s).
-__global__ __launch_bounds__(256) void colsum_bf16_partial(const __bf16* __restrict__ g, float* __restrict__ partial, int M, int K,
+__global__ __launch_bounds__(256) void colsum_bf16_partial(const h16_t* __restrict__ g, float* __restrict__ partial, int M, int K,
                                                            int rows_per_block) {
   __shared__ float red[256 * 8];
   const int cpr = K >> 3;                    // 16-byte groups per row
@@ -2053,7 +2053,7 @@ static int wgrad_bf16_impl(const void* x, int x_dtype, int x_pitch, const void* 
       if (nb > WGRAD_W8_MAX_NB) nb = WGRAD_W8_MAX_NB;
       const int rows = cdiv(M, nb);
       nb = cdiv(M, rows);
-      hipLaunchKernelGGL(colsum_bf16_partial, dim3(nb), dim3(256), 0, stream, (const __bf16*)dy, part, M, K, rows);
+      hipLaunchKernelGGL(colsum_bf16_partial, dim3(nb), dim3(256), 0, stream, (const h16_t*)dy, part, M, K, rows);
       hipLaunchKernelGGL(colsum_final_f32, dim3(cdiv(K, 32)), dim3(256), 0, stream, (const float*)part, db, nb, K, accumulate, rowscale);
     }
     return utv2_launch_status();
@@ -2065,10 +2065,10 @@ static int wgrad_bf16_impl(const void* x, int x_dtype, int x_pitch, const void* 
   const int tiles = cdiv(K, 128) * cdiv(a.Kred, 128);
   const dim3 g(tiles * a.splits), b(256);
   if (x_dtype == UTV2_BF16) {
-    if (dy_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_wgrad_bf16<__bf16, __bf16>), g, b, 0, stream, a);
-    else hipLaunchKernelGGL((conv_wgrad_bf16<__bf16, float>), g, b, 0, stream, a);
+    if (dy_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_wgrad_bf16<h16_t, h16_t>), g, b, 0, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_bf16<h16_t, float>), g, b, 0, stream, a);
   } else {
-    if (dy_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_wgrad_bf16<float, __bf16>), g, b, 0, stream, a);
+    if (dy_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_wgrad_bf16<float, h16_t>), g, b, 0, stream, a);
     else hipLaunchKernelGGL((conv_wgrad_bf16<float, float>), g, b, 0, stream, a);
   }
   int rb = cdiv((int64_t)n / 4, 256);   // n = K * Kred, both multiples of 8

@@ -47,6 +47,64 @@ __global__ __launch_bounds__(256) void sgd_momentum_f32(float* __restrict__ p, f
 }
 
 // ---------------------------------------------------------------------------------------------
+// Dynamic loss scaling for the fp16 AMP mode, with torch.cuda.amp.GradScaler's semantics (the reference: engine/trainer.py:207,
+// 424-426 `scaler.scale(losses).backward(); scaler.step(optimizer); scaler.update()`), entirely on the device - no host read of
+// the inf flag.  state = fp32 {scale, found_inf, growth_tracker}:
+//   backward runs on scale * loss;  amp_found_inf marks non-finite gradients;  sgd_momentum_amp unscales (g / scale) and applies
+//   the update unless found_inf (GradScaler.step skips optimizer.step());  amp_update_scale: found_inf ? scale *= backoff, tracker = 0
+//   : (++tracker == interval ? scale *= growth, tracker = 0), then clears found_inf.
+__global__ __launch_bounds__(256) void amp_found_inf_f32(const float* __restrict__ g, size_t n4, size_t n, float* __restrict__ state) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (; i < n4; i += stride) {
+    const f32x4 v = ((const f32x4*)g)[i];
+    // x - x is 0 for finite x, NaN for +-inf and NaN
+    const float t = (v[0] - v[0]) + (v[1] - v[1]) + (v[2] - v[2]) + (v[3] - v[3]);
+    bad |= !(t == 0.f);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (size_t k = n4 * 4; k < n; ++k) bad |= !((g[k] - g[k]) == 0.f);
+  if (__any(bad) && (threadIdx.x & 63) == 0) state[1] = 1.0f;   // every writer stores the same value: order-free
+}
+
+__global__ __launch_bounds__(256) void sgd_momentum_amp_f32(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          size_t n, float lr, float mom, float wd, float gscale,
+                                                          const float* __restrict__ state) {
+  if (state[1] != 0.f) return;                       // non-finite gradients: the step is skipped
+  const float inv = 1.0f / state[0];                 // the scale is a power of two: exact
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float pv = p[i];
+    float gv = __fmul_rn(__fmul_rn(g[i], inv), gscale);
+    gv = __fadd_rn(gv, __fmul_rn(wd, pv));
+    const float mv = __fadd_rn(__fmul_rn(mom, m[i]), gv);
+    m[i] = mv;
+    p[i] = __fsub_rn(pv, __fmul_rn(lr, mv));
+  }
+}
+
+__global__ void amp_update_scale_f32(float* __restrict__ state, float growth, float backoff, int interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float scale = state[0], tracker = state[2];
+  if (state[1] != 0.f) {
+    scale *= backoff;
+    tracker = 0.f;
+  } else {
+    tracker += 1.f;
+    if (tracker >= (float)interval) {
+      const float grown = scale * growth;
+      if (grown - grown == 0.f) scale = grown;     // only while the grown scale is finite
+      tracker = 0.f;
+    }
+  }
+  state[0] = scale;
+  state[1] = 0.f;
+  state[2] = tracker;
+}
+
+// ---------------------------------------------------------------------------------------------
 // out = (mask_y ? (y > 0 ? dy : 0) : dy) * (scale ? scale[c] : 1)     on [M][C]
 template <typename T>
 __global__ __launch_bounds__(256) void relu_bwd_scale_k(const T* __restrict__ dy, const T* __restrict__ y,
@@ -111,7 +169,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_k(const TI* __restrict_
 }
 
 // bf16 -> bf16 form with 8 channels (16 bytes) per thread and 32-bit index arithmetic (max is exact: same result as the generic kernel)
-__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_bf16x8_k(const __bf16* __restrict__ x, __bf16* __restrict__ y, int N, int H, int W,
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_bf16x8_k(const h16_t* __restrict__ x, h16_t* __restrict__ y, int N, int H, int W,
                                                                 int C8, int OH, int OW) {
   const unsigned total = (unsigned)N * OH * OW * C8;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -138,7 +196,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_bf16x8_k(const __bf16* 
     }
     bf16x8_t o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (__bf16)m[e];
+    for (int e = 0; e < 8; ++e) o[e] = (h16_t)m[e];
     ((bf16x8_t*)y)[i] = o;
   }
 }
@@ -236,7 +294,7 @@ __global__ __launch_bounds__(256) void preprocess_chw_to_nhwc4(const T* __restri
 // bf16 form for the MFMA stem: the image lands at pixel offset (3, 3) of a [Hp+6][Wp+8][4] bf16 buffer whose border the
 // caller zeroed once (rows pitch Wp+8); the padded canvas beyond the image is written as zeros here.
 template <typename T>
-__global__ __launch_bounds__(256) void preprocess_chw_to_nhwc4_bf16pad(const T* __restrict__ src, __bf16* __restrict__ dst, int H, int W,
+__global__ __launch_bounds__(256) void preprocess_chw_to_nhwc4_bf16pad(const T* __restrict__ src, h16_t* __restrict__ dst, int H, int W,
                                                                      int Hp, int Wp, float m0, float m1, float m2, float s0,
                                                                      float s1, float s2) {
   const size_t total = (size_t)Hp * Wp;
@@ -263,11 +321,11 @@ struct PreBatch {
   int H[PRE_MAX_IMGS], W[PRE_MAX_IMGS];
 };
 template <typename T>
-__global__ __launch_bounds__(256) void preprocess_batch_bf16pad(PreBatch b, __bf16* __restrict__ dst, int Hp, int Wp, float m0, float m1,
+__global__ __launch_bounds__(256) void preprocess_batch_bf16pad(PreBatch b, h16_t* __restrict__ dst, int Hp, int Wp, float m0, float m1,
                                                               float m2, float s0, float s1, float s2) {
   const int n = blockIdx.y, H = b.H[n], W = b.W[n];
   const T* __restrict__ src = (const T*)b.src[n];
-  __bf16* out = dst + (size_t)n * (Hp + 6) * (Wp + 8) * 4;
+  h16_t* out = dst + (size_t)n * (Hp + 6) * (Wp + 8) * 4;
   const size_t total = (size_t)Hp * Wp;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -397,7 +455,7 @@ __global__ __launch_bounds__(256) void gn_stats_final(GnSegs sg, const float* __
 // per group): one block per segment; the 32-row blocks that lie inside the segment come from `part32`, the (< 32) rows in front of
 // the first and behind the last whole block - segments start at arbitrary rows - are summed here from x itself.  Thread (g = t % G,
 // lane = t / G); double accumulation, fixed order.
-__global__ __launch_bounds__(256) void gn_stats_final_p32(GnSegs sg, const float* __restrict__ part32, const __bf16* __restrict__ x,
+__global__ __launch_bounds__(256) void gn_stats_final_p32(GnSegs sg, const float* __restrict__ part32, const h16_t* __restrict__ x,
                                                         float* __restrict__ mean, float* __restrict__ rstd, int G, int C, float eps) {
   __shared__ double red[2][256];
   const int seg = blockIdx.x;
@@ -748,6 +806,29 @@ int utv2_sgd_momentum(float* param, float* grad, float* mom_buf, int64_t n, floa
   return utv2_launch_status();
 }
 
+// state: device fp32[3] = {loss scale, found_inf flag, growth tracker} (see amp_found_inf_f32)
+int utv2_amp_found_inf(const float* grad, int64_t n, float* state, hipStream_t stream) {
+  if (!grad || !state || n < 0 || ((uintptr_t)grad & 15)) return UTV2_EARG;
+  if (n == 0) return UTV2_OK;
+  hipLaunchKernelGGL(amp_found_inf_f32, dim3(grid_for((size_t)n / 4 + 1)), dim3(256), 0, stream, grad, (size_t)n / 4, (size_t)n, state);
+  return utv2_launch_status();
+}
+
+int utv2_sgd_momentum_amp(float* param, const float* grad, float* mom_buf, int64_t n, float lr, float momentum, float weight_decay,
+                          float grad_scale, const float* state, hipStream_t stream) {
+  if (!param || !grad || !mom_buf || !state || n < 0) return UTV2_EARG;
+  if (n == 0) return UTV2_OK;
+  hipLaunchKernelGGL(sgd_momentum_amp_f32, dim3(grid_for((size_t)n)), dim3(256), 0, stream, param, grad, mom_buf, (size_t)n, lr, momentum,
+                     weight_decay, grad_scale, state);
+  return utv2_launch_status();
+}
+
+int utv2_amp_update_scale(float* state, float growth_factor, float backoff_factor, int growth_interval, hipStream_t stream) {
+  if (!state || growth_interval < 1) return UTV2_EARG;
+  hipLaunchKernelGGL(amp_update_scale_f32, dim3(1), dim3(64), 0, stream, state, growth_factor, backoff_factor, growth_interval);
+  return utv2_launch_status();
+}
+
 // out[M][C] = (y? relu-mask by y : 1) * dy * (scale? scale[c] : 1).  C % 4 == 0.  dy / y / out are `dtype`.
 int utv2_relu_bwd_scale(const void* dy, const void* y, const float* scale, void* out, int64_t M, int C, int dtype,
                         hipStream_t stream) {
@@ -755,8 +836,8 @@ int utv2_relu_bwd_scale(const void* dy, const void* y, const float* scale, void*
   const size_t n4 = (size_t)M * C / 4;
   if (n4 == 0) return UTV2_OK;
   if (dtype == UTV2_BF16)
-    hipLaunchKernelGGL(relu_bwd_scale_k<__bf16>, dim3(grid_for(n4)), dim3(256), 0, stream, (const __bf16*)dy, (const __bf16*)y,
-                       scale, (__bf16*)out, n4, C / 4);
+    hipLaunchKernelGGL(relu_bwd_scale_k<h16_t>, dim3(grid_for(n4)), dim3(256), 0, stream, (const h16_t*)dy, (const h16_t*)y,
+                       scale, (h16_t*)out, n4, C / 4);
   else
     hipLaunchKernelGGL(relu_bwd_scale_k<float>, dim3(grid_for(n4)), dim3(256), 0, stream, (const float*)dy, (const float*)y,
                        scale, (float*)out, n4, C / 4);
@@ -778,13 +859,13 @@ int utv2_maxpool3x3s2_nhwc(const void* x, int x_dtype, void* y, int y_dtype, int
   if (x_dtype == UTV2_F32 && y_dtype == UTV2_F32)
     hipLaunchKernelGGL((maxpool3x3s2_nhwc_k<float, float>), g, b, 0, stream, (const float*)x, (float*)y, N, H, W, C / 4, OH, OW);
   else if (x_dtype == UTV2_F32 && y_dtype == UTV2_BF16)
-    hipLaunchKernelGGL((maxpool3x3s2_nhwc_k<float, __bf16>), g, b, 0, stream, (const float*)x, (__bf16*)y, N, H, W, C / 4, OH, OW);
+    hipLaunchKernelGGL((maxpool3x3s2_nhwc_k<float, h16_t>), g, b, 0, stream, (const float*)x, (h16_t*)y, N, H, W, C / 4, OH, OW);
   else if (x_dtype == UTV2_BF16 && y_dtype == UTV2_BF16 && (C & 7) == 0 && (size_t)N * OH * OW * C / 8 < (1ull << 31) &&
            (size_t)N * H * W < (1ull << 31))
     hipLaunchKernelGGL(maxpool3x3s2_nhwc_bf16x8_k, dim3(grid_for((size_t)N * OH * OW * C / 8, 256, 1 << 16)), b, 0, stream,
-                       (const __bf16*)x, (__bf16*)y, N, H, W, C / 8, OH, OW);
+                       (const h16_t*)x, (h16_t*)y, N, H, W, C / 8, OH, OW);
   else if (x_dtype == UTV2_BF16 && y_dtype == UTV2_BF16)
-    hipLaunchKernelGGL((maxpool3x3s2_nhwc_k<__bf16, __bf16>), g, b, 0, stream, (const __bf16*)x, (__bf16*)y, N, H, W, C / 4, OH, OW);
+    hipLaunchKernelGGL((maxpool3x3s2_nhwc_k<h16_t, h16_t>), g, b, 0, stream, (const h16_t*)x, (h16_t*)y, N, H, W, C / 4, OH, OW);
   else
     return UTV2_EARG;
   return utv2_launch_status();
@@ -795,7 +876,7 @@ int utv2_upsample2x_add_nhwc(const void* lateral, const void* top, void* out, in
   if (!lateral || !top || !out || (C & 3) || (H & 1) || (W & 1)) return UTV2_EARG;
   const dim3 g(grid_for((size_t)N * H * W * C / 4, 256, 1 << 16)), b(256);
   if (dtype == UTV2_BF16)
-    hipLaunchKernelGGL(upsample2x_add_nhwc_k<__bf16>, g, b, 0, stream, (const __bf16*)lateral, (const __bf16*)top, (__bf16*)out, N,
+    hipLaunchKernelGGL(upsample2x_add_nhwc_k<h16_t>, g, b, 0, stream, (const h16_t*)lateral, (const h16_t*)top, (h16_t*)out, N,
                        H, W, C / 4);
   else if (dtype == UTV2_F32)
     hipLaunchKernelGGL(upsample2x_add_nhwc_k<float>, g, b, 0, stream, (const float*)lateral, (const float*)top, (float*)out, N, H,
@@ -810,7 +891,7 @@ int utv2_downsample2x_sum_nhwc(const void* g, void* dtop, int N, int TH, int TW,
   if (!g || !dtop || (C & 3)) return UTV2_EARG;
   const dim3 gr(grid_for((size_t)N * TH * TW * C / 4, 256, 1 << 16)), b(256);
   if (dtype == UTV2_BF16)
-    hipLaunchKernelGGL(downsample2x_sum_nhwc_k<__bf16>, gr, b, 0, stream, (const __bf16*)g, (__bf16*)dtop, N, TH, TW, C / 4,
+    hipLaunchKernelGGL(downsample2x_sum_nhwc_k<h16_t>, gr, b, 0, stream, (const h16_t*)g, (h16_t*)dtop, N, TH, TW, C / 4,
                        accumulate);
   else if (dtype == UTV2_F32)
     hipLaunchKernelGGL(downsample2x_sum_nhwc_k<float>, gr, b, 0, stream, (const float*)g, (float*)dtop, N, TH, TW, C / 4, accumulate);
@@ -825,7 +906,7 @@ int utv2_zero_interleave2x_nhwc(const void* src, const void* mask, void* dst, in
   const int TH = (H + 1) / 2, TW = (W + 1) / 2;
   const dim3 g(grid_for((size_t)N * H * W * C / 4, 256, 1 << 16)), b(256);
   if (dtype == UTV2_BF16)
-    hipLaunchKernelGGL(zero_interleave2x_nhwc_k<__bf16>, g, b, 0, stream, (const __bf16*)src, (const __bf16*)mask, (__bf16*)dst, N, H, W, TH, TW, C / 4);
+    hipLaunchKernelGGL(zero_interleave2x_nhwc_k<h16_t>, g, b, 0, stream, (const h16_t*)src, (const h16_t*)mask, (h16_t*)dst, N, H, W, TH, TW, C / 4);
   else if (dtype == UTV2_F32)
     hipLaunchKernelGGL(zero_interleave2x_nhwc_k<float>, g, b, 0, stream, (const float*)src, (const float*)mask, (float*)dst, N, H, W, TH, TW, C / 4);
   else
@@ -858,9 +939,9 @@ int utv2_preprocess_image_bf16pad(const void* src, int is_u8, void* dst16, int H
   const int g = grid_for((size_t)Hp * Wp, 256, 1 << 16);
   if (is_u8)
     hipLaunchKernelGGL((preprocess_chw_to_nhwc4_bf16pad<unsigned char>), dim3(g), dim3(256), 0, stream, (const unsigned char*)src,
-                       (__bf16*)dst16, H, W, Hp, Wp, m0, m1, m2, s0, s1, s2);
+                       (h16_t*)dst16, H, W, Hp, Wp, m0, m1, m2, s0, s1, s2);
   else
-    hipLaunchKernelGGL((preprocess_chw_to_nhwc4_bf16pad<float>), dim3(g), dim3(256), 0, stream, (const float*)src, (__bf16*)dst16,
+    hipLaunchKernelGGL((preprocess_chw_to_nhwc4_bf16pad<float>), dim3(g), dim3(256), 0, stream, (const float*)src, (h16_t*)dst16,
                        H, W, Hp, Wp, m0, m1, m2, s0, s1, s2);
   return utv2_launch_status();
 }
@@ -880,10 +961,10 @@ int utv2_preprocess_images_bf16pad(const void* const* src_host, int is_u8, void*
   const float s0 = std3_host[0], s1 = std3_host[1], s2 = std3_host[2];
   const int g = grid_for((size_t)Hp * Wp, 256, 1 << 12);
   if (is_u8)
-    hipLaunchKernelGGL((preprocess_batch_bf16pad<unsigned char>), dim3(g, N), dim3(256), 0, stream, b, (__bf16*)dst16, Hp, Wp, m0, m1, m2, s0,
+    hipLaunchKernelGGL((preprocess_batch_bf16pad<unsigned char>), dim3(g, N), dim3(256), 0, stream, b, (h16_t*)dst16, Hp, Wp, m0, m1, m2, s0,
                        s1, s2);
   else
-    hipLaunchKernelGGL((preprocess_batch_bf16pad<float>), dim3(g, N), dim3(256), 0, stream, b, (__bf16*)dst16, Hp, Wp, m0, m1, m2, s0, s1, s2);
+    hipLaunchKernelGGL((preprocess_batch_bf16pad<float>), dim3(g, N), dim3(256), 0, stream, b, (h16_t*)dst16, Hp, Wp, m0, m1, m2, s0, s1, s2);
   return utv2_launch_status();
 }
 
@@ -913,7 +994,7 @@ int utv2_groupnorm_relu_seg_fwd(const void* x, const float* gamma, const float* 
   if (!x || !y || !mean || !rstd || !ws || !gn_check(nseg, C, G) || (dtype != UTV2_F32 && dtype != UTV2_BF16)) return UTV2_EARG;
   GnSegs sg;
   const int chunks = gn_fill(sg, nseg, seg_rows_host);
-  if (dtype == UTV2_BF16) gn_fwd_launch<__bf16>(sg, chunks, nseg, x, gamma, beta, y, mean, rstd, ws, C, G, eps, relu, stream);
+  if (dtype == UTV2_BF16) gn_fwd_launch<h16_t>(sg, chunks, nseg, x, gamma, beta, y, mean, rstd, ws, C, G, eps, relu, stream);
   else gn_fwd_launch<float>(sg, chunks, nseg, x, gamma, beta, y, mean, rstd, ws, C, G, eps, relu, stream);
   return utv2_launch_status();
 }
@@ -927,9 +1008,9 @@ int utv2_groupnorm_relu_seg_fwd_p32(const void* x, const float* gamma, const flo
   if (!x || !y || !mean || !rstd || !part32 || !gn_check(nseg, C, G) || C != 8 * G) return UTV2_EARG;
   GnSegs sg;
   const int chunks = gn_fill(sg, nseg, seg_rows_host);
-  hipLaunchKernelGGL(gn_stats_final_p32, dim3(nseg), dim3(256), 0, stream, sg, part32, (const __bf16*)x, mean, rstd, G, C, eps);
-  hipLaunchKernelGGL(gn_apply_relu<__bf16>, dim3(chunks), dim3(256), 0, stream, sg, (const __bf16*)x, (const float*)mean, (const float*)rstd,
-                     gamma, beta, (__bf16*)y, C, G, relu);
+  hipLaunchKernelGGL(gn_stats_final_p32, dim3(nseg), dim3(256), 0, stream, sg, part32, (const h16_t*)x, mean, rstd, G, C, eps);
+  hipLaunchKernelGGL(gn_apply_relu<h16_t>, dim3(chunks), dim3(256), 0, stream, sg, (const h16_t*)x, (const float*)mean, (const float*)rstd,
+                     gamma, beta, (h16_t*)y, C, G, relu);
   return utv2_launch_status();
 }
 
@@ -952,7 +1033,7 @@ int utv2_groupnorm_relu_seg_bwd_colsum(const void* dy, const void* y, const void
   GnSegs sg;
   const int chunks = gn_fill(sg, nseg, seg_rows_host);
   if (dtype == UTV2_BF16)
-    gn_bwd_launch<__bf16>(sg, chunks, nseg, dy, y, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, ws, C, G, relu, colsum_part, stream);
+    gn_bwd_launch<h16_t>(sg, chunks, nseg, dy, y, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, ws, C, G, relu, colsum_part, stream);
   else gn_bwd_launch<float>(sg, chunks, nseg, dy, y, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, ws, C, G, relu, colsum_part, stream);
   return utv2_launch_status();
 }

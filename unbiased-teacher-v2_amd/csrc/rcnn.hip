@@ -984,8 +984,8 @@ int utv2_roi_align_fwd(int num_levels, int min_level, const void* const* feats_h
     return UTV2_EARG;
   if (R == 0) return UTV2_OK;
   if (dtype == UTV2_BF16)
-    hipLaunchKernelGGL((roi_align_kernel<false, __bf16>), dim3(R * PH * PW), dim3(64), 0, stream, L, rois, roi_batch, roi_valid, C, PH,
-                       PW, (__bf16*)out);
+    hipLaunchKernelGGL((roi_align_kernel<false, h16_t>), dim3(R * PH * PW), dim3(64), 0, stream, L, rois, roi_batch, roi_valid, C, PH,
+                       PW, (h16_t*)out);
   else
     hipLaunchKernelGGL((roi_align_kernel<false, float>), dim3(R * PH * PW), dim3(64), 0, stream, L, rois, roi_batch, roi_valid, C, PH,
                        PW, (float*)out);
@@ -1002,8 +1002,8 @@ int utv2_roi_align_bwd(int num_levels, int min_level, float* const* dfeats_host,
     return UTV2_EARG;
   if (R == 0) return UTV2_OK;
   if (dtype == UTV2_BF16)
-    hipLaunchKernelGGL((roi_align_kernel<true, __bf16>), dim3(R * PH * PW), dim3(64), 0, stream, L, rois, roi_batch, roi_valid, C, PH,
-                       PW, (__bf16*)dy);
+    hipLaunchKernelGGL((roi_align_kernel<true, h16_t>), dim3(R * PH * PW), dim3(64), 0, stream, L, rois, roi_batch, roi_valid, C, PH,
+                       PW, (h16_t*)dy);
   else
     hipLaunchKernelGGL((roi_align_kernel<true, float>), dim3(R * PH * PW), dim3(64), 0, stream, L, rois, roi_batch, roi_valid, C, PH,
                        PW, (float*)dy);
@@ -1035,10 +1035,10 @@ int utv2_roi_align_bwd_tiled(int num_levels, int min_level, void* const* dfeats_
   a.num_levels = num_levels; a.min_level = min_level; a.N = N; a.P = rois_per_image; a.C = C; a.PH = PH; a.PW = PW;
   const dim3 g(blocks), b(256);
   if (dy_dtype == UTV2_BF16) {
-    if (out_dtype == UTV2_BF16) hipLaunchKernelGGL((roi_align_bwd_tiled<__bf16, __bf16>), g, b, 0, stream, a, rois, roi_valid, (const __bf16*)dy);
-    else hipLaunchKernelGGL((roi_align_bwd_tiled<__bf16, float>), g, b, 0, stream, a, rois, roi_valid, (const __bf16*)dy);
+    if (out_dtype == UTV2_BF16) hipLaunchKernelGGL((roi_align_bwd_tiled<h16_t, h16_t>), g, b, 0, stream, a, rois, roi_valid, (const h16_t*)dy);
+    else hipLaunchKernelGGL((roi_align_bwd_tiled<h16_t, float>), g, b, 0, stream, a, rois, roi_valid, (const h16_t*)dy);
   } else {
-    if (out_dtype == UTV2_BF16) hipLaunchKernelGGL((roi_align_bwd_tiled<float, __bf16>), g, b, 0, stream, a, rois, roi_valid, (const float*)dy);
+    if (out_dtype == UTV2_BF16) hipLaunchKernelGGL((roi_align_bwd_tiled<float, h16_t>), g, b, 0, stream, a, rois, roi_valid, (const float*)dy);
     else hipLaunchKernelGGL((roi_align_bwd_tiled<float, float>), g, b, 0, stream, a, rois, roi_valid, (const float*)dy);
   }
   return utv2_launch_status();

@@ -131,7 +131,7 @@ def _make(base):
             self.optimizer.zero_grad()
             self._backward(losses)
             gscale = self._allreduce_grads()
-            self.optimizer.step(grad_scale=gscale)
+            self.optimizer.step(grad_scale=gscale, amp_state=self._amp_state)
             return losses
 
         # test() / build_test_loader() / build_evaluator() come from the shared base (reference trainer.py:986-1023 ≡ :554-608): the

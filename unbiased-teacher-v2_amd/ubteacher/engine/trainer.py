@@ -49,13 +49,21 @@ class ArenaSGD:
     def zero_grad(self):
         self.store.grad.zero_()
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, amp_state=None):
+        """amp_state (fp16 mode): device fp32 {loss scale, found_inf, growth tracker} - the step unscales the gradients and is skipped on
+        the device when they hold a non-finite value (GradScaler.step)"""
         st = self.store
         lr = self.param_groups[0]["lr"]
+        if amp_state is not None:
+            hip.amp_found_inf(st.grad, amp_state)
         for kind, wd in (("decay", self.wd), ("nodecay", self.wd_norm)):
             s, e = st.ranges[kind]
-            if e > s:
+            if e > s and amp_state is not None:
+                hip.sgd_momentum_amp(st.flat[s:e], st.grad[s:e], st.mom[s:e], lr, self.momentum, wd, grad_scale, amp_state)
+            elif e > s:
                 hip.sgd_momentum(st.flat[s:e], st.grad[s:e], st.mom[s:e], lr, self.momentum, wd, grad_scale, zero_grad=False)
+        if amp_state is not None:
+            hip.amp_update_scale(amp_state, 2.0, 0.5, 2000)   # torch.cuda.amp.GradScaler defaults [SURVEY appendix C]
         ops.bump_version()
         st.touch()
 
@@ -185,10 +193,16 @@ class _TrainerBase:
 
     def _common_init(self, cfg, data_loader=None):
         self.cfg = cfg
-        # SOLVER.AMP.ENABLED (reference: autocast + GradScaler, trainer.py:194-198,423-426) selects the bf16-MFMA conv
-        # kernels; bf16 has fp32's exponent range so no loss scaling is needed.  UTV2_PRECISION overrides.
+        # SOLVER.AMP.ENABLED (reference: autocast + GradScaler, trainer.py:194-198,423-426) selects the 16-bit MFMA conv kernels:
+        # bf16 by default (fp32's exponent range: no loss scaling, nothing to overflow on unnormalised features), or - UTV2_PRECISION=fp16 -
+        # the reference's own element type, IEEE fp16, with GradScaler's dynamic loss scale kept on the device (the config surface
+        # is the reference's, key for key: the 16-bit type is an environment choice, not a new config key)
         import os
-        ops.set_precision(os.environ.get("UTV2_PRECISION", "bf16" if cfg.SOLVER.AMP.ENABLED else "fp32"))
+        amp_kind = os.environ.get("UTV2_PRECISION") or ("bf16" if cfg.SOLVER.AMP.ENABLED else "fp32")
+        ops.set_precision({"f32": "fp32", "f16": "fp16"}.get(amp_kind, amp_kind))
+        self._amp_state = None
+        if ops.PRECISION[0] == "fp16":
+            self._amp_state = torch.tensor([65536.0, 0.0, 0.0], dtype=torch.float32).to(self.model.store.flat.device)   # GradScaler init_scale
         self.start_iter = 0
         self.max_iter = cfg.SOLVER.MAX_ITER
         self.iter = 0
@@ -288,6 +302,8 @@ class _TrainerBase:
             gs.arm()
         ops.wgrad_side_stream(True)      # weight gradients on a side stream, next to the dgrad chain (ops._wgrad_launch)
         try:
+            if getattr(self, "_amp_state", None) is not None:
+                losses = losses * self._amp_state[0]     # scaler.scale(losses): every gradient of the backward carries the loss scale
             losses.backward()
             ops.FanIn.check()            # a gradient handed from one producer to another's epilogue must have been picked up
         finally:
@@ -553,7 +569,7 @@ class UBTeacherTrainer(_TrainerBase):
         self.optimizer.zero_grad()
         self._backward(losses)
         gscale = self._allreduce_grads()
-        self.optimizer.step(grad_scale=gscale)
+        self.optimizer.step(grad_scale=gscale, amp_state=self._amp_state)
         return losses
 
 

@@ -12,6 +12,20 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libutv2_hip.so")
+# two builds of the same sources (csrc/common.h h16_t): the 16-bit float type of the mixed-precision kernels is bfloat16 in the first and
+# IEEE fp16 (the reference's own autocast element type) in the second; the dtype code UTV2_BF16 means "the library's 16-bit type"
+LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(os.path.dirname(_HERE), "lib", "libutv2_hip_f16.so")}
+H16 = ["bf16"]          # the build every call goes to (ops.set_precision selects it)
+
+
+def set_h16(kind):
+    assert kind in LIB_PATHS
+    H16[0] = kind
+
+
+def h16_dtype():
+    """torch dtype of the selected library's 16-bit activations"""
+    return torch.bfloat16 if H16[0] == "bf16" else torch.float16
 
 _lib = None
 
@@ -57,21 +71,26 @@ _PLAIN = {"utv2_aug_resize_workspace_bytes", "utv2_topk_rows_workspace_bytes", "
           "utv2_nms_mpad", "utv2_nms_workspace_bytes"}  # return a value, not a status
 
 
-def load():
-    """dlopen the library and bind every declared symbol (works without a GPU)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+_libs = {}
+
+
+def load(kind=None):
+    """dlopen the library (of the selected 16-bit type, or of `kind`) and bind every declared symbol (works without a GPU)."""
+    kind = kind or H16[0]
+    lib = _libs.get(kind)
+    if lib is not None:
+        return lib
+    path = LIB_PATHS[kind]
+    if not os.path.exists(path):
         raise RuntimeError(
-            "HIP extension %s is missing - run `python __graft_entry__.py` (hipcc, gfx950)" % LIB_PATH
+            "HIP extension %s is missing - run `python __graft_entry__.py` (hipcc, gfx950)" % path
         )
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[kind] = lib
     return lib
 
 
@@ -94,9 +113,9 @@ def _dt(t):
     """element-type code of an activation tensor (UTV2_F32 / UTV2_BF16 in include/utv2.h)"""
     if t.dtype == torch.float32:
         return 0
-    if t.dtype == torch.bfloat16:
+    if t.dtype == h16_dtype():
         return 1
-    raise TypeError("activation tensors are fp32 or bf16, got %s" % t.dtype)
+    raise TypeError("activation tensors are fp32 or %s (the selected library's 16-bit type), got %s" % (h16_dtype(), t.dtype))
 
 
 def _same_dt(*ts):
@@ -222,6 +241,19 @@ def sgd_momentum(param, grad, mom, lr, momentum, weight_decay, grad_scale=1.0, z
          float(weight_decay), float(grad_scale), int(zero_grad), _stream())
 
 
+def amp_found_inf(grad, state):
+    call("utv2_amp_found_inf", _p(grad), grad.numel(), _p(state), _stream())
+
+
+def sgd_momentum_amp(param, grad, mom, lr, momentum, weight_decay, grad_scale, state):
+    call("utv2_sgd_momentum_amp", _p(param), _p(grad), _p(mom), param.numel(), float(lr), float(momentum), float(weight_decay),
+         float(grad_scale), _p(state), _stream())
+
+
+def amp_update_scale(state, growth=2.0, backoff=0.5, interval=2000):
+    call("utv2_amp_update_scale", _p(state), float(growth), float(backoff), int(interval), _stream())
+
+
 def relu_bwd_scale(dy, y=None, scale=None, out=None):
     C = dy.shape[-1]
     M = dy.numel() // C
@@ -293,12 +325,12 @@ def preprocess_images(images, mean, std, size_divisibility, bf16_stem=False):
     if bf16_stem and Wm % 2 == 0:
         # keyed by stream too (as workspace() is): the teacher's pass on its side stream and a student pass on the main stream may
         # preprocess batches of the same shape concurrently
-        key = (len(images), Hm, Wm, str(dev), int(torch.cuda.current_stream(dev).cuda_stream))
+        key = (len(images), Hm, Wm, str(dev), int(torch.cuda.current_stream(dev).cuda_stream), H16[0])
         out = _stem_in_cache.get(key)
         if out is None:
             if len(_stem_in_cache) > 16:
                 _stem_in_cache.clear()
-            out = torch.zeros((len(images), Hm + 6, Wm + 8, 4), dtype=torch.bfloat16, device=dev)
+            out = torch.zeros((len(images), Hm + 6, Wm + 8, 4), dtype=h16_dtype(), device=dev)
             _stem_in_cache[key] = out
         n = len(images)
         dt = images[0].dtype
@@ -339,7 +371,7 @@ def stem_weight_image(w208):
     """fp32 [K, 208] (7x7x4 taps, 16-padded rows) -> bf16 [K, 7*32]: per kernel row 7 taps x 4 channels + 4 zeros"""
     K = w208.shape[0]
     w = w208[:, :196].reshape(K, 7, 28)
-    return torch.nn.functional.pad(w, (0, 4)).reshape(K, 224).to(torch.bfloat16).contiguous()
+    return torch.nn.functional.pad(w, (0, 4)).reshape(K, 224).to(h16_dtype()).contiguous()
 
 
 def frozenbn_fold(w, b, mean, var, scale, shift, eps=1e-5):
@@ -764,7 +796,7 @@ def f32_to_bf16(src, dst16):
 
 def weight_flip_transpose_bf16(w, K, kh, kw, C, scale=None):
     """dgrad weight image; scale [K] (optional) = folded FrozenBN multiplier applied per output channel"""
-    wt = torch.empty((C, kh * kw * K), dtype=torch.bfloat16, device=w.device)
+    wt = torch.empty((C, kh * kw * K), dtype=h16_dtype(), device=w.device)
     call("utv2_weight_flip_transpose_bf16", _p(w), _p(wt), _p(scale), K, kh, kw, C, _stream())
     return wt
 
@@ -776,7 +808,7 @@ def _act_dtype(x, out_dtype):
 def pad_cols_bf16(src2d, cpad):
     """[rows, c] fp32 / bf16 -> bf16 [rows, cpad], zero padded columns"""
     rows, c = src2d.shape
-    out = torch.empty((rows, cpad), dtype=torch.bfloat16, device=src2d.device)
+    out = torch.empty((rows, cpad), dtype=h16_dtype(), device=src2d.device)
     call("utv2_pad_cols_bf16", _p(src2d), _dt(src2d), _p(out), rows, c, cpad, _stream())
     return out
 
@@ -791,7 +823,7 @@ def conv2d_fwd_bf16(x, w16, scale=None, bias=None, residual=None, stride=1, pad=
     """x: fp32 or bf16 NHWC; the output (and `residual`) element type is out_dtype (default: x's)."""
     N, H, W, C = x.shape
     K = w16.shape[0]
-    assert w16.dtype == torch.bfloat16 and C % 8 == 0
+    assert w16.dtype == h16_dtype() and C % 8 == 0
     if out_hw is None:
         OH, OW = conv_out_size(H, kh, stride, pad), conv_out_size(W, kw, stride, pad)
     else:
@@ -853,7 +885,7 @@ def gn_part_buffer(P, K, device):
 def groupnorm_relu_seg_fwd_p32(x2d, seg_rows, gamma, beta, part32, G, eps=1e-5, relu=True):
     """groupnorm_relu_seg_fwd for bf16 x2d with 8 channels per group whose producer left the statistics partials in part32"""
     rows, C = x2d.shape
-    assert sum(seg_rows) == rows and x2d.dtype == torch.bfloat16 and C == 8 * G
+    assert sum(seg_rows) == rows and x2d.dtype == h16_dtype() and C == 8 * G
     y = torch.empty_like(x2d)
     S = len(seg_rows)
     mean = torch.empty((S, G), dtype=torch.float32, device=x2d.device)

@@ -142,12 +142,12 @@ class ResNet50:
             raise NotImplementedError("MODEL.BACKBONE.FREEZE_AT < 1 (trainable stem) is not built: no shipped config uses it")
         # frozen stem + pool run outside autograd; under AMP the bf16 activation pipeline starts at the stem's output
         sc, sh = self.stem.scale_shift()
-        if x4.dtype == torch.bfloat16:  # AMP: bf16-MFMA stem on the zero-bordered bf16 image
-            v = self.stem_w.store.version
+        if x4.dtype == hip.h16_dtype():  # AMP: 16-bit MFMA stem on the zero-bordered 16-bit image
+            v = (self.stem_w.store.version, hip.H16[0])
             if getattr(self, "_w16s_version", None) != v:
                 self._w16s = hip.stem_weight_image(self.stem_w.t)
                 self._w16s_version = v
-            x = hip.conv2d_stem_fwd_bf16(x4, self._w16s, sc, sh, True, torch.bfloat16)
+            x = hip.conv2d_stem_fwd_bf16(x4, self._w16s, sc, sh, True, hip.h16_dtype())
         else:
             x = hip.conv2d_stem_fwd(x4, self.stem_w.t, sc, sh, 2, 3, 7, 7, True, ops.act_dtype())
         x = hip.maxpool3x3s2(x)

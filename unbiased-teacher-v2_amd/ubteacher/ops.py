@@ -15,17 +15,26 @@ import torch
 from . import hip
 
 _HOOKS = {}
-PRECISION = ["fp32"]  # "fp32" (exact-f32 MFMA; the parity path) or "bf16" (AMP: bf16 MFMA operands, fp32 accumulate)
+# "fp32" (exact-f32 MFMA; the parity path), "bf16" (AMP: bf16 MFMA operands, fp32 accumulate) or "fp16" (AMP with the reference's own
+# autocast element type: IEEE fp16 operands / activations / activation gradients on v_mfma_f32_32x32x16_f16 - same rate -, dynamic
+# loss scaling with torch.cuda.amp.GradScaler's semantics, engine/trainer.py:195,207,424-426; the second build of the kernel library)
+PRECISION = ["fp32"]
 
 
 def set_precision(p):
-    assert p in ("fp32", "bf16")
+    assert p in ("fp32", "bf16", "fp16")
     PRECISION[0] = p
+    hip.set_h16("fp16" if p == "fp16" else "bf16")
+
+
+def amp():
+    """mixed precision: 16-bit MFMA operands and activations (either 16-bit type)"""
+    return PRECISION[0] != "fp32"
 
 
 def act_dtype():
-    """Element type of activations (and their gradients) in HBM: bf16 under AMP, like autocast's conv outputs."""
-    return torch.bfloat16 if PRECISION[0] == "bf16" else torch.float32
+    """Element type of activations (and their gradients) in HBM: 16-bit under AMP, like autocast's conv outputs."""
+    return hip.h16_dtype() if amp() else torch.float32
 
 
 _VERSION = [0]  # bumped by the optimizer step: invalidates cached dgrad weight images
@@ -144,16 +153,17 @@ class FlipBank:
         self.single = {}      # id(layer) -> (version, tensor): per-layer images served before the layer is in the tables
 
     def _current(self):
-        return (_VERSION[0], self.store.version)
+        return (_VERSION[0], self.store.version, hip.H16[0])
 
     def _rebuild(self):
         import struct
+        self.h16 = hip.H16[0]
         dev = self.store.flat.device
         offs, total = [], 0
         for layer, _ in self.layers:
             offs.append(total)
             total += (layer.dgrad_cout() * layer.k * layer.k * layer.cin + 7) // 8 * 8
-        self.bank = torch.empty(total, dtype=torch.bfloat16, device=dev)
+        self.bank = torch.empty(total, dtype=hip.h16_dtype(), device=dev)
         self.scales = None
         rec = bytearray()
         self.nrec = 0
@@ -194,7 +204,7 @@ class FlipBank:
             return self.views[i]
         elif self.version != cur and (i is not None):
             # first request after the arena changed: refresh every registered layer in one launch
-            if self.dirty or self.bank is None:
+            if self.dirty or self.bank is None or self.h16 != hip.H16[0]:
                 self._rebuild()
             hip.weight_flip_transpose_bf16_batched(self.store.flat, self.scales, self.bank, self.table, self.nrec)
             self.version = cur
@@ -273,10 +283,10 @@ class Conv:
         return self.cout
 
     def use_bf16(self):
-        return PRECISION[0] == "bf16" and self.cin % 8 == 0 and self.kred == self.k * self.k * self.cin
+        return amp() and self.cin % 8 == 0 and self.kred == self.k * self.k * self.cin
 
     def use_bf16_wgrad(self):
-        return (PRECISION[0] == "bf16" and self.cin % 8 == 0 and self.cout % 8 == 0 and self.k * self.k <= 16
+        return (amp() and self.cin % 8 == 0 and self.cout % 8 == 0 and self.k * self.k <= 16
                 and self.kred == self.k * self.k * self.cin)
 
     def gn_stats_fused(self):
@@ -292,7 +302,7 @@ class Conv:
             and os.environ.get("UTV2_GN_BIAS_GRAD", "1") != "0"
 
     def use_bf16_dgrad(self):
-        return PRECISION[0] == "bf16" and self.cout % 8 == 0
+        return amp() and self.cout % 8 == 0
 
     def __call__(self, x, residual=None, out=None, colscale_handle=None, meta=None):
         """x: NHWC tensor, or a level-first [P, C] matrix with `meta` (one launch for all levels; k x k
@@ -308,7 +318,7 @@ class Conv:
         w = self.w.store.bf16(self.w) if b16 else self.w.t
         kw = {}
         if b16:  # output element type: the destination's if one is given, else bf16 unless this layer feeds fp32 consumers
-            kw["out_dtype"] = out.dtype if out is not None else (torch.float32 if self.out_fp32 else torch.bfloat16)
+            kw["out_dtype"] = out.dtype if out is not None else (torch.float32 if self.out_fp32 else hip.h16_dtype())
         else:
             assert x.dtype == torch.float32, "the fp32 conv kernels take fp32 activations (layer cin=%d)" % self.cin
         if not b16 and not x.is_contiguous():
@@ -319,7 +329,7 @@ class Conv:
             assert self.stride == 1 and self.pad == (self.k - 1) // 2
             if b16:
                 part = None
-                if self.gn_stats_fused() and out is None and residual is None and kw["out_dtype"] == torch.bfloat16 and self.cin % 32 == 0:
+                if self.gn_stats_fused() and out is None and residual is None and kw["out_dtype"] == hip.h16_dtype() and self.cin % 32 == 0:
                     part = hip.gn_part_buffer(x.shape[0], self.cout, x.device)
                 y = hip.conv2d_ml_fwd_bf16(x, w, meta.level_hw, meta.N, scale=sc, bias=sh, residual=residual, k=self.k, pad=self.pad,
                                            relu=self.relu, out=out, groups=self.groups, gn_part=part, **kw)
@@ -507,7 +517,7 @@ def _wgrad16(layer, x4, g4):
 
 def _dgrad16(layer, g4, in_shape, mask=None, residual=None, post_mask=None):
     return hip.conv2d_dgrad_bf16(g4, layer.wt16(layer.bn.scale), tuple(in_shape), layer.stride, layer.pad, layer.k, layer.k,
-                                 out_dtype=torch.bfloat16, mask=mask, residual=residual, post_mask=post_mask)
+                                 out_dtype=hip.h16_dtype(), mask=mask, residual=residual, post_mask=post_mask)
 
 
 def premask_on():
@@ -556,8 +566,8 @@ class _BottleneckFn(torch.autograd.Function):
             if cs is None:
                 dx = _dgrad16(c1, g1, x.shape, residual=gm, post_mask=pm)   # identity branch added in the epilogue
             elif c1.stride == 2:
-                c = hip.conv2d_fwd_bf16(gm, cs.wt16(cs.bn.scale), out_dtype=torch.bfloat16)       # compact grids: only the
-                c = hip.conv2d_fwd_bf16(g1, c1.wt16(c1.bn.scale), residual=c, out_dtype=torch.bfloat16)   # even pixels get gradient
+                c = hip.conv2d_fwd_bf16(gm, cs.wt16(cs.bn.scale), out_dtype=hip.h16_dtype())       # compact grids: only the
+                c = hip.conv2d_fwd_bf16(g1, c1.wt16(c1.bn.scale), residual=c, out_dtype=hip.h16_dtype())   # even pixels get gradient
                 dx = hip.zero_interleave2x(c, x.shape[1], x.shape[2], mask=pm)
             else:
                 d = _dgrad16(cs, gm, x.shape)
@@ -572,7 +582,7 @@ class _BottleneckFn(torch.autograd.Function):
 def bottleneck(block, x):
     """one fused autograd node when every conv of the block runs on the bf16 kernels, else the per-conv graph"""
     convs = [c for c in (block.conv1, block.conv2, block.conv3, block.shortcut) if c is not None]
-    fused = (PRECISION[0] == "bf16" and torch.is_grad_enabled() and x.dtype == torch.bfloat16
+    fused = (amp() and torch.is_grad_enabled() and x.dtype == hip.h16_dtype()
              and all(c.trainable and c.bn is not None and c.bias is None and c.use_bf16() and c.use_bf16_wgrad() and c.use_bf16_dgrad()
                      for c in convs)
              and block.conv1.stride in (1, 2) and block.conv1.k == 1 and block.conv3.k == 1)
@@ -668,7 +678,7 @@ class GroupNormReLU:
         gp = conv._gn_part if conv is not None else None
         if gp is not None:
             conv._gn_part = None
-            if gp[0] == x.data_ptr() and x.dtype == torch.bfloat16:   # x is the output that conv just wrote: its epilogue left the statistics
+            if gp[0] == x.data_ptr() and x.dtype == hip.h16_dtype():   # x is the output that conv just wrote: its epilogue left the statistics
                 return hip.groupnorm_relu_seg_fwd_p32(x, meta.seg_rows, self.gamma.t, self.beta.t, gp[1], self.groups, self.eps, self.relu)
         return hip.groupnorm_relu_seg_fwd(x, meta.seg_rows, self.gamma.t, self.beta.t, self.groups, self.eps, self.relu)
 
@@ -855,7 +865,7 @@ class FanIn:
 
 
 def fanin_enabled():
-    return PRECISION[0] == "bf16" and os.environ.get("UTV2_FANIN", "1") != "0"
+    return amp() and os.environ.get("UTV2_FANIN", "1") != "0"
 
 
 class _AssembleFn(torch.autograd.Function):
@@ -897,7 +907,7 @@ class _RoIAlignFn(torch.autograd.Function):
         R = rois.shape[0]
         if ctx.per_image > 0 and R == N * ctx.per_image and C <= 256 and out_size <= 7:
             # ROIs laid out image by image (the ROI heads' [N, P] slots): deterministic gather, final dtype written directly
-            st = ctx.fanin.store(C, ctx.fdtype, dy.device) if (ctx.fanin is not None and ctx.fdtype == torch.bfloat16) else None
+            st = ctx.fanin.store(C, ctx.fdtype, dy.device) if (ctx.fanin is not None and ctx.fdtype == hip.h16_dtype()) else None
             if st is not None and [tuple(o.shape) for o in st[1]] == [tuple(x) for x in ctx.shapes]:
                 # the RPN conv's dgrad adds these level gradients in its epilogue (FanIn): no gradient reported from here
                 hip.roi_align_bwd_tiled(ctx.shapes, ctx.fdtype, scales, min_level, rois, roi_valid, dy.contiguous(), ctx.per_image, outs=st[1])

@@ -105,10 +105,11 @@ class ParamStore:
 
     def bf16(self, h):
         """bf16 view of handle `h` from the arena's bf16 mirror (ONE conversion launch per arena version)."""
-        if self._flat16 is None:
-            self._flat16 = torch.empty(self.total, dtype=torch.bfloat16, device=self.flat.device)
+        from . import hip
+        if self._flat16 is None or self._flat16.dtype != hip.h16_dtype():
+            self._flat16 = torch.empty(self.total, dtype=hip.h16_dtype(), device=self.flat.device)
+            self._v16 = -1
         if self._v16 != self.version:
-            from . import hip
             hip.f32_to_bf16(self.flat, self._flat16)
             self._v16 = self.version
         return self._flat16[h.offset: h.offset + h.numel].view(h.shape)
