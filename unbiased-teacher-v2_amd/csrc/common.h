@@ -32,7 +32,7 @@ typedef _Float16 mfma_f16x8 __attribute__((ext_vector_type(8)));
 // v_mfma_f32_32x32x16_{bf16,f16}: same shape, same rate (2.5 PFLOP/s dense), fp32 accumulate
 __device__ __forceinline__ float __attribute__((ext_vector_type(16))) mfma_32x32x16(mfma_bf16x8 a, mfma_bf16x8 b,
                                                                                  float __attribute__((ext_vector_type(16))) c) {
-  return mfma_32x32x16(a, b, c);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ float __attribute__((ext_vector_type(16))) mfma_32x32x16(mfma_f16x8 a, mfma_f16x8 b,
                                                                                  float __attribute__((ext_vector_type(16))) c) {
