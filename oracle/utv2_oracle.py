@@ -276,12 +276,22 @@ def nl_loss(inp, inp_std, target, iou_weight):
     return (s * iou_weight).mean()
 
 
-def kl_loss(inp, inp_std, target, beta=1.0):
-    """layers/kl_loss.py:11-66 (KLLoss) as fcos_outputs.py calls it: default beta 1.0, method LOC_FUN_ALL "mean"; input_std enters
-    raw (no sigmoid), the centerness / IoU weights are ignored by that method."""
+def kl_loss(inp, inp_std, target, beta=1.0, method="mean", weight=None, loss_denorm=None):
+    """layers/kl_loss.py:11-66 (KLLoss) as fcos_outputs.py calls it: default beta 1.0, method = MODEL.FCOS.LOC_FUN_ALL (config.py
+    default "mean"); input_std enters raw (no sigmoid); `weight` (the centerness / quality targets) and `loss_denorm` are used by the
+    weight_ctr_* methods only (:52-58), the IoU weight by none."""
     n = torch.abs(inp - target)
     l1_smooth = torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta)
-    return (torch.exp(-inp_std) * l1_smooth + 0.5 * inp_std).mean()
+    loss = torch.exp(-inp_std) * l1_smooth + 0.5 * inp_std
+    if method == "weight_ctr_sum":
+        return (loss.sum(dim=1) * weight).sum()
+    if method == "weight_ctr_mean":
+        return (loss.sum(dim=1) * weight).sum() / loss_denorm
+    if method == "sum":
+        return loss.sum()
+    if method == "mean":
+        return loss.mean()
+    raise ValueError("No defined regression loss method")
 
 
 class FCOSCfg:
@@ -302,6 +312,7 @@ class FCOSCfg:
         # config-reachable variants (config.py:153,168,196-198; SEMISUPNET.CONSIST_REG_LOSS :191)
         self.kl_loss, self.kl_loss_type, self.quality_est, self.loc_loss_type = True, "nlloss", "centerness", "giou"
         self.reg_unsup_loss = "ts_locvar_better_nms_nll_l1"
+        self.loc_fun_all = "mean"   # MODEL.FCOS.LOC_FUN_ALL: the reduction of the KLLoss variant (kl_loss.py:48-64); NLLoss ignores it
         self.__dict__.update(kw)
         soi, prev = [], -1
         for s in self.soi_edges:
@@ -441,7 +452,7 @@ def fcos_losses(cfg, logits, reg, std, ctr, locations, gts, world_size=1):
             if cfg.kl_loss_type == "nlloss":
                 kl = cfg.kl_weight * nl_loss(reg_pred, sdv, regt, iou_t)  # :400
             elif cfg.kl_loss_type == "klloss":
-                kl = cfg.kl_weight * kl_loss(reg_pred, sdv, regt)  # :381
+                kl = cfg.kl_weight * kl_loss(reg_pred, sdv, regt, method=cfg.loc_fun_all, weight=ctr_t, loss_denorm=loss_denorm)  # :381
             else:
                 raise NotImplementedError
             reg_loss = cfg.kl_weight * kl + iou_loss  # :397,:416 (weight applied twice)
@@ -483,7 +494,8 @@ def fcos_pseudo_losses(cfg, logits, reg, std, ctr, locations, gt_dict, world_siz
                 if cfg.kl_loss_type == "nlloss":
                     term = nl_loss(reg_pred, sdv[pos], regt[pos], iou_targets(reg_pred.detach(), regt[pos]))
                 else:
-                    term = kl_loss(reg_pred, sdv[pos], regt[pos])
+                    term = kl_loss(reg_pred, sdv[pos], regt[pos], method=cfg.loc_fun_all, weight=ctr_t,
+                                   loss_denorm=max(ctr_t.sum().item() / world_size, 1e-6))   # :521,:577-584
                 losses["loss_fcos_loc"] = cfg.kl_weight * term
             else:
                 reg_pred = integral(rg[pos], cfg.reg_max)

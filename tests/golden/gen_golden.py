@@ -383,6 +383,10 @@ def gen_fcos_loss_variants(structures, fo):
         "lociou": dict(LOC_LOSS_TYPE="iou"),
         "loclinear": dict(LOC_LOSS_TYPE="linear_iou"),
         "klloss_iouq_linear": dict(KL_LOSS_TYPE="klloss", QUALITY_EST="iou", LOC_LOSS_TYPE="linear_iou"),
+        # MODEL.FCOS.LOC_FUN_ALL: the reduction of the KLLoss term (kl_loss.py:48-64); the default "mean" is the cases above
+        "klloss_sum": dict(KL_LOSS_TYPE="klloss", LOC_FUN_ALL="sum"),
+        "klloss_wsum": dict(KL_LOSS_TYPE="klloss", LOC_FUN_ALL="weight_ctr_sum"),
+        "klloss_wmean_iouq": dict(KL_LOSS_TYPE="klloss", LOC_FUN_ALL="weight_ctr_mean", QUALITY_EST="iou"),
     }
     for case, over in cases.items():
         cfg = fcos_cfg()
@@ -401,7 +405,8 @@ def gen_fcos_loss_variants(structures, fo):
             for l in range(5):
                 d["%s_g%s%d" % (case, nm, l)] = npy(lst[l].grad if lst[l].grad is not None else torch.zeros_like(lst[l]))
     # pseudo regression loss = weight * KL / NLL term when CONSIST_REG_LOSS is not the TS-better selection
-    for case, over in (("pseudo_nll", dict()), ("pseudo_kl", dict(KL_LOSS_TYPE="klloss"))):
+    for case, over in (("pseudo_nll", dict()), ("pseudo_kl", dict(KL_LOSS_TYPE="klloss")),
+                       ("pseudo_kl_wmean", dict(KL_LOSS_TYPE="klloss", LOC_FUN_ALL="weight_ctr_mean"))):
         cfg = fcos_cfg()
         cfg.SEMISUPNET.CONSIST_REG_LOSS = "mse_loss_all_raw"  # config.py:191 default
         for k, v in over.items():

@@ -467,6 +467,9 @@ LOSS_VARIANTS = {
     "lociou": dict(LOC_LOSS_TYPE="iou"),
     "loclinear": dict(LOC_LOSS_TYPE="linear_iou"),
     "klloss_iouq_linear": dict(KL_LOSS_TYPE="klloss", QUALITY_EST="iou", LOC_LOSS_TYPE="linear_iou"),
+    "klloss_sum": dict(KL_LOSS_TYPE="klloss", LOC_FUN_ALL="sum"),                       # MODEL.FCOS.LOC_FUN_ALL (kl_loss.py:48-64)
+    "klloss_wsum": dict(KL_LOSS_TYPE="klloss", LOC_FUN_ALL="weight_ctr_sum"),
+    "klloss_wmean_iouq": dict(KL_LOSS_TYPE="klloss", LOC_FUN_ALL="weight_ctr_mean", QUALITY_EST="iou"),
 }
 
 
@@ -498,14 +501,16 @@ def test_supervised_loss_variants_vs_reference_golden(case):
     _variant_grads(lv, case, head_out)
 
 
-@pytest.mark.parametrize("case,kl_type", [("pseudo_nll", "nlloss"), ("pseudo_kl", "klloss")])
-def test_pseudo_regression_kl_term_vs_reference_golden(case, kl_type):
+@pytest.mark.parametrize("case,kl_type,fun", [("pseudo_nll", "nlloss", "mean"), ("pseudo_kl", "klloss", "mean"),
+                                              ("pseudo_kl_wmean", "klloss", "weight_ctr_mean")])
+def test_pseudo_regression_kl_term_vs_reference_golden(case, kl_type, fun):
     """CONSIST_REG_LOSS other than the TS-better selection: loss_fcos_loc = KLLOSS_WEIGHT * (NLL | KL) on the regression pseudo set."""
     from ubteacher.modeling.fcos import FCOSOutputs
     lv = dict(np.load(os.path.join(G, "fcos_loss_variants.npz")))
     cfg = fcos_cfg()
     cfg.SEMISUPNET.CONSIST_REG_LOSS = "mse_loss_all_raw"
     cfg.MODEL.FCOS.KL_LOSS_TYPE = kl_type
+    cfg.MODEL.FCOS.LOC_FUN_ALL = fun
     outm = FCOSOutputs(cfg)
     head_out, level_hw = build_head_out(lv, True)
     N = int(lv["N"])

@@ -168,6 +168,9 @@ LOSS_VARIANTS = {
     "lociou": dict(loc_loss_type="iou"),
     "loclinear": dict(loc_loss_type="linear_iou"),
     "klloss_iouq_linear": dict(kl_loss_type="klloss", quality_est="iou", loc_loss_type="linear_iou"),
+    "klloss_sum": dict(kl_loss_type="klloss", loc_fun_all="sum"),                       # MODEL.FCOS.LOC_FUN_ALL (kl_loss.py:48-64)
+    "klloss_wsum": dict(kl_loss_type="klloss", loc_fun_all="weight_ctr_sum"),
+    "klloss_wmean_iouq": dict(kl_loss_type="klloss", loc_fun_all="weight_ctr_mean", quality_est="iou"),
 }
 
 
@@ -189,7 +192,8 @@ def test_supervised_loss_variants(case):
             close(g, lv["%s_g%s%d" % (case, nm, l)], rtol=1e-4, atol=1e-7)
 
 
-@pytest.mark.parametrize("case,kw", [("pseudo_nll", {}), ("pseudo_kl", dict(kl_loss_type="klloss"))])
+@pytest.mark.parametrize("case,kw", [("pseudo_nll", {}), ("pseudo_kl", dict(kl_loss_type="klloss")),
+                                     ("pseudo_kl_wmean", dict(kl_loss_type="klloss", loc_fun_all="weight_ctr_mean"))])
 def test_pseudo_regression_kl_term(case, kw):
     """SEMISUPNET.CONSIST_REG_LOSS other than the TS-better selection: loss_fcos_loc = KLLOSS_WEIGHT * (NLL | KL) on the regression
     pseudo set (fcos_outputs.py:571-585)."""

@@ -315,6 +315,8 @@ __device__ __forceinline__ float giou_ltrb(const float* d, const float* t, float
 #define LT_QUALITY_IOU 1  // MODEL.FCOS.QUALITY_EST "iou": the centerness target is IoU(pred.detach, target) (fcos_outputs.py:355-359)
 #define LT_KLLOSS 2       // MODEL.FCOS.KL_LOSS_TYPE "klloss": column 4 = sum_b exp(-std_b)*smoothL1_1(d_b - t_b) + std_b/2 (kl_loss.py:11-66)
 #define LT_LOC_SHIFT 2    // bits 2-3: loc_type
+#define LT_KL_WCTR 16     // with LT_KLLOSS: each positive's KL term is weighted by its centerness / quality target (MODEL.FCOS.LOC_FUN_ALL
+                          // "weight_ctr_sum" / "weight_ctr_mean", kl_loss.py:52-58) instead of 1 ("sum" / "mean")
 
 template <int R1>
 __global__ __launch_bounds__(128) void fcos_loc_fwd_kernel(const int* __restrict__ labels, const float* __restrict__ box, int BS,
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(128) void fcos_loc_fwd_kernel(const int* __restrict
     for (int b = 0; b < 4; ++b) t[b] = reg_targets[i * 4 + b];
     float ctr_t = sqrtf((fminf(t[0], t[2]) / fmaxf(t[0], t[2])) * (fminf(t[1], t[3]) / fmaxf(t[1], t[3])));
     float iou;
-    const float gl = giou_ltrb(d, t, &iou, nullptr, flags >> LT_LOC_SHIFT);
+    const float gl = giou_ltrb(d, t, &iou, nullptr, (flags >> LT_LOC_SHIFT) & 3);
     if (flags & LT_QUALITY_IOU) ctr_t = iou;
     float nll = 0.f;
     const float* sp = row + 4 * R1;
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(128) void fcos_loc_fwd_kernel(const int* __restrict
         const float n = fabsf(d[b] - t[b]);
         nll += expf(-sp[b]) * (n < 1.f ? 0.5f * n * n : n - 0.5f) + 0.5f * sp[b];
       }
-      iou = 1.f;  // KLLoss ignores the IoU weight
+      iou = (flags & LT_KL_WCTR) ? ctr_t : 1.f;  // KLLoss ignores the IoU weight; LOC_FUN_ALL weight_ctr_*: the centerness target
     } else {
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(128) void fcos_loc_bwd_kernel(const int* __restrict
     for (int b = 0; b < 4; ++b) t[b] = reg_targets[i * 4 + b];
     float ctr_t = sqrtf((fminf(t[0], t[2]) / fmaxf(t[0], t[2])) * (fminf(t[1], t[3]) / fmaxf(t[1], t[3])));
     float iou, gg[4];
-    giou_ltrb(d, t, &iou, gg, flags >> LT_LOC_SHIFT);
+    giou_ltrb(d, t, &iou, gg, (flags >> LT_LOC_SHIFT) & 3);
     if (flags & LT_QUALITY_IOU) ctr_t = iou;  // detached target
     const float* sp = row + 4 * R1;
     float dd[4], ds[4];
@@ -421,8 +423,9 @@ __global__ __launch_bounds__(128) void fcos_loc_bwd_kernel(const int* __restrict
         // kl_b = exp(-s) * sl1(n) + s/2, n = |d - t|: d/dd = exp(-s) * min(n, 1) * sign(d - t); d/ds = 1/2 - exp(-s) * sl1(n)
         const float n = fabsf(df), es = expf(-sp[b]);
         const float sgn = df < 0.f ? 1.f : (df > 0.f ? -1.f : 0.f);
-        dd[b] = c_giou * ctr_t * gg[b] + c_nll * es * fminf(n, 1.f) * sgn;
-        ds[b] = c_nll * (0.5f - es * (n < 1.f ? 0.5f * n * n : n - 0.5f));
+        const float wk = (flags & LT_KL_WCTR) ? ctr_t : 1.f;   // a detached target
+        dd[b] = c_giou * ctr_t * gg[b] + c_nll * wk * es * fminf(n, 1.f) * sgn;
+        ds[b] = c_nll * wk * (0.5f - es * (n < 1.f ? 0.5f * n * n : n - 0.5f));
       } else {
         // nll_b = df^2/(2 sg^2) + log(sg);  d/dd = -df/sg^2 ; d/ds = (1-sg) * (1 - df^2/sg^2)
         dd[b] = c_giou * ctr_t * gg[b] + c_nll * iou * (-df / (sg * sg));
@@ -701,7 +704,7 @@ int utv2_sigmoid_focal_bwd(const float* logits, const int* labels, int64_t P, in
 int utv2_fcos_loc_terms_fwd(const int* labels, const float* box, int box_stride, const float* reg_targets,
                             const float* bvars, int64_t P, int num_classes, int reg_max, float ts_better, float ts_cert,
                             int flags, float* sums, float* ws, hipStream_t stream) {
-  if (!labels || !box || !reg_targets || !sums || !ws || reg_max != 16 || flags < 0 || (flags >> LT_LOC_SHIFT) > 2 || box_stride < 4 * 17 + 5 || (box_stride & 3)) return UTV2_EARG;
+  if (!labels || !box || !reg_targets || !sums || !ws || reg_max != 16 || flags < 0 || ((flags >> LT_LOC_SHIFT) & 3) > 2 || flags >= 32 || box_stride < 4 * 17 + 5 || (box_stride & 3)) return UTV2_EARG;
   hipLaunchKernelGGL((fcos_loc_fwd_kernel<17>), dim3(LOC_BLOCKS), dim3(128), 0, stream, labels, box, box_stride, reg_targets,
                      bvars, (size_t)P, num_classes, ts_better, ts_cert, flags, ws);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(LT_NSUM), dim3(256), 0, stream, (const float*)ws, LOC_BLOCKS, LT_NSUM, sums);
@@ -711,7 +714,7 @@ int utv2_fcos_loc_terms_fwd(const int* labels, const float* box, int box_stride,
 int utv2_fcos_loc_terms_bwd(const int* labels, const float* box, int box_stride, const float* reg_targets,
                             const float* bvars, int64_t P, int num_classes, int reg_max, float ts_better, float ts_cert,
                             int flags, const float* coef, float* dbox, hipStream_t stream) {
-  if (!labels || !box || !reg_targets || !coef || !dbox || reg_max != 16 || flags < 0 || (flags >> LT_LOC_SHIFT) > 2 || box_stride < 4 * 17 + 5 || (box_stride & 3)) return UTV2_EARG;
+  if (!labels || !box || !reg_targets || !coef || !dbox || reg_max != 16 || flags < 0 || ((flags >> LT_LOC_SHIFT) & 3) > 2 || flags >= 32 || box_stride < 4 * 17 + 5 || (box_stride & 3)) return UTV2_EARG;
   hipLaunchKernelGGL((fcos_loc_bwd_kernel<17>), dim3(cdiv(P, 128)), dim3(128), 0, stream, labels, box, box_stride, reg_targets,
                      bvars, (size_t)P, num_classes, ts_better, ts_cert, flags, coef, dbox);
   return utv2_launch_status();

@@ -452,7 +452,7 @@ def sigmoid_focal_bwd(logits, labels, alpha, gamma, coef, out=None):
     return out
 
 
-LT_QUALITY_IOU, LT_KLLOSS, LT_LOC_IOU, LT_LOC_LINEAR_IOU = 1, 2, 1 << 2, 2 << 2  # variant flags of the fcos_loc_terms kernels
+LT_QUALITY_IOU, LT_KLLOSS, LT_LOC_IOU, LT_LOC_LINEAR_IOU, LT_KL_WCTR = 1, 2, 1 << 2, 2 << 2, 16  # variant flags of the fcos_loc_terms kernels
 
 
 def fcos_loc_terms_fwd(labels, box, reg_targets, bvars, num_classes, reg_max, ts_better, ts_cert, flags=0):

@@ -409,11 +409,16 @@ class FCOSOutputs:
             raise NotImplementedError("MODEL.FCOS.LOC_LOSS_TYPE %r" % (fc.LOC_LOSS_TYPE,))  # iou_loss.py:70-71
         if fc.QUALITY_EST not in ("centerness", "iou"):
             raise ValueError("MODEL.FCOS.QUALITY_EST must be 'centerness' or 'iou'")
-        if fc.LOC_FUN_ALL != "mean":
-            raise NotImplementedError("MODEL.FCOS.LOC_FUN_ALL %r (only 'mean', the config.py default, is built)" % (fc.LOC_FUN_ALL,))
+        # LOC_FUN_ALL is the `method` of the KL-type term (fcos_outputs.py:388,407,583): NLLoss ignores it (kl_loss.py:86-105), KLLoss
+        # reduces by it (kl_loss.py:48-64)
+        if fc.LOC_FUN_ALL not in ("mean", "sum", "weight_ctr_sum", "weight_ctr_mean"):
+            raise ValueError("No defined regression loss method")   # kl_loss.py:63-64
+        self.loc_fun_all = fc.LOC_FUN_ALL
         self.loc_flags = {"giou": 0, "iou": hip.LT_LOC_IOU, "linear_iou": hip.LT_LOC_LINEAR_IOU}[fc.LOC_LOSS_TYPE]
         if self.kl_loss and self.kl_loss_type == "klloss":
             self.loc_flags |= hip.LT_KLLOSS
+            if self.loc_fun_all in ("weight_ctr_sum", "weight_ctr_mean"):
+                self.loc_flags |= hip.LT_KL_WCTR
         self.quality_iou = fc.QUALITY_EST == "iou"
         self.kl_loss_weight = fc.KLLOSS_WEIGHT
         self.reg_unsup_loss = cfg.SEMISUPNET.CONSIST_REG_LOSS
@@ -454,11 +459,18 @@ class FCOSOutputs:
             return None
         return torch.cat([comm.reduce_sum(x[0:2].detach().clone()) for x in (sums_s, sums_c, sums_r)])
 
-    def _kl_mean(self, sums):
-        """LOC_FUN_ALL "mean" of the KL-type term: NLLoss averages over positives (kl_loss.py:93-105), KLLoss over positives x 4
-        boundaries (kl_loss.py:59-60)."""
+    def _kl_mean(self, sums, den=None):
+        """The KL-type term reduced by LOC_FUN_ALL: NLLoss always averages over positives (kl_loss.py:93-105); KLLoss "mean" averages over
+        positives x 4 boundaries (kl_loss.py:59-60), "sum" / "weight_ctr_sum" sum (the latter with the centerness-target weight the
+        kernel applied, LT_KL_WCTR), "weight_ctr_mean" divides that by the loss normaliser (`den`, fcos_outputs.py:362)."""
         n = sums[0].detach().clamp(min=1.0)
-        return sums[4] / (4.0 * n) if self.kl_loss_type == "klloss" else sums[4] / n
+        if self.kl_loss_type != "klloss":
+            return sums[4] / n
+        if self.loc_fun_all == "mean":
+            return sums[4] / (4.0 * n)
+        if self.loc_fun_all == "weight_ctr_mean":
+            return sums[4] / den
+        return sums[4]
 
     # -- supervised branch (fcos_outputs.py:212-444) -------------------------------------------------
     def losses(self, head_out, level_hw, gt, branch="labeled", active=None):
@@ -474,7 +486,7 @@ class FCOSOutputs:
         loc = sums[3] / den
         if self.kl_loss:
             w = self.kl_loss_weight
-            loc = w * (w * self._kl_mean(sums)) + loc  # weight applied twice (:381/:397, :400/:416)
+            loc = w * (w * self._kl_mean(sums, den)) + loc  # weight applied twice (:381/:397, :400/:416)
         losses = {"loss_fcos_cls": focal[0] / npa, "loss_fcos_loc": loc, "loss_fcos_ctr": sums[2] / npa}
         extras = {"labels": labels, "reg_targets": reg_t, "gt_inds": gt_inds, "loss_denorm": den, "sums": sums}
         return extras, losses
@@ -499,12 +511,12 @@ class FCOSOutputs:
                 tsbetter = self.reg_unsup_loss == "ts_locvar_better_nms_nll_l1"
                 sums = ops.fcos_loc_terms(box_all, labels, reg_t, bvars if tsbetter else None,
                                           (self.num_classes, self.reg_max, self.tsbetter_reg, self.tsbetter_reg_cert, self.loc_flags))
-                self._normalisers(sums)  # the reference issues the same two reductions here (:504,:521)
+                _, den_r = self._normalisers(sums)  # the reference issues the same two reductions here (:504,:521)
                 if tsbetter:
                     losses["loss_fcos_loc"] = sums[6] / sums[5].detach().clamp(min=1.0)
                     losses["teacher_better_student"] = sums[5].detach()
                 else:  # any other CONSIST_REG_LOSS: KLLOSS_WEIGHT * (NLL | KL) term on the pseudo set (:571-585)
-                    losses["loss_fcos_loc"] = self.kl_loss_weight * self._kl_mean(sums)
+                    losses["loss_fcos_loc"] = self.kl_loss_weight * self._kl_mean(sums, den_r)
             else:
                 raise ValueError(labeltype)
             extras["labels_" + labeltype] = labels
@@ -728,6 +740,7 @@ class FCOS:
         head_out, level_hw, n_labeled, N = ctx["head_out"], ctx["level_hw"], ctx["n_labeled"], ctx["N"]
         fo = self.fcos_outputs
         if (loss_weights is not None and set(gt_unlabeled) == {"cls", "reg"} and fo.kl_loss and all(k in loss_weights for k in fo.LOSS_KEYS)
+                and (fo.kl_loss_type != "klloss" or fo.loc_fun_all == "mean")   # the fused scalar tail knows the "mean" reduction only
                 and ctx["gt_labeled"].n == n_labeled and all(v.n == N - n_labeled for v in gt_unlabeled.values())):
             l_sup, l_uns, total = fo.joint_losses(head_out, level_hw, ctx["gt_labeled"], gt_unlabeled, n_labeled, N, loss_weights)
             l_sup["weighted_total"] = total
