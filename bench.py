@@ -706,6 +706,37 @@ def worker(args):
                                              "note": "teacher_better_student count of the regression pseudo set; each mode thresholds its OWN teacher's detections, so the pseudo "
                                                      "classification loss also moves with which borderline detections pass the score threshold, not only with rounding"}}
         del tr32
+        torch.cuda.empty_cache()
+        # the same step on the fp16 build of the kernels (IEEE half operands / activations / gradients, dynamic loss scale): the 16-bit
+        # type the reference itself trains in; deviation of its first step from the f32 step, and its speed
+        try:
+            tr16 = make_trainer("f16")
+            tr16.model.flat_state().copy_(s0); tr16.model_teacher.flat_state().copy_(t0)
+            tr16.model.store.touch(); tr16.model_teacher.store.touch(); ops.bump_version()
+            tr16.run_step_full_semisup(); tr16.iter += 1
+            first16 = dict(tr16.flush_metrics())
+            tr16.run_step_full_semisup(); tr16.iter += 1
+            torch.cuda.synchronize()
+            k16 = 5
+            t1 = time.perf_counter()
+            for _ in range(k16):
+                tr16.run_step_full_semisup(); tr16.iter += 1
+            torch.cuda.synchronize()
+            d16 = time.perf_counter() - t1
+            last16 = dict(tr16.flush_metrics())
+            f32_rec["f16_first_step_losses"] = {k: first16[k] for k in keys}
+            f32_rec["f16_vs_f32_first_step_rel_dev"] = {k: abs(first16[k] - first32[k]) / max(abs(first32[k]), 1e-12) for k in keys}
+            f32_rec["f16"] = {"value": (args.label + args.unlabel) * k16 / d16, "unit": "images/sec", "ms_per_step": 1e3 * d16 / k16, "steps": k16,
+                              "warmup": 2, "dtype": "f16",
+                              "loss_scale_state": dict(zip(("scale", "found_inf", "clean_steps"), tr16._amp_state.cpu().tolist())),
+                              "losses_finite": all(v == v and abs(v) != float("inf") for v in last16.values()),
+                              "pseudo_boxes": first16.get("teacher_better_student_pseudo")}
+            del tr16
+        except Exception as e:  # noqa: BLE001
+            f32_rec["f16"] = {"error": repr(e)}
+        finally:
+            os.environ.pop("UTV2_PRECISION", None)
+            ops.set_precision("bf16")
 
     parity_full = None
     if dump is not None and os.path.exists(dump):

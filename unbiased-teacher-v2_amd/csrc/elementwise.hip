@@ -2,6 +2,7 @@
 // All arithmetic fp32, one rounding per written operation (the library is built with
 // -ffp-contract=off) so results are comparable op-for-op with the reference's eager
 // PyTorch expressions.
+#include <stdlib.h>
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -367,6 +368,8 @@ __global__ void frozenbn_fold_f32(const float* __restrict__ w, const float* __re
 #define GN_MAX_SEG 160
 struct GnSegs {
   int nseg;
+  int rev;                     // apply passes walk the chunks LAST to FIRST: the pass before them (statistics / partial sums, or the conv
+                               // that wrote x) ended on the tensor's tail, which is what the 256 MB Infinity Cache still holds
   int row0[GN_MAX_SEG + 1];    // first row of each segment (prefix sums)
   int chunk0[GN_MAX_SEG + 1];  // first chunk of each segment
 };
@@ -497,12 +500,17 @@ __global__ __launch_bounds__(256) void gn_stats_final_p32(GnSegs sg, const float
   }
 }
 
+__device__ __forceinline__ int gn_chunk_of_block(const GnSegs& sg) {
+  const int nch = sg.chunk0[sg.nseg], b = (int)blockIdx.x;
+  return (sg.rev && b < nch) ? nch - 1 - b : b;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_relu(GnSegs sg, const T* __restrict__ x, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, T* __restrict__ y, int C, int G, int relu) {
   int seg, r0, r1;
-  gn_locate(sg, blockIdx.x, seg, r0, r1);
+  gn_locate(sg, gn_chunk_of_block(sg), seg, r0, r1);
   const int C4 = C >> 2, cpg = C / G;
   const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, RL = blockDim.x / C4;
   const int g = (c4 * 4) / cpg;
@@ -676,7 +684,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(GnSegs sg, const T* __restri
                                                   float* __restrict__ colpart) {
   if ((int)blockIdx.x < param_blocks) gn_bwd_param(AB, dgamma, dbeta, sg.nseg, C, blockIdx.x);
   int seg, r0, r1;
-  gn_locate(sg, blockIdx.x, seg, r0, r1);
+  const int chunk = gn_chunk_of_block(sg);
+  gn_locate(sg, chunk, seg, r0, r1);
   const int C4 = C >> 2, cpg = C / G;
   const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, RL = blockDim.x / C4;
   const int g = (c4 * 4) / cpg;
@@ -732,17 +741,20 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(GnSegs sg, const T* __restri
 #pragma unroll
     for (int e = 0; e < 4; ++e) cred[threadIdx.x * 4 + e] = csum[e];
     __syncthreads();
-    if (rl == 0 && (int)blockIdx.x < sg.chunk0[sg.nseg]) {
+    if (rl == 0 && chunk < sg.chunk0[sg.nseg]) {
       for (int k = 1; k < RL; ++k)
 #pragma unroll
         for (int e = 0; e < 4; ++e) csum[e] += cred[(k * C4 + c4) * 4 + e];
-      *(f32x4*)(colpart + (size_t)blockIdx.x * C + c4 * 4) = csum;
+      *(f32x4*)(colpart + (size_t)chunk * C + c4 * 4) = csum;
     }
   }
 }
 
+static const bool g_gn_reverse = [] { const char* v = getenv("UTV2_GN_REVERSE"); return !(v && v[0] == '0'); }();   // A/B switch, read once
+
 static int gn_fill(GnSegs& sg, int nseg, const int* seg_rows) {
   sg.nseg = nseg;
+  sg.rev = g_gn_reverse ? 1 : 0;
   int r = 0, c = 0;
   for (int s = 0; s < nseg; ++s) {
     sg.row0[s] = r;
