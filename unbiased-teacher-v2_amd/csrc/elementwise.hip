@@ -460,37 +460,41 @@ __global__ __launch_bounds__(256) void gn_stats_final(GnSegs sg, const float* __
 // lane = t / G); double accumulation, fixed order.
 __global__ __launch_bounds__(256) void gn_stats_final_p32(GnSegs sg, const float* __restrict__ part32, const h16_t* __restrict__ x,
                                                         float* __restrict__ mean, float* __restrict__ rstd, int G, int C, float eps) {
+  // grid (segments, G / 8): a workgroup owns 8 groups of one segment, thread (group, lane of 32) walks every 32nd block
   __shared__ double red[2][256];
   const int seg = blockIdx.x;
-  const int g = threadIdx.x % G, ln = threadIdx.x / G, L = blockDim.x / G;
+  const int gl = threadIdx.x & 7, ln = threadIdx.x >> 3, L = 32;
+  const int g = blockIdx.y * 8 + gl;
   const int r0 = sg.row0[seg], r1 = sg.row0[seg + 1];
   int b0 = (r0 + 31) >> 5, b1 = r1 >> 5;      // whole blocks [b0, b1)
   if (b1 < b0) b1 = b0;                        // the segment lies inside one block
   double s = 0.0, q = 0.0;
-  for (int b = b0 + ln; b < b1; b += L) {
-    const float* p = part32 + ((size_t)b * G + g) * 2;
-    s += (double)p[0];
-    q += (double)p[1];
-  }
-  // edge rows: [r0, min(b0 * 32, r1)) and [max(b1 * 32, head end), r1)
-  const int h1 = (b0 << 5) < r1 ? (b0 << 5) : r1;
-  const int t0 = (b1 << 5) > h1 ? (b1 << 5) : h1;
-  for (int pass = 0; pass < 2; ++pass) {
-    const int e0 = pass == 0 ? r0 : t0, e1 = pass == 0 ? h1 : r1;
-    for (int r = e0 + ln; r < e1; r += L) {
-      const bf16x8_t v = *(const bf16x8_t*)(x + (size_t)r * C + g * 8);
-      float fs = 0.f, fq = 0.f;
+  if (g < G) {
+    for (int b = b0 + ln; b < b1; b += L) {
+      const float2 p = *(const float2*)(part32 + ((size_t)b * G + g) * 2);
+      s += (double)p.x;
+      q += (double)p.y;
+    }
+    // edge rows: [r0, min(b0 * 32, r1)) and [max(b1 * 32, head end), r1)
+    const int h1 = (b0 << 5) < r1 ? (b0 << 5) : r1;
+    const int t0 = (b1 << 5) > h1 ? (b1 << 5) : h1;
+    for (int pass = 0; pass < 2; ++pass) {
+      const int e0 = pass == 0 ? r0 : t0, e1 = pass == 0 ? h1 : r1;
+      for (int r = e0 + ln; r < e1; r += L) {
+        const bf16x8_t v = *(const bf16x8_t*)(x + (size_t)r * C + g * 8);
+        float fs = 0.f, fq = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; fs += f; fq += f * f; }
-      s += (double)fs;
-      q += (double)fq;
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; fs += f; fq += f * f; }
+        s += (double)fs;
+        q += (double)fq;
+      }
     }
   }
   red[0][threadIdx.x] = s;
   red[1][threadIdx.x] = q;
   __syncthreads();
-  if (ln == 0) {
-    for (int k = 1; k < L; ++k) { s += red[0][k * G + g]; q += red[1][k * G + g]; }
+  if (ln == 0 && g < G) {
+    for (int k = 1; k < L; ++k) { s += red[0][k * 8 + gl]; q += red[1][k * 8 + gl]; }
     const double cnt = (double)(r1 - r0) * 8.0;
     const double m = s / cnt;
     double var = q / cnt - m * m;
@@ -609,41 +613,48 @@ __global__ __launch_bounds__(256) void gn_bwd_partial(GnSegs sg, const T* __rest
   }
 }
 
-// backward stage 2 (one block per segment): AB[seg][c][2] = sum over the segment's chunks; s1 = sum_c gamma*A,
-// s2 = sum_c gamma*B per group.
+// backward stage 2: AB[seg][c][2] = sum over the segment's chunks; s1 = sum_c gamma*A, s2 = sum_c gamma*B per (seg, group).
+// Grid (segments, C / 64): a workgroup owns 64 channels (whole groups: cpg divides 64) of one segment, thread (channel, lane) walks
+// every 4th chunk with four loads in flight and the four lanes are combined in a fixed order - one block per segment with one walk per
+// channel was pure load latency (78 us per launch on the backward's critical path for 0.3 MB of partials).
 __global__ __launch_bounds__(256) void gn_bwd_reduce(GnSegs sg, const float* __restrict__ part, const float* __restrict__ gamma,
                                                    float* __restrict__ AB, float* __restrict__ s12, int C, int G) {
-  const int seg = blockIdx.x;
-  const int cpg = C / G;
-  extern __shared__ float sh[];  // [C][2]
+  __shared__ float ra[256], rb[256], sh[64][2];
+  const int seg = blockIdx.x, cl = threadIdx.x & 63, ln = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl, cpg = C / G;
   const int k0 = sg.chunk0[seg], k1 = sg.chunk0[seg + 1];
-  // 4 interleaved chunk walks per channel, their loads in flight together (the largest level has 50 chunks per image; one dependent
-  // walk per thread was pure load latency), combined in a fixed order.  256 threads: a 1024-thread workgroup waits for a whole free CU
-  // while the side-stream convolutions hold every CU's registers (measured 267 us per launch inside the step against 7 us alone).
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = k0; k < k1; k += 4) {
+  float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    for (int k = k0 + ln; k < k1; k += 16) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (k + q < k1) {
-          const float2 v = *(const float2*)(part + ((size_t)(k + q) * C + c) * 2);
+        if (k + 4 * q < k1) {
+          const float2 v = *(const float2*)(part + ((size_t)(k + 4 * q) * C + c) * 2);
           a[q] += v.x;
           b[q] += v.y;
         }
     }
-    const float sa = (a[0] + a[1]) + (a[2] + a[3]), sb = (b[0] + b[1]) + (b[2] + b[3]);
+  }
+  ra[threadIdx.x] = (a[0] + a[1]) + (a[2] + a[3]);
+  rb[threadIdx.x] = (b[0] + b[1]) + (b[2] + b[3]);
+  __syncthreads();
+  if (ln == 0 && c < C) {
+    const float sa = (ra[cl] + ra[cl + 64]) + (ra[cl + 128] + ra[cl + 192]);
+    const float sb = (rb[cl] + rb[cl + 64]) + (rb[cl + 128] + rb[cl + 192]);
     AB[((size_t)seg * C + c) * 2] = sa;
     AB[((size_t)seg * C + c) * 2 + 1] = sb;
-    sh[c * 2] = sa * gamma[c];
-    sh[c * 2 + 1] = sb * gamma[c];
+    sh[cl][0] = sa * gamma[c];
+    sh[cl][1] = sb * gamma[c];
   }
   __syncthreads();
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+  const int gpb = 64 / cpg;   // groups per block
+  if ((int)threadIdx.x < gpb && blockIdx.y * 64 + threadIdx.x * cpg < C) {
     float s1 = 0.f, s2 = 0.f;
     for (int k = 0; k < cpg; ++k) {
-      s1 += sh[(g * cpg + k) * 2];
-      s2 += sh[(g * cpg + k) * 2 + 1];
+      s1 += sh[threadIdx.x * cpg + k][0];
+      s2 += sh[threadIdx.x * cpg + k][1];
     }
+    const int g = blockIdx.y * gpb + threadIdx.x;
     s12[(seg * G + g) * 2] = s1;
     s12[(seg * G + g) * 2 + 1] = s2;
   }
@@ -791,7 +802,7 @@ static void gn_bwd_launch(const GnSegs& sg, int chunks, int nseg, const void* dy
   float* s12 = AB + (size_t)nseg * C * 2;
   hipLaunchKernelGGL(gn_bwd_partial<T>, dim3(chunks), dim3(256), 0, stream, sg, (const T*)dy, (const T*)y, (const T*)x, mean, rstd,
                      gamma, beta, part, C, G, relu);
-  hipLaunchKernelGGL(gn_bwd_reduce, dim3(nseg), dim3(256), 2 * C * sizeof(float), stream, sg, (const float*)part, gamma, AB, s12, C, G);
+  hipLaunchKernelGGL(gn_bwd_reduce, dim3(nseg, cdiv(C, 64)), dim3(256), 0, stream, sg, (const float*)part, gamma, AB, s12, C, G);
   const int pb = cdiv(C, 64);   // workgroups that also run gn_bwd_param (a workgroup past the last chunk finds no rows)
   hipLaunchKernelGGL(gn_bwd_apply<T>, dim3(chunks > pb ? chunks : pb), dim3(256), 0, stream, sg, (const T*)dy, (const T*)y, (const T*)x, mean,
                      rstd, gamma, beta, (const float*)s12, (T*)dx, C, G, relu, (const float*)AB, dgamma, dbeta, pb, colpart);
@@ -996,7 +1007,7 @@ int64_t utv2_groupnorm_seg_workspace_floats(int nseg, const int* seg_rows_host, 
 }
 
 static int gn_check(int nseg, int C, int G) {
-  return !(nseg < 1 || nseg > GN_MAX_SEG || (C & 3) || ((C / G) & 3) || C / 4 > 256 || (256 % (C / 4)) || (256 % G));
+  return !(nseg < 1 || nseg > GN_MAX_SEG || (C & 3) || ((C / G) & 3) || C / 4 > 256 || (256 % (C / 4)) || (256 % G) || (C % G) || (64 % (C / G)));
 }
 
 // x,y: [rows][C] of `dtype`; mean,rstd: fp32 [nseg][G] (saved for backward).  Statistics and arithmetic are fp32.
@@ -1020,7 +1031,7 @@ int utv2_groupnorm_relu_seg_fwd_p32(const void* x, const float* gamma, const flo
   if (!x || !y || !mean || !rstd || !part32 || !gn_check(nseg, C, G) || C != 8 * G) return UTV2_EARG;
   GnSegs sg;
   const int chunks = gn_fill(sg, nseg, seg_rows_host);
-  hipLaunchKernelGGL(gn_stats_final_p32, dim3(nseg), dim3(256), 0, stream, sg, part32, (const h16_t*)x, mean, rstd, G, C, eps);
+  hipLaunchKernelGGL(gn_stats_final_p32, dim3(nseg, cdiv(G, 8)), dim3(256), 0, stream, sg, part32, (const h16_t*)x, mean, rstd, G, C, eps);
   hipLaunchKernelGGL(gn_apply_relu<h16_t>, dim3(chunks), dim3(256), 0, stream, sg, (const h16_t*)x, (const float*)mean, (const float*)rstd,
                      gamma, beta, (h16_t*)y, C, G, relu);
   return utv2_launch_status();
