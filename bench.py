@@ -102,9 +102,10 @@ class ConvTimer:
     def __init__(self, dtype):
         self.pairs = []
         self.enabled = False
-        self.bf16 = dtype == "bf16"
+        self.bf16 = dtype != "f32"      # a 16-bit MFMA mode (either type: the same kernels)
         self.entry = "conv2d_ml_fwd_bf16" if self.bf16 else "conv2d_ml_fwd"
-        self.kernel = "conv_igemm_bf16_pp<true,__bf16>+conv_igemm_bf16_v2<128,true,64,__bf16>" if self.bf16 else "conv_igemm_f32<128,0,true>"
+        t16 = "_Float16" if dtype == "f16" else "__bf16"    # element type of the kernel library's 16-bit build (csrc/common.h h16_t)
+        self.kernel = ("conv_igemm_bf16_pp<true,%s>+conv_igemm_bf16_v2<128,true,64,%s>" % (t16, t16)) if self.bf16 else "conv_igemm_f32<128,0,true>"
 
     def install(self):
         from ubteacher import hip
@@ -209,7 +210,9 @@ def pmc_traffic(kernel, model="fcos"):
             continue
         try:
             with open(path) as f:
-                t = json.load(f).get(kernel)
+                j = json.load(f)
+            t = j.get("tower_conv") if kernel.startswith("conv_igemm") else None    # r03 files: one key whatever the 16-bit type
+            t = t if t is not None else j.get(kernel, j.get(kernel.replace("_Float16", "__bf16")))
             if t is not None:
                 return float(t["hbm_bytes_per_launch"])
         except (OSError, ValueError, KeyError):
@@ -381,6 +384,7 @@ def parity_fullsize(dump, device_index):
     from ubteacher.engine import UBTeacherTrainer
     from ubteacher.presets import get_config
     from ubteacher import ops
+    os.environ.pop("UTV2_PRECISION", None)    # exact-f32 mode (SOLVER.AMP.ENABLED False), whatever 16-bit type the headline ran in
     d = torch.load(dump, weights_only=False)
     lq, lk, uq, uk = d["batch"]
     dev = "cuda:%d" % device_index
@@ -438,6 +442,7 @@ def rcnn_subrecord(args, device_index, timer, steps=10, warmup=3):
     cfg = get_config("rcnn", 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label, "SOLVER.IMG_PER_BATCH_UNLABEL", args.unlabel,
                                  "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", True, "MODEL.DEVICE", "cuda:%d" % device_index])
     torch.manual_seed(0)
+    os.environ.pop("UTV2_PRECISION", None)       # BASELINE configs[4] names the bf16 MFMA conv path
     tr = UBRCNNTeacherTrainer(cfg)
     tr.iter = 1
     tr.log_period = 10 ** 9
@@ -456,6 +461,7 @@ def rcnn_subrecord(args, device_index, timer, steps=10, warmup=3):
     timer.enabled = False
     conv = timer.summary()
     metrics = tr.flush_metrics()
+    amp_state = tr._amp_state.cpu().tolist() if getattr(tr, "_amp_state", None) is not None else None
     lp = getattr(tr, "_last_pseudo", None)
     out = {"value": (args.label + args.unlabel) * steps / dt, "unit": "images/sec", "ms_per_step": 1e3 * dt / steps, "steps": steps,
            "warmup": warmup, "dtype": "bf16",
@@ -464,9 +470,9 @@ def rcnn_subrecord(args, device_index, timer, steps=10, warmup=3):
            "losses": {k: v for k, v in metrics.items() if k.startswith("loss")},
            "pseudo_boxes_last_step": None if lp is None else int(lp["valid"].sum())}
     if conv:
-        out["roofline"] = {"bound": "mfma", "kernel": timer.kernel + " (RPN head 3x3 conv over p2-p6, fwd+dgrad launches)",
+        out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_bf16_pp<true,__bf16>+conv_igemm_bf16_v2<128,true,64,__bf16> (RPN head 3x3 conv over p2-p6, fwd+dgrad launches)",
                            "achieved": conv["tflops"], "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": conv["tflops"] / PEAK_BF16_MFMA_TFLOPS, "traffic": pmc_traffic(timer.kernel, "rcnn"),
+                           "frac": conv["tflops"] / PEAK_BF16_MFMA_TFLOPS, "traffic": pmc_traffic("conv_igemm_bf16_pp<true,__bf16>+conv_igemm_bf16_v2<128,true,64,__bf16>", "rcnn"),
                            "algorithmic_bytes": conv["alg_bytes"], "launches": conv["launches"], "avg_us": conv["avg_us"]}
     del tr
     torch.cuda.empty_cache()
@@ -495,10 +501,15 @@ def parse_args(argv=None):
     ap.add_argument("--model", choices=["fcos", "rcnn"], default="fcos",
                     help="fcos: BASELINE configs[1] (the headline workload); rcnn: the Faster-RCNN UTv2 trainer of configs[2] / [4] on the same "
                          "per-GPU batch (its shipped configs run fp32: --dtype f32; configs[4] is the bf16 MFMA path)")
-    ap.add_argument("--dtype", choices=["bf16", "f32", "f16"], default="bf16",
-                    help="conv arithmetic: bf16 = the config's SOLVER.AMP.ENABLED path (bf16 MFMA, fp32 accumulate); f16 = the same path on the "
-                         "fp16 build of the kernels (the reference's own autocast type) with GradScaler-style dynamic loss scaling; f32 = exact-f32 MFMA")
-    return ap.parse_args(argv)
+    ap.add_argument("--dtype", choices=["f16", "bf16", "f32"], default=None,
+                    help="conv arithmetic of the config's SOLVER.AMP.ENABLED path.  f16 (default for --model fcos): IEEE fp16 MFMA operands / "
+                         "activations / gradients with GradScaler-style dynamic loss scaling - the reference's own autocast type "
+                         "(engine/trainer.py:195,207), losses within 1e-3 of the f32 step; bf16 (default for --model rcnn: BASELINE configs[4] names "
+                         "the bf16 MFMA path): no loss scaling; f32 = exact-f32 MFMA")
+    a = ap.parse_args(argv)
+    if a.dtype is None:
+        a.dtype = "bf16" if a.model == "rcnn" else "f16"
+    return a
 
 
 def _launcher_name(world):
@@ -586,7 +597,7 @@ def worker(args):
     batch = tr._data_loader.batches[0]
     (tune_rcnn_for_pseudo_labels if rcnn else tune_for_pseudo_labels)(tr, batch)
     tr.sync_replicas()   # identical students / teachers on every rank (DDP broadcasts rank 0's parameters at construction)
-    parity = rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_f32 and not rcnn
+    parity = rank == 0 and world == 1 and args.dtype != "f32" and not args.no_f32 and not rcnn
     if parity:
         s0, t0 = tr.model.flat_state().clone(), tr.model_teacher.flat_state().clone()
     first = None
@@ -619,6 +630,7 @@ def worker(args):
         dt = float(t.item())
         devices = comm.all_gather_object(device_index)
     metrics = tr.flush_metrics()
+    amp_state = tr._amp_state.cpu().tolist() if getattr(tr, "_amp_state", None) is not None else None
     lp = getattr(tr, "_last_pseudo", None)
     if lp is None:
         pseudo_count = None
@@ -696,44 +708,49 @@ def worker(args):
         torch.cuda.synchronize()
         d32 = time.perf_counter() - t1
         keys = [k for k in first32 if k.startswith("loss")]
+        main16, other16 = args.dtype, ("bf16" if args.dtype == "f16" else "f16")
+
+        def rel(a_):
+            return {k: abs(a_[k] - first32[k]) / max(abs(first32[k]), 1e-12) for k in keys}
         f32_rec = {"value": (args.label + args.unlabel) * k32 / d32, "unit": "images/sec", "ms_per_step": 1e3 * d32 / k32, "steps": k32,
                    "warmup": 2, "dtype": "f32",
                    "first_step_losses": {k: first32[k] for k in keys},
-                   "bf16_first_step_losses": {k: first[k] for k in keys},
-                   "bf16_vs_f32_first_step_rel_dev": {k: abs(first[k] - first32[k]) / max(abs(first32[k]), 1e-12) for k in keys},
+                   "%s_first_step_losses" % main16: {k: first[k] for k in keys},
+                   "%s_vs_f32_first_step_rel_dev" % main16: rel(first),
                    "pseudo_boxes_per_step": {"f32": first32.get("teacher_better_student_pseudo"),
-                                             "bf16": first.get("teacher_better_student_pseudo"),
+                                             main16: first.get("teacher_better_student_pseudo"),
                                              "note": "teacher_better_student count of the regression pseudo set; each mode thresholds its OWN teacher's detections, so the pseudo "
                                                      "classification loss also moves with which borderline detections pass the score threshold, not only with rounding"}}
+        f32_rec["headline_within_1e-3_of_f32"] = max(f32_rec["%s_vs_f32_first_step_rel_dev" % main16].values()) <= 1e-3
         del tr32
         torch.cuda.empty_cache()
-        # the same step on the fp16 build of the kernels (IEEE half operands / activations / gradients, dynamic loss scale): the 16-bit
-        # type the reference itself trains in; deviation of its first step from the f32 step, and its speed
+        # the same step in the OTHER 16-bit type (bf16: no loss scaling, 8 mantissa bits; f16: the reference's own autocast type, 11 bits,
+        # dynamic loss scale): deviation of its first step from the f32 step, and its speed
         try:
-            tr16 = make_trainer("f16")
-            tr16.model.flat_state().copy_(s0); tr16.model_teacher.flat_state().copy_(t0)
-            tr16.model.store.touch(); tr16.model_teacher.store.touch(); ops.bump_version()
-            tr16.run_step_full_semisup(); tr16.iter += 1
-            first16 = dict(tr16.flush_metrics())
-            tr16.run_step_full_semisup(); tr16.iter += 1
+            tro = make_trainer(other16)
+            tro.model.flat_state().copy_(s0); tro.model_teacher.flat_state().copy_(t0)
+            tro.model.store.touch(); tro.model_teacher.store.touch(); ops.bump_version()
+            tro.run_step_full_semisup(); tro.iter += 1
+            firsto = dict(tro.flush_metrics())
+            tro.run_step_full_semisup(); tro.iter += 1
             torch.cuda.synchronize()
-            k16 = 5
+            ko = 5
             t1 = time.perf_counter()
-            for _ in range(k16):
-                tr16.run_step_full_semisup(); tr16.iter += 1
+            for _ in range(ko):
+                tro.run_step_full_semisup(); tro.iter += 1
             torch.cuda.synchronize()
-            d16 = time.perf_counter() - t1
-            last16 = dict(tr16.flush_metrics())
-            f32_rec["f16_first_step_losses"] = {k: first16[k] for k in keys}
-            f32_rec["f16_vs_f32_first_step_rel_dev"] = {k: abs(first16[k] - first32[k]) / max(abs(first32[k]), 1e-12) for k in keys}
-            f32_rec["f16"] = {"value": (args.label + args.unlabel) * k16 / d16, "unit": "images/sec", "ms_per_step": 1e3 * d16 / k16, "steps": k16,
-                              "warmup": 2, "dtype": "f16",
-                              "loss_scale_state": dict(zip(("scale", "found_inf", "clean_steps"), tr16._amp_state.cpu().tolist())),
-                              "losses_finite": all(v == v and abs(v) != float("inf") for v in last16.values()),
-                              "pseudo_boxes": first16.get("teacher_better_student_pseudo")}
-            del tr16
+            do = time.perf_counter() - t1
+            lasto = dict(tro.flush_metrics())
+            f32_rec["%s_first_step_losses" % other16] = {k: firsto[k] for k in keys}
+            f32_rec["%s_vs_f32_first_step_rel_dev" % other16] = rel(firsto)
+            f32_rec["pseudo_boxes_per_step"][other16] = firsto.get("teacher_better_student_pseudo")
+            f32_rec[other16] = {"value": (args.label + args.unlabel) * ko / do, "unit": "images/sec", "ms_per_step": 1e3 * do / ko, "steps": ko,
+                                "warmup": 2, "dtype": other16, "losses_finite": all(v == v and abs(v) != float("inf") for v in lasto.values())}
+            if tro._amp_state is not None:
+                f32_rec[other16]["loss_scale_state"] = dict(zip(("scale", "found_inf", "clean_steps"), tro._amp_state.cpu().tolist()))
+            del tro
         except Exception as e:  # noqa: BLE001
-            f32_rec["f16"] = {"error": repr(e)}
+            f32_rec[other16] = {"error": repr(e)}
         finally:
             os.environ.pop("UTV2_PRECISION", None)
             ops.set_precision("bf16")
@@ -753,7 +770,7 @@ def worker(args):
             os.remove(dump)
 
     rcnn_rec = None
-    if rank == 0 and world == 1 and not rcnn and not args.no_rcnn and not args.timed_only and args.dtype == "bf16":
+    if rank == 0 and world == 1 and not rcnn and not args.no_rcnn and not args.timed_only and args.dtype != "f32":
         # the Faster-RCNN UTv2 trainer (BASELINE configs[2] / [4]: bf16 MFMA conv path) on the same per-GPU batch, as a sub-record
         try:
             torch.cuda.empty_cache()
@@ -784,10 +801,12 @@ def worker(args):
             "ranks": {"world_size": world, "backend": info["backend"], "devices": devices,
                       "launcher": _launcher_name(world), "rccl_selfcheck": rccl},
             "host": {"ms_per_step_on_96x128_images": host_ms, "enqueue_ms_per_step": 1e3 * t_host / args.steps,
-                     "cabi_calls_per_step": calls_per_step, "gpu_dispatches": dispatches_per_step(args.model) if args.dtype == "bf16" else None},
+                     "cabi_calls_per_step": calls_per_step, "gpu_dispatches": dispatches_per_step(args.model) if args.dtype != "f32" else None},
             "losses": {k: v for k, v in metrics.items() if k.startswith("loss") or k.startswith("teacher")},
             "pseudo_boxes_last_step": pseudo_count,
         }
+        if amp_state is not None:
+            out["loss_scale_state"] = dict(zip(("scale", "found_inf", "clean_steps"), amp_state))
         if conv:
             out["roofline"] = {"bound": "mfma", "kernel": timer.kernel + (" (RPN head 3x3 conv over p2-p6, fwd+dgrad launches)" if rcnn else
                                                                          " (FCOS tower 3x3 convs, all fwd+dgrad launches)"),

@@ -8,7 +8,8 @@ usage: make_traffic.py FETCH.txt WRITE.txt KERNEL_STATS.txt OUT.json"""
 import json
 import sys
 
-TOWER = ("_Z18conv_igemm_bf16_ppILb1EDF16bEv10ConvArgs16", "_Z18conv_igemm_bf16_v2ILi128ELb1ELi64EDF16bEv10ConvArgs16")
+# DF16b = __bf16 (libutv2_hip.so), DF16_ = _Float16 (libutv2_hip_f16.so: the same kernels on the fp16 build)
+TOWERS = [("_Z18conv_igemm_bf16_ppILb1EDF16%sEv10ConvArgs16" % t, "_Z18conv_igemm_bf16_v2ILi128ELb1ELi64EDF16%sEv10ConvArgs16" % t) for t in ("_", "b")]
 WGRAD = "_Z18conv_wgrad_bf16_w811Wgrad16Args"
 
 
@@ -32,6 +33,7 @@ def durations(path):
 
 fetch, write, dur = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), durations(sys.argv[3])
 res = {"fetch_correction": 2.0, "source": "%s, %s, %s" % tuple(sys.argv[1:4])}
+TOWER = next((t for t in TOWERS if t[0] in fetch), TOWERS[0])
 if TOWER[0] in fetch:
     # the 256-tile kernel's share of the launch (whole rounds of 256 x 256 tiles: 97.5 % of the student's rows, 73 % of the teacher's); the
     # remaining rows run on conv_igemm_bf16_v2<128,true,64>, whose PMC row cannot be split from the head prediction convs that use
@@ -39,7 +41,8 @@ if TOWER[0] in fetch:
     n = fetch[TOWER[0]][0]
     fk = fetch[TOWER[0]][1] / n
     wk = write[TOWER[0]][1] / n
-    res["conv_igemm_bf16_pp<true,__bf16>+conv_igemm_bf16_v2<128,true,64,__bf16>"] = {
+    res["tower_conv"] = {
+        "kernel": TOWER[0],
         "fetch_size_kib_per_launch": round(fk, 2), "write_size_kib_per_launch": round(wk, 2),
         "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0, "launches_in_pmc_run": n,
         "covers": "conv_igemm_bf16_pp<true,__bf16> only (the whole rounds of 256x256 tiles of each launch)"}
