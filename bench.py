@@ -433,7 +433,7 @@ def parity_fullsize(dump, device_index):
     return out
 
 
-def rcnn_subrecord(args, device_index, timer, steps=10, warmup=3):
+def rcnn_subrecord(args, device_index, timer, steps=10, warmup=5):
     """images/sec of UBRCNNTeacherTrainer.run_step_full_semisup (BASELINE configs[2] / [4]: Faster-RCNN R50-FPN UTv2, bf16 MFMA conv
     path) on the same per-GPU batch as the headline, timed by the same rule (barrier-free at world 1: synchronize on both sides);
     its dominant kernel = the RPN head 3x3 conv over p2-p6 (the same multi-level implicit-GEMM kernel), timed by HIP events."""

@@ -2,12 +2,15 @@
 # Round measurement of record (run on the GPU box through gpurun): bench lines, kernel traces, PMC passes for the FCOS (headline) and the
 # Faster-RCNN step.  usage: tools/measure_record.sh <tag>     outputs -> gpurun_out/<tag>_*
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD
 mkdir -p gpurun_out
-timeout 900 python bench.py > gpurun_out/${TAG}_bench_bf16.json 2> gpurun_out/${TAG}_bench_bf16.err < /dev/null
+# the default FCOS run is the fp16 AMP mode (the reference's own autocast type) since round 3; file names keep the "4p4_bf16" stem of the
+# earlier rounds (same kernels, the 16-bit element type of the library build differs)
+timeout 900 python bench.py > gpurun_out/${TAG}_bench_f16.json 2> gpurun_out/${TAG}_bench_f16.err < /dev/null
+timeout 600 python bench.py --dtype bf16 --no-cpu-baseline --no-rcnn > gpurun_out/${TAG}_bench_bf16.json 2> /dev/null < /dev/null
 timeout 600 python bench.py --model rcnn > gpurun_out/${TAG}_bench_rcnn_bf16.json 2> /dev/null < /dev/null
-timeout 600 python bench.py --model rcnn --dtype f32 --steps 5 > gpurun_out/${TAG}_bench_rcnn_f32.json 2> /dev/null < /dev/null
+timeout 600 python bench.py --model rcnn --dtype f32 --steps 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_rcnn_f32.json 2> /dev/null < /dev/null
 cd /tmp && export TMPDIR=/tmp
 prof() {  # prof <dir> <extra rocprof args> -- <bench args>
   local d=$1; shift
@@ -30,6 +33,7 @@ timeout 120 python tools/rocpd_pmc.py "$(db _pw)" 40 > gpurun_out/${TAG}_fcos_4p
 timeout 60 python tools/make_traffic.py gpurun_out/${TAG}_fcos_4p4_bf16_pmc_fetch.txt gpurun_out/${TAG}_fcos_4p4_bf16_pmc_write.txt \
   gpurun_out/${TAG}_fcos_4p4_bf16_kernel_stats.txt gpurun_out/${TAG}_traffic.json > gpurun_out/${TAG}_traffic.log 2>&1 < /dev/null
 timeout 120 python tools/rocpd_timeline.py "$(db _kt)" steps 10 6 > gpurun_out/${TAG}_fcos_4p4_bf16_timeline.txt 2>&1 < /dev/null
+timeout 120 python tools/rocpd_gaps.py "$(db _kt)" 10 6 30 > gpurun_out/${TAG}_fcos_4p4_gaps.txt 2>&1 < /dev/null
 timeout 120 python tools/rocpd_timeline.py "$(db _rkt)" steps 10 6 > gpurun_out/${TAG}_rcnn_4p4_bf16_timeline.txt 2>&1 < /dev/null
 timeout 120 python tools/rocpd_stats.py "$(db _rkt)" > gpurun_out/${TAG}_rcnn_4p4_bf16_kernel_stats.txt 2>&1 < /dev/null
 timeout 120 python tools/rocpd_pmc.py "$(db _rpf)" 60 > gpurun_out/${TAG}_rcnn_4p4_bf16_pmc_fetch.txt 2>&1 < /dev/null
@@ -37,4 +41,4 @@ timeout 120 python tools/rocpd_pmc.py "$(db _rpw)" 60 > gpurun_out/${TAG}_rcnn_4
 timeout 60 python tools/make_traffic.py gpurun_out/${TAG}_rcnn_4p4_bf16_pmc_fetch.txt gpurun_out/${TAG}_rcnn_4p4_bf16_pmc_write.txt \
   gpurun_out/${TAG}_rcnn_4p4_bf16_kernel_stats.txt gpurun_out/${TAG}_rcnn_traffic.json > gpurun_out/${TAG}_rcnn_traffic.log 2>&1 < /dev/null
 rm -rf gpurun_out/_kt gpurun_out/_pf gpurun_out/_pw gpurun_out/_rkt gpurun_out/_rpf gpurun_out/_rpw
-tail -c 600 gpurun_out/${TAG}_bench_bf16.json; echo; tail -c 400 gpurun_out/${TAG}_bench_rcnn_bf16.json; echo; tail -30 gpurun_out/${TAG}_rcnn_traffic.log
+tail -c 600 gpurun_out/${TAG}_bench_f16.json; echo; tail -c 400 gpurun_out/${TAG}_bench_rcnn_bf16.json; echo; tail -30 gpurun_out/${TAG}_rcnn_traffic.log

@@ -13,7 +13,7 @@ def main(path, total_steps, k, top=40, queue=None):
     cols = [r[1] for r in cur.execute("pragma table_info(%s)" % kd)]
     qcol = "queue_id" if "queue_id" in cols else "stream_id"
     rows = cur.execute(f"select d.start, d.end, s.kernel_name, d.{qcol} from {kd} d join {ks} s on d.kernel_id = s.id order by d.start").fetchall()
-    marks = [r[1] for r in rows if "sgd_momentum_f32" in r[2]]
+    marks = [r[1] for r in rows if "sgd_momentum" in r[2]]
     cps = len(marks) // total_steps
     w0, w1 = marks[-k * cps - 1], marks[-1]
     rows = [r for r in rows if r[0] >= w0 and r[1] <= w1]

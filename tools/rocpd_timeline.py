@@ -25,7 +25,7 @@ def main(path, frac=0.5, steps=None, total_steps=None):
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     w0 = t1 - (t1 - t0) * frac
     if total_steps:
-        marks = [r[1] for r in rows if "sgd_momentum_f32" in r[2]]
+        marks = [r[1] for r in rows if "sgd_momentum" in r[2]]
         cps = len(marks) // total_steps
         w0, t1 = marks[-steps * cps - 1], marks[-1]
         rows = [r for r in rows if r[1] <= t1]
