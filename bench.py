@@ -225,8 +225,8 @@ def dispatches_per_step(model):
     (profiles/rNN_<model>_4p4_bf16_timeline.txt, newest round, tools/rocpd_timeline.py over the last 6 of `bench.py --timed-only` steps)"""
     import re
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((q for q in (os.path.join(here, "%s_%s_4p4_bf16_timeline.txt" % (r, model)) for r in ("r03", "r02")) if os.path.exists(q)),
-                os.path.join(here, "r02_%s_4p4_bf16_timeline.txt" % model))
+    names = ["%s_%s_4p4_%s_timeline.txt" % (r, model, t) for r in ("r03", "r02") for t in ("f16", "bf16")]
+    path = next((q for q in (os.path.join(here, n) for n in names) if os.path.exists(q)), os.path.join(here, "r02_%s_4p4_bf16_timeline.txt" % model))
     try:
         with open(path) as f:
             m = re.search(r"window [0-9.]+ ms \(([0-9.]+) ms / step\), (\d+) dispatches", f.read())
@@ -442,6 +442,8 @@ def rcnn_subrecord(args, device_index, timer, steps=10, warmup=5):
     cfg = get_config("rcnn", 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label, "SOLVER.IMG_PER_BATCH_UNLABEL", args.unlabel,
                                  "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", True, "MODEL.DEVICE", "cuda:%d" % device_index])
     torch.manual_seed(0)
+    import gc
+    gc.collect()                                 # this step is close to host-bound: start from a collected heap (several trainers came and went)
     os.environ.pop("UTV2_PRECISION", None)       # BASELINE configs[4] names the bf16 MFMA conv path
     tr = UBRCNNTeacherTrainer(cfg)
     tr.iter = 1

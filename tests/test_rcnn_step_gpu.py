@@ -313,17 +313,20 @@ def test_rcnn_step_vs_reference_trainer_golden():
     check_state_fingerprints(d, "student", cpu_state(tr.model), 1e-4, rtol_update=5e-2)
 
 
-def test_rcnn_step_bf16_vs_rounding_oracle():
-    """BASELINE configs[4] (Faster-RCNN, bf16 MFMA conv path): the full AMP step against the oracle with the same operand rounding
-    emulated in its convs / linears (O.CONV_ROUND).  Discrete selections are decoupled from rounding noise the way the FCOS AMP
+@pytest.mark.parametrize("kind,tol", [("bf16", 1e-2), ("fp16", 3e-3)])
+def test_rcnn_step_bf16_vs_rounding_oracle(kind, tol, monkeypatch):
+    """BASELINE configs[4] (Faster-RCNN, bf16 MFMA conv path; and the same on the fp16 build of the kernels with the dynamic loss scale,
+    UTV2_PRECISION=fp16): the full AMP step against the oracle with the same operand rounding emulated in its convs / linears (O.CONV_ROUND).  Discrete selections are decoupled from rounding noise the way the FCOS AMP
     test does it: the oracle is handed the product's pseudo labels and the product's RPN proposals of the two student passes, and
     both sides use the same injected sampling keys; then every loss must agree within 1e-2 relative and the teacher after EMA is
     bit exact.  The product's own teacher detections must mostly coincide with the rounding oracle's."""
     from ubteacher import ops
+    if kind == "fp16":
+        monkeypatch.setenv("UTV2_PRECISION", "fp16")
     try:
-        O.CONV_ROUND[0] = "bf16"
+        O.CONV_ROUND[0] = kind
         d, cfg, tr, orac, sd_s, sd_t, K, mean, pstd = _golden_setup(amp=True)
-        assert ops.PRECISION[0] == "bf16"
+        assert ops.PRECISION[0] == kind
         pg = tr.model.proposal_generator
         calls = []
         orig_cls_call = type(pg).__call__
@@ -386,10 +389,12 @@ def test_rcnn_step_bf16_vs_rounding_oracle():
             hit += int((O.pairwise_iou(p["boxes"], q["boxes"]).max(dim=1)[0] > 0.9).sum())
     assert tot > 0 and hit >= 0.6 * tot, (hit, tot)
     for k, v in rec_o.items():
-        assert abs(rec[k] - v) <= 1e-2 * max(abs(v), 1e-6), (k, rec[k], v)
+        assert abs(rec[k] - v) <= tol * max(abs(v), 1e-6), (k, rec[k], v)
     t_after = cpu_state(tr.model_teacher)
     for k in new_t:
         assert torch.equal(t_after[k], new_t[k]), k
+    if kind == "fp16":
+        assert tr._amp_state.cpu().tolist() == [65536.0, 0.0, 1.0]   # finite gradients: step applied, flag cleared
 
 
 def test_rcnn_step_is_bit_deterministic():
