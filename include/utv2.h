@@ -73,6 +73,12 @@ int utv2_conv2d_nhwc_fwd_bf16(const void* x, int x_dtype, const void* w16, void*
                               const float* bias, const void* residual, const void* mask, const void* post_mask, int N, int H, int W, int C, int K,
                               int KH, int KW, int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate,
                               utv2_stream_t stream);
+/* the same with the per-output-pixel geometry table of utv2_conv2d_wgrad_bf16 (rowinfo, optional; in_dil == 1): the tile prologues of
+ * the bf16-input kernels load their rows' geometry instead of decoding it (2 us of a 70 us tile on the 256-tile kernel) */
+int utv2_conv2d_nhwc_fwd_bf16_ri(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
+                                 const float* bias, const void* residual, const void* mask, const void* post_mask, int N, int H, int W, int C,
+                                 int K, int KH, int KW, int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate,
+                                 const int* rowinfo, utv2_stream_t stream);
 int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
                             const float* bias, const void* residual, int nlev, const int* H_host, const int* W_host, int N,
                             int C, int K, int KH, int KW, int pad, int relu, int accumulate, utv2_stream_t stream);
@@ -81,11 +87,12 @@ int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y
  * [g*C, (g+1)*C) (C = input channels PER GROUP), w16 = bf16 [K][KH*KW*C], y / residual have row pitch y_pitch >= K.
  * Anything but (groups 1, x_pitch C, y_pitch K) needs bf16 x, C % 32 == 0, K % 4 == 0, pitches % 8 == 0, (K / groups) % 128 == 0.
  * gn_part (optional; bf16 y, K % 8 == 0): fp32 [ceil(P / 32)][K / 8][2] - per 32-row block and 8-channel group the sum and the sum of
- * squares of y as stored: the statistics pass of the GroupNorm that consumes y (fcos/fcos.py:263-264), see ..._seg_fwd_p32. */
+ * squares of y as stored: the statistics pass of the GroupNorm that consumes y (fcos/fcos.py:263-264), see ..._seg_fwd_p32.
+ * rowinfo (optional): device int32[P][2], the geometry table of utv2_conv2d_wgrad_bf16 for this conv (same k and pad). */
 int utv2_conv2d_ml_fwd_bf16_g(const void* x, int x_dtype, int x_pitch, const void* w16, void* y, int y_dtype, int y_pitch,
                               const float* scale, const float* bias, const void* residual, int nlev, const int* H_host,
                               const int* W_host, int N, int C, int K, int KH, int KW, int pad, int relu, int accumulate, int groups,
-                              float* gn_part, utv2_stream_t stream);
+                              float* gn_part, const int* rowinfo, utv2_stream_t stream);
 /* bf16 wgrad (+ fused bias gradient); rowinfo = device int32[M][2] per OUTPUT pixel:
  * {input pixel index of tap (0,0), (W << 16) | mask of the taps that fall inside the image}; KH*KW <= 16 */
 int utv2_conv2d_wgrad_bf16_splits(int M, int K, int Kred);

@@ -19,7 +19,7 @@ int main() {
   ConvArgs16 a{};
   a.x = x; a.w = (const __bf16*)w; a.y = y;
   a.N = N; a.H = H; a.W = W; a.C = C; a.OH = H; a.OW = W; a.K = K; a.KH = 3; a.KW = 3; a.stride = 1; a.pad = 1; a.in_dil = 1;
-  a.Kred = 9 * C; a.M = (int)P; a.xs = C;
+  a.Kred = 9 * C; a.M = (int)P; a.xs = C; a.groups = 1; a.ldy = K; a.gn_part = nullptr; a.m_begin = 0;
   const int smem = 2 * (256 + 256) * 128 + 8192;
   hipFuncSetAttribute((const void*)conv_igemm_bf16_pp<false, __bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   const int tiles = (int)(P / 256);
@@ -47,5 +47,10 @@ int main() {
     }
     printf("   chunk period %u\n", (t[48] - t[16]) / 4);
   }
+  unsigned long long ph[2][5];
+  hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_pp_phase), sizeof(ph));
+  for (int b = 0; b < 2; ++b)
+    printf("workgroup %s: geometry %llu  prologue DMA + wait %llu  main loop %llu  epilogue incl. store drain %llu  cycles (total %llu)\n",
+           b ? "mid-grid" : "0", ph[b][1] - ph[b][0], ph[b][2] - ph[b][1], ph[b][3] - ph[b][2], ph[b][4] - ph[b][3], ph[b][4] - ph[b][0]);
   return 0;
 }

@@ -49,6 +49,10 @@ struct ConvArgs16 {
                              // FCOS towers (cls | bbox, two independent 256 -> 256 chains) run as ONE launch per depth this way.
   int ldy;                   // elements between consecutive rows of y / residual / mask / post_mask (>= K: y may be a column slice)
   float* gn_part;            // optional: per (32-row block, 8-channel group) sum / sum of squares of the stored output (see epilogue_rows)
+  const int2* rowinfo;       // optional: per OUTPUT row m {input pixel index of tap (0,0), (W << 16) | tap-validity mask} - the table the weight
+                             // gradient kernels read (utv2_conv2d_wgrad_bf16): the tile prologue then loads its rows' geometry instead of
+                             // decoding it (level search, two integer divisions and a KH x KW bounds loop per staged row: 2.0-2.2 us of a
+                             // 70 us tile on the 256-tile kernel, tools/probe/pp_trace)
 };
 
 __device__ __forceinline__ void ml_decode16(const LevelTab& lt, int m, int& pixbase, int& H, int& W, int& oh, int& ow) {
@@ -430,6 +434,13 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
     const bool mv = m < p.M;
     const int mm = mv ? m : 0;
     int pb, H, W, ih0, iw0;
+    if (p.rowinfo) {
+      const int2 ri = p.rowinfo[mm];
+      aoff[j] = ri.x * p.xs + slot * 8 + goff;
+      awc[j] = (ri.y >> 16) * p.xs;
+      amask[j] = mv ? (unsigned)(ri.y & 0xffff) : 0u;
+      continue;
+    }
     if constexpr (ML) {
       int oh, ow;
       ml_decode16(p.lt, mm, pb, H, W, oh, ow);
@@ -648,6 +659,13 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
     const bool mv = m < p.M;
     const int mm = mv ? m : 0;
     int pb, H, W, ih0, iw0;
+    if (p.rowinfo) {
+      const int2 ri = p.rowinfo[mm];
+      aoff[j] = ri.x * p.xs + kslot * 8 + goff;
+      awc[j] = (ri.y >> 16) * p.xs;
+      amask[j] = mv ? (unsigned)(ri.y & 0xffff) : 0u;
+      continue;
+    }
     if constexpr (ML) {
       int oh, ow;
       ml_decode16(p.lt, mm, pb, H, W, oh, ow);
@@ -796,6 +814,8 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
 #ifdef UTV2_PP_TRACE
 // tools/probe/pp_trace.hip: s_memtime at both ends of every slot of chunks 8..15 of workgroup 0, kept in the unused LDS above the ring
 __device__ unsigned g_pp_trace[8 * 128];
+// phase stamps (kernel entry, first DMA issue, main loop start, main loop end, kernel end) of workgroup 0 and of a mid-grid workgroup
+__device__ unsigned long long g_pp_phase[2][5];
 #define PP_STAMP                                                                                         \
   if (blockIdx.x == 0 && c >= 8 && c < 16) {                                                             \
     const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime();                                          \
@@ -812,6 +832,9 @@ __device__ unsigned g_pp_trace[8 * 128];
 #endif
 template <bool ML, typename TO>
 __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
+#ifdef UTV2_PP_TRACE
+  const unsigned long long ph_entry = __builtin_amdgcn_s_memtime();
+#endif
   constexpr int BM = 256, BN = 256, BK = 64, SEGB = 64;
   constexpr int OPSEG = 256 * SEGB, OPB = 2 * OPSEG, STAGE = 2 * OPB;  // 16 KB, 32 KB, 64 KB
   constexpr int TM = 4, TN = 2;
@@ -845,6 +868,13 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
     const bool mv = m < p.M;
     const int mm = mv ? m : 0;
     int pb, H, W, ih0, iw0;
+    if (p.rowinfo) {
+      const int2 ri = p.rowinfo[mm];
+      aoff[j] = ri.x * p.xs + kslot * 8 + goff;
+      awc[j] = (ri.y >> 16) * p.xs;
+      amask[j] = mv ? (unsigned)(ri.y & 0xffff) : 0u;
+      continue;
+    }
     if constexpr (ML) {
       int oh, ow;
       ml_decode16(p.lt, mm, pb, H, W, oh, ow);
@@ -995,6 +1025,9 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   PP_BARRIER;
+#ifdef UTV2_PP_TRACE
+  const unsigned long long ph_loop = __builtin_amdgcn_s_memtime();
+#endif
   // C(2c) sends segment 2c+3 = (chunk c+1, segment 1), C(2c+1) segment 2c+4 = (chunk c+2, segment 0) - into the ring slot whose last
   // readers finished two barriers earlier.  Waits (end of every odd slot): everything but the batches younger than the segment the
   // next LOAD slot reads.
@@ -1079,6 +1112,9 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
 #undef PP_WAIT_FRAGS
 #undef PP_VMWAIT
 #undef PP_BARRIER
+#ifdef UTV2_PP_TRACE
+  const unsigned long long ph_loop_end = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
 #ifdef UTV2_PP_TRACE
   if (blockIdx.x == 0) {
@@ -1096,6 +1132,13 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
   for (int half = 0; half < 2; ++half)
     epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[2 * half], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
                           p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part);
+#ifdef UTV2_PP_TRACE
+  if ((blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left: what a successor workgroup on this CU waits for is the wave's end
+    unsigned long long* o = g_pp_phase[blockIdx.x == 0 ? 0 : 1];
+    o[0] = ph_entry; o[1] = clk0; o[2] = ph_loop; o[3] = ph_loop_end; o[4] = __builtin_amdgcn_s_memtime();
+  }
+#endif
 }
 
 // A/B switches for bench runs and tests, read ONCE per process (never on the launch path): UTV2_W8=0 keeps every forward / dgrad
@@ -1185,17 +1228,32 @@ int utv2_conv2d_bf16_supported(int C, int KH, int KW) { return (C % 8 == 0) ? 1 
 
 // w16: bf16 [K][KH*KW*C].  x is `x_dtype`, y and residual are `y_dtype` (UTV2_F32 / UTV2_BF16).  Otherwise the
 // contract of utv2_conv2d_nhwc_fwd (also serves as dgrad).
+// rowinfo (optional): the per-output-pixel geometry table of utv2_conv2d_wgrad_bf16 for this conv (device int32[N*OH*OW][2] =
+// {input pixel index of tap (0,0), (W << 16) | tap-validity mask}; in_dil == 1 only): tile prologues load it instead of decoding it
+int utv2_conv2d_nhwc_fwd_bf16_ri(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
+                                 const float* bias, const void* residual, const void* mask, const void* post_mask, int N, int H, int W, int C,
+                                 int K, int KH, int KW, int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate,
+                                 const int* rowinfo, hipStream_t stream);
+
 int utv2_conv2d_nhwc_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
                               const float* bias, const void* residual, const void* mask, const void* post_mask, int N, int H, int W, int C,
                               int K, int KH,
                               int KW, int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate, hipStream_t stream) {
-  if (!x || !w16 || !y || (C % 8) || bad_dtype(x_dtype) || bad_dtype(y_dtype)) return UTV2_EARG;
+  return utv2_conv2d_nhwc_fwd_bf16_ri(x, x_dtype, w16, y, y_dtype, scale, bias, residual, mask, post_mask, N, H, W, C, K, KH, KW, stride, pad,
+                                      in_dil, OH, OW, relu, accumulate, nullptr, stream);
+}
+
+int utv2_conv2d_nhwc_fwd_bf16_ri(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
+                                 const float* bias, const void* residual, const void* mask, const void* post_mask, int N, int H, int W, int C,
+                                 int K, int KH, int KW, int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate,
+                                 const int* rowinfo, hipStream_t stream) {
+  if (!x || !w16 || !y || (C % 8) || bad_dtype(x_dtype) || bad_dtype(y_dtype) || (rowinfo && in_dil > 1)) return UTV2_EARG;
   ConvArgs16 a;
   a.lt.n = 0;
   a.x = x; a.w = (const h16_t*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = mask; a.post_mask = post_mask;
   a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.K = K; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
   a.in_dil = in_dil < 1 ? 1 : in_dil; a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.M = N * OH * OW;
-  a.xs = C; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr;
+  a.xs = C; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr; a.rowinfo = (const int2*)rowinfo;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   if (small) launch_igemm16<64, false>(a, tiles, x_dtype, y_dtype, stream);
@@ -1209,15 +1267,17 @@ int utv2_conv2d_nhwc_fwd_bf16(const void* x, int x_dtype, const void* w16, void*
 //   C % 32 == 0, K % 4 == 0 and (K / groups) % 128 == 0.
 //   gn_part (optional; bf16 y, K % 8 == 0): fp32 [ceil(P / 32)][K / 8][2], per 32-row block and 8-channel group the sum / sum of squares
 //   of y as stored - the statistics pass of the GroupNorm that follows (utv2_groupnorm_relu_seg_fwd_p32).
+//   rowinfo (optional): device int32[P][2], the per-output-row geometry table of utv2_conv2d_wgrad_bf16 for this conv (same pad and k):
+//   the tile prologues load it instead of decoding (level, image, row, column) and the tap bounds per staged row.
 int utv2_conv2d_ml_fwd_bf16_g(const void* x, int x_dtype, int x_pitch, const void* w16, void* y, int y_dtype, int y_pitch,
                               const float* scale, const float* bias, const void* residual, int nlev, const int* H_host,
                               const int* W_host, int N, int C, int K, int KH, int KW, int pad, int relu, int accumulate, int groups,
-                              float* gn_part, hipStream_t stream) {
+                              float* gn_part, const int* rowinfo, hipStream_t stream) {
   if (gn_part && (y_dtype != UTV2_BF16 || (K & 7) || (y_pitch & 7) || x_dtype != UTV2_BF16 || (C % 32) || accumulate)) return UTV2_EARG;
   if (!x || !w16 || !y || nlev < 1 || nlev > CONV_MAX_LEVELS || (C % 8) || N <= 0 || bad_dtype(x_dtype) || bad_dtype(y_dtype) || groups < 1 ||
       K % groups || x_pitch < groups * C || y_pitch < K)
     return UTV2_EARG;
-  const bool plain = groups == 1 && x_pitch == C && y_pitch == K && !gn_part;
+  const bool plain = groups == 1 && x_pitch == C && y_pitch == K && !gn_part && !rowinfo;
   if (!plain && (x_dtype != UTV2_BF16 || (C % 32) || (K & 3) || KH * KW > 16 || (x_pitch & 7) || (y_pitch & 7) ||
                  (groups > 1 && (K / groups) % 128)))
     return UTV2_EARG;
@@ -1226,7 +1286,7 @@ int utv2_conv2d_ml_fwd_bf16_g(const void* x, int x_dtype, int x_pitch, const voi
   if (!plain && ((int64_t)a.M * x_pitch >= (1ll << 31) || (int64_t)K * KH * KW * C >= (1ll << 31))) return UTV2_EARG;
   a.x = x; a.w = (const h16_t*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad; a.in_dil = 1;
-  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = x_pitch; a.m_begin = 0; a.groups = groups; a.ldy = y_pitch; a.gn_part = gn_part;
+  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = x_pitch; a.m_begin = 0; a.groups = groups; a.ldy = y_pitch; a.gn_part = gn_part; a.rowinfo = (const int2*)rowinfo;
   const bool small = K <= 64 && plain;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   if (small) launch_igemm16<64, true>(a, tiles, x_dtype, y_dtype, stream);
@@ -1243,7 +1303,7 @@ int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y
   a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
   a.x = x; a.w = (const h16_t*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad; a.in_dil = 1;
-  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = C; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr;
+  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = C; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr; a.rowinfo = nullptr;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   if (small) launch_igemm16<64, true>(a, tiles, x_dtype, y_dtype, stream);
@@ -1265,7 +1325,7 @@ int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int
   a.lt.n = 0;
   a.x = xpad16; a.w = (const h16_t*)w16s; a.y = y; a.scale = scale; a.bias = bias; a.residual = nullptr; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = H + 6; a.W = W + 8; a.C = 32; a.OH = OH; a.OW = OW; a.K = K; a.KH = 7; a.KW = 1; a.stride = 2; a.pad = 0;
-  a.in_dil = 1; a.relu = relu; a.accumulate = 0; a.Kred = 7 * 32; a.M = N * OH * OW; a.xs = 4; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr;
+  a.in_dil = 1; a.relu = relu; a.accumulate = 0; a.Kred = 7 * 32; a.M = N * OH * OW; a.xs = 4; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr; a.rowinfo = nullptr;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   const dim3 g(tiles), b(256);
