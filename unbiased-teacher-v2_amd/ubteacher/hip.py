@@ -831,7 +831,7 @@ def conv2d_fwd_bf16(x, w16, scale=None, bias=None, residual=None, stride=1, pad=
     if out is None:
         out = torch.empty((N, OH, OW, K), dtype=_act_dtype(x, out_dtype), device=x.device)
     ri = None
-    if kh * kw > 1 and in_dil == 1 and x.dtype == h16_dtype() and C % 32 == 0 and kh * kw <= 16 and W < 32768:
+    if _CONV_ROWINFO and kh * kw > 1 and in_dil == 1 and x.dtype == h16_dtype() and C % 32 == 0 and kh * kw <= 16 and W < 32768:
         ri = rowinfo_nhwc(N, H, W, OH, OW, stride, pad, kh, kw, x.device)   # the table the weight gradient of this conv reads
     call("utv2_conv2d_nhwc_fwd_bf16_ri", _p(x), _dt(x), _p(w16), _p(out), _same_dt(out, residual, mask, post_mask), _p(scale), _p(bias),
          _p(residual), _p(mask), _p(post_mask), N, H, W, C, K, kh, kw, stride, pad, in_dil, OH, OW, int(relu), int(accumulate), _p(ri), _stream())
@@ -846,7 +846,7 @@ def conv2d_dgrad_bf16(dy, wt16, in_shape, stride, pad, kh, kw, out=None, out_dty
     if out is None:
         out = torch.empty((N, H, W, C), dtype=_act_dtype(dy, out_dtype), device=dy.device)
     ri = None
-    if kh * kw > 1 and stride == 1 and dy.dtype == h16_dtype() and K % 32 == 0 and kh * kw <= 16 and OW < 32768:
+    if _CONV_ROWINFO and kh * kw > 1 and stride == 1 and dy.dtype == h16_dtype() and K % 32 == 0 and kh * kw <= 16 and OW < 32768:
         ri = rowinfo_nhwc(N, OH, OW, H, W, 1, kh - 1 - pad, kh, kw, dy.device)   # dgrad = a stride-1 conv over dy with pad k-1-pad
     call("utv2_conv2d_nhwc_fwd_bf16_ri", _p(dy), _dt(dy), _p(wt16), _p(out), _same_dt(out, residual, mask, post_mask), c_p(0), c_p(0),
          _p(residual), _p(mask), _p(post_mask), N, OH, OW, K, C, kh, kw, 1, kh - 1 - pad, stride, H, W, 0, 0, _p(ri), _stream())
@@ -874,7 +874,7 @@ def conv2d_ml_fwd_bf16(x2d, w16, level_hw, N, scale=None, bias=None, residual=No
     yp, ypitch = _rows_ptr(out)
     # the geometry table the weight gradients read (cached per geometry): the conv's tile prologues load it instead of decoding it
     ri = None
-    if (k > 1 and x2d.dtype == h16_dtype() and C % 32 == 0 and K % 4 == 0 and xpitch % 8 == 0 and ypitch % 8 == 0
+    if (_CONV_ROWINFO and k > 1 and x2d.dtype == h16_dtype() and C % 32 == 0 and K % 4 == 0 and xpitch % 8 == 0 and ypitch % 8 == 0
             and (groups == 1 or (K // groups) % 128 == 0) and P * xpitch < (1 << 31)):
         ri = rowinfo_ml(N, level_hw, pad, k, x2d.device)
     if groups == 1 and xpitch == C and ypitch == K and gn_part is None and ri is None:
@@ -908,6 +908,7 @@ def groupnorm_relu_seg_fwd_p32(x2d, seg_rows, gamma, beta, part32, G, eps=1e-5, 
 
 
 _rowinfo_cache = {}
+_CONV_ROWINFO = os.environ.get("UTV2_CONV_ROWINFO", "1") != "0"   # A/B: conv tile prologues decode their geometry themselves
 
 
 def _rowinfo_part(N, H, W, OH, OW, stride, pad, kh, kw, start):
