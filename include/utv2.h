@@ -368,6 +368,14 @@ int utv2_softmax_focal_fwd(const float* logits, const int* target, int R, int C,
                            utv2_stream_t stream);
 int utv2_softmax_focal_bwd(const float* logits, const int* target, int R, int C, float gamma, const float* coef,
                            float* dlogits, utv2_stream_t stream);
+/* The scalar tail of the Faster-RCNN UTv2 losses in one launch (roi_heads/fast_rcnn.py:925-936 normalisation by the number of sampled
+ * ROIs, proposal_generator/rpn.py:214-224 normalisation + loss weights, engine/trainer.py:880-893 weighting and sum): raw kernel sums of
+ * the supervised and the pseudo branch -> rec[9] = {loss_cls, loss_box_reg, loss_rpn_cls, loss_rpn_loc} x {supervised, pseudo}, total;
+ * coef[8] = d total / d raw sum.  wt_host: host float[8], the trainer's weight per loss in rec order. */
+int utv2_rcnn_loss_combine(const float* rpn_sup, const float* rpn_uns, const float* focal_sup, const float* focal_uns, const float* box_sup,
+                           const float* box_uns, const int* tgt_sup, int n_sup, const int* tgt_uns, int n_uns, float rpn_norm_sup,
+                           float rpn_norm_uns, float w_rpn_cls, float w_rpn_loc, float w_box, const float* wt_host, float* rec, float* coef,
+                           utv2_stream_t stream);
 
 /* ---- two-crop data path: the pixel arithmetic of the reference's weak / strong views, on uint8 [H][W][3] images
  * in HBM, bit-exact to Pillow (which Detectron2 / torchvision / the reference call on the CPU) ------------------------------------- */

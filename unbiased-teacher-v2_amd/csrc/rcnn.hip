@@ -1044,6 +1044,51 @@ int utv2_roi_align_bwd_tiled(int num_levels, int min_level, void* const* dfeats_
   return utv2_launch_status();
 }
 
+// The scalar tail of the Faster-RCNN UTv2 losses in ONE launch (the FCOS counterpart is utv2_fcos_loss_combine): raw kernel sums of the
+// two loss branches -> the eight losses of the trainer's record_dict, their weighted total and d total / d raw sums.
+//   loss_cls = focal / Rn, loss_box_reg = w_box * box / Rn   (Rn = number of sampled ROIs = targets >= 0, at least 1: fast_rcnn.py:925-936)
+//   loss_rpn_cls = w_rpn_cls * rpn[0] / norm, loss_rpn_loc = w_rpn_loc * rpn[1] / norm   (norm = batch_size_per_image * images, rpn.py:214-224;
+//   the RPN weights arrive squared: applied inside losses() and again in forward())
+//   total = sum_k wt[k] * loss_k in record_dict order (engine/trainer.py:880-893: pseudo terms x UNSUP_LOSS_WEIGHT, loss_box_reg_pseudo x
+//   UNSUP_REG_LOSS_WEIGHT, loss_rpn_loc_pseudo x 0).   rec[9] = {cls, box, rpn_cls, rpn_loc} x {supervised, pseudo}, total;  coef[8].
+struct RcnnCombineArgs {
+  const float* rpn[2];
+  const float* focal[2];
+  const float* box[2];
+  const int* tgt[2];
+  int ntgt[2];
+  float rpn_norm[2];
+  float w_rpn_cls, w_rpn_loc, w_box;
+  float wt[8];
+};
+
+__global__ __launch_bounds__(64) void rcnn_loss_combine_kernel(RcnnCombineArgs a, float* __restrict__ rec, float* __restrict__ coef) {
+  const int lane = threadIdx.x;
+  float rn[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    float c = 0.f;
+    for (int i = lane; i < a.ntgt[b]; i += 64) c += a.tgt[b][i] >= 0 ? 1.f : 0.f;   // exact in fp32 (counts < 2^24)
+    c = wave_reduce_sum(c);
+    rn[b] = fmaxf(__shfl(c, 0, 64), 1.f);
+  }
+  if (lane != 0) return;
+  float total = 0.f;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const float v[4] = {a.focal[b][0] / rn[b], a.w_box * (a.box[b][0] / rn[b]), a.w_rpn_cls * (a.rpn[b][0] / a.rpn_norm[b]),
+                        a.w_rpn_loc * (a.rpn[b][1] / a.rpn_norm[b])};
+    const float d[4] = {1.f / rn[b], a.w_box / rn[b], a.w_rpn_cls / a.rpn_norm[b], a.w_rpn_loc / a.rpn_norm[b]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      rec[4 * b + k] = v[k];
+      coef[4 * b + k] = a.wt[4 * b + k] * d[k];
+      total += v[k] * a.wt[4 * b + k];
+    }
+  }
+  rec[8] = total;
+}
+
 #define SF_BLOCKS 256
 // loss_sum[0] = sum_r (1-p_r)^gamma * CE_r over rows with target >= 0.  ws >= 256 floats.
 int utv2_softmax_focal_fwd(const float* logits, const int* target, int R, int C, float gamma, float* loss_sum, float* ws,
@@ -1051,6 +1096,25 @@ int utv2_softmax_focal_fwd(const float* logits, const int* target, int R, int C,
   if (!logits || !target || !loss_sum || !ws) return UTV2_EARG;
   hipLaunchKernelGGL(softmax_focal_fwd_kernel, dim3(SF_BLOCKS), dim3(256), 0, stream, logits, target, R, C, gamma, ws);
   hipLaunchKernelGGL(sum_partials_f32, dim3(1), dim3(64), 0, stream, (const float*)ws, SF_BLOCKS, loss_sum);
+  return utv2_launch_status();
+}
+
+// rpn_*: device float[2] {sum BCE, sum L1} of utv2_rpn_loss_fwd; focal_* / box_*: device float[1] (utv2_softmax_focal_fwd, utv2_roi_box_loss);
+// tgt_*: the int32 class targets of the sampled ROIs (< 0 = empty slot); wt_host: host float[8], the trainer's weight per loss in the
+// order {cls, box_reg, rpn_cls, rpn_loc} x {supervised, pseudo}.  rec: device float[9], coef: device float[8].
+int utv2_rcnn_loss_combine(const float* rpn_sup, const float* rpn_uns, const float* focal_sup, const float* focal_uns, const float* box_sup,
+                           const float* box_uns, const int* tgt_sup, int n_sup, const int* tgt_uns, int n_uns, float rpn_norm_sup,
+                           float rpn_norm_uns, float w_rpn_cls, float w_rpn_loc, float w_box, const float* wt_host, float* rec, float* coef,
+                           hipStream_t stream) {
+  if (!rpn_sup || !rpn_uns || !focal_sup || !focal_uns || !box_sup || !box_uns || !tgt_sup || !tgt_uns || !wt_host || !rec || !coef ||
+      n_sup < 0 || n_uns < 0 || !(rpn_norm_sup > 0.f) || !(rpn_norm_uns > 0.f))
+    return UTV2_EARG;
+  RcnnCombineArgs a;
+  a.rpn[0] = rpn_sup; a.rpn[1] = rpn_uns; a.focal[0] = focal_sup; a.focal[1] = focal_uns; a.box[0] = box_sup; a.box[1] = box_uns;
+  a.tgt[0] = tgt_sup; a.tgt[1] = tgt_uns; a.ntgt[0] = n_sup; a.ntgt[1] = n_uns; a.rpn_norm[0] = rpn_norm_sup; a.rpn_norm[1] = rpn_norm_uns;
+  a.w_rpn_cls = w_rpn_cls; a.w_rpn_loc = w_rpn_loc; a.w_box = w_box;
+  for (int k = 0; k < 8; ++k) a.wt[k] = wt_host[k];
+  hipLaunchKernelGGL(rcnn_loss_combine_kernel, dim3(1), dim3(64), 0, stream, a, rec, coef);
   return utv2_launch_status();
 }
 

@@ -95,8 +95,15 @@ def _make(base):
                         torch.cuda.set_stream(main)
                 self._last_pseudo = gt
 
+                # the trainer's weighting of the loss dict (below) as one weight per key: the fused student pass folds it, the normalisers
+                # and the sum into its single scalar-tail launch (UTV2_FUSE_LOSS_TAIL=0: the ATen op chain; identical values)
+                lw = None
+                if fuse and os.environ.get("UTV2_FUSE_LOSS_TAIL", "1") != "0":
+                    lw = {"loss_cls": 1.0, "loss_box_reg": 1.0, "loss_rpn_cls": 1.0, "loss_rpn_loc": 1.0,
+                          "loss_cls_pseudo": S.UNSUP_LOSS_WEIGHT, "loss_box_reg_pseudo": S.UNSUP_REG_LOSS_WEIGHT,
+                          "loss_rpn_cls_pseudo": S.UNSUP_LOSS_WEIGHT, "loss_rpn_loc_pseudo": 0.0}
                 if fuse:
-                    ctx = self.model.forward_joint_begin(all_label_data, unlabel_data_q)
+                    ctx = self.model.forward_joint_begin(all_label_data, unlabel_data_q, loss_weights=lw)
                 else:
                     rec_l, _, _, _ = self.model(all_label_data, branch="supervised")
                 if overlap:
@@ -111,8 +118,9 @@ def _make(base):
                 for k, v in rec_u.items():
                     record_dict[k + "_pseudo"] = v
 
+                fused_total = record_dict.pop("weighted_total", None)
                 loss_dict = {}
-                for key in record_dict.keys():
+                for key in ([] if fused_total is not None else record_dict.keys()):
                     if key[:4] != "loss":
                         continue
                     if key == "loss_rpn_loc_pseudo":
@@ -123,7 +131,7 @@ def _make(base):
                         loss_dict[key] = record_dict[key] * S.UNSUP_LOSS_WEIGHT
                     else:
                         loss_dict[key] = record_dict[key]
-                losses = sum(loss_dict.values())
+                losses = fused_total if fused_total is not None else sum(loss_dict.values())
 
             metrics_dict = record_dict
             metrics_dict["data_time"] = data_time

@@ -751,6 +751,18 @@ def softmax_focal_fwd(logits, target, gamma):
     return out
 
 
+def rcnn_loss_combine(rpn_sup, rpn_uns, focal_sup, focal_uns, box_sup, box_uns, tgt_sup, tgt_uns, norm_sup, norm_uns, w_rpn_cls, w_rpn_loc,
+                      w_box, wt):
+    """(rec [9], coef [8]) - see utv2_rcnn_loss_combine"""
+    dev = rpn_sup.device
+    rec = torch.empty(9, dtype=torch.float32, device=dev)
+    coef = torch.empty(8, dtype=torch.float32, device=dev)
+    call("utv2_rcnn_loss_combine", _p(rpn_sup), _p(rpn_uns), _p(focal_sup), _p(focal_uns), _p(box_sup), _p(box_uns), _p(tgt_sup),
+         tgt_sup.numel(), _p(tgt_uns), tgt_uns.numel(), float(norm_sup), float(norm_uns), float(w_rpn_cls), float(w_rpn_loc), float(w_box),
+         ctypes.cast(_farr(wt), c_p), _p(rec), _p(coef), _stream())
+    return rec, coef
+
+
 def softmax_focal_bwd(logits, target, gamma, coef):
     R, C = logits.shape
     out = torch.empty_like(logits)

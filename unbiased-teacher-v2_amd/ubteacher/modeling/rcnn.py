@@ -269,14 +269,16 @@ class PseudoLabRPN:
                 proposals = self.predict_proposals(anchors, obj, dl, image_sizes)
         return proposals, losses
 
-    def forward_joint_begin(self, image_sizes, features, n_labeled, gt_labeled):
+    def forward_joint_begin(self, image_sizes, features, n_labeled, gt_labeled, raw=False):
         """The labeled and the pseudo-labeled images of one iteration as ONE batch (images [0, n_labeled) carry ground truth): head,
-        proposals of every image, and the labeled images' losses - everything that does not need the pseudo labels."""
+        proposals of every image, and the labeled images' losses - everything that does not need the pseudo labels.
+        raw: the losses as raw kernel sums for the fused scalar tail (TwoStagePseudoLabGeneralizedRCNN.forward_joint_finish)."""
         big, hw, N = self._head(features)
         anchors = self.anchor_generator(hw, big.device)
         acat = self._anchors_cat(anchors, hw, big.device)
-        losses = self.losses(acat, big, None, gt_labeled, head_hw=hw, batch=N, img0=0)
-        losses = {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}  # applied twice (SURVEY B2), as in forward()
+        losses = self.losses(acat, big, None, gt_labeled, head_hw=hw, batch=N, img0=0, raw=raw)
+        if not raw:
+            losses = {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}  # applied twice (SURVEY B2), as in forward()
         sample_l = self._last_sample
         with torch.no_grad():
             sel = self._pre_nms_topk(big.detach(), N, hw)
@@ -287,9 +289,11 @@ class PseudoLabRPN:
                 proposals = self.predict_proposals(anchors, obj, dl, image_sizes)
         return dict(big=big, hw=hw, N=N, acat=acat, n_labeled=n_labeled, sample_l=sample_l), proposals, losses
 
-    def forward_joint_finish(self, ctx, gt_unlabeled):
+    def forward_joint_finish(self, ctx, gt_unlabeled, raw=False):
         """the pseudo-labeled images' losses of a forward_joint_begin batch"""
-        losses = self.losses(ctx["acat"], ctx["big"], None, gt_unlabeled, head_hw=ctx["hw"], batch=ctx["N"], img0=ctx["n_labeled"])
+        losses = self.losses(ctx["acat"], ctx["big"], None, gt_unlabeled, head_hw=ctx["hw"], batch=ctx["N"], img0=ctx["n_labeled"], raw=raw)
+        if raw:
+            return losses
         return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
 
     def _anchors_cat(self, anchors, hw, dev):
@@ -386,7 +390,7 @@ class PseudoLabRPN:
         nval = nval & (torch.arange(nidx.shape[1], device=anchors.device)[None, :] < (self.batch_size_per_image - npos))
         return dict(pos_idx=pidx, pos_valid=pval, neg_idx=nidx, neg_valid=nval, matched32=arg, has_gt=has_gt)
 
-    def losses(self, anchors, obj, deltas, gt, head_hw=None, batch=None, img0=0):
+    def losses(self, anchors, obj, deltas, gt, head_hw=None, batch=None, img0=0, raw=False):
         """rpn.py:153-225: BCE(sum) over sampled anchors (optionally weighted by the matched pseudo-box score,
         negatives too - SURVEY B4) + L1 on positives, both / (batch_size_per_image * N), weights applied here too.
         One fused forward launch and one backward launch (utv2_rpn_loss_fwd / _bwd).  obj [N,R] + deltas [N,R,4], or - head_hw given -
@@ -396,8 +400,10 @@ class PseudoLabRPN:
         s = self.label_and_sample(anchors, gt)
         sums = _RpnLossFn.apply(obj, obj if head_hw is not None else deltas, self, anchors, s, gt, head_hw, N, batch, img0)
         norm = self.batch_size_per_image * N
-        out = {"loss_rpn_cls": sums[0] / norm, "loss_rpn_loc": sums[1] / norm}
         self._last_sample = s
+        if raw:   # the fused scalar tail (ops.rcnn_loss_combine) divides, weights (twice: SURVEY B2) and sums
+            return {"raw_sums": sums, "norm": float(norm)}
+        out = {"loss_rpn_cls": sums[0] / norm, "loss_rpn_loc": sums[1] / norm}
         return {k: v * self.loss_weight.get(k, 1.0) for k, v in out.items()}
 
     # -- proposals (D2 find_top_rpn_proposals) -----------------------------------------------------------
@@ -474,17 +480,21 @@ class FastRCNNFocaltLossBoundaryVarOutputLayers:
         K = self.K
         return y[:, :K + 1], y[:, K + 1:K + 5], y[:, K + 5:K + 9]
 
-    def losses(self, predictions, sampled, branch):
+    def losses(self, predictions, sampled, branch, raw=False):
         scores, deltas, std = predictions
         cls = sampled["gt_classes"].reshape(-1)           # -1 = empty slot
-        Rn = (cls >= 0).sum().clamp(min=1).float()        # gt_classes.numel() of the reference
         tgt = cls.to(torch.int32).contiguous()
-        loss_cls = ops.softmax_focal_sum(scores, tgt, self.focal_gamma)[0] / Rn
+        focal = ops.softmax_focal_sum(scores, tgt, self.focal_gamma)
         pseudo = branch == "unsup_data_train"
         mode = (2 if self.box_pseudo_reg_loss_type == "tsbetter" else 3) if pseudo else (0 if self.box_reg_loss_type == "nlloss" else 1)
         gstd = sampled["gt_loc_std"].reshape(-1, 4).contiguous() if (mode == 2 and "gt_loc_std" in sampled) else None
         box = _RoiBoxLossFn.apply(deltas, std, cls.long().contiguous(), sampled["proposal_boxes"].reshape(-1, 4).contiguous(),
-                                  sampled["gt_boxes"].reshape(-1, 4).contiguous(), gstd, self, mode)[0]
+                                  sampled["gt_boxes"].reshape(-1, 4).contiguous(), gstd, self, mode)
+        if raw:   # the fused scalar tail counts the sampled ROIs (targets >= 0), divides, weights and sums
+            return {"focal": focal, "box": box, "tgt": tgt}
+        Rn = (cls >= 0).sum().clamp(min=1).float()        # gt_classes.numel() of the reference
+        loss_cls = focal[0] / Rn
+        box = box[0]
         out = {"loss_cls": loss_cls, "loss_box_reg": box / Rn}
         return {k: v * self.loss_weight.get(k, 1.0) for k, v in out.items()}
 
@@ -648,7 +658,7 @@ class StandardROIHeadsPseudoLab:
 
     __call__ = forward
 
-    def forward_joint(self, features, proposals, n_labeled, gt_labeled, gt_unlabeled):
+    def forward_joint(self, features, proposals, n_labeled, gt_labeled, gt_unlabeled, raw=False):
         """forward(..., branch="supervised") on images [0, n_labeled) and forward(..., branch="unsup_data_train") on the rest as one
         RoIAlign / box head / predictor pass over all sampled ROIs; sampling and the losses stay per branch (the predictor output's rows
         are image-major, so each branch owns a contiguous row range).  Returns the two loss dicts."""
@@ -662,8 +672,8 @@ class StandardROIHeadsPseudoLab:
         valid = torch.cat((s_l["valid"], s_u["valid"]), dim=0)
         scores, deltas, std = self.box_predictor(self._box_features(feats, boxes, valid, fanin=features.get("_fanin")))
         r = nl * boxes.shape[1]
-        l_l = self.box_predictor.losses((scores[:r], deltas[:r], std[:r]), s_l, "supervised")
-        l_u = self.box_predictor.losses((scores[r:], deltas[r:], std[r:]), s_u, "unsup_data_train")
+        l_l = self.box_predictor.losses((scores[:r], deltas[:r], std[:r]), s_l, "supervised", raw=raw)
+        l_u = self.box_predictor.losses((scores[r:], deltas[r:], std[r:]), s_u, "unsup_data_train", raw=raw)
         return l_l, l_u
 
 
@@ -721,12 +731,14 @@ class TwoStagePseudoLabGeneralizedRCNN(ArenaModel):
         w = max(int(x["image"].shape[2]) for x in batched_inputs)
         return ((h + d - 1) // d * d, (w + d - 1) // d * d) if d > 1 else (h, w)
 
-    def forward_joint_begin(self, labeled_inputs, unlabeled_inputs):
+    def forward_joint_begin(self, labeled_inputs, unlabeled_inputs, loss_weights=None):
         """model(labeled, branch="supervised") and model(unlabeled, branch="unsup_data_train") of one iteration (reference
         trainer.py:838-866) as ONE pass over the concatenated batch - every layer is per-image (FrozenBN; RPN / ROI heads work per image),
         so when both lists pad to the same canvas (the caller checks) the results are those of the two passes, with larger GEMMs, half
         the launches and one weight gradient per layer.  This first half runs everything that does not need the pseudo labels (backbone,
-        RPN head, the proposals of all images, the labeled images' RPN losses) - the trainer runs it next to the teacher."""
+        RPN head, the proposals of all images, the labeled images' RPN losses) - the trainer runs it next to the teacher.
+        loss_weights (optional, key -> the trainer's weight of that loss, `_pseudo` keys included): forward_joint_finish then runs the
+        scalar tail of all eight losses fused and returns their weighted total as l_sup["weighted_total"]."""
         assert self.training
         both = list(labeled_inputs) + list(unlabeled_inputs)
         images = [x["image"].to(self.device) for x in both]
@@ -736,12 +748,34 @@ class TwoStagePseudoLabGeneralizedRCNN(ArenaModel):
         self.folder.fold()
         features = self.backbone(x4)
         self._fan_in(features)
-        rctx, proposals, rpn_l = self.proposal_generator.forward_joint_begin(image_sizes, features, len(labeled_inputs), gt_l)
-        return dict(features=features, rpn=rctx, proposals=proposals, rpn_l=rpn_l, gt_l=gt_l, n_labeled=len(labeled_inputs))
+        raw = loss_weights is not None
+        rctx, proposals, rpn_l = self.proposal_generator.forward_joint_begin(image_sizes, features, len(labeled_inputs), gt_l, raw=raw)
+        return dict(features=features, rpn=rctx, proposals=proposals, rpn_l=rpn_l, gt_l=gt_l, n_labeled=len(labeled_inputs),
+                    loss_weights=loss_weights)
+
+    LOSS_KEYS = ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc")
 
     def forward_joint_finish(self, ctx, gt_unlabeled):
         """second half: the pseudo-labeled images' RPN losses and the ROI heads of both branches, given the pseudo ground truth
-        (a PaddedBoxes of the unlabeled images).  Returns (supervised loss dict, pseudo loss dict)."""
+        (a PaddedBoxes of the unlabeled images).  Returns (supervised loss dict, pseudo loss dict).  When forward_joint_begin was given
+        the trainer's loss weights (key -> weight) the scalar tail runs fused - ONE launch maps the raw kernel sums to the eight losses,
+        their weighted total (l_sup["weighted_total"]) and the backward coefficients (ops.rcnn_loss_combine) instead of ~60 single-element
+        ATen launches, each waiting for the host with nothing else queued."""
+        lw = ctx.get("loss_weights")
+        if lw is not None:
+            pg, rh = self.proposal_generator, self.roi_heads
+            rpn_l = ctx["rpn_l"]
+            rpn_u = pg.forward_joint_finish(ctx["rpn"], gt_unlabeled, raw=True)
+            roi_l, roi_u = rh.forward_joint(ctx["features"], ctx["proposals"], ctx["n_labeled"], ctx["gt_l"], gt_unlabeled, raw=True)
+            wt = [float(lw[k]) for k in self.LOSS_KEYS] + [float(lw[k + "_pseudo"]) for k in self.LOSS_KEYS]
+            consts = (rpn_l["norm"], rpn_u["norm"], pg.loss_weight.get("loss_rpn_cls", 1.0) ** 2, pg.loss_weight.get("loss_rpn_loc", 1.0) ** 2,
+                      rh.box_predictor.loss_weight.get("loss_box_reg", 1.0), wt)
+            total, rec = ops.rcnn_loss_combine(rpn_l["raw_sums"], rpn_u["raw_sums"], roi_l["focal"], roi_u["focal"], roi_l["box"], roi_u["box"],
+                                               roi_l["tgt"], roi_u["tgt"], consts)
+            l_l = {k: rec[i] for i, k in enumerate(self.LOSS_KEYS)}
+            l_u = {k: rec[4 + i] for i, k in enumerate(self.LOSS_KEYS)}
+            l_l["weighted_total"] = total
+            return l_l, l_u
         rpn_u = self.proposal_generator.forward_joint_finish(ctx["rpn"], gt_unlabeled)
         roi_l, roi_u = self.roi_heads.forward_joint(ctx["features"], ctx["proposals"], ctx["n_labeled"], ctx["gt_l"], gt_unlabeled)
         l_l, l_u = {}, {}

@@ -814,6 +814,28 @@ def fcos_loss_combine(focal_sup, sums_sup, focal_cls, sums_cls, sums_reg, norm, 
     return _FcosCombineFn.apply(focal_sup, sums_sup, focal_cls, sums_cls, sums_reg, norm, world, flags, kl_weight, wmul, wdiv)
 
 
+class _RcnnCombineFn(torch.autograd.Function):
+    """The scalar tail of the Faster-RCNN losses of a fused student pass as one node (utv2_rcnn_loss_combine): raw kernel sums of both
+    branches -> (weighted total, the eight losses for the metrics); backward = the stored d total / d sums, scaled."""
+
+    @staticmethod
+    def forward(ctx, rpn_sup, rpn_uns, focal_sup, focal_uns, box_sup, box_uns, tgt_sup, tgt_uns, consts):
+        rec, coef = hip.rcnn_loss_combine(rpn_sup.detach(), rpn_uns.detach(), focal_sup.detach(), focal_uns.detach(), box_sup.detach(),
+                                          box_uns.detach(), tgt_sup, tgt_uns, *consts)
+        ctx.save_for_backward(coef)
+        ctx.mark_non_differentiable(rec)
+        return rec[8].clone(), rec
+
+    @staticmethod
+    def backward(ctx, g, _):
+        c = ctx.saved_tensors[0] * g      # order: {cls, box, rpn_cls, rpn_loc} x {sup, uns}
+        return (torch.stack((c[2], c[3])), torch.stack((c[6], c[7])), c[0:1], c[4:5], c[1:2], c[5:6], None, None, None)
+
+
+def rcnn_loss_combine(rpn_sup, rpn_uns, focal_sup, focal_uns, box_sup, box_uns, tgt_sup, tgt_uns, consts):
+    return _RcnnCombineFn.apply(rpn_sup, rpn_uns, focal_sup, focal_uns, box_sup, box_uns, tgt_sup, tgt_uns, consts)
+
+
 def fcos_loc_terms(box, labels, reg_targets, bvars, args):
     return _LocTermsFn.apply(box, labels, reg_targets, bvars, args)
 
