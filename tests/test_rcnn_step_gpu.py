@@ -339,8 +339,8 @@ def test_rcnn_step_bf16_vs_rounding_oracle(kind, tol, monkeypatch):
         type(pg).__call__ = patched
         orig_joint = pg.forward_joint_begin
 
-        def joint(image_sizes, features, n_labeled, gt_labeled):   # the fused student pass: one RPN call for both image sets
-            out = orig_joint(image_sizes, features, n_labeled, gt_labeled)
+        def joint(image_sizes, features, n_labeled, gt_labeled, **kw):   # the fused student pass: one RPN call for both image sets
+            out = orig_joint(image_sizes, features, n_labeled, gt_labeled, **kw)
             calls.extend((out[1].images(0, n_labeled), out[1].images(n_labeled, out[1].n)))
             return out
         pg.forward_joint_begin = joint
