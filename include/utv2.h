@@ -79,6 +79,15 @@ int utv2_conv2d_nhwc_fwd_bf16_ri(const void* x, int x_dtype, const void* w16, vo
                                  const float* bias, const void* residual, const void* mask, const void* post_mask, int N, int H, int W, int C,
                                  int K, int KH, int KW, int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate,
                                  const int* rowinfo, utv2_stream_t stream);
+/* the same with ReLU masks as BIT planes (16-bit y, K % 8 == 0): uint8 [N*OH*OW][K / 8], bit q of byte c = channel 8c + q.
+ * relu_bits (optional, WRITTEN): bit = the stored output is > 0 - all the backward of the ReLU needs of it; mask_bits / post_mask_bits
+ * (optional, read) take the place of mask / post_mask (one form per mask).  The dgrads of a bottleneck (engine/trainer.py's backward
+ * through D2 BottleneckBlock) then read K / 8 bytes per pixel for a sign instead of re-reading 2 K bytes of forward activation. */
+int utv2_conv2d_nhwc_fwd_bf16_bits(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
+                                   const float* bias, const void* residual, const void* mask, const void* post_mask, int N, int H, int W,
+                                   int C, int K, int KH, int KW, int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate,
+                                   const int* rowinfo, void* relu_bits, const void* mask_bits, const void* post_mask_bits,
+                                   utv2_stream_t stream);
 int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
                             const float* bias, const void* residual, int nlev, const int* H_host, const int* W_host, int N,
                             int C, int K, int KH, int KW, int pad, int relu, int accumulate, utv2_stream_t stream);
@@ -202,6 +211,8 @@ int utv2_groupnorm_relu_bwd(const float* dy, const float* y, const float* x, con
 
 /* ---- FCOS targets / losses / decode: modeling/fcos/fcos_outputs.py --------------------------- */
 /* :649-698,:772-906; center_radius > 0 = CENTER_SAMPLE with POS_RADIUS (get_sample_region :700-770), 0 = plain in-box test.
+ * drop_empty: bit 0 = images without gt drop all their locations (label -1; keep_locations of :804-815,310-311), bit 1 = ignore_near
+ * (:841-848): a location inside some box but inside no box's centre-sampling region is dropped.
  * H,W,strides,soi are HOST arrays.  img_active (optional, device uint8[N]):
  * images flagged 0 get label -1 everywhere (ignored by the loss kernels) - the two student passes of one iteration
  * (trainer.py:396-411) run as one batch and each loss branch sees only its own images. */

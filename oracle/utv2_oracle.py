@@ -349,8 +349,8 @@ def center_sample_region(cfg, boxes, num_loc, xs, ys):
     return torch.stack((left, top, right, bottom), -1).min(-1)[0] > 0
 
 
-def fcos_targets(cfg, locations, gts):
-    """fcos_outputs.py:649-698 + 772-906 (ignore_near False; CENTER_SAMPLE per cfg.center_sample).
+def fcos_targets(cfg, locations, gts, ignore_near=False):
+    """fcos_outputs.py:649-698 + 772-906 (CENTER_SAMPLE per cfg.center_sample; ignore_near = SEMISUPNET.PSEUDO_CLS_IGNORE_NEAR, :841-851).
     gts: list of dict(boxes [G,4], classes [G] long, reg_pred_std [G,4] optional).
     Returns level-first dict of lists (labels, reg_targets (stride-normalised), boundary_vars, target_inds,
     keep_locations)."""
@@ -376,7 +376,7 @@ def fcos_targets(cfg, locations, gts):
         t = ys[:, None] - bboxes[:, 1][None]
         r = bboxes[:, 2][None] - xs[:, None]
         b = bboxes[:, 3][None] - ys[:, None]
-        reg = torch.stack([l, t, r, b], dim=2)
+        reg = reg_all = torch.stack([l, t, r, b], dim=2)
         if cfg.center_sample:
             is_in = center_sample_region(cfg, bboxes, num_loc, xs, ys)
         else:
@@ -397,7 +397,11 @@ def fcos_targets(cfg, locations, gts):
         out["labels"].append(lab)
         out["reg_targets"].append(reg)
         out["target_inds"].append(tinds)
-        out["keep_locations"].append(torch.ones(L, dtype=torch.bool))
+        if ignore_near:  # :841-848: a location inside some box is kept only if it is inside some box's sampling region
+            keep = ~((reg_all.min(dim=2)[0] > 0).sum(1) > 0) | (is_in.sum(1) > 0)
+        else:
+            keep = torch.ones(L, dtype=torch.bool)
+        out["keep_locations"].append(keep)
         out["boundary_vars"].append(bv)
 
     def transpose(lst):
@@ -420,9 +424,9 @@ def _flatten_preds(cfg, logits, reg, std, ctr):
     return lg, rg, sd_, ct
 
 
-def fcos_losses(cfg, logits, reg, std, ctr, locations, gts, world_size=1):
+def fcos_losses(cfg, logits, reg, std, ctr, locations, gts, world_size=1, ignore_near=False):
     """Supervised branch: fcos_outputs.py:212-444 (branch 'labeled')."""
-    tg = fcos_targets(cfg, locations, gts)
+    tg = fcos_targets(cfg, locations, gts, ignore_near)
     labels = torch.cat([x.reshape(-1) for x in tg["labels"]])
     keep = torch.cat([x.reshape(-1) for x in tg["keep_locations"]])
     regt = torch.cat([x.reshape(-1, 4) for x in tg["reg_targets"]])
@@ -466,12 +470,13 @@ def fcos_losses(cfg, logits, reg, std, ctr, locations, gts, world_size=1):
     return {"loss_fcos_cls": class_loss, "loss_fcos_loc": reg_loss, "loss_fcos_ctr": ctr_loss}, tg
 
 
-def fcos_pseudo_losses(cfg, logits, reg, std, ctr, locations, gt_dict, world_size=1):
-    """Unsupervised branch: fcos_outputs.py:447-631 (cls set -> cls+ctr; reg set -> loc)."""
+def fcos_pseudo_losses(cfg, logits, reg, std, ctr, locations, gt_dict, world_size=1, ignore_near=False):
+    """Unsupervised branch: fcos_outputs.py:447-631 (cls set -> cls+ctr; reg set -> loc).  ignore_near only fills keep_locations (:474),
+    which this branch never reads (:487-631): PSEUDO_CLS_IGNORE_NEAR does not change a pseudo loss."""
     losses, extras = {}, {}
     lg, rg, sdv, ct = _flatten_preds(cfg, logits, reg, std, ctr)
     for labeltype, gts in gt_dict.items():
-        tg = fcos_targets(cfg, locations, gts)
+        tg = fcos_targets(cfg, locations, gts, ignore_near)
         extras[labeltype] = tg
         labels = torch.cat([x.reshape(-1) for x in tg["labels"]])
         regt = torch.cat([x.reshape(-1, 4) for x in tg["reg_targets"]])

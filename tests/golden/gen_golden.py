@@ -355,6 +355,29 @@ def gen_fcos_center_sample(structures, fo):
         d["labels%d" % l] = npy(tt["labels"][l])
         d["regt%d" % l] = npy(tt["reg_targets"][l])
         d["tinds%d" % l] = npy(tt["target_inds"][l])
+    # SEMISUPNET.PSEUDO_CLS_IGNORE_NEAR (fcos_outputs.py:841-851): with centre sampling, locations inside a box but outside its
+    # sampling region are dropped from the supervised losses (:310-311) ...
+    leaves = [[t.clone().requires_grad_(True) for t in lst] for lst in (logits, reg, std, ctr)]
+    extras, losses = outm.losses(leaves[0], leaves[1], leaves[3], locs, gts, leaves[2], [], True, branch="labeled")
+    (losses["loss_fcos_cls"] + 2.0 * losses["loss_fcos_loc"] + 3.0 * losses["loss_fcos_ctr"]).backward()
+    for k, v in losses.items():
+        d["ign_loss_%s" % k] = npy(v)
+    for nm, lst in zip(("logits", "reg", "std", "ctr"), leaves):
+        for l in range(5):
+            d["ign_g%s%d" % (nm, l)] = npy(lst[l].grad if lst[l].grad is not None else torch.zeros_like(lst[l]))
+    tt = outm._get_ground_truth(locs, gts, True)
+    for l in range(5):
+        d["ign_keep%d" % l] = npy(tt["keep_locations"][l].to(torch.uint8))
+    # ... and is never consulted by the pseudo losses (:487-631), the only branch the trainer hands the switch to (trainer.py:340,347)
+    pg_ = make_gts(g, N, H, W, structures, with_scores=True)
+    pl = []
+    for ign in (False, True):
+        ex, lo = outm.pseudo_losses(logits, reg, ctr, locs, {"cls": pg_, "reg": pg_}, std, [], ign, branch="unlabeled")
+        pl.append({k: npy(v.float() if torch.is_tensor(v) else torch.tensor(float(v))) for k, v in lo.items()})
+    assert all(np.array_equal(pl[0][k], pl[1][k]) for k in pl[0]), "ignore_near changed a pseudo loss"
+    gts_to_arrays("ign_pgt", pg_, d)
+    for k, v in pl[1].items():
+        d["ign_pseudo_%s" % k] = v
     np.savez_compressed(os.path.join(HERE, "fcos_center_sample.npz"), **d)
     print("fcos_center_sample.npz:", len(d), "arrays")
 
@@ -672,6 +695,11 @@ def gen_rcnn(structures):
 
 if __name__ == "__main__":
     structures, fo, pg, tr = install_shims()
+    if len(sys.argv) > 1:  # python gen_golden.py center_sample loss_variants ... : only those files
+        for name in sys.argv[1:]:
+            fn = globals()["gen_" + name] if name in ("rcnn", "data_pipeline") else globals()["gen_fcos_" + name]
+            fn(*{"rcnn": (structures,), "data_pipeline": ()}.get(name, (structures, fo)))
+        sys.exit(0)
     gen_rcnn(structures)
     gen_fcos(structures, fo, pg)
     gen_fcos_center_sample(structures, fo)

@@ -484,6 +484,49 @@ def test_post_mask_epilogue_and_masked_zero_interleave():
     assert torch.equal(hip.zero_interleave2x(c, 20, 24)[:, ::2, ::2], c)
 
 
+def _pack_bits(t):
+    """uint8 [..., K / 8]: bit q of byte c = t[..., 8c + q] > 0"""
+    b = (t.float() > 0).reshape(t.shape[:-1] + (t.shape[-1] // 8, 8)).to(torch.int32)
+    return (b << torch.arange(8, device=t.device, dtype=torch.int32)).sum(-1).to(torch.uint8)
+
+
+@pytest.mark.parametrize("case", [(2, 20, 24, 64, 128, 1, "v2"), (2, 14, 18, 64, 64, 3, "small"), (4, 64, 80, 256, 256, 3, "tile256"),
+                                  (2, 50, 84, 256, 1024, 1, "wide")])
+def test_relu_bit_planes_written_and_read_by_the_conv_epilogues(case):
+    """utv2_conv2d_nhwc_fwd_bf16_bits: the forward epilogue writes the bit plane `output > 0`; a dgrad that reads bit planes in place of
+    the 16-bit mask / post_mask tensors returns the same bits (every tile kernel: 64- and 128-wide tiles, the 256 x 256 tile)."""
+    from ubteacher import hip
+    N, H, W, C, K, k, _ = case
+    g = torch.Generator().manual_seed(C + K + k)
+    x = torch.randn(N, H, W, C, generator=g).cuda().to(BF)
+    w16 = (torch.randn(K, k * k * C, generator=g) * (1.0 / (k * k * C) ** 0.5)).cuda().to(BF)
+    bias = torch.randn(K, generator=g).cuda() * 0.1
+    res = torch.randn(N, H, W, K, generator=g).cuda().to(BF)
+    y0 = hip.conv2d_fwd_bf16(x, w16, bias=bias, residual=res, pad=k // 2, relu=True, kh=k, kw=k, out_dtype=BF)
+    bits = hip.relu_bits_buffer((N, H, W, K), x.device)
+    bits.fill_(0xA5)
+    y1 = hip.conv2d_fwd_bf16(x, w16, bias=bias, residual=res, pad=k // 2, relu=True, kh=k, kw=k, out_dtype=BF, relu_bits=bits)
+    assert torch.equal(y0, y1)
+    assert torch.equal(bits, _pack_bits(y1))
+    assert 0.2 < float((y1 > 0).float().mean()) < 0.8
+    # dgrad of a K -> C layer: the output has C channels; masks as 16-bit tensors vs as bit planes
+    wt16 = (torch.randn(C, k * k * K, generator=g) * 0.05).cuda().to(BF)
+    dy = torch.randn(N, H, W, K, generator=g).cuda().to(BF)
+    mk = torch.relu(torch.randn(N, H, W, C, generator=g)).cuda().to(BF)
+    pm = torch.relu(torch.randn(N, H, W, C, generator=g)).cuda().to(BF)
+    rs = torch.randn(N, H, W, C, generator=g).cuda().to(BF)
+    for kw16, kwb in ((dict(mask=mk), dict(mask_bits=_pack_bits(mk))),
+                      (dict(post_mask=pm, residual=rs), dict(post_mask_bits=_pack_bits(pm), residual=rs)),
+                      (dict(mask=mk, post_mask=pm, residual=rs), dict(mask_bits=_pack_bits(mk), post_mask_bits=_pack_bits(pm), residual=rs)),
+                      (dict(mask=mk, post_mask=pm), dict(mask=mk, post_mask_bits=_pack_bits(pm)))):
+        a = hip.conv2d_dgrad_bf16(dy, wt16, (N, H, W, C), 1, k // 2, k, k, out_dtype=BF, **kw16)
+        b = hip.conv2d_dgrad_bf16(dy, wt16, (N, H, W, C), 1, k // 2, k, k, out_dtype=BF, **kwb)
+        assert torch.equal(a, b), sorted(kwb)
+    # both forms of one mask, an fp32 output or K % 8 != 0 are rejected
+    with pytest.raises(Exception):
+        hip.conv2d_dgrad_bf16(dy, wt16, (N, H, W, C), 1, k // 2, k, k, out_dtype=torch.float32, mask_bits=_pack_bits(mk))
+
+
 def test_batched_weight_flip_equals_per_layer_flip():
     """one launch for all layers (tiled transpose) == the per-layer element-wise kernel, bit for bit, incl. ragged K / C, scales and a
     zero-padded output-channel axis"""

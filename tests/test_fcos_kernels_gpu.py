@@ -460,6 +460,40 @@ def test_center_sample_variant_vs_reference_golden():
     assert sum(int((x < 80).sum()) for x in tg["labels"]) == 0
 
 
+def test_ignore_near_variant_vs_reference_golden():
+    """SEMISUPNET.PSEUDO_CLS_IGNORE_NEAR through the product (fcos_outputs.py:841-851 in the target kernel): dropped locations, supervised
+    losses and head gradients vs the reference's own (fcos_center_sample.npz, ign_*); the pseudo branch takes the switch and, like the
+    reference (which never reads keep_locations there), returns the same losses."""
+    from ubteacher.modeling.fcos import FCOSOutputs
+    cs = dict(np.load(os.path.join(G, "fcos_center_sample.npz")))
+    cfg = fcos_cfg()
+    cfg.MODEL.FCOS.CENTER_SAMPLE = True
+    cfg.MODEL.FCOS.POS_RADIUS = float(cs["radius"])
+    outm = FCOSOutputs(cfg)
+    head_out, level_hw = build_head_out(cs, True)
+    N = int(cs["N"])
+    extras, losses = outm.losses(head_out, level_hw, padded_gt(cs, "gt", N), ignore_near=True)
+    lab = extras["labels"].cpu().numpy()
+    r = 0
+    for l, (h, w) in enumerate(level_hw):
+        assert np.array_equal(lab[r:r + N * h * w] >= 0, cs["ign_keep%d" % l].astype(bool))
+        r += N * h * w
+    for k in ("loss_fcos_cls", "loss_fcos_loc", "loss_fcos_ctr"):
+        close(losses[k], cs["ign_loss_%s" % k], rtol=2e-5)
+    (losses["loss_fcos_cls"] + 2.0 * losses["loss_fcos_loc"] + 3.0 * losses["loss_fcos_ctr"]).backward()
+    meta = head_out["meta"]
+    for l in range(5):
+        close(meta.level_view(head_out["logits"].grad, l).permute(0, 3, 1, 2), cs["ign_glogits%d" % l], rtol=1e-4, atol=2e-7)
+        gb = meta.level_view(head_out["box"].grad, l)
+        close(gb[..., :68].permute(0, 3, 1, 2), cs["ign_greg%d" % l], rtol=1e-4, atol=2e-7)
+        close(gb[..., 72:73].permute(0, 3, 1, 2), cs["ign_gctr%d" % l], rtol=1e-4, atol=2e-7)
+    head_out, level_hw = build_head_out(cs, False)
+    pg = padded_gt(cs, "ign_pgt", N)
+    _, pl = outm.pseudo_losses(head_out, level_hw, {"cls": pg, "reg": pg})
+    for k in ("loss_fcos_cls", "loss_fcos_loc", "loss_fcos_ctr"):
+        close(pl[k], cs["ign_pseudo_%s" % k], rtol=2e-5)
+
+
 LOSS_VARIANTS = {
     "klloss": dict(KL_LOSS_TYPE="klloss"),
     "nokl": dict(KL_LOSS=False),

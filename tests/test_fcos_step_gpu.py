@@ -317,6 +317,41 @@ def test_premasked_backbone_gradients_bit_identical(monkeypatch):
     assert calls[1] < calls[0] and calls[0] - calls[1] >= 13   # the 13 trainable bottlenecks of res3-res5 lost their mask pass
 
 
+def test_relu_bit_planes_backbone_gradients_bit_identical(monkeypatch):
+    """The fused bottlenecks' dgrads read the sign of the forward activations from the bit planes their forward conv epilogues wrote
+    (utv2_conv2d_nhwc_fwd_bf16_bits; default) instead of the 16-bit activations (UTV2_RELU_BITS=0): same step, bit for bit, and the
+    planes are really used - y1, y2 of the 13 trainable blocks, the block input of the 10 that return an input gradient to a fused
+    block, the 3 premasked FPN laterals."""
+    import hashlib
+    from ubteacher import ops
+    from ubteacher.engine import UBTeacherTrainer
+    cfg = small_fcos_cfg()
+    cfg.SOLVER.AMP.ENABLED = True
+    prod, orac = make_batch(12, 2, 2, H, W, "cuda")
+    digests, stats = [], []
+    try:
+        for flag in ("0", "1"):
+            monkeypatch.setenv("UTV2_RELU_BITS", flag)
+            torch.manual_seed(0)
+            tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+            sd_s = tune_state_for_pseudo_labels(cpu_state(tr.model), [d["image"] for d in orac[3]])
+            tr.model.load_state_dict(sd_s)
+            tr.model_teacher.load_state_dict(sd_s)
+            before = dict(ops.BITS_STATS)
+            tr.iter = 1
+            tr.run_step_full_semisup()
+            torch.cuda.synchronize()
+            stats.append({k: ops.BITS_STATS[k] - before[k] for k in before})
+            state = tr.model.flat_state().detach().float().cpu().numpy()
+            assert np.isfinite(state).all()
+            digests.append(hashlib.sha1(state.tobytes()).hexdigest())
+    finally:
+        ops.set_precision("fp32")
+    assert digests[0] == digests[1]
+    assert stats[0] == {"planes": 0, "reads": 0}
+    assert stats[1]["planes"] == 3 * 13 and stats[1]["reads"] == 2 * 13 + 10 + 3, stats[1]
+
+
 def test_fcos_step_vs_reference_trainer_golden():
     """One full FCOS UTv2 iteration of the PRODUCT against the golden produced by executing the reference's own
     UBTeacherTrainer.run_step_full_semisup on its own OneStageDetector / FCOS / PseudoGenerator modules

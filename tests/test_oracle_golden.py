@@ -161,6 +161,35 @@ def test_center_sample_variant():
     assert sum(int((tg0["labels"][l] < 80).sum()) for l in range(5)) > npos
 
 
+def test_ignore_near_variant():
+    """SEMISUPNET.PSEUDO_CLS_IGNORE_NEAR (fcos_outputs.py:841-851) on the centre-sampling inputs: kept locations, supervised losses and
+    gradients vs the reference's own; the pseudo losses do not depend on it (the reference never reads keep_locations there)."""
+    cs = dict(np.load(os.path.join(G, "fcos_center_sample.npz")))
+    cfg = O.FCOSCfg(center_sample=True, radius=float(cs["radius"]))
+    (lg, rg, sd, ct), locs = head(cs, True)
+    N = int(cs["N"])
+    losses, tg = O.fcos_losses(cfg, lg, rg, sd, ct, locs, gts(cs, "gt", N), ignore_near=True)
+    dropped = 0
+    for l in range(5):
+        assert np.array_equal(tg["keep_locations"][l].numpy().astype(np.uint8), cs["ign_keep%d" % l])
+        dropped += int((cs["ign_keep%d" % l] == 0).sum())
+    assert dropped > 0
+    for k in ("loss_fcos_cls", "loss_fcos_loc", "loss_fcos_ctr"):
+        close(losses[k].detach(), cs["ign_loss_%s" % k])
+    assert abs(float(cs["ign_loss_loss_fcos_cls"]) - float(cs["loss_loss_fcos_cls"])) > 1.0     # the switch matters on these inputs
+    (losses["loss_fcos_cls"] + 2.0 * losses["loss_fcos_loc"] + 3.0 * losses["loss_fcos_ctr"]).backward()
+    for nm, lst in zip(("logits", "reg", "std", "ctr"), (lg, rg, sd, ct)):
+        for l in range(5):
+            g = lst[l].grad if lst[l].grad is not None else torch.zeros_like(lst[l])
+            close(g, cs["ign_g%s%d" % (nm, l)], rtol=1e-4, atol=1e-7)
+    (lg, rg, sd, ct), locs = head(cs, False)
+    pg = gts(cs, "ign_pgt", N)
+    for ign in (False, True):
+        pl, _ = O.fcos_pseudo_losses(cfg, lg, rg, sd, ct, locs, {"cls": pg, "reg": pg}, ignore_near=ign)
+        for k in ("loss_fcos_cls", "loss_fcos_loc", "loss_fcos_ctr"):
+            close(pl[k].detach().float(), cs["ign_pseudo_%s" % k])
+
+
 LOSS_VARIANTS = {
     "klloss": dict(kl_loss_type="klloss"),
     "nokl": dict(kl_loss=False),

@@ -95,13 +95,22 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
 // stores (and reads the residual the same way).  `lds` = wave-private float[32 * (TN*32 + 4)].
 // TO = element type of y / residual (float or __bf16); arithmetic is fp32, one rounding at the store.
 // Every lane moves 16 bytes per access: 4 fp32 or 8 bf16 channels.
+// ReLU masks as BIT planes (16-bit outputs with K % 8 == 0 and ldy % 8 == 0; byte index = element offset / 8, bit q = channel co + q):
+// relu_bits is WRITTEN (bit = stored value > 0), mask_bits / post_bits are read in place of mask / post_mask - a sixteenth of the bytes
+// of the 16-bit tensors those arguments would re-read for a sign.
+struct EpiBits {
+  unsigned char* relu_bits;
+  const unsigned char* mask_bits;
+  const unsigned char* post_bits;
+};
+
 template <int TN, typename TO = float>
 __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float* lds, int lane, TO* __restrict__ y,
                                               const float* __restrict__ scale, const float* __restrict__ bias,
                                               const TO* __restrict__ residual, int relu, int accumulate, int m_base,
                                               int co_base, int M, int K, const TO* __restrict__ mask = nullptr,
                                               const TO* __restrict__ post_mask = nullptr, int ldy = 0,
-                                              float* __restrict__ gn_part = nullptr) {
+                                              float* __restrict__ gn_part = nullptr, EpiBits eb = EpiBits{nullptr, nullptr, nullptr}) {
   // gn_part (optional, bf16 outputs with K % 8 == 0): fp32 [ceil(M / 32)][K / 8][2] - per 32-row block and 8-channel group the sum and
   // the sum of squares of the values AS STORED (after the bf16 rounding): the statistics pass of the GroupNorm(8 channels per group)
   // that consumes this conv's output (fcos/fcos.py:263-264), taken while the rows are in registers.  m_base is a multiple of 32; rows
@@ -175,6 +184,10 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
               const bf16x8_t mk = *(const bf16x8_t*)(mask + off);
 #pragma unroll
               for (int q = 0; q < 8; ++q) v[q >> 2][q & 3] = (float)mk[q] > 0.f ? v[q >> 2][q & 3] : 0.f;
+            } else if (eb.mask_bits) {
+              const unsigned mb = eb.mask_bits[off >> 3];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q >> 2][q & 3] = ((mb >> q) & 1u) ? v[q >> 2][q & 3] : 0.f;
             }
             if (residual) {
               const bf16x8_t r = rpre[i][it];
@@ -185,6 +198,10 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
               const bf16x8_t mk = *(const bf16x8_t*)(post_mask + off);
 #pragma unroll
               for (int q = 0; q < 8; ++q) v[q >> 2][q & 3] = (float)mk[q] > 0.f ? v[q >> 2][q & 3] : 0.f;
+            } else if (eb.post_bits) {
+              const unsigned mb = eb.post_bits[off >> 3];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q >> 2][q & 3] = ((mb >> q) & 1u) ? v[q >> 2][q & 3] : 0.f;
             }
             if (relu) {
 #pragma unroll
@@ -199,6 +216,12 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
 #pragma unroll
             for (int q = 0; q < 8; ++q) o[q] = (h16_t)v[q >> 2][q & 3];
             *(bf16x8_t*)(y + off) = o;
+            if (eb.relu_bits) {
+              unsigned b = 0;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) b |= ((float)o[q] > 0.f ? 1u : 0u) << q;
+              eb.relu_bits[off >> 3] = (unsigned char)b;
+            }
             if (gn_part) {
               float f[8];
 #pragma unroll

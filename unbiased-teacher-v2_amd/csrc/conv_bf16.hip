@@ -49,6 +49,7 @@ struct ConvArgs16 {
                              // FCOS towers (cls | bbox, two independent 256 -> 256 chains) run as ONE launch per depth this way.
   int ldy;                   // elements between consecutive rows of y / residual / mask / post_mask (>= K: y may be a column slice)
   float* gn_part;            // optional: per (32-row block, 8-channel group) sum / sum of squares of the stored output (see epilogue_rows)
+  EpiBits bits;              // optional ReLU bit planes (see epilogue_rows): written from / read in place of 16-bit sign tensors
   const int2* rowinfo;       // optional: per OUTPUT row m {input pixel index of tap (0,0), (W << 16) | tap-validity mask} - the table the weight
                              // gradient kernels read (utv2_conv2d_wgrad_bf16): the tile prologue then loads its rows' geometry instead of
                              // decoding it (level search, two integer divisions and a KH x KW bounds loop per staged row: 2.0-2.2 us of a
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
     // all MFMAs retired and every wave is past the last barrier of the K loop: the staging LDS is free
     float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
     epilogue_rows<TN, TO>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
-                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part);
+                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
     return;
   }
   TO* yo = (TO*)p.y;
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
     static_assert(sizeof(smem) >= 4 * 32 * ((BN / 2) + 4) * sizeof(float), "epilogue patches must fit the staging LDS");
     float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
     epilogue_rows<TN, TO>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
-                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part);
+                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
     return;
   }
   TO* yo = (TO*)p.y;
@@ -789,7 +790,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
 #pragma unroll
   for (int half = 0; half < 2; ++half)
     epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[2 * half], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
-                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part);
+                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1131,7 +1132,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
 #pragma unroll
   for (int half = 0; half < 2; ++half)
     epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[2 * half], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
-                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part);
+                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
 #ifdef UTV2_PP_TRACE
   if ((blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left: what a successor workgroup on this CU waits for is the wave's end
@@ -1243,12 +1244,43 @@ int utv2_conv2d_nhwc_fwd_bf16(const void* x, int x_dtype, const void* w16, void*
                                       in_dil, OH, OW, relu, accumulate, nullptr, stream);
 }
 
+static int conv2d_nhwc_fwd_bf16_impl(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
+                                     const float* bias, const void* residual, const void* mask, const void* post_mask, int N, int H, int W, int C,
+                                     int K, int KH, int KW, int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate,
+                                     const int* rowinfo, EpiBits bits, hipStream_t stream);
+
 int utv2_conv2d_nhwc_fwd_bf16_ri(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
                                  const float* bias, const void* residual, const void* mask, const void* post_mask, int N, int H, int W, int C,
                                  int K, int KH, int KW, int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate,
                                  const int* rowinfo, hipStream_t stream) {
+  return conv2d_nhwc_fwd_bf16_impl(x, x_dtype, w16, y, y_dtype, scale, bias, residual, mask, post_mask, N, H, W, C, K, KH, KW, stride, pad,
+                                   in_dil, OH, OW, relu, accumulate, rowinfo, EpiBits{nullptr, nullptr, nullptr}, stream);
+}
+
+// The same with ReLU masks as BIT planes (16-bit y, K % 8 == 0; uint8 [N*OH*OW][K / 8], bit q of byte c = channel 8c + q):
+//   relu_bits (optional, written): bit = the stored output is > 0 - what the backward of the ReLU needs of it;
+//   mask_bits / post_mask_bits (optional, read): take the place of mask / post_mask (do not pass both forms of one mask).
+// The dgrad of a bottleneck's convs then reads K / 8 bytes per pixel for a sign instead of the 2 K bytes of the forward activation.
+int utv2_conv2d_nhwc_fwd_bf16_bits(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
+                                   const float* bias, const void* residual, const void* mask, const void* post_mask, int N, int H, int W,
+                                   int C, int K, int KH, int KW, int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate,
+                                   const int* rowinfo, void* relu_bits, const void* mask_bits, const void* post_mask_bits,
+                                   hipStream_t stream) {
+  if ((relu_bits || mask_bits || post_mask_bits) && (y_dtype != UTV2_BF16 || (K & 7))) return UTV2_EARG;
+  if ((mask && mask_bits) || (post_mask && post_mask_bits)) return UTV2_EARG;
+  return conv2d_nhwc_fwd_bf16_impl(x, x_dtype, w16, y, y_dtype, scale, bias, residual, mask, post_mask, N, H, W, C, K, KH, KW, stride, pad,
+                                   in_dil, OH, OW, relu, accumulate, rowinfo,
+                                   EpiBits{(unsigned char*)relu_bits, (const unsigned char*)mask_bits, (const unsigned char*)post_mask_bits},
+                                   stream);
+}
+
+static int conv2d_nhwc_fwd_bf16_impl(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
+                                     const float* bias, const void* residual, const void* mask, const void* post_mask, int N, int H, int W, int C,
+                                     int K, int KH, int KW, int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate,
+                                     const int* rowinfo, EpiBits bits, hipStream_t stream) {
   if (!x || !w16 || !y || (C % 8) || bad_dtype(x_dtype) || bad_dtype(y_dtype) || (rowinfo && in_dil > 1)) return UTV2_EARG;
   ConvArgs16 a;
+  a.bits = bits;
   a.lt.n = 0;
   a.x = x; a.w = (const h16_t*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = mask; a.post_mask = post_mask;
   a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.K = K; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
@@ -1282,6 +1314,7 @@ int utv2_conv2d_ml_fwd_bf16_g(const void* x, int x_dtype, int x_pitch, const voi
                  (groups > 1 && (K / groups) % 128)))
     return UTV2_EARG;
   ConvArgs16 a;
+  a.bits = EpiBits{nullptr, nullptr, nullptr};
   a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
   if (!plain && ((int64_t)a.M * x_pitch >= (1ll << 31) || (int64_t)K * KH * KW * C >= (1ll << 31))) return UTV2_EARG;
   a.x = x; a.w = (const h16_t*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
@@ -1300,6 +1333,7 @@ int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y
   if (!x || !w16 || !y || nlev < 1 || nlev > CONV_MAX_LEVELS || (C % 8) || N <= 0 || bad_dtype(x_dtype) || bad_dtype(y_dtype))
     return UTV2_EARG;
   ConvArgs16 a;
+  a.bits = EpiBits{nullptr, nullptr, nullptr};
   a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
   a.x = x; a.w = (const h16_t*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad; a.in_dil = 1;
@@ -1322,6 +1356,7 @@ int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int
       OW != (W + 6 - 7) / 2 + 1 || (int64_t)N * (H + 6) * (W + 8) * 4 >= (1ll << 31))
     return UTV2_EARG;
   ConvArgs16 a;
+  a.bits = EpiBits{nullptr, nullptr, nullptr};
   a.lt.n = 0;
   a.x = xpad16; a.w = (const h16_t*)w16s; a.y = y; a.scale = scale; a.bias = bias; a.residual = nullptr; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = H + 6; a.W = W + 8; a.C = 32; a.OH = OH; a.OW = OW; a.K = K; a.KH = 7; a.KW = 1; a.stride = 2; a.pad = 0;

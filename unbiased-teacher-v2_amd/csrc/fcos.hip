@@ -32,8 +32,9 @@ __device__ __forceinline__ int level_of(const LevelTable& t, int loc) {
 // gt arrays are padded to MAXG per image with a validity byte (the thresholded pseudo-label
 // mask, pseudo_generator.py:85, stays on the device; compaction order == index order).
 // One thread per (image, location); gts of the image staged in LDS.
-//   labels[p]      class id, num_classes for background, -1 for "location dropped" (image has
-//                  no gt and drop_empty != 0: the keep_locations filter of :310-311,804-815)
+//   labels[p]      class id, num_classes for background, -1 for "location dropped" (the keep_locations filter of :310-311: the
+//                  image has no gt and drop_empty & 1 (:804-815), or drop_empty & 2 = ignore_near (:841-848) and the location
+//                  lies inside a box but in no box's centre-sampling region)
 //   reg_targets[p] ltrb / stride of the min-area matching gt (gt 0 when none, as the reference)
 //   bvars[p]       teacher reg_pred_std of the matched gt (99999 for background, 0 if no gt)
 //   gt_inds[p]     matched gt slot (or -1 when the image has no gt)
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void fcos_targets_kernel(LevelTable lt, int N,
   // an inactive image (it belongs to the other loss branch of a fused student pass) is ignored like a dropped one
   const bool inactive = !in_range || (img_active != nullptr && !img_active[n]);
   if (G == 0 || inactive) {
-    labels[p] = (drop_empty || inactive) ? -1 : num_classes;
+    labels[p] = ((drop_empty & 1) || inactive) ? -1 : num_classes;
     gt_inds[p] = -1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { reg_targets[p * 4 + e] = 0.f; bvars[p * 4 + e] = 0.f; }
@@ -98,9 +99,11 @@ __global__ __launch_bounds__(256) void fcos_targets_kernel(LevelTable lt, int N,
   const bool cs = center_radius > 0.f;
   const float sr = s * center_radius;
   const bool cs_none = cs && (sb[0][0] + sb[0][2]) * 0.5f * (float)L == 0.f;
+  bool inside_any = false, sampled_any = false;
   for (int k = 0; k < G; ++k) {
     const float lft = xs - sb[k][0], top = ys - sb[k][1], rgt = sb[k][2] - xs, bot = sb[k][3] - ys;
     float mn = fminf(fminf(lft, top), fminf(rgt, bot));
+    inside_any |= mn > 0.f;
     const float mx = fmaxf(fmaxf(lft, top), fmaxf(rgt, bot));
     if (cs) {
       const float cx = (sb[k][0] + sb[k][2]) * 0.5f, cy = (sb[k][1] + sb[k][3]) * 0.5f;
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(256) void fcos_targets_kernel(LevelTable lt, int N,
       const float x1 = xmax > sb[k][2] ? sb[k][2] : xmax, y1 = ymax > sb[k][3] ? sb[k][3] : ymax;
       mn = cs_none ? -1.f : fminf(fminf(xs - x0, ys - y0), fminf(x1 - xs, y1 - ys));
     }
+    sampled_any |= mn > 0.f;
     float a = sarea[k];
     if (!(mn > 0.f)) a = INF;
     if (!(mx >= lt.soi_lo[l] && mx <= lt.soi_hi[l])) a = INF;
@@ -116,7 +120,8 @@ __global__ __launch_bounds__(256) void fcos_targets_kernel(LevelTable lt, int N,
   }
   const bool bg = (best == INF);
   const int g = sidx[bi];
-  labels[p] = bg ? num_classes : gt_classes[gi * MAXG + g];
+  const bool ignored = (drop_empty & 2) && inside_any && !sampled_any;
+  labels[p] = ignored ? -1 : bg ? num_classes : gt_classes[gi * MAXG + g];
   gt_inds[p] = g;
   reg_targets[p * 4 + 0] = (xs - sb[bi][0]) / s;
   reg_targets[p * 4 + 1] = (ys - sb[bi][1]) / s;

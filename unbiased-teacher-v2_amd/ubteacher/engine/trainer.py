@@ -490,7 +490,9 @@ class UBTeacherTrainer(_TrainerBase):
             # The reference runs two student forwards (trainer.py:396-411).  Every layer is per-image (FrozenBN, per-image
             # GroupNorm), so when both lists pad to the same canvas they are ONE batch here: larger GEMMs, one weight
             # gradient per layer instead of two.  Different canvases (zero padding differs) keep the two passes.
-            fuse = (self.fuse_student_passes and not S.PSEUDO_CLS_IGNORE_NEAR
+            # (SEMISUPNET.PSEUDO_CLS_IGNORE_NEAR reaches the pseudo branch only - trainer.py:340,347 - where the reference never reads
+            # the keep_locations it fills, fcos_outputs.py:487-631: it does not change a loss, so it does not constrain the fusion)
+            fuse = (self.fuse_student_passes
                     and self.model.padded_canvas(all_label_data) == self.model.padded_canvas(unlabel_data_q))
             # The student's forward needs the pseudo labels only in its loss kernels: with one student batch the teacher (forward,
             # top-k, decode, NMS, thresholding - the last four latency-bound) runs on a side stream NEXT TO the student's backbone /

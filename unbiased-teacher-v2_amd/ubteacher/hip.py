@@ -830,9 +830,24 @@ def weight_flip_transpose_bf16_batched(arena, scales, bank, table, nlayers):
          _p(table), int(nlayers), _stream())
 
 
+def relu_bits_buffer(shape, device):
+    """uint8 bit plane of an NHWC / [P, K] 16-bit activation (K % 8 == 0): one bit per element, `value > 0` (utv2_conv2d_nhwc_fwd_bf16_bits)"""
+    assert shape[-1] % 8 == 0
+    return torch.empty(tuple(shape[:-1]) + (shape[-1] // 8,), dtype=torch.uint8, device=device)
+
+
+def _bits_ok(bits, shape):
+    n = 1
+    for d in shape:
+        n *= int(d)
+    assert bits.dtype == torch.uint8 and bits.is_contiguous() and bits.numel() * 8 == n, "bit plane of another tensor"
+    return bits
+
+
 def conv2d_fwd_bf16(x, w16, scale=None, bias=None, residual=None, stride=1, pad=0, relu=False, kh=1, kw=1, out=None,
-                    in_dil=1, out_hw=None, accumulate=False, out_dtype=None, mask=None, post_mask=None):
-    """x: fp32 or bf16 NHWC; the output (and `residual`) element type is out_dtype (default: x's)."""
+                    in_dil=1, out_hw=None, accumulate=False, out_dtype=None, mask=None, post_mask=None, relu_bits=None):
+    """x: fp32 or bf16 NHWC; the output (and `residual`) element type is out_dtype (default: x's).  relu_bits (optional uint8
+    [N, OH, OW, K / 8], written): bit plane `output > 0` of a 16-bit output."""
     N, H, W, C = x.shape
     K = w16.shape[0]
     assert w16.dtype == h16_dtype() and C % 8 == 0
@@ -845,14 +860,22 @@ def conv2d_fwd_bf16(x, w16, scale=None, bias=None, residual=None, stride=1, pad=
     ri = None
     if _CONV_ROWINFO and kh * kw > 1 and in_dil == 1 and x.dtype == h16_dtype() and C % 32 == 0 and kh * kw <= 16 and W < 32768:
         ri = rowinfo_nhwc(N, H, W, OH, OW, stride, pad, kh, kw, x.device)   # the table the weight gradient of this conv reads
+    if relu_bits is not None:
+        assert out.dtype == h16_dtype()
+        call("utv2_conv2d_nhwc_fwd_bf16_bits", _p(x), _dt(x), _p(w16), _p(out), _same_dt(out, residual, mask, post_mask), _p(scale), _p(bias),
+             _p(residual), _p(mask), _p(post_mask), N, H, W, C, K, kh, kw, stride, pad, in_dil, OH, OW, int(relu), int(accumulate), _p(ri),
+             _p(_bits_ok(relu_bits, out.shape)), c_p(0), c_p(0), _stream())
+        return out
     call("utv2_conv2d_nhwc_fwd_bf16_ri", _p(x), _dt(x), _p(w16), _p(out), _same_dt(out, residual, mask, post_mask), _p(scale), _p(bias),
          _p(residual), _p(mask), _p(post_mask), N, H, W, C, K, kh, kw, stride, pad, in_dil, OH, OW, int(relu), int(accumulate), _p(ri), _stream())
     return out
 
 
-def conv2d_dgrad_bf16(dy, wt16, in_shape, stride, pad, kh, kw, out=None, out_dtype=None, mask=None, residual=None, post_mask=None):
+def conv2d_dgrad_bf16(dy, wt16, in_shape, stride, pad, kh, kw, out=None, out_dtype=None, mask=None, residual=None, post_mask=None,
+                      mask_bits=None, post_mask_bits=None):
     """dx = dgrad(dy); mask (the forward activation dx is the gradient of): dx = mask > 0 ? dx : 0; residual: dx += residual;
-    post_mask: dx = post_mask > 0 ? dx : 0 after the residual add"""
+    post_mask: dx = post_mask > 0 ? dx : 0 after the residual add.  mask_bits / post_mask_bits: the same masks as the bit planes the
+    forward convs wrote (relu_bits) - a sixteenth of the bytes."""
     N, H, W, C = in_shape
     _, OH, OW, K = dy.shape
     if out is None:
@@ -860,6 +883,13 @@ def conv2d_dgrad_bf16(dy, wt16, in_shape, stride, pad, kh, kw, out=None, out_dty
     ri = None
     if _CONV_ROWINFO and kh * kw > 1 and stride == 1 and dy.dtype == h16_dtype() and K % 32 == 0 and kh * kw <= 16 and OW < 32768:
         ri = rowinfo_nhwc(N, OH, OW, H, W, 1, kh - 1 - pad, kh, kw, dy.device)   # dgrad = a stride-1 conv over dy with pad k-1-pad
+    if mask_bits is not None or post_mask_bits is not None:
+        assert out.dtype == h16_dtype() and (mask is None or mask_bits is None) and (post_mask is None or post_mask_bits is None)
+        call("utv2_conv2d_nhwc_fwd_bf16_bits", _p(dy), _dt(dy), _p(wt16), _p(out), _same_dt(out, residual, mask, post_mask), c_p(0), c_p(0),
+             _p(residual), _p(mask), _p(post_mask), N, OH, OW, K, C, kh, kw, 1, kh - 1 - pad, stride, H, W, 0, 0, _p(ri), c_p(0),
+             _p(_bits_ok(mask_bits, out.shape)) if mask_bits is not None else c_p(0),
+             _p(_bits_ok(post_mask_bits, out.shape)) if post_mask_bits is not None else c_p(0), _stream())
+        return out
     call("utv2_conv2d_nhwc_fwd_bf16_ri", _p(dy), _dt(dy), _p(wt16), _p(out), _same_dt(out, residual, mask, post_mask), c_p(0), c_p(0),
          _p(residual), _p(mask), _p(post_mask), N, OH, OW, K, C, kh, kw, 1, kh - 1 - pad, stride, H, W, 0, 0, _p(ri), _stream())
     return out

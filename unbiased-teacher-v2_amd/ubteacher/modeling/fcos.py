@@ -473,12 +473,13 @@ class FCOSOutputs:
         return sums[4]
 
     # -- supervised branch (fcos_outputs.py:212-444) -------------------------------------------------
-    def losses(self, head_out, level_hw, gt, branch="labeled", active=None):
-        """active (optional, uint8 [N]): images of the batch this branch owns (fused student pass); the others are ignored."""
+    def losses(self, head_out, level_hw, gt, branch="labeled", active=None, ignore_near=False):
+        """active (optional, uint8 [N]): images of the batch this branch owns (fused student pass); the others are ignored.
+        ignore_near (fcos_outputs.py:841-851, with CENTER_SAMPLE): locations inside a box but in no box's sampling region are dropped."""
         if branch != "labeled":
             raise ValueError("Incorrect branch name")
         logits_all, box_all = head_out["logits"], head_out["box"]
-        labels, reg_t, bvars, gt_inds = self._targets(level_hw, gt, drop_empty=1, active=active)
+        labels, reg_t, bvars, gt_inds = self._targets(level_hw, gt, drop_empty=3 if ignore_near else 1, active=active)
         focal = ops.focal_loss_sum(logits_all, labels, self.focal_loss_alpha, self.focal_loss_gamma)
         flags = self.loc_flags | (hip.LT_QUALITY_IOU if self.quality_iou else 0)  # QUALITY_EST acts on this branch only (:353-359)
         sums = ops.fcos_loc_terms(box_all, labels, reg_t, None, (self.num_classes, self.reg_max, 0.0, 0.0, flags))
@@ -699,11 +700,11 @@ class FCOS:
         raw_output = RawOutput(head_out, level_hw, image_sizes, self.fpn_strides, self.fcos_outputs.reg_max)
         results = {}
         if self.training:
-            if ignore_near:
-                raise NotImplementedError("PSEUDO_CLS_IGNORE_NEAR is False in every shipped config")
             if branch == "labeled":
-                results, losses = self.fcos_outputs.losses(head_out, level_hw, gt_instances, branch=branch)
+                results, losses = self.fcos_outputs.losses(head_out, level_hw, gt_instances, branch=branch, ignore_near=ignore_near)
             elif branch == "unlabeled":
+                # ignore_near (SEMISUPNET.PSEUDO_CLS_IGNORE_NEAR, trainer.py:340,347) only fills keep_locations in the reference
+                # (fcos_outputs.py:474,841-851), which its pseudo losses never read (:487-631): accepted, no effect - as there
                 results, losses = self.fcos_outputs.pseudo_losses(head_out, level_hw, gt_instances, branch=branch)
             elif branch == "raw":
                 results, losses = {}, {}

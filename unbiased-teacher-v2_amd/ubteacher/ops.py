@@ -312,7 +312,7 @@ class Conv:
                                  colscale_handle, meta)
         return self._forward(x, residual, out, colscale_handle, meta)
 
-    def _forward(self, x, residual, out, cs, meta):
+    def _forward(self, x, residual, out, cs, meta, relu_bits=None):
         sc, sh = self.scale_shift()
         b16 = self.use_bf16()
         w = self.w.store.bf16(self.w) if b16 else self.w.t
@@ -349,6 +349,8 @@ class Conv:
                    out=None if out is None else out.view(1, x.shape[0], 1, -1), **kw).view(x.shape[0], self.cout)
         else:
             fn = hip.conv2d_fwd_bf16 if b16 else hip.conv2d_fwd
+            if relu_bits is not None:
+                kw["relu_bits"] = relu_bits
             y = fn(x, w, scale=sc, bias=sh, residual=residual, stride=self.stride, pad=self.pad, relu=self.relu, kh=self.k,
                    kw=self.k, out=out, **kw)
         if cs is not None:
@@ -371,6 +373,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.cs = cs
         ctx.meta = meta
         ctx.has_res = residual is not None
+        ctx.x_bits = _bits_of(x) if (layer.premask_input and meta is None) else None   # x: a fused bottleneck's ReLU output
         if GRAD_SYNC[0] is not None:
             GRAD_SYNC[0].on_forward(_sync_handles(layer, cs))
         ctx.save_for_backward(x, y if (layer.relu or cs is not None) else None)
@@ -479,8 +482,10 @@ class _ConvFn(torch.autograd.Function):
                     gd = g4
                     if layer.dgrad_cout() != layer.cout:
                         gd = hip.pad_cols_bf16(g4.reshape(-1, layer.cout), layer.dgrad_cout()).view(g4.shape[:-1] + (layer.dgrad_cout(),))
+                    pb = ctx.x_bits if (pm is not None and relu_bits_on() and x.dtype == hip.h16_dtype()) else None
+                    BITS_STATS["reads"] += pb is not None
                     dx = hip.conv2d_dgrad_bf16(gd, layer.wt16(wsc), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k,
-                                               out_dtype=x.dtype, mask=pm)
+                                               out_dtype=x.dtype, mask=None if pb is not None else pm, mask_bits=pb)
                 else:
                     dx = hip.conv2d_dgrad(g4, layer.wt(), tuple(x4.shape), layer.stride, layer.pad, layer.k, layer.k)
                     if pm is not None:
@@ -515,9 +520,33 @@ def _wgrad16(layer, x4, g4):
                                                 rowscale=layer.bn.scale), x4, g4)
 
 
-def _dgrad16(layer, g4, in_shape, mask=None, residual=None, post_mask=None):
+def _dgrad16(layer, g4, in_shape, mask=None, residual=None, post_mask=None, mask_bits=None, post_mask_bits=None):
+    if mask_bits is not None:
+        mask = None
+    if post_mask_bits is not None:
+        post_mask = None
+    BITS_STATS["reads"] += (mask_bits is not None) + (post_mask_bits is not None)
     return hip.conv2d_dgrad_bf16(g4, layer.wt16(layer.bn.scale), tuple(in_shape), layer.stride, layer.pad, layer.k, layer.k,
-                                 out_dtype=hip.h16_dtype(), mask=mask, residual=residual, post_mask=post_mask)
+                                 out_dtype=hip.h16_dtype(), mask=mask, residual=residual, post_mask=post_mask, mask_bits=mask_bits,
+                                 post_mask_bits=post_mask_bits)
+
+
+def relu_bits_on():
+    """The fused bottlenecks keep the sign of their three ReLU outputs as bit planes (written by the forward conv epilogues, a sixteenth of
+    the activation's bytes) and their dgrads read those instead of the 16-bit activations (22 C -> 16.4 C bytes per pixel of a block's
+    dgrad chain).  UTV2_RELU_BITS=0: the dgrads re-read the activations (A/B runs; identical results)."""
+    return os.environ.get("UTV2_RELU_BITS", "1") != "0"
+
+
+BITS_STATS = {"planes": 0, "reads": 0}     # bit planes written / read in place of a 16-bit tensor since import (tests)
+
+
+def _bits_of(t):
+    """the bit plane `t > 0` its producer attached to a ReLU output (None: unknown, read the tensor)"""
+    b = getattr(t, "_utv2_relu_bits", None)
+    if b is not None and (b[0] != t.data_ptr() or b[1] != t._version):
+        return None     # another tensor's plane, or the tensor was written since
+    return None if b is None else b[2]
 
 
 def premask_on():
@@ -532,10 +561,21 @@ class _BottleneckFn(torch.autograd.Function):
     def forward(ctx, x, hk, block):
         c1, c2, c3, cs = block.conv1, block.conv2, block.conv3, block.shortcut
         res = cs._forward(x, None, None, None, None) if cs is not None else x
-        y1 = c1._forward(x, None, None, None, None)
-        y2 = c2._forward(y1, None, None, None, None)
-        y3 = c3._forward(y2, res, None, None, None)
+        b1 = b2 = b3 = None
+        if relu_bits_on() and all(c.relu and c.cout % 8 == 0 for c in (c1, c2, c3)):
+            planes, (n_, h_, w_, _) = [], x.shape
+            for c in (c1, c2, c3):
+                h_, w_ = hip.conv_out_size(h_, c.k, c.stride, c.pad), hip.conv_out_size(w_, c.k, c.stride, c.pad)
+                planes.append(hip.relu_bits_buffer((n_, h_, w_, c.cout), x.device))
+            b1, b2, b3 = planes
+            BITS_STATS["planes"] += 3
+        y1 = c1._forward(x, None, None, None, None, relu_bits=b1)
+        y2 = c2._forward(y1, None, None, None, None, relu_bits=b2)
+        y3 = c3._forward(y2, res, None, None, None, relu_bits=b3)
         ctx.block = block
+        ctx.bits = (_bits_of(x), b1, b2)
+        if b3 is not None:
+            y3._utv2_relu_bits = (y3.data_ptr(), y3._version, b3)    # for whoever back-propagates into this ReLU output
         ctx.save_for_backward(x, y1, y2, y3)
         if GRAD_SYNC[0] is not None:
             for l in (c1, c2, c3, cs):
@@ -554,24 +594,27 @@ class _BottleneckFn(torch.autograd.Function):
         else:
             gm = hip.relu_bwd_scale(dy.contiguous(), y3, None)     # gradient at conv3's BN output == at the residual input
         pm = x if (pre and block.input_relu) else None              # x is a ReLU output whose producer expects a masked gradient
+        bx, b1, b2 = ctx.bits
+        if pm is None:
+            bx = None
         _wgrad16(c3, y2, gm)
-        g2 = _dgrad16(c3, gm, y2.shape, mask=y2)                    # ... through ReLU(conv2): at conv2's BN output
+        g2 = _dgrad16(c3, gm, y2.shape, mask=y2, mask_bits=b2)      # ... through ReLU(conv2): at conv2's BN output
         _wgrad16(c2, y1, g2)
-        g1 = _dgrad16(c2, g2, y1.shape, mask=y1)
+        g1 = _dgrad16(c2, g2, y1.shape, mask=y1, mask_bits=b1)
         _wgrad16(c1, x, g1)
         if cs is not None:
             _wgrad16(cs, x, gm)
         dx = None
         if ctx.needs_input_grad[0]:
             if cs is None:
-                dx = _dgrad16(c1, g1, x.shape, residual=gm, post_mask=pm)   # identity branch added in the epilogue
+                dx = _dgrad16(c1, g1, x.shape, residual=gm, post_mask=pm, post_mask_bits=bx)   # identity branch added in the epilogue
             elif c1.stride == 2:
                 c = hip.conv2d_fwd_bf16(gm, cs.wt16(cs.bn.scale), out_dtype=hip.h16_dtype())       # compact grids: only the
                 c = hip.conv2d_fwd_bf16(g1, c1.wt16(c1.bn.scale), residual=c, out_dtype=hip.h16_dtype())   # even pixels get gradient
                 dx = hip.zero_interleave2x(c, x.shape[1], x.shape[2], mask=pm)
             else:
                 d = _dgrad16(cs, gm, x.shape)
-                dx = _dgrad16(c1, g1, x.shape, residual=d, post_mask=pm)
+                dx = _dgrad16(c1, g1, x.shape, residual=d, post_mask=pm, post_mask_bits=bx)
         if GRAD_SYNC[0] is not None:
             for l in (c3, c2, c1, cs):
                 if l is not None:
