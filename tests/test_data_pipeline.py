@@ -87,6 +87,23 @@ def test_resize_shortest_edge_and_boxes():
     assert np.allclose(f, [[1280 - 220, 40, 1280 - 20, 440]])
 
 
+def test_random_crop_sizes_and_positions():
+    """INPUT.CROP (data/dataset_mapper.py:38-41 -> Detectron2 T.RandomCrop): the four crop types' size rules and an in-image corner"""
+    from ubteacher.data.transforms import RandomCrop
+    rng = np.random.default_rng(3)
+    assert RandomCrop("relative", (0.5, 0.25)).get_crop_size(rng, 481, 640) == (241, 160)          # int(x + 0.5)
+    assert RandomCrop("absolute", (384, 600)).get_crop_size(rng, 300, 800) == (300, 600)          # capped at the image
+    for _ in range(50):
+        ch, cw = RandomCrop("relative_range", (0.9, 0.9)).get_crop_size(rng, 480, 640)
+        assert int(0.9 * 480 + 0.5) <= ch <= 480 and int(0.9 * 640 + 0.5) <= cw <= 640
+        ch, cw = RandomCrop("absolute_range", (384, 600)).get_crop_size(rng, 480, 640)
+        assert 384 <= ch <= 480 and 384 <= cw <= 600
+        x0, y0, w, h = RandomCrop("relative_range", (0.5, 0.5)).get_params(rng, 480, 640)
+        assert 0 <= x0 and x0 + w <= 640 and 0 <= y0 and y0 + h <= 480 and w >= 320 and h >= 240
+    xs = {RandomCrop("absolute", (100, 100)).get_params(rng, 120, 130)[:2] for _ in range(200)}
+    assert len(xs) > 50 and max(x for x, _ in xs) == 30 and max(y for _, y in xs) == 20             # corners cover [0, w - cw] x [0, h - ch]
+
+
 def test_strong_param_sampling_ranges():
     from ubteacher.data.transforms import sample_strong_params
     rng = np.random.default_rng(5)

@@ -123,3 +123,43 @@ def test_mapper_reads_files_handles_empty_annotations_and_eval_mode(tmp_path):
     assert isinstance(out, dict) and tuple(out["image"].shape) == (3, 120, 180) and "instances" not in out
     ref = np.asarray(Image.fromarray(np.ascontiguousarray(rgb[:, :, ::-1])).resize((180, 120), Image.BILINEAR))
     assert np.array_equal(out["image"].cpu().numpy(), ref.transpose(2, 0, 1))
+
+
+def test_mapper_random_crop_in_front_of_the_weak_augmentation(tmp_path):
+    """INPUT.CROP.ENABLED (data/dataset_mapper.py:38-41): the crop comes first - the weak view is the resized CROP, the boxes move with
+    it (shift, then scale, one clip at the end) and the ones left outside are dropped (filter_empty_instances)."""
+    from PIL import Image
+    from ubteacher.data import DatasetMapperTwoCropSeparate
+    cfg = cfg_for_data("syn_file", 2)
+    cfg.INPUT.MIN_SIZE_TRAIN = (96,)
+    cfg.INPUT.MIN_SIZE_TRAIN_SAMPLING = "choice"
+    cfg.INPUT.RANDOM_FLIP = "none"
+    cfg.INPUT.CROP.ENABLED = True
+    cfg.INPUT.CROP.TYPE = "absolute"
+    cfg.INPUT.CROP.SIZE = [48, 72]
+    rgb = np.random.default_rng(1).integers(0, 256, (60, 90, 3), dtype=np.uint8)
+    path = str(tmp_path / "img.png")
+    Image.fromarray(rgb).save(path)
+    annos = [{"bbox": [0, 0, 90, 60], "category_id": 1}, {"bbox": [80, 50, 90, 60], "category_id": 2}, {"bbox": [0, 0, 4, 4], "category_id": 3}]
+    mapper = DatasetMapperTwoCropSeparate(cfg, True)
+    seen = set()
+    for _ in range(12):
+        strong, weak = mapper({"file_name": path, "height": 60, "width": 90, "annotations": annos})
+        x0, y0, cw, ch = mapper.last_params["crop"]
+        seen.add((x0, y0))
+        assert (cw, ch) == (72, 48) and 0 <= x0 <= 18 and 0 <= y0 <= 12
+        crop = np.ascontiguousarray(rgb[y0:y0 + ch, x0:x0 + cw, ::-1])
+        ref = np.asarray(Image.fromarray(crop).resize((144, 96), Image.BILINEAR))
+        assert np.array_equal(weak["image"].cpu().numpy(), ref.transpose(2, 0, 1))
+        inst = weak["instances"]
+        want = []
+        for a in annos:
+            b = np.array(a["bbox"], dtype=np.float64) - [x0, y0, x0, y0]
+            b = np.minimum(np.clip(b * 2.0, 0, None), [144, 96, 144, 96])
+            if b[2] - b[0] > 1e-5 and b[3] - b[1] > 1e-5:
+                want.append((b, a["category_id"]))
+        assert len(inst) == len(want)
+        for i, (b, c) in enumerate(want):
+            assert np.allclose(inst.gt_boxes.tensor[i].numpy(), b) and int(inst.gt_classes[i]) == c
+    assert len(seen) > 3
+    assert DatasetMapperTwoCropSeparate(cfg, False).crop is None          # is_train only

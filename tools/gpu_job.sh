@@ -1,24 +1,6 @@
 #!/bin/bash
-# scratch: the GPU job of the moment - A/B of UTV2_RELU_BITS on one box (FCOS f16 headline + Faster-RCNN bf16)
+# scratch: the GPU job of the moment
 cd /root/repo
 mkdir -p gpurun_out
-B="--steps 23 --warmup 5 --no-cpu-baseline --no-rcnn --no-f32 --timed-only"
-for r in 1 2 3; do
-  for f in 0 1; do
-    UTV2_RELU_BITS=$f timeout 600 python bench.py $B > gpurun_out/ab_B${f}_${r}.json 2> gpurun_out/ab_err.txt
-  done
-done
-for r in 1 2; do
-  for f in 0 1; do
-    UTV2_RELU_BITS=$f timeout 600 python bench.py $B --model rcnn > gpurun_out/ab_RB${f}_${r}.json 2> gpurun_out/ab_err.txt
-  done
-done
-python - <<'PY'
-import json, glob
-for f in sorted(glob.glob("gpurun_out/ab_B*.json") + glob.glob("gpurun_out/ab_RB*.json")):
-    try:
-        d = json.loads(open(f).read().strip().splitlines()[-1])
-        print(f, d["dtype"], round(d["value"], 2), round(d["ms_per_step"], 3))
-    except Exception as e:
-        print(f, "ERR", e)
-PY
+timeout 1200 python -m pytest tests/test_data_pipeline_gpu.py -x -q -m gpu > gpurun_out/t11.log 2>&1
+tail -5 gpurun_out/t11.log

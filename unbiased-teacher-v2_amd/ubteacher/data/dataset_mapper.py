@@ -73,8 +73,8 @@ def to_xyxy_abs(anno):
 
 class DatasetMapperTwoCropSeparate:
     def __init__(self, cfg, is_train=True, seed=None, device=None):
-        if cfg.INPUT.CROP.ENABLED and is_train:
-            raise NotImplementedError("INPUT.CROP (no shipped UTv2 config enables it)")
+        # data/dataset_mapper.py:38-41: the crop goes in FRONT of the weak augmentation (both views see the cropped image)
+        self.crop = T.RandomCrop(cfg.INPUT.CROP.TYPE, cfg.INPUT.CROP.SIZE) if (cfg.INPUT.CROP.ENABLED and is_train) else None
         self.resize, self.flip_prob = T.build_weak_augmentation(cfg, is_train)
         self.img_format = cfg.INPUT.FORMAT
         self.is_train = is_train
@@ -93,6 +93,10 @@ class DatasetMapperTwoCropSeparate:
         check_image_size(dataset_dict, image)
         dataset_dict.pop("image", None)
         h, w = image.shape[:2]
+        cx0 = cy0 = 0
+        if self.crop is not None:
+            cx0, cy0, w, h = self.crop.get_params(self.rng, h, w)
+            image = np.ascontiguousarray(image[cy0:cy0 + h, cx0:cx0 + w])
         newh, neww = self.resize.get_params(self.rng, h, w)
         flip = bool(self.rng.random() < self.flip_prob) if self.flip_prob > 0 else False
         x = torch.from_numpy(image).to(self.device, non_blocking=True)
@@ -102,7 +106,8 @@ class DatasetMapperTwoCropSeparate:
             return dataset_dict
         if annos_in is not None:
             keep = [a for a in annos_in if a.get("iscrowd", 0) == 0]
-            boxes = T.transform_boxes([to_xyxy_abs(a) for a in keep], h, w, newh, neww, flip) if keep else np.zeros((0, 4), np.float32)
+            raw = np.asarray([to_xyxy_abs(a) for a in keep], dtype=np.float64).reshape(-1, 4) - np.array([cx0, cy0, cx0, cy0], dtype=np.float64)
+            boxes = T.transform_boxes(raw, h, w, newh, neww, flip) if keep else np.zeros((0, 4), np.float32)   # one clip, after all transforms
             classes = np.array([a["category_id"] for a in keep], dtype=np.int64)
             nonempty = ((boxes[:, 2] - boxes[:, 0]) > 1e-5) & ((boxes[:, 3] - boxes[:, 1]) > 1e-5)  # filter_empty_instances
             inst = Instances((newh, neww))
@@ -110,7 +115,7 @@ class DatasetMapperTwoCropSeparate:
             inst.gt_classes = torch.from_numpy(classes[nonempty])
             dataset_dict["instances"] = inst
         p = T.sample_strong_params(self.rng, newh, neww)
-        self.last_params = dict(p, newh=newh, neww=neww, flip=flip)
+        self.last_params = dict(p, newh=newh, neww=neww, flip=flip, crop=(cx0, cy0, w, h))
         strong = T.apply_strong(weak, p, generator=self.generator)
         strong_dict = dataset_dict
         weak_dict = dict(dataset_dict)

@@ -42,6 +42,40 @@ class ResizeShortestEdge:
         return int(newh + 0.5), int(neww + 0.5)
 
 
+class RandomCrop:
+    """Detectron2 `T.RandomCrop(crop_type, crop_size)` [D2-recall], which the reference's mapper puts in front of the weak augmentation
+    when INPUT.CROP.ENABLED (data/dataset_mapper.py:38-41): crop size by type ("relative": fractions of (h, w); "relative_range":
+    fractions drawn uniformly from [crop_size, 1]; "absolute": pixels, capped at the image; "absolute_range": both sides drawn from
+    [crop_size[0], crop_size[1]] capped at the image), sizes rounded half up, the corner uniform over the positions that fit."""
+
+    def __init__(self, crop_type, crop_size):
+        assert crop_type in ("relative_range", "relative", "absolute", "absolute_range"), crop_type
+        self.crop_type, self.crop_size = crop_type, tuple(crop_size)
+
+    def get_crop_size(self, rng, h, w):
+        if self.crop_type == "relative":
+            ch, cw = self.crop_size
+            return int(h * ch + 0.5), int(w * cw + 0.5)
+        if self.crop_type == "relative_range":
+            cs = np.asarray(self.crop_size, dtype=np.float32)
+            ch, cw = cs + rng.random(2) * (1 - cs)
+            return int(h * ch + 0.5), int(w * cw + 0.5)
+        if self.crop_type == "absolute":
+            return min(int(self.crop_size[0]), h), min(int(self.crop_size[1]), w)
+        assert self.crop_size[0] <= self.crop_size[1]
+        ch = int(rng.integers(min(h, int(self.crop_size[0])), min(h, int(self.crop_size[1])) + 1))
+        cw = int(rng.integers(min(w, int(self.crop_size[0])), min(w, int(self.crop_size[1])) + 1))
+        return ch, cw
+
+    def get_params(self, rng, h, w):
+        """(x0, y0, crop_w, crop_h) of the CropTransform"""
+        ch, cw = self.get_crop_size(rng, h, w)
+        assert h >= ch and w >= cw, "Shape computation in RandomCrop has bugs."
+        y0 = int(rng.integers(h - ch + 1))
+        x0 = int(rng.integers(w - cw + 1))
+        return x0, y0, cw, ch
+
+
 def build_weak_augmentation(cfg, is_train=True):
     """(ResizeShortestEdge, flip probability) of Detectron2's build_augmentation for this cfg"""
     if is_train:
