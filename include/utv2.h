@@ -164,6 +164,11 @@ int utv2_downsample2x_sum_nhwc(const void* g, void* dtop, int N, int TH, int TW,
 /* dgrad of a stride-2 1x1 conv (D2 STRIDE_IN_1X1 bottlenecks): dst[n,2i,2j,:] = src[n,i,j,:], zeros elsewhere;
  * src is [N][(H+1)/2][(W+1)/2][C] - the compact gradient comes from a plain GEMM instead of a 4x larger masked one */
 int utv2_zero_interleave2x_nhwc(const void* src, const void* mask, void* dst, int N, int H, int W, int C, int dtype, utv2_stream_t stream);
+/* the same on 16-bit tensors (C % 8 == 0) with the fusions of the stride-2 bottlenecks' backward: dst = add + (even pixel ? masked src : 0);
+ * the mask as a 16-bit tensor or as a bit plane (utv2_conv2d_nhwc_fwd_bf16_bits); `add` = the gradient another consumer of the same
+ * activation produced (already masked by its producer) - no elementwise add pass.  mask, mask_bits, add optional. */
+int utv2_zero_interleave2x_add_nhwc(const void* src, const void* mask, const void* mask_bits, const void* add, void* dst, int N, int H, int W,
+                                    int C, utv2_stream_t stream);
 /* modeling/one_stage_detector.py:88-90 / meta_arch/rcnn.py:18 (preprocess_image + ImageList pad) */
 int utv2_preprocess_image(const void* src, int is_u8, float* dst, int H, int W, int Hp, int Wp,
                           const float* mean3_host, const float* std3_host, utv2_stream_t stream);

@@ -477,6 +477,12 @@ def test_post_mask_epilogue_and_masked_zero_interleave():
     assert torch.equal(f32, torch.where(pm.float() > 0, base + res.float(), torch.zeros_like(base)))
     c = torch.randn(N, 10, 12, C, device="cuda").to(BF)
     full_mask = torch.randn(N, 20, 24, C, device="cuda").to(BF)
+    other = torch.randn(N, 20, 24, C, device="cuda").to(BF)       # fused add of another producer's gradient, mask as a bit plane
+    za = hip.zero_interleave2x(c, 20, 24, mask_bits=_pack_bits(full_mask), add=other)
+    refa = other.float().clone()
+    refa[:, ::2, ::2] += torch.where(full_mask[:, ::2, ::2].float() > 0, c, torch.zeros_like(c)).float()
+    assert torch.equal(za, refa.to(BF))
+    assert torch.equal(hip.zero_interleave2x(c, 20, 24, add=other)[:, 1::2], other[:, 1::2])
     z = hip.zero_interleave2x(c, 20, 24, mask=full_mask)
     ref = torch.zeros(N, 20, 24, C, device="cuda", dtype=BF)
     ref[:, ::2, ::2] = torch.where(full_mask[:, ::2, ::2].float() > 0, c, torch.zeros_like(c))

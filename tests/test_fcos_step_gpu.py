@@ -288,6 +288,7 @@ def test_premasked_backbone_gradients_bit_identical(monkeypatch):
     prod, orac = make_batch(12, 2, 2, H, W, "cuda")
     digests, calls = [], []
     try:
+        monkeypatch.setenv("UTV2_GRAD_HANDOFF", "0")   # the hand-off (on with premasking only) rounds the stage-output gradient sum once less
         for flag in ("0", "1"):
             monkeypatch.setenv("UTV2_PREMASK", flag)
             torch.manual_seed(0)
@@ -349,7 +350,49 @@ def test_relu_bit_planes_backbone_gradients_bit_identical(monkeypatch):
         ops.set_precision("fp32")
     assert digests[0] == digests[1]
     assert stats[0] == {"planes": 0, "reads": 0}
-    assert stats[1]["planes"] == 3 * 13 and stats[1]["reads"] == 2 * 13 + 10 + 3, stats[1]
+    assert stats[1]["planes"] == 3 * 13 and stats[1]["reads"] == 2 * 13 + 12 + 3, stats[1]
+
+
+def test_stage_output_gradient_handoff(monkeypatch):
+    """The gradient of a backbone stage output has two producers (the FPN lateral's dgrad, the next stage's first block).  By default the
+    lateral parks its part and the block adds it in the kernel that makes its own (utv2_zero_interleave2x_add_nhwc) instead of autograd
+    summing two 16-bit tensors in a pass of its own: the sum is rounded once instead of twice, so the steps agree to 16-bit rounding
+    noise, not to the bit; both hand-offs of the FCOS backbone (res3 -> res4, res4 -> res5) happen and nothing stays parked."""
+    from ubteacher import ops
+    from ubteacher.engine import UBTeacherTrainer
+    cfg = small_fcos_cfg()
+    cfg.SOLVER.AMP.ENABLED = True
+    prod, orac = make_batch(12, 2, 2, H, W, "cuda")
+    states, parks = [], []
+    orig_park = ops.GradHandoff.park
+    try:
+        for flag in ("0", "1"):
+            monkeypatch.setenv("UTV2_GRAD_HANDOFF", flag)
+            n = [0]
+
+            def park(self, g, n=n):
+                ok = orig_park(self, g)
+                n[0] += bool(ok)
+                return ok
+            monkeypatch.setattr(ops.GradHandoff, "park", park)
+            torch.manual_seed(0)
+            tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+            sd_s = tune_state_for_pseudo_labels(cpu_state(tr.model), [d["image"] for d in orac[3]])
+            tr.model.load_state_dict(sd_s)
+            tr.model_teacher.load_state_dict(sd_s)
+            before = tr.model.flat_state().detach().float().clone()
+            tr.iter = 1
+            tr.run_step_full_semisup()      # _backward ends with FanIn.check(): a parked gradient nobody took raises
+            torch.cuda.synchronize()
+            states.append((tr.model.flat_state().detach().float() - before).cpu())
+            parks.append(n[0])
+    finally:
+        ops.set_precision("fp32")
+    assert parks == [0, 2]
+    upd0, upd1 = states
+    assert float(upd0.abs().max()) > 0
+    assert float((upd0 - upd1).abs().max()) <= 2e-2 * float(upd0.abs().max())
+    assert float((upd0 - upd1).norm()) <= 5e-3 * float(upd0.norm())
 
 
 def test_fcos_step_vs_reference_trainer_golden():

@@ -269,6 +269,51 @@ __global__ __launch_bounds__(256) void zero_interleave2x_nhwc_k(const T* __restr
   }
 }
 
+// The same on 16-bit tensors, 8 channels per thread, with the two fusions the stride-2 bottlenecks' backward wants: `add` (optional,
+// [N][H][W][C]) is summed in (the gradient another consumer of the same activation produced: no elementwise add pass in autograd) and
+// the ReLU mask of the even pixels can come as a bit plane (mask_bits, see epilogue_rows).  `add` is NOT masked here: its producer did.
+__global__ __launch_bounds__(256) void zero_interleave2x_add_h16_k(const h16_t* __restrict__ src, const h16_t* __restrict__ mask,
+                                                                  const unsigned char* __restrict__ mask_bits,
+                                                                  const h16_t* __restrict__ add, h16_t* __restrict__ dst, int N, int H,
+                                                                  int W, int TH, int TW, int C8) {
+  const size_t total = (size_t)N * H * W * C8;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    size_t t = i;
+    const int c = (int)(t % C8); t /= C8;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); t /= H;
+    const int n = (int)t;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = 0.f;
+    if (!((h | w) & 1)) {
+      const bf16x8_t sv = *(const bf16x8_t*)(src + (((size_t)(n * TH + (h >> 1)) * TW + (w >> 1)) * C8 + c) * 8);
+      unsigned mb = 0xffu;
+      if (mask_bits) mb = mask_bits[i];
+      else if (mask) {
+        const bf16x8_t mk = *(const bf16x8_t*)(mask + i * 8);
+        mb = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) mb |= ((float)mk[q] > 0.f ? 1u : 0u) << q;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = ((mb >> q) & 1u) ? (float)sv[q] : 0.f;
+    }
+    bf16x8_t o;
+    if (add) {
+      const bf16x8_t a = *(const bf16x8_t*)(add + i * 8);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = (h16_t)(v[q] + (float)a[q]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = (h16_t)v[q];
+    }
+    *(bf16x8_t*)(dst + i * 8) = o;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Image normalisation + CHW -> padded NHWC4 (one_stage_detector.py:88-90 / D2 preprocess_image +
 // ImageList.from_tensors): dst[n,h,w,c] = (src[c,h,w] - mean[c]) / std[c] for h<H,w<W, else 0.
@@ -934,6 +979,18 @@ int utv2_zero_interleave2x_nhwc(const void* src, const void* mask, void* dst, in
     hipLaunchKernelGGL(zero_interleave2x_nhwc_k<float>, g, b, 0, stream, (const float*)src, (const float*)mask, (float*)dst, N, H, W, TH, TW, C / 4);
   else
     return UTV2_EARG;
+  return utv2_launch_status();
+}
+
+// 16-bit tensors, C % 8 == 0: dst = add + (even pixel ? (mask ? src : 0) : 0); mask as a 16-bit tensor OR as a bit plane (uint8 [N][H][W][C / 8]);
+// mask, mask_bits and add are optional
+int utv2_zero_interleave2x_add_nhwc(const void* src, const void* mask, const void* mask_bits, const void* add, void* dst, int N, int H, int W,
+                                    int C, hipStream_t stream) {
+  if (!src || !dst || (C & 7) || (mask && mask_bits)) return UTV2_EARG;
+  const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+  const dim3 g(grid_for((size_t)N * H * W * C / 8, 256, 1 << 16)), b(256);
+  hipLaunchKernelGGL(zero_interleave2x_add_h16_k, g, b, 0, stream, (const h16_t*)src, (const h16_t*)mask, (const unsigned char*)mask_bits,
+                     (const h16_t*)add, (h16_t*)dst, N, H, W, TH, TW, C / 8);
   return utv2_launch_status();
 }
 

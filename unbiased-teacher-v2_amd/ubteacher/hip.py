@@ -294,14 +294,23 @@ def downsample2x_sum(g, out=None, accumulate=False):
     return out
 
 
-def zero_interleave2x(src, H, W, mask=None):
+def zero_interleave2x(src, H, W, mask=None, mask_bits=None, add=None):
     """[N,(H+1)//2,(W+1)//2,C] -> [N,H,W,C] with src on the even pixels and zeros elsewhere; mask (optional, [N,H,W,C], same dtype):
-    the values are zeroed where mask <= 0"""
+    the values are zeroed where mask <= 0 (mask_bits: the same mask as a bit plane); add (optional, [N,H,W,C]): summed in, unmasked"""
     N, TH, TW, C = src.shape
     assert TH == (H + 1) // 2 and TW == (W + 1) // 2
     out = torch.empty((N, H, W, C), dtype=src.dtype, device=src.device)
     if mask is not None:
         assert mask.dtype == src.dtype and tuple(mask.shape) == (N, H, W, C)
+    if src.dtype == h16_dtype() and C % 8 == 0 and (mask_bits is not None or add is not None or mask is not None):
+        if add is not None:
+            assert add.dtype == src.dtype and tuple(add.shape) == (N, H, W, C) and add.is_contiguous()
+        if mask_bits is not None:
+            mask = None
+            _bits_ok(mask_bits, out.shape)
+        call("utv2_zero_interleave2x_add_nhwc", _p(src), _p(mask), _p(mask_bits), _p(add), _p(out), N, H, W, C, _stream())
+        return out
+    assert mask_bits is None and add is None, "bit-plane mask / fused add: 16-bit tensors with C % 8 == 0"
     call("utv2_zero_interleave2x_nhwc", _p(src), _p(mask), _p(out), N, H, W, C, _dt(src), _stream())
     return out
 

@@ -374,6 +374,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.meta = meta
         ctx.has_res = residual is not None
         ctx.x_bits = _bits_of(x) if (layer.premask_input and meta is None) else None   # x: a fused bottleneck's ReLU output
+        ctx.handoff = getattr(x, "_utv2_handoff", None) if (layer.premask_input and meta is None and grad_handoff_on()) else None
         if GRAD_SYNC[0] is not None:
             GRAD_SYNC[0].on_forward(_sync_handles(layer, cs))
         ctx.save_for_backward(x, y if (layer.relu or cs is not None) else None)
@@ -492,6 +493,8 @@ class _ConvFn(torch.autograd.Function):
                         dx = hip.relu_bwd_scale(dx, x4, None)
                 if meta is not None:
                     dx = dx.view(x.shape)
+                elif ctx.handoff is not None and pm is not None and dx.dtype == hip.h16_dtype() and ctx.handoff.park(dx):
+                    dx = None    # the next stage's first block adds it where it makes its own gradient of x (GradHandoff)
             if layer.use_bf16_wgrad():
                 n_, h_, w_, _ = x4.shape
                 ri = hip.rowinfo_nhwc(n_, h_, w_, g4.shape[1], g4.shape[2], layer.stride, layer.pad, layer.k, layer.k, x.device)
@@ -529,6 +532,38 @@ def _dgrad16(layer, g4, in_shape, mask=None, residual=None, post_mask=None, mask
     return hip.conv2d_dgrad_bf16(g4, layer.wt16(layer.bn.scale), tuple(in_shape), layer.stride, layer.pad, layer.k, layer.k,
                                  out_dtype=hip.h16_dtype(), mask=mask, residual=residual, post_mask=post_mask, mask_bits=mask_bits,
                                  post_mask_bits=post_mask_bits)
+
+
+class GradHandoff:
+    """Gradient fan-in of a backbone stage output without autograd's add pass: the activation feeds the next stage's first block and the
+    FPN lateral; the lateral was built later, so its backward runs first - it parks its (already masked) input gradient here and reports
+    none, and the block adds it where it makes its own input gradient (the zero-interleave of a stride-2 block, a dgrad epilogue's
+    residual otherwise).  Either side falls back to the plain path when the other has not / has already run; FanIn.check() after
+    backward() fails loudly if a parked gradient was never picked up.  UTV2_GRAD_HANDOFF=0: autograd sums (A/B; the sum is the same
+    one rounding later: the parked 16-bit gradient is added in fp32 before the block's gradient is rounded)."""
+    _live = []
+
+    def __init__(self):
+        self.grad = None
+        self.closed = False
+        if len(GradHandoff._live) >= 64:
+            del GradHandoff._live[:32]
+        GradHandoff._live.append(self)
+
+    def park(self, g):
+        if self.closed or self.grad is not None:
+            return False
+        self.grad = g
+        return True
+
+    def take(self):
+        self.closed = True
+        g, self.grad = self.grad, None
+        return g
+
+
+def grad_handoff_on():
+    return premask_on() and os.environ.get("UTV2_GRAD_HANDOFF", "1") != "0"
 
 
 def relu_bits_on():
@@ -573,6 +608,9 @@ class _BottleneckFn(torch.autograd.Function):
         y2 = c2._forward(y1, None, None, None, None, relu_bits=b2)
         y3 = c3._forward(y2, res, None, None, None, relu_bits=b3)
         ctx.block = block
+        ctx.handoff = None
+        if ctx.needs_input_grad[0] and grad_handoff_on() and getattr(x, "_utv2_handoff", None) is None:
+            ctx.handoff = x._utv2_handoff = GradHandoff()   # a premasked consumer of x built later (FPN lateral) parks its gradient here
         ctx.bits = (_bits_of(x), b1, b2)
         if b3 is not None:
             y3._utv2_relu_bits = (y3.data_ptr(), y3._version, b3)    # for whoever back-propagates into this ReLU output
@@ -606,14 +644,21 @@ class _BottleneckFn(torch.autograd.Function):
             _wgrad16(cs, x, gm)
         dx = None
         if ctx.needs_input_grad[0]:
+            parked = ctx.handoff.take() if ctx.handoff is not None else None   # the FPN lateral's gradient of x (masked by x > 0 there)
+            if parked is not None and (parked.dtype != hip.h16_dtype() or tuple(parked.shape) != tuple(x.shape)):
+                raise RuntimeError("GradHandoff: parked gradient of another shape / type")
             if cs is None:
                 dx = _dgrad16(c1, g1, x.shape, residual=gm, post_mask=pm, post_mask_bits=bx)   # identity branch added in the epilogue
+                if parked is not None:
+                    dx = dx + parked
             elif c1.stride == 2:
                 c = hip.conv2d_fwd_bf16(gm, cs.wt16(cs.bn.scale), out_dtype=hip.h16_dtype())       # compact grids: only the
                 c = hip.conv2d_fwd_bf16(g1, c1.wt16(c1.bn.scale), residual=c, out_dtype=hip.h16_dtype())   # even pixels get gradient
-                dx = hip.zero_interleave2x(c, x.shape[1], x.shape[2], mask=pm)
+                dx = hip.zero_interleave2x(c, x.shape[1], x.shape[2], mask=pm if bx is None else None, mask_bits=bx if pm is not None else None,
+                                           add=parked)
+                BITS_STATS["reads"] += (bx is not None and pm is not None)
             else:
-                d = _dgrad16(cs, gm, x.shape)
+                d = _dgrad16(cs, gm, x.shape, residual=parked)
                 dx = _dgrad16(c1, g1, x.shape, residual=d, post_mask=pm, post_mask_bits=bx)
         if GRAD_SYNC[0] is not None:
             for l in (c3, c2, c1, cs):
@@ -927,6 +972,10 @@ class FanIn:
         for f in live:
             if f.buf is not None:
                 raise RuntimeError("FanIn: a RoIAlign gradient was stored but the RPN dgrad that adds it never ran")
+        parked, GradHandoff._live = GradHandoff._live, []
+        for h in parked:
+            if h.grad is not None:
+                raise RuntimeError("GradHandoff: a lateral's input gradient was parked but the block that adds it never ran")
 
 
 def fanin_enabled():
