@@ -10,7 +10,8 @@
  *   - the last argument is the hipStream_t to launch on; nothing synchronises the stream,
  *     nothing allocates; scratch memory is passed in (size from the *_workspace_* twin);
  *   - return 0 on success, -(hipError_t) on a launch failure, -1000 on a bad argument.
- *   - re-entrant; no global state.
+ *   - re-entrant; no mutable global state (the A/B environment switches and two one-time kernel attributes are read / set once per
+ *     process, thread-safely, and never change a result).
  */
 #ifndef UTV2_H
 #define UTV2_H

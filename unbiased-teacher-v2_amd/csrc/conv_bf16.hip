@@ -14,6 +14,7 @@
 // BK = 32: a row of the LDS tile is 32 bf16 = 64 B (+16 B pad -> the same conflict-free 80-byte
 // stride); each thread stages 8 consecutive k of a row (two 16-byte global loads -> one
 // ds_write_b128); each MFMA reads one ds_read_b128 per operand fragment.
+#include <mutex>
 #include <stdlib.h>
 #include "common.h"
 #include <type_traits>
@@ -1182,14 +1183,14 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
         ConvArgs16 m = a;
         m.M = main_tiles == tiles_all ? a.M : main_m * 256;
         const int smem = 2 * (256 + 256) * 128;
-        static bool attr_done = false;
-        if (!attr_done) {
-          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_w8<ML, h16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_w8<ML, float>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_pp<ML, h16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_pp<ML, float>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-          attr_done = true;
-        }
+        static std::once_flag attr_once;   // one-time function attribute (thread-safe; the only write-once state of this entry)
+        std::call_once(attr_once, [] {
+          constexpr int smem_ = 2 * (256 + 256) * 128;
+          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_w8<ML, h16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);
+          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_w8<ML, float>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);
+          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_pp<ML, h16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);
+          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_pp<ML, float>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);
+        });
         if (g_use_pp) {
           if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, h16_t>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
           else hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, float>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
@@ -2132,11 +2133,10 @@ static int wgrad_bf16_impl(const void* x, int x_dtype, int x_pitch, const void* 
     a.debug = g_wgrad_debug;
     const size_t n = (size_t)K * a.Kred;
     const int smem = 2 * 2 * WGRAD_W8_BP * 512;
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_w8, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-      attr_done = true;
-    }
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_w8, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * WGRAD_W8_BP * 512);
+    });
     hipLaunchKernelGGL(conv_wgrad_bf16_w8, dim3(wgrad16_w8_budget()), dim3(512), smem, stream, a);
     int rb = cdiv((int64_t)n / 4, 256);
     if (rb > 8192) rb = 8192;
