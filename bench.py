@@ -314,8 +314,12 @@ def cpu_baseline_run(model_kind, label, unlabel, warmup, steps, dump=None):
         g = torch.Generator().manual_seed(99)
         R = 3 * sum(-(-800 // s) * -(-1344 // s) for s in (4, 8, 16, 32, 64))
 
+        roi_log = []    # (proposals, gts, keys) per image of the FIRST step, in call order: the parity run replays them
+
         def roi_k(nprop, ngt):
-            return torch.rand(nprop + ngt, generator=g)
+            k = torch.rand(nprop + ngt, generator=g)
+            roi_log.append((int(nprop), int(ngt), k))
+            return k
         keys = dict(rpn_sup=torch.rand(2 * label, R, generator=g), rpn_unsup=torch.rand(unlabel, R, generator=g),
                     roi_sup=[roi_k] * (2 * label), roi_unsup=[roi_k] * unlabel)
     init = (student, teacher)
@@ -338,8 +342,11 @@ def cpu_baseline_run(model_kind, label, unlabel, warmup, steps, dump=None):
         if it == 0:
             first, pseudo_n = rec, npseudo
             if dump:
-                torch.save({"student": init[0], "teacher": init[1], "batch": batch, "record": rec, "pseudo": npseudo,
-                            "keep_rate": S.EMA_KEEP_RATE}, dump)
+                extra = {}
+                if model_kind != "fcos":
+                    extra = {"rpn_keys": (keys["rpn_sup"], keys["rpn_unsup"]), "roi_keys": list(roi_log), "label": label, "unlabel": unlabel}
+                torch.save(dict({"student": init[0], "teacher": init[1], "batch": batch, "record": rec, "pseudo": npseudo,
+                                 "keep_rate": S.EMA_KEEP_RATE, "model": model_kind}, **extra), dump)
         if it >= warmup:
             times.append(dt)
             for k, v in ph.items():
@@ -381,11 +388,12 @@ def parity_fullsize(dump, device_index):
     first oracle step on: per-loss relative deviation of the two record_dicts (north-star tolerance 1e-3).  Every 256-tile / ping-pong /
     multi-round top-k / 1000-candidate NMS path that the 96x128 parity tests cannot reach is exercised here at benchmark resolution."""
     from ubteacher.d2.structures import Boxes, Instances
-    from ubteacher.engine import UBTeacherTrainer
+    from ubteacher.engine import UBRCNNTeacherTrainer, UBTeacherTrainer
     from ubteacher.presets import get_config
     from ubteacher import ops
     os.environ.pop("UTV2_PRECISION", None)    # exact-f32 mode (SOLVER.AMP.ENABLED False), whatever 16-bit type the headline ran in
     d = torch.load(dump, weights_only=False)
+    kind = d.get("model", "fcos")
     lq, lk, uq, uk = d["batch"]
     dev = "cuda:%d" % device_index
 
@@ -408,26 +416,65 @@ def parity_fullsize(dump, device_index):
 
         def __next__(self):
             return tuple([dict(x) for x in part] for part in batch)
-    cfg = get_config("fcos", 1, ["SOLVER.IMG_PER_BATCH_LABEL", len(lq), "SOLVER.IMG_PER_BATCH_UNLABEL", len(uq), "SEMISUPNET.BURN_UP_STEP", 0,
-                                 "SOLVER.AMP.ENABLED", False, "MODEL.DEVICE", dev])
+    cfg = get_config(kind, 1, ["SOLVER.IMG_PER_BATCH_LABEL", len(lq), "SOLVER.IMG_PER_BATCH_UNLABEL", len(uq), "SEMISUPNET.BURN_UP_STEP", 0,
+                               "SOLVER.AMP.ENABLED", False, "MODEL.DEVICE", dev])
     torch.manual_seed(0)
-    tr = UBTeacherTrainer(cfg, data_loader=Fixed())
+    tr = (UBTeacherTrainer if kind == "fcos" else UBRCNNTeacherTrainer)(cfg, data_loader=Fixed())
     tr.model.load_state_dict(d["student"]); tr.model_teacher.load_state_dict(d["teacher"])
     tr.model.store.touch(); tr.model_teacher.store.touch(); ops.bump_version()
     tr.iter = 1
     tr.log_period = 10 ** 9
-    tr.run_step_full_semisup()
-    rec = dict(tr.flush_metrics())
-    torch.cuda.synchronize()
-    pc, pr = tr._last_pseudo
     ref = d["record"]
+    if kind == "fcos":
+        tr.run_step_full_semisup()
+        rec = dict(tr.flush_metrics())
+        torch.cuda.synchronize()
+        pc, pr = tr._last_pseudo
+        extra = {"pseudo_boxes": {"oracle": d["pseudo"], "product": {"cls": int(pc["valid"].sum()), "reg": int(pr["valid"].sum())}},
+                 "teacher_better_student_pseudo": {"oracle": ref.get("teacher_better_student_pseudo"),
+                                                   "product": rec.get("teacher_better_student_pseudo")}}
+        tol = {}
+    else:
+        # The oracle's draws replayed: anchor keys per pass as they were; ROI keys per image in its compact (proposals ++ gts) convention,
+        # laid out in the product's (proposal slots, then gt slots) - the proposal counts must agree for that to line up, which is part
+        # of what is being checked.  lr does not enter the record of the first step.
+        post = cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN
+        calls = {"rpn": 0, "roi": 0}
+        nsup = 2 * d["label"]
+
+        def rpn_src(n, m, device):
+            k = d["rpn_keys"][calls["rpn"]]
+            calls["rpn"] += 1
+            assert tuple(k.shape) == (n, m), ("anchor keys", tuple(k.shape), (n, m))
+            return k.to(device)
+
+        def roi_src(n, m, device):
+            first = 0 if calls["roi"] == 0 else nsup
+            calls["roi"] += 1
+            out_k = torch.full((n, m), 0.5)
+            for i in range(n):
+                nprop, ngt, k = d["roi_keys"][first + i]
+                out_k[i, :nprop] = k[:nprop]
+                out_k[i, post:post + ngt] = k[nprop:]
+            return out_k.to(device)
+        tr.model.proposal_generator.sample_keys = rpn_src
+        tr.model.roi_heads.sample_keys = roi_src
+        tr.run_step_full_semisup()
+        rec = dict(tr.flush_metrics())
+        torch.cuda.synchronize()
+        gl = tr._last_pseudo
+        extra = {"pseudo_boxes": {"oracle": d["pseudo"], "product": int(gl["valid"].sum())}, "key_draws_replayed": dict(calls)}
+        # as tests/test_rcnn_step_gpu.py: the two pseudo RPN terms hang on exact-equality / near-tie selections against pseudo boxes
+        # that differ by 1e-5 between the two teachers (loss_rpn_loc_pseudo has weight 0 in the objective, trainer.py:888-890)
+        tol = {"loss_rpn_loc_pseudo": 2e-2, "loss_rpn_cls_pseudo": 5e-3}
     dev_ = {k: abs(rec[k] - v) / max(abs(v), 1e-12) for k, v in ref.items() if k.startswith("loss") and k in rec}
-    out = {"mode": "f32", "images": "%d labeled (weak+strong) + %d unlabeled 1333x800" % (len(lq), len(uq)), "tolerance": 1e-3,
+    out = {"mode": "f32", "model": kind, "images": "%d labeled (weak+strong) + %d unlabeled 1333x800" % (len(lq), len(uq)), "tolerance": 1e-3,
            "rel_dev": dev_, "max_rel_dev": max(dev_.values()) if dev_ else None,
-           "within_tolerance": bool(dev_) and max(dev_.values()) <= 1e-3,
-           "oracle_losses": {k: ref[k] for k in dev_}, "product_losses": {k: rec[k] for k in dev_},
-           "pseudo_boxes": {"oracle": d["pseudo"], "product": {"cls": int(pc["valid"].sum()), "reg": int(pr["valid"].sum())}},
-           "teacher_better_student_pseudo": {"oracle": ref.get("teacher_better_student_pseudo"), "product": rec.get("teacher_better_student_pseudo")}}
+           "within_tolerance": bool(dev_) and all(v <= tol.get(k, 1e-3) for k, v in dev_.items()),
+           "oracle_losses": {k: ref[k] for k in dev_}, "product_losses": {k: rec[k] for k in dev_}}
+    if tol:
+        out["looser_terms"] = tol
+    out.update(extra)
     del tr
     torch.cuda.empty_cache()
     return out
@@ -566,7 +613,9 @@ def worker(args):
             cpu_rec = cpu_baseline("fcos", args.cpu_images, args.cpu_images, args.cpu_warmup, args.cpu_steps, dump=dump)
         if rcnn or not args.no_rcnn:
             # BASELINE configs[0]: Faster-RCNN 2+2, MODEL.DEVICE=cpu, 1 process (a step costs ~2x the FCOS one: fewer repetitions)
-            cpu_rcnn = cpu_baseline("rcnn", 2, 2, 1, 2)
+            if rcnn:
+                dump = os.path.join(tempfile.gettempdir(), "utv2_bench_parity_%d.pt" % os.getpid())
+            cpu_rcnn = cpu_baseline("rcnn", 2, 2, 1, 2, dump=dump if rcnn else None)
         if rcnn:
             cpu_rec = cpu_rcnn
 

@@ -1,6 +1,10 @@
 #!/bin/bash
 # scratch: the GPU job of the moment
 cd /root/repo
-timeout 600 python -m pytest tests/test_conv_bf16_gpu.py -x -q -m gpu -k "tile or big or w8" > gpurun_out/t13.log 2>&1
-tail -3 gpurun_out/t13.log
-bash tools/measure_record.sh r03
+timeout 900 python bench.py --model rcnn --steps 5 --warmup 2 > gpurun_out/rcnn_parity.json 2> gpurun_out/rcnn_parity.err
+python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/rcnn_parity.json").read().strip().splitlines()[-1])
+print(json.dumps(d.get("parity_fullsize"), indent=1)[:3000])
+PY
+tail -5 gpurun_out/rcnn_parity.err
