@@ -29,6 +29,26 @@ outs["n2"] = hip.conv2d_fwd_bf16(xn, wn, stride=1, pad=1, kh=3, kw=3, out_dtype=
 x1 = torch.randn(4, 128, 160, 1024, device="cuda").to(BF)
 w1 = (torch.randn(256, 1024, device="cuda") * 0.03).to(BF)
 outs["p1"] = hip.conv2d_fwd_bf16(x1, w1)
+# the epilogue's plain path with everything it carries: bias, GroupNorm partial sums (level-first tower conv) / scale + bias + ReLU and the
+# ReLU bit plane (NHWC conv)
+bias = torch.randn(256, device="cuda")
+part = hip.gn_part_buffer(P, 256, x.device)
+outs["ml_gn"] = hip.conv2d_ml_fwd_bf16(x, w16, level_hw, N, bias=bias, k=3, pad=1, gn_part=part)
+outs["ml_gn_part"] = part.clone()
+bits = hip.relu_bits_buffer((8, 100, 100, 512), xn.device)
+outs["nb"] = hip.conv2d_fwd_bf16(xn, wn, scale=sc, bias=bi, stride=1, pad=1, relu=True, kh=3, kw=3, relu_bits=bits)
+outs["nb_bits"] = bits.clone()
+# the lean epilogue forms with operands: residual + ReLU (+ bit plane) - a bottleneck's conv3; mask plane - its conv3 / conv2 dgrads;
+# residual + post-mask plane - its conv1 dgrad (3x3 here so that the 256-tile kernels take it too)
+def pack_bits(t):
+    b = (t.float() > 0).reshape(t.shape[:-1] + (t.shape[-1] // 8, 8)).to(torch.int32)
+    return (b << torch.arange(8, device=t.device, dtype=torch.int32)).sum(-1).to(torch.uint8)
+bits1 = hip.relu_bits_buffer((8, 100, 100, 512), xn.device)
+outs["m1"] = hip.conv2d_fwd_bf16(xn, wn, scale=sc, bias=bi, residual=res, stride=1, pad=1, relu=True, kh=3, kw=3, relu_bits=bits1)
+outs["m1_bits"] = bits1.clone()
+mb, pb = pack_bits(msk), pack_bits(res)
+outs["m2"] = hip.conv2d_dgrad_bf16(xn, wn, (8, 100, 100, 512), 1, 1, 3, 3, mask_bits=mb)
+outs["m5"] = hip.conv2d_dgrad_bf16(xn, wn, (8, 100, 100, 512), 1, 1, 3, 3, residual=res, post_mask_bits=pb)
 torch.cuda.synchronize()
 if sys.argv[1] == "save":
     torch.save({k: v.cpu() for k, v in outs.items()}, sys.argv[2])

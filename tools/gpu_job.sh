@@ -1,10 +1,23 @@
 #!/bin/bash
-# scratch: the GPU job of the moment
+# scratch: the GPU job of the moment - previous commit's libraries against the current ones on one box
 cd /root/repo
-timeout 900 python bench.py --model rcnn --steps 5 --warmup 2 > gpurun_out/rcnn_parity.json 2> gpurun_out/rcnn_parity.err
+mkdir -p gpurun_out
+B="--steps 23 --warmup 5 --no-cpu-baseline --no-rcnn --no-f32 --timed-only"
+P=$PWD/unbiased-teacher-v2_amd/lib_prev
+for r in 1 2 3; do
+  UTV2_LIB_DIR=$P timeout 600 python bench.py $B > gpurun_out/ab_L0_${r}.json 2> gpurun_out/ab_err.txt
+  timeout 600 python bench.py $B > gpurun_out/ab_L1_${r}.json 2> gpurun_out/ab_err.txt
+done
+for r in 1 2; do
+  UTV2_LIB_DIR=$P timeout 600 python bench.py $B --model rcnn > gpurun_out/ab_RL0_${r}.json 2> gpurun_out/ab_err.txt
+  timeout 600 python bench.py $B --model rcnn > gpurun_out/ab_RL1_${r}.json 2> gpurun_out/ab_err.txt
+done
 python - <<'PY'
-import json
-d = json.loads(open("gpurun_out/rcnn_parity.json").read().strip().splitlines()[-1])
-print(json.dumps(d.get("parity_fullsize"), indent=1)[:3000])
+import json, glob
+for f in sorted(glob.glob("gpurun_out/ab_L*.json") + glob.glob("gpurun_out/ab_RL*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print(f, d["dtype"], round(d["value"], 2), round(d["ms_per_step"], 3), round(d["roofline"]["frac"], 4))
+    except Exception as e:
+        print(f, "ERR", e)
 PY
-tail -5 gpurun_out/rcnn_parity.err

@@ -104,7 +104,100 @@ struct EpiBits {
   const unsigned char* post_bits;
 };
 
-template <int TN, typename TO = float>
+// One operand combination of epilogue_rows' 16-bit path, fixed at compile time (see the LEAN dispatch there).  Order of operations as in
+// the general path: value = acc * scale + bias; mask plane; + residual; post-mask plane; max(lo) (lo = 0: ReLU, -inf: none); round; store;
+// ReLU bit plane; GroupNorm partial sums.
+template <int TN, bool RES, bool MB, bool PB>
+__device__ __forceinline__ void epilogue_rows_lean(const f32x16 (&acc)[2][TN], float* lds, int lane, h16_t* __restrict__ y,
+                                                   const f32x4 (&sc)[2], const f32x4 (&bi)[2], const h16_t* __restrict__ residual, float lo,
+                                                   int m_base, int co, int M, int K, int LDY, float* __restrict__ gn_part, EpiBits eb) {
+  constexpr int COLS = TN * 32, LD = COLS + 4, CV = COLS / 8, RPI = 64 / CV;
+  const int frow = lane & 31, fh = lane >> 5;
+  const int cv = lane % CV, rsub = lane / CV;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float gs = 0.f, gq = 0.f;
+    bf16x8_t rpre[32 / RPI];   // this pass's residual rows, fetched before the accumulators bounce through LDS: the loads overlap the bounce
+    if constexpr (RES) {
+#pragma unroll
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int m = m_base + i * 32 + it * RPI + rsub;
+        rpre[it] = *(const bf16x8_t*)(residual + (size_t)(m < M ? m : M - 1) * LDY + co);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) lds[((e & 3) + 8 * (e >> 2) + 4 * fh) * LD + j * 32 + frow] = acc[i][j][e];
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed (wave-private patch)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int row = it * RPI + rsub;
+      const int m = m_base + i * 32 + row;
+      const f32x4 a0 = *(const f32x4*)(lds + row * LD + cv * 8), a1 = *(const f32x4*)(lds + row * LD + cv * 8 + 4);
+      const bool in = m < M;
+      const size_t off = (size_t)(in ? m : 0) * LDY + co;
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] = a0[q] * sc[0][q] + bi[0][q];
+        v[4 + q] = a1[q] * sc[1][q] + bi[1][q];
+      }
+      if constexpr (MB) {
+        const unsigned mb = in ? eb.mask_bits[off >> 3] : 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = ((mb >> q) & 1u) ? v[q] : 0.f;
+      }
+      if constexpr (RES) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += (float)rpre[it][q];
+      }
+      if constexpr (PB) {
+        const unsigned pb = in ? eb.post_bits[off >> 3] : 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = ((pb >> q) & 1u) ? v[q] : 0.f;
+      }
+      bf16x8_t o;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = (h16_t)fmaxf(v[q], lo);
+      if (in) {
+        *(bf16x8_t*)(y + off) = o;
+        if (eb.relu_bits) {
+          unsigned b = 0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) b |= ((float)o[q] > 0.f ? 1u : 0u) << q;
+          eb.relu_bits[off >> 3] = (unsigned char)b;
+        }
+        if (gn_part) {
+          float f[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) f[q] = (float)o[q];
+          gs += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+          gq += ((f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3])) + ((f[4] * f[4] + f[5] * f[5]) + (f[6] * f[6] + f[7] * f[7]));
+        }
+      }
+    }
+    if (gn_part) {   // lanes cv, cv + CV, ... hold the row parts of channel group co / 8: fixed-order butterfly, lane rsub == 0 writes
+#pragma unroll
+      for (int d = CV; d < 64; d <<= 1) {
+        gs += __shfl_xor(gs, d, 64);
+        gq += __shfl_xor(gq, d, 64);
+      }
+      const int mb = m_base + i * 32;
+      if (rsub == 0 && mb < M) {
+        float* dst = gn_part + ((size_t)(mb >> 5) * (K >> 3) + (co >> 3)) * 2;
+        dst[0] = gs;
+        dst[1] = gq;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// LEAN_OPS: also instantiate the lean forms with operands (kernels with register headroom; the 128-VGPR kernels keep the plain form only:
+// the extra variants cost them ~75 spills)
+template <int TN, typename TO = float, bool LEAN_OPS = true>
 __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float* lds, int lane, TO* __restrict__ y,
                                               const float* __restrict__ scale, const float* __restrict__ bias,
                                               const TO* __restrict__ residual, int relu, int accumulate, int m_base,
@@ -118,6 +211,8 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
   // ldy (optional): elements between consecutive rows of y / residual / mask / post_mask (0 = K); y may be a column slice of a wider
   // matrix (the operands that share y's shape share its pitch)
   const int LDY = ldy > 0 ? ldy : K;
+  const bool no_plain = (relu & 2) != 0;   // bit 1 of relu (A/B runs, UTV2_EPI_PLAIN=0): keep the general path
+  relu &= 1;
   // mask (optional, y's type and shape): y = mask > 0 ? value : 0, applied before the residual add - the ReLU backward of
   // the layer that produced this conv's input, fused into the dgrad that computes its gradient
   // post_mask (optional, same type and shape): y = post_mask > 0 ? value : 0 AFTER the residual add - the ReLU backward of the layer
@@ -140,6 +235,27 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
     }
   }
   const bool full = cok[NQ - 1] && (K & 7) == 0 && (LDY & 7) == 0;  // keeps the 16-byte accesses 16-byte aligned
+  if constexpr (NQ == 2) {
+    // LEAN paths (wave-uniform choice): 16-bit outputs of a tile that lies inside K whose optional operands are among {residual, mask bit
+    // plane, post-mask bit plane} in one of the combinations the step uses - every forward conv (plain; bottleneck conv3: residual), the
+    // bottleneck dgrads (mask plane; residual + post-mask plane), the FPN / RPN dgrads.  The same arithmetic in the same order as the
+    // general path below (bit-identical outputs, same gn_part reduction tree) with the operand set fixed at compile time: the general
+    // path tests eight runtime flags per stored row, each a taken s_cbranch (measured: +2.1 % FCOS step, +1.8 % Faster-RCNN for the plain form).
+    const bool lean = (K & 7) == 0 && (LDY & 7) == 0 && co_base + COLS <= K && !mask && !post_mask && !accumulate && !no_plain;
+    if (lean) {
+      const float lo = relu ? 0.f : -__builtin_inff();
+      const int mode = (residual ? 1 : 0) | (eb.mask_bits ? 2 : 0) | (eb.post_bits ? 4 : 0);
+#define UTV2_LEAN(R, MB, PB)                                                                                                          \
+  epilogue_rows_lean<TN, R, MB, PB>(acc, lds, lane, (h16_t*)y, sc, bi, (const h16_t*)residual, lo, m_base, co, M, K, LDY, gn_part, eb)
+      if (mode == 0) { UTV2_LEAN(false, false, false); return; }
+      if constexpr (LEAN_OPS) {
+        if (mode == 1) { UTV2_LEAN(true, false, false); return; }
+        if (mode == 2) { UTV2_LEAN(false, true, false); return; }
+        if (mode == 5) { UTV2_LEAN(true, false, true); return; }
+      }
+#undef UTV2_LEAN
+    }
+  }
   // bf16 residual rows are fetched BEFORE the accumulators bounce through LDS: the loads then overlap the bounce instead of
   // sitting, one dependent load after another, between it and the stores
   bf16x8_t rpre[2][32 / RPI];

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
   if ((p.K & 3) == 0) {
     // all MFMAs retired and every wave is past the last barrier of the K loop: the staging LDS is free
     float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
-    epilogue_rows<TN, TO>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
+    epilogue_rows<TN, TO, false>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
                           m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
     return;
   }
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
         if (msk) v = (float)msk[off] > 0.f ? v : 0.f;
         if (res) v += (float)res[off];
         if (p.post_mask) v = (float)((const TO*)p.post_mask)[off] > 0.f ? v : 0.f;
-        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.relu & 1) v = fmaxf(v, 0.f);
         if (p.accumulate) v += (float)yo[off];
         yo[off] = (TO)v;
       }
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
   if ((p.K & 3) == 0) {
     static_assert(sizeof(smem) >= 4 * 32 * ((BN / 2) + 4) * sizeof(float), "epilogue patches must fit the staging LDS");
     float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
-    epilogue_rows<TN, TO>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
+    epilogue_rows<TN, TO, (BK != 32)>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
                           m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
     return;
   }
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
         if (msk) v = (float)msk[off] > 0.f ? v : 0.f;
         if (res) v += (float)res[off];
         if (p.post_mask) v = (float)((const TO*)p.post_mask)[off] > 0.f ? v : 0.f;
-        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.relu & 1) v = fmaxf(v, 0.f);
         if (p.accumulate) v += (float)yo[off];
         yo[off] = (TO)v;
       }
@@ -788,10 +788,11 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_w8(ConvArgs16 p) {
 
   // K % 4 == 0 is guaranteed by the launcher
   float* patch = (float*)smem + wid * (32 * (TN * 32 + 4));
-#pragma unroll
-  for (int half = 0; half < 2; ++half)
-    epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[2 * half], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
-                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
+  // two explicit calls (a loop the optimizer declines to unroll would index the accumulator registers dynamically: scratch)
+  epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[0], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
+                        p.relu, p.accumulate, m0 + wm * 128, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
+  epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[2], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
+                        p.relu, p.accumulate, m0 + wm * 128 + 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1130,10 +1131,11 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
 #endif
 
   float* patch = (float*)smem + wid * (32 * (TN * 32 + 4));
-#pragma unroll
-  for (int half = 0; half < 2; ++half)
-    epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[2 * half], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
-                          p.relu, p.accumulate, m0 + wm * 128 + half * 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
+  // two explicit calls (a loop the optimizer declines to unroll would index the accumulator registers dynamically: scratch)
+  epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[0], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
+                        p.relu, p.accumulate, m0 + wm * 128, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
+  epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[2], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
+                        p.relu, p.accumulate, m0 + wm * 128 + 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
 #ifdef UTV2_PP_TRACE
   if ((blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left: what a successor workgroup on this CU waits for is the wave's end
@@ -1156,6 +1158,7 @@ static int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 static const int g_wgrad_debug = env_int("UTV2_WGRAD_DEBUG", 0);
+static const int g_epi_general = env_int("UTV2_EPI_PLAIN", 1) ? 0 : 2;   // OR-ed into ConvArgs16::relu (see epilogue_rows)
 static const int g_use_pp = env_int("UTV2_PP", 1);  // 256 x 256 forward tile: 1 = ping-pong schedule, 0 = conv_igemm_bf16_w8
 
 template <int BN, bool ML>
@@ -1285,7 +1288,7 @@ static int conv2d_nhwc_fwd_bf16_impl(const void* x, int x_dtype, const void* w16
   a.lt.n = 0;
   a.x = x; a.w = (const h16_t*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = mask; a.post_mask = post_mask;
   a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.K = K; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
-  a.in_dil = in_dil < 1 ? 1 : in_dil; a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.M = N * OH * OW;
+  a.in_dil = in_dil < 1 ? 1 : in_dil; a.relu = (relu ? 1 : 0) | g_epi_general; a.accumulate = accumulate; a.Kred = KH * KW * C; a.M = N * OH * OW;
   a.xs = C; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr; a.rowinfo = (const int2*)rowinfo;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
@@ -1320,7 +1323,7 @@ int utv2_conv2d_ml_fwd_bf16_g(const void* x, int x_dtype, int x_pitch, const voi
   if (!plain && ((int64_t)a.M * x_pitch >= (1ll << 31) || (int64_t)K * KH * KW * C >= (1ll << 31))) return UTV2_EARG;
   a.x = x; a.w = (const h16_t*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad; a.in_dil = 1;
-  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = x_pitch; a.m_begin = 0; a.groups = groups; a.ldy = y_pitch; a.gn_part = gn_part; a.rowinfo = (const int2*)rowinfo;
+  a.relu = (relu ? 1 : 0) | g_epi_general; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = x_pitch; a.m_begin = 0; a.groups = groups; a.ldy = y_pitch; a.gn_part = gn_part; a.rowinfo = (const int2*)rowinfo;
   const bool small = K <= 64 && plain;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   if (small) launch_igemm16<64, true>(a, tiles, x_dtype, y_dtype, stream);
@@ -1338,7 +1341,7 @@ int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y
   a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
   a.x = x; a.w = (const h16_t*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad; a.in_dil = 1;
-  a.relu = relu; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = C; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr; a.rowinfo = nullptr;
+  a.relu = (relu ? 1 : 0) | g_epi_general; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = C; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr; a.rowinfo = nullptr;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   if (small) launch_igemm16<64, true>(a, tiles, x_dtype, y_dtype, stream);
@@ -1361,7 +1364,7 @@ int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int
   a.lt.n = 0;
   a.x = xpad16; a.w = (const h16_t*)w16s; a.y = y; a.scale = scale; a.bias = bias; a.residual = nullptr; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = H + 6; a.W = W + 8; a.C = 32; a.OH = OH; a.OW = OW; a.K = K; a.KH = 7; a.KW = 1; a.stride = 2; a.pad = 0;
-  a.in_dil = 1; a.relu = relu; a.accumulate = 0; a.Kred = 7 * 32; a.M = N * OH * OW; a.xs = 4; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr; a.rowinfo = nullptr;
+  a.in_dil = 1; a.relu = (relu ? 1 : 0) | g_epi_general; a.accumulate = 0; a.Kred = 7 * 32; a.M = N * OH * OW; a.xs = 4; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr; a.rowinfo = nullptr;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   const dim3 g(tiles), b(256);

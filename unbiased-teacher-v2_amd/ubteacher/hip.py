@@ -11,10 +11,11 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libutv2_hip.so")
+_LIB_DIR = os.environ.get("UTV2_LIB_DIR") or os.path.join(os.path.dirname(_HERE), "lib")   # UTV2_LIB_DIR: A/B of two builds on one box
+LIB_PATH = os.path.join(_LIB_DIR, "libutv2_hip.so")
 # two builds of the same sources (csrc/common.h h16_t): the 16-bit float type of the mixed-precision kernels is bfloat16 in the first and
 # IEEE fp16 (the reference's own autocast element type) in the second; the dtype code UTV2_BF16 means "the library's 16-bit type"
-LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(os.path.dirname(_HERE), "lib", "libutv2_hip_f16.so")}
+LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_LIB_DIR, "libutv2_hip_f16.so")}
 H16 = ["bf16"]          # the build every call goes to (ops.set_precision selects it)
 
 
