@@ -564,7 +564,7 @@ def test_batched_weight_flip_equals_per_layer_flip():
 
 def test_big_tile_kernels_bit_identical_across_schedules(tmp_path):
     """The three kernels a deep bf16 conv can run on - the 128 x 128 tile (UTV2_W8=0), the 256 x 256 lock-step tile (UTV2_PP=0) and
-    the 256 x 256 ping-pong tile (default) - accumulate every output element in the same order: bit-identical outputs on a multi-level
+    the 256 x 256 ping-pong tile (one tile per workgroup, UTV2_PP=1, and the default persistent grid) - accumulate every output element in the same order: bit-identical outputs on a multi-level
     tower conv, a 3x3 with mask + residual + ReLU epilogue, an fp32-output conv and a wide 1x1 (tools/check_w8.py; the switches are
     read once per process, hence the subprocesses)."""
     import os
@@ -583,6 +583,6 @@ def test_big_tile_kernels_bit_identical_across_schedules(tmp_path):
     run({"UTV2_W8": "0"}, "save", ref)
     # ... and the epilogue's branch-free plain path (default) stores the same bits as the general one (UTV2_EPI_PLAIN=0), GroupNorm
     # partial sums and ReLU bit planes included
-    for env in ({"UTV2_PP": "0"}, {}, {"UTV2_EPI_PLAIN": "0"}, {"UTV2_EPI_PLAIN": "0", "UTV2_W8": "0"}):
+    for env in ({"UTV2_PP": "0"}, {"UTV2_PP": "1"}, {}, {"UTV2_EPI_PLAIN": "0"}, {"UTV2_EPI_PLAIN": "0", "UTV2_W8": "0"}):
         lines = [ln for ln in run(env, "cmp", ref).splitlines() if ln.strip()]
         assert len(lines) == 12 and all("bit-identical" in ln and "nan" not in ln for ln in lines), lines

@@ -50,6 +50,7 @@ struct ConvArgs16 {
                              // FCOS towers (cls | bbox, two independent 256 -> 256 chains) run as ONE launch per depth this way.
   int ldy;                   // elements between consecutive rows of y / residual / mask / post_mask (>= K: y may be a column slice)
   float* gn_part;            // optional: per (32-row block, 8-channel group) sum / sum of squares of the stored output (see epilogue_rows)
+  int ntiles;                // conv_igemm_bf16_pp as a persistent grid: total tiles (0 = one tile per workgroup)
   EpiBits bits;              // optional ReLU bit planes (see epilogue_rows): written from / read in place of 16-bit sign tensors
   const int2* rowinfo;       // optional: per OUTPUT row m {input pixel index of tap (0,0), (W << 16) | tap-validity mask} - the table the weight
                              // gradient kernels read (utv2_conv2d_wgrad_bf16): the tile prologue then loads its rows' geometry instead of
@@ -849,10 +850,13 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 2, wn = wid & 3;
   const int tilesN = (p.K + BN - 1) / BN;
-  const int nwg = gridDim.x;
+  // p.ntiles > 0: PERSISTENT grid (UTV2_PP=2) - gridDim.x workgroups walk the ntiles tiles round by round (virtual block vb = the block
+  // index a one-tile-per-workgroup launch would have had: same XCD-aware tile order); 0: one tile per workgroup
+  const int nwg = p.ntiles > 0 ? p.ntiles : (int)gridDim.x;
+  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
   int tile;
   {
-    const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int bid = vb, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int mt = tile / tilesN, nt = tile - mt * tilesN;
@@ -1143,6 +1147,8 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
     o[0] = ph_entry; o[1] = clk0; o[2] = ph_loop; o[3] = ph_loop_end; o[4] = __builtin_amdgcn_s_memtime();
   }
 #endif
+  __syncthreads();   // persistent grid: every wave is done with its epilogue patch before the next tile's first DMA pieces land there
+  }
 }
 
 // A/B switches for bench runs and tests, read ONCE per process (never on the launch path): UTV2_W8=0 keeps every forward / dgrad
@@ -1159,7 +1165,8 @@ static int env_int(const char* name, int dflt) {
 }
 static const int g_wgrad_debug = env_int("UTV2_WGRAD_DEBUG", 0);
 static const int g_epi_general = env_int("UTV2_EPI_PLAIN", 1) ? 0 : 2;   // OR-ed into ConvArgs16::relu (see epilogue_rows)
-static const int g_use_pp = env_int("UTV2_PP", 1);  // 256 x 256 forward tile: 1 = ping-pong schedule, 0 = conv_igemm_bf16_w8
+static const int g_use_pp = env_int("UTV2_PP", 2);  // 256 x 256 forward tile: 2 = ping-pong schedule on a persistent grid of 256 workgroups,
+                                                    // 1 = ping-pong, one tile per workgroup, 0 = conv_igemm_bf16_w8 (lock-step)
 
 template <int BN, bool ML>
 static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dtype, hipStream_t stream) {
@@ -1195,8 +1202,10 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
           (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_pp<ML, float>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);
         });
         if (g_use_pp) {
-          if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, h16_t>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
-          else hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, float>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
+          int grid = main_m * tilesN;
+          if (g_use_pp == 2 && grid > 256) { m.ntiles = grid; grid = 256; }
+          if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, h16_t>), dim3(grid), dim3(512), smem, stream, m);
+          else hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, float>), dim3(grid), dim3(512), smem, stream, m);
         } else if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_w8<ML, h16_t>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
         else hipLaunchKernelGGL((conv_igemm_bf16_w8<ML, float>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
         if (m.M == a.M) return;
@@ -1284,6 +1293,7 @@ static int conv2d_nhwc_fwd_bf16_impl(const void* x, int x_dtype, const void* w16
                                      const int* rowinfo, EpiBits bits, hipStream_t stream) {
   if (!x || !w16 || !y || (C % 8) || bad_dtype(x_dtype) || bad_dtype(y_dtype) || (rowinfo && in_dil > 1)) return UTV2_EARG;
   ConvArgs16 a;
+  a.ntiles = 0;
   a.bits = bits;
   a.lt.n = 0;
   a.x = x; a.w = (const h16_t*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = mask; a.post_mask = post_mask;
@@ -1318,6 +1328,7 @@ int utv2_conv2d_ml_fwd_bf16_g(const void* x, int x_dtype, int x_pitch, const voi
                  (groups > 1 && (K / groups) % 128)))
     return UTV2_EARG;
   ConvArgs16 a;
+  a.ntiles = 0;
   a.bits = EpiBits{nullptr, nullptr, nullptr};
   a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
   if (!plain && ((int64_t)a.M * x_pitch >= (1ll << 31) || (int64_t)K * KH * KW * C >= (1ll << 31))) return UTV2_EARG;
@@ -1337,6 +1348,7 @@ int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y
   if (!x || !w16 || !y || nlev < 1 || nlev > CONV_MAX_LEVELS || (C % 8) || N <= 0 || bad_dtype(x_dtype) || bad_dtype(y_dtype))
     return UTV2_EARG;
   ConvArgs16 a;
+  a.ntiles = 0;
   a.bits = EpiBits{nullptr, nullptr, nullptr};
   a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
   a.x = x; a.w = (const h16_t*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
@@ -1360,6 +1372,7 @@ int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int
       OW != (W + 6 - 7) / 2 + 1 || (int64_t)N * (H + 6) * (W + 8) * 4 >= (1ll << 31))
     return UTV2_EARG;
   ConvArgs16 a;
+  a.ntiles = 0;
   a.bits = EpiBits{nullptr, nullptr, nullptr};
   a.lt.n = 0;
   a.x = xpad16; a.w = (const h16_t*)w16s; a.y = y; a.scale = scale; a.bias = bias; a.residual = nullptr; a.mask = nullptr; a.post_mask = nullptr;
