@@ -1,6 +1,5 @@
 #!/bin/bash
 # scratch: the GPU job of the moment
 cd /root/repo
-mkdir -p gpurun_out
-timeout 2400 python -m pytest tests/test_conv_bf16_gpu.py tests/test_conv_ml_gpu.py tests/test_fcos_step_gpu.py tests/test_rcnn_step_gpu.py -x -q -m gpu > gpurun_out/t15.log 2>&1
-tail -5 gpurun_out/t15.log
+bash tools/measure_record.sh r03 > gpurun_out/measure.log 2>&1
+tail -c 300 gpurun_out/r03_bench_f16.json
