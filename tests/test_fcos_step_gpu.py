@@ -353,6 +353,41 @@ def test_relu_bit_planes_backbone_gradients_bit_identical(monkeypatch):
     assert stats[1]["planes"] == 3 * 13 and stats[1]["reads"] == 2 * 13 + 12 + 3, stats[1]
 
 
+def test_weight_gradient_lanes_bit_identical(monkeypatch):
+    """The weight gradients are spread over UTV2_WGRAD_LANES side streams (default 2), a layer always on the same one: the step is the
+    same to the bit on 1, 2 and 3 lanes (every layer's launches keep their order, the split-K workspaces are per stream)."""
+    import hashlib
+    from ubteacher import ops
+    from ubteacher.engine import UBTeacherTrainer
+    cfg = small_fcos_cfg()
+    cfg.SOLVER.AMP.ENABLED = True
+    prod, orac = make_batch(12, 2, 2, H, W, "cuda")
+    digests = []
+    try:
+        for lanes in ("1", "2", "3"):
+            monkeypatch.setenv("UTV2_WGRAD_LANES", lanes)
+            ops._WGRAD["streams"].clear(); ops._WGRAD["lane_of"].clear(); ops._WGRAD["next"] = 0
+            torch.manual_seed(0)
+            tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+            sd_s = tune_state_for_pseudo_labels(cpu_state(tr.model), [d["image"] for d in orac[3]])
+            tr.model.load_state_dict(sd_s)
+            tr.model_teacher.load_state_dict(sd_s)
+            tr.iter = 1
+            for _ in range(2):
+                tr.run_step_full_semisup()
+                tr.iter += 1
+            torch.cuda.synchronize()
+            assert len(ops._WGRAD["streams"][torch.device("cuda", torch.cuda.current_device())]) == int(lanes)
+            assert len(set(ops._WGRAD["lane_of"].values())) == (int(lanes) if int(lanes) > 1 else 0)
+            state = tr.model.flat_state().detach().float().cpu().numpy()
+            assert np.isfinite(state).all()
+            digests.append(hashlib.sha1(state.tobytes()).hexdigest())
+    finally:
+        ops._WGRAD["streams"].clear(); ops._WGRAD["lane_of"].clear(); ops._WGRAD["next"] = 0
+        ops.set_precision("fp32")
+    assert digests[0] == digests[1] == digests[2]
+
+
 def test_stage_output_gradient_handoff(monkeypatch):
     """The gradient of a backbone stage output has two producers (the FPN lateral's dgrad, the next stage's first block).  By default the
     lateral parks its part and the block adds it in the kernel that makes its own (utv2_zero_interleave2x_add_nhwc) instead of autograd

@@ -46,20 +46,44 @@ GRAD_SYNC = [None]  # utils.grad_sync.GradBuckets when data parallel: backward-o
 # the backbone's res4 / res5 layers fill 40-80 % of the chip per launch in either direction.  The arguments are recorded on the side
 # stream (the caching allocator must not hand their blocks out again while it still reads them); `join_wgrad_stream()` makes the main
 # stream wait (before the optimizer step / before a gradient bucket is all-reduced).
-_WGRAD = {"on": False, "streams": {}, "pending": set()}
+_WGRAD = {"on": False, "streams": {}, "pending": set(), "lane_of": {}, "next": 0}
+
+
+def wgrad_lanes():
+    """Side streams the weight gradients are spread over (UTV2_WGRAD_LANES, default 2).  One lane leaves the END of the backward to a
+    serial chain of weight-gradient launches that each fill a fraction of the chip (the res3 layers: 9 tiles x splits of a 4-wave
+    kernel) - 0.75 ms per step with the main stream already done; a layer always uses the SAME lane (its launches accumulate into one
+    gradient: order kept, results bit-identical), consecutive layers of the backward alternate."""
+    try:
+        return max(1, min(4, int(os.environ.get("UTV2_WGRAD_LANES", "2"))))
+    except ValueError:
+        return 2
 
 
 def wgrad_side_stream(on):
     _WGRAD["on"] = bool(on) and os.environ.get("UTV2_WGRAD_STREAM", "1") != "0"
 
 
-def _wgrad_launch(fn, *tensors):
+def _lanes(dev):
+    lanes = _WGRAD["streams"].get(dev)
+    if lanes is None:
+        lanes = _WGRAD["streams"][dev] = [torch.cuda.Stream(dev) for _ in range(wgrad_lanes())]
+    return lanes
+
+
+def _wgrad_launch(fn, *tensors, key=None):
+    """key: the layer whose gradient `fn` accumulates into (lane choice; None: lane 0)"""
     dev = tensors[0].device
     if not _WGRAD["on"] or dev.type != "cuda":
         return fn()
-    side = _WGRAD["streams"].get(dev)
-    if side is None:
-        side = _WGRAD["streams"][dev] = torch.cuda.Stream(dev)
+    lanes = _lanes(dev)
+    lane = 0
+    if key is not None and len(lanes) > 1:
+        lane = _WGRAD["lane_of"].get(id(key))
+        if lane is None:
+            lane = _WGRAD["lane_of"][id(key)] = _WGRAD["next"] % len(lanes)
+            _WGRAD["next"] += 1
+    side = lanes[lane]
     side.wait_stream(torch.cuda.current_stream(dev))   # the operands (and the zeroed gradient arena) are ready
     with torch.cuda.stream(side):
         fn()
@@ -70,21 +94,26 @@ def _wgrad_launch(fn, *tensors):
 
 
 def wgrad_stream_behind_main(dev):
-    """the wgrad side stream of `dev`, made to wait for everything the main stream has enqueued so far - or None when the weight
-    gradients are not on a side stream.  A consumer of parameter gradients that runs on its own stream (a bucket all-reduce) is issued
-    from this stream: it then waits for the gradient kernels of BOTH streams while the main stream's dgrad chain keeps running."""
+    """the first wgrad side stream of `dev`, made to wait for everything the main stream and the other lanes have enqueued so far - or
+    None when the weight gradients are not on side streams.  A consumer of parameter gradients that runs on its own stream (a bucket
+    all-reduce) is issued from this stream: it then waits for the gradient kernels of ALL streams while the main stream's dgrad chain
+    keeps running."""
     if not _WGRAD["on"] or dev.type != "cuda":
         return None
-    side = _WGRAD["streams"].get(dev)
-    if side is None:
+    lanes = _WGRAD["streams"].get(dev)
+    if lanes is None:
         return None
+    side = lanes[0]
     side.wait_stream(torch.cuda.current_stream(dev))
+    for other in lanes[1:]:
+        side.wait_stream(other)
     return side
 
 
 def join_wgrad_stream():
     for dev in list(_WGRAD["pending"]):
-        torch.cuda.current_stream(dev).wait_stream(_WGRAD["streams"][dev])
+        for side in _WGRAD["streams"][dev]:
+            torch.cuda.current_stream(dev).wait_stream(side)
     _WGRAD["pending"].clear()
 
 
@@ -452,15 +481,15 @@ class _ConvFn(torch.autograd.Function):
                 _wgrad_launch(lambda: hip.conv2d_wgrad_bf16(
                     x, gw, layer.w.g, hip.rowinfo_ml(meta.N, meta.level_hw, layer.pad, layer.k, x.device), layer.cin, layer.k, layer.k,
                     accumulate=True, db=layer.bias.g if (layer.bias is not None and not layer.bias_grad_from_gn()) else None, rowscale=wsc,
-                    groups=G, x_pitch=x.stride(0)), x, gw)
+                    groups=G, x_pitch=x.stride(0)), x, gw, key=layer)
                 bias_done = True
             elif G > 1:
                 for gi in range(G):
                     xg, gg = x[:, gi * layer.cin:(gi + 1) * layer.cin].contiguous(), g[:, gi * Kg:(gi + 1) * Kg].contiguous()
                     _wgrad_launch(lambda xg=xg, gg=gg, gi=gi: hip.conv2d_ml_wgrad(xg, gg, layer.w.g[gi * Kg:(gi + 1) * Kg], meta.level_hw, meta.N,
-                                                                                   layer.k, layer.pad, accumulate=True), xg, gg)
+                                                                                   layer.k, layer.pad, accumulate=True), xg, gg, key=layer)
             else:
-                _wgrad_launch(lambda: hip.conv2d_ml_wgrad(x, g, layer.w.g, meta.level_hw, meta.N, layer.k, layer.pad, accumulate=True), x, g)
+                _wgrad_launch(lambda: hip.conv2d_ml_wgrad(x, g, layer.w.g, meta.level_hw, meta.N, layer.k, layer.pad, accumulate=True), x, g, key=layer)
         else:
             x4 = x.view(1, x.shape[0], 1, x.shape[1]) if meta is not None else x
             g4 = g.view(1, g.shape[0], 1, g.shape[1]) if meta is not None else g
@@ -500,12 +529,12 @@ class _ConvFn(torch.autograd.Function):
                 ri = hip.rowinfo_nhwc(n_, h_, w_, g4.shape[1], g4.shape[2], layer.stride, layer.pad, layer.k, layer.k, x.device)
                 _wgrad_launch(lambda: hip.conv2d_wgrad_bf16(
                     x4, g4.reshape(-1, layer.cout), layer.w.g, ri, layer.cin, layer.k, layer.k, accumulate=True,
-                    db=layer.bias.g if (layer.bias is not None and not layer.bias_grad_from_gn()) else None, rowscale=wsc), x4, g4)
+                    db=layer.bias.g if (layer.bias is not None and not layer.bias_grad_from_gn()) else None, rowscale=wsc), x4, g4, key=layer)
                 bias_done = True
             else:
-                _wgrad_launch(lambda: hip.conv2d_wgrad(x4, g4, layer.w.g, layer.stride, layer.pad, layer.k, layer.k, accumulate=True), x4, g4)
+                _wgrad_launch(lambda: hip.conv2d_wgrad(x4, g4, layer.w.g, layer.stride, layer.pad, layer.k, layer.k, accumulate=True), x4, g4, key=layer)
         if layer.bias is not None and not bias_done:
-            _wgrad_launch(lambda: hip.colsum(g.view(-1, layer.cout), layer.bias.g, accumulate=True), g)
+            _wgrad_launch(lambda: hip.colsum(g.view(-1, layer.cout), layer.bias.g, accumulate=True), g, key=layer)
         if GRAD_SYNC[0] is not None:
             GRAD_SYNC[0].on_backward_done(_sync_handles(layer, ctx.cs))
         return dx, gres, None, None, None, None, None
@@ -520,7 +549,7 @@ def _wgrad16(layer, x4, g4):
     n_, h_, w_, _ = x4.shape
     ri = hip.rowinfo_nhwc(n_, h_, w_, g4.shape[1], g4.shape[2], layer.stride, layer.pad, layer.k, layer.k, x4.device)
     _wgrad_launch(lambda: hip.conv2d_wgrad_bf16(x4, g4.reshape(-1, layer.cout), layer.w.g, ri, layer.cin, layer.k, layer.k, accumulate=True,
-                                                rowscale=layer.bn.scale), x4, g4)
+                                                rowscale=layer.bn.scale), x4, g4, key=layer)
 
 
 def _dgrad16(layer, g4, in_shape, mask=None, residual=None, post_mask=None, mask_bits=None, post_mask_bits=None):
@@ -799,7 +828,7 @@ class _GNFn(torch.autograd.Function):
         if cs:
             dx, part = dx
             # the few-hundred-row reduction of the per-chunk sums is nobody's dependency before the optimizer: weight-gradient stream
-            _wgrad_launch(lambda: hip.colsum_partials(part, conv.bias.g, accumulate=True), part)
+            _wgrad_launch(lambda: hip.colsum_partials(part, conv.bias.g, accumulate=True), part, key=conv)
         if meta is None:
             dx = dx.view(x.shape)
         if GRAD_SYNC[0] is not None:
