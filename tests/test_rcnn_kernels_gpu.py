@@ -248,6 +248,53 @@ def test_roi_align_bf16_io():
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max() + 1e-6)
 
 
+def test_roi_align_fwd_per_roi_kernel_matches_per_bin_kernel(tmp_path):
+    """utv2_roi_align_fwd runs one workgroup per ROI (tap tables built once per ROI in LDS, 16-byte loads); UTV2_ROI_FWD_PER_ROI=0 keeps
+    the one-wave-per-(roi, bin) kernel: the same formula tap for tap - the compiler contracts the sample coordinate `start + k * bin`
+    into an FMA in one and not in the other, so the outputs agree to the last bits, not always bit for bit: <= 1e-6 of the tensor's scale in
+    fp32, <= one 16-bit rounding step in 16-bit, on ROIs of every level incl. clipped / out-of-image / degenerate / invalid ones (the
+    switch is read once per process: subprocess).  Both are checked against the oracle by test_roi_align_fwd_bwd_vs_oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, torch
+sys.path.insert(0, %r)
+from ubteacher import hip
+g = torch.Generator().manual_seed(77)
+feats32 = [torch.randn(3, h, w, 256, generator=g).to(torch.bfloat16).float().cuda() for h, w in ((100, 168), (50, 84), (25, 42), (13, 21))]
+feats16 = [f.to(torch.bfloat16) for f in feats32]
+R = 3 * 200
+x1 = torch.rand(R, generator=g) * 620 - 20; y1 = torch.rand(R, generator=g) * 380 - 20
+wh = torch.exp(torch.rand(R, 2, generator=g) * 6.5 + 0.5)
+rois = torch.stack((x1, y1, x1 + wh[:, 0], y1 + wh[:, 1]), 1)
+rois[0] = torch.tensor([10.0, 10.0, 10.0, 40.0]); rois[1] = torch.tensor([-300.0, -300.0, 900.0, 700.0]); rois[2] = torch.tensor([650.0, 390.0, 700.0, 420.0])
+rois = rois.cuda()
+batch = (torch.arange(R) // 200).to(torch.int32).cuda()
+valid = (torch.rand(R, generator=g) > 0.1).to(torch.uint8).cuda()
+scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+out = {"f32": hip.roi_align_fwd(feats32, scales, 2, rois, batch, valid, 7).cpu(), "h16": hip.roi_align_fwd(feats16, scales, 2, rois, batch, valid, 7).cpu(),
+       "novalid": hip.roi_align_fwd(feats16, scales, 2, rois, batch, None, 7).cpu(), "p5": hip.roi_align_fwd(feats16, scales, 2, rois, batch, valid, 5).cpu()}
+torch.save(out, sys.argv[1])
+""" % os.path.join(root, "unbiased-teacher-v2_amd")
+    outs = {}
+    for flag in ("0", "1"):
+        path = str(tmp_path / ("roi%s.pt" % flag))
+        e = dict(os.environ); e["UTV2_ROI_FWD_PER_ROI"] = flag
+        r = subprocess.run([sys.executable, "-c", code, path], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[flag] = torch.load(path)
+    for k in outs["0"]:
+        a, b = outs["0"][k].float(), outs["1"][k].float()
+        assert torch.isfinite(b).all() and float(b.abs().max()) > 0
+        scale = float(a.abs().max())
+        tol = 1e-6 * scale if outs["0"][k].dtype == torch.float32 else 2.0 ** -7 * a.abs() + 1e-6 * scale
+        assert bool(((a - b).abs() <= tol).all()), (k, float((a - b).abs().max()))
+        assert float(((a - b) != 0).float().mean()) < 0.01       # and almost everywhere identical
+        assert torch.equal(a == 0, b == 0)                       # invalid / empty ROIs: the same zeros
+
+
 def test_box_iou_and_add_entry_points():
     """utv2_box_iou (D2 pairwise_iou [D2-recall]) against the oracle's restatement, including degenerate and disjoint boxes;
     utv2_add bit-exact against a + b."""

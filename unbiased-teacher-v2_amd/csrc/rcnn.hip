@@ -92,6 +92,11 @@ __global__ __launch_bounds__(256) void match_lowq_kernel(const float* __restrict
   lowq[(size_t)n * P + p] = f;
 }
 
+static bool env_on(const char* name) {   // A/B switches, read once per process: on unless set to "0"
+  const char* v = getenv(name);
+  return !(v && v[0] == '0');
+}
+
 // ---------------------------------------------------------------------------------------------
 // Multi-level RoIAlign, aligned=True, sampling_ratio=0 (torchvision.ops.roi_align via D2 ROIPooler,
 // roi_heads/roi_heads.py:28-45,118 [D2-recall]).  Features NHWC per level, output [R][PH][PW][C].
@@ -269,6 +274,128 @@ __global__ __launch_bounds__(64) void roi_align_kernel(RoiLevels L, const float*
       for (int e = 0; e < 4; ++e) acc[e] /= cnt;
       st4(o, c, acc);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RoIAlign forward, one 256-thread workgroup per ROI (PH, PW <= 7).  roi_align_kernel gives every (roi, bin) its own wave, and every
+// lane of it rebuilds both axes' tap tables in registers (18-entry arrays read through compare / select chains: the kernel was bound by
+// those, 470 us for 150 MB of output with nothing else in flight).  Here 14 threads build the 7 + 7 per-axis tables of the ROI ONCE into
+// LDS (same axis_taps), then each thread takes (bin, 16-byte channel group) items: <= 3 x 3 taps of one 16-byte load each for the ROI
+// sizes the level assignment produces.  Same per-channel arithmetic in the same order as roi_align_kernel (identical up to the FMA
+// contraction of the sample coordinates: tests/test_rcnn_kernels_gpu.py).
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_fwd_roi_kernel(RoiLevels L, const float* __restrict__ rois, const int* __restrict__ roi_batch,
+                                                              const unsigned char* __restrict__ roi_valid, int C, int PH, int PW,
+                                                              T* __restrict__ out) {
+  constexpr int V = 16 / (int)sizeof(T);          // channels per 16-byte access
+  __shared__ float wt[2][7][ROI_MAXT];
+  __shared__ int lo_[2][7], n_[2][7];
+  __shared__ int all_fit;
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const int CQ = C / V, items = PH * PW * CQ;
+  T* o = out + (size_t)r * PH * PW * C;
+  if (roi_valid && roi_valid[r] == 0) {
+    for (int it = tid; it < items; it += 256) {
+      uint4 z = {0, 0, 0, 0};
+      ((uint4*)o)[it] = z;
+    }
+    return;
+  }
+  const float4 b = ((const float4*)rois)[r];
+  const int li = roi_level(b, L);
+  const int H = L.H[li], W = L.W[li];
+  const float sc = L.scale[li];
+  const float x1 = b.x * sc - 0.5f, y1 = b.y * sc - 0.5f, x2 = b.z * sc - 0.5f, y2 = b.w * sc - 0.5f;
+  const float rw = x2 - x1, rh = y2 - y1;
+  const float bw = rw / (float)PW, bh = rh / (float)PH;
+  const int gh = (int)ceilf(rh / (float)PH), gw = (int)ceilf(rw / (float)PW);
+  const float cnt = fmaxf((float)(gh * gw), 1.f);
+  const T* f = (const T*)L.feat[li] + (size_t)roi_batch[r] * H * W * C;
+  if (tid == 0) all_fit = 1;
+  __syncthreads();
+  if (tid < PH + PW) {
+    const bool isx = tid >= PH;
+    const int k = isx ? tid - PH : tid;
+    AxisTaps t;
+    const bool fits = isx ? axis_taps(x1 + k * bw, bw, gw, W, t) : axis_taps(y1 + k * bh, bh, gh, H, t);
+    if (!fits) all_fit = 0;     // benign race: every writer stores 0
+    else {
+      lo_[isx][k] = t.lo;
+      n_[isx][k] = t.n;
+#pragma unroll
+      for (int q = 0; q < ROI_MAXT; ++q) wt[isx][k][q] = t.w[q];
+    }
+  }
+  __syncthreads();
+  if (all_fit) {
+    for (int it = tid; it < items; it += 256) {
+      const int bin = it / CQ, cq = it - bin * CQ;
+      const int ph = bin / PW, pw = bin - ph * PW;
+      float acc[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] = 0.f;
+      const int ylo = lo_[0][ph], yn = n_[0][ph], xlo = lo_[1][pw], xn = n_[1][pw];
+      for (int a = 0; a < yn; ++a) {
+        const float wy = wt[0][ph][a];
+        if (wy == 0.f) continue;
+        for (int bq = 0; bq < xn; ++bq) {
+          const float w = wy * wt[1][pw][bq];
+          if (w == 0.f) continue;
+          const T* src = f + ((size_t)(ylo + a) * W + (xlo + bq)) * C + cq * V;
+          if constexpr (sizeof(T) == 2) {
+            const bf16x8_t v = *(const bf16x8_t*)src;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += w * (float)v[e];
+          } else {
+            const f32x4 v = *(const f32x4*)src;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += w * v[e];
+          }
+        }
+      }
+      if constexpr (sizeof(T) == 2) {
+        bf16x8_t ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = (h16_t)(acc[e] / cnt);
+        *(bf16x8_t*)(o + (size_t)bin * C + cq * V) = ov;
+      } else {
+        f32x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = acc[e] / cnt;
+        *(f32x4*)(o + (size_t)bin * C + cq * V) = ov;
+      }
+    }
+    return;
+  }
+  // a bin wider than ROI_MAXT pixels (never with the D2 level assignment): every sample, four taps each - roi_align_kernel's generic path
+  const int C4 = C >> 2;
+  for (int it = tid; it < PH * PW * C4; it += 256) {
+    const int bin = it / C4, c = it - bin * C4;
+    const int ph = bin / PW, pw = bin - ph * PW;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int iy = 0; iy < gh; ++iy) {
+      const float y = y1 + ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        float x = x1 + pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+        float yy = y;
+        if (yy < -1.f || yy > (float)H || x < -1.f || x > (float)W) continue;
+        if (yy <= 0.f) yy = 0.f;
+        if (x <= 0.f) x = 0.f;
+        int yl = (int)yy, xl = (int)x, yh, xh;
+        if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
+        if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+        const float ly = yy - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+        const f32x4 v1 = ld4(f, ((size_t)yl * W + xl) * C4 + c), v2 = ld4(f, ((size_t)yl * W + xh) * C4 + c);
+        const f32x4 v3 = ld4(f, ((size_t)yh * W + xl) * C4 + c), v4 = ld4(f, ((size_t)yh * W + xh) * C4 + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] /= cnt;
+    st4(o + (size_t)bin * C, c, acc);
   }
 }
 
@@ -983,6 +1110,15 @@ int utv2_roi_align_fwd(int num_levels, int min_level, const void* const* feats_h
       !roi_batch || !out || (dtype != UTV2_F32 && dtype != UTV2_BF16))
     return UTV2_EARG;
   if (R == 0) return UTV2_OK;
+  static const bool per_roi = env_on("UTV2_ROI_FWD_PER_ROI");   // A/B: 0 = one wave per (roi, bin)
+  const int V = dtype == UTV2_BF16 ? 8 : 4;
+  if (per_roi && PH <= 7 && PW <= 7 && C % V == 0) {
+    if (dtype == UTV2_BF16)
+      hipLaunchKernelGGL((roi_align_fwd_roi_kernel<h16_t>), dim3(R), dim3(256), 0, stream, L, rois, roi_batch, roi_valid, C, PH, PW, (h16_t*)out);
+    else
+      hipLaunchKernelGGL((roi_align_fwd_roi_kernel<float>), dim3(R), dim3(256), 0, stream, L, rois, roi_batch, roi_valid, C, PH, PW, (float*)out);
+    return utv2_launch_status();
+  }
   if (dtype == UTV2_BF16)
     hipLaunchKernelGGL((roi_align_kernel<false, h16_t>), dim3(R * PH * PW), dim3(64), 0, stream, L, rois, roi_batch, roi_valid, C, PH,
                        PW, (h16_t*)out);
