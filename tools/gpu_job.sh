@@ -1,5 +1,5 @@
 #!/bin/bash
+# scratch: the GPU job of the moment
 cd /root/repo
-mkdir -p gpurun_out
-timeout 2400 python -m pytest tests/test_rcnn_kernels_gpu.py tests/test_rcnn_step_gpu.py -x -q -m gpu > gpurun_out/t17.log 2>&1
-tail -5 gpurun_out/t17.log
+bash tools/measure_record.sh r03 > gpurun_out/measure.log 2>&1
+tail -c 200 gpurun_out/r03_bench_f16.json
