@@ -29,3 +29,15 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print("enqueue %.2f ms/step, wall %.2f ms/step (host ahead by %.1f ms at the end of %d steps)" % (1e3 * (t1 - t0) / K, 1e3 * (t2 - t0) / K, 1e3 * (t2 - t1), K))
+
+# GPU-side lag of the host at the step boundary: an event recorded right after a step's last launch and one right before the next step's
+# first launch are neighbours in the stream; the time between them is how long the GPU sat at the boundary waiting for the host
+ends, starts = [], []
+for _ in range(K):
+    e0 = torch.cuda.Event(enable_timing=True); e0.record(); starts.append(e0)
+    tr.run_step_full_semisup(); tr.iter += 1
+    e1 = torch.cuda.Event(enable_timing=True); e1.record(); ends.append(e1)
+torch.cuda.synchronize()
+lag = [ends[i].elapsed_time(starts[i + 1]) * 1e3 for i in range(K - 1)]
+step = [starts[i].elapsed_time(ends[i]) for i in range(K)]
+print("GPU time per step %.3f ms; boundary lag (GPU idle until the host's next step arrives): mean %.1f us, max %.1f us" % (sum(step) / K, sum(lag) / len(lag), max(lag)))
