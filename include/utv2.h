@@ -158,6 +158,11 @@ int utv2_relu_bwd_scale(const void* dy, const void* y, const float* scale, void*
 int utv2_add(const float* a, const float* b, float* out, int64_t n, utv2_stream_t stream);
 int utv2_maxpool3x3s2_nhwc(const void* x, int x_dtype, void* y, int y_dtype, int N, int H, int W, int C, int OH, int OW,
                            utv2_stream_t stream);
+/* its backward (a trainable stem, MODEL.BACKBONE.FREEZE_AT < 1; ATen max_pool2d_with_indices_backward): dx = the sum of dpool over the
+ * windows whose FIRST maximum (kh, kw scan order) the pixel is; relu != 0: times (x > 0), the ReLU in front of the pool.  x = the
+ * pool's input (x_dtype); dpool, dx: g_dtype (f32 / f32, 16-bit / 16-bit, 16-bit x with f32 gradients) */
+int utv2_maxpool3x3s2_bwd_nhwc(const void* x, int x_dtype, const void* dpool, void* dx, int g_dtype, int N, int H, int W, int C, int OH,
+                               int OW, int relu, utv2_stream_t stream);
 int utv2_upsample2x_add_nhwc(const void* lateral, const void* top, void* out, int N, int H, int W, int C, int dtype,
                              utv2_stream_t stream);
 int utv2_downsample2x_sum_nhwc(const void* g, void* dtop, int N, int TH, int TW, int C, int accumulate, int dtype,

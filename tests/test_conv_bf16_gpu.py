@@ -586,3 +586,27 @@ def test_big_tile_kernels_bit_identical_across_schedules(tmp_path):
     for env in ({"UTV2_PP": "0"}, {"UTV2_PP": "1"}, {}, {"UTV2_EPI_PLAIN": "0"}, {"UTV2_EPI_PLAIN": "0", "UTV2_W8": "0"}):
         lines = [ln for ln in run(env, "cmp", ref).splitlines() if ln.strip()]
         assert len(lines) == 12 and all("bit-identical" in ln and "nan" not in ln for ln in lines), lines
+
+
+@pytest.mark.parametrize("dt", [torch.float32, BF])
+def test_maxpool_backward_first_maximum_rule(dt):
+    """utv2_maxpool3x3s2_bwd_nhwc (trainable stem): the gradient of ATen's max_pool2d - ties go to the FIRST maximum of a window in scan
+    order, which post-ReLU inputs full of equal zeros exercise - with the ReLU mask of the layer in front fused; odd and even sizes."""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(5)
+    for (N, H, W, C) in ((2, 14, 18, 64), (1, 15, 17, 8), (2, 9, 12, 4)):
+        x = torch.relu(torch.randn(N, H, W, C, generator=g)).mul(4).round().div(4)    # many exact ties, many zeros
+        x = x.to(dt).cuda()
+        xr = x.float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+        y = F.max_pool2d(xr, 3, 2, 1)
+        dy = torch.randn(y.shape, generator=g).to(dt).cuda()
+        y.backward(dy.float())
+        want = (xr.grad * (xr > 0)).permute(0, 2, 3, 1)
+        got = hip.maxpool3x3s2_bwd(x, dy.permute(0, 2, 3, 1).contiguous(), relu=True)
+        assert got.dtype == dt
+        if dt == torch.float32:
+            assert torch.equal(got, want)
+        else:
+            assert float((got.float() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max())
+        raw = hip.maxpool3x3s2_bwd(x, dy.permute(0, 2, 3, 1).contiguous(), relu=False)
+        assert float((raw.float() - xr.grad.permute(0, 2, 3, 1)).abs().max()) <= (0 if dt == torch.float32 else 2.0 ** -7 * float(want.abs().max()))

@@ -452,3 +452,29 @@ def test_rcnn_step_fp32_tight_with_the_product_pseudo_boxes():
         err = float((s_after[k].double() - new_s[k].double()).abs().max())
         upd = float((new_s[k].double() - sd_s[k].double()).abs().max())
         assert err <= 1e-4 * float(new_s[k].abs().max()) + 1e-2 * upd + 1e-12, (k, err, upd)
+
+
+def test_rcnn_step_with_trainable_stem_runs_and_updates_it():
+    """MODEL.BACKBONE.FREEZE_AT 0 through the Faster-RCNN trainer (fp32 and AMP): the step runs, the stem and res2 weights move, nothing
+    is left parked or non-finite (the FCOS trainer's parity test pins the stem's gradient against the oracle)."""
+    from ubteacher import ops
+    from ubteacher.engine import UBRCNNTeacherTrainer
+    try:
+        for amp in (False, True):
+            cfg = rcnn_cfg()
+            cfg.MODEL.BACKBONE.FREEZE_AT = 0
+            cfg.SOLVER.AMP.ENABLED = amp
+            torch.manual_seed(0)
+            prod, orac = make_batch(31, 2, 2, H, W, "cuda")
+            tr = UBRCNNTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+            before = cpu_state(tr.model)
+            tr.iter = 1
+            tr.optimizer.param_groups[0]["lr"] = 0.01
+            tr.run_step_full_semisup()
+            torch.cuda.synchronize()
+            after = cpu_state(tr.model)
+            for k in ("backbone.bottom_up.stem.conv1.weight", "backbone.bottom_up.res2.1.conv1.weight"):
+                d = (after[k] - before[k]).abs()
+                assert torch.isfinite(after[k]).all() and float(d.max()) > 0, k
+    finally:
+        ops.set_precision("fp32")

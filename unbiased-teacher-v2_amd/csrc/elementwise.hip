@@ -169,6 +169,59 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_k(const TI* __restrict_
   }
 }
 
+// Backward of the 3x3 stride-2 pad-1 max pool (a trainable stem, MODEL.BACKBONE.FREEZE_AT < 1) as a GATHER: input pixel (h, w) collects
+// dpool of every window whose arg-max it is - ATen's rule: the FIRST maximum in (kh, kw) scan order (`val > maxval`), so ties (frequent
+// after a ReLU) go to one pixel, deterministically; relu != 0 also applies the mask x > 0 of the ReLU in front of the pool.
+template <typename TX, typename TG>
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_nhwc_k(const TX* __restrict__ x, const TG* __restrict__ dpool, TG* __restrict__ dx, int N,
+                                                             int H, int W, int C4, int OH, int OW, int relu) {
+  const size_t total = (size_t)N * H * W * C4;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    size_t t = i;
+    const int c = (int)(t % C4); t /= C4;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); t /= H;
+    const int n = (int)t;
+    const f32x4 mine = ld4(x, i);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    // windows that contain (h, w): 2 oh - 1 <= h <= 2 oh + 1, i.e. oh = h / 2 (and h / 2 + 1 for odd h)
+    for (int oh = h / 2; oh <= (h + 1) / 2; ++oh) {
+      if (oh >= OH) continue;
+      for (int ow = w / 2; ow <= (w + 1) / 2; ++ow) {
+        if (ow >= OW) continue;
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int arg[4] = {-1, -1, -1, -1};
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+          const int ih = oh * 2 - 1 + dh;
+          if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+          for (int dw = 0; dw < 3; ++dw) {
+            const int iw = ow * 2 - 1 + dw;
+            if ((unsigned)iw >= (unsigned)W) continue;
+            const f32x4 v = ld4(x, ((size_t)(n * H + ih) * W + iw) * C4 + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; arg[e] = dh * 3 + dw; }
+          }
+        }
+        const int me = (h - (oh * 2 - 1)) * 3 + (w - (ow * 2 - 1));
+        const f32x4 d = ld4(dpool, ((size_t)(n * OH + oh) * OW + ow) * C4 + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (arg[e] == me) g[e] += d[e];
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = mine[e] > 0.f ? g[e] : 0.f;
+    }
+    st4(dx, i, g);
+  }
+}
+
 // bf16 -> bf16 form with 8 channels (16 bytes) per thread and 32-bit index arithmetic (max is exact: same result as the generic kernel)
 __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_bf16x8_k(const h16_t* __restrict__ x, h16_t* __restrict__ y, int N, int H, int W,
                                                                 int C8, int OH, int OW) {
@@ -920,6 +973,23 @@ int utv2_add(const float* a, const float* b, float* out, int64_t n, hipStream_t 
 }
 
 // x is `x_dtype`, y is `y_dtype` (the stem conv writes fp32, the bf16 activation pipeline starts here)
+// dx[n][h][w][c] = sum of dpool over the windows whose (first) arg-max pixel (h, w) is; relu: times (x > 0).  x: the pool's INPUT
+// (x_dtype), dpool / dx: g_dtype.
+int utv2_maxpool3x3s2_bwd_nhwc(const void* x, int x_dtype, const void* dpool, void* dx, int g_dtype, int N, int H, int W, int C, int OH,
+                               int OW, int relu, hipStream_t stream) {
+  if (!x || !dpool || !dx || (C & 3)) return UTV2_EARG;
+  const dim3 g(grid_for((size_t)N * H * W * C / 4, 256, 1 << 16)), b(256);
+  if (x_dtype == UTV2_F32 && g_dtype == UTV2_F32)
+    hipLaunchKernelGGL((maxpool3x3s2_bwd_nhwc_k<float, float>), g, b, 0, stream, (const float*)x, (const float*)dpool, (float*)dx, N, H, W, C / 4, OH, OW, relu);
+  else if (x_dtype == UTV2_BF16 && g_dtype == UTV2_BF16)
+    hipLaunchKernelGGL((maxpool3x3s2_bwd_nhwc_k<h16_t, h16_t>), g, b, 0, stream, (const h16_t*)x, (const h16_t*)dpool, (h16_t*)dx, N, H, W, C / 4, OH, OW, relu);
+  else if (x_dtype == UTV2_BF16 && g_dtype == UTV2_F32)
+    hipLaunchKernelGGL((maxpool3x3s2_bwd_nhwc_k<h16_t, float>), g, b, 0, stream, (const h16_t*)x, (const float*)dpool, (float*)dx, N, H, W, C / 4, OH, OW, relu);
+  else
+    return UTV2_EARG;
+  return utv2_launch_status();
+}
+
 int utv2_maxpool3x3s2_nhwc(const void* x, int x_dtype, void* y, int y_dtype, int N, int H, int W, int C, int OH, int OW,
                            hipStream_t stream) {
   if (!x || !y || (C & 3)) return UTV2_EARG;

@@ -271,6 +271,16 @@ def add(a, b, out=None):
     return out
 
 
+def maxpool3x3s2_bwd(x, dpool, relu=True):
+    """gradient of maxpool3x3s2 w.r.t. its input x [N,H,W,C] given dpool [N,OH,OW,C] (first-maximum rule), times (x > 0) when relu"""
+    N, H, W, C = x.shape
+    _, OH, OW, _ = dpool.shape
+    dpool = dpool.contiguous()
+    dx = torch.empty((N, H, W, C), dtype=dpool.dtype, device=x.device)
+    call("utv2_maxpool3x3s2_bwd_nhwc", _p(x), _dt(x), _p(dpool), _p(dx), _dt(dpool), N, H, W, C, OH, OW, int(relu), _stream())
+    return dx
+
+
 def maxpool3x3s2(x, out_dtype=None):
     N, H, W, C = x.shape
     OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1

@@ -138,8 +138,16 @@ class ResNet50:
 
     def __call__(self, x4):
         outs = {}
-        if self.stem.trainable:
-            raise NotImplementedError("MODEL.BACKBONE.FREEZE_AT < 1 (trainable stem) is not built: no shipped config uses it")
+        if self.stem.trainable and torch.is_grad_enabled():
+            # MODEL.BACKBONE.FREEZE_AT < 1: the stem trains (ops._StemFn; the image comes as fp32 NHWC4 in every precision mode)
+            assert x4.dtype == torch.float32 and x4.shape[-1] == 4, "a trainable stem takes the fp32 NHWC4 image"
+            x = ops.stem(self.stem, x4)
+            for name, blocks, trainable in self.stages:
+                for b in blocks:
+                    x = b(x)
+                if name in self.out_features:
+                    outs[name] = x
+            return outs
         # frozen stem + pool run outside autograd; under AMP the bf16 activation pipeline starts at the stem's output
         sc, sh = self.stem.scale_shift()
         if x4.dtype == hip.h16_dtype():  # AMP: 16-bit MFMA stem on the zero-bordered 16-bit image

@@ -45,7 +45,7 @@ class PseudoProposalNetwork(ArenaModel):
         # (x - pixel_mean) / pixel_std + pad to size_divisibility, fused into the NHWC4 conversion.
         # Host copies of mean/std are used (the device buffers only change by EMA rounding).
         x4, image_sizes = hip.preprocess_images(images, self._mean_host, self._std_host, self.backbone.size_divisibility,
-                                                 bf16_stem=ops.amp())
+                                                 bf16_stem=ops.amp() and not self.backbone.bottom_up.stem.trainable)
         self.folder.fold()
         return self.backbone(x4), image_sizes
 

@@ -743,7 +743,7 @@ class TwoStagePseudoLabGeneralizedRCNN(ArenaModel):
         both = list(labeled_inputs) + list(unlabeled_inputs)
         images = [x["image"].to(self.device) for x in both]
         x4, image_sizes = hip.preprocess_images(images, self._mean_host, self._std_host, self.backbone.size_divisibility,
-                                                 bf16_stem=ops.amp())
+                                                 bf16_stem=ops.amp() and not self.backbone.bottom_up.stem.trainable)
         gt_l = self._gt(labeled_inputs)
         self.folder.fold()
         features = self.backbone(x4)
@@ -788,7 +788,7 @@ class TwoStagePseudoLabGeneralizedRCNN(ArenaModel):
             return self.inference(batched_inputs)
         images = [x["image"].to(self.device) for x in batched_inputs]
         x4, image_sizes = hip.preprocess_images(images, self._mean_host, self._std_host, self.backbone.size_divisibility,
-                                                 bf16_stem=ops.amp())
+                                                 bf16_stem=ops.amp() and not self.backbone.bottom_up.stem.trainable)
         gt = self._gt(batched_inputs) if "instances" in batched_inputs[0] else None
         self.folder.fold()
         features = self.backbone(x4)
@@ -812,7 +812,7 @@ class TwoStagePseudoLabGeneralizedRCNN(ArenaModel):
     def inference(self, batched_inputs):
         images = [x["image"].to(self.device) for x in batched_inputs]
         x4, image_sizes = hip.preprocess_images(images, self._mean_host, self._std_host, self.backbone.size_divisibility,
-                                                 bf16_stem=ops.amp())
+                                                 bf16_stem=ops.amp() and not self.backbone.bottom_up.stem.trainable)
         self.folder.fold()
         features = self.backbone(x4)
         proposals, _ = self.proposal_generator(image_sizes, features, None, compute_loss=False)

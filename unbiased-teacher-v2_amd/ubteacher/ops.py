@@ -711,6 +711,44 @@ def bottleneck(block, x):
     return block.conv3(out, residual=sc)
 
 
+class _StemFn(torch.autograd.Function):
+    """A TRAINABLE ResNet stem (MODEL.BACKBONE.FREEZE_AT < 1; D2 BasicStem: 7x7 stride-2 conv + FrozenBN + ReLU + 3x3 stride-2 max pool)
+    on the fp32 NHWC4 image as one autograd node: the backward routes the pooled gradient to the first maximum of every window and
+    through the ReLU in one gather kernel (utv2_maxpool3x3s2_bwd_nhwc), then takes the weight gradient with the exact-f32 kernel (K
+    reduction 7 * 7 * 4 = 196: a small layer; its 16-bit activations are widened once).  The image needs no gradient."""
+
+    @staticmethod
+    def forward(ctx, x4, hk, layer):
+        sc, sh = layer.scale_shift()
+        y = hip.conv2d_stem_fwd(x4, layer.w.t, sc, sh, layer.stride, layer.pad, layer.k, layer.k, True, act_dtype())
+        ctx.layer = layer
+        ctx.save_for_backward(x4, y)
+        if GRAD_SYNC[0] is not None:
+            GRAD_SYNC[0].on_forward(_sync_handles(layer))
+        return hip.maxpool3x3s2(y)
+
+    @staticmethod
+    def backward(ctx, dpool):
+        layer = ctx.layer
+        x4, y = ctx.saved_tensors
+        g = hip.maxpool3x3s2_bwd(y, dpool.contiguous(), relu=True)                 # d(conv * scale + shift), ReLU and pool undone
+        g = g.float() * layer.bn.scale                                              # through the frozen BN's scale
+        K, kred = layer.cout, layer.k * layer.k * layer.cin
+
+        def wgrad():
+            dw = torch.empty((K, kred), dtype=torch.float32, device=g.device)
+            hip.conv2d_wgrad(x4, g, dw, layer.stride, layer.pad, layer.k, layer.k, accumulate=False)
+            layer.w.g.view(K, -1)[:, :kred] += dw                                   # rows are padded to 208 in the arena
+        _wgrad_launch(wgrad, x4, g, key=layer)
+        if GRAD_SYNC[0] is not None:
+            GRAD_SYNC[0].on_backward_done(_sync_handles(layer))
+        return None, None, None
+
+
+def stem(layer, x4):
+    return _StemFn.apply(x4, hook(x4.device), layer)
+
+
 class ColPair:
     """The two column halves of a [P, 2C] matrix (the paired towers' output: cls | bbox) as separate autograd tensors for their two
     consumers, without a cat pass in the backward: each consumer's dgrad writes its half of ONE [P, 2C] gradient buffer (row pitch 2C,
