@@ -1,5 +1,3 @@
 #!/bin/bash
-# scratch: the GPU job of the moment
 cd /root/repo
-bash tools/measure_record.sh r03 > gpurun_out/measure.log 2>&1
-tail -c 200 gpurun_out/r03_bench_f16.json
+timeout 300 python tools/bench_narrowk.py 2>&1 | tail -4
