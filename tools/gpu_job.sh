@@ -1,3 +1,18 @@
 #!/bin/bash
 cd /root/repo
-timeout 300 python tools/bench_narrowk.py 2>&1 | tail -4
+mkdir -p gpurun_out
+B="--steps 23 --warmup 5 --no-cpu-baseline --no-rcnn --no-f32 --timed-only"
+for r in 1 2 3; do
+  for f in 0 256; do
+    UTV2_WGRAD_DEBUG=$f timeout 600 python bench.py $B > gpurun_out/ab_S${f}_${r}.json 2> gpurun_out/ab_err.txt
+  done
+done
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/ab_S*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print(f, d["dtype"], round(d["value"], 2), round(d["ms_per_step"], 3))
+    except Exception as e:
+        print(f, "ERR", e)
+PY

@@ -2156,8 +2156,11 @@ static int wgrad_bf16_impl(const void* x, int x_dtype, int x_pitch, const void* 
     hipLaunchKernelGGL(conv_wgrad_bf16_w8, dim3(wgrad16_w8_budget()), dim3(512), smem, stream, a);
     int rb = cdiv((int64_t)n / 4, 256);
     if (rb > 8192) rb = 8192;
-    hipLaunchKernelGGL(reduce_slabs16_f32, dim3(rb), dim3(256), 0, stream, (const float*)ws, dw, n, a.splits, accumulate, rowscale,
-                       a.Kred);
+    // UTV2_WGRAD_DEBUG & 256 (timing experiments only - the gradients are then WRONG): no slab reduction, to bound what a workspace-free
+    // weight gradient could buy on the step
+    if (!(g_wgrad_debug & 256))
+      hipLaunchKernelGGL(reduce_slabs16_f32, dim3(rb), dim3(256), 0, stream, (const float*)ws, dw, n, a.splits, accumulate, rowscale,
+                         a.Kred);
     if (db) {
       float* part = ws + (size_t)a.splits * n;
       int nb = cdiv(M, 64);
@@ -2184,8 +2187,9 @@ static int wgrad_bf16_impl(const void* x, int x_dtype, int x_pitch, const void* 
   }
   int rb = cdiv((int64_t)n / 4, 256);   // n = K * Kred, both multiples of 8
   if (rb > 8192) rb = 8192;
-  hipLaunchKernelGGL(reduce_slabs16_f32, dim3(rb), dim3(256), 0, stream, (const float*)ws, dw, n, a.splits, accumulate, rowscale,
-                     a.Kred);
+  if (!(g_wgrad_debug & 256))
+    hipLaunchKernelGGL(reduce_slabs16_f32, dim3(rb), dim3(256), 0, stream, (const float*)ws, dw, n, a.splits, accumulate, rowscale,
+                       a.Kred);
   if (db)
     hipLaunchKernelGGL(reduce_slabs16_scalar_f32, dim3(cdiv(K, 256)), dim3(256), 0, stream, (const float*)a.bias_ws, db, (size_t)K,
                        a.splits, accumulate, rowscale);
