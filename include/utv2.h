@@ -282,6 +282,13 @@ int utv2_fcos_decode(const long long* topkeys, int K, const float* logits, const
 int utv2_scale_cols(float* y, int64_t rows, int row_stride, int ncols, const float* s, utv2_stream_t stream);
 int utv2_scale_cols_bwd(float* g, const float* ypost, int64_t rows, int row_stride, int ncols, const float* s, float* dsum,
                         float* ws, utv2_stream_t stream);
+/* the Scale layers of ALL levels of a level-first matrix at once (one launch forward, two backward instead of four per level):
+ * row0_host = host int64[nlev + 1] (first row of each level, then the end), s_host / sgrad_host = host arrays of nlev DEVICE pointers
+ * (the per-level scalar and its gradient, accumulated: sgrad_l += sum(g_in * ypost) / s_l).  nlev <= 8; ws >= nlev * 256 floats */
+int utv2_scale_cols_ml(float* y, int nlev, const int64_t* row0_host, int row_stride, int ncols, const float* const* s_host,
+                       utv2_stream_t stream);
+int utv2_scale_cols_bwd_ml(float* g, const float* ypost, int nlev, const int64_t* row0_host, int row_stride, int ncols,
+                           const float* const* s_host, float* const* sgrad_host, float* ws, utv2_stream_t stream);
 
 /* ---- NMS / IoU: layers/ml_nms.py:27, D2 batched_nms / pairwise_iou ---------------------------- */
 int utv2_nms_mpad(int M);

@@ -576,6 +576,59 @@ __global__ __launch_bounds__(256) void scale_cols_bwd_kernel(float* __restrict__
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
+// The Scale layers of ALL FPN levels of a level-first matrix in one launch (fcos/fcos.py:22-28,306-340: one learnable scalar per level):
+// rows [row0[l], row0[l + 1]) belong to level l; blockIdx.y = level.
+#define SC_MAXL 8
+struct ScaleLevels {
+  long long row0[SC_MAXL + 1];
+  const float* s[SC_MAXL];
+  float* sgrad[SC_MAXL];
+  int nlev;
+};
+
+__global__ __launch_bounds__(256) void scale_cols_ml_kernel(float* __restrict__ y, ScaleLevels L, int BS, int ncols) {
+  const int l = blockIdx.y;
+  float* yl = y + (size_t)L.row0[l] * BS;
+  const size_t total = (size_t)(L.row0[l + 1] - L.row0[l]) * (size_t)ncols;
+  const float k = L.s[l][0];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / ncols;
+    const int c = (int)(i - r * ncols);
+    yl[r * BS + c] *= k;
+  }
+}
+
+// backward: g[:, 0:ncols] *= s_l ; partial[l][b] = sum g_in * y_post over the block's share of level l
+__global__ __launch_bounds__(256) void scale_cols_bwd_ml_kernel(float* __restrict__ g, const float* __restrict__ ypost, ScaleLevels L, int BS,
+                                                              int ncols, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int l = blockIdx.y;
+  float* gl = g + (size_t)L.row0[l] * BS;
+  const float* yl = ypost + (size_t)L.row0[l] * BS;
+  const size_t total = (size_t)(L.row0[l + 1] - L.row0[l]) * (size_t)ncols;
+  const float k = L.s[l][0];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / ncols;
+    const int c = (int)(i - r * ncols);
+    const float gv = gl[r * BS + c];
+    acc += gv * yl[r * BS + c];
+    gl[r * BS + c] = gv * k;
+  }
+  const float t = block_reduce_sum(acc, red);
+  if (threadIdx.x == 0) partial[(size_t)l * gridDim.x + blockIdx.x] = t;
+}
+
+// one block per level: d s_l += (sum of the level's partials, fixed order) / s_l
+__global__ __launch_bounds__(256) void scale_cols_bwd_ml_final(ScaleLevels L, const float* __restrict__ partial, int nb) {
+  __shared__ float red[4];
+  const int l = blockIdx.x;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) acc += partial[(size_t)l * nb + i];
+  const float t = block_reduce_sum(acc, red);
+  if (threadIdx.x == 0) L.sgrad[l][0] += t / L.s[l][0];
+}
+
 static LevelTable make_table(int num_levels, const int* H, const int* W, const int* strides, const float* soi) {
   LevelTable t;
   t.num_levels = num_levels;
@@ -763,6 +816,47 @@ int utv2_scale_cols_bwd(float* g, const float* ypost, int64_t rows, int row_stri
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(scale_cols_bwd_kernel, dim3(nb), dim3(256), 0, stream, g, ypost, (size_t)rows, row_stride, ncols, s, ws);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, nb, 1, dsum);
+  return utv2_launch_status();
+}
+
+static int fill_scale_levels(ScaleLevels& L, int nlev, const int64_t* row0_host, const float* const* s_host, float* const* sgrad_host) {
+  if (nlev < 1 || nlev > SC_MAXL || !row0_host || !s_host) return UTV2_EARG;
+  L.nlev = nlev;
+  for (int l = 0; l <= SC_MAXL; ++l) L.row0[l] = row0_host[l <= nlev ? l : nlev];
+  for (int l = 0; l < SC_MAXL; ++l) {
+    L.s[l] = l < nlev ? s_host[l] : nullptr;
+    L.sgrad[l] = (l < nlev && sgrad_host) ? sgrad_host[l] : nullptr;
+    if (l < nlev && (!L.s[l] || L.row0[l + 1] < L.row0[l])) return UTV2_EARG;
+  }
+  return UTV2_OK;
+}
+
+// y[rows of level l, 0:ncols] *= s_l[0] for every level in ONE launch.  row0_host: host int64[nlev + 1] (first row of each level, then
+// the end); s_host: host array of nlev DEVICE pointers (one scalar each).
+int utv2_scale_cols_ml(float* y, int nlev, const int64_t* row0_host, int row_stride, int ncols, const float* const* s_host,
+                       hipStream_t stream) {
+  ScaleLevels L;
+  if (!y || fill_scale_levels(L, nlev, row0_host, s_host, nullptr) != UTV2_OK) return UTV2_EARG;
+  int64_t most = 0;
+  for (int l = 0; l < nlev; ++l) most = L.row0[l + 1] - L.row0[l] > most ? L.row0[l + 1] - L.row0[l] : most;
+  int gx = cdiv(most * ncols, 256 * 4);
+  if (gx > 1024) gx = 1024;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(scale_cols_ml_kernel, dim3(gx, nlev), dim3(256), 0, stream, y, L, row_stride, ncols);
+  return utv2_launch_status();
+}
+
+// backward of all levels in two launches: g[rows of level l, 0:ncols] *= s_l in place and sgrad_l[0] += sum(g_in * ypost) / s_l
+// (sgrad_host: host array of nlev device pointers into the gradient arena).  ws >= nlev * 256 floats.
+int utv2_scale_cols_bwd_ml(float* g, const float* ypost, int nlev, const int64_t* row0_host, int row_stride, int ncols,
+                           const float* const* s_host, float* const* sgrad_host, float* ws, hipStream_t stream) {
+  ScaleLevels L;
+  if (!g || !ypost || !ws || !sgrad_host || fill_scale_levels(L, nlev, row0_host, s_host, sgrad_host) != UTV2_OK) return UTV2_EARG;
+  for (int l = 0; l < nlev; ++l)
+    if (!L.sgrad[l]) return UTV2_EARG;
+  const int nb = 256;
+  hipLaunchKernelGGL(scale_cols_bwd_ml_kernel, dim3(nb, nlev), dim3(256), 0, stream, g, ypost, L, row_stride, ncols, ws);
+  hipLaunchKernelGGL(scale_cols_bwd_ml_final, dim3(nlev), dim3(256), 0, stream, L, (const float*)ws, nb);
   return utv2_launch_status();
 }
 

@@ -66,6 +66,9 @@ class ArenaSGD:
             hip.amp_update_scale(amp_state, 2.0, 0.5, 2000)   # torch.cuda.amp.GradScaler defaults [SURVEY appendix C]
         ops.bump_version()
         st.touch()
+        bank = getattr(st, "_flipbank", None)
+        if bank is not None:
+            bank.refresh_ahead()     # the dgrad weight images of the new weights, on a side stream: ready long before the next backward
 
     def state_dict(self):
         return {"momentum_buffer": self.store.mom, "lr": self.param_groups[0]["lr"]}

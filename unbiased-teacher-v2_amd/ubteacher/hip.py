@@ -540,6 +540,29 @@ def scale_cols(y2d, ncols, s):
     call("utv2_scale_cols", _p(y2d), rows, BS, ncols, _p(s), _stream())
 
 
+def _i64arr(vals):
+    return (ctypes.c_int64 * len(vals))(*[int(v) for v in vals])
+
+
+def scale_cols_ml(y2d, rows, ncols, scales):
+    """the Scale layers of all FPN levels of a level-first matrix in one launch: rows = [(r0, r1)] per level (contiguous, ascending),
+    scales = the per-level 1-element tensors"""
+    assert len(rows) == len(scales) <= 8 and all(rows[i][1] == rows[i + 1][0] for i in range(len(rows) - 1))
+    r0 = _i64arr([r[0] for r in rows] + [rows[-1][1]])
+    sp = _ptr_array(scales)
+    call("utv2_scale_cols_ml", _p(y2d), len(rows), ctypes.cast(r0, c_p), y2d.shape[1], ncols, ctypes.cast(sp, c_p), _stream())
+
+
+def scale_cols_bwd_ml(g2d, ypost2d, rows, ncols, scales, sgrads):
+    """backward of scale_cols_ml: g2d[:, :ncols] *= s_l in place, sgrads[l] += sum(g_in * ypost) / s_l (two launches for all levels)"""
+    assert len(rows) == len(scales) == len(sgrads) <= 8 and all(rows[i][1] == rows[i + 1][0] for i in range(len(rows) - 1))
+    r0 = _i64arr([r[0] for r in rows] + [rows[-1][1]])
+    sp, gp = _ptr_array(scales), _ptr_array(sgrads)
+    ws = workspace(8 * 256, g2d.device, "loss")
+    call("utv2_scale_cols_bwd_ml", _p(g2d), _p(ypost2d), len(rows), ctypes.cast(r0, c_p), g2d.shape[1], ncols, ctypes.cast(sp, c_p),
+         ctypes.cast(gp, c_p), _p(ws), _stream())
+
+
 def scale_cols_bwd(g2d, ypost2d, ncols, s):
     rows, BS = g2d.shape
     dsum = torch.empty(1, dtype=torch.float32, device=g2d.device)

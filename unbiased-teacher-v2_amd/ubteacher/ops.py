@@ -167,6 +167,10 @@ class LevelMeta:
             t2d.untyped_storage(), t2d.storage_offset() + r0 * C, (self.N, h, w, C), (h * w * C, w * C, C, 1))
 
 
+def _scale_ml_on():
+    return os.environ.get("UTV2_SCALE_ML", "1") != "0"
+
+
 class FlipBank:
     """dgrad weight images ([C][KH][KW][K] bf16, optionally times the FrozenBN multiplier) of every registered layer of one
     ParamStore, refreshed by ONE launch whenever the arena changes (utv2_weight_flip_transpose_bf16_batched)."""
@@ -222,8 +226,35 @@ class FlipBank:
         self.dirty = False
         self.single.clear()
 
+    def refresh_ahead(self):
+        """Right after the optimizer step: rebuild every registered image for the NEW weights on a side stream, off the next backward's
+        critical path (the batched launch used to be the first thing a backward waited for: 67 us with the chip idle at the forward /
+        backward seam).  The first get() of the new version waits for the side stream's event instead of launching."""
+        cur = self._current()
+        if self.bank is None or self.dirty or self.version == cur or self.h16 != hip.H16[0] or os.environ.get("UTV2_FLIP_AHEAD", "1") == "0":
+            return
+        dev = self.store.flat.device
+        if dev.type != "cuda":
+            return
+        side = self.__dict__.get("_side")
+        if side is None:
+            side = self._side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))      # the optimizer's writes
+        with torch.cuda.stream(side):
+            hip.weight_flip_transpose_bf16_batched(self.store.flat, self.scales, self.bank, self.table, self.nrec)
+            self._ahead = torch.cuda.Event()
+            self._ahead.record(side)
+        self.version = cur
+
+    def _join_ahead(self):
+        ev = self.__dict__.pop("_ahead", None)
+        if ev is not None:
+            torch.cuda.current_stream(self.store.flat.device).wait_event(ev)
+
     def get(self, layer, scale):
         cur = self._current()
+        if "_ahead" in self.__dict__:
+            self._join_ahead()
         i = self.slot.get(id(layer))
         if i is None:
             self.slot[id(layer)] = len(self.layers)
@@ -384,7 +415,9 @@ class Conv:
                    kw=self.k, out=out, **kw)
         if cs is not None:
             assert y.dtype == torch.float32
-            if meta is not None:
+            if meta is not None and _scale_ml_on() and y.is_contiguous():
+                hip.scale_cols_ml(y, meta.rows, self.colscale, [h.t for h in cs])      # all levels in one launch
+            elif meta is not None:
                 for l, h in enumerate(cs):
                     r0, r1 = meta.rows[l]
                     hip.scale_cols(y[r0:r1], self.colscale, h.t)
@@ -423,7 +456,10 @@ class _ConvFn(torch.autograd.Function):
         meta = ctx.meta
         if ctx.cs is not None:
             g = dy.clone()
-            if meta is not None:
+            if meta is not None and _scale_ml_on() and y.is_contiguous():
+                # all levels in two launches (it was four per level, each waiting for the one before at the forward / backward seam)
+                hip.scale_cols_bwd_ml(g, y, meta.rows, layer.colscale, [h.t for h in ctx.cs], [h.g for h in ctx.cs])
+            elif meta is not None:
                 for l, h in enumerate(ctx.cs):
                     r0, r1 = meta.rows[l]
                     dsum = hip.scale_cols_bwd(g[r0:r1], y[r0:r1], layer.colscale, h.t)
