@@ -1203,7 +1203,8 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
         });
         if (g_use_pp) {
           int grid = main_m * tilesN;
-          if (g_use_pp == 2 && grid > 256) { m.ntiles = grid; grid = 256; }
+          static const int pp_wgs = [] { int v = env_int("UTV2_PP_WGS", 256); return v < 8 ? 8 : (v > 256 ? 256 : v / 8 * 8); }();   // A/B: CUs the persistent grid takes
+          if (g_use_pp == 2 && grid > 256) { m.ntiles = grid; grid = pp_wgs; }
           if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, h16_t>), dim3(grid), dim3(512), smem, stream, m);
           else hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, float>), dim3(grid), dim3(512), smem, stream, m);
         } else if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_w8<ML, h16_t>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
