@@ -582,6 +582,25 @@ def threshold_bbox(det, thr):
                 centerness=det["centerness"][m], cls_confid=det["cls_confid"][m], reg_pred_std=det["reg_pred_std"][m])
 
 
+def threshold_cls_ctr_bbox(det, thr):
+    """pseudo_generator.py:107-131: keep a detection when BOTH its classification confidence and its centerness pass
+    (`cls_confid > thr[0]` and `centerness > thr[1]`, strict); the ranking score is carried along, not tested."""
+    m = (det["cls_confid"] > thr[0]) & (det["centerness"] > thr[1])
+    return dict(boxes=det["boxes"][m], classes=det["classes"][m], scores=det["scores"][m],
+                centerness=det["centerness"][m], cls_confid=det["cls_confid"][m], reg_pred_std=det["reg_pred_std"][m])
+
+
+def process_pseudo_label(dets, cur_threshold, method):
+    """pseudo_generator.py:39-60: per-image thresholding by the configured method + the mean number of kept boxes."""
+    if method == "thresholding":
+        out = [threshold_bbox(d, cur_threshold) for d in dets]
+    elif method == "thresholding_cls_ctr":
+        out = [threshold_cls_ctr_bbox(d, cur_threshold) for d in dets]
+    else:
+        raise ValueError("Unkown pseudo label boxes methods")
+    return out, sum(len(o["scores"]) for o in out) / float(len(dets))
+
+
 # =================================================================================================
 # EMA / SGD / step
 # =================================================================================================
@@ -644,8 +663,9 @@ def fcos_semisup_step(cfg, student_sd, teacher_sd, batch, keep_rate, lam_u=3.0, 
         _mark("teacher_forward")
         det_cls = fcos_predict(cfg, *tl[:4], tl[4], tl[5], "cls")
         det_loc = fcos_predict(cfg, *tl[:4], tl[4], tl[5], "cls_n_loc")
-    pseudo_cls = [threshold_bbox(d, thr_cls) for d in det_cls]
-    pseudo_reg = [threshold_bbox(d, thr_reg) for d in det_loc]
+    # a pair of thresholds selects SEMISUPNET.PSEUDO_BBOX_SAMPLE(_REG) = "thresholding_cls_ctr" (engine/trainer.py:253-276)
+    pseudo_cls, _ = process_pseudo_label(det_cls, thr_cls, "thresholding_cls_ctr" if isinstance(thr_cls, (tuple, list)) else "thresholding")
+    pseudo_reg, _ = process_pseudo_label(det_loc, thr_reg, "thresholding_cls_ctr" if isinstance(thr_reg, (tuple, list)) else "thresholding")
     _mark("decode_nms_threshold")
     if pseudo_override is not None:  # (mixed-precision tests: decouple the student check from teacher selection noise)
         pseudo_cls, pseudo_reg = pseudo_override

@@ -255,6 +255,9 @@ def gts_to_arrays(prefix, gts, d):
             d["%s%d_scores" % (prefix, i)] = npy(x.scores)
 
 
+THR_CLS_CTR = (0.85, 0.7)
+
+
 def gen_fcos(structures, fo, pg):
     cfg = fcos_cfg()
     outm = fo.FCOSOutputs(cfg)
@@ -323,6 +326,18 @@ def gen_fcos(structures, fo, pg):
                 th, _ = gen.process_pseudo_label([r], 0.3, "roih", "thresholding")
                 d["thr_%s_%d_boxes" % (m, i)] = npy(th[0].gt_boxes.tensor)
                 d["thr_%s_%d_scores" % (m, i)] = npy(th[0].scores)
+                # round 4: the two-threshold selection (pseudo_generator.py:107-131, reached through process_pseudo_label :49-52):
+                # cls_confid > thr[0] AND centerness > thr[1]; thresholds chosen so that each of the two tests alone rejects some
+                # of the detections the other accepts
+                thcc, ncc = gen.process_pseudo_label([r], THR_CLS_CTR, "roih", "thresholding_cls_ctr")
+                d["thrcc_%s_%d_boxes" % (m, i)] = npy(thcc[0].gt_boxes.tensor)
+                d["thrcc_%s_%d_classes" % (m, i)] = npy(thcc[0].gt_classes)
+                d["thrcc_%s_%d_scores" % (m, i)] = npy(thcc[0].scores)
+                d["thrcc_%s_%d_ctr" % (m, i)] = npy(thcc[0].centerness)
+                d["thrcc_%s_%d_conf" % (m, i)] = npy(thcc[0].cls_confid)
+                d["thrcc_%s_%d_std" % (m, i)] = npy(thcc[0].reg_pred_std)
+                d["thrcc_%s_%d_num" % (m, i)] = np.float64(ncc)
+    d["thrcc_thresholds"] = np.asarray(THR_CLS_CTR, np.float64)
     np.savez_compressed(os.path.join(HERE, "fcos_outputs.npz"), **d)
     print("fcos_outputs.npz:", len(d), "arrays")
 
@@ -629,6 +644,44 @@ def gen_rcnn(structures):
     res, keep = cls_.inference(duck, (sc, de, sd_), [pi])
     d.update(inf_scores=npy(sc), inf_deltas=npy(de), inf_std=npy(sd_), inf_boxes=npy(res[0].pred_boxes.tensor),
              inf_sc=npy(res[0].scores), inf_cls=npy(res[0].pred_classes), inf_bstd=npy(res[0].pred_boxes_std), inf_keep=npy(keep[0]))
+    # ---- round 4: the +-62.5 clamp of Box2BoxXYXYTransform.apply_deltas (box_regression.py:88-128) driven through the predictor's
+    # inference and through the supervised nlloss (its IoU weight decodes the predicted deltas: fast_rcnn.py:938-1016).  Own generator:
+    # the arrays above and below keep their values.  Rows 0-11 are 2-4 px proposals in the middle of the image with |delta / 10|
+    # far beyond 62.5, so the clamped boxes stay inside the image (an unclamped decode would hit the image border instead).
+    g2 = torch.Generator().manual_seed(78)
+    Rc = 40
+    cxy = torch.rand(Rc, 2, generator=g2) * 150 + 20
+    propc = torch.cat([cxy, cxy + torch.rand(Rc, 2, generator=g2) * 60 + 4], 1)
+    propc[:12, :2] = 150 + torch.rand(12, 2, generator=g2) * 4
+    propc[:12, 2:] = propc[:12, :2] + 2 + torch.rand(12, 2, generator=g2) * 0.2
+    dec = torch.randn(Rc, 4, generator=g2) * 2
+    big = torch.tensor([[900.0, -900.0, 2000.0, -2000.0], [-900.0, 900.0, -2000.0, 2000.0], [-700.0, -650.0, -626.0, -1e4],
+                        [626.0, 700.0, 1e4, 650.0], [-624.0, 624.0, -625.5, 625.5], [0.0, 900.0, 0.0, 900.0]])
+    dec[:6] = big; dec[6:12] = -big
+    scc = torch.randn(Rc, 81, generator=g2) * 3
+    scc[:12, 80] = -9.0                                 # the clamped rows are confident foreground: they survive score threshold and NMS
+    scc[torch.arange(12), torch.arange(12)] = 9.0
+    sdc = torch.randn(Rc, 4, generator=g2)
+    pic = Instances((300, 300)); pic.proposal_boxes = Boxes(propc)
+    resc, keepc = cls_.inference(duck, (scc, dec, sdc), [pic])
+    assert set(range(12)) <= set(keepc[0].tolist()), "the clamped rows must be among the kept detections"
+    d.update(infc_prop=npy(propc), infc_scores=npy(scc), infc_deltas=npy(dec), infc_std=npy(sdc), infc_boxes=npy(resc[0].pred_boxes.tensor),
+             infc_sc=npy(resc[0].scores), infc_cls=npy(resc[0].pred_classes), infc_bstd=npy(resc[0].pred_boxes_std), infc_keep=npy(keepc[0]))
+    clsc = torch.randint(0, 80, (Rc,), generator=g2)
+    clsc[20:] = 80
+    gtbc = propc + torch.randn(Rc, 4, generator=g2) * 1.5
+    gstdc = torch.randn(Rc, 4, generator=g2) * 2 - 1.0
+    instc = Instances((300, 300))
+    instc.proposal_boxes = Boxes(propc); instc.gt_boxes = Boxes(gtbc); instc.gt_classes = clsc; instc.gt_loc_std = gstdc
+    d.update(rcc_prop=npy(propc), rcc_gtb=npy(gtbc), rcc_cls=npy(clsc), rcc_gstd=npy(gstdc))
+    for branch in ("supervised", "unsup_data_train"):
+        leaves = [scc.clone().requires_grad_(True), dec.clone().requires_grad_(True), (sdc * 1.5 + (1.0 if branch != "supervised" else 0.0)).requires_grad_(True)]
+        ls = cls_.losses(duck, tuple(leaves), [instc], branch)
+        (ls["loss_cls"] + 2.0 * ls["loss_box_reg"]).backward()
+        for k, v in zip(("scores", "deltas", "std"), leaves):
+            d["rcc_%s_%s" % (branch, k)] = npy(v)
+            d["rcc_%s_g%s" % (branch, k)] = npy(v.grad if v.grad is not None else torch.zeros_like(v))
+        d["rcc_%s_loss_cls" % branch] = npy(ls["loss_cls"]); d["rcc_%s_loss_box_reg" % branch] = npy(ls["loss_box_reg"])
     # ---- PseudoLabRPN: label_and_sample_anchors_pseudo + losses (weights on all valid anchors) ----
     hw = [(6, 8), (3, 4)]
     anchors = O.make_anchors(hw, [16, 32], sizes=(32, 64))
@@ -697,8 +750,8 @@ if __name__ == "__main__":
     structures, fo, pg, tr = install_shims()
     if len(sys.argv) > 1:  # python gen_golden.py center_sample loss_variants ... : only those files
         for name in sys.argv[1:]:
-            fn = globals()["gen_" + name] if name in ("rcnn", "data_pipeline") else globals()["gen_fcos_" + name]
-            fn(*{"rcnn": (structures,), "data_pipeline": ()}.get(name, (structures, fo)))
+            fn = globals()["gen_" + name] if name in ("rcnn", "data_pipeline", "fcos") else globals()["gen_fcos_" + name]
+            fn(*{"rcnn": (structures,), "data_pipeline": (), "fcos": (structures, fo, pg)}.get(name, (structures, fo)))
         sys.exit(0)
     gen_rcnn(structures)
     gen_fcos(structures, fo, pg)

@@ -196,6 +196,20 @@ def test_decode_nms(fc, method):
     th = det.threshold(0.3).to_instances(as_gt=True)
     for i, r in enumerate(th):
         close(r.gt_boxes.tensor, fc["thr_%s_%d_boxes" % (method, i)], rtol=1e-5, atol=2e-4)
+    # SEMISUPNET.PSEUDO_BBOX_SAMPLE "thresholding_cls_ctr" through the product's PseudoGenerator (reference
+    # pseudo_generator.py:49-52,107-131): kept set exact against the reference's own output
+    from ubteacher.modeling.pseudo_generator import PseudoGenerator
+    thr = tuple(float(v) for v in fc["thrcc_thresholds"])
+    out, num = PseudoGenerator(fcos_cfg()).process_pseudo_label(det, thr, "roih", "thresholding_cls_ctr")
+    want_num = np.mean([float(fc["thrcc_%s_%d_num" % (method, i)]) for i in range(N)])
+    assert abs(float(num) - want_num) < 1e-6
+    for i, r in enumerate(out.to_instances(as_gt=True)):
+        assert np.array_equal(r.gt_classes.cpu().numpy(), fc["thrcc_%s_%d_classes" % (method, i)])
+        close(r.gt_boxes.tensor, fc["thrcc_%s_%d_boxes" % (method, i)], rtol=1e-5, atol=2e-4)
+        close(r.scores, fc["thrcc_%s_%d_scores" % (method, i)], rtol=2e-5)
+        close(r.centerness, fc["thrcc_%s_%d_ctr" % (method, i)], rtol=2e-5)
+        close(r.cls_confid, fc["thrcc_%s_%d_conf" % (method, i)], rtol=2e-5)
+        close(r.reg_pred_std, fc["thrcc_%s_%d_std" % (method, i)])
 
 
 def test_nms_bit_exact_vs_oracle():

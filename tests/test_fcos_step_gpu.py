@@ -104,6 +104,51 @@ def test_full_semisup_step_parity(freeze_at):
     assert checked > 100
 
 
+def test_full_semisup_step_cls_ctr_thresholding():
+    """SEMISUPNET.PSEUDO_BBOX_SAMPLE(_REG) = "thresholding_cls_ctr" (reference engine/trainer.py:253-276 -> pseudo_generator.py:49-52,
+    107-131: keep a detection when cls_confid > BBOX_THRESHOLD and centerness > BBOX_CTR_THRESHOLD) through a whole step: same pseudo
+    sets as the oracle (whose selection is pinned by the reference-executed golden thrcc_* arrays), every loss within 1e-3."""
+    from ubteacher.engine import UBTeacherTrainer
+    cfg = small_fcos_cfg()
+    S = cfg.SEMISUPNET
+    S.PSEUDO_BBOX_SAMPLE = S.PSEUDO_BBOX_SAMPLE_REG = "thresholding_cls_ctr"
+    S.BBOX_THRESHOLD, S.BBOX_CTR_THRESHOLD = 0.5, 0.68
+    S.BBOX_THRESHOLD_REG, S.BBOX_CTR_THRESHOLD_REG = 0.45, 0.7
+    torch.manual_seed(0)
+    prod, orac = make_batch(12, 2, 2, H, W, "cuda")
+    tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+    sd_s = tune_state_for_pseudo_labels(cpu_state(tr.model), [d["image"] for d in orac[3]])
+    sd_t = dict(sd_s)
+    sd_t["proposal_generator.fcos_head.bbox_pred_std.bias"] = torch.full((4,), -3.0)
+    tr.model.load_state_dict(sd_s)
+    tr.model_teacher.load_state_dict(sd_t)
+    tr.iter = 1
+    tr.optimizer.param_groups[0]["lr"] = 0.01
+    tr.run_step_full_semisup()
+    rec = tr.flush_metrics()
+    torch.cuda.synchronize()
+    common = dict(keep_rate=S.EMA_KEEP_RATE, lam_u=S.UNSUP_LOSS_WEIGHT, lam_r=S.UNSUP_REG_LOSS_WEIGHT, lr=0.01, momentum=0.9, wd=1e-4,
+                  mean=sd_s["pixel_mean"], pix_std=sd_s["pixel_std"])
+    rec_o, _, new_t, _, _, pseudo = O.fcos_semisup_step(
+        O.FCOSCfg(), sd_s, sd_t, orac, thr_cls=(S.BBOX_THRESHOLD, S.BBOX_CTR_THRESHOLD), thr_reg=(S.BBOX_THRESHOLD_REG, S.BBOX_CTR_THRESHOLD_REG), **common)
+    _, _, _, _, _, pseudo_plain = O.fcos_semisup_step(O.FCOSCfg(), sd_s, sd_t, orac, thr_cls=S.BBOX_THRESHOLD, thr_reg=S.BBOX_THRESHOLD_REG, **common)
+    n_cc = [sum(len(p["boxes"]) for p in ps) for ps in pseudo]
+    n_pl = [sum(len(p["boxes"]) for p in ps) for ps in pseudo_plain]
+    assert 0 < n_cc[0] and 0 < n_cc[1] and (n_cc[0] != n_pl[0] or n_cc[1] != n_pl[1]), (n_cc, n_pl)   # the second threshold decides
+    pc, pr = tr._last_pseudo
+    for got, want in ((pc, pseudo[0]), (pr, pseudo[1])):
+        for i, p in enumerate(want):
+            m = got["valid"][i].bool()
+            assert int(m.sum()) == len(p["boxes"])
+            assert torch.equal(got["classes"][i][m].cpu().long(), p["classes"].long())
+            assert float((got["boxes"][i][m].cpu() - p["boxes"]).abs().max()) < 1e-2 if len(p["boxes"]) else True
+    for k, v in rec_o.items():
+        assert abs(rec[k] - v) <= 1e-3 * max(abs(v), 1e-6), (k, rec[k], v)
+    t_after = cpu_state(tr.model_teacher)
+    for k in new_t:
+        assert torch.equal(t_after[k], new_t[k]), k
+
+
 def test_trainable_stem_amp_step_vs_rounding_oracle():
     """MODEL.BACKBONE.FREEZE_AT 0 under AMP: the stem takes the fp32 image in every precision mode, its pool / ReLU backward runs on the
     16-bit activations, its weight gradient in exact f32.  Against the oracle with the operand rounding emulated in its convs, GIVEN the

@@ -101,6 +101,15 @@ def test_decode_nms_threshold(fc, method):
         th = O.threshold_bbox(r, 0.3)
         close(th["boxes"], fc["thr_%s_%d_boxes" % (method, i)], rtol=1e-5, atol=1e-4)
         close(th["scores"], fc["thr_%s_%d_scores" % (method, i)])
+        # the two-threshold selection, pseudo_generator.py:107-131 (kept set exact: same classes in the same order, same count)
+        thr = tuple(float(v) for v in fc["thrcc_thresholds"])
+        (tc,), num = O.process_pseudo_label([r], thr, "thresholding_cls_ctr")
+        assert np.array_equal(tc["classes"].numpy(), fc["thrcc_%s_%d_classes" % (method, i)])
+        assert num == float(fc["thrcc_%s_%d_num" % (method, i)])
+        close(tc["boxes"], fc["thrcc_%s_%d_boxes" % (method, i)], rtol=1e-5, atol=1e-4)
+        for k, g in (("scores", "scores"), ("centerness", "ctr"), ("cls_confid", "conf"), ("reg_pred_std", "std")):
+            close(tc[k], fc["thrcc_%s_%d_%s" % (method, i, g)])
+        assert 0 < len(tc["scores"]) < len(r["scores"])          # the thresholds bite
 
 
 def test_small_ops():

@@ -34,10 +34,12 @@ def test_box2box_xyxy(rc):
 
 
 @pytest.mark.parametrize("branch", ["supervised", "unsup_data_train"])
-@pytest.mark.parametrize("pre,gamma", [("rc", 1.5), ("rcce", 0.0)])  # FocalLoss_BoundaryVar | CrossEntropy_BoundaryVar predictor
-def test_roi_losses(rc, branch, pre, gamma):
-    scores, deltas, std = (T(rc["rc_%s_%s" % (branch, k)]).clone().requires_grad_(True) for k in ("scores", "deltas", "std"))
-    cls, prop, gtb, gstd = T(rc["rc_cls"]), T(rc["rc_prop"]), T(rc["rc_gtb"]), T(rc["rc_gstd"])
+# FocalLoss_BoundaryVar | CrossEntropy_BoundaryVar predictor | round 4: "rcc" = predicted deltas beyond the +-62.5 clamp of
+# Box2BoxXYXYTransform.apply_deltas (box_regression.py:115-118) inside the nlloss IoU weight
+@pytest.mark.parametrize("pre,gamma,src", [("rc", 1.5, "rc"), ("rcce", 0.0, "rc"), ("rcc", 1.5, "rcc")])
+def test_roi_losses(rc, branch, pre, gamma, src):
+    scores, deltas, std = (T(rc["%s_%s_%s" % (src, branch, k)]).clone().requires_grad_(True) for k in ("scores", "deltas", "std"))
+    cls, prop, gtb, gstd = (T(rc["%s_%s" % (src, k)]) for k in ("cls", "prop", "gtb", "gstd"))
     lc = O.softmax_focal(scores, cls, gamma)
     lb = O.roi_box_reg_loss(prop, gtb, deltas, std, cls) if branch == "supervised" else O.roi_box_reg_pseudo_loss(prop, gtb, deltas, std, gstd, cls)
     close(lc, rc["%s_%s_loss_cls" % (pre, branch)]); close(lb, rc["%s_%s_loss_box_reg" % (pre, branch)])
@@ -46,14 +48,21 @@ def test_roi_losses(rc, branch, pre, gamma):
         close(v.grad if v.grad is not None else torch.zeros_like(v), rc["%s_%s_g%s" % (pre, branch, k)], rtol=1e-4, atol=1e-7)
 
 
-def test_roi_inference(rc):
-    prop = T(rc["rc_prop"])
-    boxes = O.xyxy_apply_deltas(T(rc["inf_deltas"]), prop)
-    dets, rows = O.fast_rcnn_inference(boxes, F.softmax(T(rc["inf_scores"]), dim=-1), (300, 300))
-    assert np.array_equal(rows.numpy(), rc["inf_keep"])
-    assert np.array_equal(dets["classes"].numpy(), rc["inf_cls"])
-    close(dets["boxes"], rc["inf_boxes"], atol=1e-4); close(dets["scores"], rc["inf_sc"])
-    close(T(rc["inf_std"])[rows], rc["inf_bstd"])
+@pytest.mark.parametrize("pre,prop_key", [("inf", "rc_prop"), ("infc", "infc_prop")])   # infc: rows 0-11 decode through the clamp
+def test_roi_inference(rc, pre, prop_key):
+    prop = T(rc[prop_key])
+    boxes = O.xyxy_apply_deltas(T(rc[pre + "_deltas"]), prop)
+    dets, rows = O.fast_rcnn_inference(boxes, F.softmax(T(rc[pre + "_scores"]), dim=-1), (300, 300))
+    assert np.array_equal(rows.numpy(), rc[pre + "_keep"])
+    assert np.array_equal(dets["classes"].numpy(), rc[pre + "_cls"])
+    close(dets["boxes"], rc[pre + "_boxes"], atol=1e-4); close(dets["scores"], rc[pre + "_sc"])
+    close(T(rc[pre + "_std"])[rows], rc[pre + "_bstd"])
+    if pre == "infc":
+        # the clamp decided these boxes: |delta / 10| > 62.5 on a 2 px proposal moves an edge by exactly 62.5 widths, inside the image
+        kept = {int(r): i for i, r in enumerate(rc["infc_keep"])}
+        w = rc["infc_prop"][0, 2] - rc["infc_prop"][0, 0]
+        assert abs((rc["infc_boxes"][kept[0], 0] - rc["infc_prop"][0, 0]) - 62.5 * w) < 1e-3   # delta +900 -> +62.5 widths, not +90
+        assert 0.0 < rc["infc_boxes"][kept[0], 0] < 300.0
 
 
 def test_rpn_pseudo_losses(rc):

@@ -1,6 +1,14 @@
 #!/bin/bash
-# scratch: the GPU job of the moment
-cd /root/repo
-timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 900 python -m pytest tests/test_rcnn_step_gpu.py -x -q -m gpu -k "deterministic or trainable_stem" 2>&1 | tail -2
-timeout 600 python bench.py --steps 23 --warmup 5 --no-cpu-baseline --no-rcnn --no-f32 --timed-only 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['dtype'], round(d['value'],2), round(d['roofline']['frac'],4))"
+# scratch: the GPU job of the moment (run through gpurun from the repo root)
+R=$PWD
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace -d $R/gpurun_out/_kt -o run -- python $R/bench.py --no-cpu-baseline --no-f32 --timed-only --steps 8 --warmup 2 > $R/gpurun_out/r04_kt.log 2>&1 < /dev/null
+cd $R
+DB=$(find gpurun_out/_kt -name '*.db' | head -1)
+python tools/rocpd_timeline.py "$DB" steps 10 6 > gpurun_out/r04_base_timeline.txt 2>&1
+python tools/rocpd_gaps.py "$DB" 10 6 30 > gpurun_out/r04_base_gaps.txt 2>&1
+python tools/rocpd_stats.py "$DB" > gpurun_out/r04_base_kernel_stats.txt 2>&1
+python tools/rocpd_solo.py "$DB" 10 6 40 > gpurun_out/r04_base_solo.txt 2>&1
+cp "$DB" gpurun_out/r04_base_kt.db
+rm -rf gpurun_out/_kt
+head -40 gpurun_out/r04_base_timeline.txt
