@@ -86,8 +86,14 @@ def tune_rcnn_for_pseudo_labels(trainer, batch, target_std=8.0, bg_bias=0.0):
     wb.mul_(0.5 / s_d.clamp(min=1e-12))
     ws.mul_(0.5 / s_s.clamp(min=1e-12))
     b[-1] = bg_bias
+    # confident teacher boundaries, a less certain student (as tune_for_pseudo_labels does for FCOS): the "tsbetter" selection of
+    # box_reg_pseudo_loss (fast_rcnn.py:1018-1092: c_t > c_s + 0.1 and c_t > 0.5 per boundary, c = 1 - sigmoid(std)) is then non-empty
+    # and loss_box_reg_pseudo / its backward do real work inside the timed step
+    sb = sd["roi_heads.box_predictor.bbox_pred_std.bias"]
+    sb.fill_(-3.0)
     m.store.touch()
     trainer._update_teacher_model(keep_rate=0.0)  # teacher := student
+    sb.fill_(0.0)
     m.store.touch()
 
 
@@ -480,43 +486,47 @@ def parity_fullsize(dump, device_index):
     return out
 
 
-def rcnn_subrecord(args, device_index, timer, steps=10, warmup=5):
+def rcnn_subrecord(args, device_index, timer, steps=10, warmup=5, dtype="bf16"):
     """images/sec of UBRCNNTeacherTrainer.run_step_full_semisup (BASELINE configs[2] / [4]: Faster-RCNN R50-FPN UTv2, bf16 MFMA conv
     path) on the same per-GPU batch as the headline, timed by the same rule (barrier-free at world 1: synchronize on both sides);
     its dominant kernel = the RPN head 3x3 conv over p2-p6 (the same multi-level implicit-GEMM kernel), timed by HIP events."""
     from ubteacher.engine import UBRCNNTeacherTrainer
     from ubteacher.presets import get_config
     cfg = get_config("rcnn", 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label, "SOLVER.IMG_PER_BATCH_UNLABEL", args.unlabel,
-                                 "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", True, "MODEL.DEVICE", "cuda:%d" % device_index])
+                                 "SEMISUPNET.BURN_UP_STEP", 0, "SOLVER.AMP.ENABLED", dtype != "f32", "MODEL.DEVICE", "cuda:%d" % device_index])
     torch.manual_seed(0)
     import gc
     gc.collect()                                 # this step is close to host-bound: start from a collected heap (several trainers came and went)
-    os.environ.pop("UTV2_PRECISION", None)       # BASELINE configs[4] names the bf16 MFMA conv path
+    os.environ.pop("UTV2_PRECISION", None)       # BASELINE configs[4] names the bf16 MFMA conv path; configs[2] (no AMP in its YAML) is f32
     tr = UBRCNNTeacherTrainer(cfg)
     tr.iter = 1
     tr.log_period = 10 ** 9
     tr.optimizer.param_groups[0]["lr"] = 1e-12   # see make_trainer: keeps the synthetic problem stationary
     tune_rcnn_for_pseudo_labels(tr, tr._data_loader.batches[0])
-    for _ in range(warmup):
+    pseudo_first = None
+    for i in range(warmup):
         tr.run_step_full_semisup(); tr.iter += 1
+        if i == 0:
+            pseudo_first = int(tr._last_pseudo["valid"].sum())
     torch.cuda.synchronize()
     timer.pairs = []
-    timer.enabled = True
+    timer.enabled = dtype != "f32"               # the timer is installed on the 16-bit entry point
     t0 = time.perf_counter()
     for _ in range(steps):
         tr.run_step_full_semisup(); tr.iter += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timer.enabled = False
-    conv = timer.summary()
+    conv = timer.summary() if dtype != "f32" else None
     metrics = tr.flush_metrics()
-    amp_state = tr._amp_state.cpu().tolist() if getattr(tr, "_amp_state", None) is not None else None
     lp = getattr(tr, "_last_pseudo", None)
     out = {"value": (args.label + args.unlabel) * steps / dt, "unit": "images/sec", "ms_per_step": 1e3 * dt / steps, "steps": steps,
-           "warmup": warmup, "dtype": "bf16",
-           "workload": "Faster-RCNN R50-FPN UTv2 sup1 (the trainer of configs[2] / [4]): %d labeled + %d unlabeled 1333x800 images per GPU, "
-                       "post-burn-in semi-supervised step" % (args.label, args.unlabel),
+           "warmup": warmup, "dtype": dtype,
+           "workload": "Faster-RCNN R50-FPN UTv2 sup1 (the trainer of configs[2] / [4]; %s): %d labeled + %d unlabeled 1333x800 images per GPU, "
+                       "post-burn-in semi-supervised step" % ("fp32 as configs[2]'s YAML, no AMP" if dtype == "f32" else "configs[4]'s bf16 MFMA conv path",
+                                                              args.label, args.unlabel),
            "losses": {k: v for k, v in metrics.items() if k.startswith("loss")},
+           "pseudo_boxes_first_step": pseudo_first,
            "pseudo_boxes_last_step": None if lp is None else int(lp["valid"].sum())}
     if conv:
         out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_bf16_pp<true,__bf16>+conv_igemm_bf16_v2<128,true,64,__bf16> (RPN head 3x3 conv over p2-p6, fwd+dgrad launches)",
@@ -605,7 +615,7 @@ def worker(args):
     from ubteacher import hip, ops
     hip.load()
     rcnn = args.model == "rcnn"
-    cpu_rec = cpu_rcnn = dump = None
+    cpu_rec = cpu_rcnn = dump = dump_rcnn = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # before any GPU work, in its own process
         import tempfile
         if not rcnn:
@@ -613,9 +623,12 @@ def worker(args):
             cpu_rec = cpu_baseline("fcos", args.cpu_images, args.cpu_images, args.cpu_warmup, args.cpu_steps, dump=dump)
         if rcnn or not args.no_rcnn:
             # BASELINE configs[0]: Faster-RCNN 2+2, MODEL.DEVICE=cpu, 1 process (a step costs ~2x the FCOS one: fewer repetitions)
+            # its first oracle step is dumped either way: the parent replays it through the product's f32 step (`parity_fullsize` of the
+            # Faster-RCNN trainer: in the headline line under rcnn.parity_fullsize)
+            dump_rcnn = os.path.join(tempfile.gettempdir(), "utv2_bench_parity_rcnn_%d.pt" % os.getpid())
             if rcnn:
-                dump = os.path.join(tempfile.gettempdir(), "utv2_bench_parity_%d.pt" % os.getpid())
-            cpu_rcnn = cpu_baseline("rcnn", 2, 2, 1, 2, dump=dump if rcnn else None)
+                dump = dump_rcnn
+            cpu_rcnn = cpu_baseline("rcnn", 2, 2, 1, 2, dump=dump_rcnn)
         if rcnn:
             cpu_rec = cpu_rcnn
 
@@ -631,11 +644,12 @@ def worker(args):
         t = (UBRCNNTeacherTrainer if rcnn else UBTeacherTrainer)(cfg)
         t.iter = 1
         t.log_period = 10 ** 9
-        if rcnn:
-            # random-init R50 features are not normalised (|x| ~ 1e4 in the box head): at any practical learning rate ONE SGD step moves
-            # the student far enough that the EMA teacher stops emitting pseudo boxes and the pseudo-label branch degenerates.  The step's
-            # work does not depend on the learning rate: a vanishing one keeps the synthetic problem stationary (100 pseudo boxes / image).
-            t.optimizer.param_groups[0]["lr"] = 1e-12
+        # random-init R50 features are not normalised (|x| ~ 1e4 in the box head): at any practical learning rate ONE SGD step moves
+        # the student far enough that the EMA teacher stops emitting pseudo boxes and the pseudo-label branch degenerates (FCOS at the
+        # config's lr: 89 classification pseudo boxes in the first step, 1 after 25).  The step's work does not depend on the learning
+        # rate: a vanishing one keeps the synthetic problem stationary over the timed window - `pseudo_boxes_first_step` /
+        # `pseudo_boxes_last_step` report both ends.
+        t.optimizer.param_groups[0]["lr"] = 1e-12
         return t
 
     timer = ConvTimer(args.dtype)
@@ -651,11 +665,21 @@ def worker(args):
     parity = rank == 0 and world == 1 and args.dtype != "f32" and not args.no_f32 and not rcnn
     if parity:
         s0, t0 = tr.model.flat_state().clone(), tr.model_teacher.flat_state().clone()
-    first = None
+    def pseudo_counts(t):
+        lp_ = getattr(t, "_last_pseudo", None)
+        if lp_ is None:
+            return None
+        if isinstance(lp_, tuple):
+            return {"cls": int(lp_[0]["valid"].sum()), "reg": int(lp_[1]["valid"].sum())}
+        return int(lp_["valid"].sum())
+
+    first = pseudo_first = None
     for i in range(args.warmup):
         tr.run_step_full_semisup(); tr.iter += 1
-        if i == 0 and parity:
-            first = dict(tr.flush_metrics())
+        if i == 0:
+            pseudo_first = pseudo_counts(tr)
+            if parity:
+                first = dict(tr.flush_metrics())
 
     def sync():
         torch.cuda.synchronize()
@@ -682,13 +706,7 @@ def worker(args):
         devices = comm.all_gather_object(device_index)
     metrics = tr.flush_metrics()
     amp_state = tr._amp_state.cpu().tolist() if getattr(tr, "_amp_state", None) is not None else None
-    lp = getattr(tr, "_last_pseudo", None)
-    if lp is None:
-        pseudo_count = None
-    elif isinstance(lp, tuple):
-        pseudo_count = {"cls": int(lp[0]["valid"].sum()), "reg": int(lp[1]["valid"].sum())}
-    else:
-        pseudo_count = int(lp["valid"].sum())
+    pseudo_count = pseudo_counts(tr)
     conv, wg = timer.summary(), wtimer.summary()
 
     # the same launches with the step's side streams off (teacher pass / weight gradients back on the main stream): the dominant kernels
@@ -823,12 +841,27 @@ def worker(args):
     rcnn_rec = None
     if rank == 0 and world == 1 and not rcnn and not args.no_rcnn and not args.timed_only and args.dtype != "f32":
         # the Faster-RCNN UTv2 trainer (BASELINE configs[2] / [4]: bf16 MFMA conv path) on the same per-GPU batch, as a sub-record
+        args_r = argparse.Namespace(**vars(args)); args_r.model = "rcnn"
         try:
             torch.cuda.empty_cache()
-            args_r = argparse.Namespace(**vars(args)); args_r.model = "rcnn"
             rcnn_rec = rcnn_subrecord(args_r, device_index, timer)
         except Exception as e:  # noqa: BLE001
             rcnn_rec = {"error": repr(e)}
+        # the same trainer at the precision of its own shipped YAML (configs[2]: no SOLVER.AMP -> fp32; exact-f32 MFMA here), driver-timed
+        try:
+            torch.cuda.empty_cache()
+            rcnn_rec["f32"] = rcnn_subrecord(args_r, device_index, timer, steps=5, warmup=2, dtype="f32")
+        except Exception as e:  # noqa: BLE001
+            rcnn_rec["f32"] = {"error": repr(e)}
+        # ... and that f32 step against the cpu_baseline_rcnn child's first oracle step on the same 2+2 1333x800 batch
+        if dump_rcnn is not None and os.path.exists(dump_rcnn):
+            try:
+                torch.cuda.empty_cache()
+                rcnn_rec["parity_fullsize"] = parity_fullsize(dump_rcnn, device_index)
+            except Exception as e:  # noqa: BLE001
+                rcnn_rec["parity_fullsize"] = {"error": repr(e)}
+    if dump_rcnn is not None and dump_rcnn != dump and os.path.exists(dump_rcnn):
+        os.remove(dump_rcnn)
 
     if rank == 0:
         per_step_images = (args.label + args.unlabel) * world
@@ -854,7 +887,8 @@ def worker(args):
             "host": {"ms_per_step_on_96x128_images": host_ms, "enqueue_ms_per_step": 1e3 * t_host / args.steps,
                      "cabi_calls_per_step": calls_per_step, "gpu_dispatches": dispatches_per_step(args.model) if args.dtype != "f32" else None},
             "losses": {k: v for k, v in metrics.items() if k.startswith("loss") or k.startswith("teacher")},
-            "pseudo_boxes_last_step": pseudo_count,
+            "pseudo_boxes_first_step": pseudo_first, "pseudo_boxes_last_step": pseudo_count,
+            "learning_rate": "1e-12 (keeps the synthetic pseudo-label problem stationary over the timed window; the step's work does not depend on it)",
         }
         if amp_state is not None:
             out["loss_scale_state"] = dict(zip(("scale", "found_inf", "clean_steps"), amp_state))

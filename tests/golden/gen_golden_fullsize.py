@@ -1,0 +1,91 @@
+"""Full-size step fixtures: ONE post-burn-in UTv2 iteration on 1 labeled + 1 unlabeled 1333x800 image, FCOS and Faster-RCNN, by the
+CPU oracle (oracle/utv2_oracle.py: pinned against the reference-executed goldens of this directory by tests/test_oracle_golden*.py and
+tests/test_step_golden.py).  Run in the build container (CPU, ~1 min):
+
+    python tests/golden/gen_golden_fullsize.py            ->  tests/golden/fullsize_fcos.npz, fullsize_rcnn.npz
+
+The GPU tests (tests/test_fullsize_gpu.py) replay exactly this step through the product's exact-f32 mode: this is the resolution at which
+the 256-tile / ping-pong convolutions, the multi-round top-k and the 1000-candidate NMS engage (the other step tests run 96x128 images).
+
+What is stored (a few hundred KB; nothing that can be regenerated bit-exactly from a seed is stored as data):
+  * how to rebuild the inputs: the numpy seed of bench._synthetic_cpu_batch + CRC32 of every generated image, the ground truth as arrays;
+  * how to rebuild the initial weights: torch seed of the product's CPU initialisation + per-tensor fingerprints of it (a changed RNG fails
+    loudly), and the tensors the data-driven head rescaling changed (cpu_baseline_run: the teacher must emit pseudo boxes) as arrays;
+  * Faster-RCNN: the torch seed / draw sizes of the oracle's sampling keys (+ CRC32 of the drawn keys);
+  * expected outputs: every record_dict entry of the oracle's step, its pseudo-box counts."""
+import os
+import sys
+import tempfile
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "unbiased-teacher-v2_amd"))
+
+import bench  # noqa: E402
+from tests.utv2_testutil import state_fingerprint  # noqa: E402
+
+
+def crc(t):
+    return zlib.crc32(np.ascontiguousarray(t.detach().cpu().numpy() if torch.is_tensor(t) else t).tobytes()) & 0xFFFFFFFF
+
+
+def fresh_init(kind):
+    from ubteacher.modeling import build_model
+    from ubteacher.presets import get_config
+    cfg = get_config(kind, 1, ["MODEL.DEVICE", "cpu", "SEMISUPNET.BURN_UP_STEP", 0])
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    return {k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}
+
+
+def gen(kind):
+    label = unlabel = 1
+    dump = os.path.join(tempfile.gettempdir(), "utv2_fullsize_%s_%d.pt" % (kind, os.getpid()))
+    out = bench.cpu_baseline_run(kind, label, unlabel, 0, 1, dump=dump)
+    d = torch.load(dump, weights_only=False)
+    os.remove(dump)
+    init = fresh_init(kind)
+    fx = {"kind": kind, "label": label, "unlabel": unlabel, "batch_seed": 0, "init_seed": 0, "keep_rate": float(d["keep_rate"])}
+    # inputs
+    lq, lk, uq, uk = d["batch"]
+    fx["image_crc"] = np.asarray([crc(x["image"]) for part in (lq, lk, uq, uk) for x in part], np.uint64)
+    for i, x in enumerate(lk):
+        fx["lab%d_boxes" % i] = x["gt"]["boxes"].numpy()
+        fx["lab%d_classes" % i] = x["gt"]["classes"].numpy()
+    # initial weights: fingerprints of the untouched initialisation, the changed tensors as data
+    fkeys = [k for k in init if init[k].dtype.is_floating_point]
+    fx["init_keys"] = np.asarray(fkeys)
+    fx["init_fp"] = np.stack([state_fingerprint(init[k]) for k in fkeys])
+    changed_s = [k for k in init if not torch.equal(init[k], d["student"][k])]
+    changed_t = [k for k in init if not torch.equal(d["student"][k], d["teacher"][k])]
+    fx["student_changed"] = np.asarray(changed_s)
+    fx["teacher_changed"] = np.asarray(changed_t)
+    for k in changed_s:
+        fx["student::" + k] = d["student"][k].numpy()
+    for k in changed_t:
+        fx["teacher::" + k] = d["teacher"][k].numpy()
+    # expected outputs
+    for k, v in d["record"].items():
+        fx["rec_" + k] = np.float64(float(v))
+    if kind == "fcos":
+        fx["pseudo_cls"], fx["pseudo_reg"] = np.int64(d["pseudo"]["cls"]), np.int64(d["pseudo"]["reg"])
+    else:
+        fx["pseudo"] = np.int64(d["pseudo"])
+        fx["key_seed"] = np.int64(99)
+        fx["rpn_keys_shape"] = np.asarray([list(d["rpn_keys"][0].shape), list(d["rpn_keys"][1].shape)], np.int64)
+        fx["rpn_keys_crc"] = np.asarray([crc(d["rpn_keys"][0]), crc(d["rpn_keys"][1])], np.uint64)
+        fx["roi_draws"] = np.asarray([[n, g] for n, g, _ in d["roi_keys"]], np.int64)
+        fx["roi_keys_crc"] = np.asarray([crc(k) for _, _, k in d["roi_keys"]], np.uint64)
+    path = os.path.join(HERE, "fullsize_%s.npz" % kind)
+    np.savez_compressed(path, **fx)
+    print(path, os.path.getsize(path), "bytes;", {k: float(v) for k, v in d["record"].items()}, d["pseudo"], "%.1f s/step" % out["step_seconds"][0])
+
+
+if __name__ == "__main__":
+    for kind in (sys.argv[1:] or ["fcos", "rcnn"]):
+        gen(kind)

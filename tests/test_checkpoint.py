@@ -103,6 +103,8 @@ class _Opt:
         return {"momentum_buffer": self.mom, "lr": self.lr}
 
     def load_state_dict(self, sd):
+        if "momentum_buffer" not in sd:
+            raise ValueError("not an ArenaSGD state")
         self.mom = sd["momentum_buffer"].clone()
         self.lr = sd["lr"]
 
@@ -183,3 +185,96 @@ def test_weights_path_resolution_and_non_resume_semantics(tmp_path, monkeypatch)
     DetectionCheckpointer(m, str(tmp_path / "e")).resume_or_load(str(plain), resume=False)
     for (k, v), (_, w) in zip(a.modelTeacher.state_dict().items(), m.state_dict().items()):
         assert torch.equal(v, w), k
+
+
+def test_arena_sgd_state_is_per_key_and_layout_independent(tmp_path, monkeypatch):
+    """the momentum arena's layout follows the parameter arena's, which depends on the build (paired FCOS towers merge
+    cls_tower / bbox_tower tensors into one handle).  The optimizer state is saved per state_dict key through the weights' export views:
+    a checkpoint written under one layout resumes under another with every tensor's momentum on that tensor; a torch.optim.SGD
+    state (the reference's checkpoints) maps by Detectron2's parameter order with shape checks; the old flat form is refused."""
+    import pytest
+    from ubteacher.engine.trainer import ArenaSGD
+    from ubteacher.modeling import build_model
+    from ubteacher.presets import get_config
+    cfg = get_config("fcos", 1, ["MODEL.DEVICE", "cpu"])
+    torch.manual_seed(0)
+    a = build_model(cfg)
+    oa = ArenaSGD(cfg, a)
+    g = torch.Generator().manual_seed(1)
+    oa.store.mom.copy_(torch.randn(oa.store.mom.shape, generator=g))
+    oa.param_groups[0]["lr"] = 0.0123
+    sd = oa.state_dict()
+    assert "momentum_buffer" not in sd and list(sd["momentum"]) == [k for k in a.state_dict() if k in sd["momentum"]]
+    k_cls, k_box = "proposal_generator.fcos_head.cls_tower.3.weight", "proposal_generator.fcos_head.bbox_tower.3.weight"
+    assert tuple(sd["momentum"][k_cls].shape) == tuple(a.state_dict()[k_cls].shape) == (256, 256, 3, 3)
+    assert not torch.equal(sd["momentum"][k_cls], sd["momentum"][k_box])
+    # another layout of the same model: the two towers as separate chains
+    monkeypatch.setenv("UTV2_PAIR_TOWERS", "0")
+    b = build_model(cfg)
+    monkeypatch.delenv("UTV2_PAIR_TOWERS")
+    ob = ArenaSGD(cfg, b)
+    assert [h.shape for h in a.store.handles] != [h.shape for h in b.store.handles]          # the arenas really differ
+    assert list(a.state_dict()) == list(b.state_dict())                                       # the surface does not
+    ob.load_state_dict(sd)
+    assert ob.param_groups[0]["lr"] == 0.0123
+    back = ob.state_dict()["momentum"]
+    for k, v in sd["momentum"].items():
+        assert torch.equal(back[k], v), k
+    assert not torch.equal(oa.store.mom, ob.store.mom)            # a flat copy would have been wrong
+    # through a file
+    from ubteacher.checkpoint import DetectionTSCheckpointer
+    from ubteacher.modeling.ts_ensemble import EnsembleTSModel
+    DetectionTSCheckpointer(EnsembleTSModel(a, a), str(tmp_path), optimizer=oa).save("model_0000001", iteration=1)
+    ob.store.mom.zero_()
+    ck = DetectionTSCheckpointer(EnsembleTSModel(b, b), str(tmp_path), optimizer=ob)
+    ck.resume_or_load("", resume=True)
+    assert not ck.last_optimizer_skipped
+    for k, v in sd["momentum"].items():
+        assert torch.equal(ob.state_dict()["momentum"][k], v), k
+    # the flat form of rounds 1-3 carries no layout: refused
+    with pytest.raises(ValueError, match="flat"):
+        ob.load_state_dict({"momentum_buffer": oa.store.mom.clone(), "lr": 0.1})
+    # a torch.optim.SGD state in Detectron2's parameter order: weights / biases (group 0), then norm parameters (group 1)
+    keys = list(sd["momentum"])
+    norm = [k for k in keys if ".cls_tower." in k or ".bbox_tower." in k]
+    norm = [k for k in norm if int(k.split("_tower.")[1].split(".")[0]) % 3 == 1]            # GroupNorm weight / bias
+    assert len(norm) == 16
+    dec = [k for k in keys if k not in norm]
+    state = {i: {"momentum_buffer": sd["momentum"][k].clone()} for i, k in enumerate(dec + norm)}
+    torch_sd = {"state": state, "param_groups": [{"lr": 0.5, "weight_decay": 1e-4, "params": list(range(len(dec)))},
+                                                 {"lr": 0.5, "weight_decay": 0.0, "params": list(range(len(dec), len(keys)))}]}
+    ob.store.mom.zero_()
+    ob.load_state_dict(torch_sd)
+    assert ob.param_groups[0]["lr"] == 0.5
+    for k, v in sd["momentum"].items():
+        assert torch.equal(ob.state_dict()["momentum"][k], v), k
+    state[3]["momentum_buffer"] = torch.zeros(7)                                              # a shape that cannot be this tensor's
+    before = ob.store.mom.clone()
+    with pytest.raises(ValueError, match="size mismatch"):
+        ob.load_state_dict(torch_sd)
+    assert torch.equal(ob.store.mom, before)                                                  # nothing written on failure
+
+
+def test_amp_scaler_state_round_trips(tmp_path):
+    """the fp16 loss-scale state (scale, growth tracker) is a checkpointable (`grad_scaler`), not restarted at 65536"""
+    from ubteacher.checkpoint import DetectionTSCheckpointer
+    from ubteacher.engine.trainer import AmpScalerState
+
+    class T:
+        _amp_state = torch.tensor([1024.0, 0.0, 37.0])
+    t1, t2 = T(), T()
+    t2._amp_state = torch.tensor([65536.0, 0.0, 0.0])
+
+    class M:
+        def state_dict(self):
+            return {"modelStudent.w": torch.zeros(1)}
+
+        def load_state_dict(self, sd, strict=False):
+            pass
+    DetectionTSCheckpointer(M(), str(tmp_path), grad_scaler=AmpScalerState(t1)).save("model_0000005", iteration=5)
+    ck = DetectionTSCheckpointer(M(), str(tmp_path), grad_scaler=AmpScalerState(t2))
+    assert ck.last_optimizer_skipped is False            # initialised (ADVICE r3: the attribute used to exist only after a skipped load)
+    ck.resume_or_load("", resume=True)
+    assert t2._amp_state.tolist() == [1024.0, 0.0, 37.0]
+    t3 = T(); t3._amp_state = None                       # bf16 / f32 run resuming an fp16 checkpoint: ignored
+    DetectionTSCheckpointer(M(), str(tmp_path), grad_scaler=AmpScalerState(t3)).resume_or_load("", resume=True)

@@ -93,3 +93,24 @@ def test_bench_dry_nccl_selfcheck_two_ranks():
     rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert rep["n_gpus"] == 2 and rep["rccl_ranks"] == 2 and rep["rccl"]["ok"] and rep["rccl"]["sum"] == 1.0
     assert sorted(rep["rccl"]["devices"]) == [0, 1]
+
+
+def _fails_after_joining(out_dir):
+    from ubteacher.engine.launch import dist_info
+    with open(os.path.join(out_dir, "runs.txt"), "a") as f:
+        f.write("rank%d\n" % dist_info()["rank"])
+    raise OSError("[Errno 98] Address already in use (a socket main_func opened itself)")
+
+
+def test_address_in_use_after_the_rendezvous_is_not_retried(tmp_path, monkeypatch):
+    """only the rendezvous is retried on EADDRINUSE; the same message raised by main_func after the ranks joined propagates
+    (re-running main_func from scratch would repeat training progress and checkpoint writes)"""
+    sys.path.insert(0, PKG)
+    from ubteacher.engine.launch import launch
+    monkeypatch.setenv("UTV2_DIST_BACKEND", "gloo")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
+    with pytest.raises(Exception, match="Address already in use"):
+        launch(_fails_after_joining, 2, args=(str(tmp_path),))
+    runs = open(tmp_path / "runs.txt").read().split()
+    assert len(runs) <= 2 and len(set(runs)) == len(runs), runs      # every rank ran main_func at most once

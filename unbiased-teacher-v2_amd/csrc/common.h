@@ -105,7 +105,7 @@ struct EpiBits {
 };
 
 // One operand combination of epilogue_rows' 16-bit path, fixed at compile time (see the LEAN dispatch there).  Order of operations as in
-// the general path: value = acc * scale + bias; mask plane; + residual; post-mask plane; max(lo) (lo = 0: ReLU, -inf: none); round; store;
+// the general path: value = acc * scale + bias; mask plane; + residual; post-mask plane; ReLU (lo = 0) or nothing (lo = -inf: non-finite values propagate as in the general path); round; store;
 // ReLU bit plane; GroupNorm partial sums.
 template <int TN, bool RES, bool MB, bool PB>
 __device__ __forceinline__ void epilogue_rows_lean(const f32x16 (&acc)[2][TN], float* lds, int lane, h16_t* __restrict__ y,
@@ -114,6 +114,7 @@ __device__ __forceinline__ void epilogue_rows_lean(const f32x16 (&acc)[2][TN], f
   constexpr int COLS = TN * 32, LD = COLS + 4, CV = COLS / 8, RPI = 64 / CV;
   const int frow = lane & 31, fh = lane >> 5;
   const int cv = lane % CV, rsub = lane / CV;
+  const bool relu_on = lo == 0.f;   // lo: 0 = ReLU, -inf = none (wave-uniform)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     float gs = 0.f, gq = 0.f;
@@ -160,7 +161,7 @@ __device__ __forceinline__ void epilogue_rows_lean(const f32x16 (&acc)[2][TN], f
       }
       bf16x8_t o;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) o[q] = (h16_t)fmaxf(v[q], lo);
+      for (int q = 0; q < 8; ++q) o[q] = (h16_t)(relu_on ? fmaxf(v[q], 0.f) : v[q]);   // no ReLU: the value as is (a NaN stays a NaN, as in the general path)
       if (in) {
         *(bf16x8_t*)(y + off) = o;
         if (eb.relu_bits) {

@@ -95,12 +95,26 @@ def load_checkpoint_file(path):
     return torch.load(path, map_location="cpu")
 
 
+def _to_cpu(obj):
+    if torch.is_tensor(obj):
+        return obj.detach().cpu()
+    if isinstance(obj, dict):
+        return type(obj)((k, _to_cpu(v)) for k, v in obj.items())
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to_cpu(v) for v in obj)
+    return obj
+
+
 class DetectionTSCheckpointer:
-    def __init__(self, model, save_dir="", optimizer=None, scheduler=None):
+    def __init__(self, model, save_dir="", optimizer=None, scheduler=None, **checkpointables):
         self.model = model
         self.save_dir = save_dir
         self.optimizer = optimizer
         self.scheduler = scheduler
+        # further objects with state_dict() / load_state_dict(), saved under their keyword (Detectron2 Checkpointer(**checkpointables)
+        # [D2-recall]): the trainers register the fp16 loss scaler as `grad_scaler`
+        self.extra = dict(checkpointables)
+        self.last_optimizer_skipped = False   # set by every load(): True when the file's optimizer state could not be applied
         # resuming from a checkpoint whose optimizer entry is a torch.optim state (every reference-produced teacher/student checkpoint):
         # False = warn and resume weights / scheduler / iteration with zero momentum; True = refuse
         self.strict_optimizer = False
@@ -119,9 +133,11 @@ class DetectionTSCheckpointer:
         os.makedirs(self.save_dir, exist_ok=True)
         data = {"model": {k: v.detach().cpu().contiguous() for k, v in self.model.state_dict().items()}}
         if self.optimizer is not None:
-            data["optimizer"] = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in self.optimizer.state_dict().items()}
+            data["optimizer"] = _to_cpu(self.optimizer.state_dict())
         if self.scheduler is not None:
             data["scheduler"] = self.scheduler.state_dict()
+        for name, obj in self.extra.items():
+            data[name] = obj.state_dict()
         data.update(kwargs)
         fn = "{}.pth".format(name)
         torch.save(data, os.path.join(self.save_dir, fn))
@@ -136,24 +152,26 @@ class DetectionTSCheckpointer:
         path = resolve_path(path)
         ck = load_checkpoint_file(path)
         self._load_model(ck, ck.get("model", ck))
-        want = ("optimizer", "scheduler") if checkpointables is None else tuple(checkpointables)
+        want = ("optimizer", "scheduler") + tuple(self.extra) if checkpointables is None else tuple(checkpointables)
+        self.last_optimizer_skipped = False
         if "optimizer" in want and "optimizer" in ck and self.optimizer is not None:
-            osd = ck["optimizer"]
-            if isinstance(osd, dict) and "momentum_buffer" in osd:
-                self.optimizer.load_state_dict(osd)
-            elif self.strict_optimizer:
-                raise ValueError("checkpoint {!r}: the optimizer state is not an ArenaSGD state (a torch.optim state_dict of the reference "
-                                 "cannot be mapped onto the flat momentum arena); load it without resuming to take the weights only"
-                                 .format(path))
-            else:
-                # a reference (torch.optim.SGD) checkpoint: weights, scheduler and iteration resume, the momentum restarts from zero
+            try:
+                self.optimizer.load_state_dict(ck["optimizer"])
+            except ValueError as e:
+                if self.strict_optimizer:
+                    raise ValueError("checkpoint {!r}: the optimizer state cannot be mapped onto this model's ArenaSGD state ({}); load it "
+                                     "without resuming to take the weights only".format(path, e))
+                # weights, scheduler and iteration resume, the momentum restarts from zero
                 import logging
                 logging.getLogger(__name__).warning(
-                    "checkpoint %r holds a torch.optim optimizer state that cannot be mapped onto the flat momentum arena: resuming "
-                    "model / scheduler / iteration WITHOUT momentum (set checkpointer.strict_optimizer = True to make this an error)", path)
+                    "checkpoint %r holds an optimizer state that cannot be mapped onto this model (%s): resuming model / scheduler / "
+                    "iteration WITHOUT momentum (set checkpointer.strict_optimizer = True to make this an error)", path, e)
                 self.last_optimizer_skipped = True
         if "scheduler" in want and "scheduler" in ck and self.scheduler is not None:
             self.scheduler.load_state_dict(ck["scheduler"])
+        for name, obj in self.extra.items():
+            if name in want and name in ck:
+                obj.load_state_dict(ck[name])
         return ck
 
     def _load_model(self, ck, sd):

@@ -40,13 +40,16 @@ def _backend():
     return os.environ.get("UTV2_DIST_BACKEND", "nccl")
 
 
-def _bind_and_join(rank, local_rank, world_size, dist_url, expect_world):
+def _bind_and_join(rank, local_rank, world_size, dist_url, expect_world, external=False):
     single_dev = os.environ.get("UTV2_BENCH_SINGLE_DEVICE") == "1"  # dry runs of the N > 1 path on a box with one GPU
     dev = 0 if single_dev else local_rank
     if torch.cuda.is_available():
         nvis = torch.cuda.device_count()
-        if not single_dev and nvis == 1 and local_rank > 0:
-            dev = 0   # started with one visible device per process (CUDA/HIP_VISIBLE_DEVICES set by the external launcher)
+        if not single_dev and external and nvis == 1 and local_rank > 0:
+            # an EXTERNAL launcher (torch.distributed.run) may start each rank with its own one-device view (CUDA/HIP_VISIBLE_DEVICES per
+            # process).  Ranks spawned here all inherit the parent's view: there one visible GPU for N ranks stays the hard error below
+            # (N ranks on one device would hang or fail inside RCCL with a duplicate-GPU error).
+            dev = 0
         elif not single_dev and nvis <= dev:
             # the device THIS rank binds must exist; the world size is not a device count (ranks may see one device each)
             raise RuntimeError("launch: rank %d (local rank %d) binds device %d but only %d GPUs are visible"
@@ -63,10 +66,12 @@ def _bind_and_join(rank, local_rank, world_size, dist_url, expect_world):
                  device=dev)
 
 
-def _worker(local_rank, main_func, world_size, dist_url, args):
+def _worker(local_rank, main_func, world_size, dist_url, args, joined=None):
     os.environ["RANK"] = os.environ["LOCAL_RANK"] = str(local_rank)
     os.environ["WORLD_SIZE"] = os.environ["LOCAL_WORLD_SIZE"] = str(world_size)
     _bind_and_join(local_rank, local_rank, world_size, dist_url, world_size)
+    if joined is not None:
+        joined[local_rank] = 1     # the rendezvous succeeded: from here on nothing is retried (see launch)
     try:
         main_func(*args)
     finally:
@@ -88,7 +93,7 @@ def launch(main_func, num_gpus_per_machine, num_machines=1, machine_rank=0, dist
             raise RuntimeError("launch: started inside a world of %d ranks (WORLD_SIZE) but %d GPUs were requested" % (world, n))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         url = "env://"
-        _bind_and_join(int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"])), world, url, n)
+        _bind_and_join(int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"])), world, url, n, external=True)
         try:
             return main_func(*args)
         finally:
@@ -107,15 +112,20 @@ def launch(main_func, num_gpus_per_machine, num_machines=1, machine_rank=0, dist
     if dist_url not in (None, "auto"):
         mp.spawn(_worker, nprocs=n, args=(main_func, n, dist_url, args), join=True)
         return None
-    # find_free_port closes its probe socket before the workers bind: another process can take the port in between.  A rendezvous
-    # that dies on EADDRINUSE is retried on a fresh port (anything else propagates).
+    # find_free_port closes its probe socket before the workers bind: another process can take the port in between.  A RENDEZVOUS
+    # that dies on EADDRINUSE is retried on a fresh port; once any worker has joined the process group (it then runs main_func: training
+    # progress, checkpoint writes) nothing is retried - an "address already in use" raised later by main_func itself (a metrics or
+    # dataloader socket) propagates like any other error instead of re-running the job from scratch.
+    ctx = mp.get_context("spawn")
     for attempt in range(4):
         dist_url = "tcp://127.0.0.1:%d" % find_free_port()
+        joined = ctx.Array("i", n)     # one flag per rank, set right after init_process_group returned
         try:
-            mp.spawn(_worker, nprocs=n, args=(main_func, n, dist_url, args), join=True)
+            mp.spawn(_worker, nprocs=n, args=(main_func, n, dist_url, args, joined), join=True)
             return None
         except Exception as e:  # noqa: BLE001
             msg = str(e)
-            if attempt == 3 or not ("EADDRINUSE" in msg or "Address already in use" in msg or "address already in use" in msg):
+            in_use = "EADDRINUSE" in msg or "Address already in use" in msg or "address already in use" in msg
+            if attempt == 3 or not in_use or any(joined[:]):
                 raise
     return None

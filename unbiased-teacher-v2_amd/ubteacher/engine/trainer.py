@@ -70,12 +70,92 @@ class ArenaSGD:
         if bank is not None:
             bank.refresh_ahead()     # the dgrad weight images of the new weights, on a side stream: ready long before the next backward
 
+    # ---- checkpoint surface -----------------------------------------------------------------------------------------------
+    # The momentum arena is laid out like the parameter arena, and that layout is an implementation detail (the paired FCOS towers
+    # merge cls_tower / bbox_tower tensors into one handle, conditional on the config): a flat copy would resume silently with the
+    # momentum of one tensor applied to another after any layout change.  The state is therefore saved PER state_dict KEY, through
+    # the same export views as the weights (reference key names and shapes), and loaded key by key with shape checks.
+    def _momentum_views(self):
+        """OrderedDict key -> (handle, exported view of the momentum arena, kind) in the model's state_dict (= reference) key order"""
+        st = self.store
+        per_key = {}
+        for h in st.handles:
+            if h.kind not in ("decay", "nodecay"):
+                continue
+            m = st.mom[h.offset: h.offset + h.numel].view(h.shape)
+            for key, fn in h.exports:
+                per_key[key] = (h, m if fn is None else fn(m), m)
+        return OrderedDict((k, per_key[k]) for k in st.state_dict() if k in per_key)
+
     def state_dict(self):
-        return {"momentum_buffer": self.store.mom, "lr": self.param_groups[0]["lr"]}
+        mv = self._momentum_views()
+        return {"format": "utv2-arena-sgd/2", "lr": self.param_groups[0]["lr"],
+                "momentum": OrderedDict((k, v.detach().clone().contiguous()) for k, (_, v, _) in mv.items())}
+
+    def _load_momentum(self, per_key):
+        mv = self._momentum_views()
+        missing = [k for k in mv if k not in per_key]
+        unexpected = [k for k in per_key if k not in mv]
+        if missing or unexpected:
+            raise ValueError("optimizer state does not match this model's trainable tensors: missing %s unexpected %s"
+                             % (missing[:4], unexpected[:4]))
+        for k, (h, view, raw) in mv.items():
+            src = per_key[k]
+            if tuple(src.shape) != tuple(view.shape):
+                raise ValueError("optimizer state: size mismatch for %s: %s vs %s" % (k, tuple(src.shape), tuple(view.shape)))
+        with torch.no_grad():
+            for k, (h, view, raw) in mv.items():
+                src = per_key[k].to(device=raw.device, dtype=raw.dtype)
+                if k in h.loaders:
+                    h.loaders[k](raw, src)
+                else:
+                    view.copy_(src)
 
     def load_state_dict(self, sd):
-        self.store.mom.copy_(sd["momentum_buffer"])
-        self.param_groups[0]["lr"] = sd["lr"]
+        """Accepts (1) this class's per-key state; (2) a torch.optim.SGD state_dict as the reference's checkpoints hold it
+        (Detectron2 build_optimizer: one entry per trainable parameter in model.named_parameters() order, grouped by equal
+        hyper-parameters in order of first appearance - weights / biases first, norm parameters (WEIGHT_DECAY_NORM) second
+        [D2-recall]; every buffer is shape-checked against the tensor it is mapped to, any mismatch raises ValueError and nothing
+        is written).  The round-1..3 flat `momentum_buffer` form carried no layout information and is refused."""
+        if isinstance(sd, dict) and "momentum" in sd and str(sd.get("format", "")).startswith("utv2-arena-sgd"):
+            self._load_momentum(sd["momentum"])
+            self.param_groups[0]["lr"] = sd["lr"]
+            return
+        if isinstance(sd, dict) and "state" in sd and "param_groups" in sd:
+            mv = self._momentum_views()
+            order = [k for k, (h, _, _) in mv.items() if h.kind == "decay"] + [k for k, (h, _, _) in mv.items() if h.kind == "nodecay"]
+            ids = [i for g in sd["param_groups"] for i in g["params"]]
+            if len(ids) != len(order):
+                raise ValueError("optimizer state holds %d parameters, this model trains %d" % (len(ids), len(order)))
+            per_key = {}
+            for k, i in zip(order, ids):
+                buf = sd["state"].get(i, {}).get("momentum_buffer")
+                per_key[k] = torch.zeros_like(mv[k][1]) if buf is None else buf
+            self._load_momentum(per_key)
+            self.param_groups[0]["lr"] = sd["param_groups"][0]["lr"]
+            return
+        raise ValueError("not an ArenaSGD state (a flat `momentum_buffer` without key names cannot be mapped safely onto the arena)")
+
+
+class AmpScalerState:
+    """checkpointable view of the device-side GradScaler state {scale, found_inf, growth tracker} (fp16 mode; reference
+    engine/trainer.py:207 GradScaler, saved by Detectron2's AMPTrainer.state_dict [D2-recall])"""
+
+    def __init__(self, trainer):
+        self.trainer = trainer
+
+    def state_dict(self):
+        st = self.trainer._amp_state
+        if st is None:
+            return {}
+        scale, _, tracker = st.detach().cpu().tolist()
+        return {"scale": scale, "_growth_tracker": int(tracker)}
+
+    def load_state_dict(self, sd):
+        st = self.trainer._amp_state
+        if st is None or not sd:
+            return
+        st.copy_(torch.tensor([float(sd["scale"]), 0.0, float(sd.get("_growth_tracker", 0))], dtype=torch.float32))
 
 
 class WarmupMultiStepLR:
@@ -220,7 +300,8 @@ class _TrainerBase:
         self._last_metrics = {}
         ensem = EnsembleTSModel(self.model_teacher, self.model)
         self.ensem_ts_model = ensem
-        self.checkpointer = DetectionTSCheckpointer(ensem, cfg.OUTPUT_DIR, optimizer=self.optimizer, scheduler=self.scheduler)
+        self.checkpointer = DetectionTSCheckpointer(ensem, cfg.OUTPUT_DIR, optimizer=self.optimizer, scheduler=self.scheduler,
+                                                    grad_scaler=AmpScalerState(self))
         self._setup_grad_sync()
         self.sync_replicas()
 

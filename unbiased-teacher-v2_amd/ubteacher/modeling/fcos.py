@@ -15,6 +15,8 @@ arguments, re-laid-out for MI355X:
 """
 import math
 
+import os
+
 import torch
 
 from .. import hip, ops
@@ -271,7 +273,8 @@ class FCOSHead:
         # depth instead of two (the 256-tile kernel runs whole rounds of 256 tiles; 2 x 1050 tiles = 8 rounds + 52 instead of
         # 2 x (4 rounds + 26)), half the split-K slabs of the weight gradients (18 tiles x 14 pixel splits instead of 2 x 9 x 28), and the
         # two gradients of the FPN feature are summed inside depth 0's dgrad K loop instead of by an add pass.
-        self.paired = fc.NUM_CLS_CONVS == fc.NUM_BOX_CONVS and fc.NUM_SHARE_CONVS == 0 and fc.NUM_CLS_CONVS > 0
+        self.paired = (fc.NUM_CLS_CONVS == fc.NUM_BOX_CONVS and fc.NUM_SHARE_CONVS == 0 and fc.NUM_CLS_CONVS > 0
+                       and os.environ.get("UTV2_PAIR_TOWERS", "1") != "0")      # 0: two separate chains (A/B knob; another arena layout)
         if self.paired:
             n = fc.NUM_CLS_CONVS
             ws = []
