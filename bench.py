@@ -25,9 +25,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse headline)
 
 
-def tune_for_pseudo_labels(trainer, batch, target_std=1.5, bias=-6.0):
+def tune_for_pseudo_labels(trainer, batch, target_std=1.5, per_image=40):
     """Random-init weights give no confident detections; rescale the student's cls_logits (on the
-    device, with the product's own forward) so the teacher emits some pseudo boxes per image."""
+    device, with the product's own forward) so the teacher emits some pseudo boxes per image: logits of std `target_std`, the bias
+    placed so that ~`per_image` logits per weak image clear p = 0.6 (as cpu_baseline_run does for the oracle's copy of the problem):
+    both pseudo-label sets (criteria "cls" and "cls_n_loc", threshold 0.5) are non-empty and the classification branch is not degenerate."""
     from ubteacher.modeling.fcos import PaddedBoxes  # noqa: F401
     m = trainer.model
     sd = m.state_dict()
@@ -39,11 +41,14 @@ def tune_for_pseudo_labels(trainer, batch, target_std=1.5, bias=-6.0):
     m.eval()
     with torch.no_grad():
         _, raw = m(batch[3], output_raw=True, nms_method="cls", branch="teacher_weak")
-        s = torch.cat([x.reshape(-1) for x in raw["logits_pred"]]).std()
+        lg = torch.cat([x.reshape(-1) for x in raw["logits_pred"]]).float()
+        s = lg.std()
+        scale = target_std / s.clamp(min=1e-12)
+        kth = torch.topk(lg, per_image * len(batch[3])).values[-1] * scale
     m.train()
     m.store.touch()
-    w.mul_(target_std / s.clamp(min=1e-12))
-    b.fill_(bias)
+    w.mul_(scale)
+    b.fill_(float(0.405 - kth))
     sd["proposal_generator.fcos_head.bbox_pred_std.bias"].fill_(-3.0)
     m.store.touch()
     trainer._update_teacher_model(keep_rate=0.0)  # teacher := student
@@ -470,9 +475,12 @@ def parity_fullsize(dump, device_index):
         torch.cuda.synchronize()
         gl = tr._last_pseudo
         extra = {"pseudo_boxes": {"oracle": d["pseudo"], "product": int(gl["valid"].sum())}, "key_draws_replayed": dict(calls)}
-        # as tests/test_rcnn_step_gpu.py: the two pseudo RPN terms hang on exact-equality / near-tie selections against pseudo boxes
-        # that differ by 1e-5 between the two teachers (loss_rpn_loc_pseudo has weight 0 in the objective, trainer.py:888-890)
-        tol = {"loss_rpn_loc_pseudo": 2e-2, "loss_rpn_cls_pseudo": 5e-3}
+        # as tests/test_rcnn_step_gpu.py: the two pseudo RPN terms hang on the Matcher's exact-equality low-quality rule against pseudo
+        # boxes that differ by ~1e-5 px between the two teachers - anchors of equal area INSIDE a pseudo box tie at the 1-ulp level of the
+        # fp32 IoU, and which of them tie changes with the last bits of the box (tests/test_rcnn_conditioning.py shows 18 vs 8 positives
+        # for one real box pair on the oracle alone).  loss_rpn_loc_pseudo - a sum over <= 64 sampled positives per image - has weight
+        # 0 in the objective (trainer.py:888-890); with the SAME pseudo boxes on both sides both terms agree to 1e-6.
+        tol = {"loss_rpn_loc_pseudo": 1e-1, "loss_rpn_cls_pseudo": 5e-3}
     dev_ = {k: abs(rec[k] - v) / max(abs(v), 1e-12) for k, v in ref.items() if k.startswith("loss") and k in rec}
     out = {"mode": "f32", "model": kind, "images": "%d labeled (weak+strong) + %d unlabeled 1333x800" % (len(lq), len(uq)), "tolerance": 1e-3,
            "rel_dev": dev_, "max_rel_dev": max(dev_.values()) if dev_ else None,
@@ -704,6 +712,17 @@ def worker(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         devices = comm.all_gather_object(device_index)
+    replicas = None
+    if world > 1:
+        # data parallel keeps the replicas in lock step (the reference wraps the student in DDP, engine/trainer.py:59-63,631-635; the
+        # teacher's EMA is local and deterministic): bit-exact fingerprints of every rank's student and teacher after the timed steps
+        import hashlib
+
+        def digest(t):
+            return hashlib.sha1(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+        fps = comm.all_gather_object((digest(tr.model.flat_state()), digest(tr.model_teacher.flat_state())))
+        replicas = {"students_bit_identical": len({f[0] for f in fps}) == 1, "teachers_bit_identical": len({f[1] for f in fps}) == 1,
+                    "ranks_compared": len(fps)}
     metrics = tr.flush_metrics()
     amp_state = tr._amp_state.cpu().tolist() if getattr(tr, "_amp_state", None) is not None else None
     pseudo_count = pseudo_counts(tr)
@@ -883,7 +902,7 @@ def worker(args):
                                             "losses / weight gradients / master weights",
                                      "f32": "fp32 MFMA, fp32 everywhere"}[args.dtype]},
             "ranks": {"world_size": world, "backend": info["backend"], "devices": devices,
-                      "launcher": _launcher_name(world), "rccl_selfcheck": rccl},
+                      "launcher": _launcher_name(world), "rccl_selfcheck": rccl, "replicas": replicas},
             "host": {"ms_per_step_on_96x128_images": host_ms, "enqueue_ms_per_step": 1e3 * t_host / args.steps,
                      "cabi_calls_per_step": calls_per_step, "gpu_dispatches": dispatches_per_step(args.model) if args.dtype != "f32" else None},
             "losses": {k: v for k, v in metrics.items() if k.startswith("loss") or k.startswith("teacher")},

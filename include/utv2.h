@@ -254,6 +254,17 @@ int utv2_fcos_loc_terms_fwd(const int* labels, const float* box, int box_stride,
 int utv2_fcos_loc_terms_bwd(const int* labels, const float* box, int box_stride, const float* reg_targets,
                             const float* bvars, int64_t P, int num_classes, int reg_max, float ts_better, float ts_cert,
                             int flags, const float* coef, float* dbox, utv2_stream_t stream);
+/* The backward launches of SEVERAL loss branches of one fused student pass into ONE gradient tensor per head output (the supervised,
+ * pseudo-classification and pseudo-regression target sets of engine/trainer.py:396-411 all differentiate the same logits / box
+ * buffers): coef = the d total / d sum vector of utv2_fcos_loss_combine for this branch (focal: 1 float; loc terms: the 8 floats of
+ * d total / d sums[8], read at [2], [3], [4], [6]), gscale = optional device scalar multiplied in (the node's upstream gradient).
+ * accumulate 0: writes every row (zeros where the branch has no gradient); 1: rows without a gradient (label < 0; for the location
+ * terms also background) are left untouched, the others ADDED - no per-branch gradient tensors, no elementwise add passes. */
+int utv2_sigmoid_focal_bwd_acc(const float* logits, const int* labels, int64_t P, int C, float alpha, float gamma, const float* coef,
+                               const float* gscale, float* dlogits, int accumulate, utv2_stream_t stream);
+int utv2_fcos_loc_terms_bwd_acc(const int* labels, const float* box, int box_stride, const float* reg_targets, const float* bvars,
+                                int64_t P, int num_classes, int reg_max, float ts_better, float ts_cert, int flags, const float* coef8,
+                                const float* gscale, float* dbox, int accumulate, utv2_stream_t stream);
 /* scalar tail of the FCOS losses of a fused student pass (normalisation fcos_outputs.py:317-321,361-362,381-416; pseudo branch
  * :504-585; loss weighting engine/trainer.py:396-417): the raw sums of utv2_sigmoid_focal_fwd / utv2_fcos_loc_terms_fwd of the
  * supervised, pseudo-cls and pseudo-reg target sets -> rec[8] = {cls, loc, ctr, cls_pseudo, ctr_pseudo, loc_pseudo,
@@ -284,7 +295,7 @@ int utv2_scale_cols_bwd(float* g, const float* ypost, int64_t rows, int row_stri
                         float* ws, utv2_stream_t stream);
 /* the Scale layers of ALL levels of a level-first matrix at once (one launch forward, two backward instead of four per level):
  * row0_host = host int64[nlev + 1] (first row of each level, then the end), s_host / sgrad_host = host arrays of nlev DEVICE pointers
- * (the per-level scalar and its gradient, accumulated: sgrad_l += sum(g_in * ypost) / s_l).  nlev <= 8; ws >= nlev * 256 floats */
+ * (the per-level scalar and its gradient, accumulated: sgrad_l += sum(g_in * ypost) / s_l).  nlev <= 8; ws >= nlev * 1024 floats */
 int utv2_scale_cols_ml(float* y, int nlev, const int64_t* row0_host, int row_stride, int ncols, const float* const* s_host,
                        utv2_stream_t stream);
 int utv2_scale_cols_bwd_ml(float* g, const float* ypost, int nlev, const int64_t* row0_host, int row_stride, int ncols,

@@ -145,3 +145,26 @@ def test_rccl_world_of_one_rank_dry_run_and_step():
     rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert rep["ranks"]["backend"] == "nccl" and rep["ranks"]["rccl_selfcheck"]["ok"] and rep["value"] > 0
     assert all(v == v for v in rep["losses"].values())   # finite (no NaN)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the real RCCL path between two devices (a one-GPU test box skips it)")
+def test_two_gpus_real_rccl_bench_gate():
+    """The first thing to run on a multi-GPU node: `bench.py --gpus 2` over RCCL (nccl backend, one rank per GPU, gradients of the
+    student all-reduced in buckets during backward - reference engine/trainer.py:59-63,631-635 DDP).  Both ranks answered the RCCL
+    self-check, the replicas are bit-identical after the timed steps, and two GPUs process more than 1.6x the images of one
+    (weak scaling, 4+4 per GPU)."""
+    import json
+    common = ["--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-f32", "--no-rcnn", "--timed-only"]
+    r1 = _bench({}, ["--gpus", "1", *common])
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    r2 = _bench({}, ["--gpus", "2", *common], timeout=1200)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["ranks"]["world_size"] == 2 and two["ranks"]["backend"] == "nccl"
+    assert two["ranks"]["rccl_selfcheck"]["ok"] and two["ranks"]["rccl_selfcheck"]["ranks"] == 2
+    assert sorted(two["ranks"]["devices"]) == [0, 1]
+    assert two["ranks"]["replicas"] == {"students_bit_identical": True, "teachers_bit_identical": True, "ranks_compared": 2}
+    assert all(v == v for v in two["losses"].values())
+    assert two["config"]["global_batch"] == 2 * one["config"]["global_batch"] and two["scaling"] == "weak"
+    assert two["value"] > 1.6 * one["value"], (one["value"], two["value"])

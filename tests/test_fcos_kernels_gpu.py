@@ -593,3 +593,33 @@ def test_two_criteria_in_one_launch_set_equal_two_calls(fc):
             assert torch.equal(res[k], one[k]), (m, k)
     with pytest.raises(ValueError):
         outm.predict_proposals(head_out, level_hw, sizes, ("cls", "nope"))
+
+
+def test_scale_cols_ml_forward_backward_vs_torch():
+    """the per-level Scale layers (reference fcos/fcos.py:22-41,338-364: bbox_pred * scale_l) of all levels in one launch forward / two
+    backward, against plain torch arithmetic: y[:, :68] *= s_l; dL/dx = g * s_l; dL/ds_l = sum(g * x) (= sum(g * y) / s_l)"""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(21)
+    rows = [(0, 4033), (4033, 5050), (5050, 5301), (5301, 5367), (5367, 5387)]
+    P, BS, nc = rows[-1][1], 80, 68
+    x = torch.randn(P, BS, generator=g).to(DEV)
+    gy = torch.randn(P, BS, generator=g).to(DEV)
+    scales = [torch.tensor([0.5 + 0.37 * l], device=DEV) for l in range(5)]
+    y = x.clone()
+    hip.scale_cols_ml(y, rows, nc, scales)
+    want = x.clone()
+    for (a, b), s in zip(rows, scales):
+        want[a:b, :nc] *= s
+    assert torch.equal(y, want)
+    sgr = [torch.full((1,), 0.25, device=DEV) for _ in range(5)]          # accumulated into
+    gin = gy.clone()
+    hip.scale_cols_bwd_ml(gin, y, rows, nc, scales, sgr)
+    for l, ((a, b), s) in enumerate(zip(rows, scales)):
+        assert torch.equal(gin[a:b, :nc], gy[a:b, :nc] * s) and torch.equal(gin[a:b, nc:], gy[a:b, nc:])
+        ds = (gy[a:b, :nc].double() * x[a:b, :nc].double()).sum()
+        assert abs(float(sgr[l]) - 0.25 - float(ds)) <= 2e-5 * float((gy[a:b, :nc].double() * x[a:b, :nc].double()).abs().sum()) + 1e-6
+    # bit-deterministic (fixed-order partial sums)
+    sgr2 = [torch.full((1,), 0.25, device=DEV) for _ in range(5)]
+    gin2 = gy.clone()
+    hip.scale_cols_bwd_ml(gin2, y, rows, nc, scales, sgr2)
+    assert all(torch.equal(a, b) for a, b in zip(sgr, sgr2))

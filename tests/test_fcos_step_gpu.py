@@ -104,22 +104,43 @@ def test_full_semisup_step_parity(freeze_at):
     assert checked > 100
 
 
+def _gap_threshold(values, lo=0.35, hi=0.65):
+    """a threshold in the middle of the widest gap between consecutive sorted values around the median: cuts the set roughly in half and
+    leaves a margin on both sides (1e-5-level differences between two implementations cannot move a detection across it)"""
+    v = torch.sort(values.double().flatten())[0]
+    a, b = int(lo * (len(v) - 1)), max(int(hi * (len(v) - 1)), int(lo * (len(v) - 1)) + 1)
+    gaps = v[a + 1:b + 1] - v[a:b]
+    i = int(torch.argmax(gaps)) + a
+    return float((v[i] + v[i + 1]) / 2)
+
+
 def test_full_semisup_step_cls_ctr_thresholding():
     """SEMISUPNET.PSEUDO_BBOX_SAMPLE(_REG) = "thresholding_cls_ctr" (reference engine/trainer.py:253-276 -> pseudo_generator.py:49-52,
     107-131: keep a detection when cls_confid > BBOX_THRESHOLD and centerness > BBOX_CTR_THRESHOLD) through a whole step: same pseudo
-    sets as the oracle (whose selection is pinned by the reference-executed golden thrcc_* arrays), every loss within 1e-3."""
+    sets as the oracle (whose selection is pinned by the reference-executed golden thrcc_* arrays), every loss within 1e-3.  The four
+    thresholds are placed inside gaps of the oracle teacher's own confidence / centerness values, so both tests of the rule decide."""
     from ubteacher.engine import UBTeacherTrainer
     cfg = small_fcos_cfg()
     S = cfg.SEMISUPNET
     S.PSEUDO_BBOX_SAMPLE = S.PSEUDO_BBOX_SAMPLE_REG = "thresholding_cls_ctr"
-    S.BBOX_THRESHOLD, S.BBOX_CTR_THRESHOLD = 0.5, 0.68
-    S.BBOX_THRESHOLD_REG, S.BBOX_CTR_THRESHOLD_REG = 0.45, 0.7
     torch.manual_seed(0)
     prod, orac = make_batch(12, 2, 2, H, W, "cuda")
     tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
     sd_s = tune_state_for_pseudo_labels(cpu_state(tr.model), [d["image"] for d in orac[3]])
     sd_t = dict(sd_s)
     sd_t["proposal_generator.fcos_head.bbox_pred_std.bias"] = torch.full((4,), -3.0)
+    # thresholds from the oracle teacher's detections under the two criteria of the step (trainer.py:232-251)
+    with torch.no_grad():
+        t_sd = O.ema_update(sd_s, sd_t, S.EMA_KEEP_RATE)
+        tl = O.fcos_forward(t_sd, [d["image"] for d in orac[3]], sd_s["pixel_mean"], sd_s["pixel_std"])
+        det_cls = O.fcos_predict(O.FCOSCfg(), *tl[:4], tl[4], tl[5], "cls")
+        det_loc = O.fcos_predict(O.FCOSCfg(), *tl[:4], tl[4], tl[5], "cls_n_loc")
+    conf = torch.cat([d["cls_confid"] for d in det_cls])
+    S.BBOX_THRESHOLD = _gap_threshold(conf)
+    S.BBOX_CTR_THRESHOLD = _gap_threshold(torch.cat([d["centerness"] for d in det_cls])[conf > S.BBOX_THRESHOLD])
+    conf_r = torch.cat([d["cls_confid"] for d in det_loc])
+    S.BBOX_THRESHOLD_REG = _gap_threshold(conf_r, 0.2, 0.5)
+    S.BBOX_CTR_THRESHOLD_REG = _gap_threshold(torch.cat([d["centerness"] for d in det_loc])[conf_r > S.BBOX_THRESHOLD_REG])
     tr.model.load_state_dict(sd_s)
     tr.model_teacher.load_state_dict(sd_t)
     tr.iter = 1
@@ -131,17 +152,18 @@ def test_full_semisup_step_cls_ctr_thresholding():
                   mean=sd_s["pixel_mean"], pix_std=sd_s["pixel_std"])
     rec_o, _, new_t, _, _, pseudo = O.fcos_semisup_step(
         O.FCOSCfg(), sd_s, sd_t, orac, thr_cls=(S.BBOX_THRESHOLD, S.BBOX_CTR_THRESHOLD), thr_reg=(S.BBOX_THRESHOLD_REG, S.BBOX_CTR_THRESHOLD_REG), **common)
-    _, _, _, _, _, pseudo_plain = O.fcos_semisup_step(O.FCOSCfg(), sd_s, sd_t, orac, thr_cls=S.BBOX_THRESHOLD, thr_reg=S.BBOX_THRESHOLD_REG, **common)
     n_cc = [sum(len(p["boxes"]) for p in ps) for ps in pseudo]
-    n_pl = [sum(len(p["boxes"]) for p in ps) for ps in pseudo_plain]
-    assert 0 < n_cc[0] and 0 < n_cc[1] and (n_cc[0] != n_pl[0] or n_cc[1] != n_pl[1]), (n_cc, n_pl)   # the second threshold decides
+    n_cls_only = [int((conf > S.BBOX_THRESHOLD).sum()), int((conf_r > S.BBOX_THRESHOLD_REG).sum())]
+    assert 0 < n_cc[0] < n_cls_only[0] and 0 < n_cc[1] < n_cls_only[1], (n_cc, n_cls_only)   # the centerness test decides too
+    assert n_cls_only[0] < len(conf) and n_cls_only[1] < len(conf_r)                         # ... and so does the confidence test
     pc, pr = tr._last_pseudo
     for got, want in ((pc, pseudo[0]), (pr, pseudo[1])):
         for i, p in enumerate(want):
             m = got["valid"][i].bool()
             assert int(m.sum()) == len(p["boxes"])
             assert torch.equal(got["classes"][i][m].cpu().long(), p["classes"].long())
-            assert float((got["boxes"][i][m].cpu() - p["boxes"]).abs().max()) < 1e-2 if len(p["boxes"]) else True
+            if len(p["boxes"]):
+                assert float((got["boxes"][i][m].cpu() - p["boxes"]).abs().max()) < 1e-2
     for k, v in rec_o.items():
         assert abs(rec[k] - v) <= 1e-3 * max(abs(v), 1e-6), (k, rec[k], v)
     t_after = cpu_state(tr.model_teacher)

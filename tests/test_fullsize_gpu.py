@@ -1,0 +1,108 @@
+"""Parity at BENCHMARK resolution inside the GPU test suite: one whole post-burn-in UTv2 iteration on 1 labeled + 1 unlabeled 1333x800
+image, FCOS (reference engine/trainer.py:181-429) and Faster-RCNN (:786-912), the product's exact-f32 mode against the committed oracle
+fixture tests/golden/fullsize_{fcos,rcnn}.npz (generator: tests/golden/gen_golden_fullsize.py, run in the build container).  This is the
+size at which the 256-tile / ping-pong convolution kernels, the multi-round radix top-k and the 1000-candidate NMS engage - the other
+step tests run 96x128 images.  Tolerance: every loss within 1e-3 relative (north star); identical pseudo-box counts.  The two pseudo-label
+RPN terms of the Faster-RCNN step carry the looser bounds bench.parity_fullsize states (`looser_terms`): the reference's low-quality
+anchor matching is discontinuous at the 1-ulp level of the pseudo boxes (tests/test_rcnn_conditioning.py); loss_rpn_loc_pseudo enters
+the objective with weight 0 (engine/trainer.py:888-890).
+
+The CPU half (`-m "not gpu"`) checks that the fixture's inputs and initial weights rebuild bit-exactly from their seeds here."""
+import os
+import sys
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "unbiased-teacher-v2_amd"))
+
+
+def _crc(t):
+    return zlib.crc32(np.ascontiguousarray(t.detach().cpu().numpy() if torch.is_tensor(t) else t).tobytes()) & 0xFFFFFFFF
+
+
+def rebuild(kind):
+    """the dict bench.parity_fullsize consumes (the cpu_baseline child's dump format), rebuilt from the fixture: inputs and initial
+    weights from their seeds - verified against the stored checksums / fingerprints -, changed tensors and expected outputs from arrays"""
+    import bench
+    from tests.utv2_testutil import state_fingerprint
+    from ubteacher.modeling import build_model
+    from ubteacher.presets import get_config
+    fx = np.load(os.path.join(G, "fullsize_%s.npz" % kind), allow_pickle=False)
+    label, unlabel = int(fx["label"]), int(fx["unlabel"])
+    assert int(fx["batch_seed"]) == 0 and int(fx["init_seed"]) == 0
+    batch = bench._synthetic_cpu_batch(label, unlabel)
+    crcs = [_crc(x["image"]) for part in batch for x in part]
+    assert crcs == [int(c) for c in fx["image_crc"]], "the synthetic 1333x800 images are not the ones the fixture was computed on"
+    for i, x in enumerate(batch[1]):
+        assert np.array_equal(x["gt"]["boxes"].numpy(), fx["lab%d_boxes" % i]) and np.array_equal(x["gt"]["classes"].numpy(), fx["lab%d_classes" % i])
+    cfg = get_config(kind, 1, ["MODEL.DEVICE", "cpu", "SEMISUPNET.BURN_UP_STEP", 0])
+    torch.manual_seed(int(fx["init_seed"]))
+    model = build_model(cfg)
+    init = {k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}
+    del model
+    keys = [str(k) for k in fx["init_keys"]]
+    assert keys == [k for k in init if init[k].dtype.is_floating_point], "state-dict surface differs from the fixture's"
+    fp = np.stack([state_fingerprint(init[k]) for k in keys])
+    assert np.array_equal(fp, fx["init_fp"]), "CPU initialisation is not the one the fixture's step started from"
+    student = dict(init)
+    for k in fx["student_changed"]:
+        student[str(k)] = torch.from_numpy(fx["student::" + str(k)].copy())
+    teacher = dict(student)
+    for k in fx["teacher_changed"]:
+        teacher[str(k)] = torch.from_numpy(fx["teacher::" + str(k)].copy())
+    rec = {k[4:]: float(fx[k]) for k in fx.files if k.startswith("rec_")}
+    d = {"student": student, "teacher": teacher, "batch": batch, "record": rec, "keep_rate": float(fx["keep_rate"]), "model": kind}
+    if kind == "fcos":
+        d["pseudo"] = {"cls": int(fx["pseudo_cls"]), "reg": int(fx["pseudo_reg"])}
+    else:
+        d["pseudo"] = int(fx["pseudo"])
+        g = torch.Generator().manual_seed(int(fx["key_seed"]))
+        shp = [tuple(int(v) for v in s) for s in fx["rpn_keys_shape"]]
+        rpn = (torch.rand(shp[0], generator=g), torch.rand(shp[1], generator=g))     # the draw order of bench.cpu_baseline_run
+        assert [_crc(k) for k in rpn] == [int(c) for c in fx["rpn_keys_crc"]], "torch.rand stream differs from the fixture's anchor sampling keys"
+        roi = []
+        for (nprop, ngt), c in zip(fx["roi_draws"], fx["roi_keys_crc"]):
+            k = torch.rand(int(nprop) + int(ngt), generator=g)
+            assert _crc(k) == int(c), "torch.rand stream differs from the fixture's ROI sampling keys"
+            roi.append((int(nprop), int(ngt), k))
+        d.update(rpn_keys=rpn, roi_keys=roi, label=label, unlabel=unlabel)
+    return d
+
+
+@pytest.mark.parametrize("kind", ["fcos", "rcnn"])
+def test_fullsize_fixture_rebuilds_from_its_seeds(kind):
+    d = rebuild(kind)
+    assert d["record"] and all(np.isfinite(v) for v in d["record"].values())
+    assert any(k.endswith("_pseudo") and v > 0 for k, v in d["record"].items())       # the pseudo-label branch did real work
+    if kind == "rcnn":
+        assert d["record"]["loss_box_reg_pseudo"] > 0 and d["pseudo"] > 0             # SURVEY a18 is exercised
+    else:
+        assert d["pseudo"]["cls"] > 0 and d["pseudo"]["reg"] > 0 and d["record"]["teacher_better_student_pseudo"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["fcos", "rcnn"])
+def test_fullsize_step_parity_vs_oracle_fixture(kind, tmp_path):
+    import bench
+    d = rebuild(kind)
+    dump = str(tmp_path / ("fullsize_%s.pt" % kind))
+    torch.save(d, dump)
+    out = bench.parity_fullsize(dump, 0)
+    assert out["mode"] == "f32" and out["model"] == kind and out["rel_dev"], out
+    if kind == "fcos":
+        assert out["pseudo_boxes"]["product"] == out["pseudo_boxes"]["oracle"], out["pseudo_boxes"]
+        assert out["teacher_better_student_pseudo"]["product"] == out["teacher_better_student_pseudo"]["oracle"]
+        tol = {}
+    else:
+        assert out["pseudo_boxes"]["product"] == out["pseudo_boxes"]["oracle"], out["pseudo_boxes"]
+        assert out["key_draws_replayed"] == {"rpn": 2, "roi": 2}
+        tol = out.get("looser_terms", {})
+    for k, v in out["rel_dev"].items():
+        assert v <= tol.get(k, 1e-3), (k, v, out["oracle_losses"][k], out["product_losses"][k])
+    assert set(out["rel_dev"]) == {k for k in d["record"] if k.startswith("loss")}

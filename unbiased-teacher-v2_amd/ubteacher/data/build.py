@@ -102,3 +102,50 @@ def build_detection_semisup_train_loader_two_crops(cfg, mapper=None):
     return build_semisup_batch_data_loader_two_crop(
         (label_dicts, unlabel_dicts), (label_sampler, unlabel_sampler), cfg.SOLVER.IMG_PER_BATCH_LABEL, cfg.SOLVER.IMG_PER_BATCH_UNLABEL,
         aspect_ratio_grouping=cfg.DATALOADER.ASPECT_RATIO_GROUPING, num_workers=cfg.DATALOADER.NUM_WORKERS, mapper=mapper)
+
+
+class InferenceSampler:
+    """Detectron2 InferenceSampler [D2-recall]: the indices 0..size-1 cut into world_size contiguous shards whose sizes differ by at
+    most one (the first size % world shards take the extra element); rank r iterates its shard in order."""
+
+    def __init__(self, size, rank=None, world_size=None):
+        assert size > 0
+        rank = comm.get_rank() if rank is None else rank
+        world = comm.get_world_size() if world_size is None else world_size
+        shard, left = size // world, size % world
+        sizes = [shard + int(r < left) for r in range(world)]
+        begin = sum(sizes[:rank])
+        self._indices = range(begin, min(begin + sizes[rank], size))
+
+    def __iter__(self):
+        yield from self._indices
+
+    def __len__(self):
+        return len(self._indices)
+
+
+class DetectionTestLoader:
+    """fixed-length loader of the evaluation path: batches of ONE mapped image (Detectron2 build_detection_test_loader: batch size 1,
+    InferenceSampler, trivial collate [D2-recall]).  Mapped lazily: the decode + resize of image i happens when batch i is asked for."""
+
+    def __init__(self, dicts, mapper, sampler):
+        self.dicts, self.mapper, self.sampler = dicts, mapper, sampler
+
+    def __len__(self):
+        return len(self.sampler)
+
+    def __iter__(self):
+        for idx in self.sampler:
+            yield [self.mapper(self.dicts[idx])]
+
+
+def build_detection_test_loader(cfg, dataset_name, mapper=None):
+    """Detectron2 build_detection_test_loader(cfg, name) [D2-recall] as the reference's trainers call it (engine/trainer.py:554-608 via
+    DefaultTrainer.build_test_loader): every image of the set (no filtering), the test-time mapper (ResizeShortestEdge(MIN_SIZE_TEST,
+    MAX_SIZE_TEST), no flip; the dict keeps the ORIGINAL height / width and image_id, annotations are dropped), one image per batch,
+    the set sharded over the ranks."""
+    dicts = get_detection_dataset_dicts(dataset_name, filter_empty=False)
+    if mapper is None:
+        from .dataset_mapper import DatasetMapperTwoCropSeparate
+        mapper = DatasetMapperTwoCropSeparate(cfg, is_train=False)
+    return DetectionTestLoader(dicts, mapper, InferenceSampler(len(dicts)))

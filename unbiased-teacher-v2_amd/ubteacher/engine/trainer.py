@@ -270,7 +270,7 @@ class _TrainerBase:
         same output contract: 4 lists of dicts per iteration."""
         from ..data import DatasetCatalog, build_detection_semisup_train_loader_two_crops
         names = cfg.DATASETS.TRAIN_LABEL + cfg.DATASETS.TRAIN_UNLABEL if cfg.DATASETS.CROSS_DATASET else cfg.DATASETS.TRAIN
-        if len(names) and all(n in DatasetCatalog for n in names):
+        if len(names) and all(DatasetCatalog.available(n) for n in names):
             return build_detection_semisup_train_loader_two_crops(cfg, mapper=None)
         return SyntheticTwoCropLoader(cfg)
 
@@ -446,15 +446,26 @@ class _TrainerBase:
     # -- evaluation path (trainer.py:554-608) --------------------------------------------------------
     @classmethod
     def build_test_loader(cls, cfg, dataset_name):
-        """no dataset registry here: every test-set name resolves to the synthetic COCO-shaped test loader"""
+        """reference engine/trainer.py:114-116 (DefaultTrainer.build_test_loader -> Detectron2 build_detection_test_loader): a registered
+        set whose files are there (COCO-format json + image folder, data/datasets.py) goes through the test-time mapper; when the
+        named set is not available - the shipped configs name coco_2017_val and no dataset exists in this environment - the synthetic
+        COCO-shaped test set stands in, with a warning (its numbers exercise the plumbing, not accuracy)."""
+        from ..data import DatasetCatalog, build_detection_test_loader
+        if DatasetCatalog.available(dataset_name):
+            return build_detection_test_loader(cfg, dataset_name)
+        import logging
+        logging.getLogger(__name__).warning("test set %r is not available (not registered, or its annotation file is missing): evaluating "
+                                            "on the synthetic COCO-shaped test set", dataset_name)
         from ..data.synthetic import SyntheticTestLoader
         return SyntheticTestLoader(cfg)
 
     @classmethod
     def build_evaluator(cls, cfg, dataset_name, output_folder=None):
+        from ..data import DatasetCatalog
         from ..evaluation import COCOBoxEvaluator
         rcnn = cfg.SEMISUPNET.Trainer == "ubteacher_rcnn"
-        return COCOBoxEvaluator(cfg.MODEL.ROI_HEADS.NUM_CLASSES if rcnn else cfg.MODEL.FCOS.NUM_CLASSES)
+        nc = cfg.MODEL.ROI_HEADS.NUM_CLASSES if rcnn else cfg.MODEL.FCOS.NUM_CLASSES
+        return COCOBoxEvaluator(nc, dataset_name=dataset_name if DatasetCatalog.available(dataset_name) else None)
 
     @classmethod
     def test(cls, cfg, model, evaluators=None):

@@ -33,11 +33,14 @@ def _iou_matrix(dets, gts, crowd):
     return inter / np.maximum(union, 1e-12)
 
 
-def _evaluate_image(dets, scores, gts, crowd, rng):
-    """one (image, category, area range): returns (scores, matched[T,D], ignored[T,D], number of non-ignored gt)"""
+def _evaluate_image(dets, scores, gts, crowd, rng, garea=None):
+    """one (image, category, area range): returns (scores, matched[T,D], ignored[T,D], number of non-ignored gt).
+    garea: the annotations' `area` field when the ground truth comes from a COCO json (pycocotools ranks ground truth by that field -
+    the segment area -, not by the box area); None = box areas"""
     order = np.argsort(-scores, kind="mergesort")[:MAX_DETS]
     dets, scores = dets[order], scores[order]
-    garea = (gts[:, 2] - gts[:, 0]) * (gts[:, 3] - gts[:, 1]) if len(gts) else np.zeros(0)
+    if garea is None:
+        garea = (gts[:, 2] - gts[:, 0]) * (gts[:, 3] - gts[:, 1]) if len(gts) else np.zeros(0)
     gignore = crowd | (garea < rng[0]) | (garea > rng[1])
     gorder = np.argsort(gignore, kind="mergesort")  # non-ignored first
     gts, crowd, gignore = gts[gorder], crowd[gorder], gignore[gorder]
@@ -85,6 +88,7 @@ def coco_box_ap(predictions, ground_truth, num_classes=None):
                 gb = np.asarray(g["boxes"], float).reshape(-1, 4)
                 gc = np.asarray(g["classes"]).reshape(-1)
                 gcrowd = np.asarray(g.get("iscrowd", np.zeros(len(gc))), bool).reshape(-1)
+                gar = np.asarray(g["area"], float).reshape(-1) if g.get("area") is not None else None
                 sel = gc == c
                 p = predictions.get(img)
                 if p is not None and len(np.asarray(p["classes"]).reshape(-1)):
@@ -96,7 +100,7 @@ def coco_box_ap(predictions, ground_truth, num_classes=None):
                     pb, ps = np.zeros((0, 4)), np.zeros(0)
                 if not sel.any() and len(pb) == 0:
                     continue
-                s, dm, di, n = _evaluate_image(pb, ps, gb[sel], gcrowd[sel], rng)
+                s, dm, di, n = _evaluate_image(pb, ps, gb[sel], gcrowd[sel], rng, None if gar is None else gar[sel])
                 sc_all.append(s); dm_all.append(dm); di_all.append(di); npig += n
             if npig == 0:
                 continue
@@ -133,8 +137,23 @@ class COCOBoxEvaluator:
     and `instances` (gt_boxes, gt_classes) at the ORIGINAL image size (`height`, `width`); outputs are the model's eval-mode
     results `{"instances": Instances(pred_boxes, scores, pred_classes)}` already rescaled by detector_postprocess."""
 
-    def __init__(self, num_classes=None):
+    def __init__(self, num_classes=None, dataset_name=None):
+        """dataset_name: a registered dataset (DatasetCatalog) whose dicts carry the ground truth - Detectron2's COCOEvaluator(dataset_name)
+        reads it from the set's json [D2-recall]; the test mapper drops `annotations` from its inputs.  None: the ground truth rides on
+        every input as `instances` (the synthetic test loader)."""
         self.num_classes = num_classes
+        self._dataset_gt = None
+        if dataset_name is not None:
+            from ..data import DatasetCatalog
+            from ..data.dataset_mapper import to_xyxy_abs
+            self._dataset_gt = {}
+            for d in DatasetCatalog.get(dataset_name):
+                annos = d.get("annotations", [])
+                self._dataset_gt[d["image_id"]] = dict(
+                    boxes=np.asarray([to_xyxy_abs(a) for a in annos], float).reshape(-1, 4),
+                    classes=np.asarray([a["category_id"] for a in annos], np.int64),
+                    iscrowd=np.asarray([a.get("iscrowd", 0) for a in annos], bool),
+                    area=np.asarray([a["area"] for a in annos], float) if annos and all("area" in a for a in annos) else None)
         self.reset()
 
     def reset(self):
@@ -143,6 +162,12 @@ class COCOBoxEvaluator:
     def process(self, inputs, outputs):
         for inp, out in zip(inputs, outputs):
             iid = inp["image_id"]
+            if self._dataset_gt is not None:
+                self._gt[iid] = self._dataset_gt[iid]
+                inst = out["instances"] if "instances" in out else out["proposals"]
+                self._pred[iid] = dict(boxes=inst.pred_boxes.tensor.detach().cpu().numpy(), scores=inst.scores.detach().cpu().numpy(),
+                                       classes=inst.pred_classes.detach().cpu().numpy())
+                continue
             gt = inp["instances"]
             self._gt[iid] = dict(boxes=gt.gt_boxes.tensor.detach().cpu().numpy(), classes=gt.gt_classes.detach().cpu().numpy())
             inst = out["instances"] if "instances" in out else out["proposals"]

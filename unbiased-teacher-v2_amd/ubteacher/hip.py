@@ -472,6 +472,21 @@ def sigmoid_focal_bwd(logits, labels, alpha, gamma, coef, out=None):
     return out
 
 
+def sigmoid_focal_bwd_acc(logits, labels, alpha, gamma, coef, gscale, out, accumulate):
+    """one branch's focal gradient written (accumulate False) or added (True) into `out` - see utv2_sigmoid_focal_bwd_acc"""
+    P, C = logits.shape
+    call("utv2_sigmoid_focal_bwd_acc", _p(logits), _p(labels), P, C, float(alpha), float(gamma), _p(coef), _p(gscale), _p(out),
+         int(bool(accumulate)), _stream())
+    return out
+
+
+def fcos_loc_terms_bwd_acc(labels, box, reg_targets, bvars, num_classes, reg_max, ts_better, ts_cert, coef8, gscale, out, accumulate, flags=0):
+    P, BS = box.shape
+    call("utv2_fcos_loc_terms_bwd_acc", _p(labels), _p(box), BS, _p(reg_targets), _p(bvars), P, num_classes, reg_max, float(ts_better),
+         float(ts_cert), int(flags), _p(coef8), _p(gscale), _p(out), int(bool(accumulate)), _stream())
+    return out
+
+
 LT_QUALITY_IOU, LT_KLLOSS, LT_LOC_IOU, LT_LOC_LINEAR_IOU, LT_KL_WCTR = 1, 2, 1 << 2, 2 << 2, 16  # variant flags of the fcos_loc_terms kernels
 
 
@@ -558,7 +573,7 @@ def scale_cols_bwd_ml(g2d, ypost2d, rows, ncols, scales, sgrads):
     assert len(rows) == len(scales) == len(sgrads) <= 8 and all(rows[i][1] == rows[i + 1][0] for i in range(len(rows) - 1))
     r0 = _i64arr([r[0] for r in rows] + [rows[-1][1]])
     sp, gp = _ptr_array(scales), _ptr_array(sgrads)
-    ws = workspace(8 * 256, g2d.device, "loss")
+    ws = workspace(8 * 1024, g2d.device, "loss")
     call("utv2_scale_cols_bwd_ml", _p(g2d), _p(ypost2d), len(rows), ctypes.cast(r0, c_p), g2d.shape[1], ncols, ctypes.cast(sp, c_p),
          ctypes.cast(gp, c_p), _p(ws), _stream())
 

@@ -538,6 +538,23 @@ class FCOSOutputs:
         pseudo dict (keys without the suffix), weighted total); the dict entries are detached (metrics)."""
         logits_all, box_all = head_out["logits"], head_out["box"]
         nc, rm = self.num_classes, self.reg_max
+        if os.environ.get("UTV2_JOINT_LOSS_NODE", "1") != "0":
+            # round 4: the three branches as ONE autograd node whose backward writes one gradient tensor per head output (ops._FcosJointLossFn)
+            lab_s, reg_s, _, _ = self._targets(level_hw, gt_labeled, drop_empty=1, batch=N, img0=0)
+            lab_c, reg_c, _, _ = self._targets(level_hw, gt_unlabeled["cls"], drop_empty=0, batch=N, img0=n_labeled)
+            lab_r, reg_r, bv_r, _ = self._targets(level_hw, gt_unlabeled["reg"], drop_empty=0, batch=N, img0=n_labeled)
+            tsbetter = self.reg_unsup_loss == "ts_locvar_better_nms_nll_l1"
+            flags = (1 if self.kl_loss else 0) | (2 if self.kl_loss_type == "klloss" else 0) | (4 if self.unify_ctrcls else 0) | (8 if tsbetter else 0)
+            consts = (self.focal_loss_alpha, self.focal_loss_gamma, nc, rm, self.loc_flags | (hip.LT_QUALITY_IOU if self.quality_iou else 0),
+                      self.loc_flags, self.tsbetter_reg, self.tsbetter_reg_cert, float(comm.get_world_size()), flags, self.kl_loss_weight,
+                      [loss_weights[k][0] for k in self.LOSS_KEYS], [loss_weights[k][1] for k in self.LOSS_KEYS])
+            total, rec = ops.fcos_joint_loss(logits_all, box_all, ((lab_s, reg_s), (lab_c, reg_c), (lab_r, reg_r, bv_r if tsbetter else None)),
+                                             consts, self._joint_normaliser_sums)
+            l_sup = {"loss_fcos_cls": rec[0], "loss_fcos_loc": rec[1], "loss_fcos_ctr": rec[2]}
+            l_uns = {"loss_fcos_cls": rec[3], "loss_fcos_ctr": rec[4], "loss_fcos_loc": rec[5]}
+            if tsbetter:
+                l_uns["teacher_better_student"] = rec[6]
+            return l_sup, l_uns, total
         # images [0, n_labeled) of the batch carry ground truth, [n_labeled, N) the pseudo labels: the target kernel takes the range
         labels, reg_t, _, _ = self._targets(level_hw, gt_labeled, drop_empty=1, batch=N, img0=0)
         focal_s = ops.focal_loss_sum(logits_all, labels, self.focal_loss_alpha, self.focal_loss_gamma)

@@ -1005,6 +1005,50 @@ def fcos_loss_combine(focal_sup, sums_sup, focal_cls, sums_cls, sums_reg, norm, 
     return _FcosCombineFn.apply(focal_sup, sums_sup, focal_cls, sums_cls, sums_reg, norm, world, flags, kl_weight, wmul, wdiv)
 
 
+class _FcosJointLossFn(torch.autograd.Function):
+    """The whole loss tail of a fused FCOS student pass as ONE autograd node (round 4): the focal / positive-location kernels of the
+    supervised, pseudo-classification and pseudo-regression target sets, the optional normaliser all-reduce and the scalar combine
+    forward; backward = five launches that write / add into ONE gradient tensor per head output (utv2_*_bwd_acc).  As separate nodes
+    every branch returned a dense [P, 80] gradient of its own and autograd folded them with three elementwise add passes, a zero fill
+    and the stack / cat glue around the coefficient vectors (about 20 launches and 0.25 ms with the chip idle between the forward and the
+    backward of the step).  Same kernels, same arithmetic per branch; the sum of the branches is formed in the order sup, cls, reg."""
+
+    @staticmethod
+    def forward(ctx, logits, box, targets, consts, norm_fn):
+        (lab_s, reg_s), (lab_c, reg_c), (lab_r, reg_r, bv_r) = targets
+        alpha, gamma, nc, rm, flags_s, flags_p, tsb, tsc, world, cflags, klw, wmul, wdiv = consts
+        lg, bx = logits.detach(), box.detach()
+        focal_s = hip.sigmoid_focal_fwd(lg, lab_s, alpha, gamma)
+        sums_s = hip.fcos_loc_terms_fwd(lab_s, bx, reg_s, None, nc, rm, 0.0, 0.0, flags=flags_s)
+        focal_c = hip.sigmoid_focal_fwd(lg, lab_c, alpha, gamma)
+        sums_c = hip.fcos_loc_terms_fwd(lab_c, bx, reg_c, None, nc, rm, 0.0, 0.0, flags=flags_p)
+        sums_r = hip.fcos_loc_terms_fwd(lab_r, bx, reg_r, bv_r, nc, rm, tsb, tsc, flags=flags_p)
+        norm = norm_fn(sums_s, sums_c, sums_r)
+        rec, coef = hip.fcos_loss_combine(focal_s, sums_s, focal_c, sums_c, sums_r, norm, world, cflags, klw, wmul, wdiv)
+        ctx.consts = consts
+        ctx.has_bv = bv_r is not None
+        ctx.save_for_backward(lg, bx, lab_s, reg_s, lab_c, reg_c, lab_r, reg_r, bv_r if bv_r is not None else lab_r, coef)
+        ctx.mark_non_differentiable(rec)
+        return rec[7].clone(), rec
+
+    @staticmethod
+    def backward(ctx, g, _):
+        lg, bx, lab_s, reg_s, lab_c, reg_c, lab_r, reg_r, bv_r, coef = ctx.saved_tensors
+        alpha, gamma, nc, rm, flags_s, flags_p, tsb, tsc = ctx.consts[:8]
+        gs = g.reshape(1).contiguous().float()
+        dlg, dbx = torch.empty_like(lg), torch.empty_like(bx)
+        hip.sigmoid_focal_bwd_acc(lg, lab_s, alpha, gamma, coef[0:1], gs, dlg, False)
+        hip.sigmoid_focal_bwd_acc(lg, lab_c, alpha, gamma, coef[9:10], gs, dlg, True)
+        hip.fcos_loc_terms_bwd_acc(lab_s, bx, reg_s, None, nc, rm, 0.0, 0.0, coef[1:9], gs, dbx, False, flags=flags_s)
+        hip.fcos_loc_terms_bwd_acc(lab_c, bx, reg_c, None, nc, rm, 0.0, 0.0, coef[10:18], gs, dbx, True, flags=flags_p)
+        hip.fcos_loc_terms_bwd_acc(lab_r, bx, reg_r, bv_r if ctx.has_bv else None, nc, rm, tsb, tsc, coef[18:26], gs, dbx, True, flags=flags_p)
+        return dlg, dbx, None, None, None
+
+
+def fcos_joint_loss(logits, box, targets, consts, norm_fn):
+    return _FcosJointLossFn.apply(logits, box, targets, consts, norm_fn)
+
+
 class _RcnnCombineFn(torch.autograd.Function):
     """The scalar tail of the Faster-RCNN losses of a fused student pass as one node (utv2_rcnn_loss_combine): raw kernel sums of both
     branches -> (weighted total, the eight losses for the metrics); backward = the stored d total / d sums, scaled."""
