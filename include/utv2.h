@@ -300,6 +300,11 @@ int utv2_scale_cols_ml(float* y, int nlev, const int64_t* row0_host, int row_str
                        utv2_stream_t stream);
 int utv2_scale_cols_bwd_ml(float* g, const float* ypost, int nlev, const int64_t* row0_host, int row_stride, int ncols,
                            const float* const* s_host, float* const* sgrad_host, float* ws, utv2_stream_t stream);
+/* the same backward, out of place, straight into the zero-padded 16-bit matrix the prediction conv's dgrad / weight gradient read:
+ * out16 = 16-bit [rows][cpad] (cpad >= row_stride, % 4 == 0): [:, :ncols] = g * s_l, [:, ncols:row_stride] = g, [:, row_stride:] = 0; g is
+ * not modified (no clone of the incoming gradient, no separate utv2_pad_cols_bf16 pass).  ws >= nlev * 1024 floats */
+int utv2_scale_cols_bwd_ml_pad16(const float* g, const float* ypost, int nlev, const int64_t* row0_host, int row_stride, int ncols,
+                                 const float* const* s_host, float* const* sgrad_host, float* ws, void* out16, int cpad, utv2_stream_t stream);
 
 /* ---- NMS / IoU: layers/ml_nms.py:27, D2 batched_nms / pairwise_iou ---------------------------- */
 int utv2_nms_mpad(int M);

@@ -623,3 +623,26 @@ def test_scale_cols_ml_forward_backward_vs_torch():
     gin2 = gy.clone()
     hip.scale_cols_bwd_ml(gin2, y, rows, nc, scales, sgr2)
     assert all(torch.equal(a, b) for a, b in zip(sgr, sgr2))
+
+
+def test_scale_cols_bwd_pad16_equals_scale_then_pad():
+    """utv2_scale_cols_bwd_ml_pad16 (Scale backward + conversion + zero padding in one out-of-place pass) == utv2_scale_cols_bwd_ml on
+    a clone followed by utv2_pad_cols_bf16, bit for bit (values and the Scale gradients), and leaves the incoming gradient untouched"""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(22)
+    rows = [(0, 4033), (4033, 5050), (5050, 5301), (5301, 5367), (5367, 5387)]
+    P, BS, nc, cpad = rows[-1][1], 80, 68, 96
+    y = torch.randn(P, BS, generator=g).to(DEV)
+    gy = torch.randn(P, BS, generator=g).to(DEV)
+    scales = [torch.tensor([0.5 + 0.37 * l], device=DEV) for l in range(5)]
+    sg_a = [torch.zeros(1, device=DEV) for _ in range(5)]
+    sg_b = [torch.zeros(1, device=DEV) for _ in range(5)]
+    ref = gy.clone()
+    hip.scale_cols_bwd_ml(ref, y, rows, nc, scales, sg_a)
+    want = hip.pad_cols_bf16(ref, cpad)
+    keep = gy.clone()
+    got = hip.scale_cols_bwd_ml_pad16(gy, y, rows, nc, scales, sg_b, cpad)
+    assert torch.equal(gy, keep)
+    assert got.dtype == hip.h16_dtype() and tuple(got.shape) == (P, cpad) and torch.equal(got, want)
+    assert float(got[:, BS:].abs().max()) == 0.0
+    assert all(abs(float(a) - float(b)) <= 1e-5 * max(abs(float(a)), 1.0) for a, b in zip(sg_a, sg_b))   # another partition of the same sum

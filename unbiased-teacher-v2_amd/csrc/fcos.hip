@@ -660,6 +660,40 @@ __global__ __launch_bounds__(256) void scale_cols_bwd_ml_kernel(float* __restric
   if (threadIdx.x == 0) partial[(size_t)l * gridDim.x + blockIdx.x] = t;
 }
 
+// The same backward with the result written as the zero-padded 16-bit matrix the prediction conv's dgrad / weight gradient read
+// (out16 [rows][cpad], cpad >= BS): out[:, :ncols] = g * s_l, out[:, ncols:BS] = g, out[:, BS:] = 0; g itself is NOT modified.  One pass
+// instead of three (clone of the incoming gradient + in-place scale + pad / convert): 224 MB instead of 568 MB on the student batch.
+__global__ __launch_bounds__(256) void scale_cols_bwd_ml_pad16_kernel(const float* __restrict__ g, const float* __restrict__ ypost, ScaleLevels L,
+                                                                    int BS, int ncols, float* __restrict__ partial, h16_t* __restrict__ out,
+                                                                    int cpad) {
+  __shared__ float red[4];
+  const int l = blockIdx.y;
+  const float* gl = g + (size_t)L.row0[l] * BS;
+  const float* yl = ypost + (size_t)L.row0[l] * BS;
+  h16_t* ol = out + (size_t)L.row0[l] * cpad;
+  const float k = L.s[l][0];
+  float acc = 0.f;
+  const unsigned q = (unsigned)BS >> 2, qn = (unsigned)ncols >> 2, qp = (unsigned)cpad >> 2;
+  const unsigned total = (unsigned)(L.row0[l + 1] - L.row0[l]) * qp;
+  typedef h16_t h16x4 __attribute__((ext_vector_type(4)));
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned r = i / qp, c4 = i - r * qp;
+    f32x4 gv = {0.f, 0.f, 0.f, 0.f};
+    if (c4 < q) {
+      gv = *(const f32x4*)(gl + ((size_t)r * q + c4) * 4);
+      if (c4 < qn) {
+        const f32x4 yv = *(const f32x4*)(yl + ((size_t)r * q + c4) * 4);
+        acc += ((gv[0] * yv[0] + gv[1] * yv[1]) + (gv[2] * yv[2] + gv[3] * yv[3]));
+        gv[0] *= k; gv[1] *= k; gv[2] *= k; gv[3] *= k;
+      }
+    }
+    h16x4 o = {(h16_t)gv[0], (h16_t)gv[1], (h16_t)gv[2], (h16_t)gv[3]};
+    *(h16x4*)(ol + (size_t)i * 4) = o;
+  }
+  const float t = block_reduce_sum(acc, red);
+  if (threadIdx.x == 0) partial[(size_t)l * gridDim.x + blockIdx.x] = t;
+}
+
 // one block per level: d s_l += (sum of the level's partials, fixed order) / s_l
 __global__ __launch_bounds__(256) void scale_cols_bwd_ml_final(ScaleLevels L, const float* __restrict__ partial, int nb) {
   __shared__ float red[4];
@@ -920,6 +954,23 @@ int utv2_scale_cols_bwd_ml(float* g, const float* ypost, int nlev, const int64_t
                     rows_max * (row_stride >> 2) < (int64_t)1 << 31;
   if (vec4) hipLaunchKernelGGL(scale_cols_bwd_ml_kernel<true>, dim3(nb, nlev), dim3(256), 0, stream, g, ypost, L, row_stride, ncols, ws);
   else hipLaunchKernelGGL(scale_cols_bwd_ml_kernel<false>, dim3(nb, nlev), dim3(256), 0, stream, g, ypost, L, row_stride, ncols, ws);
+  hipLaunchKernelGGL(scale_cols_bwd_ml_final, dim3(nlev), dim3(256), 0, stream, L, (const float*)ws, nb);
+  return utv2_launch_status();
+}
+
+int utv2_scale_cols_bwd_ml_pad16(const float* g, const float* ypost, int nlev, const int64_t* row0_host, int row_stride, int ncols,
+                                 const float* const* s_host, float* const* sgrad_host, float* ws, void* out16, int cpad, hipStream_t stream) {
+  ScaleLevels L;
+  if (!g || !ypost || !ws || !sgrad_host || !out16 || fill_scale_levels(L, nlev, row0_host, s_host, sgrad_host) != UTV2_OK) return UTV2_EARG;
+  for (int l = 0; l < nlev; ++l)
+    if (!L.sgrad[l]) return UTV2_EARG;
+  int64_t rows_max = 0;
+  for (int l = 0; l < nlev; ++l) rows_max = rows_max > row0_host[l + 1] - row0_host[l] ? rows_max : row0_host[l + 1] - row0_host[l];
+  if ((row_stride & 3) || (ncols & 3) || (cpad & 3) || cpad < row_stride || ncols > row_stride || ((((uintptr_t)g | (uintptr_t)ypost) & 15) != 0) ||
+      (((uintptr_t)out16) & 7) != 0 || rows_max * (cpad >> 2) >= (int64_t)1 << 31)
+    return UTV2_EARG;
+  const int nb = 1024;
+  hipLaunchKernelGGL(scale_cols_bwd_ml_pad16_kernel, dim3(nb, nlev), dim3(256), 0, stream, g, ypost, L, row_stride, ncols, ws, (h16_t*)out16, cpad);
   hipLaunchKernelGGL(scale_cols_bwd_ml_final, dim3(nlev), dim3(256), 0, stream, L, (const float*)ws, nb);
   return utv2_launch_status();
 }

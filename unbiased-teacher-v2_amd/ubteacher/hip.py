@@ -578,6 +578,18 @@ def scale_cols_bwd_ml(g2d, ypost2d, rows, ncols, scales, sgrads):
          ctypes.cast(gp, c_p), _p(ws), _stream())
 
 
+def scale_cols_bwd_ml_pad16(g2d, ypost2d, rows, ncols, scales, sgrads, cpad):
+    """scale_cols_bwd_ml out of place: returns the 16-bit [P, cpad] zero-padded scaled gradient, g2d untouched (utv2_scale_cols_bwd_ml_pad16)"""
+    assert len(rows) == len(scales) == len(sgrads) <= 8 and all(rows[i][1] == rows[i + 1][0] for i in range(len(rows) - 1))
+    r0 = _i64arr([r[0] for r in rows] + [rows[-1][1]])
+    sp, gp = _ptr_array(scales), _ptr_array(sgrads)
+    ws = workspace(8 * 1024, g2d.device, "loss")
+    out = torch.empty((g2d.shape[0], cpad), dtype=h16_dtype(), device=g2d.device)
+    call("utv2_scale_cols_bwd_ml_pad16", _p(g2d), _p(ypost2d), len(rows), ctypes.cast(r0, c_p), g2d.shape[1], ncols, ctypes.cast(sp, c_p),
+         ctypes.cast(gp, c_p), _p(ws), _p(out), int(cpad), _stream())
+    return out
+
+
 def scale_cols_bwd(g2d, ypost2d, ncols, s):
     rows, BS = g2d.shape
     dsum = torch.empty(1, dtype=torch.float32, device=g2d.device)

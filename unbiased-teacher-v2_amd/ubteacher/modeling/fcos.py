@@ -288,6 +288,7 @@ class FCOSHead:
                 b = store.new((2 * C,), "decay", lambda t: t.zero_())
                 b.export(pc + ".bias", lambda t: t[:C]).export(pb + ".bias", lambda t: t[C:])
                 conv = ops.Conv(w, C, 2 * C, 3, 1, 1, bias=b, groups=1 if i == 0 else 2)
+                conv.defer_wgrad = True     # see ops.defer_tower_wgrads (UTV2_DEFER_TOWER_WGRAD)
                 gc, gb = "%s.cls_tower.%d" % (prefix, 3 * i + 1), "%s.bbox_tower.%d" % (prefix, 3 * i + 1)
                 ga = store.new((2 * C,), "nodecay", lambda t: t.fill_(1.0))
                 ga.export(gc + ".weight", lambda t: t[:C]).export(gb + ".weight", lambda t: t[C:])

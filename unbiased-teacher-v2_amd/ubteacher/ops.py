@@ -46,7 +46,16 @@ GRAD_SYNC = [None]  # utils.grad_sync.GradBuckets when data parallel: backward-o
 # the backbone's res4 / res5 layers fill 40-80 % of the chip per launch in either direction.  The arguments are recorded on the side
 # stream (the caching allocator must not hand their blocks out again while it still reads them); `join_wgrad_stream()` makes the main
 # stream wait (before the optimizer step / before a gradient bucket is all-reduced).
-_WGRAD = {"on": False, "streams": {}, "pending": set(), "lane_of": {}, "next": 0}
+_WGRAD = {"on": False, "streams": {}, "pending": set(), "lane_of": {}, "next": 0, "deferred": []}
+
+
+def defer_tower_wgrads():
+    """UTV2_DEFER_TOWER_WGRAD=1 (experiment, round 4): the weight gradients of layers marked `defer_wgrad` (the paired FCOS towers -
+    MFMA-bound, one 256-workgroup launch per depth that holds every CU) are not launched next to the tower's own dgrad chain - where
+    they compete with another MFMA-bound full-chip kernel and starve the HBM-bound GroupNorm backward - but held back until the first
+    weight gradient of the backbone / FPN backward, whose dgrad chain is mostly HBM-bound 1x1 layers.  Off in a data-parallel world
+    (the gradient buckets are reported ready when a layer's backward returns)."""
+    return os.environ.get("UTV2_DEFER_TOWER_WGRAD", "0") == "1" and GRAD_SYNC[0] is None
 
 
 def wgrad_lanes():
@@ -76,6 +85,25 @@ def _wgrad_launch(fn, *tensors, key=None):
     dev = tensors[0].device
     if not _WGRAD["on"] or dev.type != "cuda":
         return fn()
+    if key is not None and getattr(key, "defer_wgrad", False) and defer_tower_wgrads():
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))            # the operands are ready from here on
+        _WGRAD["deferred"].append((fn, tensors, key, ev))
+        _WGRAD["ndeferred"] = _WGRAD.get("ndeferred", 0) + 1
+        _WGRAD["pending"].add(dev)
+        return None
+    flush_deferred_wgrads()
+    _wgrad_issue(fn, tensors, key, None)
+
+
+def flush_deferred_wgrads():
+    held, _WGRAD["deferred"] = _WGRAD["deferred"], []
+    for fn, tensors, key, ev in held:
+        _wgrad_issue(fn, tensors, key, ev)
+
+
+def _wgrad_issue(fn, tensors, key, ready):
+    dev = tensors[0].device
     lanes = _lanes(dev)
     lane = 0
     if key is not None and len(lanes) > 1:
@@ -84,7 +112,10 @@ def _wgrad_launch(fn, *tensors, key=None):
             lane = _WGRAD["lane_of"][id(key)] = _WGRAD["next"] % len(lanes)
             _WGRAD["next"] += 1
     side = lanes[lane]
-    side.wait_stream(torch.cuda.current_stream(dev))   # the operands (and the zeroed gradient arena) are ready
+    if ready is not None:
+        side.wait_event(ready)                             # a deferred launch: only what was enqueued when its layer's backward ran
+    else:
+        side.wait_stream(torch.cuda.current_stream(dev))   # the operands (and the zeroed gradient arena) are ready
     with torch.cuda.stream(side):
         fn()
     for t in tensors:
@@ -111,6 +142,7 @@ def wgrad_stream_behind_main(dev):
 
 
 def join_wgrad_stream():
+    flush_deferred_wgrads()
     for dev in list(_WGRAD["pending"]):
         for side in _WGRAD["streams"][dev]:
             torch.cuda.current_stream(dev).wait_stream(side)
@@ -454,7 +486,16 @@ class _ConvFn(torch.autograd.Function):
             x = x.contiguous()   # a column slice (paired towers) in exact-f32 mode: the fp32 kernels take dense matrices
         sc, _ = layer.scale_shift()
         meta = ctx.meta
-        if ctx.cs is not None:
+        gp_ready = None
+        if (ctx.cs is not None and meta is not None and _scale_ml_on() and y.is_contiguous() and dy.dtype == torch.float32
+                and layer.k > 1 and ctx.needs_input_grad[0] and layer.use_bf16_dgrad() and layer.use_bf16_wgrad()
+                and layer.dgrad_cout() != layer.cout and not layer.relu and sc is None and not ctx.has_res
+                and os.environ.get("UTV2_SCALE_BWD_PAD16", "1") != "0"):
+            # the bbox prediction conv (fcos.py:338-364): Scale backward, conversion and zero padding of the gradient in ONE pass, out of
+            # place - no clone of the incoming gradient, no in-place scale, no separate pad pass (568 -> 224 MB on the student batch)
+            gp_ready = hip.scale_cols_bwd_ml_pad16(dy, y, meta.rows, layer.colscale, [h.t for h in ctx.cs], [h.g for h in ctx.cs],
+                                                   layer.dgrad_cout())
+        elif ctx.cs is not None:
             g = dy.clone()
             if meta is not None and _scale_ml_on() and y.is_contiguous():
                 # all levels in two launches (it was four per level, each waiting for the one before at the forward / backward seam)
@@ -494,7 +535,7 @@ class _ConvFn(torch.autograd.Function):
             Kg = layer.cout // G
             if ctx.needs_input_grad[0]:
                 if d16:
-                    gp = g if layer.dgrad_cout() == layer.cout else hip.pad_cols_bf16(g, layer.dgrad_cout())
+                    gp = gp_ready if gp_ready is not None else (g if layer.dgrad_cout() == layer.cout else hip.pad_cols_bf16(g, layer.dgrad_cout()))
                     other = ctx.fanin.take() if ctx.fanin is not None else None
                     if other is not None and (other.dtype != x.dtype or tuple(other.shape) != tuple(x.shape)):
                         raise RuntimeError("FanIn: stored gradient does not match the conv input")
