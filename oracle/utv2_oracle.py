@@ -1096,6 +1096,48 @@ def rcnn_teacher(sd, images, mean, pix_std, pre_topk=2000, post_topk=1000, thr=0
     return out, props
 
 
+def detector_postprocess(det, size, out_hw):
+    """Detectron2 detector_postprocess [D2-recall]: boxes scaled by (out_w / in_w, out_h / in_h), clipped to the output size, empty boxes
+    dropped (the reference calls it per image, one_stage_detector.py:16-43,136-145; D2 GeneralizedRCNN._postprocess for the two-stage model)"""
+    oh, ow = out_hw
+    sx, sy = ow / size[1], oh / size[0]
+    b = det["boxes"].clone()
+    b[:, 0::2] *= sx
+    b[:, 1::2] *= sy
+    b[:, 0::2] = b[:, 0::2].clamp(min=0, max=ow)
+    b[:, 1::2] = b[:, 1::2].clamp(min=0, max=oh)
+    keep = ((b[:, 2] - b[:, 0]) > 0) & ((b[:, 3] - b[:, 1]) > 0)
+    out = {k: (v[keep] if torch.is_tensor(v) and v.shape[:1] == keep.shape else v) for k, v in det.items()}
+    out["boxes"] = b[keep]
+    return out
+
+
+def rcnn_inference(sd, images, mean, pix_std, out_sizes=None, pre_topk=1000, post_topk=1000):
+    """The eval-mode two-stage detector (meta_arch/rcnn.py:12-13 -> Detectron2 GeneralizedRCNN.inference [D2-recall]): RPN with the *_TEST
+    top-k (proposal_generator/rpn.py:21-76, inference branch), box head on the pooled proposals, the predictor's inference
+    (roi_heads/roi_heads.py:118-139, roi_heads/fast_rcnn.py:1094-1125: XYXY decode, softmax, score threshold 0.05, class-aware NMS 0.5,
+    top 100, pred_boxes_std of the kept rows), detector_postprocess to the requested output sizes."""
+    p, sizes = rcnn_backbone(sd, images, mean, pix_std)
+    feats = [p[k] for k in ("p2", "p3", "p4", "p5", "p6")]
+    hw = [(f.shape[2], f.shape[3]) for f in feats]
+    anchors = make_anchors(hw, [4, 8, 16, 32, 64])
+    obj, dl = rpn_head(sd, feats)
+    props = find_top_rpn_proposals(anchors, obj, dl, sizes, pre_topk, post_topk)
+    pooled = roi_pool(feats[:4], [q["boxes"] for q in props])
+    scores, deltas, std = box_head(sd, pooled)
+    out, r = [], 0
+    for n, q in enumerate(props):
+        k = len(q["boxes"])
+        boxes = xyxy_apply_deltas(deltas[r:r + k], q["boxes"])
+        dets, rows = fast_rcnn_inference(boxes, F.softmax(scores[r:r + k], dim=-1), sizes[n])
+        dets["pred_boxes_std"] = std[r:r + k][rows]
+        if out_sizes is not None:
+            dets = detector_postprocess(dets, sizes[n], out_sizes[n])
+        out.append(dets)
+        r += k
+    return out, props
+
+
 def rcnn_student_losses(sd, images, gts, rpn_keys, roi_keys, pseudo, mean, pix_std, pre_topk=2000, post_topk=1000, props_override=None):
     """meta_arch/rcnn.py:23-37 / :57-72.  props_override (mixed-precision tests): RPN proposals to use instead of this forward's
     own (a discrete top-k + NMS selection, decoupled from rounding noise the same way pseudo_override decouples the teacher)."""

@@ -1,0 +1,169 @@
+"""Evaluation on a COCO-format dataset (reference evaluation/evaluator.py:14-104, engine/trainer.py:554-608,
+train_net.py:37-54, data/datasets/builtin.py): a tiny annotation json + image files written to a temporary directory, registered with
+register_coco_instances, loaded through the test-time mapper and scored by the COCO box evaluator.
+CPU: json -> dataset dicts (category remap, XYWH, crowd, area), the inference sampler's shards, ground truth from the dataset, the
+unlabeled split's loader.  GPU: Trainer.test() / train_net.py --eval-only run the eval-mode model over the registered set."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "unbiased-teacher-v2_amd"))
+sys.path.insert(0, ROOT)
+
+CATS = [{"id": 1, "name": "person"}, {"id": 18, "name": "dog"}, {"id": 44, "name": "bottle"}, {"id": 90, "name": "toothbrush"}]
+
+
+def write_tiny_coco(root, n=5, seed=0):
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    os.makedirs(os.path.join(root, "images"), exist_ok=True)
+    images, annos, aid = [], [], 1
+    for i in range(n):
+        h, w = [(60, 80), (72, 64), (48, 96)][i % 3]
+        fn = "img_%03d.png" % i
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), "RGB").save(os.path.join(root, "images", fn))
+        images.append({"id": 100 + 7 * (n - i), "file_name": fn, "height": h, "width": w})     # ids neither contiguous nor in file order
+        for _ in range(int(rng.integers(1, 4))):
+            bw, bh = float(rng.uniform(8, w / 2)), float(rng.uniform(8, h / 2))
+            x, y = float(rng.uniform(0, w - bw)), float(rng.uniform(0, h - bh))
+            annos.append({"id": aid, "image_id": images[-1]["id"], "category_id": CATS[int(rng.integers(0, 4))]["id"], "bbox": [x, y, bw, bh],
+                          "area": bw * bh * 0.7, "iscrowd": int(rng.random() < 0.15)})
+            aid += 1
+    annos.append({"id": aid, "image_id": images[0]["id"], "category_id": 1, "bbox": [1, 1, 5, 5], "area": 25.0, "iscrowd": 0, "ignore": 1})
+    path = os.path.join(root, "instances_tiny.json")
+    with open(path, "w") as f:
+        json.dump({"images": images, "annotations": annos, "categories": CATS[::-1]}, f)
+    return path, os.path.join(root, "images")
+
+
+@pytest.fixture
+def tiny(tmp_path):
+    from ubteacher.data import DatasetCatalog, register_coco_instances
+    jf, img_root = write_tiny_coco(str(tmp_path))
+    name = "tiny_coco_val_%d" % os.getpid()
+    if name in DatasetCatalog:
+        DatasetCatalog.remove(name)
+    register_coco_instances(name, {}, jf, img_root)
+    yield name, jf, img_root
+    DatasetCatalog.remove(name)
+
+
+def test_load_coco_json_contract(tiny):
+    from ubteacher.data import DatasetCatalog, MetadataCatalog
+    name, jf, img_root = tiny
+    assert DatasetCatalog.available(name) and not DatasetCatalog.available("coco_2017_val") and "coco_2017_val" in DatasetCatalog
+    dicts = DatasetCatalog.get(name)
+    raw = json.load(open(jf))
+    assert [d["image_id"] for d in dicts] == sorted(i["id"] for i in raw["images"])            # ascending image id
+    meta = MetadataCatalog.get(name)
+    assert meta.thing_dataset_id_to_contiguous_id == {1: 0, 18: 1, 44: 2, 90: 3} and meta.thing_classes == ["person", "dog", "bottle", "toothbrush"]
+    n_anno = 0
+    for d in dicts:
+        assert os.path.exists(d["file_name"]) and d["file_name"].startswith(img_root)
+        for a in d["annotations"]:
+            src = next(r for r in raw["annotations"] if r["image_id"] == d["image_id"] and r["bbox"] == a["bbox"])
+            assert a["bbox_mode"] == "XYWH_ABS" and a["category_id"] == meta.thing_dataset_id_to_contiguous_id[src["category_id"]]
+            assert a["iscrowd"] == src["iscrowd"] and a["area"] == src["area"]
+            n_anno += 1
+    assert n_anno == len(raw["annotations"]) - 1                                                  # the `ignore` annotation is skipped
+
+
+def test_inference_sampler_shards_cover_the_set_once():
+    from ubteacher.data import InferenceSampler
+    for size, world in ((10, 3), (5, 8), (7, 1), (16, 4)):
+        if size < world:
+            shards = [list(InferenceSampler(size, r, world)) for r in range(world)]
+            assert sorted(sum(shards, [])) == list(range(size))
+            continue
+        shards = [list(InferenceSampler(size, r, world)) for r in range(world)]
+        assert sum(shards, []) == list(range(size))                       # contiguous, in order, nothing twice
+        assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+
+
+def test_evaluator_takes_ground_truth_from_the_dataset(tiny):
+    """a detector that returns the ground truth scores 100 (crowd boxes and the annotations' `area` field included), a shifted one less"""
+    from ubteacher.d2.structures import Boxes, Instances
+    from ubteacher.data import DatasetCatalog
+    from ubteacher.data.dataset_mapper import to_xyxy_abs
+    from ubteacher.evaluation import COCOBoxEvaluator
+    name = tiny[0]
+    dicts = DatasetCatalog.get(name)
+
+    def outputs(shift):
+        ins, outs = [], []
+        for d in dicts:
+            keep = [a for a in d["annotations"] if not a["iscrowd"]]
+            inst = Instances((d["height"], d["width"]))
+            inst.pred_boxes = Boxes(torch.tensor([to_xyxy_abs(a) for a in keep], dtype=torch.float32).reshape(-1, 4) + shift)
+            inst.scores = torch.linspace(0.9, 0.5, len(keep))
+            inst.pred_classes = torch.tensor([a["category_id"] for a in keep], dtype=torch.int64)
+            ins.append({"image_id": d["image_id"], "height": d["height"], "width": d["width"]})      # the test mapper drops annotations
+            outs.append({"instances": inst})
+        return ins, outs
+    ev = COCOBoxEvaluator(80, dataset_name=name)
+    ev.process(*outputs(0.0))
+    res = ev.evaluate()["bbox"]
+    assert res["AP"] == pytest.approx(100.0) and res["AP50"] == pytest.approx(100.0)
+    ev.reset()
+    ev.process(*outputs(3.0))
+    res2 = ev.evaluate()["bbox"]
+    assert 0.0 < res2["AP"] < 100.0 and res2["AP50"] >= res2["AP75"]
+
+
+def test_unlabeled_split_and_builtin_names(tmp_path):
+    from ubteacher.data import DatasetCatalog, register_coco_unlabel_instances
+    jf, img_root = write_tiny_coco(str(tmp_path))
+    name = "tiny_unlabel_%d" % os.getpid()
+    register_coco_unlabel_instances(name, {}, jf, img_root)
+    try:
+        dicts = DatasetCatalog.get(name)
+        assert len(dicts) == 5 and all(set(d) == {"file_name", "height", "width"} for d in dicts)   # reference builtin.py:60-96
+    finally:
+        DatasetCatalog.remove(name)
+    assert {"coco_2017_train", "coco_2017_val", "coco_2017_unlabel"} <= set(DatasetCatalog)
+    with pytest.raises(FileNotFoundError):
+        DatasetCatalog.get("coco_2017_val")          # registered lazily; the files are not in this environment
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["fcos", "rcnn"])
+def test_trainer_test_runs_on_a_registered_coco_dataset(tiny, kind):
+    """Trainer.test(cfg, model) (reference engine/trainer.py:554-608; the --eval-only path of train_net.py:37-54) with DATASETS.TEST naming
+    a registered COCO-format set: real decode + test-time ResizeShortestEdge on the GPU, detections rescaled to the ORIGINAL image
+    sizes, the COCO box-AP dict from the dataset's own ground truth - no synthetic stand-in involved."""
+    from tests.utv2_testutil import small_fcos_cfg
+    from ubteacher.engine import UBRCNNTeacherTrainer, UBTeacherTrainer
+    from ubteacher.presets import get_config
+    name = tiny[0]
+    if kind == "fcos":
+        cfg, T = small_fcos_cfg(), UBTeacherTrainer
+    else:
+        cfg = get_config("rcnn", 1, ["SOLVER.IMG_PER_BATCH_LABEL", 2, "SOLVER.IMG_PER_BATCH_UNLABEL", 2, "SEMISUPNET.BURN_UP_STEP", 0, "MODEL.DEVICE", "cuda"])
+        T = UBRCNNTeacherTrainer
+    cfg.DATASETS.TEST = (name,)
+    cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = 96, 160
+    loader = T.build_test_loader(cfg, name)
+    assert type(loader).__name__ == "DetectionTestLoader" and len(loader) == 5
+    first = next(iter(loader))[0]
+    assert "annotations" not in first and first["image"].dtype == torch.uint8 and first["image"].shape[0] == 3
+    assert min(first["image"].shape[1:]) == 96 and (first["height"], first["width"]) in ((60, 80), (72, 64), (48, 96))
+    torch.manual_seed(0)
+    tr = T(cfg)
+    seen = {}
+    ev = T.build_evaluator(cfg, name)
+    assert ev._dataset_gt is not None and len(ev._dataset_gt) == 5
+    orig_process = ev.process
+
+    def process(inputs, outputs):
+        for i, o in zip(inputs, outputs):
+            seen[i["image_id"]] = (tuple(o["instances"].image_size), (i["height"], i["width"]))
+        orig_process(inputs, outputs)
+    ev.process = process
+    res = T.test(cfg, tr.model_teacher, evaluators=ev)
+    assert set(res["bbox"]) == {"AP", "AP50", "AP75", "APs", "APm", "APl"} and res["_speed"]["images"] >= 1
+    assert len(seen) == 5 and all(a == b for a, b in seen.values())      # detections live in the ORIGINAL image frame

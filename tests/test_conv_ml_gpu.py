@@ -179,3 +179,42 @@ def test_groupnorm_statistics_from_the_conv_epilogue(groups):
         assert torch.allclose(m1, m0, rtol=1e-5, atol=1e-6) and torch.allclose(r1, r0, rtol=1e-5)
         d = (z1.float() - z0.float()).abs()
         assert float(d.max()) <= 2 ** -7 * float(z0.float().abs().max()) and float((d > 0).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("K", [80, 72, 96])
+@pytest.mark.parametrize("out_dtype", ["f32", "h16"])
+def test_narrow_prediction_convs_on_the_96_wide_tile(K, out_dtype):
+    """The 256 -> 80 prediction convs of the FCOS head (fcos/fcos.py:306-376: cls_logits; bbox_pred | bbox_pred_std | ctrness fused)
+    run on the 256 x 96 tile of conv_igemm_bf16_v2<96> (round 4) when the level-first matrix is large enough: the same values as the
+    leading K columns of a 128-channel conv with the weight zero-padded (that one runs on the 128-wide tile: same K-loop order, same
+    fp32 accumulation -> bit-identical), with a bias, reading a column slice (row pitch 512), fp32 and 16-bit outputs; and against
+    torch on the same rounded operands.  A ragged last row tile and levels that start off the tile grid are part of the geometry."""
+    from ubteacher import hip
+    from ubteacher.ops import LevelMeta
+    g = torch.Generator().manual_seed(13)
+    C, N = 256, 2
+    level_hw = [(100, 84), (50, 42), (25, 21), (13, 11), (7, 6)]
+    meta = LevelMeta(N, level_hw)
+    P = meta.P
+    assert P >= 8192 and P % 256 != 0
+    h16 = hip.h16_dtype()
+    od = torch.float32 if out_dtype == "f32" else h16
+    x = (torch.randn(P, 2 * C, generator=g) * 0.5).to(h16).cuda()
+    w = (torch.randn(K, 9 * C, generator=g) * 0.02).to(h16).cuda()
+    b = torch.randn(K, generator=g).cuda()
+    y = hip.conv2d_ml_fwd_bf16(x[:, C:], w, level_hw, N, bias=b, k=3, pad=1, out_dtype=od)
+    assert tuple(y.shape) == (P, K) and y.dtype == od
+    w128 = torch.zeros(128, 9 * C, dtype=h16, device="cuda")
+    w128[:K] = w
+    b128 = torch.zeros(128, device="cuda")
+    b128[:K] = b
+    y128 = hip.conv2d_ml_fwd_bf16(x[:, C:].contiguous(), w128, level_hw, N, bias=b128, k=3, pad=1, out_dtype=od)
+    assert torch.equal(y, y128[:, :K])
+    xr = meta.level_view(x[:, C:].contiguous(), 1).float().permute(0, 3, 1, 2).cpu()
+    ref = F.conv2d(xr, w.float().view(K, 3, 3, C).permute(0, 3, 1, 2).cpu(), b.cpu(), 1, 1)
+    got = meta.level_view(y, 1).float().permute(0, 3, 1, 2).cpu()
+    assert relerr(got, ref) < (2e-4 if out_dtype == "f32" else 1e-2)
+    # relu + accumulate forms of the epilogue on both column blocks
+    y2 = hip.conv2d_ml_fwd_bf16(x[:, :C], w, level_hw, N, bias=b, k=3, pad=1, out_dtype=od, relu=True)
+    y2r = hip.conv2d_ml_fwd_bf16(x[:, :C].contiguous(), w128, level_hw, N, bias=b128, k=3, pad=1, out_dtype=od, relu=True)
+    assert torch.equal(y2, y2r[:, :K]) and float(y2.float().min()) >= 0.0

@@ -478,3 +478,49 @@ def test_rcnn_step_with_trainable_stem_runs_and_updates_it():
                 assert torch.isfinite(after[k]).all() and float(d.max()) > 0, k
     finally:
         ops.set_precision("fp32")
+
+
+def test_rcnn_eval_detections_vs_reference_golden():
+    """Faster-RCNN test-mode inference of the PRODUCT (Trainer.test -> inference_on_dataset -> eval-mode two-stage model -> RPN with the
+    *_TEST top-k -> box head -> predictor inference -> detector_postprocess) against the golden produced by executing the reference's
+    own eval-mode call chain (tests/golden/gen_golden_eval.py::gen_rcnn_eval; meta_arch/rcnn.py:8-13, proposal_generator/rpn.py:21-76,
+    roi_heads/roi_heads.py:75-139, roi_heads/fast_rcnn.py:1094-1125): a two-image ragged batch rescaled to original sizes; kept detections
+    identical in class and order, scores 1e-3, boxes 1e-3 of the image size, pred_boxes_std 1e-3."""
+    from tests.test_step_golden import _rcnn_eval_golden, rcnn_eval_golden_state
+    from ubteacher.engine import UBRCNNTeacherTrainer
+    from ubteacher.evaluation import inference_on_dataset
+    d = _rcnn_eval_golden()
+    _, sd = rcnn_eval_golden_state(d)
+    cfg = rcnn_cfg()
+    assert cfg.MODEL.RPN.PRE_NMS_TOPK_TEST == int(d["pre_topk"]) and cfg.MODEL.RPN.POST_NMS_TOPK_TEST == int(d["post_topk"])
+    torch.manual_seed(0)
+    prod, _ = make_batch(31, 2, 2, H, W, "cuda")
+    tr = UBRCNNTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+    tr.model_teacher.load_state_dict(sd)
+    batch = []
+    for i in range(2):
+        oh, ow = [int(x) for x in d["orig%d" % i]]
+        batch.append({"image": torch.from_numpy(d["img%d" % i]).cuda(), "height": oh, "width": ow, "image_id": i})
+
+    class Capture:
+        def reset(self):
+            self.out = []
+
+        def process(self, inputs, outputs):
+            self.out.extend(outputs)
+
+        def evaluate(self):
+            return {}
+    ev = Capture()
+    inference_on_dataset(tr.model_teacher, [batch], ev, cfg)
+    assert len(ev.out) == 2
+    for i, r in enumerate(ev.out):
+        x = r["instances"]
+        oh, ow = [int(v) for v in d["orig%d" % i]]
+        assert tuple(x.image_size) == (oh, ow)
+        cls, sc, bx, sd_ = d["classes%d" % i], d["scores%d" % i], d["boxes%d" % i], d["std%d" % i]
+        assert len(x) == len(cls) and len(cls) > 0, (len(x), len(cls))
+        assert np.array_equal(x.pred_classes.long().cpu().numpy(), cls)
+        np.testing.assert_allclose(x.scores.cpu().numpy(), sc, rtol=1e-3)
+        np.testing.assert_allclose(x.pred_boxes.tensor.cpu().numpy(), bx, rtol=0, atol=1e-3 * max(oh, ow))
+        np.testing.assert_allclose(x.pred_boxes_std.cpu().numpy(), sd_, rtol=1e-3, atol=1e-4)

@@ -143,3 +143,38 @@ def test_fcos_eval_oracle_vs_reference_golden():
             assert np.array_equal(det["classes"][keep].numpy(), d["%s_classes%d" % (name, i)]), (name, i)
             np.testing.assert_allclose(det["scores"][keep].numpy(), d["%s_scores%d" % (name, i)], rtol=1e-5)
             np.testing.assert_allclose(b[keep].numpy(), d["%s_boxes%d" % (name, i)], rtol=1e-4, atol=1e-3)
+
+
+def _rcnn_eval_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rcnn_eval.npz"), allow_pickle=False)
+
+
+def rcnn_eval_golden_state(d):
+    """the weights the Faster-RCNN eval golden ran on: product CPU init (fingerprint-checked) + the stored rescaled prediction layers"""
+    from tests.utv2_testutil import golden_init_state
+    cfg, sd = golden_init_state("rcnn", d)
+    sd = dict(sd)
+    for k in d["changed"]:
+        sd[str(k)] = torch.from_numpy(d["state::" + str(k)].copy())
+    return cfg, sd
+
+
+def test_rcnn_eval_oracle_vs_reference_golden():
+    """Faster-RCNN test-mode inference (tests/golden/gen_golden_eval.py::gen_rcnn_eval: the reference's eval-mode
+    TwoStagePseudoLabGeneralizedRCNN.forward -> PseudoLabRPN.forward -> StandardROIHeadsPseudoLab.forward -> predictor.inference,
+    meta_arch/rcnn.py:8-13, proposal_generator/rpn.py:21-76, roi_heads/roi_heads.py:75-139, roi_heads/fast_rcnn.py:1094-1125): the oracle's
+    rcnn_inference reproduces the kept detections - classes and order exact, scores 1e-5, boxes 1e-4, pred_boxes_std 1e-5."""
+    d = _rcnn_eval_golden()
+    cfg, sd = rcnn_eval_golden_state(d)
+    images = [torch.from_numpy(d["img%d" % i]) for i in range(2)]
+    mean, pstd = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1), torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1)
+    origs = [tuple(int(v) for v in d["orig%d" % i]) for i in range(2)]
+    with torch.no_grad():
+        dets, props = O.rcnn_inference(sd, images, mean, pstd, origs, int(d["pre_topk"]), int(d["post_topk"]))
+    for i, det in enumerate(dets):
+        assert len(props[i]["boxes"]) == int(d["nprop%d" % i])
+        assert np.array_equal(det["classes"].numpy(), d["classes%d" % i]) and len(det["classes"]) > 0
+        np.testing.assert_allclose(det["scores"].numpy(), d["scores%d" % i], rtol=1e-5)
+        np.testing.assert_allclose(det["boxes"].numpy(), d["boxes%d" % i], rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(det["pred_boxes_std"].numpy(), d["std%d" % i], rtol=1e-5, atol=1e-6)

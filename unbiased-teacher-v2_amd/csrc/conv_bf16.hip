@@ -403,19 +403,25 @@ static int fill_levels16(LevelTab& lt, int nlev, int N, const int* H, const int*
 //     s ^ ((r >> 2) & 3) (BK = 32): the 16 rows a ds_read_b128 lane group touches then fall on 16 distinct slots of the
 //     256-byte bank row (the padded 80-byte rows of the fp32-input kernel cost 2-way ds_write conflicts).
 // Stride-1-in-the-input only (in_dil == 1); KH*KW <= 16.
+// BN = 96 (round 4): the narrow prediction convs (256 -> 80: cls_logits, bbox_pred | std | ctrness of fcos/fcos.py:306-376).  On the
+// 128-wide tile 37 % of their MFMAs and fragment reads computed zero columns.  Here the four waves stack in M (256 x 96 tile, 64 x 96
+// per wave = 2 x 3 accumulators): 5 fragment reads feed 6 MFMAs per k16 step (4 : 4 on the 128 x 128 tile) and 83 % of the columns are
+// real.  Same staging, swizzle, pipeline and epilogue (called on the 64- and the 32-column part of the wave tile).
 template <int BN, bool ML, int BK, typename TO>
-__global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(ConvArgs16 p) {
-  constexpr int BM = 128, ROWB = BK * 2;              // LDS row = BK bf16
+__global__ __launch_bounds__(256, (BK == 32 && BN != 96) ? 4 : 2) void conv_igemm_bf16_v2(ConvArgs16 p) {
+  constexpr int WN = BN == 96 ? 1 : 2, WM = 4 / WN, WCOLS = BN / WN;   // waves along N / M; output columns per wave
+  constexpr int BM = WM * 64, ROWB = BK * 2;          // LDS row = BK bf16
   constexpr int SLOTS = BK / 8, RPP = 256 / SLOTS;    // 16-byte slots per row; rows staged per pass of the 256 threads
-  constexpr int TM = 2, TN = BN / 64, AP = BM / RPP, BP = BN / RPP, KS = BK / 16;  // pieces per thread; k16 steps per chunk
-  constexpr int ABUF = BM * ROWB, BBUF = BN * ROWB;
-  constexpr int STAGE = 2 * (ABUF + BBUF), PATCH = 4 * 32 * ((BN / 2) + 4) * 4;  // staging buffers; epilogue patches
+  constexpr int TM = 2, TN = WCOLS / 32, AP = BM / RPP, BP = (BN + RPP - 1) / RPP, KS = BK / 16;  // pieces per thread; k16 steps per chunk
+  constexpr int ABUF = BM * ROWB, BBUF = BP * RPP * ROWB;
+  constexpr int PCOLS = WCOLS > 64 ? 64 : WCOLS;      // widest column block one epilogue call handles
+  constexpr int STAGE = 2 * (ABUF + BBUF), PATCH = 4 * 32 * (PCOLS + 4) * 4;  // staging buffers; epilogue patches
   __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE > PATCH ? STAGE : PATCH];
   unsigned char* As = smem;
   unsigned char* Bs = smem + 2 * ABUF;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / WN, wn = wid % WN;
   const int tilesN = (p.K + BN - 1) / BN;
   const int nwg = gridDim.x;
   int tile;
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
 #pragma unroll
   for (int j = 0; j < BP; ++j) {
     const int co = n0 + lrow + RPP * j;
-    bvalid[j] = co < p.K;
+    bvalid[j] = co < p.K && lrow + RPP * j < BN;
     boff[j] = (bvalid[j] ? co : 0) * p.Kred + slot * 8;
   }
 
@@ -530,7 +536,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
   int koff[KS];  // byte offset of the lane's 8 k-elements of k16-step s inside its (swizzled) row
 #pragma unroll
   for (int s = 0; s < KS; ++s) koff[s] = ((2 * s + fh) ^ swz) * 16;
-  const int arow = (wm * 64 + frow) * ROWB, brow = (wn * (BN / 2) + frow) * ROWB;
+  const int arow = (wm * 64 + frow) * ROWB, brow = (wn * WCOLS + frow) * ROWB;
 
   cursor_next();
 #pragma unroll
@@ -580,10 +586,22 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
   iteration(kc & 1, no{}, no{});
 
   if ((p.K & 3) == 0) {
-    static_assert(sizeof(smem) >= 4 * 32 * ((BN / 2) + 4) * sizeof(float), "epilogue patches must fit the staging LDS");
-    float* patch = (float*)smem + wid * (32 * ((BN / 2) + 4));
-    epilogue_rows<TN, TO, (BK != 32)>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
-                          m0 + wm * 64, n0 + wn * (BN / 2), p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
+    static_assert(sizeof(smem) >= 4 * 32 * (PCOLS + 4) * sizeof(float), "epilogue patches must fit the staging LDS");
+    float* patch = (float*)smem + wid * (32 * (PCOLS + 4));
+    if constexpr (TN == 3) {
+      // the wave's 64 x 96 tile as a 64-column and a 32-column block (the epilogue's lane mapping needs a power-of-two column count)
+      f32x16 lo[2][2], hi[2][1];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { lo[i][0] = acc[i][0]; lo[i][1] = acc[i][1]; hi[i][0] = acc[i][2]; }
+      epilogue_rows<2, TO, true>(lo, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate, m0 + wm * 64, n0,
+                                 p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, nullptr, p.bits);
+      if (n0 + 64 < p.K)
+        epilogue_rows<1, TO, true>(hi, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate, m0 + wm * 64,
+                                   n0 + 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, nullptr, p.bits);
+    } else {
+      epilogue_rows<TN, TO, (BK != 32)>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
+                            m0 + wm * 64, n0 + wn * WCOLS, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
+    }
     return;
   }
   TO* yo = (TO*)p.y;
@@ -591,7 +609,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void conv_igemm_bf16_v2(Conv
   const TO* msk = (const TO*)p.mask;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int co = n0 + wn * (BN / 2) + j * 32 + frow;
+    const int co = n0 + wn * WCOLS + j * 32 + frow;
     if (co >= p.K) continue;
     const float sc = p.scale ? p.scale[co] : 1.f;
     const float bi = p.bias ? p.bias[co] : 0.f;
@@ -1216,7 +1234,10 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
         return;
       }
     }
-    if (deep) {
+    if constexpr (BN == 96) {   // 256 x 96 tile: BK = 32 only (a BK = 64 stage would need 88 KB of LDS: one workgroup per CU)
+      if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<96, ML, 32, h16_t>), g, b, 0, stream, a);
+      else hipLaunchKernelGGL((conv_igemm_bf16_v2<96, ML, 32, float>), g, b, 0, stream, a);
+    } else if (deep) {
       if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 64, h16_t>), g, b, 0, stream, a);
       else hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 64, float>), g, b, 0, stream, a);
     } else {
@@ -1225,13 +1246,22 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
     }
     return;
   }
-  if (x_dtype == UTV2_BF16) {
-    if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, h16_t, h16_t>), g, b, 0, stream, a);
-    else hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, h16_t, float>), g, b, 0, stream, a);
-  } else {
-    if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, float, h16_t>), g, b, 0, stream, a);
-    else hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, float, float>), g, b, 0, stream, a);
+  if constexpr (BN != 96) {   // (the callers send only v2-eligible problems to the 96-wide tile: n96_eligible)
+    if (x_dtype == UTV2_BF16) {
+      if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, h16_t, h16_t>), g, b, 0, stream, a);
+      else hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, h16_t, float>), g, b, 0, stream, a);
+    } else {
+      if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, float, h16_t>), g, b, 0, stream, a);
+      else hipLaunchKernelGGL((conv_igemm_bf16<BN, ML, float, float>), g, b, 0, stream, a);
+    }
   }
+}
+
+// the 256 x 96 tile (conv_igemm_bf16_v2<96>): level-first 16-bit inputs, 64 < K <= 96 output channels, everything the v2 kernels need
+static const bool g_use_n96 = env_int("UTV2_CONV_N96", 1) != 0;
+static bool n96_eligible(const ConvArgs16& a, int x_dtype) {
+  return g_use_n96 && x_dtype == UTV2_BF16 && a.K > 64 && a.K <= 96 && (a.K & 3) == 0 && a.C % 32 == 0 && a.in_dil == 1 && a.KH * a.KW <= 16 &&
+         a.groups == 1 && !a.gn_part && a.M >= 8192 && (int64_t)a.M * a.xs < (1ll << 31) && (int64_t)a.K * a.Kred < (1ll << 31);
 }
 
 static inline bool bad_dtype(int d) { return d != UTV2_F32 && d != UTV2_BF16; }
@@ -1338,7 +1368,8 @@ int utv2_conv2d_ml_fwd_bf16_g(const void* x, int x_dtype, int x_pitch, const voi
   a.relu = (relu ? 1 : 0) | g_epi_general; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = x_pitch; a.m_begin = 0; a.groups = groups; a.ldy = y_pitch; a.gn_part = gn_part; a.rowinfo = (const int2*)rowinfo;
   const bool small = K <= 64 && plain;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
-  if (small) launch_igemm16<64, true>(a, tiles, x_dtype, y_dtype, stream);
+  if (n96_eligible(a, x_dtype)) launch_igemm16<96, true>(a, cdiv(a.M, 256), x_dtype, y_dtype, stream);
+  else if (small) launch_igemm16<64, true>(a, tiles, x_dtype, y_dtype, stream);
   else launch_igemm16<128, true>(a, tiles, x_dtype, y_dtype, stream);
   return utv2_launch_status();
 }
@@ -1357,7 +1388,8 @@ int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y
   a.relu = (relu ? 1 : 0) | g_epi_general; a.accumulate = accumulate; a.Kred = KH * KW * C; a.xs = C; a.m_begin = 0; a.groups = 1; a.ldy = K; a.gn_part = nullptr; a.rowinfo = nullptr;
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
-  if (small) launch_igemm16<64, true>(a, tiles, x_dtype, y_dtype, stream);
+  if (n96_eligible(a, x_dtype)) launch_igemm16<96, true>(a, cdiv(a.M, 256), x_dtype, y_dtype, stream);
+  else if (small) launch_igemm16<64, true>(a, tiles, x_dtype, y_dtype, stream);
   else launch_igemm16<128, true>(a, tiles, x_dtype, y_dtype, stream);
   return utv2_launch_status();
 }
