@@ -186,8 +186,7 @@ def test_groupnorm_statistics_from_the_conv_epilogue(groups):
 def test_narrow_prediction_convs_on_the_96_wide_tile(K, out_dtype):
     """The 256 -> 80 prediction convs of the FCOS head (fcos/fcos.py:306-376: cls_logits; bbox_pred | bbox_pred_std | ctrness fused)
     run on the 256 x 96 tile of conv_igemm_bf16_v2<96> (round 4) when the level-first matrix is large enough: the same values as the
-    leading K columns of a 128-channel conv with the weight zero-padded (that one runs on the 128-wide tile: same K-loop order, same
-    fp32 accumulation -> bit-identical), with a bias, reading a column slice (row pitch 512), fp32 and 16-bit outputs; and against
+    leading K columns of a 128-channel conv with the weight zero-padded (that one runs on the 128-wide tile), with a bias, reading a column slice (row pitch 512), fp32 and 16-bit outputs; and against
     torch on the same rounded operands.  A ragged last row tile and levels that start off the tile grid are part of the geometry."""
     from ubteacher import hip
     from ubteacher.ops import LevelMeta
@@ -209,7 +208,10 @@ def test_narrow_prediction_convs_on_the_96_wide_tile(K, out_dtype):
     b128 = torch.zeros(128, device="cuda")
     b128[:K] = b
     y128 = hip.conv2d_ml_fwd_bf16(x[:, C:].contiguous(), w128, level_hw, N, bias=b128, k=3, pad=1, out_dtype=od)
-    assert torch.equal(y, y128[:, :K])
+    # (the 128-wide tile walks the K loop in 64-channel chunks, this one in 32-channel chunks: the same products summed in another
+    # order in fp32 - equal to accumulation-order rounding, not bit for bit)
+    tol = 2e-5 if out_dtype == "f32" else 2 ** -9
+    assert float((y.float() - y128[:, :K].float()).abs().max()) <= tol * float(y128.float().abs().max())
     xr = meta.level_view(x[:, C:].contiguous(), 1).float().permute(0, 3, 1, 2).cpu()
     ref = F.conv2d(xr, w.float().view(K, 3, 3, C).permute(0, 3, 1, 2).cpu(), b.cpu(), 1, 1)
     got = meta.level_view(y, 1).float().permute(0, 3, 1, 2).cpu()
@@ -217,4 +219,7 @@ def test_narrow_prediction_convs_on_the_96_wide_tile(K, out_dtype):
     # relu + accumulate forms of the epilogue on both column blocks
     y2 = hip.conv2d_ml_fwd_bf16(x[:, :C], w, level_hw, N, bias=b, k=3, pad=1, out_dtype=od, relu=True)
     y2r = hip.conv2d_ml_fwd_bf16(x[:, :C].contiguous(), w128, level_hw, N, bias=b128, k=3, pad=1, out_dtype=od, relu=True)
-    assert torch.equal(y2, y2r[:, :K]) and float(y2.float().min()) >= 0.0
+    assert float((y2.float() - y2r[:, :K].float()).abs().max()) <= tol * float(y2r.float().abs().max()) and float(y2.float().min()) >= 0.0
+    # bit-deterministic
+    y3 = hip.conv2d_ml_fwd_bf16(x[:, :C], w, level_hw, N, bias=b, k=3, pad=1, out_dtype=od, relu=True)
+    assert torch.equal(y2, y3)
