@@ -549,8 +549,8 @@ def rcnn_subrecord(args, device_index, timer, steps=10, warmup=5, dtype="bf16"):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--label", type=int, default=4, help="labeled images per GPU")
     ap.add_argument("--unlabel", type=int, default=4, help="unlabeled images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -564,6 +564,7 @@ def parse_args(argv=None):
                          "all-gather), print {n_gpus, rccl_ranks, ...} on rank 0 and stop: first contact with the backend in seconds")
     ap.add_argument("--no-rcnn", action="store_true", help="skip the Faster-RCNN sub-records (GPU step of configs[2]/[4], CPU step of configs[0])")
     ap.add_argument("--timed-only", action="store_true", help="only the warmup and the timed steps (profiling runs): no exclusive pass, no host probe")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph-replay sub-record (host.step_as_hipgraph)")
     ap.add_argument("--no-f32", action="store_true", help="skip the f32 sub-record / the bf16-vs-f32 one-step loss deviation")
     ap.add_argument("--model", choices=["fcos", "rcnn"], default="fcos",
                     help="fcos: BASELINE configs[1] (the headline workload); rcnn: the Faster-RCNN UTv2 trainer of configs[2] / [4] on the same "
@@ -882,6 +883,36 @@ def worker(args):
     if dump_rcnn is not None and dump_rcnn != dump and os.path.exists(dump_rcnn):
         os.remove(dump_rcnn)
 
+    graph_rec = None
+    if rank == 0 and world == 1 and not args.timed_only and args.dtype != "f32" and not args.no_graph:
+        # the same step as ONE hipGraph launch (engine.trainer.run_step_graph): last, on a fresh trainer, so that a failed capture cannot
+        # disturb any other measurement.  host_ms = what the host spends per step inside hipGraphLaunch (on this ROCm stack the runtime
+        # enqueues the ~490 kernel nodes one by one on the host: measured 17 ms per step, MORE than the eager step's 10 ms of Python)
+        try:
+            torch.cuda.empty_cache()
+            trg = make_trainer(args.dtype)
+            (tune_rcnn_for_pseudo_labels if rcnn else tune_for_pseudo_labels)(trg, trg._data_loader.batches[0])
+            for _ in range(4):                      # two eager warm-ups, the capture (+ first replay), one more replay
+                trg.run_step_graph(); trg.iter += 1
+            torch.cuda.synchronize()
+            kg = max(args.steps, 10)
+            t1 = time.perf_counter()
+            for _ in range(kg):
+                trg.run_step_graph(); trg.iter += 1
+            th_ = time.perf_counter() - t1
+            torch.cuda.synchronize()
+            dg = time.perf_counter() - t1
+            mg = trg.flush_metrics()
+            graph_rec = {"value": (args.label + args.unlabel) * kg / dg, "unit": "images/sec", "ms_per_step": 1e3 * dg / kg, "steps": kg,
+                         "host_ms_per_step": 1e3 * th_ / kg, "losses_finite": all(v == v and abs(v) != float("inf") for v in mg.values()),
+                         "note": "the whole iteration (teacher EMA + forward, pseudo-labelling, student forward / backward on four streams, AMP "
+                                 "scaler, SGD) captured once with torch.cuda.graph and replayed: one launch per step on the host"}
+            del trg
+        except Exception as e:  # noqa: BLE001
+            graph_rec = {"error": repr(e)[:300]}
+        finally:
+            ops.STEP_GRAPH[0] = False
+
     if rank == 0:
         per_step_images = (args.label + args.unlabel) * world
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS   # f16 MFMA: the bf16 rate
@@ -940,6 +971,8 @@ def worker(args):
             out["parity_fullsize"] = parity_full
         if rcnn_rec is not None:
             out["rcnn"] = rcnn_rec
+        if graph_rec is not None:
+            out["host"]["step_as_hipgraph"] = graph_rec
         if cpu_rcnn is not None and not rcnn:
             out["cpu_baseline_rcnn"] = cpu_rcnn
         print(json.dumps(out), flush=True)

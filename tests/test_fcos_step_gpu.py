@@ -664,3 +664,50 @@ def test_checkpoint_roundtrip_on_device_arena(tmp_path):
     for k, v in rec_a.items():
         if k != "data_time":
             assert rec_b[k] == v, k
+
+
+@pytest.mark.parametrize("kind", ["fcos", "rcnn"])
+def test_step_as_hipgraph_replays_the_eager_step(kind):
+    """engine.trainer.run_step_graph: the whole UTv2 iteration (reference engine/trainer.py:181-429 / :786-912) captured once as a hipGraph and
+    replayed.  Same initial weights and the same static batch on two trainers: five eager steps against two eager + capture + three
+    replays - the same losses at every logged step and the same student / teacher afterwards (to fp32 reduction-order noise: the
+    device RNG draws of the step differ between eager and replay only in their Philox offsets, which the FCOS step does not consume for
+    anything that reaches a loss; the Faster-RCNN step samples anchors / proposals with them, so there the comparison is statistical)."""
+    from ubteacher import ops
+    from ubteacher.data.synthetic import SyntheticTwoCropLoader
+    from ubteacher.engine import UBRCNNTeacherTrainer, UBTeacherTrainer
+    from ubteacher.presets import get_config
+    import bench
+    cfg = get_config(kind, 1, ["SOLVER.IMG_PER_BATCH_LABEL", 2, "SOLVER.IMG_PER_BATCH_UNLABEL", 2, "SEMISUPNET.BURN_UP_STEP", 0,
+                               "SOLVER.AMP.ENABLED", True, "MODEL.DEVICE", "cuda"])
+    T = UBTeacherTrainer if kind == "fcos" else UBRCNNTeacherTrainer
+    outs = []
+    try:
+        for graph in (False, True):
+            torch.manual_seed(0)
+            tr = T(cfg, data_loader=SyntheticTwoCropLoader(cfg, height=96, width=128))
+            (bench.tune_for_pseudo_labels if kind == "fcos" else bench.tune_rcnn_for_pseudo_labels)(tr, tr._data_loader.batches[0])
+            tr.iter, tr.log_period = 1, 10 ** 9
+            # (random-init R50 features are not normalised: the Faster-RCNN problem only stays finite at a vanishing rate, as in bench.py)
+            tr.optimizer.param_groups[0]["lr"] = 1e-3 if kind == "fcos" else 1e-12
+            recs = []
+            for _ in range(5):
+                (tr.run_step_graph if graph else tr.run_step_full_semisup)()
+                tr.iter += 1
+                recs.append(dict(tr.flush_metrics()))
+            torch.cuda.synchronize()
+            if graph:
+                assert tr._step_graph["graph"] is not None            # steps 3..5 were replays
+            outs.append((recs, tr.model.flat_state().clone(), tr.model_teacher.flat_state().clone()))
+            ops.STEP_GRAPH[0] = False
+    finally:
+        ops.STEP_GRAPH[0] = False
+    (ra, sa, ta), (rb, sb, tb) = outs
+    tol = 1e-4 if kind == "fcos" else 0.5
+    for a, b in zip(ra, rb):
+        for k, v in a.items():
+            if k.startswith("loss"):
+                assert v == v and abs(b[k] - v) <= tol * max(abs(v), 1e-3), (k, v, b[k])
+    assert torch.isfinite(sa).all() and torch.isfinite(sb).all() and torch.isfinite(tb).all()
+    if kind == "fcos":
+        assert float((sa - sb).abs().max()) <= 1e-4 * float(sa.abs().max()) and float((ta - tb).abs().max()) <= 1e-4 * float(ta.abs().max())

@@ -77,6 +77,7 @@ class SyntheticTwoCropLoader:
                 uq.append({"image": strong.to(dev), "height": height, "width": width})
             self.batches.append((lq, lk, uq, uk))
         self._i = 0
+        self.static_batches = num_batches == 1     # the same device tensors every iteration (engine.trainer.run_step_graph)
 
     def __iter__(self):
         return self

@@ -355,6 +355,48 @@ class _TrainerBase:
             finally:
                 self.flush_metrics()
 
+    # -- one step as a hipGraph (round 4) ----------------------------------------------------------------
+    def run_step_graph(self):
+        """run_step_full_semisup as ONE hipGraph launch (torch.cuda.graph capture of the whole iteration: teacher EMA and forward on its
+        side stream, pseudo-labelling, the student's forward / losses / backward with the weight gradients on their lanes, the AMP
+        scaler, SGD - ~490 kernel nodes on four streams).  The step has no host synchronisation and no data-dependent shapes (padded
+        detections, device-side counts), which is what makes the capture legal.  MEASURED (round 4, ROCm 7.2, bench.py
+        `host.step_as_hipgraph`): the replayed step takes the GPU as long as the eager one (25.5-25.8 against 25.4 ms - the chip is busy
+        either way, there are no launch gaps to win), and hipGraphLaunch keeps the host busy for 17 ms per step (the runtime walks the
+        node list on the host) against 10 ms of Python for the eager step: no gain on either side on this stack, so it is NOT the
+        default; kept as an opt-in (a future runtime with device-side graph launch would change the host figure) and as the proof
+        that the step is capture-clean.
+        Conditions, checked here: a loader that hands the SAME device tensors every step (`static_batches`: the synthetic loader of the
+        benchmark; real loaders produce another canvas per batch), one rank (collectives inside a capture are untested on this
+        stack), the post-burn-in branch, no metric flush inside the step.  A changed learning rate re-captures (the rate is a launch
+        argument): in a real schedule that is once per milestone after the warm-up.  The first call after (re)capture conditions
+        runs eagerly (allocator warm-up)."""
+        if not getattr(self._data_loader, "static_batches", False):
+            raise RuntimeError("run_step_graph needs a loader with static device batches (data.synthetic.SyntheticTwoCropLoader, one batch)")
+        if self.data_parallel or self.model.device.type != "cuda":
+            raise RuntimeError("run_step_graph: one CUDA rank only")
+        if self.iter < self.cfg.SEMISUPNET.BURN_UP_STEP + 1:
+            return self.run_step_full_semisup()
+        ops.STEP_GRAPH[0] = True
+        key = (float(self.optimizer.param_groups[0]["lr"]),)
+        st = self.__dict__.setdefault("_step_graph", {"key": None, "graph": None, "warm": 0})
+        if st["key"] != key:
+            st.update(key=key, graph=None, warm=0)
+        flush = (self.iter + 1) % self.log_period == 0
+        if st["graph"] is None:
+            if st["warm"] < 2 or flush:
+                st["warm"] += 1
+                return self.run_step_full_semisup()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st["loss"] = self.run_step_full_semisup()
+            st["graph"], st["pending"] = g, self._pending_metrics
+        st["graph"].replay()
+        self._pending_metrics = st["pending"]        # the captured metric tensors were just rewritten by the replay
+        if flush:
+            self.flush_metrics()
+        return st["loss"]
+
     # -- EMA (trainer.py:468-486 / :950-968) ---------------------------------------------------------
     @torch.no_grad()
     def _update_teacher_model(self, keep_rate=0.996):

@@ -38,6 +38,7 @@ def act_dtype():
 
 
 _VERSION = [0]  # bumped by the optimizer step: invalidates cached dgrad weight images
+STEP_GRAPH = [False]  # a trainer runs its step as a captured hipGraph (engine.trainer.run_step_graph): no work may cross the step boundary on a side stream
 GRAD_SYNC = [None]  # utils.grad_sync.GradBuckets when data parallel: backward-overlapped all-reduce of the gradient arena
 
 
@@ -263,7 +264,8 @@ class FlipBank:
         critical path (the batched launch used to be the first thing a backward waited for: 67 us with the chip idle at the forward /
         backward seam).  The first get() of the new version waits for the side stream's event instead of launching."""
         cur = self._current()
-        if self.bank is None or self.dirty or self.version == cur or self.h16 != hip.H16[0] or os.environ.get("UTV2_FLIP_AHEAD", "1") == "0":
+        if (self.bank is None or self.dirty or self.version == cur or self.h16 != hip.H16[0] or os.environ.get("UTV2_FLIP_AHEAD", "1") == "0"
+                or STEP_GRAPH[0]):   # a one-step graph capture cannot hold work that the NEXT step joins: the first dgrad rebuilds the images
             return
         dev = self.store.flat.device
         if dev.type != "cuda":
