@@ -610,3 +610,47 @@ def test_maxpool_backward_first_maximum_rule(dt):
             assert float((got.float() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max())
         raw = hip.maxpool3x3s2_bwd(x, dy.permute(0, 2, 3, 1).contiguous(), relu=False)
         assert float((raw.float() - xr.grad.permute(0, 2, 3, 1)).abs().max()) <= (0 if dt == torch.float32 else 2.0 ** -7 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("ydt", [BF, torch.float32])
+def test_tall_256x64_tile_on_long_narrow_layers(ydt):
+    """K <= 64 layers with a real K loop and >= 65536 output pixels (res2's 3x3 64 -> 64 at benchmark size, the stem) run on the
+    256 x 64 tile of conv_igemm_bf16_v2<64, ..., TALL> (round 4): == an fp32 conv on the rounded operands, with FrozenBN scale / shift,
+    residual and ReLU in the epilogue, a ragged last row tile, and the ReLU bit plane written from the same stored values."""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(5)
+    N, H, W, C, K = 2, 203, 167, 64, 64                  # M = 67 802: not a multiple of 256
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.05
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda().to(BF)
+    w16 = w.permute(0, 2, 3, 1).reshape(K, -1).contiguous().cuda().to(BF)
+    res = torch.randn(N, H, W, K, generator=g).cuda().to(ydt)
+    y = hip.conv2d_fwd_bf16(xh, w16, scale=sc.cuda(), bias=sh.cuda(), residual=res, stride=1, pad=1, kh=3, kw=3, relu=True, out_dtype=ydt)
+    ref = torch.relu(F.conv2d(r16(x), r16(w), None, 1, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res.float().cpu().permute(0, 3, 1, 2))
+    yc = y.cpu().permute(0, 3, 1, 2)
+    assert relerr(yc, ref) < 2e-4 if ydt == torch.float32 else close16(yc, ref)
+    if ydt == BF:
+        bits = hip.relu_bits_buffer((N, H, W, K), "cuda")
+        y2 = hip.conv2d_fwd_bf16(xh, w16, scale=sc.cuda(), bias=sh.cuda(), stride=1, pad=1, kh=3, kw=3, relu=True, out_dtype=ydt, relu_bits=bits)
+        want = (y2.float() > 0).view(-1, K // 8, 8)
+        got = ((bits.view(-1, K // 8, 1).int() >> torch.arange(8, device="cuda").view(1, 1, 8)) & 1).bool()
+        assert torch.equal(got, want)
+
+
+def test_stem_on_the_tall_tile_at_benchmark_size():
+    """the image stem at a size whose 400 x 336 output grid (134 400 pixels) reaches the 256 x 64 tile"""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(8)
+    ims = [torch.randn(3, 800, 672, generator=g) * 50 + 100]
+    mean, std = [103.53, 116.28, 123.675], [57.0, 58.0, 59.0]
+    x16, _ = hip.preprocess_images([i.cuda() for i in ims], mean, std, 32, bf16_stem=True)
+    x4, _ = hip.preprocess_images([i.cuda() for i in ims], mean, std, 32)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    w208 = torch.zeros(64, 208)
+    w208[:, :196].view(64, 7, 7, 4)[..., :3] = w.permute(0, 2, 3, 1)
+    sc = (torch.rand(64, generator=g) + 0.5); sh = torch.randn(64, generator=g) * 0.1
+    y = hip.conv2d_stem_fwd_bf16(x16, hip.stem_weight_image(w208.cuda()), sc.cuda(), sh.cuda(), True, BF)
+    xin = x4[..., :3].permute(0, 3, 1, 2).cpu()
+    ref = torch.relu(F.conv2d(r16(xin), r16(w), None, 2, 3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    assert y.shape[1] * y.shape[2] >= 65536 and close16(y.cpu().permute(0, 3, 1, 2), ref)

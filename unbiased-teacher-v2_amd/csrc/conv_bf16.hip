@@ -407,9 +407,12 @@ static int fill_levels16(LevelTab& lt, int nlev, int N, const int* H, const int*
 // 128-wide tile 37 % of their MFMAs and fragment reads computed zero columns.  Here the four waves stack in M (256 x 96 tile, 64 x 96
 // per wave = 2 x 3 accumulators): 5 fragment reads feed 6 MFMAs per k16 step (4 : 4 on the 128 x 128 tile) and 83 % of the columns are
 // real.  Same staging, swizzle, pipeline and epilogue (called on the 64- and the 32-column part of the wave tile).
-template <int BN, bool ML, int BK, typename TO>
-__global__ __launch_bounds__(256, (BK == 32 && BN != 96) ? 4 : 2) void conv_igemm_bf16_v2(ConvArgs16 p) {
-  constexpr int WN = BN == 96 ? 1 : 2, WM = 4 / WN, WCOLS = BN / WN;   // waves along N / M; output columns per wave
+// TALL (BN = 64, round 4): K <= 64 layers (the stem, res2's 3x3) likewise as a 256 x 64 tile of four 64 x 64 wave tiles - 4 fragment reads per
+// 4 MFMAs instead of 3 per 2 on the 128 x 64 tile's 64 x 32 wave tiles.
+template <int BN, bool ML, int BK, typename TO, bool TALL = false>
+__global__ __launch_bounds__(256, TALL ? 3 : ((BK == 32 && BN != 96) ? 4 : 2)) void conv_igemm_bf16_v2(ConvArgs16 p) {
+  static_assert(!TALL || BN == 64, "the tall layout exists for the 64-wide tile");
+  constexpr int WN = (BN == 96 || TALL) ? 1 : 2, WM = 4 / WN, WCOLS = BN / WN;   // waves along N / M; output columns per wave
   constexpr int BM = WM * 64, ROWB = BK * 2;          // LDS row = BK bf16
   constexpr int SLOTS = BK / 8, RPP = 256 / SLOTS;    // 16-byte slots per row; rows staged per pass of the 256 threads
   constexpr int TM = 2, TN = WCOLS / 32, AP = BM / RPP, BP = (BN + RPP - 1) / RPP, KS = BK / 16;  // pieces per thread; k16 steps per chunk
@@ -1234,6 +1237,16 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
         return;
       }
     }
+    if constexpr (BN == 64) {
+      // 256 x 64 tile (TALL) for long matrices whose K loop is worth it: 3x3 / 7-tap layers (the HBM-bound 1x1 layers stay on 128 x 64)
+      static const bool use_tall = env_int("UTV2_CONV_TALL64", 1) != 0;
+      if (use_tall && a.KH * a.KW > 1 && a.M - a.m_begin >= 65536 && a.K > 32) {
+        const dim3 gt(cdiv(a.M - a.m_begin, 256) * cdiv(a.K, 64));
+        if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<64, ML, 32, h16_t, true>), gt, b, 0, stream, a);
+        else hipLaunchKernelGGL((conv_igemm_bf16_v2<64, ML, 32, float, true>), gt, b, 0, stream, a);
+        return;
+      }
+    }
     if constexpr (BN == 96) {   // 256 x 96 tile: BK = 32 only (a BK = 64 stage would need 88 KB of LDS: one workgroup per CU)
       if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<96, ML, 32, h16_t>), g, b, 0, stream, a);
       else hipLaunchKernelGGL((conv_igemm_bf16_v2<96, ML, 32, float>), g, b, 0, stream, a);
@@ -1414,7 +1427,12 @@ int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int
   const bool small = K <= 64;
   const int tiles = cdiv(a.M, 128) * cdiv(K, small ? 64 : 128);
   const dim3 g(tiles), b(256);
-  if (small) {
+  static const bool use_tall = env_int("UTV2_CONV_TALL64", 1) != 0;
+  if (small && use_tall && a.M >= 65536 && K > 32) {
+    const dim3 gt(cdiv(a.M, 256));
+    if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<64, false, 32, h16_t, true>), gt, b, 0, stream, a);
+    else hipLaunchKernelGGL((conv_igemm_bf16_v2<64, false, 32, float, true>), gt, b, 0, stream, a);
+  } else if (small) {
     if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<64, false, 32, h16_t>), g, b, 0, stream, a);
     else hipLaunchKernelGGL((conv_igemm_bf16_v2<64, false, 32, float>), g, b, 0, stream, a);
   } else {
