@@ -352,6 +352,24 @@ int utv2_rpn_rank_keys(const float* head, int num_levels, const int* hw_host, in
 int utv2_rpn_decode(const int64_t* top, int maxk, const float* head, const float* anchors, const float* image_hw, int num_levels,
                     const int* hw_host, const int* k_host, int N, int A, int ch, const float* weights_host, float scale_clamp,
                     float min_size, float* boxes, float* scores, int* lvls, unsigned char* keep, utv2_stream_t stream);
+/* The predictor's inference (roi_heads/fast_rcnn.py:1094-1125,1162-1225; D2 fast_rcnn_inference) around the top-k and the NMS:
+ * keys:   probs [N*P][K+1] (softmax), deltas [N*P][4], prop [N][P][4], valid [N][P], whwh [N][4] = (w, h, w, h) of the image ->
+ *         boxes [N][P][4] = Box2BoxXYXYTransform.apply_deltas (weights wx, wy; clamp +-scale_clamp) clipped to the image, and
+ *         keys [N][P*K]: per foreground class (order-preserving bits of its probability) << 32 | (2^32 - 1 - (p*K + c)), the key of
+ *         -1 when prob <= thr / the slot is invalid / box or probabilities are not finite.  Descending key order = (prob desc, index asc).
+ * gather: top [N][k] (the k largest keys of each image, descending) -> sc, rows (proposal index, int64), cls, cb [N][k][4], valid (sc > thr)
+ * pack:   kidx [N][D] / cnt [N] of utv2_nms_batched on (cb, sc, cls, valid) -> the padded detections + stdl [N*P][4] of their rows */
+/* the survivors of utv2_nms_batched (kidx [N][D], -1 padded; cnt [N]) gathered into padded outputs: oboxes [N][D][4], oscores [N][D],
+ * ovalid [N][D] = slot < cnt (slots beyond the count repeat candidate 0) - the tail of D2 find_top_rpn_proposals in one launch */
+int utv2_nms_pack(const int* kidx, const int* cnt, const float* boxes, const float* scores, int N, int M, int D, float* oboxes, float* oscores,
+                  unsigned char* ovalid, utv2_stream_t stream);
+int utv2_roi_infer_keys(const float* probs, const float* deltas, const float* prop, const unsigned char* valid, const float* whwh, int N, int P,
+                        int K, float wx, float wy, float scale_clamp, float thr, float* boxes, int64_t* keys, utv2_stream_t stream);
+int utv2_roi_infer_gather(const int64_t* top, const float* boxes, int N, int P, int K, int k, float thr, float* sc, int64_t* rows, int* cls,
+                          float* cb, unsigned char* valid, utv2_stream_t stream);
+int utv2_roi_infer_pack(const int* kidx, const int* cnt, const float* cb, const float* sc, const int* cls, const int64_t* rows, const float* stdl,
+                        int N, int P, int k, int D, float* oboxes, float* oscores, int* ocls, float* ostd, int64_t* orows, unsigned char* ovalid,
+                        utv2_stream_t stream);
 /* PseudoLabRPN.losses on the sampled anchors (proposal_generator/rpn.py:153-225): sums[0] = sum of BCE-with-logits over the sampled
  * positives (pos_idx [N][npos], int64 anchor indices, pos_valid) and negatives (neg_idx [N][nneg]) - every term times the score of the
  * anchor's matched pseudo box when gt_scores is given, zero when the image has no gt (has_gt [N]) -, sums[1] = sum over the valid

@@ -508,3 +508,38 @@ def test_fused_samplers_equal_the_elementwise_chains(monkeypatch):
         assert bool((a["gt_classes"][~va] == -1).all())
         fg = (a["gt_classes"] >= 0) & (a["gt_classes"] < 80)
         assert int(fg.sum()) > 0 and int(fg[2].sum()) == 0
+
+
+def test_fused_roi_inference_equals_the_aten_chain(monkeypatch):
+    """utv2_roi_infer_keys / _gather / _pack (round 4) around softmax, top-k and the class-aware NMS == the ~55-op ATen chain they replace
+    (reference roi_heads/fast_rcnn.py:1094-1125,1162-1225 + D2 fast_rcnn_inference): identical padded detections bit for bit - boxes,
+    scores, classes, pred_boxes_std, kept proposal rows, counts - with invalid proposal slots, deltas beyond the clamp, a NaN delta and an
+    infinite score among the inputs, and probability ties (duplicated rows: the flat-index tie rule decides)."""
+    from ubteacher.modeling.fcos import PaddedBoxes
+    from ubteacher.modeling.rcnn import FastRCNNFocaltLossBoundaryVarOutputLayers
+    from ubteacher.params import ParamStore
+    pred = FastRCNNFocaltLossBoundaryVarOutputLayers(rcnn_cfg(), ParamStore(), 1024, "roi_heads.box_predictor")
+    g = torch.Generator().manual_seed(17)
+    N, P = 3, 333
+    xy = torch.rand(N, P, 2, generator=g) * 200
+    boxes = torch.cat([xy, xy + torch.rand(N, P, 2, generator=g) * 90 + 2], dim=2)
+    valid = (torch.rand(N, P, generator=g) > 0.1).to(torch.uint8)
+    scores = torch.randn(N * P, 81, generator=g) * 3
+    deltas = torch.randn(N * P, 4, generator=g) * 3
+    std = torch.randn(N * P, 4, generator=g)
+    deltas[5] = torch.tensor([900.0, -900.0, 700.0, -2000.0])
+    deltas[17, 2] = float("nan")
+    scores[23, 4] = float("inf")
+    scores[40:44] = scores[40]; deltas[40:44] = deltas[40]; boxes.view(-1, 4)[40:44] = boxes.view(-1, 4)[40]     # exact probability ties
+    props = PaddedBoxes([(240, 300), (200, 280), (300, 300)], boxes=boxes.to(DEV), valid=valid.to(DEV))
+    args = (scores.to(DEV), deltas.to(DEV), std.to(DEV))
+    monkeypatch.setenv("UTV2_FUSED_ROI_INFERENCE", "0")
+    ref, rows_ref = pred.inference(args, props)
+    monkeypatch.setenv("UTV2_FUSED_ROI_INFERENCE", "1")
+    got, rows = pred.inference(args, props)
+    assert int(ref["count"].sum()) > 50
+    assert torch.equal(got["count"], ref["count"]) and torch.equal(got["valid"], ref["valid"])
+    m = ref["valid"].bool()
+    for k in ("boxes", "scores", "classes", "pred_boxes_std"):
+        assert torch.equal(got[k][m], ref[k][m]), k
+    assert torch.equal(rows[m], rows_ref[m])

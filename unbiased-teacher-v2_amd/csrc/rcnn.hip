@@ -1059,7 +1059,115 @@ __global__ __launch_bounds__(256) void roi_box_loss_kernel(const float* __restri
   if (threadIdx.x == 0) sum[0] = red[0];
 }
 
+// ---------------------------------------------------------------------------------------------
+// The predictor's inference chain (roi_heads/fast_rcnn.py:1094-1125,1162-1225 + D2 fast_rcnn_inference [D2-recall]) around the exact
+// top-k and the class-aware NMS: three launches in place of ~55 ATen ops per teacher pass.
+//   keys:   one thread per (image, proposal): Box2BoxXYXYTransform.apply_deltas (box_regression.py:88-128: divide by the weight, clamp to
+//           +-scale_clamp, scale by the proposal's width / height, add to its corner), clip to the image, and for every foreground
+//           class a sortable 63-bit key of its probability - (order-preserving float bits) << 32 | (2^32 - 1 - flat index) - or the
+//           key of -1 when the class is not a candidate (probability <= thr, invalid slot, non-finite box or probabilities).
+//           Descending key order == (probability desc, flat (proposal, class) index asc): the tie rule of the ATen chain it replaces.
+//   gather: the k best keys of an image -> probability (recovered from the key), proposal row, class, decoded box, candidate flag
+//   pack:   the NMS survivors -> padded detections (+ the raw std logits of their proposal rows, fast_rcnn.py:1118-1123)
+__device__ __forceinline__ long long order_key_f32(float v, unsigned flat) {
+  const int i = __float_as_int(v);
+  const long long mono = (long long)(i ^ ((i >> 31) & 0x7FFFFFFF));
+  return mono * 4294967296ll + (long long)(4294967295u - flat);
+}
+
+__global__ __launch_bounds__(256) void roi_infer_keys_kernel(const float* __restrict__ probs, const float* __restrict__ deltas,
+                                                           const float* __restrict__ prop, const unsigned char* __restrict__ valid,
+                                                           const float* __restrict__ whwh, int N, int P, int K, float wx, float wy,
+                                                           float clampv, float thr, float* __restrict__ boxes, long long* __restrict__ keys) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)N * P) return;
+  const int n = (int)(t / P), p = (int)(t - (long long)n * P);
+  const float4 b = *(const float4*)(prop + t * 4);
+  const float4 d = *(const float4*)(deltas + t * 4);
+  const float w = b.z - b.x, h = b.w - b.y;
+  auto cl = [clampv](float v) { return v < -clampv ? -clampv : (v > clampv ? clampv : v); };   // a NaN stays a NaN (torch.clamp)
+  // ATen divides a tensor by a host scalar as a multiplication by its fp32 reciprocal: the same here, so that the boxes are bit-identical
+  // to the op chain this replaces (a true division differs in the last bit for weights like 10)
+  const float iwx = 1.f / wx, iwy = 1.f / wy;
+  const float dl = cl(d.x * iwx), dr = cl(d.y * iwx), dd = cl(d.z * iwy), du = cl(d.w * iwy);
+  float4 o;
+  o.x = dl * w + b.x; o.y = dd * h + b.y; o.z = dr * w + b.z; o.w = du * h + b.w;
+  bool ok = valid[t] != 0 && isfinite(o.x) && isfinite(o.y) && isfinite(o.z) && isfinite(o.w);
+  const float4 lim = *(const float4*)(whwh + n * 4);
+  o.x = fminf(fmaxf(o.x, 0.f), lim.x); o.y = fminf(fmaxf(o.y, 0.f), lim.y); o.z = fminf(fmaxf(o.z, 0.f), lim.z); o.w = fminf(fmaxf(o.w, 0.f), lim.w);
+  *(float4*)(boxes + t * 4) = o;
+  const float* pr = probs + t * (K + 1);
+  for (int c = 0; c < K; ++c) ok = ok && isfinite(pr[c]);
+  long long* kr = keys + (long long)n * P * K + (long long)p * K;
+  for (int c = 0; c < K; ++c) {
+    const float v = pr[c];
+    kr[c] = order_key_f32((ok && v > thr) ? v : -1.f, (unsigned)(p * K + c));
+  }
+}
+
+__global__ __launch_bounds__(256) void roi_infer_gather_kernel(const long long* __restrict__ top, const float* __restrict__ boxes, int N,
+                                                             int P, int K, int k, float thr, float* __restrict__ sc, long long* __restrict__ rows,
+                                                             int* __restrict__ cls, float* __restrict__ cb, unsigned char* __restrict__ valid) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)N * k) return;
+  const int n = (int)(t / k);
+  const long long key = top[t];
+  const unsigned flat = 4294967295u - (unsigned)(key & 0xFFFFFFFFll);
+  const int mono = (int)(key >> 32);
+  const float v = __int_as_float(mono ^ ((mono >> 31) & 0x7FFFFFFF));
+  const unsigned r = flat / (unsigned)K;
+  sc[t] = v;
+  rows[t] = (long long)r;
+  cls[t] = (int)(flat - r * (unsigned)K);
+  *(float4*)(cb + t * 4) = *(const float4*)(boxes + ((long long)n * P + r) * 4);
+  valid[t] = v > thr ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void roi_infer_pack_kernel(const int* __restrict__ kidx, const int* __restrict__ cnt, const float* __restrict__ cb,
+                                                           const float* __restrict__ sc, const int* __restrict__ cls, const long long* __restrict__ rows,
+                                                           const float* __restrict__ stdl, int N, int P, int k, int D, float* __restrict__ oboxes,
+                                                           float* __restrict__ oscores, int* __restrict__ ocls, float* __restrict__ ostd,
+                                                           long long* __restrict__ orows, unsigned char* __restrict__ ovalid) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * D) return;
+  const int n = t / D, d = t - n * D;
+  int ix = kidx[t];
+  ix = ix < 0 ? 0 : ix;
+  const long long src = (long long)n * k + ix;
+  *(float4*)(oboxes + (long long)t * 4) = *(const float4*)(cb + src * 4);
+  oscores[t] = sc[src];
+  ocls[t] = cls[src];
+  const long long r = rows[src];
+  orows[t] = r;
+  *(float4*)(ostd + (long long)t * 4) = *(const float4*)(stdl + ((long long)n * P + r) * 4);
+  ovalid[t] = d < cnt[n] ? 1 : 0;
+}
+
+// survivors of utv2_nms_batched -> padded (boxes, scores, valid): the gather chain behind the RPN's NMS (D2 find_top_rpn_proposals)
+__global__ __launch_bounds__(256) void nms_pack_kernel(const int* __restrict__ kidx, const int* __restrict__ cnt, const float* __restrict__ boxes,
+                                                     const float* __restrict__ scores, int N, int M, int D, float* __restrict__ ob,
+                                                     float* __restrict__ os, unsigned char* __restrict__ ov) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * D) return;
+  const int n = t / D, d = t - n * D;
+  int ix = kidx[t];
+  ix = ix < 0 ? 0 : ix;
+  const long long src = (long long)n * M + ix;
+  *(float4*)(ob + (long long)t * 4) = *(const float4*)(boxes + src * 4);
+  os[t] = scores[src];
+  ov[t] = d < cnt[n] ? 1 : 0;
+}
+
 extern "C" {
+
+int utv2_nms_pack(const int* kidx, const int* cnt, const float* boxes, const float* scores, int N, int M, int D, float* oboxes, float* oscores,
+                  unsigned char* ovalid, hipStream_t stream) {
+  if (!kidx || !cnt || !boxes || !scores || !oboxes || !oscores || !ovalid || N < 1 || M < 1 || D < 1) return UTV2_EARG;
+  hipLaunchKernelGGL(nms_pack_kernel, dim3((unsigned)cdiv((long long)N * D, 256)), dim3(256), 0, stream, kidx, cnt, boxes, scores, N, M, D, oboxes,
+                     oscores, ovalid);
+  return utv2_launch_status();
+}
+
 
 // boxes: [N][P][4] (box_img_stride = P*4) or shared anchors [P][4] (box_img_stride = 0).
 // gt_max_bits (optional, [N][G] uint32, must be zeroed by the caller) receives max-over-boxes IoU bits.
@@ -1276,6 +1384,32 @@ static int fill_rpn_levels(RpnLevels& L, int num_levels, int N, const int* hw_ho
   }
   L.out0[num_levels] = out;
   return UTV2_OK;
+}
+
+int utv2_roi_infer_keys(const float* probs, const float* deltas, const float* prop, const unsigned char* valid, const float* whwh, int N, int P,
+                        int K, float wx, float wy, float scale_clamp, float thr, float* boxes, int64_t* keys, hipStream_t stream) {
+  if (!probs || !deltas || !prop || !valid || !whwh || !boxes || !keys || N < 1 || P < 1 || K < 1 || (int64_t)P * K >= (1ll << 32)) return UTV2_EARG;
+  hipLaunchKernelGGL(roi_infer_keys_kernel, dim3((unsigned)cdiv((long long)N * P, 256)), dim3(256), 0, stream, probs, deltas, prop, valid, whwh, N,
+                     P, K, wx, wy, scale_clamp, thr, boxes, (long long*)keys);
+  return utv2_launch_status();
+}
+
+int utv2_roi_infer_gather(const int64_t* top, const float* boxes, int N, int P, int K, int k, float thr, float* sc, int64_t* rows, int* cls,
+                          float* cb, unsigned char* valid, hipStream_t stream) {
+  if (!top || !boxes || !sc || !rows || !cls || !cb || !valid || N < 1 || P < 1 || K < 1 || k < 1) return UTV2_EARG;
+  hipLaunchKernelGGL(roi_infer_gather_kernel, dim3((unsigned)cdiv((long long)N * k, 256)), dim3(256), 0, stream, (const long long*)top, boxes, N, P,
+                     K, k, thr, sc, (long long*)rows, cls, cb, valid);
+  return utv2_launch_status();
+}
+
+int utv2_roi_infer_pack(const int* kidx, const int* cnt, const float* cb, const float* sc, const int* cls, const int64_t* rows, const float* stdl,
+                        int N, int P, int k, int D, float* oboxes, float* oscores, int* ocls, float* ostd, int64_t* orows, unsigned char* ovalid,
+                        hipStream_t stream) {
+  if (!kidx || !cnt || !cb || !sc || !cls || !rows || !stdl || !oboxes || !oscores || !ocls || !ostd || !orows || !ovalid || N < 1 || D < 1)
+    return UTV2_EARG;
+  hipLaunchKernelGGL(roi_infer_pack_kernel, dim3((unsigned)cdiv((long long)N * D, 256)), dim3(256), 0, stream, kidx, cnt, cb, sc, cls,
+                     (const long long*)rows, stdl, N, P, k, D, oboxes, oscores, ocls, ostd, (long long*)orows, ovalid);
+  return utv2_launch_status();
 }
 
 int utv2_rpn_rank_keys(const float* head, int num_levels, const int* hw_host, int N, int A, int ch, int64_t* keys, hipStream_t stream) {

@@ -799,6 +799,53 @@ def roi_sample(boxes, valid, mx, arg, keys, gt_boxes, gt_classes, gt_valid, gt_s
     return out
 
 
+def nms_pack(kidx, cnt, boxes, scores):
+    N, D = kidx.shape
+    M = scores.shape[1]
+    ob = torch.empty((N, D, 4), dtype=torch.float32, device=boxes.device)
+    osc = torch.empty((N, D), dtype=torch.float32, device=boxes.device)
+    ov = torch.empty((N, D), dtype=torch.uint8, device=boxes.device)
+    call("utv2_nms_pack", _p(kidx), _p(cnt), _p(boxes), _p(scores), N, M, D, _p(ob), _p(osc), _p(ov), _stream())
+    return ob, osc, ov
+
+
+def roi_infer_keys(probs, deltas, prop, valid, whwh, K, wx, wy, scale_clamp, thr):
+    """-> (decoded + clipped boxes [N, P, 4], sortable keys [N, P*K]) - see utv2_roi_infer_keys"""
+    N, P = valid.shape
+    boxes = torch.empty((N, P, 4), dtype=torch.float32, device=probs.device)
+    keys = torch.empty((N, P * K), dtype=torch.int64, device=probs.device)
+    call("utv2_roi_infer_keys", _p(probs), _p(deltas), _p(prop), _p(valid), _p(whwh), N, P, K, float(wx), float(wy), float(scale_clamp), float(thr),
+         _p(boxes), _p(keys), _stream())
+    return boxes, keys
+
+
+def roi_infer_gather(top, boxes, K, thr):
+    N, k = top.shape
+    P = boxes.shape[1]
+    dev = top.device
+    sc = torch.empty((N, k), dtype=torch.float32, device=dev)
+    rows = torch.empty((N, k), dtype=torch.int64, device=dev)
+    cls = torch.empty((N, k), dtype=torch.int32, device=dev)
+    cb = torch.empty((N, k, 4), dtype=torch.float32, device=dev)
+    valid = torch.empty((N, k), dtype=torch.uint8, device=dev)
+    call("utv2_roi_infer_gather", _p(top), _p(boxes), N, P, K, k, float(thr), _p(sc), _p(rows), _p(cls), _p(cb), _p(valid), _stream())
+    return sc, rows, cls, cb, valid
+
+
+def roi_infer_pack(kidx, cnt, cb, sc, cls, rows, std, P, D):
+    N, k = sc.shape
+    dev = sc.device
+    ob = torch.empty((N, D, 4), dtype=torch.float32, device=dev)
+    osc = torch.empty((N, D), dtype=torch.float32, device=dev)
+    oc = torch.empty((N, D), dtype=torch.int32, device=dev)
+    ostd = torch.empty((N, D, 4), dtype=torch.float32, device=dev)
+    orows = torch.empty((N, D), dtype=torch.int64, device=dev)
+    ov = torch.empty((N, D), dtype=torch.uint8, device=dev)
+    call("utv2_roi_infer_pack", _p(kidx), _p(cnt), _p(cb), _p(sc), _p(cls), _p(rows), _p(std), N, P, k, D, _p(ob), _p(osc), _p(oc), _p(ostd),
+         _p(orows), _p(ov), _stream())
+    return ob, osc, oc, ostd, orows, ov
+
+
 def roi_box_loss(deltas, std, cls, prop, gtb, gstd, num_classes, mode, wx, wy, scale_clamp, ts_better, t_cert):
     """(sum [1], d sum / d deltas [R,4], d sum / d std [R,4]); deltas / std may be column slices of the predictor output (row pitch = stride(0))"""
     R = deltas.shape[0]

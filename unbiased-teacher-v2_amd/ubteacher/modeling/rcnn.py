@@ -357,6 +357,9 @@ class PseudoLabRPN:
     def _nms_and_pack(self, boxes, scores, lvls, keep, image_sizes, post):
         dev = boxes.device
         kidx, cnt = hip.nms_batched(boxes, scores, lvls, keep, self.nms_thresh, class_aware=True, post_topk=-1, max_out=post)
+        if boxes.is_contiguous() and scores.is_contiguous() and boxes.dtype == scores.dtype == torch.float32:
+            ob, osc, ov = hip.nms_pack(kidx, cnt, boxes, scores)        # one launch instead of clamp / arange / lt / 2 gathers + casts
+            return PaddedBoxes(image_sizes, boxes=ob, objectness_logits=osc, valid=ov, count=cnt)
         ix = kidx.clamp(min=0).long()
         valid = (torch.arange(post, device=dev)[None, :] < cnt[:, None]).to(torch.uint8)
         return PaddedBoxes(image_sizes, boxes=torch.gather(boxes, 1, ix[:, :, None].expand(-1, -1, 4)).contiguous(),
@@ -505,7 +508,6 @@ class FastRCNNFocaltLossBoundaryVarOutputLayers:
         N, P = proposals["valid"].shape
         K = self.K
         pb = proposals["boxes"]
-        boxes = self.box2box_transform.apply_deltas(deltas.view(N, P, 4), pb)
         cache = self.__dict__.setdefault("_hwt_cache", {})   # a fresh torch.tensor(..., device=cuda) is a synchronizing pageable copy
         ck = (tuple(proposals.image_sizes), str(pb.device))
         hwt = cache.get(ck)
@@ -513,6 +515,21 @@ class FastRCNNFocaltLossBoundaryVarOutputLayers:
             if len(cache) >= 16:
                 cache.clear()
             hwt = cache[ck] = torch.tensor([[s[1], s[0], s[1], s[0]] for s in proposals.image_sizes], dtype=torch.float32, device=pb.device)[:, None, :]
+        if os.environ.get("UTV2_FUSED_ROI_INFERENCE", "1") != "0" and scores.dtype == deltas.dtype == std.dtype == torch.float32 and P * K < (1 << 32):
+            # round 4: decode + clip + candidate keys, the gather behind the top-k and the packing of the NMS survivors as three launches
+            # (utv2_roi_infer_*) around softmax / topk / utv2_nms_batched - the chain below is ~55 ATen launches per teacher pass.
+            # Same arithmetic per element and the same (probability desc, flat index asc) order: identical detections.
+            pr = F.softmax(scores, dim=-1).contiguous()
+            wx, wy = self.box2box_transform.weights[0], self.box2box_transform.weights[1]
+            dec, keys = hip.roi_infer_keys(pr, deltas.contiguous(), pb.contiguous(), proposals["valid"].contiguous(), hwt.view(N, 4), K, wx, wy,
+                                           self.box2box_transform.scale_clamp, self.test_score_thresh)
+            top = torch.topk(keys, min(max_cand, P * K), dim=1, sorted=True).values
+            sc, r, c, cb, valid = hip.roi_infer_gather(top, dec, K, self.test_score_thresh)
+            D = self.test_topk_per_image
+            kidx, cnt = hip.nms_batched(cb, sc, c, valid, self.test_nms_thresh, class_aware=True, post_topk=-1, max_out=D)
+            ob, osc, oc, ostd, keep_rows, ov = hip.roi_infer_pack(kidx, cnt, cb, sc, c, r, std.contiguous(), P, D)
+            return PaddedBoxes(proposals.image_sizes, boxes=ob, scores=osc, classes=oc, pred_boxes_std=ostd, valid=ov, count=cnt), keep_rows
+        boxes = self.box2box_transform.apply_deltas(deltas.view(N, P, 4), pb)
         probs = F.softmax(scores, dim=-1).view(N, P, K + 1)[:, :, :K]
         ok = proposals["valid"].bool() & torch.isfinite(boxes).all(dim=2) & torch.isfinite(probs).all(dim=2)
         boxes = torch.minimum(boxes.clamp(min=0), hwt)
