@@ -974,9 +974,10 @@ def box_head(sd, x, prefix="roi_heads"):
     x = F.relu(_linear(x, sd[prefix + ".box_head.fc1.weight"], sd[prefix + ".box_head.fc1.bias"]))
     x = F.relu(_linear(x, sd[prefix + ".box_head.fc2.weight"], sd[prefix + ".box_head.fc2.bias"]))
     p = prefix + ".box_predictor"
+    # no bbox_pred_std head = the UTv1 predictor (MODEL.ROI_HEADS.LOSS "FocalLoss", fast_rcnn.py:1296-1402): Detectron2's two Linear heads
+    std = _linear(x, sd[p + ".bbox_pred_std.weight"], sd[p + ".bbox_pred_std.bias"]) if p + ".bbox_pred_std.weight" in sd else None
     return (_linear(x, sd[p + ".cls_score.weight"], sd[p + ".cls_score.bias"]),
-            _linear(x, sd[p + ".bbox_pred.weight"], sd[p + ".bbox_pred.bias"]),
-            _linear(x, sd[p + ".bbox_pred_std.weight"], sd[p + ".bbox_pred_std.bias"]))
+            _linear(x, sd[p + ".bbox_pred.weight"], sd[p + ".bbox_pred.bias"]), std)
 
 
 def softmax_focal(scores, gt_classes, gamma=1.5):
@@ -986,6 +987,73 @@ def softmax_focal(scores, gt_classes, gamma=1.5):
     ce = F.cross_entropy(scores, gt_classes, reduction="none")
     p = torch.exp(-ce)
     return ((1 - p) ** gamma * ce).sum() / gt_classes.shape[0]
+
+
+def d2_get_deltas(src, tgt, weights):
+    """Detectron2 Box2BoxTransform.get_deltas with weights (wx, wy, ww, wh) [D2-recall]"""
+    d = rpn_get_deltas(src, tgt)
+    return d * torch.tensor(weights, dtype=d.dtype)
+
+
+def d2_apply_deltas(deltas, boxes, weights):
+    """Detectron2 Box2BoxTransform.apply_deltas with weights [D2-recall]; deltas [R, 4k] -> boxes [R, 4k]"""
+    R = deltas.shape[0]
+    d = deltas.reshape(R, -1, 4) / torch.tensor(weights, dtype=deltas.dtype)
+    out = torch.stack([rpn_apply_deltas(d[:, j], boxes) for j in range(d.shape[1])], dim=1)
+    return out.reshape(R, -1)
+
+
+def fv_giou_loss(b1, b2, eps=1e-7):
+    """fvcore.nn.giou_loss, reduction none [D2-recall]"""
+    x1, y1, x2, y2 = b1.unbind(dim=-1)
+    x1g, y1g, x2g, y2g = b2.unbind(dim=-1)
+    xk1, yk1, xk2, yk2 = torch.max(x1, x1g), torch.max(y1, y1g), torch.min(x2, x2g), torch.min(y2, y2g)
+    inter = torch.where((yk2 > yk1) & (xk2 > xk1), (xk2 - xk1) * (yk2 - yk1), torch.zeros_like(x1))
+    union = (x2 - x1) * (y2 - y1) + (x2g - x1g) * (y2g - y1g) - inter
+    area_c = (torch.max(x2, x2g) - torch.min(x1, x1g)) * (torch.max(y2, y2g) - torch.min(y1, y1g))
+    return 1 - (inter / (union + eps) - (area_c - union) / (area_c + eps))
+
+
+def utv1_roi_losses(scores, deltas, prop, gtb, gt_classes, gt_confid=None, weights=(10.0, 10.0, 5.0, 5.0), num_classes=80, beta=0.0, gamma=1.5,
+                    box_reg_loss_type="smooth_l1"):
+    """The UTv1 predictor's losses, MODEL.ROI_HEADS.LOSS "FocalLoss" (roi_heads/fast_rcnn.py:1296-1429 FastRCNNFocaltLossOutputLayers ->
+    FastRCNNFocalLoss): loss_cls = sum((1 - p)^1.5 * CE [* gt_confid]) / R; loss_box_reg (inherited, :134-194) = smooth-L1 between the
+    foreground rows' deltas of their gt class (or the 4 class-agnostic ones) and get_deltas(proposal, gt), summed, / R."""
+    R = gt_classes.shape[0]
+    ce = F.cross_entropy(scores, gt_classes, reduction="none")
+    loss = (1 - torch.exp(-ce)) ** gamma * ce
+    if gt_confid is not None:
+        loss = loss * gt_confid
+    loss_cls = loss.sum() / R
+    fg = torch.nonzero((gt_classes >= 0) & (gt_classes < num_classes)).squeeze(1)
+    if deltas.shape[1] == 4:
+        cols = torch.arange(4)[None, :].expand(len(fg), 4)
+    else:
+        cols = 4 * gt_classes[fg, None] + torch.arange(4)
+    if box_reg_loss_type == "giou":               # fast_rcnn.py:174-183
+        return loss_cls, fv_giou_loss(d2_apply_deltas(deltas[fg[:, None], cols], prop[fg], weights), gtb[fg]).sum() / R
+    tgt = d2_get_deltas(prop, gtb, weights)
+    diff = (deltas[fg[:, None], cols] - tgt[fg]).abs()
+    if beta >= 1e-5:
+        diff = torch.where(diff < beta, 0.5 * diff * diff / beta, diff - 0.5 * beta)
+    return loss_cls, diff.sum() / R
+
+
+def fast_rcnn_inference_per_class(boxes, probs, image_size, score_thresh=0.05, nms_thresh=0.5, topk=100):
+    """D2 fast_rcnn_inference_single_image [D2-recall] with per-class boxes [R, 4K] (or [R, 4]).  Returns (dets, kept proposal row)."""
+    ok = torch.isfinite(boxes).all(dim=1) & torch.isfinite(probs).all(dim=1)
+    rows = torch.nonzero(ok).squeeze(1)
+    boxes, probs = boxes[ok], probs[ok][:, :-1]
+    K = probs.shape[1]
+    h, w = image_size
+    b = boxes.reshape(boxes.shape[0], -1, 4)
+    b = torch.stack((b[..., 0].clamp(0, w), b[..., 1].clamp(0, h), b[..., 2].clamp(0, w), b[..., 3].clamp(0, h)), dim=-1)
+    m = probs > score_thresh
+    fi = m.nonzero()
+    bsel = b[fi[:, 0], 0] if b.shape[1] == 1 else b[fi[:, 0], fi[:, 1]]
+    s = probs[m]
+    keep = batched_nms(bsel, s, fi[:, 1], nms_thresh)[:topk]
+    return dict(boxes=bsel[keep], scores=s[keep], classes=fi[keep, 1]), rows[fi[keep, 0]]
 
 
 def matched_iou(b1, b2):
@@ -1043,12 +1111,14 @@ def roi_label_and_sample(prop_boxes, gt, keys, pseudo, num_classes=80, batch=512
         out["gt_boxes"] = gb[midx[sidx]]
         if pseudo:
             out["gt_confid"] = gt["scores"][midx[sidx]]
-            out["gt_loc_std"] = gt["pred_boxes_std"][midx[sidx]]
+            if "pred_boxes_std" in gt:            # roi_heads.py:200-203: only when the pseudo labels carry one
+                out["gt_loc_std"] = gt["pred_boxes_std"][midx[sidx]]
     else:
         out["gt_boxes"] = gb.new_zeros((len(sidx), 4))
         if pseudo:
             out["gt_confid"] = torch.zeros(len(sidx))
-            out["gt_loc_std"] = gb.new_zeros((len(sidx), 4))
+            if "pred_boxes_std" in gt:
+                out["gt_loc_std"] = gb.new_zeros((len(sidx), 4))
     return out
 
 
@@ -1073,6 +1143,22 @@ def rcnn_backbone(sd, images, mean, pix_std):
     return p, sizes
 
 
+UTV1_BOX_WEIGHTS = (10.0, 10.0, 5.0, 5.0)     # MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS (Detectron2 default)
+
+
+def _predictor_inference(scores, deltas, std, prop, size):
+    """one image of the box predictor's inference: boundary-variance predictors (fast_rcnn.py:1094-1125) decode with Box2BoxXYXYTransform,
+    class-agnostic, and report pred_boxes_std of the kept rows; the UTv1 predictor (std None; Detectron2 FastRCNNOutputLayers.inference
+    [D2-recall]) decodes per-class centre-size deltas"""
+    probs = F.softmax(scores, dim=-1)
+    if std is None:
+        dets, _ = fast_rcnn_inference_per_class(d2_apply_deltas(deltas, prop, UTV1_BOX_WEIGHTS), probs, size)
+        return dets
+    dets, rows = fast_rcnn_inference(xyxy_apply_deltas(deltas, prop), probs, size)
+    dets["pred_boxes_std"] = std[rows]
+    return dets
+
+
 def rcnn_teacher(sd, images, mean, pix_std, pre_topk=2000, post_topk=1000, thr=0.7):
     """meta_arch/rcnn.py:39-55 (branch unsup_data_weak, teacher left in train mode - SURVEY B13) +
     trainer.py:727-751 thresholding."""
@@ -1087,11 +1173,9 @@ def rcnn_teacher(sd, images, mean, pix_std, pre_topk=2000, post_topk=1000, thr=0
     out, r = [], 0
     for n, q in enumerate(props):
         k = len(q["boxes"])
-        boxes = xyxy_apply_deltas(deltas[r:r + k], q["boxes"])
-        dets, rows = fast_rcnn_inference(boxes, F.softmax(scores[r:r + k], dim=-1), sizes[n])
-        dets["pred_boxes_std"] = std[r:r + k][rows]
+        dets = _predictor_inference(scores[r:r + k], deltas[r:r + k], None if std is None else std[r:r + k], q["boxes"], sizes[n])
         m = dets["scores"] > thr
-        out.append(dict(boxes=dets["boxes"][m], classes=dets["classes"][m], scores=dets["scores"][m], pred_boxes_std=dets["pred_boxes_std"][m]))
+        out.append({key: v[m] for key, v in dets.items()})     # trainer.py:727-751: pred_boxes_std only when the predictor has one
         r += k
     return out, props
 
@@ -1128,9 +1212,7 @@ def rcnn_inference(sd, images, mean, pix_std, out_sizes=None, pre_topk=1000, pos
     out, r = [], 0
     for n, q in enumerate(props):
         k = len(q["boxes"])
-        boxes = xyxy_apply_deltas(deltas[r:r + k], q["boxes"])
-        dets, rows = fast_rcnn_inference(boxes, F.softmax(scores[r:r + k], dim=-1), sizes[n])
-        dets["pred_boxes_std"] = std[r:r + k][rows]
+        dets = _predictor_inference(scores[r:r + k], deltas[r:r + k], None if std is None else std[r:r + k], q["boxes"], sizes[n])
         if out_sizes is not None:
             dets = detector_postprocess(dets, sizes[n], out_sizes[n])
         out.append(dets)
@@ -1159,6 +1241,12 @@ def rcnn_student_losses(sd, images, gts, rpn_keys, roi_keys, pseudo, mean, pix_s
     cls = torch.cat([s["gt_classes"] for s in sampled])
     pb = torch.cat([s["proposal_boxes"] for s in sampled])
     gb = torch.cat([s["gt_boxes"] for s in sampled])
+    if std is None:                               # the UTv1 predictor: confidence-weighted focal + class-specific smooth-L1
+        conf = torch.cat([s["gt_confid"].float() for s in sampled]) if pseudo else None
+        lc, lb = utv1_roi_losses(scores, deltas, pb, gb, cls, conf, UTV1_BOX_WEIGHTS)
+        losses = {"loss_cls": lc, "loss_box_reg": lb}
+        losses.update(rl)
+        return losses, props, sampled
     losses = {"loss_cls": softmax_focal(scores, cls)}
     if pseudo:
         gstd = torch.cat([s["gt_loc_std"] for s in sampled])

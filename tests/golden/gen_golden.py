@@ -682,6 +682,38 @@ def gen_rcnn(structures):
             d["rcc_%s_%s" % (branch, k)] = npy(v)
             d["rcc_%s_g%s" % (branch, k)] = npy(v.grad if v.grad is not None else torch.zeros_like(v))
         d["rcc_%s_loss_cls" % branch] = npy(ls["loss_cls"]); d["rcc_%s_loss_box_reg" % branch] = npy(ls["loss_box_reg"])
+    # ---- round 4: the UTv1 predictor, MODEL.ROI_HEADS.LOSS "FocalLoss": FastRCNNFocaltLossOutputLayers.losses -> FastRCNNFocalLoss
+    # (fast_rcnn.py:1296-1429; box_reg_loss inherited from FastRCNNOutputs :134-194), class-specific and class-agnostic deltas, with and
+    # without gt_confid (the pseudo-labeled branch weights the focal term by the matched pseudo box's score).  Detectron2's
+    # Box2BoxTransform is a stand-in on the oracle's restatement [D2-recall].  Own generator.
+    g3 = torch.Generator().manual_seed(79)
+    W4 = (10.0, 10.0, 5.0, 5.0)
+    d2tf = types.SimpleNamespace(get_deltas=lambda src, tgt: O.d2_get_deltas(src, tgt, W4), apply_deltas=lambda dl, bx: O.d2_apply_deltas(dl, bx, W4))
+    R1 = 48
+    cls1 = torch.randint(0, 81, (R1,), generator=g3)
+    cls1[:16] = 80
+    cls1[-4:] = torch.tensor([0, 79, 5, 5])
+    p1 = torch.rand(R1, 2, generator=g3) * 150
+    prop1 = torch.cat([p1, p1 + torch.rand(R1, 2, generator=g3) * 80 + 4], 1)
+    gtb1 = prop1 + torch.randn(R1, 4, generator=g3) * 4
+    gtb1[:, 2:] = torch.maximum(gtb1[:, 2:], gtb1[:, :2] + 2.0)
+    conf1 = torch.rand(R1, generator=g3)
+    d.update(v1_prop=npy(prop1), v1_gtb=npy(gtb1), v1_cls=npy(cls1), v1_conf=npy(conf1))
+    lay = types.SimpleNamespace(box2box_transform=d2tf, smooth_l1_beta=0.0, box_reg_loss_type="smooth_l1", num_classes=80)
+    for name, nbx, with_conf, beta in (("spec", 80, False, 0.0), ("spec_conf", 80, True, 0.0), ("agn_conf_beta", 1, True, 0.5), ("spec_giou", 80, False, 0.0)):
+        sc1 = (torch.randn(R1, 81, generator=g3) * 2).requires_grad_(True)
+        de1 = (torch.randn(R1, 4 * nbx, generator=g3) * 0.5).requires_grad_(True)
+        i1 = Instances((300, 300))
+        i1.proposal_boxes = Boxes(prop1); i1.gt_boxes = Boxes(gtb1); i1.gt_classes = cls1
+        if with_conf:
+            i1.gt_confid = conf1
+        lay.smooth_l1_beta = beta
+        lay.box_reg_loss_type = "giou" if name.endswith("giou") else "smooth_l1"     # fast_rcnn.py:163-186
+        ls = fr.FastRCNNFocaltLossOutputLayers.losses(lay, (sc1, de1), [i1], "supervised")
+        (ls["loss_cls"] + 2.0 * ls["loss_box_reg"]).backward()
+        d["v1_%s_scores" % name], d["v1_%s_deltas" % name] = npy(sc1), npy(de1)
+        d["v1_%s_gscores" % name], d["v1_%s_gdeltas" % name] = npy(sc1.grad), npy(de1.grad)
+        d["v1_%s_loss_cls" % name], d["v1_%s_loss_box_reg" % name] = npy(ls["loss_cls"]), npy(ls["loss_box_reg"])
     # ---- PseudoLabRPN: label_and_sample_anchors_pseudo + losses (weights on all valid anchors) ----
     hw = [(6, 8), (3, 4)]
     anchors = O.make_anchors(hw, [16, 32], sizes=(32, 64))

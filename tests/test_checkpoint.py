@@ -278,3 +278,31 @@ def test_amp_scaler_state_round_trips(tmp_path):
     assert t2._amp_state.tolist() == [1024.0, 0.0, 37.0]
     t3 = T(); t3._amp_state = None                       # bf16 / f32 run resuming an fp16 checkpoint: ignored
     DetectionTSCheckpointer(M(), str(tmp_path), grad_scaler=AmpScalerState(t3)).resume_or_load("", resume=True)
+
+
+def test_roi_heads_loss_selects_the_predictor_and_its_state_dict_surface():
+    """MODEL.ROI_HEADS.LOSS (reference roi_heads/roi_heads.py:52-66): "FocalLoss" = the UTv1 predictor on Detectron2's FastRCNNOutputLayers
+    (cls_score [K+1], bbox_pred [4K], no bbox_pred_std); the *_BoundaryVar predictors add the class-agnostic bbox_pred / bbox_pred_std;
+    "CrossEntropy" cannot train in the reference either (its ROI heads call Detectron2's two-argument losses() with three) and says so."""
+    import pytest
+    from ubteacher.modeling import build_model
+    from ubteacher.presets import get_config
+    shapes = {}
+    S1 = ["MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE", "smooth_l1", "MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG", False]   # the UTv2 YAML: nlloss, agnostic
+    for loss in ("FocalLoss", "FocalLoss_BoundaryVar", "CrossEntropy_BoundaryVar"):
+        m = build_model(get_config("rcnn", 1, ["MODEL.DEVICE", "cpu", "MODEL.ROI_HEADS.LOSS", loss] + (S1 if loss == "FocalLoss" else [])))
+        shapes[loss] = {k[len("roi_heads.box_predictor."):]: tuple(v.shape) for k, v in m.state_dict().items() if k.startswith("roi_heads.box_predictor.")}
+    assert shapes["FocalLoss"] == {"cls_score.weight": (81, 1024), "cls_score.bias": (81,), "bbox_pred.weight": (320, 1024), "bbox_pred.bias": (320,)}
+    want = {"cls_score.weight": (81, 1024), "cls_score.bias": (81,), "bbox_pred.weight": (4, 1024), "bbox_pred.bias": (4,),
+            "bbox_pred_std.weight": (4, 1024), "bbox_pred_std.bias": (4,)}
+    assert shapes["FocalLoss_BoundaryVar"] == want and shapes["CrossEntropy_BoundaryVar"] == want
+    m = build_model(get_config("rcnn", 1, ["MODEL.DEVICE", "cpu", "MODEL.ROI_HEADS.LOSS", "FocalLoss"] + S1[:2]))
+    assert tuple(m.state_dict()["roi_heads.box_predictor.bbox_pred.weight"].shape) == (4, 1024)
+    w = m.state_dict()["roi_heads.box_predictor.cls_score.weight"]
+    assert 0.005 < float(w.std()) < 0.02 and float(m.state_dict()["roi_heads.box_predictor.bbox_pred.weight"].std()) < 0.002    # D2: normal 0.01 / 0.001
+    with pytest.raises(ValueError, match="Invalid bbox reg loss type 'nlloss'"):      # the UTv2 YAML's box loss on the UTv1 predictor (fast_rcnn.py:184-186)
+        build_model(get_config("rcnn", 1, ["MODEL.DEVICE", "cpu", "MODEL.ROI_HEADS.LOSS", "FocalLoss"]))
+    with pytest.raises(NotImplementedError, match="roi_heads.py:124"):
+        build_model(get_config("rcnn", 1, ["MODEL.DEVICE", "cpu", "MODEL.ROI_HEADS.LOSS", "CrossEntropy"]))
+    with pytest.raises(ValueError, match="Unknown ROI head loss"):
+        build_model(get_config("rcnn", 1, ["MODEL.DEVICE", "cpu", "MODEL.ROI_HEADS.LOSS", "nope"]))

@@ -65,6 +65,35 @@ def test_roi_inference(rc, pre, prop_key):
         assert 0.0 < rc["infc_boxes"][kept[0], 0] < 300.0
 
 
+V1 = {"spec": (False, 0.0), "spec_conf": (True, 0.0), "agn_conf_beta": (True, 0.5), "spec_giou": (False, 0.0)}
+
+
+@pytest.mark.parametrize("name", sorted(V1))
+def test_utv1_focal_predictor_losses(rc, name):
+    """MODEL.ROI_HEADS.LOSS "FocalLoss" (the UTv1 predictor, fast_rcnn.py:1296-1429): class-specific and class-agnostic deltas, with and
+    without the gt_confid weighting of the pseudo-labeled branch, smooth-L1 beta 0 and 0.5; losses and gradients"""
+    conf, beta = V1[name]
+    sc = T(rc["v1_%s_scores" % name]).clone().requires_grad_(True)
+    de = T(rc["v1_%s_deltas" % name]).clone().requires_grad_(True)
+    lc, lb = O.utv1_roi_losses(sc, de, T(rc["v1_prop"]), T(rc["v1_gtb"]), T(rc["v1_cls"]), T(rc["v1_conf"]) if conf else None, beta=beta,
+                               box_reg_loss_type="giou" if name.endswith("giou") else "smooth_l1")
+    close(lc, rc["v1_%s_loss_cls" % name]); close(lb, rc["v1_%s_loss_box_reg" % name])
+    (lc + 2.0 * lb).backward()
+    close(sc.grad, rc["v1_%s_gscores" % name], rtol=1e-4, atol=1e-8); close(de.grad, rc["v1_%s_gdeltas" % name], rtol=1e-4, atol=1e-8)
+    if conf:    # the weighting bites: the unweighted loss differs
+        lc0, _ = O.utv1_roi_losses(sc.detach(), de.detach(), T(rc["v1_prop"]), T(rc["v1_gtb"]), T(rc["v1_cls"]), None, beta=beta)
+        assert abs(float(lc0) - float(lc.detach())) > 0.1 * float(lc.detach())
+
+
+def test_d2_box2box_transform_round_trip(rc):
+    """the stand-in of Detectron2's Box2BoxTransform with BBOX_REG_WEIGHTS (10, 10, 5, 5): apply(get(src, tgt), src) == tgt"""
+    W = (10.0, 10.0, 5.0, 5.0)
+    src, tgt = T(rc["v1_prop"]), T(rc["v1_gtb"])
+    d = O.d2_get_deltas(src, tgt, W)
+    close(O.d2_apply_deltas(d, src, W), tgt, rtol=1e-5, atol=1e-3)
+    close(O.d2_apply_deltas(torch.cat([d, d], 1), src, W), torch.cat([tgt, tgt], 1), rtol=1e-5, atol=1e-3)
+
+
 def test_rpn_pseudo_losses(rc):
     anchors = O.make_anchors([(6, 8), (3, 4)], [16, 32], sizes=(32, 64))
     obj = [T(rc["rpn_obj%d" % l]).clone().requires_grad_(True) for l in range(2)]

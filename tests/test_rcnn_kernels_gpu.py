@@ -120,6 +120,73 @@ def test_predictor_losses_vs_reference_golden(rc, branch, pre):
         assert float(gv[R:].abs().max()) == 0.0
 
 
+V1 = {"spec": (False, 0.0, False), "spec_conf": (True, 0.0, False), "agn_conf_beta": (True, 0.5, True), "spec_giou": (False, 0.0, False)}
+
+
+def utv1_predictor(agnostic=False, beta=0.0, box_loss="smooth_l1"):
+    from ubteacher.modeling.rcnn import FastRCNNFocaltLossOutputLayers
+    from ubteacher.params import ParamStore
+    from ubteacher.presets import get_config
+    cfg = get_config("rcnn", 1, ["MODEL.DEVICE", DEV, "MODEL.ROI_HEADS.LOSS", "FocalLoss", "MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG", agnostic,
+                                 "MODEL.ROI_BOX_HEAD.SMOOTH_L1_BETA", beta, "MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE", box_loss])
+    return FastRCNNFocaltLossOutputLayers(cfg, ParamStore(), 1024, "roi_heads.box_predictor")
+
+
+@pytest.mark.parametrize("name", sorted(V1))
+def test_utv1_focal_predictor_losses_vs_reference_golden(rc, name):
+    """MODEL.ROI_HEADS.LOSS "FocalLoss": the UTv1 predictor's losses (reference fast_rcnn.py:1296-1429 executed by gen_golden.py),
+    class-specific / class-agnostic deltas, gt_confid weighting, smooth-L1 beta; empty slots ignored"""
+    conf, beta, agn = V1[name]
+    pred = utv1_predictor(agn, beta, "giou" if name.endswith("giou") else "smooth_l1")
+    R, pad = rc["v1_cls"].shape[0], 4
+    def padded(x, fill=0.0):
+        x = T(x).float()
+        return torch.cat([x, torch.full((pad,) + tuple(x.shape[1:]), fill)]).to(DEV)
+    scores, deltas = (padded(rc["v1_%s_%s" % (name, k)]).requires_grad_(True) for k in ("scores", "deltas"))
+    sampled = dict(gt_classes=torch.cat([T(rc["v1_cls"]).long(), torch.full((pad,), -1)]).to(DEV)[None],
+                   proposal_boxes=padded(rc["v1_prop"])[None], gt_boxes=padded(rc["v1_gtb"])[None])
+    if conf:
+        sampled["gt_confid"] = padded(rc["v1_conf"])[None]
+    ls = pred.losses((scores, deltas, None), sampled, "supervised")
+    close(ls["loss_cls"], rc["v1_%s_loss_cls" % name], rtol=2e-5); close(ls["loss_box_reg"], rc["v1_%s_loss_box_reg" % name], rtol=2e-5)
+    (ls["loss_cls"] + 2.0 * ls["loss_box_reg"]).backward()
+    for k, v in (("scores", scores), ("deltas", deltas)):
+        close(v.grad[:R], rc["v1_%s_g%s" % (name, k)], rtol=1e-4, atol=2e-7)
+        assert float(v.grad[R:].abs().max()) == 0.0 and bool(torch.isfinite(v.grad).all())
+    raw = pred.losses((scores.detach(), deltas.detach(), None), sampled, "supervised", raw=True)   # the fused scalar tail's inputs
+    close(raw["focal"][0] / R, rc["v1_%s_loss_cls" % name], rtol=2e-5); close(raw["box"][0] / R, rc["v1_%s_loss_box_reg" % name], rtol=2e-5)
+    assert int((raw["tgt"] >= 0).sum()) == R
+
+
+@pytest.mark.parametrize("agnostic", [False, True])
+def test_utv1_focal_predictor_inference_vs_oracle(agnostic):
+    """Detectron2's FastRCNNOutputLayers.inference with per-class boxes (class-specific apply_deltas with BBOX_REG_WEIGHTS, clip, score
+    threshold, class-aware NMS, top-k), two images, invalid proposal slots, a non-finite row: vs the oracle's restatement"""
+    pred = utv1_predictor(agnostic)
+    from ubteacher.modeling.fcos import PaddedBoxes
+    g = torch.Generator().manual_seed(5)
+    N, P, K = 2, 40, 80
+    p0 = torch.rand(N, P, 2, generator=g) * 200
+    prop = torch.cat([p0, p0 + torch.rand(N, P, 2, generator=g) * 90 + 4], -1)
+    scores = torch.randn(N * P, K + 1, generator=g) * 3
+    deltas = torch.randn(N * P, 4 * pred.nbox, generator=g) * 1.5
+    deltas[3, :] = float("nan")
+    valid = torch.ones(N, P, dtype=torch.uint8); valid[1, 30:] = 0
+    sizes = [(300, 280), (250, 300)]
+    props = PaddedBoxes(sizes, boxes=prop.to(DEV), valid=valid.to(DEV))
+    dets, rows = pred.inference((scores.to(DEV), deltas.to(DEV), None), props)
+    for i in range(N):
+        m = valid[i].bool()
+        bx = O.d2_apply_deltas(deltas.view(N, P, -1)[i][m], prop[i][m], (10.0, 10.0, 5.0, 5.0))
+        want, wrows = O.fast_rcnn_inference_per_class(bx, F.softmax(scores.view(N, P, -1)[i][m], dim=-1), sizes[i])
+        n = int(dets["count"][i])
+        assert n == len(wrows) and n > 5
+        assert np.array_equal(rows[i, :n].cpu().numpy(), torch.nonzero(m).squeeze(1)[wrows].numpy())
+        assert np.array_equal(dets["classes"][i, :n].cpu().numpy(), want["classes"].numpy())
+        close(dets["boxes"][i, :n], want["boxes"], atol=2e-4); close(dets["scores"][i, :n], want["scores"], rtol=2e-5)
+        assert 3 not in rows[0, :int(dets["count"][0])].tolist()
+
+
 @pytest.mark.parametrize("pre,prop_key", [("inf", "rc_prop"), ("infc", "infc_prop")])
 def test_predictor_inference_vs_reference_golden(rc, pre, prop_key):
     """infc (round 4): rows 0-11 are tiny proposals whose deltas lie far beyond the +-62.5 clamp of

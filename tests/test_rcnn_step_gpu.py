@@ -23,9 +23,18 @@ def relerr(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
-def test_rcnn_full_semisup_step_parity():
+@pytest.mark.parametrize("predictor", ["FocalLoss_BoundaryVar", "FocalLoss"])
+def test_rcnn_full_semisup_step_parity(predictor):
+    """FocalLoss_BoundaryVar: the shipped UTv2 configuration.  FocalLoss: the UTv1 predictor the reference still ships
+    (roi_heads/roi_heads.py:52-66 -> fast_rcnn.py:1296-1429): class-specific centre-size deltas, confidence-weighted focal loss on the
+    pseudo-labeled branch, no boundary-variance head - pseudo boxes without pred_boxes_std (trainer.py:743-746)."""
     from ubteacher.engine import UBRCNNTeacherTrainer
     cfg = rcnn_cfg()
+    cfg.MODEL.ROI_HEADS.LOSS = predictor
+    utv1 = predictor == "FocalLoss"
+    if utv1:
+        cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE = "smooth_l1"       # the UTv2 YAML's "nlloss" is a ValueError there (fast_rcnn.py:184-186)
+        cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = False          # Detectron2's default: 4 deltas per class
     torch.manual_seed(0)
     prod, orac = make_batch(31, 2, 2, H, W, "cuda")
     tr = UBRCNNTeacherTrainer(cfg, data_loader=FixedLoader(prod))
@@ -33,7 +42,10 @@ def test_rcnn_full_semisup_step_parity():
     pstd = torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1)
     sd_s = tune(cpu_state(tr.model), [d["image"] for d in orac[3]], mean, pstd)
     sd_t = dict(sd_s)
-    sd_t["roi_heads.box_predictor.bbox_pred_std.bias"] = torch.full((4,), -3.0)
+    if utv1:
+        assert "roi_heads.box_predictor.bbox_pred_std.weight" not in sd_s and tuple(sd_s["roi_heads.box_predictor.bbox_pred.weight"].shape) == (320, 1024)
+    else:
+        sd_t["roi_heads.box_predictor.bbox_pred_std.bias"] = torch.full((4,), -3.0)
     tr.model.load_state_dict(sd_s)
     tr.model_teacher.load_state_dict(sd_t)
     tr.iter = 1
@@ -80,6 +92,7 @@ def test_rcnn_full_semisup_step_parity():
     gl = tr._last_pseudo
     for i, p in enumerate(pseudo):
         assert int(gl["valid"][i].sum()) == len(p["boxes"])
+        assert ("pred_boxes_std" in p) == (not utv1) and ("pred_boxes_std" in gl) == (not utv1)
     keys = dict(rpn_sup=rpn_keys[0], rpn_unsup=rpn_keys[1],
                 roi_sup=compact_roi(roi_keys[0], [len(p["boxes"]) for p in props_sup], [len(d["gt"]["boxes"]) for d in orac[0] + orac[1]]),
                 roi_unsup=compact_roi(roi_keys[1], [len(p["boxes"]) for p in props_uns], [len(p["boxes"]) for p in pseudo]))

@@ -121,8 +121,10 @@ def rcnn_tune(sd, images, mean, pstd, seed=0):
     sd[p + "cls_score.weight"] = torch.randn(81, 1024, generator=g) * (2.5 / (s_x * 32))
     b = torch.zeros(81); b[80] = 3.0
     sd[p + "cls_score.bias"] = b
-    sd[p + "bbox_pred.weight"] = torch.randn(4, 1024, generator=g) * (0.5 / (s_x * 32))
-    sd[p + "bbox_pred_std.weight"] = torch.randn(4, 1024, generator=g) * (0.5 / (s_x * 32))
+    nb = sd[p + "bbox_pred.weight"].shape[0]          # 4 (boundary-variance predictors) or 4 per class (the UTv1 predictor)
+    sd[p + "bbox_pred.weight"] = torch.randn(nb, 1024, generator=g) * (0.5 / (s_x * 32))
+    if p + "bbox_pred_std.weight" in sd:
+        sd[p + "bbox_pred_std.weight"] = torch.randn(4, 1024, generator=g) * (0.5 / (s_x * 32))
     return sd
 
 

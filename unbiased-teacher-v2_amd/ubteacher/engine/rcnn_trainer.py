@@ -84,8 +84,9 @@ def _make(base):
                         _, proposals_rpn_unsup_k, proposals_roih_unsup_k, _ = self.model_teacher(unlabel_data_k, branch="unsup_data_weak")
                     pseudo, _ = self.process_pseudo_label(proposals_roih_unsup_k, S.BBOX_THRESHOLD, "roih", "thresholding")
                     # student ground truth fields
+                    extra = {"pred_boxes_std": pseudo["pred_boxes_std"]} if "pred_boxes_std" in pseudo else {}   # trainer.py:743-746: when there is one
                     gt = PaddedBoxes(pseudo.image_sizes, boxes=pseudo["boxes"], classes=pseudo["classes"], valid=pseudo["valid"],
-                                     scores=pseudo["scores"], pred_boxes_std=pseudo["pred_boxes_std"])
+                                     scores=pseudo["scores"], **extra)
                     if overlap:
                         for t in gt.f.values():          # allocated on the side stream, consumed on the main one
                             if torch.is_tensor(t):

@@ -556,6 +556,130 @@ class FastRCNNFocaltLossBoundaryVarOutputLayers:
         return out, keep_rows
 
 
+class FastRCNNFocaltLossOutputLayers:
+    """MODEL.ROI_HEADS.LOSS "FocalLoss" - the Unbiased-Teacher-v1 predictor the reference still ships (roi_heads/fast_rcnn.py:1296-1402
+    `FastRCNNFocaltLossOutputLayers` / `FastRCNNFocalLoss` on Detectron2's `FastRCNNOutputLayers` [D2-recall]): cls_score (K + 1) and
+    bbox_pred (4 per class, or 4 with CLS_AGNOSTIC_BBOX_REG) Linear heads, no boundary-variance head; Detectron2's centre-size
+    `Box2BoxTransform(BBOX_REG_WEIGHTS)`; loss_cls = sum of (1 - p)^1.5 * CE, times the matched pseudo box's score when the sampled
+    proposals carry `gt_confid` (fast_rcnn.py:1379-1429), / R; loss_box_reg = smooth-L1 (SMOOTH_L1_BETA) between the foreground
+    rows' deltas of their gt class and `get_deltas(proposal, gt box)` - or, BBOX_REG_LOSS_TYPE "giou", the GIoU loss of the decoded
+    boxes -, summed, / R (fast_rcnn.py:134-194).  No shipped UTv2 YAML selects
+    it: the small losses run as ATen ops on the device (autograd differentiates them); the heads are one fused GEMM on the same
+    kernels as every other Linear.  Inference = Detectron2's `fast_rcnn_inference` with per-class boxes."""
+    focal_gamma = 1.5
+
+    def __init__(self, cfg, store, in_dim, prefix):
+        rh, bh = cfg.MODEL.ROI_HEADS, cfg.MODEL.ROI_BOX_HEAD
+        K = self.K = self.num_classes = rh.NUM_CLASSES
+        self.nbox = 1 if bh.CLS_AGNOSTIC_BBOX_REG else K
+        nb = 4 * self.nbox
+        self.ch = (K + 1 + nb + 7) // 8 * 8
+
+        def init_pred(t):
+            t.zero_()
+            t[:K + 1].normal_(0.0, 0.01)
+            t[K + 1:K + 1 + nb].normal_(0.0, 0.001)
+        w = store.new((self.ch, in_dim), "decay", init_pred)
+        w.export(prefix + ".cls_score.weight", lambda t: t[0:K + 1])
+        w.export(prefix + ".bbox_pred.weight", lambda t: t[K + 1:K + 1 + nb])
+        b = store.new((self.ch,), "decay", lambda t: t.zero_())
+        b.export(prefix + ".cls_score.bias", lambda t: t[0:K + 1])
+        b.export(prefix + ".bbox_pred.bias", lambda t: t[K + 1:K + 1 + nb])
+        self.linear = ops.Conv(w, in_dim, self.ch, 1, 1, 0, bias=b, out_fp32=True)
+        self.box_weights = tuple(bh.BBOX_REG_WEIGHTS)
+        self.smooth_l1_beta = bh.SMOOTH_L1_BETA
+        self.test_score_thresh = rh.SCORE_THRESH_TEST
+        self.test_nms_thresh = rh.NMS_THRESH_TEST
+        self.test_topk_per_image = cfg.TEST.DETECTIONS_PER_IMAGE
+        self.box_reg_loss_type = bh.BBOX_REG_LOSS_TYPE
+        self.loss_weight = {}                                    # FastRCNNFocalLoss.losses applies none (fast_rcnn.py:1379-1402)
+        if self.box_reg_loss_type not in ("smooth_l1", "giou"):  # fast_rcnn.py:163-186 raises the same at the first loss; the UTv2 YAMLs set "nlloss"
+            raise ValueError("Invalid bbox reg loss type '{}'".format(self.box_reg_loss_type))
+
+    def __call__(self, x2d):
+        y = self.linear(x2d.view(x2d.shape[0], 1, 1, -1)).view(x2d.shape[0], self.ch)
+        K = self.K
+        return y[:, :K + 1], y[:, K + 1:K + 1 + 4 * self.nbox], None
+
+    @staticmethod
+    def _giou_loss(b1, b2, eps=1e-7):
+        """fvcore.nn.giou_loss, reduction none [D2-recall]"""
+        x1, y1, x2, y2 = b1.unbind(dim=-1)
+        x1g, y1g, x2g, y2g = b2.unbind(dim=-1)
+        xk1, yk1, xk2, yk2 = torch.max(x1, x1g), torch.max(y1, y1g), torch.min(x2, x2g), torch.min(y2, y2g)
+        inter = torch.where((yk2 > yk1) & (xk2 > xk1), (xk2 - xk1) * (yk2 - yk1), torch.zeros_like(x1))
+        union = (x2 - x1) * (y2 - y1) + (x2g - x1g) * (y2g - y1g) - inter
+        area_c = (torch.max(x2, x2g) - torch.min(x1, x1g)) * (torch.max(y2, y2g) - torch.min(y1, y1g))
+        return 1 - (inter / (union + eps) - (area_c - union) / (area_c + eps))
+
+    def losses(self, predictions, sampled, branch, raw=False):
+        scores, deltas = predictions[0], predictions[1]
+        K = self.K
+        cls = sampled["gt_classes"].reshape(-1).long()          # -1 = empty slot
+        ce = F.cross_entropy(scores.float(), cls, ignore_index=-1, reduction="none")
+        loss = (1.0 - torch.exp(-ce)) ** self.focal_gamma * ce
+        if "gt_confid" in sampled:                               # fast_rcnn.py:1424-1427: the pseudo-labeled branch
+            loss = loss * sampled["gt_confid"].reshape(-1)
+        focal = loss.sum().reshape(1)
+        fg = (cls >= 0) & (cls < K)
+        prop, gtb = sampled["proposal_boxes"].reshape(-1, 4), sampled["gt_boxes"].reshape(-1, 4)
+        zero = torch.zeros((), device=prop.device)
+        if self.nbox == 1:
+            pred = deltas
+        else:
+            col = (4 * cls.clamp(min=0, max=K - 1))[:, None] + torch.arange(4, device=cls.device)[None, :]
+            pred = torch.gather(deltas, 1, col)
+        # background / empty rows carry zero gt boxes (log(0), 0/0): neutral operands there keep the backward finite
+        if self.box_reg_loss_type == "smooth_l1":
+            tgt = torch.where(fg[:, None], rpn_get_deltas(prop, gtb, self.box_weights), zero)
+            diff = (pred.float() - tgt).abs()
+            if self.smooth_l1_beta >= 1e-5:                       # fvcore smooth_l1_loss
+                diff = torch.where(diff < self.smooth_l1_beta, 0.5 * diff * diff / self.smooth_l1_beta, diff - 0.5 * self.smooth_l1_beta)
+            box = torch.where(fg[:, None], diff, zero).sum().reshape(1)
+        else:                                                     # "giou" (fast_rcnn.py:174-183)
+            bx = rpn_apply_deltas(torch.where(fg[:, None], pred.float(), zero), prop, self.box_weights)
+            box = torch.where(fg, self._giou_loss(bx, torch.where(fg[:, None], gtb, prop)), zero).sum().reshape(1)
+        if raw:
+            return {"focal": focal, "box": box, "tgt": cls.to(torch.int32).contiguous()}
+        Rn = (cls >= 0).sum().clamp(min=1).float()
+        return {"loss_cls": focal[0] / Rn, "loss_box_reg": box[0] / Rn}
+
+    @torch.no_grad()
+    def inference(self, predictions, proposals, max_cand=8192):
+        """Detectron2 FastRCNNOutputLayers.inference [D2-recall]: predict_boxes (per-class apply_deltas), softmax, clip, score threshold,
+        class-aware NMS, top-k per image; returns (padded detections, kept proposal rows)"""
+        scores, deltas = predictions[0], predictions[1]
+        N, P = proposals["valid"].shape
+        K, nbx = self.K, self.nbox
+        pb = proposals["boxes"]
+        boxes = rpn_apply_deltas(deltas.float().view(N, P, nbx, 4), pb[:, :, None, :], self.box_weights)      # [N, P, nbx, 4]
+        hwt = torch.tensor([[s[1], s[0], s[1], s[0]] for s in proposals.image_sizes], dtype=torch.float32, device=pb.device)[:, None, None, :]
+        probs = F.softmax(scores.float(), dim=-1).view(N, P, K + 1)
+        ok = proposals["valid"].bool() & torch.isfinite(boxes).all(dim=3).all(dim=2) & torch.isfinite(probs).all(dim=2)
+        probs = probs[:, :, :K]
+        boxes = torch.minimum(boxes.clamp(min=0), hwt)
+        cand = (probs > self.test_score_thresh) & ok[:, :, None]
+        flat = torch.where(cand, probs, torch.full_like(probs, -1.0)).reshape(N, P * K)
+        k = min(max_cand, P * K)
+        top = torch.topk(float_order_key(flat), k, dim=1, sorted=True).values
+        idx = 4294967295 - (top & 4294967295)
+        sc = torch.gather(flat, 1, idx)
+        r, c = idx // K, (idx % K).to(torch.int32)
+        bsel = r if nbx == 1 else idx                                   # the box of (row, class)
+        cb = torch.gather(boxes.reshape(N, P * nbx, 4), 1, bsel[:, :, None].expand(-1, -1, 4)).contiguous()
+        valid = (sc > self.test_score_thresh).to(torch.uint8)
+        D = self.test_topk_per_image
+        kidx, cnt = hip.nms_batched(cb, sc.contiguous(), c.contiguous(), valid.contiguous(), self.test_nms_thresh,
+                                    class_aware=True, post_topk=-1, max_out=D)
+        ix = kidx.clamp(min=0).long()
+        keep_rows = torch.gather(r, 1, ix)
+        out = PaddedBoxes(proposals.image_sizes,
+                          boxes=torch.gather(cb, 1, ix[:, :, None].expand(-1, -1, 4)).contiguous(),
+                          scores=torch.gather(sc, 1, ix).contiguous(), classes=torch.gather(c, 1, ix).contiguous(),
+                          valid=(torch.arange(D, device=pb.device)[None, :] < cnt[:, None]).to(torch.uint8), count=cnt)
+        return out, keep_rows
+
+
 class FastRCNNCrossEntropyBoundaryVarOutputLayers(FastRCNNFocaltLossBoundaryVarOutputLayers):
     """MODEL.ROI_HEADS.LOSS "CrossEntropy_BoundaryVar" (reference fast_rcnn.py:214-712): the same predictor, box losses and inference;
     loss_cls is the mean softmax cross-entropy (:389,:400,:412) = the focal form (1-p)^gamma * CE at gamma 0, same kernel."""
@@ -594,9 +718,14 @@ class StandardROIHeadsPseudoLab:
             self.box_predictor = FastRCNNFocaltLossBoundaryVarOutputLayers(cfg, store, dim_in, prefix + ".box_predictor")
         elif rh.LOSS == "CrossEntropy_BoundaryVar":
             self.box_predictor = FastRCNNCrossEntropyBoundaryVarOutputLayers(cfg, store, dim_in, prefix + ".box_predictor")
-        elif rh.LOSS in ("CrossEntropy", "FocalLoss"):
-            raise NotImplementedError("MODEL.ROI_HEADS.LOSS %r: the predictors without the boundary-variance head (UTv1) are not part of "
-                                      "the UTv2 path" % (rh.LOSS,))
+        elif rh.LOSS == "FocalLoss":      # the Unbiased-Teacher-v1 predictor (no boundary-variance head)
+            self.box_predictor = FastRCNNFocaltLossOutputLayers(cfg, store, dim_in, prefix + ".box_predictor")
+        elif rh.LOSS == "CrossEntropy":
+            # Detectron2's plain FastRCNNOutputLayers: the reference cannot train it either - roi_heads.py:124 calls
+            # `losses(predictions, proposals, branch)` on Detectron2's two-argument method (TypeError on the first step)
+            raise NotImplementedError("MODEL.ROI_HEADS.LOSS 'CrossEntropy' selects Detectron2's FastRCNNOutputLayers, whose losses() the "
+                                      "reference's ROI heads call with a third argument (roi_heads.py:124): it cannot train there either; "
+                                      "use 'FocalLoss' (UTv1), 'FocalLoss_BoundaryVar' or 'CrossEntropy_BoundaryVar'")
         else:
             raise ValueError("Unknown ROI head loss.")
         self.training = True
@@ -689,8 +818,8 @@ class StandardROIHeadsPseudoLab:
         valid = torch.cat((s_l["valid"], s_u["valid"]), dim=0)
         scores, deltas, std = self.box_predictor(self._box_features(feats, boxes, valid, fanin=features.get("_fanin")))
         r = nl * boxes.shape[1]
-        l_l = self.box_predictor.losses((scores[:r], deltas[:r], std[:r]), s_l, "supervised", raw=raw)
-        l_u = self.box_predictor.losses((scores[r:], deltas[r:], std[r:]), s_u, "unsup_data_train", raw=raw)
+        l_l = self.box_predictor.losses((scores[:r], deltas[:r], None if std is None else std[:r]), s_l, "supervised", raw=raw)
+        l_u = self.box_predictor.losses((scores[r:], deltas[r:], None if std is None else std[r:]), s_u, "unsup_data_train", raw=raw)
         return l_l, l_u
 
 
