@@ -625,6 +625,57 @@ def test_raw_output_contract_and_pseudo_generator_accepts_reference_dict():
     assert dets[0].has("pred_boxes") and len(dets) == 2
 
 
+def test_yield_proposal_train_time_detections_vs_oracle():
+    """MODEL.FCOS.YIELD_PROPOSAL (reference fcos/fcos.py:139-187; True in every shipped FCOS YAML): in training mode FCOS.forward also returns the student's own detections
+    - predict_proposals under INFERENCE_TH_TRAIN / PRE_NMS_TOPK_TRAIN / POST_NMS_TOPK_TRAIN, without gradient - as results["proposals"], and
+    the raw output carries the bbox tower's per-level output (fcos.py:135,338-350).  Losses are those of the same forward without it."""
+    from ubteacher.modeling import build_model
+    cfg = small_fcos_cfg()
+    assert cfg.MODEL.FCOS.YIELD_PROPOSAL is True
+    cfg.MODEL.FCOS.INFERENCE_TH_TRAIN, cfg.MODEL.FCOS.PRE_NMS_TOPK_TRAIN, cfg.MODEL.FCOS.POST_NMS_TOPK_TRAIN = 0.08, 300, 20   # != the *_TEST values
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    prod, orac = make_batch(13, 2, 2, H, W, "cuda")
+    sd = tune_state_for_pseudo_labels(cpu_state(model), [d["image"] for d in orac[3]])
+    model.load_state_dict(sd)
+    model.train()
+    losses, raw, results = model(prod[1], output_raw=True, branch="labeled")
+    assert "proposals" in results and "proposals" in results.keys()
+    props = results["proposals"]
+    assert all(not t.requires_grad for t in props.f.values() if torch.is_tensor(t))
+    fc = cfg.MODEL.FCOS
+    assert (fc.INFERENCE_TH_TRAIN, fc.PRE_NMS_TOPK_TRAIN, fc.POST_NMS_TOPK_TRAIN) != (fc.INFERENCE_TH_TEST, fc.PRE_NMS_TOPK_TEST, fc.POST_NMS_TOPK_TEST)
+    ocfg = O.FCOSCfg(pre_nms_thresh=fc.INFERENCE_TH_TRAIN, pre_nms_topk=fc.PRE_NMS_TOPK_TRAIN, post_nms_topk=fc.POST_NMS_TOPK_TRAIN, nms_thresh=fc.NMS_TH)
+    with torch.no_grad():
+        logits, reg, std, ctr, locs, sizes = O.fcos_forward(sd, [d["image"] for d in orac[1]], sd["pixel_mean"], sd["pixel_std"])
+        want = O.fcos_predict(ocfg, logits, reg, std, ctr, locs, sizes, "cls_n_ctr")
+    total = 0
+    for i, wd in enumerate(want):
+        m = props["valid"][i].bool()
+        assert int(m.sum()) == len(wd["scores"]), (i, int(m.sum()), len(wd["scores"]))
+        a = torch.argsort(props["scores"][i][m].cpu(), descending=True, stable=True)
+        b = torch.argsort(wd["scores"], descending=True, stable=True)
+        assert torch.equal(props["classes"][i][m].long().cpu()[a], wd["classes"][b])
+        assert float((props["boxes"][i][m].cpu()[a] - wd["boxes"][b]).abs().max()) < 2e-3
+        assert float((props["scores"][i][m].cpu()[a] - wd["scores"][b]).abs().max()) < 1e-5
+        total += len(b)
+    assert total > 20, "test setup: the student's train-time detections are empty"
+    tw = raw["bbox_towers"]
+    assert len(tw) == 5 and all(t.shape[:2] == (2, 256) and t.shape[2:] == raw["logits_pred"][l].shape[2:] for l, t in enumerate(tw))
+    # without the switch: same losses, no proposals, empty bbox_towers (as the reference's head returns)
+    cfg2 = small_fcos_cfg()
+    cfg2.MODEL.FCOS.YIELD_PROPOSAL = False
+    torch.manual_seed(0)
+    model2 = build_model(cfg2)
+    model2.load_state_dict(sd)
+    model2.train()
+    losses2, raw2, results2 = model2(prod[1], output_raw=True, branch="labeled")
+    assert "proposals" not in results2 and raw2["bbox_towers"] == []
+    for k, v in losses.items():
+        assert torch.equal(v, losses2[k]), k
+    sum(losses.values()).backward()      # the extra outputs hang off detached tensors: the loss graph is intact
+
+
 def test_checkpoint_roundtrip_on_device_arena(tmp_path):
     """SURVEY 8f rank 2 on the GPU: train a step, save the teacher/student checkpoint (arena -> reference-named CPU tensors), resume in a
     FRESH trainer (CPU tensors -> device arenas, momentum, scheduler, iteration) and take the next step in both: bit-identical

@@ -239,7 +239,9 @@ class RawOutput(dict):
             v = [meta.level_view(ho["box"], l) for l in range(L)]
         elif key == "locations":
             v = [compute_locations(h, w, s, ho["logits"].device) for (h, w), s in zip(hw, self._strides)]
-        else:  # top_feats (no top module), bbox_towers (YIELD_PROPOSAL False in every shipped config)
+        elif key == "bbox_towers" and "bbox_tower" in ho:      # MODEL.FCOS.YIELD_PROPOSAL (fcos.py:135,338-350), NCHW views per level
+            v = nchw(ho["bbox_tower"], 0, ho["bbox_tower"].shape[1])
+        else:  # top_feats (no top module), bbox_towers without YIELD_PROPOSAL: empty lists there too
             v = []
         self[key] = v
         return v
@@ -252,6 +254,8 @@ class RawOutput(dict):
 
 
 class FCOSHead:
+    yield_bbox_towers = False
+
     def __init__(self, cfg, store, in_channels, prefix):
         fc = cfg.MODEL.FCOS
         assert fc.NORM == "GN", "only the GN towers of the shipped configs are built"
@@ -380,7 +384,10 @@ class FCOSHead:
                 tb = gn(conv(tb, meta=meta), meta)
         logits = self.cls_logits(tc, meta=meta)
         box = self.box_head(tb, meta=meta, colscale_handle=self.scales)
-        return {"logits": logits, "box": box, "meta": meta}
+        out = {"logits": logits, "box": box, "meta": meta}
+        if self.yield_bbox_towers:       # fcos.py:338-350 (MODEL.FCOS.YIELD_PROPOSAL): the bbox tower's output, level-first [P, C] (a view)
+            out["bbox_tower"] = tb
+        return out
 
 
 class FCOSOutputs:
@@ -688,6 +695,31 @@ class FCOSOutputs:
         return res[0] if single else res
 
 
+class _LazyProposals(dict):
+    """the `results` dict of a training forward under MODEL.FCOS.YIELD_PROPOSAL: "proposals" is decoded + NMSed on first access"""
+
+    def __init__(self, base, make):
+        super().__init__(base)
+        self._make = make
+
+    def __missing__(self, key):
+        if key != "proposals":
+            raise KeyError(key)
+        with torch.no_grad():
+            v = self._make()
+        self[key] = v
+        return v
+
+    def __contains__(self, key):
+        return key == "proposals" or dict.__contains__(self, key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        return list(dict.keys(self)) + ([] if dict.__contains__(self, "proposals") else ["proposals"])
+
+
 @PROPOSAL_GENERATOR_REGISTRY.register()
 class FCOS:
     def __init__(self, cfg, store, in_channels, prefix="proposal_generator"):
@@ -696,6 +728,7 @@ class FCOS:
         self.fpn_strides = list(fc.FPN_STRIDES)
         self.yield_proposal = fc.YIELD_PROPOSAL
         self.fcos_head = FCOSHead(cfg, store, in_channels, prefix + ".fcos_head")
+        self.fcos_head.yield_bbox_towers = self.yield_proposal
         self.fcos_outputs = FCOSOutputs(cfg)
         # Integral.project is a persistent buffer in the reference (fcos_outputs.py:61-63): keep the key.
         self.project = store.new((fc.REG_MAX + 1,), "buffer",
@@ -731,8 +764,12 @@ class FCOS:
                 results, losses = {}, {}
             else:
                 raise ValueError("Unknown branch")
-            # B16: the reference also decodes + NMSes student proposals here when
-            # YIELD_PROPOSAL is set and never uses them; that wasted work is deliberately skipped.
+            if self.yield_proposal:
+                # fcos.py:176-187 (every shipped FCOS YAML sets YIELD_PROPOSAL): the student's own detections under the *_TRAIN thresholds /
+                # top-k, no gradient.  The reference computes them on every training forward and its trainer drops them
+                # (one_stage_detector.py:213-217 returns the losses); here they are decoded when somebody reads results["proposals"].
+                fo = self.fcos_outputs
+                results = _LazyProposals(results, lambda: fo.predict_proposals(head_out, level_hw, image_sizes, nms_method))
             if output_raw:
                 return results, losses, raw_output
             return results, losses
