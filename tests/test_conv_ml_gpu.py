@@ -210,8 +210,12 @@ def test_narrow_prediction_convs_on_the_96_wide_tile(K, out_dtype):
     y128 = hip.conv2d_ml_fwd_bf16(x[:, C:].contiguous(), w128, level_hw, N, bias=b128, k=3, pad=1, out_dtype=od)
     # (the 128-wide tile walks the K loop in 64-channel chunks, this one in 32-channel chunks: the same products summed in another
     # order in fp32 - equal to accumulation-order rounding, not bit for bit)
-    tol = 2e-5 if out_dtype == "f32" else 2 ** -9
-    assert float((y.float() - y128[:, :K].float()).abs().max()) <= tol * float(y128.float().abs().max())
+    # a 16-bit output may flip by one unit in the last place: 2^-7 of the top binade in bf16 (8 significant bits), 2^-10 in fp16 -
+    # and only a small fraction of the elements may differ at all
+    tol = 2e-5 if out_dtype == "f32" else (2 ** -7 if h16 == torch.bfloat16 else 2 ** -10)
+    dy = (y.float() - y128[:, :K].float()).abs()
+    assert float(dy.max()) <= tol * float(y128.float().abs().max())
+    assert out_dtype == "f32" or float((dy > 0).float().mean()) < 0.02
     xr = meta.level_view(x[:, C:].contiguous(), 1).float().permute(0, 3, 1, 2).cpu()
     ref = F.conv2d(xr, w.float().view(K, 3, 3, C).permute(0, 3, 1, 2).cpu(), b.cpu(), 1, 1)
     got = meta.level_view(y, 1).float().permute(0, 3, 1, 2).cpu()

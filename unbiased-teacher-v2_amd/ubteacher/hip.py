@@ -99,7 +99,14 @@ def symbols():
     return sorted(_SIGS)
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """the current HIP stream of the current device as a pointer (the raw getter: ~0.3 us against ~9 us for torch.cuda.current_stream(),
+    asked ~330 times per training step)"""
+    if _RAW_STREAM is not None:
+        return c_p(_RAW_STREAM(torch.cuda.current_device()))
     return c_p(torch.cuda.current_stream().cuda_stream)
 
 
