@@ -440,15 +440,16 @@ int utv2_rcnn_loss_combine(const float* rpn_sup, const float* rpn_uns, const flo
                            float rpn_norm_uns, float w_rpn_cls, float w_rpn_loc, float w_box, const float* wt_host, float* rec, float* coef,
                            utv2_stream_t stream);
 
-/* ---- one frozen ResNet identity bottleneck as ONE kernel (csrc/bottleneck.hip): D2 BottleneckBlock conv1 1x1 -> conv2 3x3 -> conv3 1x1 +
- * identity, FrozenBN folded to scale / shift, of the R-50 the reference builds through build_fcos_resnet_fpn_backbone
- * (ubteacher/modeling/backbone/fpn.py:21-22; res2 blocks 1-2 under MODEL.BACKBONE.FREEZE_AT 2).  x, y: [N, H, W, C = 256] of the library's
- * 16-bit type, y != x; w1 [MID = 64][C], w2 [MID][3][3][MID], w3 [C][MID] 16-bit; s* / b*: fp32 per output channel.
- * y = relu(conv3(relu(conv2(relu(conv1(x) * s1 + b1)) * s2 + b2)) * s3 + b3 + x).  The 64-channel intermediates never leave LDS. */
-int utv2_bottleneck_identity_supported(int C, int MID);
-int utv2_bottleneck_identity_fwd_bf16(const void* x, void* y, const void* w1, const void* w2, const void* w3, const float* s1, const float* b1,
-                                      const float* s2, const float* b2, const float* s3, const float* b3, int N, int H, int W, int C, int MID,
-                                      utv2_stream_t stream);
+/* ---- one frozen ResNet bottleneck as ONE kernel (csrc/bottleneck.hip): D2 BottleneckBlock conv1 1x1 -> conv2 3x3 -> conv3 1x1 + identity
+ * (or + the 1x1 shortcut conv of a stage's first block), FrozenBN folded to scale / shift, of the R-50 the reference builds through
+ * build_fcos_resnet_fpn_backbone (ubteacher/modeling/backbone/fpn.py:21-22; res2 under MODEL.BACKBONE.FREEZE_AT 2).
+ * x: [N, H, W, C], y: [N, H, W, 256] of the library's 16-bit type, y != x; w1 [MID = 64][C], w2 [MID][3][3][MID], w3 [256][MID] 16-bit;
+ * s* / b*: fp32 per output channel.  wsc NULL (C = 256): y = relu(conv3(relu(conv2(relu(conv1(x) s1 + b1)) s2 + b2)) s3 + b3 + x);
+ * wsc [256][C] (C = 64): ... + h16(shortcut(x) ssc + bsc) instead of + x.  The 64-channel intermediates never leave LDS. */
+int utv2_bottleneck_supported(int C, int MID, int has_shortcut);
+int utv2_bottleneck_fwd_bf16(const void* x, void* y, const void* w1, const void* w2, const void* w3, const void* wsc, const float* s1,
+                             const float* b1, const float* s2, const float* b2, const float* s3, const float* b3, const float* ssc,
+                             const float* bsc, int N, int H, int W, int C, int MID, utv2_stream_t stream);
 
 /* ---- two-crop data path: the pixel arithmetic of the reference's weak / strong views, on uint8 [H][W][3] images
  * in HBM, bit-exact to Pillow (which Detectron2 / torchvision / the reference call on the CPU) ------------------------------------- */

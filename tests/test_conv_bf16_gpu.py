@@ -656,30 +656,35 @@ def test_stem_on_the_tall_tile_at_benchmark_size():
     assert y.shape[1] * y.shape[2] >= 65536 and close16(y.cpu().permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize("shortcut", [False, True])
 @pytest.mark.parametrize("shape", [(2, 24, 48), (1, 21, 37), (3, 8, 16), (1, 5, 7)])
-def test_fused_frozen_identity_bottleneck_equals_the_three_convs(shape):
-    """csrc/bottleneck.hip (round 4): a frozen identity bottleneck (R-50 res2 blocks 1-2; D2 BottleneckBlock with FrozenBN as scale /
-    shift, reference backbone fpn.py:21-22) as ONE kernel with the 64-channel intermediates in LDS - against the three conv launches it
-    replaces (same 16-bit roundings of c1 / c2, fp32 accumulation in another chunk order) and against torch on the same rounded
-    operands.  Ragged tiles (H % 8, W % 16 != 0), images smaller than a tile, several images."""
+def test_fused_frozen_bottleneck_equals_the_conv_chain(shape, shortcut):
+    """csrc/bottleneck.hip (round 4): a frozen stride-1 bottleneck of R-50's res2 (D2 BottleneckBlock with FrozenBN as scale / shift,
+    reference backbone fpn.py:21-22) as ONE kernel with the 64-channel intermediates in LDS - the identity blocks (x has 256 channels) and
+    the stage's first block (x has 64, 1x1 shortcut conv) - against the three / four conv launches it replaces (same 16-bit roundings of
+    c1 / c2 / the shortcut, fp32 accumulation in another chunk order) and against torch on the same rounded operands.  Ragged tiles
+    (H % 8, W % 16 != 0), images smaller than a tile, several images."""
     from ubteacher import hip
     N, H, W = shape
-    C, MID = 256, 64
+    C, MID, K = (64 if shortcut else 256), 64, 256
     h16 = hip.h16_dtype()
     g = torch.Generator().manual_seed(7)
-    x = (torch.randn(N, H, W, C, generator=g).clamp(min=0) * 0.7).to(h16).cuda()          # a ReLU output, as in the network
-    w1 = (torch.randn(MID, C, generator=g) * 0.06).to(h16).cuda()
+    x = (torch.randn(N, H, W, C, generator=g).clamp(min=0) * 0.7).to(h16).cuda()          # a ReLU / max-pool output, as in the network
+    w1 = (torch.randn(MID, C, generator=g) * (0.06 if not shortcut else 0.12)).to(h16).cuda()
     w2 = (torch.randn(MID, 9 * MID, generator=g) * 0.05).to(h16).cuda()
-    w3 = (torch.randn(C, MID, generator=g) * 0.1).to(h16).cuda()
+    w3 = (torch.randn(K, MID, generator=g) * 0.1).to(h16).cuda()
+    wsc = (torch.randn(K, C, generator=g) * 0.1).to(h16).cuda() if shortcut else None
     sb = [(torch.rand(k, generator=g) + 0.5).cuda() if i % 2 == 0 else (torch.randn(k, generator=g) * 0.2).cuda()
-          for i, k in enumerate((MID, MID, MID, MID, C, C))]
-    s1, b1, s2, b2, s3, b3 = sb
-    assert hip.bottleneck_identity_supported(C, MID) and not hip.bottleneck_identity_supported(512, 128)
-    y = hip.bottleneck_identity_fwd_bf16(x, w1, w2, w3, s1, b1, s2, b2, s3, b3)
+          for i, k in enumerate((MID, MID, MID, MID, K, K, K, K))]
+    s1, b1, s2, b2, s3, b3, ssc, bsc = sb
+    assert hip.bottleneck_supported(C, MID, shortcut) and not hip.bottleneck_supported(512, 128, False) and not hip.bottleneck_supported(256, 64, True)
+    kw = dict(wsc=wsc, ssc=ssc, bsc=bsc) if shortcut else {}
+    y = hip.bottleneck_fwd_bf16(x, w1, w2, w3, s1, b1, s2, b2, s3, b3, **kw)
     c1 = hip.conv2d_fwd_bf16(x, w1, scale=s1, bias=b1, relu=True)
     c2 = hip.conv2d_fwd_bf16(c1, w2, scale=s2, bias=b2, relu=True, kh=3, kw=3, pad=1)
-    y3 = hip.conv2d_fwd_bf16(c2, w3, scale=s3, bias=b3, relu=True, residual=x)
-    assert y.shape == y3.shape and y.dtype == h16
+    r = hip.conv2d_fwd_bf16(x, wsc, scale=ssc, bias=bsc) if shortcut else x
+    y3 = hip.conv2d_fwd_bf16(c2, w3, scale=s3, bias=b3, relu=True, residual=r)
+    assert y.shape == y3.shape == (N, H, W, K) and y.dtype == h16
     d = (y.float() - y3.float()).abs()
     ulp = 2 ** -7 if h16 == torch.bfloat16 else 2 ** -10
     # c1 / c2 may flip by one 16-bit ulp between the two accumulation orders, which then propagates: bounded by a few output ulps
@@ -687,8 +692,10 @@ def test_fused_frozen_identity_bottleneck_equals_the_three_convs(shape):
     assert float((d > 0).float().mean()) < 0.05
     # torch on the same rounded operands, fp32 math with the same 16-bit roundings of the intermediates
     xf = x.float().permute(0, 3, 1, 2)
-    t1 = F.relu(F.conv2d(xf, w1.float().view(MID, C, 1, 1)) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1)).to(h16).float()
-    t2 = F.relu(F.conv2d(t1, w2.float().view(MID, 3, 3, MID).permute(0, 3, 1, 2), padding=1) * s2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1)).to(h16).float()
-    t3 = F.relu(F.conv2d(t2, w3.float().view(C, MID, 1, 1)) * s3.view(1, -1, 1, 1) + b3.view(1, -1, 1, 1) + xf)
+    v = lambda t: t.view(1, -1, 1, 1)
+    t1 = F.relu(F.conv2d(xf, w1.float().view(MID, C, 1, 1)) * v(s1) + v(b1)).to(h16).float()
+    t2 = F.relu(F.conv2d(t1, w2.float().view(MID, 3, 3, MID).permute(0, 3, 1, 2), padding=1) * v(s2) + v(b2)).to(h16).float()
+    rt = (F.conv2d(xf, wsc.float().view(K, C, 1, 1)) * v(ssc) + v(bsc)).to(h16).float() if shortcut else xf
+    t3 = F.relu(F.conv2d(t2, w3.float().view(K, MID, 1, 1)) * v(s3) + v(b3) + rt)
     assert relerr(y.float().permute(0, 3, 1, 2), t3) < (2e-2 if h16 == torch.bfloat16 else 3e-3)
-    assert torch.equal(y, hip.bottleneck_identity_fwd_bf16(x, w1, w2, w3, s1, b1, s2, b2, s3, b3))     # deterministic
+    assert torch.equal(y, hip.bottleneck_fwd_bf16(x, w1, w2, w3, s1, b1, s2, b2, s3, b3, **kw))     # deterministic

@@ -25,17 +25,24 @@ def timeit(fn, rep=20):
     return e0.elapsed_time(e1) / rep * 1e3
 
 
+wsc = (torch.randn(C, 64, generator=g) * 0.1).to(h16).cuda(); w1s = (torch.randn(MID, 64, generator=g) * 0.1).to(h16).cuda()
 for N in (12, 4):
-    x = (torch.randn(N, 200, 336, C, generator=g).clamp(min=0) * 0.7).to(h16).cuda()
-    y = torch.empty_like(x)
-    def fused():
-        hip.bottleneck_identity_fwd_bf16(x, w1, w2, w3, s1, b1, s2, b2, s3, b3, out=y)
-    def chain():
-        c1 = hip.conv2d_fwd_bf16(x, w1, scale=s1, bias=b1, relu=True)
-        c2 = hip.conv2d_fwd_bf16(c1, w2, scale=s2, bias=b2, relu=True, kh=3, kw=3, pad=1)
-        hip.conv2d_fwd_bf16(c2, w3, scale=s3, bias=b3, relu=True, residual=x, out=y)
-    tf, tc = timeit(fused), timeit(chain)
-    px = N * 200 * 336
-    fl = 2.0 * px * (C * MID + 9 * MID * MID + MID * C)
-    by = 2.0 * px * C * 2
-    print("N=%d  fused %.1f us (%.0f TF/s, %.2f TB/s on x + y)   three convs %.1f us   ratio %.2f" % (N, tf, fl / tf / 1e6, by / tf / 1e6, tc, tc / tf))
+    for shortcut in (False, True):
+        cin = 64 if shortcut else C
+        x = (torch.randn(N, 200, 336, cin, generator=g).clamp(min=0) * 0.7).to(h16).cuda()
+        y = torch.empty((N, 200, 336, C), dtype=h16, device="cuda")
+        wa = w1s if shortcut else w1
+        kw = dict(wsc=wsc, ssc=s3, bsc=b3) if shortcut else {}
+        def fused():
+            hip.bottleneck_fwd_bf16(x, wa, w2, w3, s1, b1, s2, b2, s3, b3, out=y, **kw)
+        def chain():
+            c1 = hip.conv2d_fwd_bf16(x, wa, scale=s1, bias=b1, relu=True)
+            c2 = hip.conv2d_fwd_bf16(c1, w2, scale=s2, bias=b2, relu=True, kh=3, kw=3, pad=1)
+            r = hip.conv2d_fwd_bf16(x, wsc, scale=s3, bias=b3) if shortcut else x
+            hip.conv2d_fwd_bf16(c2, w3, scale=s3, bias=b3, relu=True, residual=r, out=y)
+        tf, tc = timeit(fused), timeit(chain)
+        px = N * 200 * 336
+        fl = 2.0 * px * (cin * MID + 9 * MID * MID + MID * C + (cin * C if shortcut else 0))
+        by = 2.0 * px * (cin + C)
+        print("N=%d shortcut=%d  fused %.1f us (%.0f TF/s, %.2f TB/s on x + y)   conv chain %.1f us   ratio %.2f" % (
+            N, shortcut, tf, fl / tf / 1e6, by / tf / 1e6, tc, tc / tf))

@@ -69,7 +69,7 @@ def _parse_header(path):
 
 _SIGS = _parse_header(HEADER_PATH)
 _PLAIN = {"utv2_aug_resize_workspace_bytes", "utv2_topk_rows_workspace_bytes", "utv2_groupnorm_seg_workspace_floats", "utv2_groupnorm_seg_chunks", "utv2_conv2d_wgrad_bf16_splits", "utv2_conv2d_wgrad_bf16_workspace_floats", "utv2_conv2d_bf16_supported", "utv2_conv2d_wgrad_splits", "utv2_conv2d_wgrad_workspace_floats", "utv2_groupnorm_workspace_floats",
-          "utv2_nms_mpad", "utv2_nms_workspace_bytes", "utv2_bottleneck_identity_supported"}  # return a value, not a status
+          "utv2_nms_mpad", "utv2_nms_workspace_bytes", "utv2_bottleneck_supported"}  # return a value, not a status
 
 
 _libs = {}
@@ -995,22 +995,23 @@ def conv2d_fwd_bf16(x, w16, scale=None, bias=None, residual=None, stride=1, pad=
     return out
 
 
-def bottleneck_identity_fwd_bf16(x, w1, w2, w3, s1, b1, s2, b2, s3, b3, out=None):
-    """one frozen identity bottleneck (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + x, FrozenBN as scale / shift, ReLUs) in one launch
-    (utv2_bottleneck_identity_fwd_bf16): x [N, H, W, 256] 16-bit NHWC -> y of the same shape"""
+def bottleneck_fwd_bf16(x, w1, w2, w3, s1, b1, s2, b2, s3, b3, wsc=None, ssc=None, bsc=None, out=None):
+    """one frozen bottleneck (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + x, or + the 1x1 shortcut conv `wsc` of x; FrozenBN as scale /
+    shift; ReLUs) in one launch (utv2_bottleneck_fwd_bf16): x [N, H, W, C] 16-bit NHWC -> y [N, H, W, 256]"""
     N, H, W, C = x.shape
-    MID = w1.shape[0]
-    assert x.dtype == h16_dtype() and w1.dtype == w2.dtype == w3.dtype == h16_dtype()
-    assert tuple(w1.shape) == (MID, C) and tuple(w2.shape) == (MID, 9 * MID) and tuple(w3.shape) == (C, MID)
+    MID, K = w1.shape[0], w3.shape[0]
+    assert x.dtype == h16_dtype() and w1.dtype == w2.dtype == w3.dtype == h16_dtype() and K == 256
+    assert tuple(w1.shape) == (MID, C) and tuple(w2.shape) == (MID, 9 * MID) and tuple(w3.shape) == (K, MID)
+    assert wsc is None or (tuple(wsc.shape) == (K, C) and wsc.dtype == h16_dtype())
     if out is None:
-        out = torch.empty_like(x)
-    call("utv2_bottleneck_identity_fwd_bf16", _p(x), _p(out), _p(w1), _p(w2), _p(w3), _p(s1), _p(b1), _p(s2), _p(b2), _p(s3), _p(b3),
-         N, H, W, C, MID, _stream())
+        out = torch.empty((N, H, W, K), dtype=x.dtype, device=x.device)
+    call("utv2_bottleneck_fwd_bf16", _p(x), _p(out), _p(w1), _p(w2), _p(w3), _p(wsc), _p(s1), _p(b1), _p(s2), _p(b2), _p(s3), _p(b3),
+         _p(ssc), _p(bsc), N, H, W, C, MID, _stream())
     return out
 
 
-def bottleneck_identity_supported(C, MID):
-    return bool(load().utv2_bottleneck_identity_supported(C, MID))
+def bottleneck_supported(C, MID, has_shortcut):
+    return bool(load().utv2_bottleneck_supported(C, MID, int(has_shortcut)))
 
 
 def conv2d_dgrad_bf16(dy, wt16, in_shape, stride, pad, kh, kw, out=None, out_dtype=None, mask=None, residual=None, post_mask=None,

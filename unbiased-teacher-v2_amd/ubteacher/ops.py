@@ -788,16 +788,21 @@ def bottleneck(block, x):
              and block.conv1.stride in (1, 2) and block.conv1.k == 1 and block.conv3.k == 1)
     if fused:
         return _BottleneckFn.apply(x, hook(x.device), block)
-    if (block.shortcut is None and amp() and x.dtype == hip.h16_dtype() and x.is_contiguous() and _fused_frozen_block_on()
+    if (amp() and x.dtype == hip.h16_dtype() and x.is_contiguous() and _fused_frozen_block_on()
             and (not torch.is_grad_enabled() or not any(c.trainable for c in convs)) and not x.requires_grad
-            and block.conv1.stride == 1 and block.conv1.k == 1 and block.conv2.k == 3 and block.conv3.k == 1
+            and all(c.stride == 1 for c in convs) and block.conv1.k == 1 and block.conv2.k == 3 and block.conv3.k == 1
+            and (block.shortcut is None or block.shortcut.k == 1) and block.conv3.cout == 256
             and all(c.bn is not None and c.bias is None and c.use_bf16() for c in convs)
-            and hip.bottleneck_identity_supported(block.conv1.cin, block.conv1.cout)):
-        # a frozen identity block (res2 blocks 1-2 under FREEZE_AT 2): nothing is kept for a backward, so the three convs run as one
+            and hip.bottleneck_supported(block.conv1.cin, block.conv1.cout, block.shortcut is not None)):
+        # a frozen stride-1 block (res2 under FREEZE_AT 2; the teacher's too): nothing is kept for a backward, so its convs run as one
         # kernel with the 64-channel intermediates in LDS (csrc/bottleneck.hip)
         st = block.conv1.w.store
         (s1, b1), (s2, b2), (s3, b3) = block.conv1.scale_shift(), block.conv2.scale_shift(), block.conv3.scale_shift()
-        return hip.bottleneck_identity_fwd_bf16(x, st.bf16(block.conv1.w), st.bf16(block.conv2.w), st.bf16(block.conv3.w), s1, b1, s2, b2, s3, b3)
+        kw = {}
+        if block.shortcut is not None:
+            ssc, bsc = block.shortcut.scale_shift()
+            kw = dict(wsc=st.bf16(block.shortcut.w), ssc=ssc, bsc=bsc)
+        return hip.bottleneck_fwd_bf16(x, st.bf16(block.conv1.w), st.bf16(block.conv2.w), st.bf16(block.conv3.w), s1, b1, s2, b2, s3, b3, **kw)
     sc = block.shortcut(x) if block.shortcut is not None else x
     out = block.conv1(x)
     out = block.conv2(out)
