@@ -36,7 +36,7 @@ def arg_names():
 
 
 NAMES = arg_names()
-CONV = [n for n in NAMES if n.startswith("utv2_conv2d") and not n.endswith(("_splits", "_workspace_floats", "_supported"))]
+CONV = [n for n in NAMES if (n.startswith("utv2_conv2d") or n == "utv2_bottleneck_fwd_bf16") and not n.endswith(("_splits", "_workspace_floats", "_supported"))]
 
 
 def val(a):
@@ -53,6 +53,11 @@ def describe(name, args, levels_hw):
     """(kind, shape key, flop, bytes) of one launch"""
     A = dict(zip(NAMES[name], [val(a) for a in args]))
     eb = lambda k: 2 if A.get(k, 0) == 1 else 4          # *_dtype: 1 = the 16-bit type
+    if name == "utv2_bottleneck_fwd_bf16":               # a whole frozen bottleneck: conv1 + conv2 + conv3 (+ shortcut); bytes = x + y
+        N, H, W, C, MID = (A[k] for k in ("N", "H", "W", "C", "MID"))
+        sc = bool(A.get("wsc"))
+        fl = 2.0 * N * H * W * (C * MID + 9 * MID * MID + MID * 256 + (C * 256 if sc else 0))
+        return "block" + ("+sc" if sc else ""), (N * H * W, C, 256, 3, 1, 1), fl, 2.0 * N * H * W * (C + 256)
     if "wgrad" in name:
         if "M" in A:                                       # 16-bit wgrad over M output pixels
             M, C, K, KH, KW = A["M"], A["C"], A["K"], A["KH"], A["KW"]
@@ -165,7 +170,7 @@ def main():
     for key in recs:
         name, args = first[key]
         kind, shape, fl, by = describe(name, args, levels_hw)
-        entry = name.replace("utv2_conv2d_", "")
+        entry = name.replace("utv2_conv2d_", "").replace("utv2_", "")
         a = agg.setdefault((kind, entry) + shape, [0, 0.0, fl, by])
         a[0] += 1
         a[1] += iso[key]

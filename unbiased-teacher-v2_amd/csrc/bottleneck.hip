@@ -329,50 +329,78 @@ __global__ __launch_bounds__(256, 3) void bottleneck_fused(BtArgs a) {
         }
       }
     }
-    // value = acc * s + b (+ the shortcut, rounded to 16 bits as the unfused chain stores it) in the accumulator layout -> fp32 patch,
-    // 16 pixels per round -> full 128-byte row pieces
+    if constexpr (SC) {
+      // value = conv3 * s3 + b3 + h16(shortcut * ssc + bsc) in the accumulator layout -> fp32 patch, 16 pixels per round -> ReLU, round,
+      // full 128-byte row pieces of y (the second set of accumulators leaves no registers for the coalesced-layout form below)
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      if ((l31 >> 4) == hh) {
-        const int prow = l31 & 15;
+      for (int hh = 0; hh < 2; ++hh) {
+        if ((l31 >> 4) == hh) {
+          const int prow = l31 & 15;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+          for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int cl = u * 32 + 8 * q + 4 * fh, ch = g * 64 + cl;
-            const f32x4 sc = *(const f32x4*)(prm + 256 + ch), bi = *(const f32x4*)(prm + 512 + ch);
-            f32x4 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc3[u][4 * q + j] * sc[j] + bi[j];
-            if constexpr (SC) {
+            for (int q = 0; q < 4; ++q) {
+              const int cl = u * 32 + 8 * q + 4 * fh, ch = g * 64 + cl;
+              const f32x4 sc = *(const f32x4*)(prm + 256 + ch), bi = *(const f32x4*)(prm + 512 + ch);
               const f32x4 s2c = *(const f32x4*)(prm + 768 + ch), b2c = *(const f32x4*)(prm + 1024 + ch);
+              f32x4 v;
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] += (float)(h16_t)(accs[u][4 * q + j] * s2c[j] + b2c[j]);
+              for (int j = 0; j < 4; ++j) v[j] = acc3[u][4 * q + j] * sc[j] + bi[j] + (float)(h16_t)(accs[u][4 * q + j] * s2c[j] + b2c[j]);
+              *(f32x4*)(patch + prow * 64 + (((cl >> 2) ^ prow) << 2)) = v;
             }
-            *(f32x4*)(patch + prow * 64 + (((cl >> 2) ^ prow) << 2)) = v;
-          }
-      }
-      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed (wave-private patch)
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2) {
-        const int i = hh * 2 + i2, prow = 8 * i2 + sub;
-        const f32x4 v0 = *(const f32x4*)(patch + prow * 64 + (((2 * cv) ^ prow) << 2)), v1 = *(const f32x4*)(patch + prow * 64 + (((2 * cv + 1) ^ prow) << 2));
-        bf16x8_t o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float r0 = 0.f, r1 = 0.f;
-          if constexpr (!SC) {
-            r0 = (float)res[g & 1][i][j];
-            r1 = (float)res[g & 1][i][4 + j];
-          }
-          o[j] = (h16_t)fmaxf(v0[j] + r0, 0.f);
-          o[4 + j] = (h16_t)fmaxf(v1[j] + r1, 0.f);
         }
-        if (opix[i] >= 0 && !(a.dbg & 1)) *(bf16x8_t*)(yout + opix[i] + g * 64) = o;
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed (wave-private patch)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+          const int i = hh * 2 + i2, prow = 8 * i2 + sub;
+          const f32x4 v0 = *(const f32x4*)(patch + prow * 64 + (((2 * cv) ^ prow) << 2)), v1 = *(const f32x4*)(patch + prow * 64 + (((2 * cv + 1) ^ prow) << 2));
+          bf16x8_t o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] = (h16_t)fmaxf(v0[j], 0.f);
+            o[4 + j] = (h16_t)fmaxf(v1[j], 0.f);
+          }
+          if (opix[i] >= 0 && !(a.dbg & 1)) *(bf16x8_t*)(yout + opix[i] + g * 64) = o;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();      // the patch is rewritten by the next round
       }
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();      // the patch is rewritten by the next round
+    } else {
+      // The raw accumulators bounce through the fp32 patch, 16 pixels per round; scale / shift, the residual, ReLU and the rounding run
+      // in the coalesced layout: lane -> 8 consecutive channels of one pixel, full 128-byte row pieces of x / y.
+      const f32x4 s3a = *(const f32x4*)(prm + 256 + g * 64 + cv * 8), s3b = *(const f32x4*)(prm + 256 + g * 64 + cv * 8 + 4);
+      const f32x4 b3a = *(const f32x4*)(prm + 512 + g * 64 + cv * 8), b3b = *(const f32x4*)(prm + 512 + g * 64 + cv * 8 + 4);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        if ((l31 >> 4) == hh) {
+          const int prow = l31 & 15;
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int cl = u * 32 + 8 * q + 4 * fh;
+              const f32x4 v = {acc3[u][4 * q], acc3[u][4 * q + 1], acc3[u][4 * q + 2], acc3[u][4 * q + 3]};
+              *(f32x4*)(patch + prow * 64 + (((cl >> 2) ^ prow) << 2)) = v;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed (wave-private patch)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+          const int i = hh * 2 + i2, prow = 8 * i2 + sub;
+          const f32x4 v0 = *(const f32x4*)(patch + prow * 64 + (((2 * cv) ^ prow) << 2)), v1 = *(const f32x4*)(patch + prow * 64 + (((2 * cv + 1) ^ prow) << 2));
+          bf16x8_t o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] = (h16_t)fmaxf(v0[j] * s3a[j] + b3a[j] + (float)res[g & 1][i][j], 0.f);
+            o[4 + j] = (h16_t)fmaxf(v1[j] * s3b[j] + b3b[j] + (float)res[g & 1][i][4 + j], 0.f);
+          }
+          if (opix[i] >= 0 && !(a.dbg & 1)) *(bf16x8_t*)(yout + opix[i] + g * 64) = o;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();      // the patch is rewritten by the next round
+      }
     }
   }
 }
