@@ -440,6 +440,13 @@ int utv2_rcnn_loss_combine(const float* rpn_sup, const float* rpn_uns, const flo
                            float rpn_norm_uns, float w_rpn_cls, float w_rpn_loc, float w_box, const float* wt_host, float* rec, float* coef,
                            utv2_stream_t stream);
 
+/* ---- the frozen ResNet stem as ONE kernel (csrc/stem_pool.hip): D2 BasicStem conv1 (7x7 stride 2 pad 3, 3 -> 64, FrozenBN as scale /
+ * shift, ReLU) + max_pool2d(3, 2, 1), the first two layers of the R-50 the reference builds (backbone/fpn.py:21-22).  xpad16 / w16s as
+ * for utv2_conv2d_stem_fwd_bf16 (W even); y: 16-bit [N][PH][PW][64], OH = (H - 1) / 2 + 1, PH = (OH - 1) / 2 + 1 (same for W).  The conv
+ * output never leaves LDS. */
+int utv2_stem_pool_fwd_bf16(const void* xpad16, const void* w16s, void* y, const float* scale, const float* shift, int N, int H, int W,
+                            int K, utv2_stream_t stream);
+
 /* ---- one frozen ResNet bottleneck as ONE kernel (csrc/bottleneck.hip): D2 BottleneckBlock conv1 1x1 -> conv2 3x3 -> conv3 1x1 + identity
  * (or + the 1x1 shortcut conv of a stage's first block), FrozenBN folded to scale / shift, of the R-50 the reference builds through
  * build_fcos_resnet_fpn_backbone (ubteacher/modeling/backbone/fpn.py:21-22; res2 under MODEL.BACKBONE.FREEZE_AT 2).

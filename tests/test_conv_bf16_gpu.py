@@ -699,3 +699,41 @@ def test_fused_frozen_bottleneck_equals_the_conv_chain(shape, shortcut):
     t3 = F.relu(F.conv2d(t2, w3.float().view(K, MID, 1, 1)) * v(s3) + v(b3) + rt)
     assert relerr(y.float().permute(0, 3, 1, 2), t3) < (2e-2 if h16 == torch.bfloat16 else 3e-3)
     assert torch.equal(y, hip.bottleneck_fwd_bf16(x, w1, w2, w3, s1, b1, s2, b2, s3, b3, **kw))     # deterministic
+
+
+@pytest.mark.parametrize("hw", [(64, 96), (70, 66), (800, 1344), (33, 18)])
+def test_fused_stem_pool_equals_stem_conv_then_maxpool(hw):
+    """csrc/stem_pool.hip (round 4): the frozen BasicStem conv (7x7 s2 p3 + FrozenBN + ReLU) and max_pool2d(3, 2, 1) as one kernel with
+    the conv output in LDS - against the two launches it replaces (same 16-bit rounding of the conv output, fp32 sums in another k
+    order; the max is exact) and against torch on the same rounded operands.  Odd conv / pooled extents, tiles cut by the image edge,
+    the benchmark size."""
+    from ubteacher import hip
+    H, W = hw
+    N = 2 if H < 400 else 1
+    h16 = hip.h16_dtype()
+    g = torch.Generator().manual_seed(3)
+    imgs = [(torch.rand(3, H, W, generator=g) * 255).cuda() for _ in range(N)]
+    mean, std = [103.53, 116.28, 123.675], [57.0, 57.0, 58.0]
+    x4, sizes = hip.preprocess_images(imgs, mean, std, 2, bf16_stem=True)
+    assert x4.dtype == h16 and x4.canvas == (H + H % 2, W + W % 2)
+    w208 = torch.zeros(64, 208)
+    w208[:, :196] = torch.randn(64, 196, generator=g) * 0.05
+    w16s = hip.stem_weight_image(w208.cuda())
+    sc = (torch.rand(64, generator=g) + 0.5).cuda()
+    sh = (torch.randn(64, generator=g) * 0.3).cuda()
+    y = hip.stem_pool_fwd_bf16(x4, w16s, sc, sh)
+    c = hip.conv2d_stem_fwd_bf16(x4, w16s, sc, sh, True, h16)
+    ref = hip.maxpool3x3s2(c)
+    assert y.shape == ref.shape and y.dtype == h16
+    d = (y.float() - ref.float()).abs()
+    ulp = 2 ** -7 if h16 == torch.bfloat16 else 2 ** -10
+    assert float(d.max()) <= 2 * ulp * float(ref.float().abs().max()), float(d.max())      # a conv value one ulp off may win a window
+    assert float((d > 0).float().mean()) < 0.02
+    # torch on the same rounded operands
+    Hc, Wc = x4.canvas
+    xi = x4[:, 3:3 + Hc, 3:3 + Wc, :3].float().permute(0, 3, 1, 2)
+    wt = w16s.float().view(64, 7, 8, 4)[:, :, :7, :3].permute(0, 3, 1, 2)
+    t = F.relu(F.conv2d(xi, wt, stride=2, padding=3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).to(h16).float()
+    t = F.max_pool2d(t, 3, 2, 1)
+    assert relerr(y.float().permute(0, 3, 1, 2), t) < (2e-2 if h16 == torch.bfloat16 else 3e-3)
+    assert torch.equal(y, hip.stem_pool_fwd_bf16(x4, w16s, sc, sh))

@@ -394,6 +394,18 @@ def conv2d_stem_fwd_bf16(xpad16, w16s, scale, bias, relu, out_dtype):
     return out
 
 
+def stem_pool_fwd_bf16(xpad16, w16s, scale, shift):
+    """frozen BasicStem conv + FrozenBN + ReLU + max_pool2d(3, 2, 1) in one launch (utv2_stem_pool_fwd_bf16); inputs as conv2d_stem_fwd_bf16"""
+    N = xpad16.shape[0]
+    H, W = xpad16.canvas
+    K = w16s.shape[0]
+    OH, OW = conv_out_size(H, 7, 2, 3), conv_out_size(W, 7, 2, 3)
+    PH, PW = (OH + 2 - 3) // 2 + 1, (OW + 2 - 3) // 2 + 1
+    out = torch.empty((N, PH, PW, K), dtype=h16_dtype(), device=xpad16.device)
+    call("utv2_stem_pool_fwd_bf16", _p(xpad16), _p(w16s), _p(out), _p(scale), _p(shift), N, H, W, K, _stream())
+    return out
+
+
 def stem_weight_image(w208):
     """fp32 [K, 208] (7x7x4 taps, 16-padded rows) -> bf16 [K, 7*32]: per kernel row 7 taps x 4 channels + 4 zeros"""
     K = w208.shape[0]

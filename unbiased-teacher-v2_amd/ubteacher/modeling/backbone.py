@@ -10,6 +10,7 @@ MI355X mapping: every conv is one implicit-GEMM launch with FrozenBN/ReLU/residu
 the epilogue; stem+res2 (frozen) run outside autograd; the image batch enters as NHWC4.
 """
 import math
+import os
 
 import torch
 
@@ -155,10 +156,12 @@ class ResNet50:
             if getattr(self, "_w16s_version", None) != v:
                 self._w16s = hip.stem_weight_image(self.stem_w.t)
                 self._w16s_version = v
-            x = hip.conv2d_stem_fwd_bf16(x4, self._w16s, sc, sh, True, hip.h16_dtype())
+            if os.environ.get("UTV2_FUSED_STEM_POOL", "1") != "0" and self._w16s.shape[0] == 64:
+                x = hip.stem_pool_fwd_bf16(x4, self._w16s, sc, sh)      # conv + FrozenBN + ReLU + max pool, the conv output stays in LDS
+            else:
+                x = hip.maxpool3x3s2(hip.conv2d_stem_fwd_bf16(x4, self._w16s, sc, sh, True, hip.h16_dtype()))
         else:
-            x = hip.conv2d_stem_fwd(x4, self.stem_w.t, sc, sh, 2, 3, 7, 7, True, ops.act_dtype())
-        x = hip.maxpool3x3s2(x)
+            x = hip.maxpool3x3s2(hip.conv2d_stem_fwd(x4, self.stem_w.t, sc, sh, 2, 3, 7, 7, True, ops.act_dtype()))
         for name, blocks, trainable in self.stages:
             if trainable:
                 for b in blocks:
