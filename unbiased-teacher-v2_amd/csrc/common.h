@@ -107,7 +107,10 @@ struct EpiBits {
 // One operand combination of epilogue_rows' 16-bit path, fixed at compile time (see the LEAN dispatch there).  Order of operations as in
 // the general path: value = acc * scale + bias; mask plane; + residual; post-mask plane; ReLU (lo = 0) or nothing (lo = -inf: non-finite values propagate as in the general path); round; store;
 // ReLU bit plane; GroupNorm partial sums.
-template <int TN, bool RES, bool MB, bool PB>
+// TR: the accumulators are TRANSPOSED blocks (the kernel issued its MFMAs with the operands swapped: row = channel (e&3) + 8 (e>>2) +
+// 4 (lane>>5), col = pixel lane&31): a lane's 4 consecutive values are 4 consecutive channels of one pixel and reach the patch with 4
+// 16-byte LDS writes per block instead of 16 4-byte ones
+template <int TN, bool RES, bool MB, bool PB, bool TR = false>
 __device__ __forceinline__ void epilogue_rows_lean(const f32x16 (&acc)[2][TN], float* lds, int lane, h16_t* __restrict__ y,
                                                    const f32x4 (&sc)[2], const f32x4 (&bi)[2], const h16_t* __restrict__ residual, float lo,
                                                    int m_base, int co, int M, int K, int LDY, float* __restrict__ gn_part, EpiBits eb) {
@@ -127,9 +130,16 @@ __device__ __forceinline__ void epilogue_rows_lean(const f32x16 (&acc)[2][TN], f
       }
     }
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j) {
+      if constexpr (TR) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) lds[((e & 3) + 8 * (e >> 2) + 4 * fh) * LD + j * 32 + frow] = acc[i][j][e];
+        for (int q = 0; q < 4; ++q)
+          *(f32x4*)(lds + frow * LD + j * 32 + 8 * q + 4 * fh) = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) lds[((e & 3) + 8 * (e >> 2) + 4 * fh) * LD + j * 32 + frow] = acc[i][j][e];
+      }
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed (wave-private patch)
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -198,7 +208,7 @@ __device__ __forceinline__ void epilogue_rows_lean(const f32x16 (&acc)[2][TN], f
 
 // LEAN_OPS: also instantiate the lean forms with operands (kernels with register headroom; the 128-VGPR kernels keep the plain form only:
 // the extra variants cost them ~75 spills)
-template <int TN, typename TO = float, bool LEAN_OPS = true>
+template <int TN, typename TO = float, bool LEAN_OPS = true, bool TR = false>
 __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float* lds, int lane, TO* __restrict__ y,
                                               const float* __restrict__ scale, const float* __restrict__ bias,
                                               const TO* __restrict__ residual, int relu, int accumulate, int m_base,
@@ -247,7 +257,7 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
       const float lo = relu ? 0.f : -__builtin_inff();
       const int mode = (residual ? 1 : 0) | (eb.mask_bits ? 2 : 0) | (eb.post_bits ? 4 : 0);
 #define UTV2_LEAN(R, MB, PB)                                                                                                          \
-  epilogue_rows_lean<TN, R, MB, PB>(acc, lds, lane, (h16_t*)y, sc, bi, (const h16_t*)residual, lo, m_base, co, M, K, LDY, gn_part, eb)
+  epilogue_rows_lean<TN, R, MB, PB, TR>(acc, lds, lane, (h16_t*)y, sc, bi, (const h16_t*)residual, lo, m_base, co, M, K, LDY, gn_part, eb)
       if (mode == 0) { UTV2_LEAN(false, false, false); return; }
       if constexpr (LEAN_OPS) {
         if (mode == 1) { UTV2_LEAN(true, false, false); return; }
@@ -277,9 +287,16 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
   for (int i = 0; i < 2; ++i) {
     float gs = 0.f, gq = 0.f;   // this lane's share of the block's group statistics (gn_part)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j) {
+      if constexpr (TR) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) lds[((e & 3) + 8 * (e >> 2) + 4 * fh) * LD + j * 32 + frow] = acc[i][j][e];
+        for (int q = 0; q < 4; ++q)
+          *(f32x4*)(lds + frow * LD + j * 32 + 8 * q + 4 * fh) = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) lds[((e & 3) + 8 * (e >> 2) + 4 * fh) * LD + j * 32 + frow] = acc[i][j][e];
+      }
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed (wave-private patch)
     __builtin_amdgcn_wave_barrier();
 #pragma unroll

@@ -1026,7 +1026,8 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = mfma_32x32x16(__builtin_bit_cast(bf16x8_t, fa[ks][i]), __builtin_bit_cast(bf16x8_t, fb[ks][j]),
+          // operands swapped: acc[i][j] is the TRANSPOSED block (rows = channels, columns = pixels), see epilogue_rows<.., TR>
+          acc[i][j] = mfma_32x32x16(__builtin_bit_cast(bf16x8_t, fb[ks][j]), __builtin_bit_cast(bf16x8_t, fa[ks][i]),
                                                               acc[i][j]);
           const int n = (ks * TM + i) * TN + j;
           if ((n & 3) == 2) {
@@ -1157,9 +1158,9 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
 
   float* patch = (float*)smem + wid * (32 * (TN * 32 + 4));
   // two explicit calls (a loop the optimizer declines to unroll would index the accumulator registers dynamically: scratch)
-  epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[0], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
+  epilogue_rows<TN, TO, true, true>(*(const f32x16(*)[2][TN]) & acc[0], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
                         p.relu, p.accumulate, m0 + wm * 128, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
-  epilogue_rows<TN, TO>(*(const f32x16(*)[2][TN]) & acc[2], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
+  epilogue_rows<TN, TO, true, true>(*(const f32x16(*)[2][TN]) & acc[2], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
                         p.relu, p.accumulate, m0 + wm * 128 + 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
 #ifdef UTV2_PP_TRACE
   if ((blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && tid == 0) {
