@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256, TALL ? 3 : ((BK == 32 && BN != 96) ? 4 : 2)) v
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x16(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x16(b[j], a[i], acc[i][j]);   // operands swapped: TRANSPOSED blocks (epilogue_rows<.., TR>)
 #pragma unroll
       for (int q = s * NP / KS; q < (s + 1) * NP / KS; ++q) {
         if constexpr (STORE) store_piece(buf ^ 1, q);
@@ -596,13 +596,13 @@ __global__ __launch_bounds__(256, TALL ? 3 : ((BK == 32 && BN != 96) ? 4 : 2)) v
       f32x16 lo[2][2], hi[2][1];
 #pragma unroll
       for (int i = 0; i < 2; ++i) { lo[i][0] = acc[i][0]; lo[i][1] = acc[i][1]; hi[i][0] = acc[i][2]; }
-      epilogue_rows<2, TO, true>(lo, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate, m0 + wm * 64, n0,
+      epilogue_rows<2, TO, true, true>(lo, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate, m0 + wm * 64, n0,
                                  p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, nullptr, p.bits);
       if (n0 + 64 < p.K)
-        epilogue_rows<1, TO, true>(hi, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate, m0 + wm * 64,
+        epilogue_rows<1, TO, true, true>(hi, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate, m0 + wm * 64,
                                    n0 + 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, nullptr, p.bits);
     } else {
-      epilogue_rows<TN, TO, (BK != 32)>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
+      epilogue_rows<TN, TO, (BK != 32), true>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
                             m0 + wm * 64, n0 + wn * WCOLS, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
     }
     return;
@@ -610,17 +610,18 @@ __global__ __launch_bounds__(256, TALL ? 3 : ((BK == 32 && BN != 96) ? 4 : 2)) v
   TO* yo = (TO*)p.y;
   const TO* res = (const TO*)p.residual;
   const TO* msk = (const TO*)p.mask;
+  // (transposed blocks: value e of a lane = channel (e & 3) + 8 (e >> 2) + 4 fh of pixel frow)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int co = n0 + wn * WCOLS + j * 32 + frow;
-    if (co >= p.K) continue;
-    const float sc = p.scale ? p.scale[co] : 1.f;
-    const float bi = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const int co = n0 + wn * WCOLS + j * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (co >= p.K) continue;
+        const float sc = p.scale ? p.scale[co] : 1.f;
+        const float bi = p.bias ? p.bias[co] : 0.f;
+        const int m = m0 + wm * 64 + i * 32 + frow;
         if (m >= p.M) continue;
         const size_t off = (size_t)m * p.ldy + co;
         float v = acc[i][j][e] * sc + bi;
