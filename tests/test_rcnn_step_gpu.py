@@ -32,11 +32,13 @@ def test_rcnn_full_semisup_step_parity(predictor):
     cfg = rcnn_cfg()
     cfg.MODEL.ROI_HEADS.LOSS = predictor
     utv1 = predictor == "FocalLoss"
+    nb = 1 if utv1 else 2                  # images per group: the UTv1 variant runs 1 + 1 (half the oracle's CPU time; same code paths)
+    cfg.SOLVER.IMG_PER_BATCH_LABEL = cfg.SOLVER.IMG_PER_BATCH_UNLABEL = nb
     if utv1:
         cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE = "smooth_l1"       # the UTv2 YAML's "nlloss" is a ValueError there (fast_rcnn.py:184-186)
         cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = False          # Detectron2's default: 4 deltas per class
     torch.manual_seed(0)
-    prod, orac = make_batch(31, 2, 2, H, W, "cuda")
+    prod, orac = make_batch(31, nb, nb, H, W, "cuda")
     tr = UBRCNNTeacherTrainer(cfg, data_loader=FixedLoader(prod))
     mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1)
     pstd = torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1)
@@ -85,8 +87,8 @@ def test_rcnn_full_semisup_step_parity(predictor):
     with torch.no_grad():
         pseudo, _ = O.rcnn_teacher(t_sd, [d["image"] for d in orac[3]], mean, pstd, thr=cfg.SEMISUPNET.BBOX_THRESHOLD)
         _, props_sup, _ = O.rcnn_student_losses(sd_s, [d["image"] for d in orac[0] + orac[1]], [d["gt"] for d in orac[0] + orac[1]],
-                                                rpn_keys[0], [torch.zeros(2000)] * 4, False, mean, pstd)
-        _, props_uns, _ = O.rcnn_student_losses(sd_s, [d["image"] for d in orac[2]], pseudo, rpn_keys[1], [torch.zeros(2000)] * 2,
+                                                rpn_keys[0], [torch.zeros(2000)] * (2 * nb), False, mean, pstd)
+        _, props_uns, _ = O.rcnn_student_losses(sd_s, [d["image"] for d in orac[2]], pseudo, rpn_keys[1], [torch.zeros(2000)] * nb,
                                                 True, mean, pstd)
     assert sum(len(p["boxes"]) for p in pseudo) > 0, "test setup: teacher produced no pseudo boxes"
     gl = tr._last_pseudo
