@@ -27,7 +27,6 @@
 // so the 32-row fragment reads are conflict-free.  blockIdx -> tile is XCD-aware (contiguous tile ranges per XCD: neighbouring tiles
 // share their halo through that XCD's L2).
 #include "common.h"
-#include <stdlib.h>
 
 #define BT_TH 8
 #define BT_TW 16
@@ -47,7 +46,6 @@ struct BtArgs {
   const h16_t *w1, *w2, *w3, *wsc;               // [64][CIN], [64][3*3*64] (tap-major, channel-minor), [256][64], shortcut [256][CIN] or null
   const float *s1, *b1, *s2, *b2, *s3, *b3, *ssc, *bsc;   // folded FrozenBN scale / shift per output channel
   int N, H, W, tiles_x, tiles_y, ntiles;
-  int dbg;   // timing experiments only (UTV2_BT_DEBUG): 1 no y stores, 2 no residual loads, 4 no conv2 loop, 8 no x loads, 16 no conv3
 };
 
 __device__ __forceinline__ bf16x8_t lds_frag(const unsigned char* smem, int off) { return *(const bf16x8_t*)(smem + off); }
@@ -89,7 +87,7 @@ __global__ __launch_bounds__(256, 3) void bottleneck_fused(BtArgs a) {
     const int q = tid + 256 * i, px = q >> 2, slot = q & 3;
     const int hy = px / BT_HW, hx = px - hy * BT_HW, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
     const bool ok = px < BT_HALO && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    xsrc[i] = (ok && !(a.dbg & 8)) ? ximg + ((size_t)gy * a.W + gx) * CIN + slot * 8 : nullptr;
+    xsrc[i] = ok ? ximg + ((size_t)gy * a.W + gx) * CIN + slot * 8 : nullptr;
     xdst[i] = px * 64 + ((slot ^ ((px >> 2) & 3)) << 4);
   }
   const int wco = tid >> 2, wslot = tid & 3;
@@ -207,7 +205,6 @@ __global__ __launch_bounds__(256, 3) void bottleneck_fused(BtArgs a) {
   bf16x8_t wq[2], sq[2];
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
-    if (a.dbg & 4) break;
     unsigned char* cur = stageA + (tap & 1) * 8192;
     unsigned char* nxt = stageA + ((tap + 1) & 1) * 8192;
     if (tap + 3 < 9) {
@@ -252,13 +249,13 @@ __global__ __launch_bounds__(256, 3) void bottleneck_fused(BtArgs a) {
   bf16x8_t xf3[4];               // shortcut: this lane's own pixel of x as conv fragments (K = 64)
   if constexpr (!SC) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) res[0][i] = (opix[i] >= 0 && !(a.dbg & 2)) ? *(const bf16x8_t*)(ximg + opix[i]) : zero8;
+    for (int i = 0; i < 4; ++i) res[0][i] = opix[i] >= 0 ? *(const bf16x8_t*)(ximg + opix[i]) : zero8;
   } else {
     const int gy = y0 + pr, gx = x0 + pc;
     const bool in = gy < a.H && gx < a.W;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-      xf3[ks] = (in && !(a.dbg & 2)) ? *(const bf16x8_t*)(ximg + ((size_t)gy * a.W + gx) * CIN + ks * 16 + fh * 8) : zero8;
+      xf3[ks] = in ? *(const bf16x8_t*)(ximg + ((size_t)gy * a.W + gx) * CIN + ks * 16 + fh * 8) : zero8;
   }
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)
@@ -286,7 +283,6 @@ __global__ __launch_bounds__(256, 3) void bottleneck_fused(BtArgs a) {
   float* patch = (float*)smem + wave * (16 * 64);   // wave-private fp32 [16 px][64 ch], 16-byte quads XOR-swizzled by the row
 #pragma unroll
   for (int g = 0; g < 4; ++g) {  // channel group g: output channels 64 g .. 64 g + 63
-    if (a.dbg & 16) break;
     if (g > 0) {                 // the next quarter of the weights
       __syncthreads();
 #pragma unroll
@@ -305,7 +301,7 @@ __global__ __launch_bounds__(256, 3) void bottleneck_fused(BtArgs a) {
       if constexpr (!SC) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          res[(g + 1) & 1][i] = (opix[i] >= 0 && !(a.dbg & 2)) ? *(const bf16x8_t*)(ximg + opix[i] + (g + 1) * 64) : zero8;
+          res[(g + 1) & 1][i] = opix[i] >= 0 ? *(const bf16x8_t*)(ximg + opix[i] + (g + 1) * 64) : zero8;
       }
     }
     f32x16 acc3[2], accs[2];
@@ -361,7 +357,7 @@ __global__ __launch_bounds__(256, 3) void bottleneck_fused(BtArgs a) {
             o[j] = (h16_t)fmaxf(v0[j], 0.f);
             o[4 + j] = (h16_t)fmaxf(v1[j], 0.f);
           }
-          if (opix[i] >= 0 && !(a.dbg & 1)) *(bf16x8_t*)(yout + opix[i] + g * 64) = o;
+          if (opix[i] >= 0) *(bf16x8_t*)(yout + opix[i] + g * 64) = o;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();      // the patch is rewritten by the next round
@@ -396,7 +392,7 @@ __global__ __launch_bounds__(256, 3) void bottleneck_fused(BtArgs a) {
             o[j] = (h16_t)fmaxf(v0[j] * s3a[j] + b3a[j] + (float)res[g & 1][i][j], 0.f);
             o[4 + j] = (h16_t)fmaxf(v1[j] * s3b[j] + b3b[j] + (float)res[g & 1][i][4 + j], 0.f);
           }
-          if (opix[i] >= 0 && !(a.dbg & 1)) *(bf16x8_t*)(yout + opix[i] + g * 64) = o;
+          if (opix[i] >= 0) *(bf16x8_t*)(yout + opix[i] + g * 64) = o;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();      // the patch is rewritten by the next round
@@ -426,7 +422,6 @@ int utv2_bottleneck_fwd_bf16(const void* x, void* y, const void* w1, const void*
   const long long nt = (long long)N * a.tiles_x * a.tiles_y;
   if (nt > 0x7fffffff) return UTV2_EARG;
   a.ntiles = (int)nt;
-  { const char* e = getenv("UTV2_BT_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   if (wsc) hipLaunchKernelGGL((bottleneck_fused<64, true>), dim3((unsigned)a.ntiles), dim3(256), BT_LDS, stream, a);
   else hipLaunchKernelGGL((bottleneck_fused<256, false>), dim3((unsigned)a.ntiles), dim3(256), BT_LDS, stream, a);
   return utv2_launch_status();
