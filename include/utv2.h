@@ -151,6 +151,13 @@ int utv2_amp_found_inf(const float* grad, int64_t n, float* state, utv2_stream_t
 int utv2_sgd_momentum_amp(float* param, const float* grad, float* mom_buf, int64_t n, float lr, float momentum, float weight_decay,
                           float grad_scale, const float* state, utv2_stream_t stream);
 int utv2_amp_update_scale(float* state, float growth_factor, float backoff_factor, int growth_interval, utv2_stream_t stream);
+/* the three updates above that ALSO write the 16-bit mirror of the arena range they update (mirror16[i] = the library's 16-bit rounding of
+ * the new value; the copy the mixed-precision convs read): the weights are not re-read by a conversion pass before the next forward */
+int utv2_ema_axpby_m16(float* teacher, const float* student, void* mirror16, int64_t n, double keep_rate, utv2_stream_t stream);
+int utv2_sgd_momentum_m16(float* param, float* grad, float* mom_buf, void* mirror16, int64_t n, float lr, float momentum, float weight_decay,
+                          float grad_scale, int zero_grad, utv2_stream_t stream);
+int utv2_sgd_momentum_amp_m16(float* param, const float* grad, float* mom_buf, void* mirror16, int64_t n, float lr, float momentum,
+                              float weight_decay, float grad_scale, const float* state, utv2_stream_t stream);
 
 /* ---- elementwise pieces of ResNet / FPN ([D2-recall]) ------------------ */
 int utv2_relu_bwd_scale(const void* dy, const void* y, const float* scale, void* out, int64_t M, int C, int dtype,

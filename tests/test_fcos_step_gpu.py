@@ -762,3 +762,37 @@ def test_step_as_hipgraph_replays_the_eager_step(kind):
     assert torch.isfinite(sa).all() and torch.isfinite(sb).all() and torch.isfinite(tb).all()
     if kind == "fcos":
         assert float((sa - sb).abs().max()) <= 1e-4 * float(sa.abs().max()) and float((ta - tb).abs().max()) <= 1e-4 * float(ta.abs().max())
+
+
+@pytest.mark.parametrize("kind", ["bf16", "fp16"])
+def test_sgd_and_ema_keep_the_16bit_weight_mirror_fresh(kind, monkeypatch):
+    """The SGD step and the teacher EMA write the 16-bit copy of the weights the mixed-precision convs read themselves
+    (utv2_sgd_momentum*_m16, utv2_ema_axpby_m16) instead of a conversion pass re-reading the arena before the next forward: after some AMP
+    steps both mirrors are marked fresh AND equal the rounding of the fp32 arenas bit for bit - what utv2_f32_to_bf16 would have produced."""
+    from ubteacher import hip, ops
+    from ubteacher.engine import UBTeacherTrainer
+    cfg = small_fcos_cfg()
+    cfg.SOLVER.AMP.ENABLED = True
+    if kind == "fp16":
+        monkeypatch.setenv("UTV2_PRECISION", "fp16")
+    torch.manual_seed(0)
+    prod, orac = make_batch(12, 2, 2, H, W, "cuda")
+    try:
+        tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+        assert ops.PRECISION[0] == kind
+        sd_s = tune_state_for_pseudo_labels(cpu_state(tr.model), [d["image"] for d in orac[3]])
+        tr.model.load_state_dict(sd_s)
+        tr.model_teacher.load_state_dict(sd_s)
+        tr.iter = 1
+        tr.optimizer.param_groups[0]["lr"] = 0.01
+        for _ in range(3):
+            tr.run_step_full_semisup()
+            tr.iter += 1
+        torch.cuda.synchronize()
+        h16 = hip.h16_dtype()
+        for name, st in (("student", tr.model.store), ("teacher", tr.model_teacher.store)):
+            assert st._flat16 is not None and st._flat16.dtype == h16, name
+            assert st._v16 == st.version, "%s: the fused update did not leave the mirror fresh" % name
+            assert torch.equal(st._flat16, st.flat.to(h16)), name
+    finally:
+        ops.set_precision("fp32")

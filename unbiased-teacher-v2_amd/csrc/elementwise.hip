@@ -10,8 +10,10 @@
 //   new_teacher = student * (1 - keep) + teacher * keep      evaluated exactly as written:
 //   two rounded products and one rounded sum; a = (float)(1 - keep), b = (float)keep.
 // One launch over the whole flat state arena: 12 B/element algorithmic traffic.
+// mirror16 (optional): the 16-bit copy of the arena the mixed-precision convs read (RNE of the value just written) - saves the
+// conversion pass that would re-read the arena at the start of the next forward.
 __global__ __launch_bounds__(256) void ema_axpby_f32(float* __restrict__ teacher, const float* __restrict__ student,
-                                                   size_t n4, size_t n, float a, float b) {
+                                                   size_t n4, size_t n, float a, float b, h16_t* __restrict__ mirror16) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   f32x4* t4 = (f32x4*)teacher;
@@ -21,9 +23,19 @@ __global__ __launch_bounds__(256) void ema_axpby_f32(float* __restrict__ teacher
 #pragma unroll
     for (int e = 0; e < 4; ++e) r[e] = __fadd_rn(__fmul_rn(s[e], a), __fmul_rn(t[e], b));
     t4[j] = r;
+    if (mirror16) {
+      bf16x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (h16_t)r[e];
+      ((bf16x4_t*)mirror16)[j] = o;
+    }
   }
   // tail
-  for (size_t j = n4 * 4 + i; j < n; j += stride) teacher[j] = __fadd_rn(__fmul_rn(student[j], a), __fmul_rn(teacher[j], b));
+  for (size_t j = n4 * 4 + i; j < n; j += stride) {
+    const float r = __fadd_rn(__fmul_rn(student[j], a), __fmul_rn(teacher[j], b));
+    teacher[j] = r;
+    if (mirror16) mirror16[j] = (h16_t)r;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -33,7 +45,7 @@ __global__ __launch_bounds__(256) void ema_axpby_f32(float* __restrict__ teacher
 // inverse); grad is zeroed afterwards if zero_grad != 0 (saves the separate memset pass).
 __global__ __launch_bounds__(256) void sgd_momentum_f32(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                       size_t n, float lr, float mom, float wd, float gscale,
-                                                      int zero_grad) {
+                                                      int zero_grad, h16_t* __restrict__ mirror16) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
@@ -42,7 +54,9 @@ __global__ __launch_bounds__(256) void sgd_momentum_f32(float* __restrict__ p, f
     gv = __fadd_rn(gv, __fmul_rn(wd, pv));
     const float mv = __fadd_rn(__fmul_rn(mom, m[i]), gv);
     m[i] = mv;
-    p[i] = __fsub_rn(pv, __fmul_rn(lr, mv));
+    const float pn = __fsub_rn(pv, __fmul_rn(lr, mv));
+    p[i] = pn;
+    if (mirror16) mirror16[i] = (h16_t)pn;
     if (zero_grad) g[i] = 0.f;
   }
 }
@@ -71,8 +85,8 @@ __global__ __launch_bounds__(256) void amp_found_inf_f32(const float* __restrict
 
 __global__ __launch_bounds__(256) void sgd_momentum_amp_f32(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                           size_t n, float lr, float mom, float wd, float gscale,
-                                                          const float* __restrict__ state) {
-  if (state[1] != 0.f) return;                       // non-finite gradients: the step is skipped
+                                                          const float* __restrict__ state, h16_t* __restrict__ mirror16) {
+  if (state[1] != 0.f) return;                       // non-finite gradients: the step is skipped (a fresh mirror16 stays fresh)
   const float inv = 1.0f / state[0];                 // the scale is a power of two: exact
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -82,7 +96,9 @@ __global__ __launch_bounds__(256) void sgd_momentum_amp_f32(float* __restrict__ 
     gv = __fadd_rn(gv, __fmul_rn(wd, pv));
     const float mv = __fadd_rn(__fmul_rn(mom, m[i]), gv);
     m[i] = mv;
-    p[i] = __fsub_rn(pv, __fmul_rn(lr, mv));
+    const float pn = __fsub_rn(pv, __fmul_rn(lr, mv));
+    p[i] = pn;
+    if (mirror16) mirror16[i] = (h16_t)pn;
   }
 }
 
@@ -914,7 +930,18 @@ int utv2_ema_axpby(float* teacher, const float* student, int64_t n, double keep_
   if (((uintptr_t)teacher | (uintptr_t)student) & 15) return UTV2_EARG;
   const float a = (float)(1.0 - keep_rate), b = (float)keep_rate;
   hipLaunchKernelGGL(ema_axpby_f32, dim3(grid_for((size_t)n / 4)), dim3(256), 0, stream, teacher, student, (size_t)n / 4,
-                     (size_t)n, a, b);
+                     (size_t)n, a, b, (h16_t*)nullptr);
+  return utv2_launch_status();
+}
+
+// the same + mirror16[i] = the library's 16-bit rounding of the new teacher[i] (8-byte aligned)
+int utv2_ema_axpby_m16(float* teacher, const float* student, void* mirror16, int64_t n, double keep_rate, hipStream_t stream) {
+  if (!teacher || !student || !mirror16 || n < 0) return UTV2_EARG;
+  if (n == 0) return UTV2_OK;
+  if ((((uintptr_t)teacher | (uintptr_t)student) & 15) || ((uintptr_t)mirror16 & 7)) return UTV2_EARG;
+  const float a = (float)(1.0 - keep_rate), b = (float)keep_rate;
+  hipLaunchKernelGGL(ema_axpby_f32, dim3(grid_for((size_t)n / 4)), dim3(256), 0, stream, teacher, student, (size_t)n / 4,
+                     (size_t)n, a, b, (h16_t*)mirror16);
   return utv2_launch_status();
 }
 
@@ -923,7 +950,26 @@ int utv2_sgd_momentum(float* param, float* grad, float* mom_buf, int64_t n, floa
   if (!param || !grad || !mom_buf || n < 0) return UTV2_EARG;
   if (n == 0) return UTV2_OK;
   hipLaunchKernelGGL(sgd_momentum_f32, dim3(grid_for((size_t)n)), dim3(256), 0, stream, param, grad, mom_buf, (size_t)n, lr,
-                     momentum, weight_decay, grad_scale, zero_grad);
+                     momentum, weight_decay, grad_scale, zero_grad, (h16_t*)nullptr);
+  return utv2_launch_status();
+}
+
+// utv2_sgd_momentum / utv2_sgd_momentum_amp that also write mirror16[i] = the library's 16-bit rounding of the new param[i]
+int utv2_sgd_momentum_m16(float* param, float* grad, float* mom_buf, void* mirror16, int64_t n, float lr, float momentum, float weight_decay,
+                          float grad_scale, int zero_grad, hipStream_t stream) {
+  if (!param || !grad || !mom_buf || !mirror16 || n < 0) return UTV2_EARG;
+  if (n == 0) return UTV2_OK;
+  hipLaunchKernelGGL(sgd_momentum_f32, dim3(grid_for((size_t)n)), dim3(256), 0, stream, param, grad, mom_buf, (size_t)n, lr,
+                     momentum, weight_decay, grad_scale, zero_grad, (h16_t*)mirror16);
+  return utv2_launch_status();
+}
+
+int utv2_sgd_momentum_amp_m16(float* param, const float* grad, float* mom_buf, void* mirror16, int64_t n, float lr, float momentum,
+                              float weight_decay, float grad_scale, const float* state, hipStream_t stream) {
+  if (!param || !grad || !mom_buf || !mirror16 || !state || n < 0) return UTV2_EARG;
+  if (n == 0) return UTV2_OK;
+  hipLaunchKernelGGL(sgd_momentum_amp_f32, dim3(grid_for((size_t)n)), dim3(256), 0, stream, param, grad, mom_buf, (size_t)n, lr, momentum,
+                     weight_decay, grad_scale, state, (h16_t*)mirror16);
   return utv2_launch_status();
 }
 
@@ -940,7 +986,7 @@ int utv2_sgd_momentum_amp(float* param, const float* grad, float* mom_buf, int64
   if (!param || !grad || !mom_buf || !state || n < 0) return UTV2_EARG;
   if (n == 0) return UTV2_OK;
   hipLaunchKernelGGL(sgd_momentum_amp_f32, dim3(grid_for((size_t)n)), dim3(256), 0, stream, param, grad, mom_buf, (size_t)n, lr, momentum,
-                     weight_decay, grad_scale, state);
+                     weight_decay, grad_scale, state, (h16_t*)nullptr);
   return utv2_launch_status();
 }
 

@@ -56,16 +56,20 @@ class ArenaSGD:
         lr = self.param_groups[0]["lr"]
         if amp_state is not None:
             hip.amp_found_inf(st.grad, amp_state)
+        m16 = st.mirror16(need_fresh=True)    # the 16-bit copy the convs read: written by the update itself (no conversion pass next step)
         for kind, wd in (("decay", self.wd), ("nodecay", self.wd_norm)):
             s, e = st.ranges[kind]
+            mk = None if m16 is None else m16[s:e]
             if e > s and amp_state is not None:
-                hip.sgd_momentum_amp(st.flat[s:e], st.grad[s:e], st.mom[s:e], lr, self.momentum, wd, grad_scale, amp_state)
+                hip.sgd_momentum_amp(st.flat[s:e], st.grad[s:e], st.mom[s:e], lr, self.momentum, wd, grad_scale, amp_state, mirror16=mk)
             elif e > s:
-                hip.sgd_momentum(st.flat[s:e], st.grad[s:e], st.mom[s:e], lr, self.momentum, wd, grad_scale, zero_grad=False)
+                hip.sgd_momentum(st.flat[s:e], st.grad[s:e], st.mom[s:e], lr, self.momentum, wd, grad_scale, zero_grad=False, mirror16=mk)
         if amp_state is not None:
             hip.amp_update_scale(amp_state, 2.0, 0.5, 2000)   # torch.cuda.amp.GradScaler defaults [SURVEY appendix C]
         ops.bump_version()
         st.touch()
+        if m16 is not None:
+            st.mirror16_written()
         bank = getattr(st, "_flipbank", None)
         if bank is not None:
             bank.refresh_ahead()     # the dgrad weight images of the new weights, on a side stream: ready long before the next backward
@@ -408,8 +412,12 @@ class _TrainerBase:
             for k in t_keys:
                 if k not in sk:
                     raise Exception("{} is not found in student model".format(k))
-        hip.ema_axpby(self.model_teacher.flat_state(), self.model.flat_state(), keep_rate)
-        self.model_teacher.store.touch()
+        ts = self.model_teacher.store
+        m16 = ts.mirror16(need_fresh=False)
+        hip.ema_axpby(self.model_teacher.flat_state(), self.model.flat_state(), keep_rate, mirror16=m16)
+        ts.touch()
+        if m16 is not None:
+            ts.mirror16_written()
 
     # -- gradient exchange: ONE flat all-reduce (DDP mean semantics) -------------------------------------
     def _setup_grad_sync(self):

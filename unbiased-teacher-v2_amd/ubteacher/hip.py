@@ -239,12 +239,22 @@ def colsum(g2d, db, accumulate=True):
 
 # --------------------------------------------------------------------------------------------
 # elementwise / optimiser
-def ema_axpby(teacher_flat, student_flat, keep_rate):
+def ema_axpby(teacher_flat, student_flat, keep_rate, mirror16=None):
+    """mirror16 (optional, the library's 16-bit type, same length): also receives the 16-bit rounding of the new teacher values"""
     assert teacher_flat.numel() == student_flat.numel()
+    if mirror16 is not None:
+        assert mirror16.dtype == h16_dtype() and mirror16.numel() == teacher_flat.numel()
+        call("utv2_ema_axpby_m16", _p(teacher_flat), _p(student_flat), _p(mirror16), teacher_flat.numel(), float(keep_rate), _stream())
+        return
     call("utv2_ema_axpby", _p(teacher_flat), _p(student_flat), teacher_flat.numel(), float(keep_rate), _stream())
 
 
-def sgd_momentum(param, grad, mom, lr, momentum, weight_decay, grad_scale=1.0, zero_grad=True):
+def sgd_momentum(param, grad, mom, lr, momentum, weight_decay, grad_scale=1.0, zero_grad=True, mirror16=None):
+    if mirror16 is not None:
+        assert mirror16.dtype == h16_dtype() and mirror16.numel() == param.numel()
+        call("utv2_sgd_momentum_m16", _p(param), _p(grad), _p(mom), _p(mirror16), param.numel(), float(lr), float(momentum),
+             float(weight_decay), float(grad_scale), int(zero_grad), _stream())
+        return
     call("utv2_sgd_momentum", _p(param), _p(grad), _p(mom), param.numel(), float(lr), float(momentum),
          float(weight_decay), float(grad_scale), int(zero_grad), _stream())
 
@@ -253,7 +263,12 @@ def amp_found_inf(grad, state):
     call("utv2_amp_found_inf", _p(grad), grad.numel(), _p(state), _stream())
 
 
-def sgd_momentum_amp(param, grad, mom, lr, momentum, weight_decay, grad_scale, state):
+def sgd_momentum_amp(param, grad, mom, lr, momentum, weight_decay, grad_scale, state, mirror16=None):
+    if mirror16 is not None:
+        assert mirror16.dtype == h16_dtype() and mirror16.numel() == param.numel()
+        call("utv2_sgd_momentum_amp_m16", _p(param), _p(grad), _p(mom), _p(mirror16), param.numel(), float(lr), float(momentum),
+             float(weight_decay), float(grad_scale), _p(state), _stream())
+        return
     call("utv2_sgd_momentum_amp", _p(param), _p(grad), _p(mom), param.numel(), float(lr), float(momentum), float(weight_decay),
          float(grad_scale), _p(state), _stream())
 

@@ -13,6 +13,8 @@ views so checkpoints keep the reference's key names and shapes (modelStudent.* /
 """
 from collections import OrderedDict
 
+import os
+
 import torch
 
 KINDS = ("decay", "nodecay", "frozen", "buffer")
@@ -113,6 +115,20 @@ class ParamStore:
             hip.f32_to_bf16(self.flat, self._flat16)
             self._v16 = self.version
         return self._flat16[h.offset: h.offset + h.numel].view(h.shape)
+
+    def mirror16(self, need_fresh):
+        """the 16-bit mirror of the arena as the target of a fused update (SGD: a range, so it must be FRESH - the untouched ranges stay
+        valid; EMA: the whole arena, so existence and element type suffice), or None; UTV2_FUSED_MIRROR=0: never"""
+        from . import hip
+        if os.environ.get("UTV2_FUSED_MIRROR", "1") == "0" or self._flat16 is None or self._flat16.dtype != hip.h16_dtype():
+            return None
+        if need_fresh and self._v16 != self.version:
+            return None
+        return self._flat16
+
+    def mirror16_written(self):
+        """the update that was handed mirror16() has run and touch() has been called: the mirror is the new version's"""
+        self._v16 = self.version
 
     def region(self, kind):
         s, e = self.ranges[kind]
