@@ -793,6 +793,7 @@ def bottleneck(block, x):
             and all(c.stride == 1 for c in convs) and block.conv1.k == 1 and block.conv2.k == 3 and block.conv3.k == 1
             and (block.shortcut is None or block.shortcut.k == 1) and block.conv3.cout == 256
             and all(c.bn is not None and c.bias is None and c.use_bf16() for c in convs)
+            and x.shape[1] * x.shape[2] * 256 < 2 ** 31           # the kernel's 32-bit element offsets inside one image
             and hip.bottleneck_supported(block.conv1.cin, block.conv1.cout, block.shortcut is not None)):
         # a frozen stride-1 block (res2 under FREEZE_AT 2; the teacher's too): nothing is kept for a backward, so its convs run as one
         # kernel with the 64-channel intermediates in LDS (csrc/bottleneck.hip)
