@@ -12,6 +12,18 @@ pytestmark = pytest.mark.gpu
 H, W = 96, 128
 
 
+@pytest.fixture
+def separable_roi_align():
+    """The oracle's RoIAlign in its separable form (oracle FAST_ROI_ALIGN: the same arithmetic regrouped, pinned against the per-sample form
+    forward and backward by tests/test_oracle_golden_rcnn.py::test_fast_roi_align_equals_pinned_form; what bench.py's CPU baseline runs):
+    the per-sample form's autograd backward materialises a full feature map per ROI and tap and makes an oracle step 4x slower on the
+    host.  The whole-step tests below that only need the oracle's numbers at 1e-3 use it; test_rcnn_step_vs_reference_trainer_golden and
+    the kernel-level RoIAlign tests keep the per-sample form."""
+    O.FAST_ROI_ALIGN[0] = True
+    yield
+    O.FAST_ROI_ALIGN[0] = False
+
+
 def rcnn_cfg():
     from ubteacher.presets import get_config
     return get_config("rcnn", 1, ["SOLVER.IMG_PER_BATCH_LABEL", 2, "SOLVER.IMG_PER_BATCH_UNLABEL", 2,
@@ -24,7 +36,7 @@ def relerr(a, b):
 
 
 @pytest.mark.parametrize("predictor", ["FocalLoss_BoundaryVar", "FocalLoss"])
-def test_rcnn_full_semisup_step_parity(predictor):
+def test_rcnn_full_semisup_step_parity(predictor, separable_roi_align):
     """FocalLoss_BoundaryVar: the shipped UTv2 configuration.  FocalLoss: the UTv1 predictor the reference still ships
     (roi_heads/roi_heads.py:52-66 -> fast_rcnn.py:1296-1429): class-specific centre-size deltas, confidence-weighted focal loss on the
     pseudo-labeled branch, no boundary-variance head - pseudo boxes without pred_boxes_std (trainer.py:743-746)."""
@@ -329,7 +341,7 @@ def test_rcnn_step_vs_reference_trainer_golden():
 
 
 @pytest.mark.parametrize("kind,tol", [("bf16", 1e-2), ("fp16", 3e-3)])
-def test_rcnn_step_bf16_vs_rounding_oracle(kind, tol, monkeypatch):
+def test_rcnn_step_bf16_vs_rounding_oracle(kind, tol, monkeypatch, separable_roi_align):
     """BASELINE configs[4] (Faster-RCNN, bf16 MFMA conv path; and the same on the fp16 build of the kernels with the dynamic loss scale,
     UTV2_PRECISION=fp16): the full AMP step against the oracle with the same operand rounding emulated in its convs / linears (O.CONV_ROUND).  Discrete selections are decoupled from rounding noise the way the FCOS AMP
     test does it: the oracle is handed the product's pseudo labels and the product's RPN proposals of the two student passes, and
@@ -430,7 +442,7 @@ def test_rcnn_step_is_bit_deterministic():
     assert torch.equal(states[0][0], states[1][0]) and torch.equal(states[0][1], states[1][1])
 
 
-def test_rcnn_step_fp32_tight_with_the_product_pseudo_boxes():
+def test_rcnn_step_fp32_tight_with_the_product_pseudo_boxes(separable_roi_align):
     """The two pseudo RPN terms are compared at 5e-3 / 2e-2 above because the product's and the oracle's teachers emit pseudo boxes that
     differ by ~1e-5, which flips exact-equality low-quality matches and near-tied arg-max IoUs (an ill-conditioned SELECTION).  With the
     selection decoupled - the oracle is handed the product's pseudo boxes, as the AMP test does - the ARITHMETIC of every loss,
