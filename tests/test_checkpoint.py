@@ -306,3 +306,34 @@ def test_roi_heads_loss_selects_the_predictor_and_its_state_dict_surface():
         build_model(get_config("rcnn", 1, ["MODEL.DEVICE", "cpu", "MODEL.ROI_HEADS.LOSS", "CrossEntropy"]))
     with pytest.raises(ValueError, match="Unknown ROI head loss"):
         build_model(get_config("rcnn", 1, ["MODEL.DEVICE", "cpu", "MODEL.ROI_HEADS.LOSS", "nope"]))
+
+
+def test_weight_mirror_freshness_rules(monkeypatch):
+    """ParamStore.mirror16 (the 16-bit copy of the arena the mixed-precision convs read, handed to the SGD / EMA kernels that write it
+    themselves): a RANGE update (SGD) may only take it when it is fresh - the untouched ranges must already be valid -, a whole-arena
+    update (EMA) whenever it exists with the selected library's element type; any other writer (load_state_dict -> touch()) leaves it stale
+    for the lazy conversion; UTV2_FUSED_MIRROR=0 switches the hand-over off."""
+    import torch
+    from ubteacher import hip
+    from ubteacher.modeling import build_model
+    from ubteacher.presets import get_config
+    m = build_model(get_config("fcos", 1, ["MODEL.DEVICE", "cpu"]))
+    st = m.store
+    assert st.mirror16(need_fresh=True) is None and st.mirror16(need_fresh=False) is None      # no mirror yet
+    st._flat16 = torch.zeros(st.total, dtype=hip.h16_dtype())                                    # as bf16() creates it
+    st._v16 = st.version - 1
+    assert st.mirror16(need_fresh=True) is None and st.mirror16(need_fresh=False) is st._flat16  # stale: EMA may take it, SGD may not
+    st._v16 = st.version
+    assert st.mirror16(need_fresh=True) is st._flat16
+    st.touch()                                                                                   # the update ran
+    assert st._v16 != st.version
+    st.mirror16_written()
+    assert st._v16 == st.version and st.mirror16(need_fresh=True) is st._flat16
+    m.load_state_dict(m.state_dict())                                                            # another writer: stale again
+    assert st.mirror16(need_fresh=True) is None
+    st._v16 = st.version
+    monkeypatch.setenv("UTV2_FUSED_MIRROR", "0")
+    assert st.mirror16(need_fresh=True) is None and st.mirror16(need_fresh=False) is None
+    monkeypatch.delenv("UTV2_FUSED_MIRROR")
+    st._flat16 = st._flat16.to(torch.float16 if hip.h16_dtype() == torch.bfloat16 else torch.bfloat16)   # the other library's type
+    assert st.mirror16(need_fresh=False) is None
