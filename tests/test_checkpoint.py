@@ -248,8 +248,26 @@ def test_arena_sgd_state_is_per_key_and_layout_independent(tmp_path, monkeypatch
     assert ob.param_groups[0]["lr"] == 0.5
     for k, v in sd["momentum"].items():
         assert torch.equal(ob.state_dict()["momentum"][k], v), k
-    state[3]["momentum_buffer"] = torch.zeros(7)                                              # a shape that cannot be this tensor's
+    # older Detectron2 releases (no reduce_param_groups) emit ONE GROUP PER PARAMETER in named_parameters() order - conv and
+    # GroupNorm tensors interleaved, [256] biases next to [256] norm weights; the ids then follow the model's key order
+    per_param = {"state": {i: {"momentum_buffer": sd["momentum"][k].clone()} for i, k in enumerate(keys)},
+                 "param_groups": [{"lr": 0.25, "weight_decay": 0.0 if k in norm else 1e-4, "params": [i]} for i, k in enumerate(keys)]}
+    ob.store.mom.zero_()
+    ob.load_state_dict(per_param)
+    assert ob.param_groups[0]["lr"] == 0.25
+    for k, v in sd["momentum"].items():
+        assert torch.equal(ob.state_dict()["momentum"][k], v), k
+    # grouped layouts that cannot be verified are refused instead of shape-matched: equal weight decay in both groups, wrong group sizes
     before = ob.store.mom.clone()
+    same_wd = {"state": state, "param_groups": [dict(g, weight_decay=1e-4) for g in torch_sd["param_groups"]]}
+    with pytest.raises(ValueError, match="cannot be told apart"):
+        ob.load_state_dict(same_wd)
+    shifted = {"state": state, "param_groups": [dict(torch_sd["param_groups"][0], params=list(range(len(dec) - 1))),
+                                                 dict(torch_sd["param_groups"][1], params=list(range(len(dec) - 1, len(keys))))]}
+    with pytest.raises(ValueError, match="cannot be told apart"):
+        ob.load_state_dict(shifted)
+    assert torch.equal(ob.store.mom, before)
+    state[3]["momentum_buffer"] = torch.zeros(7)                                              # a shape that cannot be this tensor's
     with pytest.raises(ValueError, match="size mismatch"):
         ob.load_state_dict(torch_sd)
     assert torch.equal(ob.store.mom, before)                                                  # nothing written on failure
@@ -271,7 +289,14 @@ def test_amp_scaler_state_round_trips(tmp_path):
 
         def load_state_dict(self, sd, strict=False):
             pass
-    DetectionTSCheckpointer(M(), str(tmp_path), grad_scaler=AmpScalerState(t1)).save("model_0000005", iteration=5)
+    w = DetectionTSCheckpointer(M(), str(tmp_path), grad_scaler=AmpScalerState(t1))
+    w.save("model_0000005", iteration=5)
+    w.save("model_final", iteration=9)
+    # the checkpoint files carry the CALLER's names (an extra checkpointable's key used to shadow the `name` argument:
+    # every save went to grad_scaler.pth and model_final.pth never existed)
+    import os
+    assert sorted(f for f in os.listdir(str(tmp_path)) if f.endswith(".pth")) == ["model_0000005.pth", "model_final.pth"]
+    assert open(os.path.join(str(tmp_path), "last_checkpoint")).read().strip() == "model_final.pth"
     ck = DetectionTSCheckpointer(M(), str(tmp_path), grad_scaler=AmpScalerState(t2))
     assert ck.last_optimizer_skipped is False            # initialised (the attribute used to exist only after a skipped load)
     ck.resume_or_load("", resume=True)

@@ -144,6 +144,25 @@ def _worker(rank, world, port, q):
         seq.append(([d["image_id"] for d in lq], [d["image_id"] for d in uq], len(lk), len(uk)))
     out["loader_seq"] = seq
     out["label_stream"] = list(itertools.islice(iter(loader.label_dataset.sampler), 12))
+    # (5) ADVICE r4: the test loader shards the set over the ranks; COCOBoxEvaluator.evaluate() gathers every rank's predictions and
+    # ground truth on the main rank (Detectron2 COCOEvaluator(distributed=True)) - rank 0 reports the AP of the WHOLE set, the others {}
+    import numpy as np
+    from ubteacher.evaluation.coco_eval import COCOBoxEvaluator, coco_box_ap
+    def _img(i):
+        b = np.array([[10.0 + i, 10.0, 60.0 + i, 50.0]])
+        gt = dict(boxes=b, classes=np.array([i % 2]))
+        # image 1's detection has the wrong class: the whole-set AP differs from either shard's
+        pr = dict(boxes=b.copy(), scores=np.array([0.9 - 0.1 * i]), classes=np.array([0]))
+        return gt, pr
+    ev = COCOBoxEvaluator(num_classes=2)
+    for i in range(4):
+        if i % world == rank:                                       # InferenceSampler-style shard
+            ev._gt[i], ev._pred[i] = _img(i)
+    out["eval"] = ev.evaluate()
+    whole_gt, whole_pr = {}, {}
+    for i in range(4):
+        whole_gt[i], whole_pr[i] = _img(i)
+    out["eval_whole"] = {"bbox": coco_box_ap(whole_pr, whole_gt, 2)}
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -172,6 +191,8 @@ def test_world_size_2_gloo():
         assert res[r]["joint"] == pytest.approx(want)
         assert res[r]["sizes"] == (2, 2, 1, 1)                      # IMG_PER_BATCH_* // world (data/build.py:240-241)
     assert not torch.equal(res[0]["img0"], res[1]["img0"])          # ranks see different images
+    assert res[0]["eval"] == res[0]["eval_whole"] and res[1]["eval"] == {}     # dataset AP on the main rank only (gathered shards)
+    assert 0.0 < res[0]["eval"]["bbox"]["AP"] < 100.0
     m = res[0]["metrics"]
     assert m["loss_a"] == pytest.approx(1.5) and m["loss_b"] == pytest.approx(3.0) and m["other"] == pytest.approx(7.0)
     assert m["total_loss"] == pytest.approx(4.5)                    # sum of averaged keys starting with "loss"

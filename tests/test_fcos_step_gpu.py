@@ -748,9 +748,9 @@ def test_step_as_hipgraph_replays_the_eager_step(kind):
                 recs.append(dict(tr.flush_metrics()))
             torch.cuda.synchronize()
             if graph:
-                assert tr._step_graph["graph"] is not None            # steps 3..5 were replays
+                assert all(st["graph"] is not None for st in tr._step_graphs.values()) and tr._step_graphs   # steps 3..5 were replays
+            assert ops.STEP_GRAPH[0] is False          # the flag is scoped to run_step_graph, later eager steps are unaffected
             outs.append((recs, tr.model.flat_state().clone(), tr.model_teacher.flat_state().clone()))
-            ops.STEP_GRAPH[0] = False
     finally:
         ops.STEP_GRAPH[0] = False
     (ra, sa, ta), (rb, sb, tb) = outs

@@ -13,6 +13,25 @@ static inline int utv2_launch_status() {
   return e == hipSuccess ? UTV2_OK : -(int)e;
 }
 
+// Opt-in of kernels to more than 64 KB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize), once PER DEVICE: the attribute
+// belongs to the function object of the device that is current when it is set, so a process that drives several devices has to set it on
+// each (a process-wide once-flag covered the first device only).  Racing first calls both set it - idempotent.
+#ifdef __cplusplus
+#include <atomic>
+#include <initializer_list>
+struct LdsOptIn {
+  std::atomic<unsigned long long> done{0};
+  void operator()(std::initializer_list<const void*> fns, int bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_release);
+  }
+};
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // The 16-bit float type of THIS build of the library.  Every "bf16" kernel, entry point and dtype code (UTV2_BF16) is written against

@@ -1216,14 +1216,9 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
         ConvArgs16 m = a;
         m.M = main_tiles == tiles_all ? a.M : main_m * 256;
         const int smem = 2 * (256 + 256) * 128;
-        static std::once_flag attr_once;   // one-time function attribute (thread-safe; the only write-once state of this entry)
-        std::call_once(attr_once, [] {
-          constexpr int smem_ = 2 * (256 + 256) * 128;
-          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_w8<ML, h16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);
-          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_w8<ML, float>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);
-          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_pp<ML, h16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);
-          (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_pp<ML, float>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);
-        });
+        static LdsOptIn lds_opt_in;   // per-device function attribute (thread-safe; the only write-once state of this entry)
+        lds_opt_in({(const void*)conv_igemm_bf16_w8<ML, h16_t>, (const void*)conv_igemm_bf16_w8<ML, float>,
+                    (const void*)conv_igemm_bf16_pp<ML, h16_t>, (const void*)conv_igemm_bf16_pp<ML, float>}, smem);
         if (g_use_pp) {
           int grid = main_m * tilesN;
           static const int pp_wgs = [] { int v = env_int("UTV2_PP_WGS", 256); return v < 8 ? 8 : (v > 256 ? 256 : v / 8 * 8); }();   // A/B: CUs the persistent grid takes
@@ -2202,10 +2197,8 @@ static int wgrad_bf16_impl(const void* x, int x_dtype, int x_pitch, const void* 
     a.debug = g_wgrad_debug;
     const size_t n = (size_t)K * a.Kred;
     const int smem = 2 * 2 * WGRAD_W8_BP * 512;
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [] {
-      (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_w8, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * WGRAD_W8_BP * 512);
-    });
+    static LdsOptIn lds_opt_in;
+    lds_opt_in({(const void*)conv_wgrad_bf16_w8}, smem);
     hipLaunchKernelGGL(conv_wgrad_bf16_w8, dim3(wgrad16_w8_budget()), dim3(512), smem, stream, a);
     int rb = cdiv((int64_t)n / 4, 256);
     if (rb > 8192) rb = 8192;

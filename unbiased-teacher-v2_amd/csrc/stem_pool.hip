@@ -174,11 +174,8 @@ int utv2_stem_pool_fwd_bf16(const void* xpad16, const void* w16s, void* y, const
   const long long nt = (long long)N * a.tiles_x * a.tiles_y;
   if (nt > 0x7fffffff) return UTV2_EARG;
   a.ntiles = (int)nt;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)stem_pool_fused, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt_in;
+  lds_opt_in({(const void*)stem_pool_fused}, SP_LDS);
   const int grid = a.ntiles < 512 ? a.ntiles : 512;
   hipLaunchKernelGGL(stem_pool_fused, dim3((unsigned)grid), dim3(256), SP_LDS, stream, a);
   return utv2_launch_status();

@@ -136,8 +136,8 @@ class DetectionTSCheckpointer:
             data["optimizer"] = _to_cpu(self.optimizer.state_dict())
         if self.scheduler is not None:
             data["scheduler"] = self.scheduler.state_dict()
-        for name, obj in self.extra.items():
-            data[name] = obj.state_dict()
+        for key, obj in self.extra.items():   # (not `name`: the file name below is the caller's)
+            data[key] = obj.state_dict()
         data.update(kwargs)
         fn = "{}.pth".format(name)
         torch.save(data, os.path.join(self.save_dir, fn))

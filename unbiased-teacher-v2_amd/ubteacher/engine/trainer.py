@@ -127,10 +127,30 @@ class ArenaSGD:
             return
         if isinstance(sd, dict) and "state" in sd and "param_groups" in sd:
             mv = self._momentum_views()
-            order = [k for k, (h, _, _) in mv.items() if h.kind == "decay"] + [k for k, (h, _, _) in mv.items() if h.kind == "nodecay"]
-            ids = [i for g in sd["param_groups"] for i in g["params"]]
-            if len(ids) != len(order):
-                raise ValueError("optimizer state holds %d parameters, this model trains %d" % (len(ids), len(order)))
+            groups = sd["param_groups"]
+            ids = [i for g in groups for i in g["params"]]
+            if len(ids) != len(mv):
+                raise ValueError("optimizer state holds %d parameters, this model trains %d" % (len(ids), len(mv)))
+            if len(groups) == 1 or len(groups) == len(ids):
+                # one group (equal hyper-parameters everywhere) or one group PER parameter (Detectron2 releases without
+                # reduce_param_groups): the ids follow model.named_parameters() = this model's key order, kinds interleaved
+                order = list(mv)
+            else:
+                # reduce_param_groups: parameters grouped by equal hyper-parameters in order of first appearance.  The groups must
+                # be told apart by their weight decay and hold exactly this model's tensors of each kind - a [256] conv bias
+                # against a [256] GroupNorm weight passes every shape check, so the layout itself is verified
+                kinds = []
+                for k, (h, _, _) in mv.items():
+                    if h.kind not in kinds:
+                        kinds.append(h.kind)
+                by_kind = {kd: [k for k, (h, _, _) in mv.items() if h.kind == kd] for kd in kinds}
+                wds = [g.get("weight_decay") for g in groups]
+                if len(groups) != len(kinds) or [len(g["params"]) for g in groups] != [len(by_kind[kd]) for kd in kinds] or \
+                        len(set(wds)) != len(wds):
+                    raise ValueError("optimizer state: %d parameter groups of sizes %s (weight decay %s) cannot be told apart as this "
+                                     "model's %s groups of sizes %s" % (len(groups), [len(g["params"]) for g in groups], wds, kinds,
+                                                                        [len(by_kind[kd]) for kd in kinds]))
+                order = [k for kd in kinds for k in by_kind[kd]]
             per_key = {}
             for k, i in zip(order, ids):
                 buf = sd["state"].get(i, {}).get("momentum_buffer")
@@ -381,11 +401,25 @@ class _TrainerBase:
             raise RuntimeError("run_step_graph: one CUDA rank only")
         if self.iter < self.cfg.SEMISUPNET.BURN_UP_STEP + 1:
             return self.run_step_full_semisup()
+        # the flag is scoped to this call (it used to stay set for every later eager step and every other trainer of the
+        # process); it covers the eager warm-up steps too - work they parked across the step boundary would be joined INSIDE the capture
+        prev = ops.STEP_GRAPH[0]
         ops.STEP_GRAPH[0] = True
-        key = (float(self.optimizer.param_groups[0]["lr"]),)
-        st = self.__dict__.setdefault("_step_graph", {"key": None, "graph": None, "warm": 0})
-        if st["key"] != key:
-            st.update(key=key, graph=None, warm=0)
+        try:
+            return self._run_step_graph()
+        finally:
+            ops.STEP_GRAPH[0] = prev
+
+    def _run_step_graph(self):
+        S = self.cfg.SEMISUPNET
+        # every host-side decision the captured step bakes in is part of the key: the learning rate (a launch argument) and the
+        # iteration-dependent teacher update (TEACHER_UPDATE_ITER > 1: steps with and without the EMA are two graphs)
+        ema_step = (self.iter - S.BURN_UP_STEP) % S.TEACHER_UPDATE_ITER == 0
+        key = (float(self.optimizer.param_groups[0]["lr"]), ema_step)
+        graphs = self.__dict__.setdefault("_step_graphs", {})
+        if graphs and next(iter(graphs))[0] != key[0]:
+            graphs.clear()                                   # a new learning rate retires every captured step
+        st = graphs.setdefault(key, {"graph": None, "warm": 0})
         flush = (self.iter + 1) % self.log_period == 0
         if st["graph"] is None:
             if st["warm"] < 2 or flush:

@@ -175,4 +175,18 @@ class COCOBoxEvaluator:
                                    classes=inst.pred_classes.detach().cpu().numpy())
 
     def evaluate(self):
-        return {"bbox": coco_box_ap(self._pred, self._gt, self.num_classes)}
+        """Detectron2 COCOEvaluator(distributed=True).evaluate [D2-recall]: the test loader shards the set over the ranks
+        (build_detection_test_loader + InferenceSampler), so every rank's predictions (and the ground truth that rode on its inputs) are
+        gathered on the main rank, merged by image id, and scored there; the other ranks return {}."""
+        from ..utils import comm
+        pred, gt = self._pred, self._gt
+        if comm.get_world_size() > 1:
+            comm.synchronize()
+            parts = comm.gather((pred, gt), dst=0)
+            if not comm.is_main_process():
+                return {}
+            pred, gt = {}, {}
+            for p, g in parts:
+                pred.update(p)
+                gt.update(g)
+        return {"bbox": coco_box_ap(pred, gt, self.num_classes)}
