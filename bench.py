@@ -693,6 +693,16 @@ def worker(args):
     sync()
     dt = time.perf_counter() - t0_
     timer.enabled = wtimer.enabled = False
+    # shader clock the chip sustained under the last multi-level (tower / RPN head) launch of the 256-tile conv kernel inside the timed
+    # region (utv2_conv_clock_probe: s_memtime against the 100 MHz real-time counter over workgroup 0's lifetime)
+    clock_ghz = None
+    if args.dtype != "f32":
+        try:
+            from ubteacher import hip as _hip
+            g, us = _hip.conv_clock_probe()
+            clock_ghz = {"ghz": g, "workgroup_lifetime_us": us} if g > 0 else None
+        except Exception as e:  # noqa: BLE001
+            clock_ghz = {"error": repr(e)}
     calls_per_step = (calls.n - n0) / max(args.steps, 1)
     devices = [device_index]
     if world > 1:
@@ -959,6 +969,14 @@ def worker(args):
                                "algorithmic_bytes": conv["alg_bytes"], "algorithmic_GBps": conv["alg_gbps"],
                                "launches": conv["launches"], "avg_us": conv["avg_us"],
                                "time_share": conv["total_ms"] / (1e3 * dt)}
+            if clock_ghz and clock_ghz.get("ghz"):
+                # `peak` is the datasheet rate at the 2.4 GHz maximum clock; under full-chip MFMA load the board's power limit holds the
+                # clock lower (measured live, above): what the matrix pipes could have delivered at THAT clock, and the fraction of it
+                g = clock_ghz["ghz"]
+                out["roofline"]["sustained_clock_ghz"] = g
+                out["roofline"]["peak_at_sustained_clock"] = peak * g / 2.4
+                out["roofline"]["frac_of_peak_at_sustained_clock"] = conv["tflops"] / (peak * g / 2.4)
+                out["roofline"]["clock_probe"] = "utv2_conv_clock_probe: s_memtime ticks per 10 ns s_memrealtime tick over the lifetime (%.0f us) of workgroup 0 of the last multi-level 256-tile launch of the timed region" % clock_ghz["workgroup_lifetime_us"]
             if conv_x:
                 out["roofline"]["exclusive"] = {"achieved": conv_x["tflops"], "frac": conv_x["tflops"] / peak, "avg_us": conv_x["avg_us"],
                                                 "launches": conv_x["launches"],

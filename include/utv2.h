@@ -66,6 +66,12 @@ int utv2_conv2d_ml_wgrad(const float* x, const float* dy, float* dw, float* ws, 
 #define UTV2_BF16 1   /* the library's 16-bit float type: bfloat16 in libutv2_hip.so, IEEE fp16 in libutv2_hip_f16.so (the same sources built
                        * with -DUTV2_H16=_Float16; csrc/common.h h16_t) - "bf16" in the names below reads "the 16-bit type" there */
 int utv2_conv2d_bf16_supported(int C, int KH, int KW);
+
+/* Measurement aid (bench.py roofline.sustained_clock_ghz; synchronises the device, never on the training path): the shader clock in GHz
+ * that workgroup 0 of the LAST persistent-grid multi-level launch (FCOS tower / RPN head) of the 256 x 256 forward / dgrad conv tile ran at (s_memtime ticks per 10 ns
+ * s_memrealtime tick over that workgroup's lifetime) and the lifetime in microseconds; 0 / 0 before the first such launch.  The MFMA peak
+ * is quoted at 2.4 GHz; under full-chip MFMA load the board's power limit holds the clock at 1.45-1.9 GHz.  No reference counterpart. */
+int utv2_conv_clock_probe(double* ghz, double* lifetime_us);
 /* mask (optional, y's type and shape): y = mask > 0 ? conv*scale+bias : 0, before the residual add - the ReLU backward of the
  * layer that produced the input, fused into the dgrad launch that computes its gradient; post_mask (optional, same type and shape):
  * y = post_mask > 0 ? y : 0 AFTER the residual add - the ReLU whose OUTPUT this gradient flows into (a bottleneck's input), so the

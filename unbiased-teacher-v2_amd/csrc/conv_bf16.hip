@@ -856,11 +856,18 @@ __device__ unsigned long long g_pp_phase[2][5];
 #else
 #define PP_DMA(cond) (cond)
 #endif
+// Shader-clock probe (utv2_conv_clock_probe): wave 0 of workgroup 0 of every persistent-grid launch leaves {s_memtime ticks, 100 MHz
+// s_memrealtime ticks} of its own lifetime here - the clock the chip sustained under THIS kernel (the full-chip launches run at
+// 1.45-1.9 GHz of the 2.4 GHz the peak is quoted at: the board's power limit, bench.py roofline.sustained_clock_ghz)
+__device__ unsigned long long g_pp_clock[2];
 template <bool ML, typename TO>
 __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
 #ifdef UTV2_PP_TRACE
   const unsigned long long ph_entry = __builtin_amdgcn_s_memtime();
 #endif
+  const bool clk_on = ML && blockIdx.x == 0 && p.ntiles > 0;   // the multi-level (tower / RPN head) launches
+  unsigned long long clk_c0 = 0, clk_r0 = 0;
+  if (clk_on) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
   constexpr int BM = 256, BN = 256, BK = 64, SEGB = 64;
   constexpr int OPSEG = 256 * SEGB, OPB = 2 * OPSEG, STAGE = 2 * OPB;  // 16 KB, 32 KB, 64 KB
   constexpr int TM = 4, TN = 2;
@@ -1172,6 +1179,10 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
 #endif
   __syncthreads();   // persistent grid: every wave is done with its epilogue patch before the next tile's first DMA pieces land there
   }
+  if (clk_on && threadIdx.x == 0) {
+    g_pp_clock[0] = __builtin_amdgcn_s_memtime() - clk_c0;
+    g_pp_clock[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+  }
 }
 
 // A/B switches for bench runs and tests, read ONCE per process (never on the launch path): UTV2_W8=0 keeps every forward / dgrad
@@ -1277,6 +1288,19 @@ static bool n96_eligible(const ConvArgs16& a, int x_dtype) {
 static inline bool bad_dtype(int d) { return d != UTV2_F32 && d != UTV2_BF16; }
 
 extern "C" {
+
+// Measurement aid (synchronises the device; never on the training path): shader clock in GHz that workgroup 0 of the LAST persistent-grid
+// multi-level (FCOS tower / RPN head) launch of the 256-tile forward / dgrad kernel ran at (s_memtime ticks per 10 ns s_memrealtime tick over the workgroup's lifetime), and
+// that lifetime in microseconds.  0 / 0 when no such launch has run yet.
+int utv2_conv_clock_probe(double* ghz, double* lifetime_us) {
+  if (!ghz || !lifetime_us) return UTV2_EARG;
+  unsigned long long v[2] = {0, 0};
+  hipError_t e = hipMemcpyFromSymbol(v, HIP_SYMBOL(g_pp_clock), sizeof(v));
+  if (e != hipSuccess) return -(int)e;
+  *ghz = v[1] ? (double)v[0] / (10.0 * (double)v[1]) : 0.0;
+  *lifetime_us = (double)v[1] * 0.01;
+  return UTV2_OK;
+}
 
 // 1 if the bf16 MFMA kernel supports this conv (C % 8 == 0), else the caller uses the fp32 kernel
 int utv2_conv2d_bf16_supported(int C, int KH, int KW) { return (C % 8 == 0) ? 1 : 0; }

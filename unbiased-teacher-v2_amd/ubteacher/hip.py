@@ -239,6 +239,14 @@ def colsum(g2d, db, accumulate=True):
 
 # --------------------------------------------------------------------------------------------
 # elementwise / optimiser
+def conv_clock_probe():
+    """(GHz, microseconds): shader clock and lifetime of workgroup 0 of the last persistent 256-tile conv launch (utv2_conv_clock_probe;
+    a measurement aid - it synchronises the device)"""
+    ghz, us = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    call("utv2_conv_clock_probe", ctypes.byref(ghz), ctypes.byref(us))
+    return ghz.value, us.value
+
+
 def ema_axpby(teacher_flat, student_flat, keep_rate, mirror16=None):
     """mirror16 (optional, the library's 16-bit type, same length): also receives the 16-bit rounding of the new teacher values"""
     assert teacher_flat.numel() == student_flat.numel()
