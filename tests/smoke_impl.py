@@ -9,6 +9,9 @@ from tests.utv2_testutil import FixedLoader, cpu_state, make_batch, small_fcos_c
 def run():
     from ubteacher.engine import UBTeacherTrainer
     assert torch.cuda.is_available(), "smoke() needs a GPU"
+    import os
+    if (os.cpu_count() or 1) > 16:
+        torch.set_num_threads(16)      # the oracle leg: stock torch CPU kernels on small tensors slow down on the boxes' 128-256 threads (tests/conftest.py)
     H, W = 96, 128
     cfg = small_fcos_cfg(device="cuda:0")
     torch.manual_seed(0)
