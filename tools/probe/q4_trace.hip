@@ -36,7 +36,7 @@ int main() {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int which = 0; which < 3; ++which)
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < (getenv("REPS") ? atoi(getenv("REPS")) : 4); ++it) {
       hipEventRecord(e0);
       if (which == 0) hipLaunchKernelGGL((conv_igemm_bf16_pp<true, h16_t>), dim3(256), dim3(512), smem, 0, m);
       else if (which == 1) hipLaunchKernelGGL((conv_igemm_bf16_q4<true, h16_t>), dim3(256), dim3(256), smem, 0, m);
@@ -54,6 +54,11 @@ int main() {
         for (size_t i = 0; i < (size_t)(m.M / 32) * (K / 8) * 2; ++i) h = (h ^ hg[i]) * 1099511628211ull;
         sums[which] = h;
         hipMemset(y, 0xff, P * K * 2);
+      }
+      if (it && which == 0) {
+        unsigned long long ck[2];
+        hipMemcpyFromSymbol(ck, HIP_SYMBOL(g_pp_clock), sizeof(ck));
+        printf("   (pp workgroup 0: %llu cycles at %.3f GHz)\n", ck[0], ck[0] / (10.0 * ck[1]));
       }
       if (it) printf("%s launch %d: %.3f ms  %.1f TF (%d tiles, %d rounds)\n", which == 2 ? "f8" : which ? "q4" : "pp", it, ms, 2.0 * m.M * K * 9 * C / ms / 1e9, tiles, rounds);
     }
