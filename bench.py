@@ -102,6 +102,61 @@ def tune_rcnn_for_pseudo_labels(trainer, batch, target_std=8.0, bg_bias=0.0):
     m.store.touch()
 
 
+class BoardPower:
+    """Board power over the timed region: amdgpu hwmon power1_average / power1_input of EVERY card at ~25 Hz from a thread (a one-GPU
+    lease on an eight-GPU host still shows all eight in sysfs: the card under test is the one with the highest mean) and the cap
+    (power1_cap).  The step's MFMA kernels run at the board's power limit, which holds the shader clock below the 2.4 GHz the
+    datasheet peak is quoted at (profiles/r05_power_probe.txt, r05_pp_power.txt, r05_mfma_peak.txt) - this is the live figure."""
+
+    def __init__(self):
+        import glob
+        self.files = []
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            for leaf in ("power1_average", "power1_input"):
+                if os.path.exists(os.path.join(d, leaf)):
+                    self.files.append((os.path.join(d, leaf), os.path.join(d, "power1_cap")))
+                    break
+        self.rows, self._stop, self._t = [], False, None
+
+    @staticmethod
+    def _rd(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip()) / 1e6
+        except Exception:  # noqa: BLE001
+            return None
+
+    def start(self):
+        if not self.files:
+            return
+        import threading
+
+        def run():
+            while not self._stop:
+                self.rows.append([self._rd(pf) for pf, _ in self.files])
+                time.sleep(0.04)
+        self._t = threading.Thread(target=run, daemon=True)
+        self._t.start()
+
+    def stop(self):
+        if self._t is None:
+            return None
+        self._stop = True
+        self._t.join()
+        n = len(self.files)
+        means = []
+        for c in range(n):
+            v = [r[c] for r in self.rows if r[c] is not None]
+            means.append(sum(v) / len(v) if v else 0.0)
+        c = max(range(n), key=lambda i: means[i])
+        v = [r[c] for r in self.rows if r[c] is not None]
+        if not v:
+            return None
+        return {"mean_w": means[c], "max_w": max(v), "last_w": v[-1], "cap_w": self._rd(self.files[c][1]), "samples": len(v),
+                "source": self.files[c][0], "note": "busiest card's hwmon power over the timed region (the sensor averages over ~1 s: "
+                "`last_w` / `max_w` are the settled readings of a sub-second region)"}
+
+
 class ConvTimer:
     """HIP-event timing (torch events recorded on the stream the kernels are launched on) of every launch of the
     dominant kernel inside the timed region.  Dominant kernel (largest share of GPU time in profiles/): the multi-level
@@ -686,12 +741,16 @@ def worker(args):
     sync()
     timer.enabled = wtimer.enabled = True
     n0 = calls.n
+    power = BoardPower() if rank == 0 else None
+    if power is not None:
+        power.start()
     t0_ = time.perf_counter()
     for _ in range(args.steps):
         tr.run_step_full_semisup(); tr.iter += 1
     t_host = time.perf_counter() - t0_      # the host has enqueued every step (it runs ahead of the GPU)
     sync()
     dt = time.perf_counter() - t0_
+    board_power = power.stop() if power is not None else None
     timer.enabled = wtimer.enabled = False
     # shader clock the chip sustained under the last multi-level (tower / RPN head) launch of the 256-tile conv kernel inside the timed
     # region (utv2_conv_clock_probe: s_memtime against the 100 MHz real-time counter over workgroup 0's lifetime)
@@ -977,6 +1036,8 @@ def worker(args):
                 out["roofline"]["peak_at_sustained_clock"] = peak * g / 2.4
                 out["roofline"]["frac_of_peak_at_sustained_clock"] = conv["tflops"] / (peak * g / 2.4)
                 out["roofline"]["clock_probe"] = "utv2_conv_clock_probe: s_memtime ticks per 10 ns s_memrealtime tick over the lifetime (%.0f us) of workgroup 0 of the last multi-level 256-tile launch of the timed region" % clock_ghz["workgroup_lifetime_us"]
+            if board_power:
+                out["roofline"]["board_power"] = board_power
             if conv_x:
                 out["roofline"]["exclusive"] = {"achieved": conv_x["tflops"], "frac": conv_x["tflops"] / peak, "avg_us": conv_x["avg_us"],
                                                 "launches": conv_x["launches"],

@@ -29,17 +29,22 @@ def rd(p):
 
 
 class Sampler(threading.Thread):
-    def __init__(self, d):
+    """samples EVERY card's hwmon (a one-GPU lease on an eight-GPU host still shows all eight in sysfs; the card under test is the
+    one whose power moves with the load - picked per phase as the card with the highest mean power)"""
+
+    def __init__(self, dirs):
         super().__init__(daemon=True)
-        self.d, self.stop, self.rows = d, False, []
+        self.dirs, self.stop, self.rows = dirs, False, []
+        self.files = []
+        for d in dirs:
+            pf = os.path.join(d, "power1_average")
+            if not os.path.exists(pf):
+                pf = os.path.join(d, "power1_input")
+            self.files.append((pf, os.path.join(d, "freq1_input")))
 
     def run(self):
-        pf = os.path.join(self.d, "power1_average")
-        if not os.path.exists(pf):
-            pf = os.path.join(self.d, "power1_input")
-        ff = os.path.join(self.d, "freq1_input")
         while not self.stop:
-            self.rows.append((time.time(), rd(pf), rd(ff)))
+            self.rows.append((time.time(), [(rd(pf), rd(ff)) for pf, ff in self.files]))
             time.sleep(0.02)
 
 
@@ -53,7 +58,7 @@ def smi():
 
 def phase(name, fn, dirs):
     fn(); torch.cuda.synchronize()
-    s = Sampler(dirs[0]) if dirs else None
+    s = Sampler(dirs) if dirs else None
     if s:
         s.start()
     t0 = time.time(); n = 0
@@ -73,11 +78,18 @@ def phase(name, fn, dirs):
     if s:
         s.stop = True; s.join()
         rows = [r for r in s.rows if r[0] - t0 > SECS * 0.4]  # the settled part
-        pw = [r[1] for r in rows if r[1] is not None]; fq = [r[2] for r in rows if r[2] is not None]
+        means = []
+        for ci in range(len(dirs)):
+            pw = [r[1][ci][0] for r in rows if r[1][ci][0] is not None]
+            means.append(sum(pw) / len(pw) / 1e6 if pw else 0.0)
+        ci = max(range(len(dirs)), key=lambda i: means[i])
+        pw = [r[1][ci][0] for r in rows if r[1][ci][0] is not None]; fq = [r[1][ci][1] for r in rows if r[1][ci][1] is not None]
+        rec["card"] = dirs[ci].split("/")[4]
+        rec["all_cards_power_w_mean"] = [round(m, 1) for m in means]
         if pw:
             rec["power_w_mean"] = sum(pw) / len(pw) / 1e6; rec["power_w_max"] = max(pw) / 1e6
         if fq:
-            rec["sclk_mhz_mean"] = sum(fq) / len(fq) / 1e6; rec["sclk_mhz_min"] = min(fq) / 1e6
+            rec["sclk_mhz_mean"] = sum(fq) / len(fq) / 1e6; rec["sclk_mhz_min"] = min(fq) / 1e6; rec["sclk_mhz_max"] = max(fq) / 1e6
         rec["samples"] = len(rows)
     elif mid is not None:
         rec["rocm_smi"] = mid

@@ -72,6 +72,26 @@ __device__ __forceinline__ void ml_decode16(const LevelTab& lt, int m, int& pixb
   pixbase = lt.start[l] + n * hw;
 }
 
+// Matrix-pipe priority (round 5).  Two waves of one SIMD that both have 32x32x16 MFMAs ready are served alternately by the issue
+// arbiter, and alternating costs the pipe a third of its rate: a register-only MFMA loop sustains 0.95 of the issue ceiling with one
+// wave per SIMD, 0.69-0.72 with two (same workgroup or two workgroups per CU), and 0.93-0.94 again when each wave raises its
+// priority for its own burst (tools/probe/mfma_peak.hip, profiles/r05_mfma_peak2.txt).  The kernels whose waves run their MFMA
+// bursts unsynchronised (the 128-tile forward / dgrad kernel and both weight-gradient kernels; NOT the ping-pong kernel, whose
+// barriers give each wave of a SIMD the pipe in turn) bracket every burst with s_setprio.  -DUTV2_MFMA_PRIO=0 builds without it.
+#ifndef UTV2_MFMA_PRIO
+#define UTV2_MFMA_PRIO 1
+#endif
+#if UTV2_MFMA_PRIO && defined(UTV2_MFMA_PRIO_LOOSE)
+#define MFMA_BURST_BEGIN __builtin_amdgcn_s_setprio(UTV2_MFMA_PRIO)
+#define MFMA_BURST_END __builtin_amdgcn_s_setprio(0)
+#elif UTV2_MFMA_PRIO
+#define MFMA_BURST_BEGIN __builtin_amdgcn_s_setprio(UTV2_MFMA_PRIO); __builtin_amdgcn_sched_barrier(0)
+#define MFMA_BURST_END __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0)
+#else
+#define MFMA_BURST_BEGIN
+#define MFMA_BURST_END
+#endif
+
 template <int BN, bool ML, typename TI, typename TO>
 __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgs16 p) {
   constexpr bool IN16 = sizeof(TI) == 2;
@@ -568,10 +588,12 @@ __global__ __launch_bounds__(256, TALL ? 3 : ((BK == 32 && BN != 96) ? 4 : 2)) v
       for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8_t*)(ab + i * 32 * ROWB + koff[s]);
 #pragma unroll
       for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8_t*)(bb + j * 32 * ROWB + koff[s]);
+      MFMA_BURST_BEGIN;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x16(b[j], a[i], acc[i][j]);   // operands swapped: TRANSPOSED blocks (epilogue_rows<.., TR>)
+      MFMA_BURST_END;
 #pragma unroll
       for (int q = s * NP / KS; q < (s + 1) * NP / KS; ++q) {
         if constexpr (STORE) store_piece(buf ^ 1, q);
@@ -999,8 +1021,9 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
   i32x4 fa[2][TM], fb[2][TN];
 #if defined(UTV2_PP_TRACE) && defined(PP_NO_READ)
   for (int ks = 0; ks < 2; ++ks) {
-    for (int i = 0; i < TM; ++i) fa[ks][i] = i32x4{lane, 1, 2, 3};
-    for (int j = 0; j < TN; ++j) fb[ks][j] = i32x4{lane, 1, 2, 3};
+    // fp16 / bf16-plausible bit patterns (activations: half of the values zero; weights: all non-zero) - the matrix pipe's power depends on its data
+    for (int i = 0; i < TM; ++i) fa[ks][i] = i32x4{0x3c003a00 + lane * 0x00010003 + i, 0x00003d00 + lane, (0x3e00 + 37 * lane) << 16, 0x3b803c80 ^ (lane << 3)};
+    for (int j = 0; j < TN; ++j) fb[ks][j] = i32x4{0x3a10b9f0 + lane * 0x00030001 + j, (int)0xb8c03b40 ^ lane, 0x39e0ba20 + lane * 5, (int)0xbb003900 ^ (lane << 2)};
   }
 #endif
   unsigned aa0, aa1, bb0, bb1;
@@ -1035,8 +1058,12 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           // operands swapped: acc[i][j] is the TRANSPOSED block (rows = channels, columns = pixels), see epilogue_rows<.., TR>
+#if defined(UTV2_PP_TRACE) && defined(PP_NO_MFMA)
+          asm volatile("" : "+v"(acc[i][j]) : "v"(fb[ks][j]), "v"(fa[ks][i]));   // tools/probe/pp_power.hip: the slot without its matrix instructions
+#else
           acc[i][j] = mfma_32x32x16(__builtin_bit_cast(bf16x8_t, fb[ks][j]), __builtin_bit_cast(bf16x8_t, fa[ks][i]),
                                                               acc[i][j]);
+#endif
           const int n = (ks * TM + i) * TN + j;
           if ((n & 3) == 2) {
             __builtin_amdgcn_sched_barrier(0);
@@ -1677,10 +1704,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(Wgrad16Args p) {
           b[i][e] = b0[e]; b[i][4 + e] = b1[e];
         }
       }
+      MFMA_BURST_BEGIN;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16(a[i], b[j], acc[i][j]);
+      MFMA_BURST_END;
       // s = 0: the im2col pieces (they consume the rowinfo registers), s = 1: the dY pieces, then the next geometry
 #pragma unroll
       for (int q = (s == 0 ? 2 : 0); q < (s == 0 ? 4 : 2); ++q) {
@@ -1922,10 +1951,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { b[j][e] = lo[e]; b[j][4 + e] = hi[e]; }
       }
+      MFMA_BURST_BEGIN;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16(a[i], b[j], acc[i][j]);
+      MFMA_BURST_END;
     };
     if constexpr (SET == 0) bsrc0(ch + 1); else bsrc1(ch + 1);
     // k16 step s: [fragments of step s have landed] -> issue the reads of step s+1 -> 8 MFMAs -> memory work of the next chunks
