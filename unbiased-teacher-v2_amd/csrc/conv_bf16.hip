@@ -72,14 +72,17 @@ __device__ __forceinline__ void ml_decode16(const LevelTab& lt, int m, int& pixb
   pixbase = lt.start[l] + n * hw;
 }
 
-// Matrix-pipe priority (round 5).  Two waves of one SIMD that both have 32x32x16 MFMAs ready are served alternately by the issue
-// arbiter, and alternating costs the pipe a third of its rate: a register-only MFMA loop sustains 0.95 of the issue ceiling with one
-// wave per SIMD, 0.69-0.72 with two (same workgroup or two workgroups per CU), and 0.93-0.94 again when each wave raises its
-// priority for its own burst (tools/probe/mfma_peak.hip, profiles/r05_mfma_peak2.txt).  The kernels whose waves run their MFMA
-// bursts unsynchronised (the 128-tile forward / dgrad kernel and both weight-gradient kernels; NOT the ping-pong kernel, whose
-// barriers give each wave of a SIMD the pipe in turn) bracket every burst with s_setprio.  -DUTV2_MFMA_PRIO=0 builds without it.
+// Matrix-pipe priority (round 5; measured, OFF by default).  Two waves of one SIMD that both have 32x32x16 MFMAs ready are served
+// alternately by the issue arbiter, and alternating costs the pipe a third of its rate: a register-only MFMA loop sustains 0.95 of the
+// issue ceiling with one wave per SIMD, 0.69-0.72 with two (same workgroup or two workgroups per CU), and 0.93-0.94 again when each
+// wave raises its priority for its own burst (tools/probe/mfma_peak.hip, profiles/r05_mfma_peak2.txt).  The kernels whose waves run
+// their MFMA bursts unsynchronised (the 128-tile forward / dgrad kernel and both weight-gradient kernels; NOT the ping-pong kernel,
+// whose barriers give each wave of a SIMD the pipe in turn) can bracket every burst with s_setprio: -DUTV2_MFMA_PRIO=1|3
+// (-DUTV2_MFMA_PRIO_LOOSE: without the scheduling fences around the burst).  In the real kernels it buys nothing - their waves wait on
+// LDS / global data far more often than on each other's matrix instructions: per-shape replay of a whole step 21.4 ms (off) against
+// 21.7-22.0 (three variants), step 338.5 img/s (off) against 337.1-337.6 over three interleaved runs (profiles/r05_prio_ab.txt).
 #ifndef UTV2_MFMA_PRIO
-#define UTV2_MFMA_PRIO 1
+#define UTV2_MFMA_PRIO 0
 #endif
 #if UTV2_MFMA_PRIO && defined(UTV2_MFMA_PRIO_LOOSE)
 #define MFMA_BURST_BEGIN __builtin_amdgcn_s_setprio(UTV2_MFMA_PRIO)
