@@ -2,7 +2,7 @@
 # Round measurement of record (run on the GPU box through gpurun): bench lines, kernel traces, PMC passes for the FCOS (headline) and the
 # Faster-RCNN step.  usage: tools/measure_record.sh <tag>     outputs -> gpurun_out/<tag>_*
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$PWD
 mkdir -p gpurun_out
 # the default FCOS run is the fp16 AMP mode (the reference's own autocast type) since round 3; file names keep the "4p4_bf16" stem of the
