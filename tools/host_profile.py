@@ -1,5 +1,6 @@
 """Where does the HOST spend its time enqueuing one UTv2 step?  cProfile over K steps at benchmark size with the GPU left to run behind
-(no sync inside the window), sorted by own time.   python tools/host_profile.py [fcos|rcnn] [K]"""
+(no sync inside the window), sorted by own time.   python tools/host_profile.py [fcos|rcnn] [K] [images per list, default 4] [small]
+`small`: 96 x 128 images - the GPU work is negligible, the step time IS the Python / launch cost (bench.py host.ms_per_step_on_96x128_images)"""
 import cProfile
 import os
 import pstats
@@ -15,10 +16,16 @@ from ubteacher.presets import get_config
 
 model = sys.argv[1] if len(sys.argv) > 1 else "fcos"
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-cfg = get_config(model, 1, ["SOLVER.IMG_PER_BATCH_LABEL", 4, "SOLVER.IMG_PER_BATCH_UNLABEL", 4, "SEMISUPNET.BURN_UP_STEP", 0,
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+small = len(sys.argv) > 4 and sys.argv[4] == "small"
+cfg = get_config(model, 1, ["SOLVER.IMG_PER_BATCH_LABEL", B, "SOLVER.IMG_PER_BATCH_UNLABEL", B, "SEMISUPNET.BURN_UP_STEP", 0,
                             "SOLVER.AMP.ENABLED", True, "MODEL.DEVICE", "cuda"])
 torch.manual_seed(0)
-tr = (UBRCNNTeacherTrainer if model == "rcnn" else UBTeacherTrainer)(cfg)
+loader = None
+if small:
+    from ubteacher.data.synthetic import SyntheticTwoCropLoader
+    loader = SyntheticTwoCropLoader(cfg, height=96, width=128)
+tr = (UBRCNNTeacherTrainer if model == "rcnn" else UBTeacherTrainer)(cfg, data_loader=loader)
 (bench.tune_rcnn_for_pseudo_labels if model == "rcnn" else bench.tune_for_pseudo_labels)(tr, tr._data_loader.batches[0])
 tr.iter = 1; tr.log_period = 10 ** 9
 for g in tr.optimizer.param_groups:
