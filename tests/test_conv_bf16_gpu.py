@@ -583,7 +583,9 @@ def test_big_tile_kernels_bit_identical_across_schedules(tmp_path):
     run({"UTV2_W8": "0"}, "save", ref)
     # ... and the epilogue's branch-free plain path (default) stores the same bits as the general one (UTV2_EPI_PLAIN=0), GroupNorm
     # partial sums and ReLU bit planes included
-    for env in ({"UTV2_PP": "0"}, {"UTV2_PP": "1"}, {}, {"UTV2_EPI_PLAIN": "0"}, {"UTV2_EPI_PLAIN": "0", "UTV2_W8": "0"}):
+    # (the default 3x3 path is the row-span form conv_igemm_bf16_rs since round 5; UTV2_PP_RS=0: the ping-pong kernel it derives from)
+    for env in ({"UTV2_PP": "0"}, {"UTV2_PP": "1"}, {"UTV2_PP": "1", "UTV2_PP_RS": "0"}, {}, {"UTV2_PP_RS": "0"}, {"UTV2_EPI_PLAIN": "0"},
+                {"UTV2_EPI_PLAIN": "0", "UTV2_W8": "0"}):
         lines = [ln for ln in run(env, "cmp", ref).splitlines() if ln.strip()]
         assert len(lines) == 12 and all("bit-identical" in ln and "nan" not in ln for ln in lines), lines
 

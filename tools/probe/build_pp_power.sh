@@ -11,5 +11,7 @@ b mfmaonly "-DPP_NO_DMA -DPP_NO_READ"
 b dmaonly "-DPP_NO_MFMA -DPP_NO_READ"
 b readonly "-DPP_NO_MFMA -DPP_NO_DMA"
 b skeleton "-DPP_NO_MFMA -DPP_NO_DMA -DPP_NO_READ"
+b a3 "-DPP_A_EVERY=3"
+b a9 "-DPP_A_EVERY=9"
 wait
 ls -la pp_power_*

@@ -117,6 +117,8 @@ int main(int argc, char** argv) {
       "no MFMA, no reads (DMA + epilogue)";
 #elif defined(PP_NO_DMA) && defined(PP_NO_READ)
       "MFMA only (no DMA, no reads)";
+#elif defined(PP_A_EVERY)
+      PP_A_EVERY == 3 ? "im2col DMA for 1 tap in 3 (row-span emulation)" : "im2col DMA for 1 tap in 9 (halo-patch emulation)";
 #elif defined(PP_NO_MFMA)
       "no MFMA";
 #elif defined(PP_NO_DMA)

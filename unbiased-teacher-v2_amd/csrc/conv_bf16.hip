@@ -52,6 +52,7 @@ struct ConvArgs16 {
   float* gn_part;            // optional: per (32-row block, 8-channel group) sum / sum of squares of the stored output (see epilogue_rows)
   int ntiles;                // conv_igemm_bf16_pp as a persistent grid: total tiles (0 = one tile per workgroup)
   EpiBits bits;              // optional ReLU bit planes (see epilogue_rows): written from / read in place of 16-bit sign tensors
+  int mtot;                  // conv_igemm_bf16_rs: rows of x / rowinfo (>= M: a launch may cover a row range of the matrix)
   const int2* rowinfo;       // optional: per OUTPUT row m {input pixel index of tap (0,0), (W << 16) | tap-validity mask} - the table the weight
                              // gradient kernels read (utv2_conv2d_wgrad_bf16): the tile prologue then loads its rows' geometry instead of
                              // decoding it (level search, two integer divisions and a KH x KW bounds loop per staged row: 2.0-2.2 us of a
@@ -1009,6 +1010,11 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
   };
   auto issue_piece = [&](int stage, int sg, int q) {
     unsigned char* d = dma_row + stage * STAGE + sg * OPSEG + (q >> 1) * OPB + (q & 1) * 16 * SEGB;
+#if defined(UTV2_PP_TRACE) && defined(PP_A_EVERY)
+    // tools/probe/pp_power.hip: what an LDS-resident input span would save at best - the im2col pieces only for one tap in PP_A_EVERY
+    // (3: one row span per kernel row serves its three taps; 9: a patch with halo serves all nine).  Garbage results: timing / power only
+    if (q < 2 && (utap % PP_A_EVERY) != PP_A_EVERY / 2) return;
+#endif
     __builtin_amdgcn_global_load_lds((gptr_t)psrc[q], (lptr_t)d, 16, 0, 0);
   };
 
@@ -1215,6 +1221,325 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row-span form of the ping-pong kernel (round 5): 3x3, stride 1, rowinfo given.  The three taps of one kernel ROW read the same
+// input pixels shifted by one column, so the im2col operand of (64-channel chunk, kh) is staged ONCE as a span of 258 consecutive
+// rows (span row s = the centre-column pixel of output row m0 - 1 + s) and tap kw reads span rows r + kw: a third of the kernel's
+// im2col LDS-DMA traffic.  Why it pays on a power-capped board: the global -> LDS DMA is 27 % of a tile's energy; the
+// shipped kernel with its im2col pieces issued for one tap in three (timing build, garbage results) ran 0.582 -> 0.511 ms on the
+// student's paired tower launch (profiles/r05_pp_power_span.txt).
+//   * LDS: [2 group buffers][2 segments][272 span rows][64 B] (17 pieces of 16 rows; rows 258.. are never read) | the ping-pong
+//     kernel's ring of B segments [2 stages][2 segments][256][64 B] | 64 zero bytes.  Same source-side swizzle: the 16-byte k-slot q of
+//     LDS row s lives at slot q ^ ((s >> 2) & 3) - a function of the LDS row, so a fragment read that starts one row up or down stays
+//     conflict-free (any 8 consecutive rows cover all 64 banks).
+//   * Column borders: output pixel x = 0 / W-1 must read zeros for kw = 0 / 2 where the span holds the neighbouring image row's
+//     pixel: the lane's fragment address is switched to the zero bytes (tap-validity bits of the lane's four rows from rowinfo).  Row
+//     borders (kh) stay where they were: the DMA source of a span row outside the image is the zero page.
+//   * Schedule, slots, barriers, MFMA order and the B stream are the ping-pong kernel's; results are BIT-IDENTICAL to it (same
+//     products in the same order).  The span of group g+1 (4 pieces per wave + one 16-row tail piece from waves 0 / 1) is issued in
+//     the COMPUTE slots of group g's first two taps; the counted vmcnt waits follow the per-slot piece counts (below).
+template <int N>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+
+template <bool ML, typename TO>
+__global__ __launch_bounds__(512) void conv_igemm_bf16_rs(ConvArgs16 p) {
+  const bool clk_on = ML && blockIdx.x == 0 && p.ntiles > 0;
+  unsigned long long clk_c0 = 0, clk_r0 = 0;
+  if (clk_on) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+  constexpr int BM = 256, BN = 256, SEGB = 64;
+  constexpr int OPSEG = 256 * SEGB;                                  // one B segment (16 KB)
+  constexpr int SPR = 272, ASEG = SPR * SEGB;                        // span rows / bytes of one span segment
+  constexpr int BOFF = 4 * ASEG, ZOFF = BOFF + 4 * OPSEG;            // A spans | B ring | zero bytes
+  constexpr int TM = 4, TN = 2;
+  constexpr int PATCH = 8 * 32 * (TN * 32 + 4) * 4;
+  static_assert(BOFF >= PATCH, "epilogue patches must fit the span buffers");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  if (tid < 16) ((unsigned*)(smem + ZOFF))[tid] = 0u;   // visible to every wave after the first tile's prologue barrier
+  const int tilesN = (p.K + BN - 1) / BN;
+  const int nwg = p.ntiles > 0 ? p.ntiles : (int)gridDim.x;
+  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+  int tile;
+  {
+    const int bid = vb, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int mt = tile / tilesN, nt = tile - mt * tilesN;
+  const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
+  const int prow = lane >> 2;
+  const int kslot = (lane & 3) ^ ((lane >> 4) & 3);
+  const int goff = p.groups > 1 ? (n0 / (p.K / p.groups)) * p.C : 0;
+
+  // DMA role: span rows 32 * wid + 16 * j + prow (j = 0, 1) and, for waves 0 / 1, tail rows 256 + prow; a span row is the centre-column
+  // pixel (+ p.xs) of output row m0 - 1 + s, valid for kernel row kh when that row's tap (kh, 1) is
+  int aoff[3], awc[3];
+  unsigned amask[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int s = j < 2 ? wid * 32 + j * 16 + prow : 256 + prow;
+    const int m = m0 - 1 + s;
+    const bool mv = (unsigned)m < (unsigned)p.mtot && (j < 2 || prow < 2);
+    const int2 ri = p.rowinfo[mv ? m : 0];
+    aoff[j] = (ri.x + 1) * p.xs + kslot * 8 + goff;
+    awc[j] = (ri.y >> 16) * p.xs;
+    amask[j] = mv ? (unsigned)(ri.y & 0xffff) : 0u;
+  }
+  int boff[2];
+  bool bvalid[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int co = n0 + wid * 32 + j * 16 + prow;
+    bvalid[j] = co < p.K;
+    boff[j] = (bvalid[j] ? co : 0) * p.Kred + kslot * 8;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const h16_t* __restrict__ xb = (const h16_t*)p.x;
+  const int ngroups = 3 * (p.C / 64);
+  // B cursor (the ping-pong kernel's, taps innermost) and span-group cursor (kernel rows innermost)
+  int kh = 0, kw = 0, c0 = 0, tap = 0, ub = 0;
+  auto cursor_next = [&]() {
+    ub = tap * p.C + c0;
+    ++tap;
+    if (++kw == 3) {
+      kw = 0;
+      if (++kh == 3) { kh = 0; tap = 0; c0 += 64; }
+    }
+  };
+  int gkh = 0, gc0 = 0, lkh = 0, lc0 = 0;
+  auto group_next = [&]() {
+    lkh = gkh;
+    lc0 = gc0;
+    if (++gkh == 3) { gkh = 0; gc0 += 64; }
+  };
+  const h16_t* zero = (const h16_t*)g_zero64;
+  unsigned char* const dma_row = smem + (wid * 32) * SEGB;  // wave-uniform (M0)
+  const h16_t* psrcb[2];
+  const h16_t* psrca;
+  auto prep_b = [&](int sg) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) psrcb[j] = bvalid[j] ? p.w + (unsigned)(boff[j] + ub + sg * 32) : zero;
+  };
+  auto prep_a = [&](int j, int sg) {   // piece (j = 0, 1: the wave's rows; 2: tail rows) of segment sg of the latched group
+    psrca = ((amask[j] >> (lkh * 3 + 1)) & 1u) ? xb + (unsigned)(aoff[j] + lkh * awc[j] + lc0 + sg * 32) : zero;
+  };
+  auto issue_a = [&](int gb, int sg, int j) {
+    unsigned char* d = (j < 2 ? dma_row + j * 16 * SEGB : smem + 256 * SEGB) + (gb * 2 + sg) * ASEG;
+    __builtin_amdgcn_global_load_lds((gptr_t)psrca, (lptr_t)d, 16, 0, 0);
+  };
+  auto issue_b = [&](int stage, int sg, int j) {
+    unsigned char* d = dma_row + BOFF + (stage * 2 + sg) * OPSEG + j * 16 * SEGB;
+    __builtin_amdgcn_global_load_lds((gptr_t)psrcb[j], (lptr_t)d, 16, 0, 0);
+  };
+
+  // fragment role
+  const int frow = lane & 31, fh = lane >> 5, fx = (frow >> 2) & 3;
+  const unsigned lbase = (unsigned)(size_t)(lptr_t)smem;
+  unsigned a_rel[3][2], b_addr[2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      a_rel[t][ks] = lbase + (wm * 128 + frow + t) * SEGB + (((ks * 2 + fh) ^ (((frow + t) >> 2) & 3)) << 4);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) b_addr[ks] = lbase + BOFF + (wn * 64 + frow) * SEGB + (((ks * 2 + fh) ^ fx) << 4);
+  const unsigned zaddr = lbase + ZOFF;
+  // bit i: kw = 0 readable for the lane's row of block i; bit 8 + i: kw = 2 (kw = 1 always is)
+  unsigned okm = 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int m = m0 + wm * 128 + i * 32 + frow;
+    m = m < p.mtot ? m : p.mtot - 1;
+    const int y = p.rowinfo[m].y;
+    okm |= (unsigned)((y >> 3) & 1) << i;
+    okm |= (unsigned)((y >> 5) & 1) << (8 + i);
+  }
+
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  i32x4 fa[2][TM], fb[2][TN];
+#define RS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define RS_WAIT_FRAGS                                                                                                         \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                                         \
+               : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), \
+                 "+v"(fa[1][3]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]))
+#define RS_BARRIER                          \
+  __builtin_amdgcn_sched_barrier(0);        \
+  __builtin_amdgcn_s_barrier();             \
+  __builtin_amdgcn_sched_barrier(0)
+  // LOAD slot: the 12 fragment reads of (group buffer gb, segment sg, tap column t) and B (stage, sg)
+  auto load_frags = [&](int gb, int sg, int t, int stage) {
+    const unsigned abase = (unsigned)((gb * 2 + sg) * ASEG), bbase = (unsigned)((stage * 2 + sg) * OPSEG);
+    const unsigned ok = t == 1 ? 15u : (t == 0 ? okm : okm >> 8);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const unsigned a0 = a_rel[t][ks] + abase;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const unsigned ai = ((ok >> i) & 1u) ? a0 + i * 2048 : zaddr;
+        RS_READ(fa[ks][i], ai, 0);
+      }
+      const unsigned bk = b_addr[ks] + bbase;
+      RS_READ(fb[ks][0], bk, 0);
+      RS_READ(fb[ks][1], bk, 2048);
+    }
+  };
+  // COMPUTE slot: 16 MFMAs; the span piece (if any) goes out behind the 3rd, the two B pieces behind the 7th and 11th
+  auto compute = [&](bool doa, int agb, int asg, int aj, bool dob, int bstage, int bsg) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = mfma_32x32x16(__builtin_bit_cast(bf16x8_t, fb[ks][j]), __builtin_bit_cast(bf16x8_t, fa[ks][i]), acc[i][j]);
+          const int n = (ks * TM + i) * TN + j;
+          if (n == 2 || n == 6 || n == 10) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (n == 2) { if (doa) issue_a(agb, asg, aj); }
+            else if (dob) issue_b(bstage, bsg, n == 6 ? 0 : 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+  };
+
+  // prologue: the spans of group 0 (buffer 0), B segments 0, 1 (chunk 0) and 2 (chunk 1)
+  group_next();
+#pragma unroll
+  for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { prep_a(j, sg); issue_a(0, sg, j); }
+  if (wid < 2) { prep_a(2, wid); issue_a(0, wid, 2); }
+  cursor_next();
+#pragma unroll
+  for (int sg = 0; sg < 2; ++sg) {
+    prep_b(sg);
+    issue_b(0, sg, 0);
+    issue_b(0, sg, 1);
+  }
+  cursor_next();
+  prep_b(0);
+  issue_b(1, 0, 0);
+  issue_b(1, 0, 1);
+  vm_wait<0>();
+  RS_BARRIER;
+
+  // One group = 3 chunks (kw = 0, 1, 2) x 2 segments = slots p = 0..5.  Pieces a wave issues in COMPUTE(p) of a group that has a
+  // successor: p 0..3: 1 span piece + 2 B pieces, p 4, 5: 2 B pieces (+ the tail piece FIRST in p 4 on waves 0 / 1 - not counted: the
+  // waits below are then one piece stricter for those waves).  Waves 0-3 wait at the end of COMPUTE(p) for everything but the pieces of
+  // COMPUTE(p) and COMPUTE(p-1): vmcnt 5, 6, 6, 6, 5, 4; waves 4-7 (one slot behind) at the end of LOAD(p) for everything but COMPUTE(p-1)'s:
+  // 2, 3, 3, 3, 3, 2.  The last group issues no span pieces and runs the ping-pong kernel's end game with its B-only counts.
+#define RS_SLOT_G0(P, KW, SG, MOREG, WAITN)                                                                   \
+  {                                                                                                           \
+    load_frags(gb, SG, KW, st);                                                                               \
+    if (SG == 0) { prep_b(1); } else { cursor_next(); prep_b(0); }                                            \
+    if (MOREG) { if (P < 4) prep_a(P & 1, P >> 1); else if (P == 4 && wid < 2) prep_a(2, wid); }              \
+    RS_WAIT_FRAGS;                                                                                            \
+    RS_BARRIER;                                                                                               \
+    compute(MOREG && (P < 4 || (P == 4 && wid < 2)), gb ^ 1, P < 4 ? (P >> 1) : wid, P < 4 ? (P & 1) : 2, true, SG == 0 ? (st ^ 1) : st, SG == 0 ? 1 : 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    vm_wait<WAITN>();                                                                                         \
+    RS_BARRIER;                                                                                               \
+  }
+#define RS_SLOT_G1(P, KW, SG, MOREG, WAITN)                                                                   \
+  {                                                                                                           \
+    load_frags(gb, SG, KW, st);                                                                               \
+    if (SG == 0) { prep_b(1); } else { cursor_next(); prep_b(0); }                                            \
+    if (MOREG) { if (P < 4) prep_a(P & 1, P >> 1); }                                                          \
+    RS_WAIT_FRAGS;                                                                                            \
+    vm_wait<WAITN>();                                                                                         \
+    RS_BARRIER;                                                                                               \
+    compute(MOREG && P < 4, gb ^ 1, P >> 1, P & 1, true, SG == 0 ? (st ^ 1) : st, SG == 0 ? 1 : 0);            \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    RS_BARRIER;                                                                                               \
+  }
+  if (wm == 0) {
+    int g = 0;
+    for (; g + 1 < ngroups; ++g) {
+      const int gb = g & 1;
+      int st = g & 1;                 // chunk 3g + kw: stage (3g + kw) & 1 = (g + kw) & 1
+      group_next();
+      RS_SLOT_G0(0, 0, 0, true, 5) RS_SLOT_G0(1, 0, 1, true, 6)
+      st ^= 1;
+      RS_SLOT_G0(2, 1, 0, true, 6) RS_SLOT_G0(3, 1, 1, true, 6)
+      st ^= 1;
+      RS_SLOT_G0(4, 2, 0, true, 5) RS_SLOT_G0(5, 2, 1, true, 4)
+    }
+    {  // last group: chunks nchunks-3 .. nchunks-1
+      const int gb = g & 1;
+      int st = g & 1;
+      RS_SLOT_G0(0, 0, 0, false, 4) RS_SLOT_G0(1, 0, 1, false, 4)
+      st ^= 1;
+      // chunk nchunks-2: its first COMPUTE still sends (last chunk, segment 1), its second has nothing left to send
+      load_frags(gb, 0, 1, st); prep_b(1); RS_WAIT_FRAGS; RS_BARRIER;
+      compute(false, 0, 0, 0, true, st ^ 1, 1); __builtin_amdgcn_sched_barrier(0); vm_wait<4>(); RS_BARRIER;
+      load_frags(gb, 1, 1, st); RS_WAIT_FRAGS; RS_BARRIER;
+      compute(false, 0, 0, 0, false, 0, 0); __builtin_amdgcn_sched_barrier(0); vm_wait<2>(); RS_BARRIER;
+      st ^= 1;
+      load_frags(gb, 0, 2, st); RS_WAIT_FRAGS; RS_BARRIER;
+      compute(false, 0, 0, 0, false, 0, 0); __builtin_amdgcn_sched_barrier(0); vm_wait<0>(); RS_BARRIER;
+      load_frags(gb, 1, 2, st); RS_WAIT_FRAGS; RS_BARRIER;
+      compute(false, 0, 0, 0, false, 0, 0); __builtin_amdgcn_sched_barrier(0); RS_BARRIER;
+    }
+    RS_BARRIER;
+  } else {
+    RS_BARRIER;
+    int g = 0;
+    for (; g + 1 < ngroups; ++g) {
+      const int gb = g & 1;
+      int st = g & 1;
+      group_next();
+      RS_SLOT_G1(0, 0, 0, true, 2) RS_SLOT_G1(1, 0, 1, true, 3)
+      st ^= 1;
+      RS_SLOT_G1(2, 1, 0, true, 3) RS_SLOT_G1(3, 1, 1, true, 3)
+      st ^= 1;
+      RS_SLOT_G1(4, 2, 0, true, 3) RS_SLOT_G1(5, 2, 1, true, 2)
+    }
+    {
+      const int gb = g & 1;
+      int st = g & 1;
+      RS_SLOT_G1(0, 0, 0, false, 2) RS_SLOT_G1(1, 0, 1, false, 2)
+      st ^= 1;
+      load_frags(gb, 0, 1, st); prep_b(1); RS_WAIT_FRAGS; vm_wait<2>(); RS_BARRIER;
+      compute(false, 0, 0, 0, true, st ^ 1, 1); __builtin_amdgcn_sched_barrier(0); RS_BARRIER;
+      load_frags(gb, 1, 1, st); RS_WAIT_FRAGS; vm_wait<2>(); RS_BARRIER;
+      compute(false, 0, 0, 0, false, 0, 0); __builtin_amdgcn_sched_barrier(0); RS_BARRIER;
+      st ^= 1;
+      load_frags(gb, 0, 2, st); RS_WAIT_FRAGS; vm_wait<0>(); RS_BARRIER;
+      compute(false, 0, 0, 0, false, 0, 0); __builtin_amdgcn_sched_barrier(0); RS_BARRIER;
+      load_frags(gb, 1, 2, st); RS_WAIT_FRAGS; RS_BARRIER;
+      compute(false, 0, 0, 0, false, 0, 0); __builtin_amdgcn_sched_barrier(0); RS_BARRIER;
+    }
+  }
+#undef RS_SLOT_G0
+#undef RS_SLOT_G1
+#undef RS_READ
+#undef RS_WAIT_FRAGS
+#undef RS_BARRIER
+  __syncthreads();
+
+  float* patch = (float*)smem + wid * (32 * (TN * 32 + 4));
+  epilogue_rows<TN, TO, true, true>(*(const f32x16(*)[2][TN]) & acc[0], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
+                        p.relu, p.accumulate, m0 + wm * 128, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
+  epilogue_rows<TN, TO, true, true>(*(const f32x16(*)[2][TN]) & acc[2], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
+                        p.relu, p.accumulate, m0 + wm * 128 + 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
+  __syncthreads();   // persistent grid: every wave is done with its epilogue patch before the next tile's first DMA pieces land there
+  }
+  if (clk_on && threadIdx.x == 0) {
+    g_pp_clock[0] = __builtin_amdgcn_s_memtime() - clk_c0;
+    g_pp_clock[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+  }
+}
+
 // A/B switches for bench runs and tests, read ONCE per process (never on the launch path): UTV2_W8=0 keeps every forward / dgrad
 // row on the 128 x 128 kernel, UTV2_WGRAD_W8=0 keeps every wgrad on the 128 x 128 kernel.
 static bool env_flag_on(const char* name) {
@@ -1264,7 +1589,17 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
           int grid = main_m * tilesN;
           static const int pp_wgs = [] { int v = env_int("UTV2_PP_WGS", 256); return v < 8 ? 8 : (v > 256 ? 256 : v / 8 * 8); }();   // A/B: CUs the persistent grid takes
           if (g_use_pp == 2 && grid > 256) { m.ntiles = grid; grid = pp_wgs; }
-          if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, h16_t>), dim3(grid), dim3(512), smem, stream, m);
+          // 3x3 stride-1 layers with the per-row geometry table: the row-span form (a third of the im2col DMA; bit-identical results)
+          static const bool use_rs = env_int("UTV2_PP_RS", 1) != 0;
+          // ("same" geometry only: the column neighbour of an output pixel must be the centre pixel of the neighbouring output row index)
+          if (use_rs && a.rowinfo && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && (ML || (a.OH == a.H && a.OW == a.W))) {
+            const int smem_rs = 4 * 272 * 64 + 4 * 256 * 64 + 64;
+            static LdsOptIn rs_opt_in;
+            rs_opt_in({(const void*)conv_igemm_bf16_rs<ML, h16_t>, (const void*)conv_igemm_bf16_rs<ML, float>}, smem_rs);
+            m.mtot = a.M;
+            if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_rs<ML, h16_t>), dim3(grid), dim3(512), smem_rs, stream, m);
+            else hipLaunchKernelGGL((conv_igemm_bf16_rs<ML, float>), dim3(grid), dim3(512), smem_rs, stream, m);
+          } else if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, h16_t>), dim3(grid), dim3(512), smem, stream, m);
           else hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, float>), dim3(grid), dim3(512), smem, stream, m);
         } else if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_w8<ML, h16_t>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
         else hipLaunchKernelGGL((conv_igemm_bf16_w8<ML, float>), dim3(main_m * tilesN), dim3(512), smem, stream, m);
