@@ -587,7 +587,7 @@ def test_big_tile_kernels_bit_identical_across_schedules(tmp_path):
     for env in ({"UTV2_PP": "0"}, {"UTV2_PP": "1"}, {"UTV2_PP": "1", "UTV2_PP_RS": "0"}, {}, {"UTV2_PP_RS": "0"}, {"UTV2_EPI_PLAIN": "0"},
                 {"UTV2_EPI_PLAIN": "0", "UTV2_W8": "0"}):
         lines = [ln for ln in run(env, "cmp", ref).splitlines() if ln.strip()]
-        assert len(lines) == 12 and all("bit-identical" in ln and "nan" not in ln for ln in lines), lines
+        assert len(lines) == 14 and all("bit-identical" in ln and "nan" not in ln for ln in lines), lines
 
 
 @pytest.mark.parametrize("dt", [torch.float32, BF])

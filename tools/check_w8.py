@@ -35,6 +35,14 @@ bias = torch.randn(256, device="cuda")
 part = hip.gn_part_buffer(P, 256, x.device)
 outs["ml_gn"] = hip.conv2d_ml_fwd_bf16(x, w16, level_hw, N, bias=bias, k=3, pad=1, gn_part=part)
 outs["ml_gn_part"] = part.clone()
+# the paired FCOS towers: grouped (2 x 256 -> 2 x 256) level-first conv with GroupNorm partials, 12 images (a persistent-grid launch)
+N2 = 12
+P2 = N2 * sum(h * w for h, w in level_hw)
+x2 = torch.relu(torch.randn(P2, 512, device="cuda")).to(BF)
+w2 = (torch.randn(512, 9 * 256, device="cuda") * 0.05).to(BF)
+part2 = hip.gn_part_buffer(P2, 512, x2.device)
+outs["ml_g2"] = hip.conv2d_ml_fwd_bf16(x2, w2, level_hw, N2, bias=torch.randn(512, device="cuda"), k=3, pad=1, groups=2, gn_part=part2)
+outs["ml_g2_part"] = part2.clone()
 bits = hip.relu_bits_buffer((8, 100, 100, 512), xn.device)
 outs["nb"] = hip.conv2d_fwd_bf16(xn, wn, scale=sc, bias=bi, stride=1, pad=1, relu=True, kh=3, kw=3, relu_bits=bits)
 outs["nb_bits"] = bits.clone()

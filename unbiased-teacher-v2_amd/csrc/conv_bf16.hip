@@ -1229,7 +1229,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
 // shipped kernel with its im2col pieces issued for one tap in three (timing build, garbage results) ran 0.582 -> 0.511 ms on the
 // student's paired tower launch (profiles/r05_pp_power_span.txt).
 //   * LDS: [2 group buffers][2 segments][272 span rows][64 B] (17 pieces of 16 rows; rows 258.. are never read) | the ping-pong
-//     kernel's ring of B segments [2 stages][2 segments][256][64 B] | 64 zero bytes.  Same source-side swizzle: the 16-byte k-slot q of
+//     kernel's ring of B segments [2 stages][2 segments][256][64 B] | 256 zero bytes.  Same source-side swizzle: the 16-byte k-slot q of
 //     LDS row s lives at slot q ^ ((s >> 2) & 3) - a function of the LDS row, so a fragment read that starts one row up or down stays
 //     conflict-free (any 8 consecutive rows cover all 64 banks).
 //   * Column borders: output pixel x = 0 / W-1 must read zeros for kw = 0 / 2 where the span holds the neighbouring image row's
@@ -1253,12 +1253,13 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_rs(ConvArgs16 p) {
   constexpr int TM = 4, TN = 2;
   constexpr int PATCH = 8 * 32 * (TN * 32 + 4) * 4;
   static_assert(BOFF >= PATCH, "epilogue patches must fit the span buffers");
+  static_assert(ZOFF % 256 == 0, "the zero bytes mirror the bank of the address they replace");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 2, wn = wid & 3;
-  if (tid < 16) ((unsigned*)(smem + ZOFF))[tid] = 0u;   // visible to every wave after the first tile's prologue barrier
+  if (tid < 64) ((unsigned*)(smem + ZOFF))[tid] = 0u;   // 256 zero bytes (ZOFF is 256-aligned); visible to every wave after the first tile's prologue barrier
   const int tilesN = (p.K + BN - 1) / BN;
   const int nwg = p.ntiles > 0 ? p.ntiles : (int)gridDim.x;
   for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
@@ -1379,13 +1380,14 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_rs(ConvArgs16 p) {
   // LOAD slot: the 12 fragment reads of (group buffer gb, segment sg, tap column t) and B (stage, sg)
   auto load_frags = [&](int gb, int sg, int t, int stage) {
     const unsigned abase = (unsigned)((gb * 2 + sg) * ASEG), bbase = (unsigned)((stage * 2 + sg) * OPSEG);
-    const unsigned ok = t == 1 ? 15u : (t == 0 ? okm : okm >> 8);
+    const unsigned ok = t == 1 ? 15u : (t == 0 ? okm : okm >> 8);   // (the selects cost 0.7 % of the launch: a timing build without them)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const unsigned a0 = a_rel[t][ks] + abase;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const unsigned ai = ((ok >> i) & 1u) ? a0 + i * 2048 : zaddr;
+        const unsigned an = a0 + i * 2048;
+        const unsigned ai = ((ok >> i) & 1u) ? an : zaddr + (an & 255u);   // zeros from the SAME banks: a masked lane adds no conflict
         RS_READ(fa[ks][i], ai, 0);
       }
       const unsigned bk = b_addr[ks] + bbase;
@@ -1403,7 +1405,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_rs(ConvArgs16 p) {
         for (int j = 0; j < TN; ++j) {
           acc[i][j] = mfma_32x32x16(__builtin_bit_cast(bf16x8_t, fb[ks][j]), __builtin_bit_cast(bf16x8_t, fa[ks][i]), acc[i][j]);
           const int n = (ks * TM + i) * TN + j;
-          if (n == 2 || n == 6 || n == 10) {
+          if (n == 2 || n == 6 || n == 10) {   // (the span piece LAST instead of first: same time, measured)
             __builtin_amdgcn_sched_barrier(0);
             if (n == 2) { if (doa) issue_a(agb, asg, aj); }
             else if (dob) issue_b(bstage, bsg, n == 6 ? 0 : 1);
@@ -1593,7 +1595,7 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
           static const bool use_rs = env_int("UTV2_PP_RS", 1) != 0;
           // ("same" geometry only: the column neighbour of an output pixel must be the centre pixel of the neighbouring output row index)
           if (use_rs && a.rowinfo && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && (ML || (a.OH == a.H && a.OW == a.W))) {
-            const int smem_rs = 4 * 272 * 64 + 4 * 256 * 64 + 64;
+            const int smem_rs = 4 * 272 * 64 + 4 * 256 * 64 + 256;
             static LdsOptIn rs_opt_in;
             rs_opt_in({(const void*)conv_igemm_bf16_rs<ML, h16_t>, (const void*)conv_igemm_bf16_rs<ML, float>}, smem_rs);
             m.mtot = a.M;
