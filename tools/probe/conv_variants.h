@@ -501,6 +501,9 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_f8(ConvArgs16 p) {
   // one k16 step: 8 MFMAs on fragment set S; filler n goes out right behind MFMA n
   auto step = [&](auto set_tag, auto&& filler) {
     constexpr int S = decltype(set_tag)::value;
+#ifdef F8_PRIO   // round 5: the wave keeps the matrix pipe for its step of 8 (two waves of a SIMD alternating 32x32x16 MFMAs lose a third of the pipe: mfma_peak.hip)
+    __builtin_amdgcn_s_setprio(F8_PRIO);
+#endif
     static_for8([&](auto n_) {
       constexpr int n = decltype(n_)::value, i = n >> 1, j = n & 1;
       // operands swapped: acc is the TRANSPOSED block (rows = channels, columns = pixels), see epilogue_rows<.., TR>
@@ -509,6 +512,9 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_f8(ConvArgs16 p) {
       filler(n_);
       F8_PIN;
     });
+#ifdef F8_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
   using set0 = std::integral_constant<int, 0>;
   using set1 = std::integral_constant<int, 1>;
