@@ -162,7 +162,8 @@ class ConvTimer:
     dominant kernel inside the timed region.  Dominant kernel (largest share of GPU time in profiles/): the multi-level
     3x3 implicit-GEMM conv of the shared FCOS towers - forward AND dgrad launches, 256 -> 256 channels over all five FPN
     levels of the student batch in one launch:
-        bf16: conv_igemm_bf16_pp<true,__bf16> on the whole rounds of 256 x 256 tiles + conv_igemm_bf16_v2<128,true,64,__bf16> on the
+        bf16: conv_igemm_bf16_rs<true,__bf16> (the row-span form of the ping-pong kernel, round 5; UTV2_PP_RS=0: conv_igemm_bf16_pp)
+              on the whole rounds of 256 x 256 tiles + conv_igemm_bf16_v2<128,true,64,__bf16> on the
               remaining output rows (two kernels, one C-ABI call = one timed launch)      f32: conv_igemm_f32<128,0,true>"""
 
     def __init__(self, dtype):
@@ -171,7 +172,8 @@ class ConvTimer:
         self.bf16 = dtype != "f32"      # a 16-bit MFMA mode (either type: the same kernels)
         self.entry = "conv2d_ml_fwd_bf16" if self.bf16 else "conv2d_ml_fwd"
         t16 = "_Float16" if dtype == "f16" else "__bf16"    # element type of the kernel library's 16-bit build (csrc/common.h h16_t)
-        self.kernel = ("conv_igemm_bf16_pp<true,%s>+conv_igemm_bf16_v2<128,true,64,%s>" % (t16, t16)) if self.bf16 else "conv_igemm_f32<128,0,true>"
+        big = "pp" if os.environ.get("UTV2_PP_RS", "1") == "0" else "rs"
+        self.kernel = ("conv_igemm_bf16_%s<true,%s>+conv_igemm_bf16_v2<128,true,64,%s>" % (big, t16, t16)) if self.bf16 else "conv_igemm_f32<128,0,true>"
 
     def install(self):
         from ubteacher import hip
@@ -594,9 +596,9 @@ def rcnn_subrecord(args, device_index, timer, steps=10, warmup=5, dtype="bf16"):
            "pseudo_boxes_last_step": None if lp is None else int(lp["valid"].sum()),
            "enqueue_ms_per_step": 1e3 * t_enq / steps}
     if conv:
-        out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_bf16_pp<true,__bf16>+conv_igemm_bf16_v2<128,true,64,__bf16> (RPN head 3x3 conv over p2-p6, fwd+dgrad launches)",
+        out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_bf16_rs<true,__bf16>+conv_igemm_bf16_v2<128,true,64,__bf16> (RPN head 3x3 conv over p2-p6, fwd+dgrad launches)",
                            "achieved": conv["tflops"], "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": conv["tflops"] / PEAK_BF16_MFMA_TFLOPS, "traffic": pmc_traffic("conv_igemm_bf16_pp<true,__bf16>+conv_igemm_bf16_v2<128,true,64,__bf16>", "rcnn"),
+                           "frac": conv["tflops"] / PEAK_BF16_MFMA_TFLOPS, "traffic": pmc_traffic("conv_igemm_bf16_rs<true,__bf16>+conv_igemm_bf16_v2<128,true,64,__bf16>", "rcnn"),
                            "algorithmic_bytes": conv["alg_bytes"], "launches": conv["launches"], "avg_us": conv["avg_us"]}
     del tr
     torch.cuda.empty_cache()

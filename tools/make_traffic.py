@@ -2,14 +2,16 @@
 (tools/rocpd_stats.py output) of one command.  FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: 16-byte-per-lane reads are
 counted at half their bytes on gfx950; our own gn_apply_relu, which reads exactly what it writes, shows FETCH = WRITE / 2).  Per kernel:
 HBM bytes per launch = 2 * FETCH + WRITE, GB/s = bytes / the kernel-trace average duration (the PMC passes themselves run slower).
-Two aggregate keys are what bench.py reads: the FCOS tower conv launch (conv_igemm_bf16_pp<true> on whole rounds of 256 x 256 tiles +
+Two aggregate keys are what bench.py reads: the FCOS tower conv launch (conv_igemm_bf16_rs<true> - before round 5 _pp<true> - on whole rounds of 256 x 256 tiles +
 conv_igemm_bf16_v2<128,true,64> on the remaining rows: one of each per launch) and the tower weight gradient (conv_wgrad_bf16_w8).
 usage: make_traffic.py FETCH.txt WRITE.txt KERNEL_STATS.txt OUT.json"""
 import json
 import sys
 
 # DF16b = __bf16 (libutv2_hip.so), DF16_ = _Float16 (libutv2_hip_f16.so: the same kernels on the fp16 build)
-TOWERS = [("_Z18conv_igemm_bf16_ppILb1EDF16%sEv10ConvArgs16" % t, "_Z18conv_igemm_bf16_v2ILi128ELb1ELi64EDF16%sEv10ConvArgs16" % t) for t in ("_", "b")]
+# (round 5: the multi-level 3x3 launches run on the row-span form conv_igemm_bf16_rs; earlier traces / UTV2_PP_RS=0: conv_igemm_bf16_pp)
+TOWERS = [("_Z18conv_igemm_bf16_%sILb1EDF16%sEv10ConvArgs16" % (k, t), "_Z18conv_igemm_bf16_v2ILi128ELb1ELi64EDF16%sEv10ConvArgs16" % t)
+          for k in ("rs", "pp") for t in ("_", "b")]
 WGRAD = "_Z18conv_wgrad_bf16_w811Wgrad16Args"
 
 
@@ -45,7 +47,7 @@ if TOWER[0] in fetch:
         "kernel": TOWER[0],
         "fetch_size_kib_per_launch": round(fk, 2), "write_size_kib_per_launch": round(wk, 2),
         "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0, "launches_in_pmc_run": n,
-        "covers": "conv_igemm_bf16_pp<true,__bf16> only (the whole rounds of 256x256 tiles of each launch)"}
+        "covers": "the 256-tile kernel only (conv_igemm_bf16_rs<true> / _pp<true>: the whole rounds of 256x256 tiles of each launch)"}
 kernels = {}
 for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch.get(k, (1, 0))[1] + write.get(k, (1, 0))[1])):
     nf, f = fetch.get(k, (0, 0.0))
