@@ -739,3 +739,30 @@ def test_fused_stem_pool_equals_stem_conv_then_maxpool(hw):
     t = F.max_pool2d(t, 3, 2, 1)
     assert relerr(y.float().permute(0, 3, 1, 2), t) < (2e-2 if h16 == torch.bfloat16 else 3e-3)
     assert torch.equal(y, hip.stem_pool_fwd_bf16(x4, w16s, sc, sh))
+
+
+@pytest.mark.parametrize("case", [(40, 300, 3, 128, 256), (48, 350, 2, 128, 256), (34, 1000, 1, 128, 256), (8, 37, 131, 192, 384), (3, 111, 107, 256, 512)])
+def test_row_span_kernel_on_narrow_and_ragged_geometry(case):
+    """conv_igemm_bf16_rs (round 5: one LDS-resident span of input rows per kernel row serves its three taps; column borders by switching
+    a lane's fragment address to zero bytes) on the geometries that stress exactly that: images 3, 2 and 1 pixels wide (every output
+    pixel sits on a column border; at W = 1 both side taps of every row are masked; a 256-row tile spans > 80 image rows and several
+    images), an odd number of span groups (C = 192: 9), K that is not a multiple of the 256-column tile (384), a ragged last row tile -
+    forward and dgrad, against an fp32 conv on the rounded operands.  (Bit-identity with the ping-pong and the 128-tile kernels on the
+    benchmark shapes: test_big_tile_kernels_bit_identical_across_schedules.)"""
+    from ubteacher import hip
+    N, H, W, C, K = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.relu(torch.randn(N, C, H, W, generator=g))
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.05
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda().to(BF)
+    w16 = w.permute(0, 2, 3, 1).reshape(K, -1).contiguous().cuda().to(BF)
+    y = hip.conv2d_fwd_bf16(xh, w16, stride=1, pad=1, kh=3, kw=3, out_dtype=BF)
+    ref = F.conv2d(r16(x), r16(w), None, 1, 1)
+    assert close16(y.cpu().permute(0, 3, 1, 2), ref)
+    # dgrad = the same kernel over dY with the flipped / transposed weights
+    dy = torch.randn(N, K, H, W, generator=g)
+    dyh = dy.permute(0, 2, 3, 1).contiguous().cuda().to(BF)
+    wt16 = hip.weight_flip_transpose_bf16(w.permute(0, 2, 3, 1).contiguous().cuda(), K, 3, 3, C)
+    dx = hip.conv2d_dgrad_bf16(dyh, wt16, (N, H, W, C), 1, 1, 3, 3, out_dtype=BF)
+    refd = F.conv_transpose2d(r16(dy), r16(w), None, 1, 1)
+    assert close16(dx.cpu().permute(0, 3, 1, 2), refd)
