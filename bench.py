@@ -288,6 +288,22 @@ def pmc_traffic(kernel, model="fcos"):
     return None
 
 
+def board_mfma_ceiling(dtype):
+    """What the matrix pipes of this board sustain at its 1400 W power cap with NOTHING else running: the register-only MFMA loop of
+    tools/probe/mfma_peak.hip (one wave per SIMD, the shipped kernels' 32x32x16 instruction, operand data with half of the A values zero
+    like post-ReLU activations), from the committed run profiles/r05_mfma_peak2.txt.  The datasheet peak (2.5 PFLOP/s) is only reached on
+    all-zero data; this figure is the practical ceiling the roofline fraction can be read against."""
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_mfma_peak2.txt")
+    want = "32x32x16_bf16" if dtype == "bf16" else "32x32x16_f16"
+    try:
+        sect = open(path).read().split("## 256 workgroups x 256 threads")[1]
+        m = re.search(r"^%s\s+N\(0,1\), half of A zero\s+([0-9.]+) TFLOP/s\s+clock ([0-9.]+) GHz" % re.escape(want), sect, re.M)
+        return {"tflops": float(m.group(1)), "clock_ghz": float(m.group(2)), "source": "profiles/r05_mfma_peak2.txt (%s, half of A zero, one wave per SIMD)" % want}
+    except (OSError, IndexError, AttributeError, ValueError):
+        return None
+
+
 def dispatches_per_step(model):
     """GPU dispatches (kernels + copies) per step, from the committed kernel trace of THIS command
     (profiles/rNN_<model>_4p4_bf16_timeline.txt, newest round, tools/rocpd_timeline.py over the last 6 of `bench.py --timed-only` steps)"""
@@ -1040,6 +1056,10 @@ def worker(args):
                 out["roofline"]["clock_probe"] = "utv2_conv_clock_probe: s_memtime ticks per 10 ns s_memrealtime tick over the lifetime (%.0f us) of workgroup 0 of the last multi-level 256-tile launch of the timed region" % clock_ghz["workgroup_lifetime_us"]
             if board_power:
                 out["roofline"]["board_power"] = board_power
+            ceil_ = board_mfma_ceiling(args.dtype) if args.dtype != "f32" else None
+            if ceil_:
+                out["roofline"]["board_mfma_ceiling"] = ceil_
+                out["roofline"]["frac_of_board_mfma_ceiling"] = conv["tflops"] / ceil_["tflops"]
             if conv_x:
                 out["roofline"]["exclusive"] = {"achieved": conv_x["tflops"], "frac": conv_x["tflops"] / peak, "avg_us": conv_x["avg_us"],
                                                 "launches": conv_x["launches"],
