@@ -2377,6 +2377,239 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_w8(Wgrad16Args p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv_wgrad_bf16_w8 on the PING-PONG schedule of conv_igemm_bf16_pp (round 5).  The lock-step kernel above keeps the matrix pipe busy
+// 47 % of the cycles (profiles/r05_tower_sq_counters.txt): all eight waves read their fragments, multiply and issue DMA together, so both
+// waves of a SIMD sit in their non-matrix part at the same time.  Here a chunk is 32 pixels (two k16 steps = one slot of 16 MFMAs), in
+// a ring of four 32 KB stages ([dY 32 px x 512 B | X 32 px x 512 B]); waves 0-3 and 4-7 run LOAD(i) | COMPUTE(i) one slot apart,
+// slots separated by s_barrier: LOAD = the 24 transposing fragment reads of chunk i and the sources of the wave's 4 DMA pieces of
+// chunk i+3; COMPUTE = 16 MFMAs with the geometry loads of chunk i+5 in front and the 4 bare pieces of chunk i+3 behind the 3rd / 7th /
+// 11th / 15th.  Same work items, splits, slabs, accumulation order over the pixels (bit-identical slabs), same LDS row layout and swizzle.
+// vmcnt: a COMPUTE slot issues [2 geometry loads, 4 pieces]; waves 0-3 wait at the end of COMPUTE(i) for everything but the 4 pieces of
+// COMPUTE(i-1) and COMPUTE(i)'s 6 operations (the geometry of chunk i+4 and the pieces of chunk i+1 are in); waves 4-7 at the start
+// of LOAD(i) for everything but the last 10 (geometry of chunk i+3) and at its end for everything but COMPUTE(i-1)'s 6.
+__global__ __launch_bounds__(512) void conv_wgrad_bf16_pp(Wgrad16Args p) {
+  constexpr int BP = 32, ROWB = 512, OPB = BP * ROWB, STAGE = 2 * OPB;   // 16 KB per operand, 32 KB per stage, 4 stages
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  const int tilesN = p.Kred >> 8, tiles = (p.K >> 8) * tilesN;
+  const int per = gridDim.x >> 3;
+  const int wi = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (wi >= tiles * p.splits) return;
+  const int split = wi / tiles, bid = wi - split * tiles;
+  const int mt = bid / tilesN, nt = bid - mt * tilesN;
+  const int i0 = mt << 8, j0 = nt << 8;
+  const int tap = j0 / p.C, ci0 = j0 - tap * p.C + (p.groups > 1 ? (i0 / (p.K / p.groups)) * p.C : 0);
+  const int dh = tap / p.KW, dw = tap - dh * p.KW;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // the split's pixel range in 32-pixel chunks (chunks_per_split counts the lock-step kernel's 64-pixel chunks)
+  const int total_chunks = (p.M + BP - 1) / BP;
+  const int chunk_begin = split * p.chunks_per_split * 2;
+  int chunk_end = chunk_begin + p.chunks_per_split * 2;
+  if (chunk_end > total_chunks) chunk_end = total_chunks;
+  const int nslots = chunk_end - chunk_begin;
+  if (nslots <= 0) {   // (an empty split still owes its slab: zeros)
+    const int frow0 = lane & 31, fh0 = lane >> 5;
+    float* out0 = p.ws + (size_t)split * p.K * p.Kred;
+    for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 16; ++e)
+          out0[(size_t)(i0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh0) * p.Kred + j0 + wn * 64 + j * 32 + frow0] = 0.f;
+    return;
+  }
+
+  // DMA role of the lane: piece q (0, 1) of an operand = pixel rows 4*wid + 2q + (lane >> 5) of the chunk, 16 bytes at physical slot lane & 31
+  const int hr = lane >> 5, slot = lane & 31;
+  int choff[2];
+#pragma unroll
+  for (int o = 0; o < 2; ++o) choff[o] = (((slot >> 2) ^ ((2 * o + hr) & 3)) << 5) + ((slot & 3) << 3);
+  const h16_t* __restrict__ xb = (const h16_t*)p.x;
+  const h16_t* __restrict__ dyb = (const h16_t*)p.dy;
+  const h16_t* zero = (const h16_t*)g_zero64;
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  i32x2 ri[2][2];           // rowinfo of the lane's two im2col rows, two chunks in flight (set = parity of (chunk - chunk_begin))
+  const int rowl = 4 * wid + hr;  // + 2q
+#define WGP_RLOAD(SET)                                                                             \
+  [&](int chunk) {                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                \
+      int m = chunk * BP + rowl + 2 * q;                                                           \
+      m = m < p.M ? m : p.M - 1;                                                                   \
+      const int2* src = p.rowinfo + m;                                                             \
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ri[SET][q]) : "v"(src));               \
+    }                                                                                              \
+  }
+  auto rload0 = WGP_RLOAD(0);
+  auto rload1 = WGP_RLOAD(1);
+#undef WGP_RLOAD
+  const h16_t* psrc[4];    // sources of the wave's 4 pieces of one chunk: 0, 1 dY rows, 2, 3 im2col rows
+#define WGP_PREP(SET)                                                                                              \
+  [&](int chunk) {                                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                                \
+      const int m = chunk * BP + rowl + 2 * q;                                                                     \
+      const bool in = (m < p.M) & (chunk < chunk_end);                                                             \
+      const h16_t* a0 = dyb + (unsigned)(m * p.K + i0 + choff[q]);                                                 \
+      psrc[q] = in ? a0 : zero;                                                                                    \
+      const int W = ri[SET][q].y >> 16;                                                                            \
+      const h16_t* s0 = xb + (unsigned)((ri[SET][q].x + dh * W + dw) * p.xs + ci0 + choff[q]);                     \
+      psrc[2 + q] = (in & (bool)((ri[SET][q].y >> tap) & 1)) ? s0 : zero;                                          \
+    }                                                                                                              \
+  }
+  auto prep0 = WGP_PREP(0);
+  auto prep1 = WGP_PREP(1);
+#undef WGP_PREP
+  auto issue_piece = [&](int stage, int q4) {  // q4 0, 1: dY pieces, 2, 3: im2col pieces
+    unsigned char* dst = smem + stage * STAGE + (q4 < 2 ? 0 : OPB) + (4 * wid + 2 * (q4 & 1)) * ROWB;
+    __builtin_amdgcn_global_load_lds((gptr_t)psrc[q4], (lptr_t)dst, 16, 0, 0);
+  };
+
+  // transposing fragment reads (the lock-step kernel's addressing on 32-pixel stages)
+  const int G = lane >> 4, t = lane & 15, r3 = t >> 2;
+  const unsigned lrow = (unsigned)(size_t)(lptr_t)smem + (8 * (G >> 1) + r3) * ROWB + 32 * (G & 1) + 8 * (t & 3);
+  unsigned aoff[4], boff[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aoff[i] = lrow + (((wm * 4 + i) ^ r3) << 6);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) boff[j] = OPB + lrow + (((wn * 2 + j) ^ r3) << 6);
+  typedef h16_t frag_t __attribute__((ext_vector_type(8)));
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  s16x4 al[2][4], ah[2][4], bl[2][2], bh[2][2];
+#define TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define READ_FRAGS(set, S)                                                                         \
+  TR_READ(al[set][0], ab[0], (S) * 16 * ROWB); TR_READ(ah[set][0], ab[0], ((S) * 16 + 4) * ROWB);  \
+  TR_READ(al[set][1], ab[1], (S) * 16 * ROWB); TR_READ(ah[set][1], ab[1], ((S) * 16 + 4) * ROWB);  \
+  TR_READ(al[set][2], ab[2], (S) * 16 * ROWB); TR_READ(ah[set][2], ab[2], ((S) * 16 + 4) * ROWB);  \
+  TR_READ(al[set][3], ab[3], (S) * 16 * ROWB); TR_READ(ah[set][3], ab[3], ((S) * 16 + 4) * ROWB);  \
+  TR_READ(bl[set][0], bb[0], (S) * 16 * ROWB); TR_READ(bh[set][0], bb[0], ((S) * 16 + 4) * ROWB);  \
+  TR_READ(bl[set][1], bb[1], (S) * 16 * ROWB); TR_READ(bh[set][1], bb[1], ((S) * 16 + 4) * ROWB)
+#define WAIT_FRAGS2                                                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                                           \
+               : "+v"(al[0][0]), "+v"(al[0][1]), "+v"(al[0][2]), "+v"(al[0][3]), "+v"(ah[0][0]), "+v"(ah[0][1]), "+v"(ah[0][2]),  \
+                 "+v"(ah[0][3]), "+v"(bl[0][0]), "+v"(bl[0][1]), "+v"(bh[0][0]), "+v"(bh[0][1]));                                \
+  asm volatile(""                                                                                                               \
+               : "+v"(al[1][0]), "+v"(al[1][1]), "+v"(al[1][2]), "+v"(al[1][3]), "+v"(ah[1][0]), "+v"(ah[1][1]), "+v"(ah[1][2]),  \
+                 "+v"(ah[1][3]), "+v"(bl[1][0]), "+v"(bl[1][1]), "+v"(bh[1][0]), "+v"(bh[1][1]))
+  // all but the newest N VMEM operations of the wave have completed; ties the geometry registers so that no use moves above the wait
+#define WGP_VMWAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(ri[0][0]), "+v"(ri[0][1]), "+v"(ri[1][0]), "+v"(ri[1][1]) : : "memory")
+#define WGP_BARRIER                         \
+  __builtin_amdgcn_sched_barrier(0);        \
+  __builtin_amdgcn_s_barrier();             \
+  __builtin_amdgcn_sched_barrier(0)
+  auto load_slot = [&](int stage) {
+    unsigned ab[4], bb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ab[i] = aoff[i] + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bb[j] = boff[j] + stage * STAGE;
+    READ_FRAGS(0, 0);
+    READ_FRAGS(1, 1);
+  };
+  auto compute_slot = [&](int stage) {   // 16 MFMAs (steps 0, 1); the 4 pieces of the chunk three ahead go out behind the 3rd, 7th, 11th, 15th
+#pragma unroll
+    for (int set = 0; set < 2; ++set) {
+      frag_t a[4], b[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x4_t lo = __builtin_bit_cast(bf16x4_t, al[set][i]), hi = __builtin_bit_cast(bf16x4_t, ah[set][i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[i][e] = lo[e]; a[i][4 + e] = hi[e]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x4_t lo = __builtin_bit_cast(bf16x4_t, bl[set][j]), hi = __builtin_bit_cast(bf16x4_t, bh[set][j]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { b[j][e] = lo[e]; b[j][4 + e] = hi[e]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = mfma_32x32x16(a[i], b[j], acc[i][j]);
+          const int n = (set * 4 + i) * 2 + j;
+          if ((n & 3) == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece(stage, n >> 2);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+    }
+  };
+
+  // prologue: chunks 0, 1, 2 of the split (stages 0, 1, 2) and the geometry of chunks 3 (set 1) and 4 (set 0)
+  const int cb = chunk_begin;
+  rload0(cb);
+  rload1(cb + 1);
+  WGP_VMWAIT(0);
+  prep0(cb);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue_piece(0, q);
+  prep1(cb + 1);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue_piece(1, q);
+  rload0(cb + 2);
+  WGP_VMWAIT(0);
+  prep0(cb + 2);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue_piece(2, q);
+  rload1(cb + 3);
+  rload0(cb + 4);
+  WGP_VMWAIT(0);
+  WGP_BARRIER;
+
+  // slot i (chunk cb + i, stage i & 3): LOAD reads its fragments and prepares the pieces of chunk cb + i + 3 from geometry set (i + 1) & 1;
+  // COMPUTE re-fills that set with chunk cb + i + 5 and sends the pieces into stage (i + 3) & 3
+  if (wm == 0) {
+    for (int i = 0; i < nslots;) {
+      load_slot(i & 3); prep1(cb + i + 3); WAIT_FRAGS2; WGP_BARRIER;
+      rload1(cb + i + 5); compute_slot((i + 3) & 3); __builtin_amdgcn_sched_barrier(0); WGP_VMWAIT(10); WGP_BARRIER;
+      if (++i >= nslots) break;
+      load_slot(i & 3); prep0(cb + i + 3); WAIT_FRAGS2; WGP_BARRIER;
+      rload0(cb + i + 5); compute_slot((i + 3) & 3); __builtin_amdgcn_sched_barrier(0); WGP_VMWAIT(10); WGP_BARRIER;
+      ++i;
+    }
+    WGP_BARRIER;
+  } else {
+    WGP_BARRIER;
+    for (int i = 0; i < nslots;) {
+      WGP_VMWAIT(10); load_slot(i & 3); prep1(cb + i + 3); WAIT_FRAGS2; WGP_VMWAIT(6); WGP_BARRIER;
+      rload1(cb + i + 5); compute_slot((i + 3) & 3); __builtin_amdgcn_sched_barrier(0); WGP_BARRIER;
+      if (++i >= nslots) break;
+      WGP_VMWAIT(10); load_slot(i & 3); prep0(cb + i + 3); WAIT_FRAGS2; WGP_VMWAIT(6); WGP_BARRIER;
+      rload0(cb + i + 5); compute_slot((i + 3) & 3); __builtin_amdgcn_sched_barrier(0); WGP_BARRIER;
+      ++i;
+    }
+  }
+  WGP_VMWAIT(0);   // the trailing (zero-page) pieces must not land in LDS after the workgroup has gone
+#undef TR_READ
+#undef READ_FRAGS
+#undef WAIT_FRAGS2
+#undef WGP_BARRIER
+#undef WGP_VMWAIT
+
+  const int frow = lane & 31, fh = lane >> 5;
+  float* out = p.ws + (size_t)split * p.K * p.Kred;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = j0 + wn * 64 + j * 32 + frow;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = i0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        out[(size_t)co * p.Kred + k] = acc[i][j][e];
+      }
+  }
+}
+
 // Column sums of a bf16 [M][K] matrix (the bias gradient next to conv_wgrad_bf16_w8, which never holds dY in registers):
 // block b sums its contiguous row range per channel -> partial[b][K]; fixed order everywhere.  K % 8 == 0, K <= 2048.
 // Four row loads in flight per thread, ~4 blocks per CU (a single dependent load per thread streamed at 3 TB/s).
@@ -2594,7 +2827,13 @@ static int wgrad_bf16_impl(const void* x, int x_dtype, int x_pitch, const void* 
     const int smem = 2 * 2 * WGRAD_W8_BP * 512;
     static LdsOptIn lds_opt_in;
     lds_opt_in({(const void*)conv_wgrad_bf16_w8}, smem);
-    hipLaunchKernelGGL(conv_wgrad_bf16_w8, dim3(wgrad16_w8_budget()), dim3(512), smem, stream, a);
+    static const bool use_wgrad_pp = env_int("UTV2_WGRAD_PP", 1) != 0;   // the ping-pong schedule of the same tile (bit-identical slabs)
+    if (use_wgrad_pp) {
+      static LdsOptIn pp_opt_in;
+      pp_opt_in({(const void*)conv_wgrad_bf16_pp}, smem);
+      hipLaunchKernelGGL(conv_wgrad_bf16_pp, dim3(wgrad16_w8_budget()), dim3(512), smem, stream, a);
+    } else
+      hipLaunchKernelGGL(conv_wgrad_bf16_w8, dim3(wgrad16_w8_budget()), dim3(512), smem, stream, a);
     int rb = cdiv((int64_t)n / 4, 256);
     if (rb > 8192) rb = 8192;
     // UTV2_WGRAD_DEBUG & 256 (timing experiments only - the gradients are then WRONG): no slab reduction, to bound what a workspace-free
