@@ -216,9 +216,10 @@ class ConvTimer:
 
 
 class WgradTimer:
-    """HIP-event timing of the FCOS tower weight-gradient launches (conv_wgrad_bf16_w8 + reduce_slabs16_f32 + the bias column sums:
+    """HIP-event timing of the FCOS tower weight-gradient launches (conv_wgrad_bf16_pp - the ping-pong schedule of conv_wgrad_bf16_w8, round 5 - + reduce_slabs16_f32 + the bias column sums:
     one C-ABI call = one timed launch): the largest single symbol of the round-1 profile."""
-    kernel = "conv_wgrad_bf16_w8+reduce_slabs16_f32+colsum_bf16_* (FCOS tower 3x3 weight gradients)"
+    kernel = ("conv_wgrad_bf16_%s+reduce_slabs16_f32+colsum_bf16_* (FCOS tower 3x3 weight gradients)"
+              % ("w8" if os.environ.get("UTV2_WGRAD_PP", "1") == "0" else "pp"))
 
     def __init__(self):
         self.pairs = []

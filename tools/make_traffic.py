@@ -12,7 +12,7 @@ import sys
 # (round 5: the multi-level 3x3 launches run on the row-span form conv_igemm_bf16_rs; earlier traces / UTV2_PP_RS=0: conv_igemm_bf16_pp)
 TOWERS = [("_Z18conv_igemm_bf16_%sILb1EDF16%sEv10ConvArgs16" % (k, t), "_Z18conv_igemm_bf16_v2ILi128ELb1ELi64EDF16%sEv10ConvArgs16" % t)
           for k in ("rs", "pp") for t in ("_", "b")]
-WGRAD = "_Z18conv_wgrad_bf16_w811Wgrad16Args"
+WGRADS = ["_Z18conv_wgrad_bf16_pp11Wgrad16Args", "_Z18conv_wgrad_bf16_w811Wgrad16Args"]   # round 5: the ping-pong schedule; before / UTV2_WGRAD_PP=0: lock-step
 
 
 def per_kernel(path):
@@ -63,8 +63,10 @@ for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch.get(k, (1, 0)
         e["hbm_GBps"] = round(b / dur[k][1] / 1e3, 1)
     kernels[k] = e
 res["kernels"] = kernels
-if WGRAD in kernels:
-    res["conv_wgrad_bf16_w8"] = dict(kernels[WGRAD])
+for WGRAD in WGRADS:
+    if WGRAD in kernels:
+        res["conv_wgrad_bf16_w8"] = dict(kernels[WGRAD], kernel=WGRAD)   # (key name kept: bench.py reads it)
+        break
 json.dump(res, open(sys.argv[4], "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "kernels"}, indent=1))
 for k, e in list(kernels.items())[:25]:

@@ -6,7 +6,7 @@ import re
 import sqlite3
 import sys
 
-CLASSES = [("conv fwd/dgrad 256-tile", r"conv_igemm_bf16_(pp|rs|w8)"), ("conv fwd/dgrad 128-tile", r"conv_igemm_bf16"), ("conv wgrad 256-tile", r"conv_wgrad_bf16_w8"),
+CLASSES = [("conv fwd/dgrad 256-tile", r"conv_igemm_bf16_(pp|rs|w8)"), ("conv fwd/dgrad 128-tile", r"conv_igemm_bf16"), ("conv wgrad 256-tile", r"conv_wgrad_bf16_(w8|pp)"),
            ("conv wgrad 128-tile", r"conv_wgrad_bf16"), ("wgrad reduce/colsum", r"reduce_slabs|colsum"), ("group norm", r"\d+gn_(stats|apply|bwd)"),
            ("ATen", r"at::native|at6native|rocclr"), ("losses/targets", r"focal|fcos_|iou|giou|loc_|smooth|ce_|softmax"),
            ("nms/topk/decode", r"nms|topk|decode|rank"), ("optimizer/ema/cast", r"sgd|ema|f32_to_bf16|flip_transpose"),
