@@ -766,3 +766,26 @@ def test_row_span_kernel_on_narrow_and_ragged_geometry(case):
     dx = hip.conv2d_dgrad_bf16(dyh, wt16, (N, H, W, C), 1, 1, 3, 3, out_dtype=BF)
     refd = F.conv_transpose2d(r16(dy), r16(w), None, 1, 1)
     assert close16(dx.cpu().permute(0, 3, 1, 2), refd)
+
+
+def test_weight_gradient_schedules_bit_identical(tmp_path):
+    """conv_wgrad_bf16_pp (round 5: the 256-tile weight-gradient kernel on the ping-pong schedule - 32-pixel chunks in a ring of four
+    stages, the two wave groups one slot apart) writes the SAME slabs as the lock-step kernel it replaces (UTV2_WGRAD_PP=0): same work
+    items, same accumulation order over the pixels - single and paired towers, a wide layer, accumulate on / off, a ragged NHWC 3x3
+    (tools/check_wgrad_pp.py; the switch is read once per process, hence the subprocesses)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = str(tmp_path / "wref.pt")
+
+    def run(env, *args):
+        e = dict(os.environ); e.update(env)
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_wgrad_pp.py")] + list(args), env=e, capture_output=True, text=True,
+                             timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return out.stdout
+
+    run({"UTV2_WGRAD_PP": "0"}, "save", ref)
+    lines = [ln for ln in run({}, "cmp", ref).splitlines() if ln.strip() and "amdgpu" not in ln]
+    assert len(lines) == 7 and all("bit-identical" in ln and "nan" not in ln for ln in lines), lines
