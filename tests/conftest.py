@@ -14,7 +14,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
     # The oracle legs of the parity tests are stock torch CPU kernels on small tensors: beyond ~16-32 threads they get SLOWER (the GPU boxes
     # have 128-256 hardware threads and torch takes them all by default - bench.py's cpu_baseline measured 25 s per step on 128 threads
-    # against 4.6 s on 32), and the whole-step Faster-RCNN parity tests are most of the GPU suite's wall time.  Results do not depend on
+    # against 4.6 s on 32), and the whole-step Faster-RCNN parity tests are most of the GPU suite's wall time.  Results do not depend on the thread count beyond fp32 summation order.
     # Measured on a 256-thread box: test_rcnn_step_gpu.py 350 s uncapped, 58 s at 32 threads, 32 s at 16 (the default cap; UTV2_TEST_THREADS).
     # The comparisons carry stated tolerances; nothing asserts bit-equality of a CPU result across thread counts.
     try:

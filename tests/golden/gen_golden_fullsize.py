@@ -12,7 +12,8 @@ What is stored (a few hundred KB; nothing that can be regenerated bit-exactly fr
   * how to rebuild the initial weights: torch seed of the product's CPU initialisation + per-tensor fingerprints of it (a changed RNG fails
     loudly), and the tensors the data-driven head rescaling changed (cpu_baseline_run: the teacher must emit pseudo boxes) as arrays;
   * Faster-RCNN: the torch seed / draw sizes of the oracle's sampling keys (+ CRC32 of the drawn keys);
-  * expected outputs: every record_dict entry of the oracle's step, its pseudo-box counts."""
+  * expected outputs: every record_dict entry of the oracle's step, its pseudo-box counts, and (Faster-RCNN) the oracle teacher's
+    thresholded detections themselves (a few boxes: replayed into the product's student by the decoupled half of the parity check)."""
 import os
 import sys
 import tempfile
@@ -76,6 +77,9 @@ def gen(kind):
         fx["pseudo_cls"], fx["pseudo_reg"] = np.int64(d["pseudo"]["cls"]), np.int64(d["pseudo"]["reg"])
     else:
         fx["pseudo"] = np.int64(d["pseudo"])
+        for i, pb in enumerate(d["pseudo_boxes"]):       # the oracle teacher's thresholded detections (the decoupled replay, the flipped-anchor count)
+            for k, v in pb.items():
+                fx["pseudo%d_%s" % (i, k)] = v.numpy()
         fx["key_seed"] = np.int64(99)
         fx["rpn_keys_shape"] = np.asarray([list(d["rpn_keys"][0].shape), list(d["rpn_keys"][1].shape)], np.int64)
         fx["rpn_keys_crc"] = np.asarray([crc(d["rpn_keys"][0]), crc(d["rpn_keys"][1])], np.uint64)

@@ -105,8 +105,7 @@ def test_fcos_step_bf16_vs_rounding_oracle(kind, tol, monkeypatch):
     from ubteacher import ops
     cfg = small_fcos_cfg()
     cfg.SOLVER.AMP.ENABLED = True
-    if kind == "fp16":
-        monkeypatch.setenv("UTV2_PRECISION", "fp16")
+    monkeypatch.setenv("UTV2_PRECISION", kind)
     torch.manual_seed(0)
     prod, orac = make_batch(12, 2, 2, 96, 128, "cuda")
     try:
@@ -563,8 +562,9 @@ def test_batched_weight_flip_equals_per_layer_flip():
 
 
 def test_big_tile_kernels_bit_identical_across_schedules(tmp_path):
-    """The three kernels a deep bf16 conv can run on - the 128 x 128 tile (UTV2_W8=0), the 256 x 256 lock-step tile (UTV2_PP=0) and
-    the 256 x 256 ping-pong tile (one tile per workgroup, UTV2_PP=1, and the default persistent grid) - accumulate every output element in the same order: bit-identical outputs on a multi-level
+    """The kernels a deep bf16 conv can run on - the 128 x 128 tile (UTV2_W8=0), the 256 x 256 ping-pong tile (one tile per workgroup,
+    UTV2_PP=1, and the default persistent grid) and its row-span form (default for 3x3; UTV2_PP_RS=0: plain ping-pong) - accumulate every
+    output element in the same order: bit-identical outputs on a multi-level
     tower conv, a 3x3 with mask + residual + ReLU epilogue, an fp32-output conv and a wide 1x1 (tools/check_w8.py; the switches are
     read once per process, hence the subprocesses)."""
     import os
@@ -584,7 +584,7 @@ def test_big_tile_kernels_bit_identical_across_schedules(tmp_path):
     # ... and the epilogue's branch-free plain path (default) stores the same bits as the general one (UTV2_EPI_PLAIN=0), GroupNorm
     # partial sums and ReLU bit planes included
     # (the default 3x3 path is the row-span form conv_igemm_bf16_rs since round 5; UTV2_PP_RS=0: the ping-pong kernel it derives from)
-    for env in ({"UTV2_PP": "0"}, {"UTV2_PP": "1"}, {"UTV2_PP": "1", "UTV2_PP_RS": "0"}, {}, {"UTV2_PP_RS": "0"}, {"UTV2_EPI_PLAIN": "0"},
+    for env in ({"UTV2_PP": "1"}, {"UTV2_PP": "1", "UTV2_PP_RS": "0"}, {}, {"UTV2_PP_RS": "0"}, {"UTV2_EPI_PLAIN": "0"},
                 {"UTV2_EPI_PLAIN": "0", "UTV2_W8": "0"}):
         lines = [ln for ln in run(env, "cmp", ref).splitlines() if ln.strip()]
         assert len(lines) == 14 and all("bit-identical" in ln and "nan" not in ln for ln in lines), lines
@@ -768,11 +768,12 @@ def test_row_span_kernel_on_narrow_and_ragged_geometry(case):
     assert close16(dx.cpu().permute(0, 3, 1, 2), refd)
 
 
-def test_weight_gradient_schedules_bit_identical(tmp_path):
-    """conv_wgrad_bf16_pp (round 5: the 256-tile weight-gradient kernel on the ping-pong schedule - 32-pixel chunks in a ring of four
-    stages, the two wave groups one slot apart) writes the SAME slabs as the lock-step kernel it replaces (UTV2_WGRAD_PP=0): same work
-    items, same accumulation order over the pixels - single and paired towers, a wide layer, accumulate on / off, a ragged NHWC 3x3
-    (tools/check_wgrad_pp.py; the switch is read once per process, hence the subprocesses)."""
+def test_big_tile_weight_gradients_are_deterministic_across_processes(tmp_path):
+    """conv_wgrad_bf16_pp (the 256-tile weight-gradient kernel on the ping-pong schedule: 32-pixel chunks in a ring of four stages, the two
+    wave groups one slot apart) + the fixed-order slab reduction: two processes produce the SAME bits - single and paired towers, a wide
+    layer, accumulate on / off, a ragged NHWC 3x3 (tools/check_wgrad_pp.py).  (Until round 5 this compared the kernel with the lock-step
+    schedule it replaced, bit for bit; that kernel left the library in round 6 - tools/probe/conv_lockstep.h - and
+    test_conv_ml_bf16_wgrad_big_tile pins the values against the fp32 reference.)"""
     import os
     import subprocess
     import sys
@@ -786,6 +787,6 @@ def test_weight_gradient_schedules_bit_identical(tmp_path):
         assert out.returncode == 0, out.stderr[-2000:]
         return out.stdout
 
-    run({"UTV2_WGRAD_PP": "0"}, "save", ref)
+    run({}, "save", ref)
     lines = [ln for ln in run({}, "cmp", ref).splitlines() if ln.strip() and "amdgpu" not in ln]
     assert len(lines) == 7 and all("bit-identical" in ln and "nan" not in ln for ln in lines), lines

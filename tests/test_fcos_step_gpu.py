@@ -171,12 +171,13 @@ def test_full_semisup_step_cls_ctr_thresholding():
         assert torch.equal(t_after[k], new_t[k]), k
 
 
-def test_trainable_stem_amp_step_vs_rounding_oracle():
+def test_trainable_stem_amp_step_vs_rounding_oracle(monkeypatch):
     """MODEL.BACKBONE.FREEZE_AT 0 under AMP: the stem takes the fp32 image in every precision mode, its pool / ReLU backward runs on the
     16-bit activations, its weight gradient in exact f32.  Against the oracle with the operand rounding emulated in its convs, GIVEN the
     product's pseudo labels (selection drift is another test's subject): the updates of the stem, a res2 and a res3 weight agree in
     direction and size (16-bit rounding through ~50 layers of ReLU gates: a loose bound, far below what a missing mask / a wrong
     arg-max rule / a missing BN scale would give)."""
+    monkeypatch.setenv("UTV2_PRECISION", "bf16")   # written for bf16 rounding (the package default AMP type is fp16, the reference's)
     from ubteacher import ops
     from ubteacher.engine import UBTeacherTrainer
     from tests.test_conv_bf16_gpu import _to_oracle_pseudo
@@ -283,9 +284,10 @@ def test_ragged_batch_and_empty_gt_step_parity():
 
 
 @pytest.mark.parametrize("amp", [False, True])
-def test_training_reduces_loss_on_a_fixed_batch(amp):
+def test_training_reduces_loss_on_a_fixed_batch(amp, monkeypatch):
     """30 UTv2 steps (EMA teacher, pseudo labels, both branches, SGD) on one fixed batch: finite throughout and the
     supervised losses go down - the optimisation loop is wired end to end in both arithmetic modes."""
+    monkeypatch.setenv("UTV2_PRECISION", "bf16")   # written for bf16 rounding (the package default AMP type is fp16, the reference's)
     from ubteacher import ops
     from ubteacher.engine import UBTeacherTrainer
     cfg = small_fcos_cfg()
@@ -398,6 +400,7 @@ def test_premasked_backbone_gradients_bit_identical(monkeypatch):
     """AMP backward of the fused bottlenecks: masking the gradient that flows into a block's ReLU output in the PRODUCERS' dgrad epilogues
     (next block's conv1 dgrad incl. the residual branch, stride-2 zero-interleave, FPN lateral dgrad) equals the separate mask pass at the
     top of the block's backward BIT FOR BIT: two steps from the same state, the parameter gradients of every layer compared."""
+    monkeypatch.setenv("UTV2_PRECISION", "bf16")   # written for bf16 rounding (the package default AMP type is fp16, the reference's)
     import hashlib
     from ubteacher import ops
     from ubteacher.engine import UBTeacherTrainer
@@ -441,6 +444,7 @@ def test_relu_bit_planes_backbone_gradients_bit_identical(monkeypatch):
     (utv2_conv2d_nhwc_fwd_bf16_bits; default) instead of the 16-bit activations (UTV2_RELU_BITS=0): same step, bit for bit, and the
     planes are really used - y1, y2 of the 13 trainable blocks, the block input of the 10 that return an input gradient to a fused
     block, the 3 premasked FPN laterals."""
+    monkeypatch.setenv("UTV2_PRECISION", "bf16")   # written for bf16 rounding (the package default AMP type is fp16, the reference's)
     import hashlib
     from ubteacher import ops
     from ubteacher.engine import UBTeacherTrainer
@@ -474,6 +478,7 @@ def test_relu_bit_planes_backbone_gradients_bit_identical(monkeypatch):
 def test_weight_gradient_lanes_bit_identical(monkeypatch):
     """The weight gradients are spread over UTV2_WGRAD_LANES side streams (default 2), a layer always on the same one: the step is the
     same to the bit on 1, 2 and 3 lanes (every layer's launches keep their order, the split-K workspaces are per stream)."""
+    monkeypatch.setenv("UTV2_PRECISION", "bf16")   # written for bf16 rounding (the package default AMP type is fp16, the reference's)
     import hashlib
     from ubteacher import ops
     from ubteacher.engine import UBTeacherTrainer
@@ -511,6 +516,7 @@ def test_stage_output_gradient_handoff(monkeypatch):
     lateral parks its part and the block adds it in the kernel that makes its own (utv2_zero_interleave2x_add_nhwc) instead of autograd
     summing two 16-bit tensors in a pass of its own: the sum is rounded once instead of twice, so the steps agree to 16-bit rounding
     noise, not to the bit; both hand-offs of the FCOS backbone (res3 -> res4, res4 -> res5) happen and nothing stays parked."""
+    monkeypatch.setenv("UTV2_PRECISION", "bf16")   # written for bf16 rounding (the package default AMP type is fp16, the reference's)
     from ubteacher import ops
     from ubteacher.engine import UBTeacherTrainer
     cfg = small_fcos_cfg()
@@ -718,12 +724,13 @@ def test_checkpoint_roundtrip_on_device_arena(tmp_path):
 
 
 @pytest.mark.parametrize("kind", ["fcos", "rcnn"])
-def test_step_as_hipgraph_replays_the_eager_step(kind):
+def test_step_as_hipgraph_replays_the_eager_step(kind, monkeypatch):
     """engine.trainer.run_step_graph: the whole UTv2 iteration (reference engine/trainer.py:181-429 / :786-912) captured once as a hipGraph and
     replayed.  Same initial weights and the same static batch on two trainers: five eager steps against two eager + capture + three
     replays - the same losses at every logged step and the same student / teacher afterwards (to fp32 reduction-order noise: the
     device RNG draws of the step differ between eager and replay only in their Philox offsets, which the FCOS step does not consume for
     anything that reaches a loss; the Faster-RCNN step samples anchors / proposals with them, so there the comparison is statistical)."""
+    monkeypatch.setenv("UTV2_PRECISION", "bf16")   # written for bf16 rounding (the package default AMP type is fp16, the reference's)
     from ubteacher import ops
     from ubteacher.data.synthetic import SyntheticTwoCropLoader
     from ubteacher.engine import UBRCNNTeacherTrainer, UBTeacherTrainer
@@ -773,8 +780,7 @@ def test_sgd_and_ema_keep_the_16bit_weight_mirror_fresh(kind, monkeypatch):
     from ubteacher.engine import UBTeacherTrainer
     cfg = small_fcos_cfg()
     cfg.SOLVER.AMP.ENABLED = True
-    if kind == "fp16":
-        monkeypatch.setenv("UTV2_PRECISION", "fp16")
+    monkeypatch.setenv("UTV2_PRECISION", kind)
     torch.manual_seed(0)
     prod, orac = make_batch(12, 2, 2, H, W, "cuda")
     try:
@@ -794,5 +800,36 @@ def test_sgd_and_ema_keep_the_16bit_weight_mirror_fresh(kind, monkeypatch):
             assert st._flat16 is not None and st._flat16.dtype == h16, name
             assert st._v16 == st.version, "%s: the fused update did not leave the mirror fresh" % name
             assert torch.equal(st._flat16, st.flat.to(h16)), name
+    finally:
+        ops.set_precision("fp32")
+
+
+def test_amp_config_key_selects_the_reference_autocast_type(monkeypatch):
+    """SOLVER.AMP.ENABLED alone (the reference's YAML, configs/FCOS/coco-standard/*.yaml) selects what the reference's autocast computes in
+    (engine/trainer.py:194-198,318-349: torch.cuda.amp.autocast = IEEE fp16, GradScaler): the fp16 kernel library and the device-side
+    dynamic loss scale; bfloat16 is the opt-in (UTV2_PRECISION=bf16, no scaler); AMP off is exact fp32."""
+    from ubteacher import hip, ops
+    from ubteacher.engine import UBTeacherTrainer
+    torch.manual_seed(0)
+    prod, _ = make_batch(12, 2, 2, H, W, "cuda")
+    try:
+        for env, amp, want, dt in ((None, True, "fp16", torch.float16), ("bf16", True, "bf16", torch.bfloat16), (None, False, "fp32", None)):
+            if env is None:
+                monkeypatch.delenv("UTV2_PRECISION", raising=False)
+            else:
+                monkeypatch.setenv("UTV2_PRECISION", env)
+            cfg = small_fcos_cfg()
+            cfg.SOLVER.AMP.ENABLED = amp
+            tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+            assert ops.PRECISION[0] == want
+            assert (tr._amp_state is not None) == (want == "fp16")
+            if dt is not None:
+                assert hip.h16_dtype() == dt
+            if want == "fp16":
+                assert tr._amp_state.cpu().tolist() == [65536.0, 0.0, 0.0]     # GradScaler's init_scale, nothing found, no clean steps yet
+                tr.iter = 1
+                tr.run_step_full_semisup()
+                m = tr.flush_metrics()
+                assert all(np.isfinite(v) for k, v in m.items() if k.startswith("loss")), m
     finally:
         ops.set_precision("fp32")

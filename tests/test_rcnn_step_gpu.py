@@ -118,9 +118,10 @@ def test_rcnn_full_semisup_step_parity(predictor, separable_roi_align):
         # loss_rpn_loc_pseudo (weight 0 in the objective, trainer.py:888-890) sums over anchors made positive by
         # the Matcher's exact-equality low-quality rule against pseudo boxes that differ by 1e-5 between the
         # two teachers: an ill-conditioned selection, compared loosely.
-        # loss_rpn_cls_pseudo weights every sampled anchor by the score of its arg-max-IoU pseudo box:
-        # near-tied IoUs against pseudo boxes that differ by 1e-5 flip a few weights -> 5e-3.
-        tol = 2e-2 if k == "loss_rpn_loc_pseudo" else (5e-3 if k == "loss_rpn_cls_pseudo" else 1e-3)
+        # loss_rpn_cls_pseudo (weight UNSUP_LOSS_WEIGHT) holds the north star's 1e-3 like every other weighted term.  The decoupled
+        # tests (test_rcnn_step_fp32_tight_with_the_product_pseudo_boxes here, tests/test_fullsize_gpu.py at 1333x800) hold
+        # loss_rpn_loc_pseudo to 1e-3 too once both sides see the SAME pseudo boxes.
+        tol = 2e-2 if k == "loss_rpn_loc_pseudo" else 1e-3
         assert abs(rec[k] - v) <= tol * max(abs(v), 1e-6), (k, rec[k], v)
     assert rec_o["loss_box_reg_pseudo"] > 0 and rec_o["loss_rpn_cls_pseudo"] > 0
     t_after = cpu_state(tr.model_teacher)
@@ -130,14 +131,15 @@ def test_rcnn_full_semisup_step_parity(predictor, separable_roi_align):
     for k in new_s:
         err = float((s_after[k].double() - new_s[k].double()).abs().max())
         upd = float((new_s[k].double() - sd_s[k].double()).abs().max())
-        tol = 1e-4 * float(new_s[k].abs().max()) + 5e-2 * upd + 1e-12  # discrete selections (matcher ties, ReLU gates) are ill-conditioned
+        tol = 1e-4 * float(new_s[k].abs().max()) + 4e-2 * upd + 1e-12  # discrete selections (matcher ties, ReLU gates) are ill-conditioned: measured worst 3.2e-2; the decoupled test below holds 1e-2
         assert err <= tol, (k, err, tol)
 
 
-def test_rcnn_step_amp_close_to_fp32():
+def test_rcnn_step_amp_close_to_fp32(monkeypatch):
     """The AMP (bf16 activations / MFMA operands) Faster-RCNN step runs through every typed kernel path - fp32 FPN levels
     into RoIAlign, bf16 backbone / heads, fp32 loss-side outputs - and its supervised losses stay within a few per cent
     of the fp32 step on the same seeded batch and sampling keys (proposal selection is discrete, hence the loose bound)."""
+    monkeypatch.setenv("UTV2_PRECISION", "bf16")   # written for bf16 rounding (the package default AMP type is fp16, the reference's)
     from ubteacher import ops
     from ubteacher.engine import UBRCNNTeacherTrainer
     recs = {}
@@ -323,7 +325,7 @@ def test_rcnn_step_vs_reference_trainer_golden():
     for k, v in ref.items():
         if k in ("data_time", "total_loss"):
             continue
-        tol = 2e-2 if k == "loss_rpn_loc_pseudo" else (5e-3 if k == "loss_rpn_cls_pseudo" else 1e-3)
+        tol = 2e-2 if k == "loss_rpn_loc_pseudo" else 1e-3     # the one weight-0 term (trainer.py:888-890), see above
         assert abs(rec[k] - v) <= tol * max(abs(v), 1e-6), (k, rec[k], v)
     assert abs(rec["total_loss"] - ref["total_loss"]) <= 1e-3 * ref["total_loss"]
     gl = tr._last_pseudo
@@ -337,7 +339,7 @@ def test_rcnn_step_vs_reference_trainer_golden():
         i += 1
     assert i == 2
     check_state_fingerprints(d, "teacher", cpu_state(tr.model_teacher), 0.0, exact=True)
-    check_state_fingerprints(d, "student", cpu_state(tr.model), 1e-4, rtol_update=5e-2)
+    check_state_fingerprints(d, "student", cpu_state(tr.model), 1e-4, rtol_update=4e-2)
 
 
 @pytest.mark.parametrize("kind,tol", [("bf16", 1e-2), ("fp16", 3e-3)])
@@ -348,8 +350,7 @@ def test_rcnn_step_bf16_vs_rounding_oracle(kind, tol, monkeypatch, separable_roi
     both sides use the same injected sampling keys; then every loss must agree within 1e-2 relative and the teacher after EMA is
     bit exact.  The product's own teacher detections must mostly coincide with the rounding oracle's."""
     from ubteacher import ops
-    if kind == "fp16":
-        monkeypatch.setenv("UTV2_PRECISION", "fp16")
+    monkeypatch.setenv("UTV2_PRECISION", kind)
     try:
         O.CONV_ROUND[0] = kind
         d, cfg, tr, orac, sd_s, sd_t, K, mean, pstd = _golden_setup(amp=True)
@@ -481,9 +482,10 @@ def test_rcnn_step_fp32_tight_with_the_product_pseudo_boxes(separable_roi_align)
         assert err <= 1e-4 * float(new_s[k].abs().max()) + 1e-2 * upd + 1e-12, (k, err, upd)
 
 
-def test_rcnn_step_with_trainable_stem_runs_and_updates_it():
+def test_rcnn_step_with_trainable_stem_runs_and_updates_it(monkeypatch):
     """MODEL.BACKBONE.FREEZE_AT 0 through the Faster-RCNN trainer (fp32 and AMP): the step runs, the stem and res2 weights move, nothing
     is left parked or non-finite (the FCOS trainer's parity test pins the stem's gradient against the oracle)."""
+    monkeypatch.setenv("UTV2_PRECISION", "bf16")   # written for bf16 rounding (the package default AMP type is fp16, the reference's)
     from ubteacher import ops
     from ubteacher.engine import UBRCNNTeacherTrainer
     try:

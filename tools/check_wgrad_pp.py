@@ -1,5 +1,6 @@
-"""A/B of the 256-tile weight-gradient kernel's two schedules (UTV2_WGRAD_PP=1 ping-pong, 0 lock-step): same work items, same accumulation
-order over the pixels - the gradients must be BIT-identical.  usage: check_wgrad_pp.py save|cmp FILE"""
+"""Weight gradients of the 256-tile kernel (conv_wgrad_bf16_pp) saved by one process and compared bit for bit by another: two builds /
+two switch settings that keep the accumulation order (round 5: the ping-pong schedule against the lock-step one; round 6: determinism
+across processes) must agree exactly.  usage: check_wgrad_pp.py save|cmp FILE"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "unbiased-teacher-v2_amd"))

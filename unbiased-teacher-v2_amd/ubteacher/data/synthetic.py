@@ -52,8 +52,21 @@ def make_gt(rng, h, w, num_classes=80, max_boxes=15):
     return inst
 
 
+def resize_shortest_edge_size(rng, min_range, max_size, aspect=4.0 / 3.0):
+    """(h, w) of a landscape image of the given aspect ratio after Detectron2's ResizeShortestEdge with MIN_SIZE_TRAIN_SAMPLING "range":
+    the short side drawn uniformly from min_range (the UTv2 recipes: (400, 1200)), the long side capped at MAX_SIZE_TRAIN (1333)"""
+    s = int(rng.integers(min_range[0], min_range[1] + 1))
+    h, w = float(s), s * aspect
+    if w > max_size:
+        h, w = h * max_size / w, float(max_size)
+    return int(h + 0.5), int(w + 0.5)
+
+
 class SyntheticTwoCropLoader:
-    def __init__(self, cfg, height=800, width=1333, seed=0, device=None, num_batches=1):
+    def __init__(self, cfg, height=800, width=1333, seed=0, device=None, num_batches=1, ragged=None):
+        """ragged = (min_lo, min_hi, max_size): every image gets its own ResizeShortestEdge size (the reference recipes train at
+        INPUT.MIN_SIZE_TRAIN (400, 1200) "range", configs/utv2_*_r50.yaml): the labeled and the unlabeled lists then pad to different
+        canvases and the student's two passes cannot be fused (engine/trainer.py) - use with num_batches > 1"""
         ws = comm.get_world_size()
         bl, bu = cfg.SOLVER.IMG_PER_BATCH_LABEL, cfg.SOLVER.IMG_PER_BATCH_UNLABEL
         assert bl % ws == 0 and bu % ws == 0, "batch must be divisible by world size (data/build.py:228-238)"
@@ -65,12 +78,16 @@ class SyntheticTwoCropLoader:
         for _ in range(num_batches):
             lq, lk, uq, uk = [], [], [], []
             for _ in range(self.bl):
+                if ragged is not None:
+                    height, width = resize_shortest_edge_size(rng, ragged[:2], ragged[2])
                 weak = make_image(rng, height, width)
                 strong = strong_view(rng, weak)
                 gt = make_gt(rng, height, width, nc)
                 lk.append({"image": weak.to(dev), "height": height, "width": width, "instances": gt})
                 lq.append({"image": strong.to(dev), "height": height, "width": width, "instances": gt})
             for _ in range(self.bu):
+                if ragged is not None:
+                    height, width = resize_shortest_edge_size(rng, ragged[:2], ragged[2])
                 weak = make_image(rng, height, width)
                 strong = strong_view(rng, weak)
                 uk.append({"image": weak.to(dev), "height": height, "width": width})
