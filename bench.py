@@ -591,6 +591,11 @@ def parity_fullsize(dump, device_index):
                 la = O.matcher(O.pairwise_iou(o["boxes"], anchors), [0.3, 0.7], [0, -1, 1], True)[1]
                 lb = O.matcher(O.pairwise_iou(mine, anchors), [0.3, 0.7], [0, -1, 1], True)[1]
                 flipped.append(int((la != lb).sum())); positives.append(int((la == 1).sum()))
+            if sum(flipped):
+                # loss_rpn_cls_pseudo sums score-weighted BCE terms over the 256 SAMPLED anchors per image: every anchor whose label differs
+                # between the two pseudo-box sets can swap one term of that sample (1 + 1 fixture: 3 of 268 569 labels differ, the term
+                # moves by 1.5e-3; 2 + 2: 7 labels, 1.9e-4).  With identical labels (the decoupled run) it holds 1e-3 like every other term.
+                tol["loss_rpn_cls_pseudo"] = 5e-3
             extra["coupled_anchor_labels"] = {"anchors_per_image": int(anchors.shape[0]), "positives_under_oracle_boxes": positives,
                                               "labels_that_differ_under_product_boxes": flipped, "max_abs_box_dev_px": box_dev,
                                               "bound": "<= 64 labels per image (the sample of positives is 64 per image)"}
@@ -681,12 +686,16 @@ def step_subrecord(kind, args, device_index, timer=None, steps=10, warmup=5, dty
     if timer is not None:
         timer.pairs = []
         timer.enabled = True
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        tr.run_step_full_semisup(); tr.iter += 1
-    t_enq = time.perf_counter() - t0             # the host has enqueued every step
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    from ubteacher.engine.step_gc import StepGC
+    with StepGC() as step_gc:                    # the collector policy of the product's own train_loop (engine/step_gc.py)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.run_step_full_semisup(); tr.iter += 1
+            step_gc.tick()
+        t_enq = time.perf_counter() - t0             # the host has enqueued every step
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     conv = None
     if timer is not None:
         timer.enabled = False
@@ -853,17 +862,24 @@ def worker(args):
             torch.cuda.synchronize()
 
     sync()
+    gsync = getattr(tr, "_grad_sync", None)
+    if gsync is not None:
+        gsync.timing = True          # per-step exposure of the gradient all-reduce (what backward did not hide)
     timer.enabled = wtimer.enabled = True
     n0 = calls.n
     power = BoardPower() if rank == 0 else None
     if power is not None:
         power.start()
-    t0_ = time.perf_counter()
-    for _ in range(args.steps):
-        tr.run_step_full_semisup(); tr.iter += 1
-    t_host = time.perf_counter() - t0_      # the host has enqueued every step (it runs ahead of the GPU)
-    sync()
-    dt = time.perf_counter() - t0_
+    from ubteacher.engine.step_gc import StepGC
+    with StepGC() as step_gc:               # the collector policy of the product's own train_loop (engine/step_gc.py)
+        sync()
+        t0_ = time.perf_counter()
+        for _ in range(args.steps):
+            tr.run_step_full_semisup(); tr.iter += 1
+            step_gc.tick()
+        t_host = time.perf_counter() - t0_      # the host has enqueued every step (it runs ahead of the GPU)
+        sync()
+        dt = time.perf_counter() - t0_
     board_power = power.stop() if power is not None else None
     timer.enabled = wtimer.enabled = False
     # shader clock the chip sustained under the last multi-level (tower / RPN head) launch of the 256-tile conv kernel inside the timed
@@ -894,6 +910,14 @@ def worker(args):
         fps = comm.all_gather_object((digest(tr.model.flat_state()), digest(tr.model_teacher.flat_state())))
         replicas = {"students_bit_identical": len({f[0] for f in fps}) == 1, "teachers_bit_identical": len({f[1] for f in fps}) == 1,
                     "ranks_compared": len(fps)}
+    allreduce = None
+    if gsync is not None:
+        gsync.timing = False
+        expo = gsync.exposure_summary()
+        if expo is not None and world > 1:
+            allr = comm.all_gather_object(expo["exposed_ms_per_step_mean"])
+            expo["exposed_ms_per_step_mean_by_rank"] = allr
+        allreduce = expo
     metrics = tr.flush_metrics()
     amp_state = tr._amp_state.cpu().tolist() if getattr(tr, "_amp_state", None) is not None else None
     pseudo_count = pseudo_counts(tr)
@@ -1150,7 +1174,7 @@ def worker(args):
                                             "losses / weight gradients / master weights",
                                      "f32": "fp32 MFMA, fp32 everywhere"}[args.dtype]},
             "ranks": {"world_size": world, "backend": info["backend"], "devices": devices,
-                      "launcher": _launcher_name(world), "rccl_selfcheck": rccl, "replicas": replicas},
+                      "launcher": _launcher_name(world), "rccl_selfcheck": rccl, "replicas": replicas, "allreduce": allreduce},
             "host": {"ms_per_step_on_96x128_images": host_ms, "enqueue_ms_per_step": 1e3 * t_host / args.steps,
                      "cabi_calls_per_step": calls_per_step, "gpu_dispatches": dispatches_per_step(args.model) if args.dtype != "f32" else None},
             "losses": {k: v for k, v in metrics.items() if k.startswith("loss") or k.startswith("teacher")},

@@ -128,6 +128,11 @@ int utv2_conv2d_wgrad_bf16_g(const void* x, int x_dtype, int x_pitch, const void
  * (written by utv2_preprocess_image_bf16pad); w16s = bf16 [K][7][32] (7 taps x 4 channels + 4 zeros per kernel row) */
 int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int y_dtype, const float* scale,
                               const float* bias, int N, int H, int W, int K, int OH, int OW, int relu, utv2_stream_t stream);
+/* the geometry table above, built on the device: out = int32 [N*OH*OW][2] for an [N, OH, OW] output over an [N, H, W] input whose first
+ * pixel has index `start` (level-concatenated inputs: one call per level with the running pixel offset); replaces a host-side build + copy
+ * per new canvas (Detectron2 ImageList.from_tensors pads every batch to its own canvas: reference data/dataset_mapper.py, INPUT.MIN_SIZE_TRAIN) */
+int utv2_rowinfo_nhwc(int* out, int N, int H, int W, int OH, int OW, int stride, int pad, int KH, int KW, int64_t start,
+                      utv2_stream_t stream);
 int utv2_f32_to_bf16(const float* src, void* dst16, int64_t n, utv2_stream_t stream);
 int utv2_weight_flip_transpose_bf16(const float* w, void* wt16, const float* scale, int K, int KH, int KW, int C,
                                     utv2_stream_t stream);

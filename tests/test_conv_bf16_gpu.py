@@ -790,3 +790,41 @@ def test_big_tile_weight_gradients_are_deterministic_across_processes(tmp_path):
     run({}, "save", ref)
     lines = [ln for ln in run({}, "cmp", ref).splitlines() if ln.strip() and "amdgpu" not in ln]
     assert len(lines) == 7 and all("bit-identical" in ln and "nan" not in ln for ln in lines), lines
+
+
+def _rowinfo_host(N, H, W, OH, OW, stride, pad, kh, kw, start):
+    """the geometry table as the host built it until round 5 (torch CPU ops): {input pixel index of tap (0,0), (W << 16) | tap mask}"""
+    n = torch.arange(N, dtype=torch.int64).view(N, 1, 1)
+    ih0 = (torch.arange(OH, dtype=torch.int64) * stride - pad).view(1, OH, 1)
+    iw0 = (torch.arange(OW, dtype=torch.int64) * stride - pad).view(1, 1, OW)
+    anchor = (start + n * (H * W) + ih0 * W + iw0).expand(N, OH, OW)
+    mask = torch.zeros((1, OH, OW), dtype=torch.int64)
+    for a in range(kh):
+        for b in range(kw):
+            ok = ((ih0 + a >= 0) & (ih0 + a < H)) & ((iw0 + b >= 0) & (iw0 + b < W))
+            mask = mask | (ok.to(torch.int64) << (a * kw + b))
+    word = ((W << 16) | mask).expand(N, OH, OW)
+    return torch.stack((anchor, word), dim=-1).reshape(-1, 2).to(torch.int32)
+
+
+def test_device_built_geometry_tables_equal_the_host_formula():
+    """utv2_rowinfo_nhwc (round 6: the per-output-pixel geometry table of the 16-bit convs / weight gradients built on the device, so that a
+    new canvas - every batch of the reference recipes' ResizeShortestEdge range - costs no host arithmetic and no copy) against the host
+    formula it replaces, bit for bit: 3x3 / 1x1 / 7x7, strides 1 and 2, with and without padding, odd extents, a level-concatenated table."""
+    from ubteacher import hip
+    hip._rowinfo_cache.clear()
+    for (N, H, W, s, p, k) in ((2, 25, 42, 1, 1, 3), (3, 13, 21, 2, 1, 3), (2, 50, 83, 1, 0, 1), (1, 51, 85, 2, 0, 1), (2, 37, 29, 2, 3, 7 if False else 3),
+                               (4, 200, 336, 1, 1, 3), (1, 7, 11, 1, 1, 3)):
+        OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        got = hip.rowinfo_nhwc(N, H, W, OH, OW, s, p, k, k, "cuda")
+        assert got.dtype == torch.int32 and tuple(got.shape) == (N * OH * OW, 2)
+        assert torch.equal(got.cpu(), _rowinfo_host(N, H, W, OH, OW, s, p, k, k, 0)), (N, H, W, s, p, k)
+    level_hw = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    N = 3
+    got = hip.rowinfo_ml(N, level_hw, 1, 3, "cuda")
+    parts, start = [], 0
+    for h, w in level_hw:
+        parts.append(_rowinfo_host(N, h, w, h, w, 1, 1, 3, 3, start))
+        start += N * h * w
+    assert torch.equal(got.cpu(), torch.cat(parts))
+    assert hip.rowinfo_ml(N, level_hw, 1, 3, "cuda") is got       # cached per geometry

@@ -148,13 +148,16 @@ def test_rccl_world_of_one_rank_dry_run_and_step():
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the real RCCL path between two devices (a one-GPU test box skips it)")
-def test_two_gpus_real_rccl_bench_gate():
+@pytest.mark.parametrize("model,per_gpu,dtype", [("fcos", 4, "f16"), ("rcnn", 4, "bf16"), ("rcnn", 2, "bf16")])
+def test_two_gpus_real_rccl_bench_gate(model, per_gpu, dtype):
     """The first thing to run on a multi-GPU node: `bench.py --gpus 2` over RCCL (nccl backend, one rank per GPU, gradients of the
-    student all-reduced in buckets during backward - reference engine/trainer.py:59-63,631-635 DDP).  Both ranks answered the RCCL
-    self-check, the replicas are bit-identical after the timed steps, and two GPUs process more than 1.6x the images of one
-    (weak scaling, 4+4 per GPU)."""
+    student all-reduced in buckets during backward - reference engine/trainer.py:59-63,631-635 DDP) for the FCOS trainer (configs[1] / [3])
+    and the Faster-RCNN trainer (configs[2] / [4]: 4 + 4 per GPU, and the 2 + 2 per GPU that 16 + 16 over eight GPUs is).  Both ranks
+    answered the RCCL self-check, the replicas are bit-identical after the timed steps, the line explains its own efficiency
+    (`ranks.allreduce`: exposure of the gradient collectives per step), and two GPUs process more than 1.6x the images of one (weak scaling)."""
     import json
-    common = ["--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-f32", "--no-rcnn", "--timed-only"]
+    common = ["--model", model, "--dtype", dtype, "--label", str(per_gpu), "--unlabel", str(per_gpu), "--steps", "5", "--warmup", "3",
+              "--no-cpu-baseline", "--no-f32", "--no-rcnn", "--timed-only"]
     r1 = _bench({}, ["--gpus", "1", *common])
     assert r1.returncode == 0, r1.stderr[-3000:]
     one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
@@ -167,4 +170,7 @@ def test_two_gpus_real_rccl_bench_gate():
     assert two["ranks"]["replicas"] == {"students_bit_identical": True, "teachers_bit_identical": True, "ranks_compared": 2}
     assert all(v == v for v in two["losses"].values())
     assert two["config"]["global_batch"] == 2 * one["config"]["global_batch"] and two["scaling"] == "weak"
+    ar = two["ranks"]["allreduce"]
+    assert ar and ar["steps"] == 5 and ar["buckets"] >= 4 and ar["buckets_issued_during_backward_mean"] >= ar["buckets"] - 1
+    assert ar["exposed_ms_per_step_mean"] < 0.5 * two["ms_per_step"], ar      # the collectives hide behind backward
     assert two["value"] > 1.6 * one["value"], (one["value"], two["value"])

@@ -9,7 +9,9 @@ from ubteacher.engine import UBTeacherTrainer, UBRCNNTeacherTrainer
 from ubteacher.presets import get_config
 
 model = sys.argv[1] if len(sys.argv) > 1 else "fcos"
-cfg = get_config(model, 1, ["SOLVER.IMG_PER_BATCH_LABEL", 4, "SOLVER.IMG_PER_BATCH_UNLABEL", 4, "SEMISUPNET.BURN_UP_STEP", 0,
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+os.environ.setdefault("UTV2_PRECISION", "fp16" if model == "fcos" else "bf16")
+cfg = get_config(model, 1, ["SOLVER.IMG_PER_BATCH_LABEL", B, "SOLVER.IMG_PER_BATCH_UNLABEL", B, "SEMISUPNET.BURN_UP_STEP", 0,
                             "SOLVER.AMP.ENABLED", True, "MODEL.DEVICE", "cuda"])
 torch.manual_seed(0)
 tr = (UBRCNNTeacherTrainer if model == "rcnn" else UBTeacherTrainer)(cfg)

@@ -34,13 +34,15 @@ def make():
 
 
 def timed(step, n):
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        step()
-    t1 = time.perf_counter()
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
+    from ubteacher.engine.step_gc import StepGC
+    with StepGC() as g:          # UTV2_STEP_GC=0: the interpreter's default collector
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(); g.tick()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
     return (t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3
 
 

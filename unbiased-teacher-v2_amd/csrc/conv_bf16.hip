@@ -1656,6 +1656,38 @@ int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int
   return utv2_launch_status();
 }
 
+// The per-output-pixel geometry table of the 16-bit convs / weight gradients, built ON THE DEVICE (round 6): until then the host
+// built it with torch CPU ops and copied it over - 0.3-1 s of host time and a synchronising copy for every new canvas, which is every
+// step of the reference recipes (INPUT.MIN_SIZE_TRAIN (400, 1200) "range": a new padded canvas per batch).
+//   rowinfo[m] = {start + n*H*W + (oh*stride - pad)*W + (ow*stride - pad),  (W << 16) | mask of the taps (kh, kw) inside the image}
+// for output pixel m = (n, oh, ow) of an [N, OH, OW] output over an [N, H, W] input whose first pixel has index `start`.
+__global__ __launch_bounds__(256) void rowinfo_kernel(int2* __restrict__ out, int N, int H, int W, int OH, int OW, int stride, int pad,
+                                                      int KH, int KW, long long start) {
+  const long long total = (long long)N * OH * OW;
+  for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < total; m += (long long)gridDim.x * 256) {
+    const int ow = (int)(m % OW);
+    const long long t = m / OW;
+    const int oh = (int)(t % OH), n = (int)(t / OH);
+    const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
+    int mask = 0;
+    for (int a = 0; a < KH; ++a)
+      for (int b = 0; b < KW; ++b)
+        if (ih0 + a >= 0 && ih0 + a < H && iw0 + b >= 0 && iw0 + b < W) mask |= 1 << (a * KW + b);
+    out[m] = make_int2((int)(start + (long long)n * H * W + (long long)ih0 * W + iw0), (W << 16) | mask);
+  }
+}
+
+int utv2_rowinfo_nhwc(int* out, int N, int H, int W, int OH, int OW, int stride, int pad, int KH, int KW, int64_t start,
+                      hipStream_t stream) {
+  if (!out || N < 1 || H < 1 || W < 1 || OH < 1 || OW < 1 || stride < 1 || pad < 0 || KH < 1 || KW < 1 || KH * KW > 16 || W >= 32768 ||
+      start < 0 || start + (int64_t)N * H * W >= (1ll << 31))
+    return UTV2_EARG;
+  int64_t nb = ((int64_t)N * OH * OW + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(rowinfo_kernel, dim3((int)nb), dim3(256), 0, stream, (int2*)out, N, H, W, OH, OW, stride, pad, KH, KW, (long long)start);
+  return utv2_launch_status();
+}
+
 // n must be a multiple of 4; dst16: bf16[n]
 int utv2_f32_to_bf16(const float* src, void* dst16, int64_t n, hipStream_t stream) {
   if (!src || !dst16 || (n & 3)) return UTV2_EARG;
@@ -2291,6 +2323,8 @@ static int wgrad16_small_splits(int M, int K, int Kred) {
   // ~2 workgroups per CU: every split costs a K x Kred fp32 slab written and re-read, which rivals the operand traffic
   // of the HBM-bound layers; ~4 per CU only when a workgroup's share of the MFMA work is large (load balance wins)
   const double flop = 2.0 * M * K * Kred;
+  // (round 6 A/B of this budget at 75 % / 50 % - slab bytes = workgroups x 64 KB, ~3 GB written + re-read per step: FCOS 2+2 +0.5 %,
+  // FCOS 4+4 -0.6 / -1.0 %, Faster-RCNN 2+2 -1.3 %, profiles/r06_wgs_pct_ab.txt: the load balance is worth the slabs)
   int splits = cdiv(flop > 512 * 2.0e8 ? 1024 : 512, tiles);
   const int max_by_chunks = chunks / 8 > 0 ? chunks / 8 : 1;
   if (splits > max_by_chunks) splits = max_by_chunks;

@@ -28,6 +28,7 @@ from ..modeling.ts_ensemble import EnsembleTSModel
 from ..utils import comm
 from ..data.synthetic import SyntheticTwoCropLoader
 from ..checkpoint import DetectionTSCheckpointer
+from .step_gc import StepGC
 
 
 class ArenaSGD:
@@ -381,12 +382,13 @@ class _TrainerBase:
         logger.info("Starting training from iteration {}".format(start_iter))
         self.iter = self.start_iter = start_iter
         self.max_iter = max_iter
-        with EventStorage(start_iter) as self.storage:
+        with EventStorage(start_iter) as self.storage, StepGC() as step_gc:
             try:
                 for self.iter in range(start_iter, max_iter):
                     self.run_step_full_semisup()
                     self.scheduler.step()
                     self.storage.step()
+                    step_gc.tick()
                     period = self.cfg.SOLVER.CHECKPOINT_PERIOD
                     if comm.is_main_process() and period > 0 and (self.iter + 1) % period == 0:
                         self.checkpointer.save("model_{:07d}".format(self.iter), iteration=self.iter)

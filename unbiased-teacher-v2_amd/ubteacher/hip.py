@@ -1131,19 +1131,21 @@ _rowinfo_cache = {}
 _CONV_ROWINFO = os.environ.get("UTV2_CONV_ROWINFO", "1") != "0"   # A/B: conv tile prologues decode their geometry themselves
 
 
-def _rowinfo_part(N, H, W, OH, OW, stride, pad, kh, kw, start):
-    """[N*OH*OW, 2] int32: {input pixel index of tap (0,0), (W << 16) | mask of the taps inside the image}"""
-    n = torch.arange(N, dtype=torch.int64).view(N, 1, 1)
-    ih0 = (torch.arange(OH, dtype=torch.int64) * stride - pad).view(1, OH, 1)
-    iw0 = (torch.arange(OW, dtype=torch.int64) * stride - pad).view(1, 1, OW)
-    anchor = (start + n * (H * W) + ih0 * W + iw0).expand(N, OH, OW)
-    mask = torch.zeros((1, OH, OW), dtype=torch.int64)
-    for a in range(kh):
-        for b in range(kw):
-            ok = ((ih0 + a >= 0) & (ih0 + a < H)) & ((iw0 + b >= 0) & (iw0 + b < W))
-            mask = mask | (ok.to(torch.int64) << (a * kw + b))
-    word = ((W << 16) | mask).expand(N, OH, OW)
-    return torch.stack((anchor, word), dim=-1).reshape(-1, 2).to(torch.int32)
+def _rowinfo_build(parts, device):
+    """[sum N*OH*OW, 2] int32 geometry table: {input pixel index of tap (0,0), (W << 16) | mask of the taps inside the image} per output
+    pixel, built by utv2_rowinfo_nhwc on the device (one launch per part = (N, H, W, OH, OW, stride, pad, kh, kw, first pixel index)).
+    A table is built once per geometry and then read by launches of EVERY stream (teacher side stream, weight-gradient lanes): the
+    building stream is drained before the table enters the cache - once per new canvas, no host arithmetic, no copy."""
+    total = sum(p[0] * p[3] * p[4] for p in parts)
+    t = torch.empty((total, 2), dtype=torch.int32, device=device)
+    off = 0
+    for (N, H, W, OH, OW, stride, pad, kh, kw, start) in parts:
+        call("utv2_rowinfo_nhwc", c_p(t.data_ptr() + 8 * off), N, H, W, OH, OW, stride, pad, kh, kw, start, _stream())
+        off += N * OH * OW
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("a conv geometry table was built inside a hipGraph capture: run the step eagerly once for every canvas first")
+    torch.cuda.current_stream(t.device).synchronize()
+    return t
 
 
 def rowinfo_nhwc(N, H, W, OH, OW, stride, pad, kh, kw, device):
@@ -1152,8 +1154,7 @@ def rowinfo_nhwc(N, H, W, OH, OW, stride, pad, kh, kw, device):
     key = ("nhwc", N, H, W, OH, OW, stride, pad, kh, kw, str(device))
     t = _rowinfo_cache.get(key)
     if t is None:
-        t = _rowinfo_part(N, H, W, OH, OW, stride, pad, kh, kw, 0).contiguous().to(device)
-        _rowinfo_cache[key] = t
+        t = _rowinfo_cache[key] = _rowinfo_build([(N, H, W, OH, OW, stride, pad, kh, kw, 0)], device)
     return t
 
 
@@ -1163,31 +1164,10 @@ def rowinfo_ml(N, level_hw, pad, k, device):
     if t is None:
         parts, start = [], 0
         for (h, w) in level_hw:
-            parts.append(_rowinfo_part(N, h, w, h, w, 1, pad, k, k, start))
+            parts.append((N, h, w, h, w, 1, pad, k, k, start))
             start += N * h * w
-        t = torch.cat(parts).contiguous().to(device)
-        _rowinfo_cache[key] = t
+        t = _rowinfo_cache[key] = _rowinfo_build(parts, device)
     return t
-
-
-def conv2d_wgrad_bf16(x, dy2d, dw, rowinfo, C, kh, kw, accumulate=True, db=None, rowscale=None, groups=1, x_pitch=None):
-    """x: fp32/bf16 activations (any layout consistent with rowinfo; x_pitch = elements between consecutive pixels when x is a channel
-    slice of a wider matrix), dy2d [M,K] fp32/bf16 (may be the leading K columns of a wider, zero-padded matrix); dw [K, kh*kw*C] (+)=
-    wgrad (C = input channels per group); db [K] (optional) (+)= column sums of dy (bias gradient, fused into the dY staging)."""
-    M, K = dy2d.shape
-    assert dy2d.stride(1) == 1
-    dy_pitch = int(dy2d.stride(0))
-    nws = load().utv2_conv2d_wgrad_bf16_workspace_floats(M, K, kh * kw * C)
-    ws = workspace(nws, dy2d.device, "wgrad")
-    if groups == 1 and (x_pitch is None or x_pitch == C) and dy_pitch == K:
-        call("utv2_conv2d_wgrad_bf16", _p(x), _dt(x), _p(dy2d), _dt(dy2d), _p(dw), _p(db), _p(ws), _p(rowinfo), _p(rowscale), M, C, K, kh,
-             kw, int(accumulate), _stream())
-    else:
-        xp = c_p(x.data_ptr())
-        pitch = int(x_pitch) if x_pitch is not None else groups * C
-        call("utv2_conv2d_wgrad_bf16_g", xp, _dt(x), pitch, c_p(dy2d.data_ptr()), _dt(dy2d), dy_pitch, _p(dw), _p(db), _p(ws), _p(rowinfo),
-             _p(rowscale), M, C, K, kh, kw, int(accumulate), int(groups), _stream())
-    return dw
 
 
 def groupnorm_relu_seg_fwd(x2d, seg_rows, gamma, beta, G=32, eps=1e-5, relu=True):

@@ -41,6 +41,10 @@ class GradBuckets:
         self.last_order = []     # ... of the last finished step (tests)
         self.prelaunched = []    # buckets reduced at arm() (no registered writer): UTV2_GRAD_SYNC_DEBUG=1 re-checks them in finish()
         self._ops = None
+        # exposure bookkeeping (bench.py --gpus N): per step, device events around the wait in finish() = the time the main stream sat
+        # between the end of backward and the last collective's completion, and how many buckets had already been issued by then
+        self.timing = False
+        self._expo = []          # (event at finish() entry, event after the waits, buckets issued during backward, buckets in all)
 
     def bucket_of(self, h):
         return bisect.bisect_right(self.starts, int(h.offset)) - 1
@@ -104,12 +108,21 @@ class GradBuckets:
 
     def finish(self):
         """after backward: reduce the buckets that are still waiting (in the same static order), wait for everything"""
+        early = len(self.order)
+        ev0 = None
+        if self.timing and self.grad.is_cuda:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         while self.next >= 0:
             self._launch(self.next)
             self.next -= 1
         for w in self.works:
             w.wait()
         self.works = []
+        if ev0 is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            self._expo.append((ev0, ev1, early, len(self.order)))
         if _DEBUG and self.prelaunched:
             now = [float(self.grad[s:e].double().abs().sum()) for s, e in (self.bounds[b] for b in self.prelaunched)]
             bad = [b for b, x, y in zip(self.prelaunched, self._pre_sums, now) if x != y]
@@ -122,6 +135,23 @@ class GradBuckets:
         self.launched = [False] * nb
         self.next = nb - 1
         self.last_order, self.order = self.order, []
+
+
+    def exposure_summary(self, reset=True):
+        """(bench) mean / max milliseconds per step the main stream waited in finish() for the gradient collectives - the part of the
+        all-reduce that backward did NOT hide - with the bucket layout.  Synchronises on the recorded events."""
+        if not self._expo:
+            return None
+        ms = [a.elapsed_time(b) for a, b, _, _ in self._expo]
+        out = {"steps": len(ms), "exposed_ms_per_step_mean": sum(ms) / len(ms), "exposed_ms_per_step_max": max(ms),
+               "buckets": len(self.bounds), "bucket_mbytes": [round(4 * (e - s) / 2 ** 20, 2) for s, e in self.bounds],
+               "buckets_issued_during_backward_mean": sum(x[2] for x in self._expo) / len(self._expo),
+               "gradient_mbytes_per_step": round(4 * self.grad.numel() / 2 ** 20, 1),
+               "note": "device time between the end of backward on the main stream and the completion of the last bucket's all-reduce (what "
+                       "the optimizer step waits for); buckets are issued from the weight-gradient stream as their last writer reports"}
+        if reset:
+            self._expo = []
+        return out
 
 
 def param_handles(layer):
