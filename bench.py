@@ -218,7 +218,9 @@ class ConvTimer:
 class WgradTimer:
     """HIP-event timing of the FCOS tower weight-gradient launches (conv_wgrad_bf16_pp - the 256-tile kernel on the ping-pong schedule, round 5 - + reduce_slabs16_f32 + the bias column sums:
     one C-ABI call = one timed launch): the largest single symbol of the round-1 profile."""
-    kernel = "conv_wgrad_bf16_pp+reduce_slabs16_f32+colsum_bf16_* (FCOS tower 3x3 weight gradients)"
+    kernel = ("conv_wgrad_bf16_pp+colsum_bf16_partial (FCOS tower 3x3 weight gradients; their split-K tails run folded, one reduce_slabs_table launch "
+              "per <= 8 layers of a lane, outside this timing)" if os.environ.get("UTV2_WGRAD_FOLD", "0") == "1" else
+              "conv_wgrad_bf16_pp+reduce_slabs16_f32+colsum_bf16_* (FCOS tower 3x3 weight gradients)")
 
     def __init__(self):
         self.pairs = []

@@ -124,6 +124,17 @@ int utv2_conv2d_wgrad_bf16(const void* x, int x_dtype, const void* dy, int dy_dt
 int utv2_conv2d_wgrad_bf16_g(const void* x, int x_dtype, int x_pitch, const void* dy, int dy_dtype, int dy_pitch, float* dw, float* db,
                              float* ws, const int* rowinfo, const float* rowscale, int M, int C, int K, int KH, int KW, int accumulate,
                              int groups, utv2_stream_t stream);
+/* The same launch with its split-K tail (slab reduction, bias reduction) RECORDED in a caller-owned pending table - host memory of
+ * utv2_wgrad_fold_table_bytes() bytes, zero-initialised - instead of launched: utv2_wgrad_fold_flush runs the recorded tails of up to 8
+ * launches as ONE kernel, with the arithmetic of the separate kernels (bit-identical gradients).  dw / db are valid after the flush on the
+ * same stream; every recorded launch needs its own ws until then; two recorded launches must not share dw or db (EARG: flush first).
+ * utv2_wgrad_fold_pending: recorded tails (0 = nothing to flush).  The per-layer tails of a backward are 60-70 dispatches of 5-25 us. */
+int utv2_conv2d_wgrad_bf16_d(const void* x, int x_dtype, int x_pitch, const void* dy, int dy_dtype, int dy_pitch, float* dw, float* db,
+                             float* ws, const int* rowinfo, const float* rowscale, int M, int C, int K, int KH, int KW, int accumulate,
+                             int groups, void* pending, utv2_stream_t stream);
+int64_t utv2_wgrad_fold_table_bytes(void);
+int utv2_wgrad_fold_pending(const void* pending);
+int utv2_wgrad_fold_flush(void* pending, utv2_stream_t stream);
 /* D2 BasicStem conv1 on bf16 MFMA: xpad16 = bf16 [N][H+6][W+8][4], the normalised NHWC4 image inside a zero border
  * (written by utv2_preprocess_image_bf16pad); w16s = bf16 [K][7][32] (7 taps x 4 channels + 4 zeros per kernel row) */
 int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int y_dtype, const float* scale,
@@ -298,7 +309,7 @@ int utv2_fcos_loss_combine(const float* focal_sup, const float* sums_sup, const 
 int utv2_fcos_rank_keys(const float* logits, const float* box, int box_stride, int reg_max, int N, int HW, int C,
                         float thr, int method, long long* keys, int64_t key_row_stride, utv2_stream_t stream);
 /* :1238-1241 `topk(pre_nms_top_n)` for every (image, level) row at once: exact MSD radix select over ragged rows
- * (row r = keys[row_off[r] .. row_off[r+1]), row_off device int64[rows+1]); out[rows][k] descending, -1 padded; k <= 2048 */
+ * (row r = keys[row_off[r] .. row_off[r+1]), row_off device int64[rows+1]); out[rows][k] descending, -1 padded; k <= 8192 */
 int64_t utv2_topk_rows_workspace_bytes(int rows, int k);
 int utv2_topk_rows_i64(const long long* keys, const long long* row_off, int rows, int64_t max_width, int k, long long* out,
                        void* ws, utv2_stream_t stream);

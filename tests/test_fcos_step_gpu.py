@@ -511,6 +511,66 @@ def test_weight_gradient_lanes_bit_identical(monkeypatch):
     assert digests[0] == digests[1] == digests[2]
 
 
+@pytest.mark.parametrize("kind", ["fcos", "rcnn"])
+def test_folded_split_k_tails_bit_identical(kind, monkeypatch):
+    """Round 6: the weight gradients' split-K tails (slab reduction, bias reduction, bias column sums - 60-70 launches per step) are
+    recorded per weight-gradient lane and run as one launch per <= 8 layers (utv2_conv2d_wgrad_bf16_d / utv2_wgrad_fold_flush,
+    reduce_slabs_table) with the arithmetic of the kernels they replace: the student after two AMP steps is the same to the BIT with the
+    tails folded (UTV2_WGRAD_FOLD=1; opt-in: it does not move the step time) and launched one by one (default) - both trainers (shared tower weights: two launches accumulate into
+    one gradient and must not share a flush)."""
+    monkeypatch.setenv("UTV2_PRECISION", "bf16")
+    import hashlib
+    from ubteacher import ops
+    from ubteacher.engine import UBRCNNTeacherTrainer, UBTeacherTrainer
+    digests, flushes = [], []
+    try:
+        for fold in ("1", "0"):
+            monkeypatch.setenv("UTV2_WGRAD_FOLD", fold)
+            torch.manual_seed(0)
+            if kind == "fcos":
+                cfg = small_fcos_cfg()
+                cfg.SOLVER.AMP.ENABLED = True
+                prod, orac = make_batch(12, 2, 2, H, W, "cuda")
+                tr = UBTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+                sd_s = tune_state_for_pseudo_labels(cpu_state(tr.model), [d["image"] for d in orac[3]])
+                tr.model.load_state_dict(sd_s); tr.model_teacher.load_state_dict(sd_s)
+            else:
+                from tests.test_rcnn_step_gpu import rcnn_cfg
+                cfg = rcnn_cfg()
+                cfg.SOLVER.AMP.ENABLED = True
+                prod, orac = make_batch(31, 2, 2, H, W, "cuda")
+                tr = UBRCNNTeacherTrainer(cfg, data_loader=FixedLoader(prod))
+                g = torch.Generator().manual_seed(5)      # the trainer draws its sampling keys with torch.rand on the device: pin them
+                tr.model.proposal_generator.sample_keys = lambda n, m, device, g=g: torch.rand((n, m), generator=g).to(device)
+                tr.model.roi_heads.sample_keys = lambda n, m, device, g=g: torch.rand((n, m), generator=g).to(device)
+            tr.iter = 1
+            tr.optimizer.param_groups[0]["lr"] = 1e-4
+            from ubteacher import hip
+            n0 = [0]
+            orig = hip.call
+
+            def counted(name, *a, n0=n0, orig=orig):
+                if name == "utv2_wgrad_fold_flush":
+                    n0[0] += 1
+                return orig(name, *a)
+            hip.call = counted
+            try:
+                for _ in range(2):
+                    tr.run_step_full_semisup()
+                    tr.iter += 1
+            finally:
+                hip.call = orig
+            torch.cuda.synchronize()
+            state = tr.model.flat_state().detach().float().cpu().numpy()
+            assert np.isfinite(state).all()
+            digests.append(hashlib.sha1(state.tobytes()).hexdigest())
+            flushes.append(n0[0])
+    finally:
+        ops.set_precision("fp32")
+    assert digests[0] == digests[1]
+    assert flushes[0] >= 2 and flushes[1] == 0, flushes
+
+
 def test_stage_output_gradient_handoff(monkeypatch):
     """The gradient of a backbone stage output has two producers (the FPN lateral's dgrad, the next stage's first block).  By default the
     lateral parks its part and the block adds it in the kernel that makes its own (utv2_zero_interleave2x_add_nhwc) instead of autograd

@@ -2315,6 +2315,106 @@ __global__ void reduce_slabs16_scalar_f32(const float* __restrict__ ws, float* _
   dst[i] = accumulate ? dst[i] + s : s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The split-K tails of SEVERAL weight-gradient launches as ONE launch (round 6).  A step has ~56 weight-gradient launches, each followed
+// by its slab reduction (+ a bias reduction): 60-70 dispatches of 5-25 us that sit in their own launch gaps on the weight-gradient
+// lanes.  With a pending table (utv2_conv2d_wgrad_bf16_d) a launch only RECORDS its tail - {slabs, destination, splits, scale} - and
+// utv2_wgrad_fold_flush runs all recorded tails in one kernel: workgroups are dealt to the entries in proportion to their size, and every
+// entry is reduced with exactly the arithmetic (order of the partial sums included) of the kernel it replaces:
+//   kind 0 = reduce_slabs16_f32, kind 1 = reduce_slabs16_scalar_f32, kind 2 = colsum_final_f32  ->  bit-identical gradients.
+#define SLAB_FOLD_MAX 24
+struct SlabFold {
+  const float* ws;          // kind 0 / 1: [splits][n] slabs; kind 2: [splits = row blocks][n = K] partial column sums
+  float* dst;
+  const float* rowscale;
+  unsigned long long n;
+  int splits, accumulate, rowlen, kind;
+  int blk0, nblk;           // this entry's workgroups: [blk0, blk0 + nblk)
+};
+struct SlabFoldTable {
+  int count, total_blocks;
+  SlabFold e[SLAB_FOLD_MAX];
+};
+
+__global__ __launch_bounds__(256) void reduce_slabs_table(SlabFoldTable t) {
+  __shared__ float red[256];
+  int ei = 0;
+  for (int i = 1; i < t.count; ++i)
+    if ((int)blockIdx.x >= t.e[i].blk0) ei = i;
+  const SlabFold f = t.e[ei];
+  const int lb = (int)blockIdx.x - f.blk0;
+  if (f.kind == 0) {          // == reduce_slabs16_f32
+    const size_t n4 = f.n >> 2;
+    const size_t stride = (size_t)f.nblk * 256;
+    for (size_t i = (size_t)lb * 256 + threadIdx.x; i < n4; i += stride) {
+      f32x4 s[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      int k = 0;
+      for (; k + 4 <= f.splits; k += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[u] += ((const f32x4*)(f.ws + (size_t)(k + u) * f.n))[i];
+      }
+      for (; k < f.splits; ++k) s[0] += ((const f32x4*)(f.ws + (size_t)k * f.n))[i];
+      f32x4 v = (s[0] + s[1]) + (s[2] + s[3]);
+      if (f.rowscale) {
+        const float r = f.rowscale[(i * 4) / f.rowlen];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= r;
+      }
+      if (f.accumulate) v += ((const f32x4*)f.dst)[i];
+      ((f32x4*)f.dst)[i] = v;
+    }
+  } else if (f.kind == 1) {   // == reduce_slabs16_scalar_f32
+    for (size_t i = (size_t)lb * 256 + threadIdx.x; i < f.n; i += (size_t)f.nblk * 256) {
+      float s = 0.f;
+      for (int k = 0; k < f.splits; ++k) s += f.ws[(size_t)k * f.n + i];
+      if (f.rowscale) s *= f.rowscale[i];
+      f.dst[i] = f.accumulate ? f.dst[i] + s : s;
+    }
+  } else {                    // == colsum_final_f32 (one workgroup per 32 channels; the branch is workgroup-uniform)
+    const int K = (int)f.n, nb = f.splits;
+    const int c = lb * 32 + (threadIdx.x & 31), part = threadIdx.x >> 5;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < K) {
+      int b = part;
+      for (; b + 24 < nb; b += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[u] += f.ws[(size_t)(b + 8 * u) * K + c];
+      }
+      for (; b < nb; b += 8) s[0] += f.ws[(size_t)b * K + c];
+    }
+    red[threadIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (part == 0 && c < K) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v += red[threadIdx.x + 32 * k];
+      if (f.rowscale) v *= f.rowscale[c];
+      f.dst[c] = f.accumulate ? f.dst[c] + v : v;
+    }
+  }
+}
+
+static int slab_fold_add(SlabFoldTable* t, int kind, const float* ws, float* dst, const float* rowscale, size_t n, int splits, int accumulate,
+                         int rowlen) {
+  if (t->count < 0 || t->count >= SLAB_FOLD_MAX) return UTV2_EARG;
+  for (int i = 0; i < t->count; ++i)   // two tails of one table run concurrently: they must not write the same gradient
+    if (t->e[i].dst == dst) return UTV2_EARG;
+  SlabFold& f = t->e[t->count];
+  f.kind = kind; f.ws = ws; f.dst = dst; f.rowscale = rowscale; f.n = n; f.splits = splits; f.accumulate = accumulate; f.rowlen = rowlen;
+  int nb;
+  if (kind == 0) { nb = cdiv((int64_t)n / 4, 256); if (nb > 2048) nb = 2048; }
+  else if (kind == 1) nb = cdiv((int64_t)n, 256);
+  else nb = cdiv((int64_t)n, 32);
+  if (nb < 1) nb = 1;
+  f.blk0 = t->count == 0 ? 0 : t->e[t->count - 1].blk0 + t->e[t->count - 1].nblk;
+  f.nblk = nb;
+  t->total_blocks = f.blk0 + nb;
+  ++t->count;
+  return UTV2_OK;
+}
+
 extern "C" {
 
 static int wgrad16_small_splits(int M, int K, int Kred) {
@@ -2391,7 +2491,7 @@ int64_t utv2_conv2d_wgrad_bf16_workspace_floats(int M, int K, int Kred) {
 // (K / groups) % 128 == 0, x_pitch >= groups * C.
 static int wgrad_bf16_impl(const void* x, int x_dtype, int x_pitch, const void* dy, int dy_dtype, int dy_pitch, float* dw, float* db,
                            float* ws, const int* rowinfo, const float* rowscale, int M, int C, int K, int KH, int KW, int accumulate,
-                           int groups, hipStream_t stream);
+                           int groups, hipStream_t stream, SlabFoldTable* pending = nullptr);
 
 int utv2_conv2d_wgrad_bf16(const void* x, int x_dtype, const void* dy, int dy_dtype, float* dw, float* db, float* ws,
                            const int* rowinfo, const float* rowscale, int M, int C, int K, int KH, int KW, int accumulate,
@@ -2406,9 +2506,37 @@ int utv2_conv2d_wgrad_bf16_g(const void* x, int x_dtype, int x_pitch, const void
                          stream);
 }
 
+// The same with the split-K tail RECORDED in a caller-owned pending table instead of launched (see reduce_slabs_table): dw / db hold the
+// result only after utv2_wgrad_fold_flush(pending, stream) on the same stream; ws must stay untouched until then (a separate workspace per
+// recorded launch), and two recorded launches of one table must not share dw or db (the call refuses: flush first).  Room for 8 launches.
+int utv2_conv2d_wgrad_bf16_d(const void* x, int x_dtype, int x_pitch, const void* dy, int dy_dtype, int dy_pitch, float* dw, float* db,
+                             float* ws, const int* rowinfo, const float* rowscale, int M, int C, int K, int KH, int KW, int accumulate,
+                             int groups, void* pending, hipStream_t stream) {
+  if (!pending) return UTV2_EARG;
+  SlabFoldTable* t = (SlabFoldTable*)pending;
+  if (t->count < 0 || t->count + 3 > SLAB_FOLD_MAX) return UTV2_EARG;
+  return wgrad_bf16_impl(x, x_dtype, x_pitch, dy, dy_dtype, dy_pitch, dw, db, ws, rowinfo, rowscale, M, C, K, KH, KW, accumulate, groups,
+                         stream, t);
+}
+
+int64_t utv2_wgrad_fold_table_bytes(void) { return (int64_t)sizeof(SlabFoldTable); }
+
+int utv2_wgrad_fold_pending(const void* pending) { return pending ? ((const SlabFoldTable*)pending)->count : -1; }
+
+int utv2_wgrad_fold_flush(void* pending, hipStream_t stream) {
+  if (!pending) return UTV2_EARG;
+  SlabFoldTable* t = (SlabFoldTable*)pending;
+  if (t->count < 0 || t->count > SLAB_FOLD_MAX) return UTV2_EARG;
+  if (t->count == 0) return UTV2_OK;
+  hipLaunchKernelGGL(reduce_slabs_table, dim3(t->total_blocks), dim3(256), 0, stream, *t);
+  t->count = 0;
+  t->total_blocks = 0;
+  return utv2_launch_status();
+}
+
 static int wgrad_bf16_impl(const void* x, int x_dtype, int x_pitch, const void* dy, int dy_dtype, int dy_pitch, float* dw, float* db,
                            float* ws, const int* rowinfo, const float* rowscale, int M, int C, int K, int KH, int KW, int accumulate,
-                           int groups, hipStream_t stream) {
+                           int groups, hipStream_t stream, SlabFoldTable* pending) {
   if (!x || !dy || !dw || !ws || !rowinfo || (C & 7) || (K & 7) || M <= 0 || KH * KW > 16 || bad_dtype(x_dtype) ||
       bad_dtype(dy_dtype) || groups < 1 || K % groups || x_pitch < groups * C || (groups > 1 && (K / groups) % 128) ||
       (x_pitch != C && (x_pitch & (x_dtype == UTV2_BF16 ? 7 : 3))) || dy_pitch < K || (dy_pitch != K && (dy_pitch & (dy_dtype == UTV2_BF16 ? 7 : 3))))
@@ -2427,7 +2555,10 @@ static int wgrad_bf16_impl(const void* x, int x_dtype, int x_pitch, const void* 
     hipLaunchKernelGGL(conv_wgrad_bf16_pp, dim3(wgrad16_w8_budget()), dim3(512), smem, stream, a);
     int rb = cdiv((int64_t)n / 4, 256);
     if (rb > 8192) rb = 8192;
-    hipLaunchKernelGGL(reduce_slabs16_f32, dim3(rb), dim3(256), 0, stream, (const float*)ws, dw, n, a.splits, accumulate, rowscale,
+    if (pending) {
+      if (int rc = slab_fold_add(pending, 0, ws, dw, rowscale, n, a.splits, accumulate, a.Kred)) return rc;
+    } else
+      hipLaunchKernelGGL(reduce_slabs16_f32, dim3(rb), dim3(256), 0, stream, (const float*)ws, dw, n, a.splits, accumulate, rowscale,
                          a.Kred);
     if (db) {
       float* part = ws + (size_t)a.splits * n;
@@ -2436,7 +2567,10 @@ static int wgrad_bf16_impl(const void* x, int x_dtype, int x_pitch, const void* 
       const int rows = cdiv(M, nb);
       nb = cdiv(M, rows);
       hipLaunchKernelGGL(colsum_bf16_partial, dim3(nb), dim3(256), 0, stream, (const h16_t*)dy, part, M, K, rows);
-      hipLaunchKernelGGL(colsum_final_f32, dim3(cdiv(K, 32)), dim3(256), 0, stream, (const float*)part, db, nb, K, accumulate, rowscale);
+      if (pending) {
+        if (int rc = slab_fold_add(pending, 2, part, db, rowscale, (size_t)K, nb, accumulate, 1)) return rc;
+      } else
+        hipLaunchKernelGGL(colsum_final_f32, dim3(cdiv(K, 32)), dim3(256), 0, stream, (const float*)part, db, nb, K, accumulate, rowscale);
     }
     return utv2_launch_status();
   }
@@ -2455,6 +2589,12 @@ static int wgrad_bf16_impl(const void* x, int x_dtype, int x_pitch, const void* 
   }
   int rb = cdiv((int64_t)n / 4, 256);   // n = K * Kred, both multiples of 8
   if (rb > 8192) rb = 8192;
+  if (pending) {
+    if (int rc = slab_fold_add(pending, 0, ws, dw, rowscale, n, a.splits, accumulate, a.Kred)) return rc;
+    if (db)
+      if (int rc = slab_fold_add(pending, 1, a.bias_ws, db, rowscale, (size_t)K, a.splits, accumulate, 1)) return rc;
+    return utv2_launch_status();
+  }
   hipLaunchKernelGGL(reduce_slabs16_f32, dim3(rb), dim3(256), 0, stream, (const float*)ws, dw, n, a.splits, accumulate, rowscale,
                        a.Kred);
   if (db)

@@ -14,7 +14,7 @@
 #include "common.h"
 
 #define TK_BINS 2048
-#define TK_MAXK 2048
+#define TK_MAXK 8192   // the bitonic sort of the selected keys runs in LDS: 8192 x 8 B = 64 KB (opt-in above 48 KB, see the launcher)
 
 struct TkState {
   unsigned long long prefix;  // decided high bits of the k-th largest key
@@ -200,7 +200,7 @@ int64_t utv2_topk_rows_workspace_bytes(int rows, int k) {
 }
 
 // keys: ragged rows, row r = keys[row_off[r] .. row_off[r+1]) (row_off: device int64[rows+1]); max_width = widest row (host).
-// out[rows][k] = the k largest keys of every row in descending order, -1 padded.  1 <= k <= 2048.
+// out[rows][k] = the k largest keys of every row in descending order, -1 padded.  1 <= k <= 8192.
 int utv2_topk_rows_i64(const long long* keys, const long long* row_off, int rows, int64_t max_width, int k, long long* out, void* ws,
                        hipStream_t stream) {
   if (!keys || !row_off || !out || !ws || rows <= 0 || k < 1 || k > TK_MAXK || max_width < 1) return UTV2_EARG;
@@ -223,6 +223,8 @@ int utv2_topk_rows_i64(const long long* keys, const long long* row_off, int rows
                      stage, k, rows);
   int kpad = 2;
   while (kpad < k) kpad <<= 1;
+  static LdsOptIn sort_opt_in;
+  sort_opt_in({(const void*)topk_sort_kernel}, TK_MAXK * (int)sizeof(long long));
   hipLaunchKernelGGL(topk_sort_kernel, dim3(rows), dim3(256), kpad * sizeof(long long), stream, (const int*)cursors,
                      (const long long*)stage, out, k, kpad);
   return utv2_launch_status();

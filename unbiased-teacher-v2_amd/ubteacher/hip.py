@@ -69,7 +69,7 @@ def _parse_header(path):
 
 _SIGS = _parse_header(HEADER_PATH)
 _PLAIN = {"utv2_aug_resize_workspace_bytes", "utv2_topk_rows_workspace_bytes", "utv2_groupnorm_seg_workspace_floats", "utv2_groupnorm_seg_chunks", "utv2_conv2d_wgrad_bf16_splits", "utv2_conv2d_wgrad_bf16_workspace_floats", "utv2_conv2d_bf16_supported", "utv2_conv2d_wgrad_splits", "utv2_conv2d_wgrad_workspace_floats", "utv2_groupnorm_workspace_floats",
-          "utv2_nms_mpad", "utv2_nms_workspace_bytes", "utv2_bottleneck_supported"}  # return a value, not a status
+          "utv2_nms_mpad", "utv2_nms_workspace_bytes", "utv2_bottleneck_supported", "utv2_wgrad_fold_table_bytes", "utv2_wgrad_fold_pending"}  # return a value, not a status
 
 
 _libs = {}
@@ -1168,6 +1168,74 @@ def rowinfo_ml(N, level_hw, pad, k, device):
             start += N * h * w
         t = _rowinfo_cache[key] = _rowinfo_build(parts, device)
     return t
+
+
+class WgradFoldLane:
+    """The recorded split-K tails of one weight-gradient stream (include/utv2.h utv2_conv2d_wgrad_bf16_d): up to CAP launches leave their
+    slabs in consecutive pieces of one arena and their {slabs, gradient, splits, scale} in a host table; flush() reduces all of them with
+    ONE launch (bit-identical to the per-launch kernels) instead of 1-2 launches behind every weight gradient.  Everything here is issued
+    on the lane's stream, the caller's current stream."""
+    CAP = max(1, min(8, int(os.environ.get("UTV2_WGRAD_FOLD_CAP", "8"))))
+
+    def __init__(self):
+        self.table = ctypes.create_string_buffer(int(load().utv2_wgrad_fold_table_bytes()))
+        self.arena = None
+        self.off = 0
+        self.n = 0
+        self.dsts = set()
+
+    def take(self, nfloats, device, dsts):
+        """a piece of the arena for one launch whose tails write `dsts` (data pointers); flushes first when the table is full, the arena
+        is, or an already recorded tail writes the same gradient (two tails of one flush run concurrently)"""
+        nfl = (int(nfloats) + 63) // 64 * 64
+        if self.n >= self.CAP or any(d in self.dsts for d in dsts) or (self.arena is not None and self.off + nfl > self.arena.numel()):
+            self.flush()
+        if self.arena is None or nfl > self.arena.numel():
+            self.flush()
+            self.arena = torch.empty(max(4 * nfl, 1 << 24), dtype=torch.float32, device=device)
+            self.off = 0
+        v = self.arena[self.off:self.off + nfl]
+        self.off += nfl
+        self.n += 1
+        self.dsts.update(dsts)
+        return v
+
+    def flush(self):
+        if self.n:
+            call("utv2_wgrad_fold_flush", ctypes.cast(self.table, c_p), _stream())
+        self.n = 0
+        self.off = 0
+        self.dsts.clear()
+
+
+WGRAD_FOLD = [None]     # the WgradFoldLane the weight gradients of the current stream record their tails in (ops._wgrad_issue), or None
+
+
+def conv2d_wgrad_bf16(x, dy2d, dw, rowinfo, C, kh, kw, accumulate=True, db=None, rowscale=None, groups=1, x_pitch=None):
+    """x: fp32/bf16 activations (any layout consistent with rowinfo; x_pitch = elements between consecutive pixels when x is a channel
+    slice of a wider matrix), dy2d [M,K] fp32/bf16 (may be the leading K columns of a wider, zero-padded matrix); dw [K, kh*kw*C] (+)=
+    wgrad (C = input channels per group); db [K] (optional) (+)= column sums of dy (bias gradient, fused into the dY staging)."""
+    M, K = dy2d.shape
+    assert dy2d.stride(1) == 1
+    dy_pitch = int(dy2d.stride(0))
+    nws = load().utv2_conv2d_wgrad_bf16_workspace_floats(M, K, kh * kw * C)
+    lane = WGRAD_FOLD[0]
+    if lane is not None:
+        ws = lane.take(nws, dy2d.device, [dw.data_ptr()] + ([db.data_ptr()] if db is not None else []))
+        pitch = int(x_pitch) if x_pitch is not None else groups * C
+        call("utv2_conv2d_wgrad_bf16_d", c_p(x.data_ptr()), _dt(x), pitch, c_p(dy2d.data_ptr()), _dt(dy2d), dy_pitch, _p(dw), _p(db), _p(ws),
+             _p(rowinfo), _p(rowscale), M, C, K, kh, kw, int(accumulate), int(groups), ctypes.cast(lane.table, c_p), _stream())
+        return dw
+    ws = workspace(nws, dy2d.device, "wgrad")
+    if groups == 1 and (x_pitch is None or x_pitch == C) and dy_pitch == K:
+        call("utv2_conv2d_wgrad_bf16", _p(x), _dt(x), _p(dy2d), _dt(dy2d), _p(dw), _p(db), _p(ws), _p(rowinfo), _p(rowscale), M, C, K, kh,
+             kw, int(accumulate), _stream())
+    else:
+        xp = c_p(x.data_ptr())
+        pitch = int(x_pitch) if x_pitch is not None else groups * C
+        call("utv2_conv2d_wgrad_bf16_g", xp, _dt(x), pitch, c_p(dy2d.data_ptr()), _dt(dy2d), dy_pitch, _p(dw), _p(db), _p(ws), _p(rowinfo),
+             _p(rowscale), M, C, K, kh, kw, int(accumulate), int(groups), _stream())
+    return dw
 
 
 def groupnorm_relu_seg_fwd(x2d, seg_rows, gamma, beta, G=32, eps=1e-5, relu=True):

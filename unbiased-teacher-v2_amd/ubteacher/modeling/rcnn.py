@@ -523,7 +523,17 @@ class FastRCNNFocaltLossBoundaryVarOutputLayers:
             wx, wy = self.box2box_transform.weights[0], self.box2box_transform.weights[1]
             dec, keys = hip.roi_infer_keys(pr, deltas.contiguous(), pb.contiguous(), proposals["valid"].contiguous(), hwt.view(N, 4), K, wx, wy,
                                            self.box2box_transform.scale_clamp, self.test_score_thresh)
-            top = torch.topk(keys, min(max_cand, P * K), dim=1, sorted=True).values
+            # the (probability desc, flat index asc) top candidates of every image: the exact radix select of the FCOS / RPN top-k
+            # (utv2_topk_rows_i64, 9 launches) - torch.topk on an [N, P*K = 80 000] matrix with k = 8192 is ~40 launches (multi-block radix
+            # select + segmented sort); same keys, same order (distinct keys: the selected set and its order are unique)
+            kk = min(max_cand, P * K)
+            if os.environ.get("UTV2_ROI_TOPK", "1") != "0" and kk <= 8192:
+                ro = cache.get(("row_off", N, P * K, str(pb.device)))
+                if ro is None:
+                    ro = cache[("row_off", N, P * K, str(pb.device))] = (torch.arange(N + 1, dtype=torch.int64) * (P * K)).to(pb.device)
+                top = hip.topk_rows(keys.view(-1), ro, N, P * K, kk)
+            else:
+                top = torch.topk(keys, kk, dim=1, sorted=True).values
             sc, r, c, cb, valid = hip.roi_infer_gather(top, dec, K, self.test_score_thresh)
             D = self.test_topk_per_image
             kidx, cnt = hip.nms_batched(cb, sc, c, valid, self.test_nms_thresh, class_aware=True, post_topk=-1, max_out=D)

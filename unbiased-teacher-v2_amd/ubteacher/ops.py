@@ -118,11 +118,40 @@ def _wgrad_issue(fn, tensors, key, ready):
     else:
         side.wait_stream(torch.cuda.current_stream(dev))   # the operands (and the zeroed gradient arena) are ready
     with torch.cuda.stream(side):
-        fn()
+        if _fold_on():
+            # the split-K tails (slab / bias reductions) of this lane's launches are recorded and run as one launch per <= 8 launches
+            folds = _WGRAD.setdefault("folds", {})
+            fl = folds.get(side)
+            if fl is None:
+                fl = folds[side] = hip.WgradFoldLane()
+            prev, hip.WGRAD_FOLD[0] = hip.WGRAD_FOLD[0], fl
+            try:
+                fn()
+            finally:
+                hip.WGRAD_FOLD[0] = prev
+        else:
+            fn()
     for t in tensors:
         if t is not None:
             t.record_stream(side)
     _WGRAD["pending"].add(dev)
+
+
+def _fold_on():
+    """UTV2_WGRAD_FOLD=1 (opt-in).  Measured (round 6, profiles/r06_fold_ab.txt, r06_fold_cap_ab.txt; interleaved runs on one box): 472 ->
+    ~415 dispatches per FCOS step and NO change of the step time - FCOS 2+2 298.7-299.6 against 298.7 img/s, 4+4 347.7-347.9 against
+    347.1-350.1, Faster-RCNN 2+2 276-279 against 280.8 (the last flush of a lane sits between the end of backward and the optimizer),
+    at any flush period (2 / 4 / 8 launches): the per-layer tails were already hidden on the weight-gradient lanes."""
+    return os.environ.get("UTV2_WGRAD_FOLD", "0") == "1"
+
+
+def flush_wgrad_folds(dev=None):
+    """run the recorded split-K tails of every weight-gradient lane (on its own stream): after this the gradient arena holds every
+    launch issued so far - called before anything reads gradients (the join in front of the optimizer, a gradient bucket's all-reduce)"""
+    for side, fl in _WGRAD.get("folds", {}).items():
+        if fl.n and (dev is None or side.device == dev):
+            with torch.cuda.stream(side):
+                fl.flush()
 
 
 def wgrad_stream_behind_main(dev):
@@ -135,6 +164,7 @@ def wgrad_stream_behind_main(dev):
     lanes = _WGRAD["streams"].get(dev)
     if lanes is None:
         return None
+    flush_wgrad_folds(dev)
     side = lanes[0]
     side.wait_stream(torch.cuda.current_stream(dev))
     for other in lanes[1:]:
@@ -144,6 +174,7 @@ def wgrad_stream_behind_main(dev):
 
 def join_wgrad_stream():
     flush_deferred_wgrads()
+    flush_wgrad_folds()
     for dev in list(_WGRAD["pending"]):
         for side in _WGRAD["streams"][dev]:
             torch.cuda.current_stream(dev).wait_stream(side)
