@@ -61,6 +61,32 @@ torch.cuda.synchronize()
 if sys.argv[1] == "save":
     torch.save({k: v.cpu() for k, v in outs.items()}, sys.argv[2])
     print("saved", {k: tuple(v.shape) for k, v in outs.items()})
+elif sys.argv[1] == "cmpclose":
+    # two kernels that sum the same products in ANOTHER order (the row-span kernel on v_mfma_f32_16x16x32 against the 32x32x16 kernels): the
+    # fp32 sums differ in their last bits, so a 16-bit output may land on the neighbouring value - never further - on a small fraction of
+    # the elements; fp32 outputs agree to 1e-5 of the tensor's range; bit planes / GroupNorm partial sums follow their tensors
+    ref = torch.load(sys.argv[2])
+    for k, v in outs.items():
+        a, b = v.cpu(), ref[k]
+        if torch.equal(a, b):
+            print(k, "bit-identical")
+            continue
+        if a.dtype == torch.uint8:       # ReLU bit planes: a sign can only flip where the value rounds to +-0 neighbours
+            frac = float((a != b).float().mean())
+            print(k, "close" if frac < 1e-3 else "DIFF", "bytes that differ %.2e" % frac)
+            continue
+        af, bf = a.float(), b.float()
+        d = (af - bf).abs()
+        if a.dtype == torch.float32:
+            lim = 1e-5 * float(bf.abs().max()) if "part" not in k else 2e-3 * float(bf.abs().max())
+            ok = float(d.max()) <= lim
+            print(k, "close" if ok else "DIFF", "max abs dev %.3g (limit %.3g)" % (float(d.max()), lim))
+        else:
+            ulp = torch.maximum(af.abs(), bf.abs()) * (2.0 ** -7 if a.dtype == torch.bfloat16 else 2.0 ** -10) + 1e-30
+            worst = float((d / ulp).max())
+            frac = float((d > 0).float().mean())
+            ok = worst <= 1.01 and frac < 0.05 and not torch.isnan(af).any()
+            print(k, "close" if ok else "DIFF", "elements that differ %.2e, worst %.2f ulp16" % (frac, worst))
 else:
     ref = torch.load(sys.argv[2])
     for k, v in outs.items():
