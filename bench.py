@@ -274,7 +274,7 @@ def pmc_traffic(kernel, model="fcos"):
     16-byte-per-lane reads on gfx950).  The newest round's file wins."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     stem = "traffic.json" if model == "fcos" else "%s_traffic.json" % model
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(here, "%s_%s" % (rnd, stem))
         if not os.path.exists(path):
             continue
@@ -311,7 +311,7 @@ def dispatches_per_step(model):
     (profiles/rNN_<model>_4p4_bf16_timeline.txt, newest round, tools/rocpd_timeline.py over the last 6 of `bench.py --timed-only` steps)"""
     import re
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    names = ["%s_%s_4p4_%s_timeline.txt" % (r, model, t) for r in ("r05", "r04", "r03", "r02") for t in ("f16", "bf16")]
+    names = ["%s_%s_4p4_%s_timeline.txt" % (r, model, t) for r in ("r06", "r05", "r04", "r03", "r02") for t in ("f16", "bf16")]
     path = next((q for q in (os.path.join(here, n) for n in names) if os.path.exists(q)), os.path.join(here, "r02_%s_4p4_bf16_timeline.txt" % model))
     try:
         with open(path) as f:

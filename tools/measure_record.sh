@@ -2,12 +2,12 @@
 # Round measurement of record (run on the GPU box through gpurun): bench lines, kernel traces, PMC passes for the FCOS (headline) and the
 # Faster-RCNN step.  usage: tools/measure_record.sh <tag>     outputs -> gpurun_out/<tag>_*
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$PWD
 mkdir -p gpurun_out
 # the default FCOS run is the fp16 AMP mode (the reference's own autocast type) since round 3; file names keep the "4p4_bf16" stem of the
 # earlier rounds (same kernels, the 16-bit element type of the library build differs)
-timeout 900 python bench.py > gpurun_out/${TAG}_bench_f16.json 2> gpurun_out/${TAG}_bench_f16.err < /dev/null
+timeout 1200 python bench.py > gpurun_out/${TAG}_bench_f16.json 2> gpurun_out/${TAG}_bench_f16.err < /dev/null
 timeout 600 python bench.py --dtype bf16 --no-cpu-baseline --no-rcnn > gpurun_out/${TAG}_bench_bf16.json 2> /dev/null < /dev/null
 timeout 600 python bench.py --model rcnn > gpurun_out/${TAG}_bench_rcnn_bf16.json 2> /dev/null < /dev/null
 timeout 600 python bench.py --model rcnn --dtype f32 --steps 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_rcnn_f32.json 2> /dev/null < /dev/null
