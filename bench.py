@@ -730,6 +730,27 @@ def step_subrecord(kind, args, device_index, timer=None, steps=10, warmup=5, dty
     return out
 
 
+def subrecord_child(kind, dtype, label, unlabel, steps, warmup, ragged=False, timeout=600):
+    """step_subrecord in a FRESH process.  The host-bound sub-records (2 + 2 images per GPU, ragged canvases: the step enqueues for 12-26 ms and
+    runs for 13-29) are measured the way a user runs the product - one trainer in one process: inside the bench process, which has built
+    and dropped half a dozen trainers by then, the same Faster-RCNN 2 + 2 step enqueues 15.3 ms instead of 13.5 (246 against 282 img/s,
+    profiles/r06_bench_f16.json against r06_fold_ab.txt) while the GPU-bound 4 + 4 sub-records do not move."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--subrecord-only", "--model", kind, "--dtype", dtype, "--label", str(label), "--unlabel", str(unlabel),
+           "--steps", str(steps), "--warmup", str(warmup)] + (["--ragged"] if ragged else [])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        out = json.loads(line[-1])
+        out["process"] = "fresh child process (one trainer, as a user runs it)"
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -743,6 +764,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--cpu-images", type=int, default=2, help="labeled and unlabeled images of the CPU baseline sample (SURVEY 8d protocol: 2)")
     ap.add_argument("--cpu-dump", default=None, help="(internal) file that receives the first oracle step's inputs / record_dict")
+    ap.add_argument("--subrecord-only", action="store_true", help="(internal) run step_subrecord for --model / --dtype / --label / --unlabel / --steps / "
+                    "--warmup (/ --ragged) on this process's GPU and print its record")
+    ap.add_argument("--ragged", action="store_true", help="(internal, with --subrecord-only) every image at its own ResizeShortestEdge size")
     ap.add_argument("--dry-nccl", action="store_true",
                     help="join the world, run the RCCL self-check (one tiny all-reduce per rank, a device-bound barrier, an object "
                          "all-gather), print {n_gpus, rccl_ranks, ...} on rank 0 and stop: first contact with the backend in seconds")
@@ -1069,17 +1093,11 @@ def worker(args):
         for kind_, dt_ in (("fcos", args.dtype), ("rcnn", "bf16")):
             if kind_ == "rcnn" and args.no_rcnn:
                 continue
-            try:
-                torch.cuda.empty_cache()
-                small_rec[kind_] = step_subrecord(kind_, args, device_index, None, steps=40, warmup=8, dtype=dt_, label=2, unlabel=2)
-            except Exception as e:  # noqa: BLE001
-                small_rec[kind_] = {"error": repr(e)}
-        # the reference recipes' input sizes (INPUT.MIN_SIZE_TRAIN (400, 1200) "range", MAX_SIZE_TRAIN 1333): ragged canvases, the two-pass student
-        try:
             torch.cuda.empty_cache()
-            ragged_rec = step_subrecord(args.model, args, device_index, None, steps=24, warmup=16, dtype=args.dtype, ragged=(400, 1200, 1333))
-        except Exception as e:  # noqa: BLE001
-            ragged_rec = {"error": repr(e)}
+            small_rec[kind_] = subrecord_child(kind_, dt_, 2, 2, 40, 8)
+        # the reference recipes' input sizes (INPUT.MIN_SIZE_TRAIN (400, 1200) "range", MAX_SIZE_TRAIN 1333): ragged canvases, the two-pass student
+        torch.cuda.empty_cache()
+        ragged_rec = subrecord_child(args.model, args.dtype, args.label, args.unlabel, 24, 16, ragged=True)
 
     graph_rec = None
     if rank == 0 and world == 1 and not args.timed_only and args.dtype != "f32" and not args.no_graph:
@@ -1247,6 +1265,12 @@ def main(argv=None):
     args = parse_args(argv)
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline_run(args.model, args.label, args.unlabel, args.cpu_warmup, args.cpu_steps, dump=args.cpu_dump)), flush=True)
+        return
+    if args.subrecord_only:
+        from ubteacher import hip
+        hip.load()
+        print(json.dumps(step_subrecord(args.model, args, 0, None, steps=args.steps, warmup=args.warmup, dtype=args.dtype,
+                                        ragged=(400, 1200, 1333) if args.ragged else None)), flush=True)
         return
     from ubteacher.engine.launch import launch
     launch(worker, args.gpus, args=(args,))
