@@ -14,8 +14,7 @@ dtype = sys.argv[2] if len(sys.argv) > 2 else ("f16" if model == "fcos" else "bf
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 K = int(sys.argv[4]) if len(sys.argv) > 4 else 30
 small = len(sys.argv) > 5 and sys.argv[5] == "small"
-if dtype == "f16":
-    os.environ["UTV2_PRECISION"] = "fp16"
+bench.set_amp_type(dtype)      # (the package's AMP default is fp16 since round 6: name the 16-bit type explicitly)
 cfg = get_config(model, 1, ["SOLVER.IMG_PER_BATCH_LABEL", B, "SOLVER.IMG_PER_BATCH_UNLABEL", B, "SEMISUPNET.BURN_UP_STEP", 0,
                             "SOLVER.AMP.ENABLED", True, "MODEL.DEVICE", "cuda"])
 
