@@ -670,7 +670,12 @@ def step_subrecord(kind, args, device_index, timer=None, steps=10, warmup=5, dty
     tr.iter = 1
     tr.log_period = 10 ** 9
     tr.optimizer.param_groups[0]["lr"] = 1e-12   # see make_trainer: keeps the synthetic problem stationary
-    (tune_rcnn_for_pseudo_labels if rcnn else tune_for_pseudo_labels)(tr, tr._data_loader.batches[0])
+    if ragged is not None and not rcnn:
+        # the bias is placed on the first batch's logits; the other seven batches have other canvases (fewer / more locations): four times
+        # the margin of the static batch, so that every batch of the cycle has classification pseudo boxes
+        tune_for_pseudo_labels(tr, tr._data_loader.batches[0], per_image=160)
+    else:
+        (tune_rcnn_for_pseudo_labels if rcnn else tune_for_pseudo_labels)(tr, tr._data_loader.batches[0])
 
     def counts():
         lp = getattr(tr, "_last_pseudo", None)
@@ -680,10 +685,13 @@ def step_subrecord(kind, args, device_index, timer=None, steps=10, warmup=5, dty
             return {"cls": int(lp[0]["valid"].sum()), "reg": int(lp[1]["valid"].sum())}
         return int(lp["valid"].sum())
     pseudo_first = None
+    pseudo_cycle = []
     for i in range(warmup):
         tr.run_step_full_semisup(); tr.iter += 1
         if i == 0:
             pseudo_first = counts()
+        if ragged is not None and i < len(tr._data_loader.batches):
+            pseudo_cycle.append(counts())       # one entry per batch of the cycle (a device read each: warm-up only)
     torch.cuda.synchronize()
     if timer is not None:
         timer.pairs = []
@@ -717,6 +725,7 @@ def step_subrecord(kind, args, device_index, timer=None, steps=10, warmup=5, dty
         px = [sum(int(x["image"].shape[1]) * int(x["image"].shape[2]) for part in (b[0], b[2]) for x in part) for b in tr._data_loader.batches]
         out["megapixels_per_sec"] = (sum(px) / len(px)) * steps / dt / 1e6
         out["canvases"] = [[list(tr.model.padded_canvas(b[0] + b[1])), list(tr.model.padded_canvas(b[2]))] for b in tr._data_loader.batches]
+        out["pseudo_boxes_per_batch_of_the_cycle"] = pseudo_cycle
         out["note"] = ("8 different batches cycled, every image at its own size: labeled and unlabeled lists pad to different canvases, so the student runs the "
                        "reference's two passes (engine/trainer.py:396-411 / :838-866) instead of the fused one; geometry tables and workspaces are per shape")
     if conv:
@@ -1098,6 +1107,8 @@ def worker(args):
         # the reference recipes' input sizes (INPUT.MIN_SIZE_TRAIN (400, 1200) "range", MAX_SIZE_TRAIN 1333): ragged canvases, the two-pass student
         torch.cuda.empty_cache()
         ragged_rec = subrecord_child(args.model, args.dtype, args.label, args.unlabel, 24, 16, ragged=True)
+        if not rcnn and not args.no_rcnn and isinstance(rcnn_rec, dict) and "error" not in rcnn_rec:
+            rcnn_rec["ragged_canvases"] = subrecord_child("rcnn", "bf16", args.label, args.unlabel, 24, 16, ragged=True)
 
     graph_rec = None
     if rank == 0 and world == 1 and not args.timed_only and args.dtype != "f32" and not args.no_graph:
