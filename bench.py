@@ -740,10 +740,10 @@ def step_subrecord(kind, args, device_index, timer=None, steps=10, warmup=5, dty
 
 
 def subrecord_child(kind, dtype, label, unlabel, steps, warmup, ragged=False, timeout=600):
-    """step_subrecord in a FRESH process.  The host-bound sub-records (2 + 2 images per GPU, ragged canvases: the step enqueues for 12-26 ms and
-    runs for 13-29) are measured the way a user runs the product - one trainer in one process: inside the bench process, which has built
-    and dropped half a dozen trainers by then, the same Faster-RCNN 2 + 2 step enqueues 15.3 ms instead of 13.5 (246 against 282 img/s,
-    profiles/r06_bench_f16.json against r06_fold_ab.txt) while the GPU-bound 4 + 4 sub-records do not move."""
+    """step_subrecord in a FRESH process.  The sub-records with the thinnest host margin (2 + 2 images per GPU, ragged canvases: ~10 ms of host
+    work under a 13 ms step) are measured the way a user runs the product - one trainer in one process: inside the bench process, which
+    has built and dropped half a dozen trainers by then, the host is slower and the same Faster-RCNN 2 + 2 step becomes host-bound (246
+    against 282-290 img/s, profiles/r06_bench_f16.json against r06_fold_ab.txt / r06_bench_f16_final.json); the 4 + 4 sub-records do not move."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--subrecord-only", "--model", kind, "--dtype", dtype, "--label", str(label), "--unlabel", str(unlabel),
            "--steps", str(steps), "--warmup", str(warmup)] + (["--ragged"] if ragged else [])
