@@ -1258,6 +1258,11 @@ def worker(args):
         if rcnn_rec is not None:
             out["rcnn"] = rcnn_rec
         if small_rec:
+            # images / s at 2 + 2 per GPU over images / s at 4 + 4 per GPU, same trainer and 16-bit type: 1.0 = no per-image penalty for the small batch
+            ref = {"fcos": out["value"], "rcnn": (rcnn_rec or {}).get("value")}
+            for k_, r_ in small_rec.items():
+                if isinstance(r_, dict) and r_.get("value") and ref.get(k_):
+                    r_["per_image_rate_vs_4p4"] = r_["value"] / ref[k_]
             out["small_batch"] = small_rec
         if ragged_rec is not None:
             out["ragged_canvases"] = ragged_rec
