@@ -739,6 +739,56 @@ def step_subrecord(kind, args, device_index, timer=None, steps=10, warmup=5, dty
     return out
 
 
+def rcnn_first_step_deviation(args, device_index):
+    """Faster-RCNN: deviation of ONE 16-bit step (bf16 = BASELINE configs[4]'s arithmetic, fp16 = the package's AMP default) from the exact-f32
+    step on the same 1333x800 batch, from the same initial student / teacher and with the same device RNG stream for the sampling keys.
+    Unlike FCOS the step SELECTS (RPN top-k / NMS, ROI sampling, pseudo-label threshold) on rounded scores, so a term can move by more than
+    its arithmetic error: `same_pseudo_count` / `pseudo_boxes` say whether the two runs even saw the same pseudo-label set."""
+    from ubteacher.engine import UBRCNNTeacherTrainer
+    from ubteacher.presets import get_config
+    from ubteacher import ops
+
+    def make(dtype):
+        cfg = get_config("rcnn", 1, ["SOLVER.IMG_PER_BATCH_LABEL", args.label, "SOLVER.IMG_PER_BATCH_UNLABEL", args.unlabel, "SEMISUPNET.BURN_UP_STEP", 0,
+                                     "SOLVER.AMP.ENABLED", dtype != "f32", "MODEL.DEVICE", "cuda:%d" % device_index])
+        set_amp_type(dtype)
+        torch.manual_seed(0)
+        t = UBRCNNTeacherTrainer(cfg)
+        t.iter = 1
+        t.log_period = 10 ** 9
+        t.optimizer.param_groups[0]["lr"] = 1e-12
+        return t
+    tr = make("f32")
+    tune_rcnn_for_pseudo_labels(tr, tr._data_loader.batches[0])
+    s0, t0 = tr.model.flat_state().clone(), tr.model_teacher.flat_state().clone()
+    out = {}
+    ref = None
+    for dtype in ("f32", "bf16", "f16"):
+        if dtype != "f32":
+            del tr
+            torch.cuda.empty_cache()
+            tr = make(dtype)
+            tr.model.flat_state().copy_(s0); tr.model_teacher.flat_state().copy_(t0)
+            tr.model.store.touch(); tr.model_teacher.store.touch(); ops.bump_version()
+        torch.manual_seed(1)                      # the same sampling-key draws in every mode
+        tr.run_step_full_semisup()
+        rec = dict(tr.flush_metrics())
+        npseudo = int(tr._last_pseudo["valid"].sum())
+        losses = {k: v for k, v in rec.items() if k.startswith("loss")}
+        if dtype == "f32":
+            ref, ref_n = losses, npseudo
+            out["f32_first_step_losses"] = losses
+            out["pseudo_boxes"] = {"f32": npseudo}
+        else:
+            out["%s_vs_f32_first_step_rel_dev" % dtype] = {k: abs(losses[k] - ref[k]) / max(abs(ref[k]), 1e-12) for k in ref}
+            out["pseudo_boxes"][dtype] = npseudo
+    del tr
+    torch.cuda.empty_cache()
+    out["note"] = ("one step per mode from the same state; selection steps (top-k / NMS / sampling / thresholding) act on rounded scores, so these "
+                   "are not pure arithmetic errors (tests/test_rcnn_step_gpu.py::test_rcnn_step_bf16_vs_rounding_oracle decouples them: 1e-2 / 3e-3)")
+    return out
+
+
 def subrecord_child(kind, dtype, label, unlabel, steps, warmup, ragged=False, timeout=600):
     """step_subrecord in a FRESH process.  The sub-records with the thinnest host margin (2 + 2 images per GPU, ragged canvases: ~10 ms of host
     work under a 13 ms step) are measured the way a user runs the product - one trainer in one process: inside the bench process, which
@@ -1093,6 +1143,12 @@ def worker(args):
             rcnn_rec["f32"] = step_subrecord("rcnn", args_r, device_index, timer32, steps=5, warmup=2, dtype="f32")
         except Exception as e:  # noqa: BLE001
             rcnn_rec["f32"] = {"error": repr(e)}
+
+        try:
+            torch.cuda.empty_cache()
+            rcnn_rec["first_step_vs_f32"] = rcnn_first_step_deviation(args_r, device_index)
+        except Exception as e:  # noqa: BLE001
+            rcnn_rec["first_step_vs_f32"] = {"error": repr(e)}
 
     small_rec = ragged_rec = None
     if rank == 0 and world == 1 and not args.timed_only and args.dtype != "f32" and not args.no_small and (args.label, args.unlabel) == (4, 4):
