@@ -109,6 +109,15 @@ int utv2_conv2d_ml_fwd_bf16_g(const void* x, int x_dtype, int x_pitch, const voi
                               const float* scale, const float* bias, const void* residual, int nlev, const int* H_host,
                               const int* W_host, int N, int C, int K, int KH, int KW, int pad, int relu, int accumulate, int groups,
                               float* gn_part, const int* rowinfo, utv2_stream_t stream);
+/* The dgrad that produces the gradient of a GroupNorm + ReLU OUTPUT (the FCOS towers' conv -> GN -> ReLU chain, fcos/fcos.py:252-304,
+ * in backward): a 16-bit level-first conv as ..._g with dense y (pitch K) whose epilogue applies the ReLU mask - mask_bits: [P * K / 8]
+ * bytes, the plane utv2_groupnorm_relu_seg_fwd_p32b wrote - and leaves GroupNorm backward's first reduction, taken while the rows are in
+ * registers: gnb_part fp32 [ceil(P / 64)][K][2] = {sum y, sum y * gnb_x} per 64-row block and channel over the rows as stored
+ * (gnb_x: [P][K], the GroupNorm's input, 16-bit).  utv2_groupnorm_seg_bwd_p64 finishes the backward from them.
+ * C % 64 == 0, KH * KW * C >= 1024, (K / groups) % 128 == 0. */
+int utv2_conv2d_ml_fwd_bf16_gnb(const void* x, int x_pitch, const void* w16, void* y, int nlev, const int* H_host, const int* W_host, int N,
+                                int C, int K, int KH, int KW, int pad, int groups, const int* rowinfo, const void* mask_bits,
+                                const void* gnb_x, float* gnb_part, utv2_stream_t stream);
 /* bf16 wgrad (+ fused bias gradient); rowinfo = device int32[M][2] per OUTPUT pixel:
  * {input pixel index of tap (0,0), (W << 16) | mask of the taps that fall inside the image}; KH*KW <= 16 */
 int utv2_conv2d_wgrad_bf16_splits(int M, int K, int Kred);
@@ -228,6 +237,11 @@ int utv2_groupnorm_relu_seg_fwd(const void* x, const float* gamma, const float* 
 int utv2_groupnorm_relu_seg_fwd_p32(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                     const float* part32, int nseg, const int* seg_rows_host, int C, int G, float eps, int relu,
                                     utv2_stream_t stream);
+/* ... that also writes the ReLU mask as a bit plane: relu_bits (optional; C % 32 == 0) [rows * C / 8] bytes, bit (row * C + c) = y > 0 in
+ * fp32, before the 16-bit rounding (the reference's ReLU follows an fp32 GroupNorm under autocast): the mask ..._seg_bwd recomputes from x */
+int utv2_groupnorm_relu_seg_fwd_p32b(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                     const float* part32, int nseg, const int* seg_rows_host, int C, int G, float eps, int relu,
+                                     void* relu_bits, utv2_stream_t stream);
 /* beta (optional): the ReLU mask is recomputed from x with the forward expression instead of read from y (y may be null) */
 int utv2_groupnorm_relu_seg_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
                                 const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, float* ws,
@@ -240,6 +254,11 @@ int utv2_groupnorm_relu_seg_bwd_colsum(const void* dy, const void* y, const void
                                        const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, float* ws,
                                        int nseg, const int* seg_rows_host, int C, int G, int relu, int dtype, float* colsum_part,
                                        utv2_stream_t stream);
+/* GroupNorm (+ ReLU) backward from the partial sums of utv2_conv2d_ml_fwd_bf16_gnb: g = the incoming gradient with the ReLU mask already
+ * applied (16-bit [rows][C]), part64 = that conv's gnb_part.  dx / dgamma / dbeta / colsum_part / ws as ..._seg_bwd_colsum. */
+int utv2_groupnorm_seg_bwd_p64(const void* g, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
+                               float* dgamma, float* dbeta, float* ws, int nseg, const int* seg_rows_host, int C, int G,
+                               const float* part64, float* colsum_part, utv2_stream_t stream);
 /* db[c] (+)= sum_b partial[b][c], partial fp32 [nb][K] (the colsum_part above; fixed summation order) */
 int utv2_colsum_partials(const float* partial, float* db, int nb, int K, int accumulate, utv2_stream_t stream);
 int64_t utv2_groupnorm_workspace_floats(int N, int HW, int C);

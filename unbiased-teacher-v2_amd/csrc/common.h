@@ -117,10 +117,17 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
 // ReLU masks as BIT planes (16-bit outputs with K % 8 == 0 and ldy % 8 == 0; byte index = element offset / 8, bit q = channel co + q):
 // relu_bits is WRITTEN (bit = stored value > 0), mask_bits / post_bits are read in place of mask / post_mask - a sixteenth of the bytes
 // of the 16-bit tensors those arguments would re-read for a sign.
+// GroupNorm-backward partial sums (gnb_part, with mask_bits and gnb_x; 64 x 64 wave tiles of the multi-level kernels): the conv is the
+// dgrad that produces the gradient of a GroupNorm + ReLU OUTPUT; with the ReLU mask applied here (mask_bits: the plane that GroupNorm's apply
+// pass wrote) the stored rows are g = dy * (y > 0), and per 64-row block b and output channel c the epilogue also leaves
+// gnb_part[b][c] = {sum g, sum g * x} over the block's rows (g as stored; x = gnb_x, the GroupNorm's INPUT, same shape and pitch as the
+// output) - GroupNorm backward's first tensor pass (gn_bwd_partial: dy and x, read again from HBM) without the reads.
 struct EpiBits {
   unsigned char* relu_bits;
   const unsigned char* mask_bits;
   const unsigned char* post_bits;
+  const void* gnb_x;
+  float* gnb_part;
 };
 
 // One operand combination of epilogue_rows' 16-bit path, fixed at compile time (see the LEAN dispatch there).  Order of operations as in
@@ -129,7 +136,7 @@ struct EpiBits {
 // TR: the accumulators are TRANSPOSED blocks (the kernel issued its MFMAs with the operands swapped: row = channel (e&3) + 8 (e>>2) +
 // 4 (lane>>5), col = pixel lane&31): a lane's 4 consecutive values are 4 consecutive channels of one pixel and reach the patch with 4
 // 16-byte LDS writes per block instead of 16 4-byte ones
-template <int TN, bool RES, bool MB, bool PB, bool TR = false>
+template <int TN, bool RES, bool MB, bool PB, bool TR = false, bool GNB = false>
 __device__ __forceinline__ void epilogue_rows_lean(const f32x16 (&acc)[2][TN], float* lds, int lane, h16_t* __restrict__ y,
                                                    const f32x4 (&sc)[2], const f32x4 (&bi)[2], const h16_t* __restrict__ residual, float lo,
                                                    int m_base, int co, int M, int K, int LDY, float* __restrict__ gn_part, EpiBits eb) {
@@ -137,6 +144,26 @@ __device__ __forceinline__ void epilogue_rows_lean(const f32x16 (&acc)[2][TN], f
   const int frow = lane & 31, fh = lane >> 5;
   const int cv = lane % CV, rsub = lane / CV;
   const bool relu_on = lo == 0.f;   // lo: 0 = ReLU, -inf = none (wave-uniform)
+  static_assert(!GNB || (TN == 2 && MB && !RES && !PB), "GroupNorm-backward partials: 64-column wave tiles, mask plane only");
+  float s0[GNB ? 8 : 1], s1[GNB ? 8 : 1];   // GNB: this lane's 8 channels over its rows of BOTH passes: sum g, sum g * x
+  // GNB: the rows of the GroupNorm input and the mask bytes of BOTH passes are requested up front - these kernels run one workgroup per
+  // CU and every wave of it is in its epilogue at the same time, so nothing else hides a load issued next to its use (measured: the
+  // per-pass form cost the tower dgrad +85 us per launch, more than half of what the fusion saves)
+  bf16x8_t xpre[GNB ? 2 : 1][32 / RPI];
+  unsigned mpre[GNB ? 2 : 1][32 / RPI];
+  if constexpr (GNB) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s0[q] = s1[q] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int m = m_base + i * 32 + it * RPI + rsub;
+        const size_t off = (size_t)(m < M ? m : M - 1) * LDY + co;
+        xpre[i][it] = *(const bf16x8_t*)((const h16_t*)eb.gnb_x + off);
+        mpre[i][it] = eb.mask_bits[off >> 3];
+      }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     float gs = 0.f, gq = 0.f;
@@ -175,7 +202,9 @@ __device__ __forceinline__ void epilogue_rows_lean(const f32x16 (&acc)[2][TN], f
         v[4 + q] = a1[q] * sc[1][q] + bi[1][q];
       }
       if constexpr (MB) {
-        const unsigned mb = in ? eb.mask_bits[off >> 3] : 0u;
+        unsigned mb;
+        if constexpr (GNB) mb = mpre[i][it];
+        else mb = in ? eb.mask_bits[off >> 3] : 0u;
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = ((mb >> q) & 1u) ? v[q] : 0.f;
       }
@@ -193,6 +222,14 @@ __device__ __forceinline__ void epilogue_rows_lean(const f32x16 (&acc)[2][TN], f
       for (int q = 0; q < 8; ++q) o[q] = (h16_t)(relu_on ? fmaxf(v[q], 0.f) : v[q]);   // no ReLU: the value as is (a NaN stays a NaN, as in the general path)
       if (in) {
         *(bf16x8_t*)(y + off) = o;
+        if constexpr (GNB) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float f = (float)o[q];
+            s0[q] += f;
+            s1[q] += f * (float)xpre[i][it][q];
+          }
+        }
         if (eb.relu_bits) {
           unsigned b = 0;
 #pragma unroll
@@ -223,17 +260,37 @@ __device__ __forceinline__ void epilogue_rows_lean(const f32x16 (&acc)[2][TN], f
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if constexpr (GNB) {
+    // the 8 row lanes of a channel octet meet in the (now free) patch: lane (cv, rsub) leaves {s0, s1} of its 8 channels in row rsub,
+    // lane L then owns channel co_base + L and adds the 8 rows in a fixed order - one 8-byte store per lane, 512 contiguous bytes per wave
+    constexpr int LE = 2 * COLS + 4;
+    float* ex = lds + rsub * LE + cv * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(f32x4*)(ex + 4 * q) = f32x4{s0[2 * q], s1[2 * q], s0[2 * q + 1], s1[2 * q + 1]};
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int r = 0; r < RPI; ++r) {
+      const float2 v = *(const float2*)(lds + r * LE + 2 * lane);
+      a += v.x;
+      b += v.y;
+    }
+    if (m_base < M) *(float2*)(eb.gnb_part + ((size_t)(m_base >> 6) * K + (co - cv * 8) + lane) * 2) = float2{a, b};
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // LEAN_OPS: also instantiate the lean forms with operands (kernels with register headroom; the 128-VGPR kernels keep the plain form only:
 // the extra variants cost them ~75 spills)
-template <int TN, typename TO = float, bool LEAN_OPS = true, bool TR = false>
+// GNB_OK: also instantiate the GroupNorm-backward partial-sum form (EpiBits::gnb_part; the multi-level kernels the tower dgrads run on)
+template <int TN, typename TO = float, bool LEAN_OPS = true, bool TR = false, bool GNB_OK = false>
 __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float* lds, int lane, TO* __restrict__ y,
                                               const float* __restrict__ scale, const float* __restrict__ bias,
                                               const TO* __restrict__ residual, int relu, int accumulate, int m_base,
                                               int co_base, int M, int K, const TO* __restrict__ mask = nullptr,
                                               const TO* __restrict__ post_mask = nullptr, int ldy = 0,
-                                              float* __restrict__ gn_part = nullptr, EpiBits eb = EpiBits{nullptr, nullptr, nullptr}) {
+                                              float* __restrict__ gn_part = nullptr, EpiBits eb = EpiBits{nullptr, nullptr, nullptr, nullptr, nullptr}) {
   // gn_part (optional, bf16 outputs with K % 8 == 0): fp32 [ceil(M / 32)][K / 8][2] - per 32-row block and 8-channel group the sum and
   // the sum of squares of the values AS STORED (after the bf16 rounding): the statistics pass of the GroupNorm(8 channels per group)
   // that consumes this conv's output (fcos/fcos.py:263-264), taken while the rows are in registers.  m_base is a multiple of 32; rows
@@ -278,6 +335,13 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][TN], float*
 #define UTV2_LEAN(R, MB, PB)                                                                                                          \
   epilogue_rows_lean<TN, R, MB, PB, TR>(acc, lds, lane, (h16_t*)y, sc, bi, (const h16_t*)residual, lo, m_base, co, M, K, LDY, gn_part, eb)
       if (mode == 0) { UTV2_LEAN(false, false, false); return; }
+      if constexpr (GNB_OK && LEAN_OPS && TN == 2) {
+        if (mode == 2 && eb.gnb_part) {
+          epilogue_rows_lean<TN, false, true, false, TR, true>(acc, lds, lane, (h16_t*)y, sc, bi, (const h16_t*)residual, lo, m_base, co, M, K, LDY,
+                                                               gn_part, eb);
+          return;
+        }
+      }
       if constexpr (LEAN_OPS) {
         if (mode == 1) { UTV2_LEAN(true, false, false); return; }
         if (mode == 2) { UTV2_LEAN(false, true, false); return; }

@@ -433,7 +433,7 @@ static int fill_levels16(LevelTab& lt, int nlev, int N, const int* H, const int*
 // real.  Same staging, swizzle, pipeline and epilogue (called on the 64- and the 32-column part of the wave tile).
 // TALL (BN = 64, round 4): K <= 64 layers (the stem, res2's 3x3) likewise as a 256 x 64 tile of four 64 x 64 wave tiles - 4 fragment reads per
 // 4 MFMAs instead of 3 per 2 on the 128 x 64 tile's 64 x 32 wave tiles.
-template <int BN, bool ML, int BK, typename TO, bool TALL = false>
+template <int BN, bool ML, int BK, typename TO, bool TALL = false, bool GNB = false>   // GNB: see EpiBits::gnb_part (an instantiation of its own)
 __global__ __launch_bounds__(256, TALL ? 3 : ((BK == 32 && BN != 96) ? 4 : 2)) void conv_igemm_bf16_v2(ConvArgs16 p) {
   static_assert(!TALL || BN == 64, "the tall layout exists for the 64-wide tile");
   constexpr int WN = (BN == 96 || TALL) ? 1 : 2, WM = 4 / WN, WCOLS = BN / WN;   // waves along N / M; output columns per wave
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256, TALL ? 3 : ((BK == 32 && BN != 96) ? 4 : 2)) v
         epilogue_rows<1, TO, true, true>(hi, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate, m0 + wm * 64,
                                    n0 + 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, nullptr, p.bits);
     } else {
-      epilogue_rows<TN, TO, (BK != 32), true>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
+      epilogue_rows<TN, TO, (BK != 32), true, GNB>(acc, patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual, p.relu, p.accumulate,
                             m0 + wm * 64, n0 + wn * WCOLS, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
     }
     return;
@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_pp(ConvArgs16 p) {
 template <int N>
 __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
-template <bool ML, typename TO>
+template <bool ML, typename TO, bool GNB = false>   // GNB: see EpiBits::gnb_part (an instantiation of its own: the plain one keeps its registers)
 __global__ __launch_bounds__(512) void conv_igemm_bf16_rs(ConvArgs16 p) {
   const bool clk_on = ML && blockIdx.x == 0 && p.ntiles > 0;
   unsigned long long clk_c0 = 0, clk_r0 = 0;
@@ -1355,9 +1355,9 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_rs(ConvArgs16 p) {
   __syncthreads();
 
   float* patch = (float*)smem + wid * (32 * (TN * 32 + 4));
-  epilogue_rows<TN, TO, true, true>(*(const f32x16(*)[2][TN]) & acc[0], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
+  epilogue_rows<TN, TO, true, true, GNB>(*(const f32x16(*)[2][TN]) & acc[0], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
                         p.relu, p.accumulate, m0 + wm * 128, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
-  epilogue_rows<TN, TO, true, true>(*(const f32x16(*)[2][TN]) & acc[2], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
+  epilogue_rows<TN, TO, true, true, GNB>(*(const f32x16(*)[2][TN]) & acc[2], patch, lane, (TO*)p.y, p.scale, p.bias, (const TO*)p.residual,
                         p.relu, p.accumulate, m0 + wm * 128 + 64, n0 + wn * 64, p.M, p.K, (const TO*)p.mask, (const TO*)p.post_mask, p.ldy, p.gn_part, p.bits);
   __syncthreads();   // persistent grid: every wave is done with its epilogue patch before the next tile's first DMA pieces land there
   }
@@ -1394,8 +1394,13 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
     // BK = 64 holds 2 workgroups per CU (64 KB LDS) against 4 for BK = 32: worth it for long K loops (MFMA-bound 3x3 /
     // wide 1x1 layers) unless the grid is a little over one 512-slot round (tail), not for short HBM-bound ones.
     const bool tail = tiles > 512 && tiles <= 768;
-    const bool deep = a.C % 64 == 0 && a.Kred >= 1024 && !tail;
-    const bool w8 = g_use_w8;
+    const bool deep = a.C % 64 == 0 && a.Kred >= 1024 && (!tail || a.bits.gnb_part);   // (the GroupNorm-backward partials exist in the BK = 64 form)
+    // 3x3 stride-1 layers with the per-row geometry table: the row-span form (a third of the im2col DMA; bit-identical results)
+    // ("same" geometry only: the column neighbour of an output pixel must be the centre pixel of the neighbouring output row index)
+    static const bool use_rs = env_int("UTV2_PP_RS", 1) != 0;
+    const bool rs_ok = use_rs && a.rowinfo && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && (ML || (a.OH == a.H && a.OW == a.W));
+    const bool gnb = ML && BN == 128 && a.bits.gnb_part != nullptr;   // GroupNorm-backward partials: row-span and 128 x 128 BK = 64 kernels
+    const bool w8 = g_use_w8 && (!gnb || rs_ok);
     if (w8 && BN == 128 && a.xs >= a.groups * a.C && (a.xs & 7) == 0 && a.C % 64 == 0 && a.Kred >= 1024 && a.K >= 256 && (a.K & 3) == 0 &&
         a.m_begin == 0 && (a.groups == 1 || (a.K / a.groups) % 256 == 0)) {
       // Whole rounds of 256 tiles (one per CU) always pay.  The rest: a partial round costs one 256-tile time (~76 us on the tower
@@ -1415,15 +1420,14 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
           int grid = main_m * tilesN;
           static const int pp_wgs = [] { int v = env_int("UTV2_PP_WGS", 256); return v < 8 ? 8 : (v > 256 ? 256 : v / 8 * 8); }();   // A/B: CUs the persistent grid takes
           if (g_use_pp == 2 && grid > 256) { m.ntiles = grid; grid = pp_wgs; }
-          // 3x3 stride-1 layers with the per-row geometry table: the row-span form (a third of the im2col DMA; bit-identical results)
-          static const bool use_rs = env_int("UTV2_PP_RS", 1) != 0;
-          // ("same" geometry only: the column neighbour of an output pixel must be the centre pixel of the neighbouring output row index)
-          if (use_rs && a.rowinfo && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && (ML || (a.OH == a.H && a.OW == a.W))) {
+          if (rs_ok) {
             const int smem_rs = 4 * 272 * 64 + 4 * 256 * 64 + 256;
             static LdsOptIn rs_opt_in;
-            rs_opt_in({(const void*)conv_igemm_bf16_rs<ML, h16_t>, (const void*)conv_igemm_bf16_rs<ML, float>}, smem_rs);
+            rs_opt_in({(const void*)conv_igemm_bf16_rs<ML, h16_t>, (const void*)conv_igemm_bf16_rs<ML, float>,
+                       (const void*)conv_igemm_bf16_rs<ML, h16_t, ML>}, smem_rs);
             m.mtot = a.M;
-            if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_rs<ML, h16_t>), dim3(grid), dim3(512), smem_rs, stream, m);
+            if (gnb) hipLaunchKernelGGL((conv_igemm_bf16_rs<ML, h16_t, ML>), dim3(grid), dim3(512), smem_rs, stream, m);
+            else if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_rs<ML, h16_t>), dim3(grid), dim3(512), smem_rs, stream, m);
             else hipLaunchKernelGGL((conv_igemm_bf16_rs<ML, float>), dim3(grid), dim3(512), smem_rs, stream, m);
           } else if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, h16_t>), dim3(grid), dim3(512), smem, stream, m);
           else hipLaunchKernelGGL((conv_igemm_bf16_pp<ML, float>), dim3(grid), dim3(512), smem, stream, m);
@@ -1449,7 +1453,8 @@ static void launch_igemm16(const ConvArgs16& a, int tiles, int x_dtype, int y_dt
       if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<96, ML, 32, h16_t>), g, b, 0, stream, a);
       else hipLaunchKernelGGL((conv_igemm_bf16_v2<96, ML, 32, float>), g, b, 0, stream, a);
     } else if (deep) {
-      if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 64, h16_t>), g, b, 0, stream, a);
+      if (gnb) hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 64, h16_t, false, (ML && BN == 128)>), g, b, 0, stream, a);
+      else if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 64, h16_t>), g, b, 0, stream, a);
       else hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 64, float>), g, b, 0, stream, a);
     } else {
       if (y_dtype == UTV2_BF16) hipLaunchKernelGGL((conv_igemm_bf16_v2<BN, ML, 32, h16_t>), g, b, 0, stream, a);
@@ -1525,7 +1530,7 @@ int utv2_conv2d_nhwc_fwd_bf16_ri(const void* x, int x_dtype, const void* w16, vo
                                  int K, int KH, int KW, int stride, int pad, int in_dil, int OH, int OW, int relu, int accumulate,
                                  const int* rowinfo, hipStream_t stream) {
   return conv2d_nhwc_fwd_bf16_impl(x, x_dtype, w16, y, y_dtype, scale, bias, residual, mask, post_mask, N, H, W, C, K, KH, KW, stride, pad,
-                                   in_dil, OH, OW, relu, accumulate, rowinfo, EpiBits{nullptr, nullptr, nullptr}, stream);
+                                   in_dil, OH, OW, relu, accumulate, rowinfo, EpiBits{nullptr, nullptr, nullptr, nullptr, nullptr}, stream);
 }
 
 // The same with ReLU masks as BIT planes (16-bit y, K % 8 == 0; uint8 [N*OH*OW][K / 8], bit q of byte c = channel 8c + q):
@@ -1541,7 +1546,7 @@ int utv2_conv2d_nhwc_fwd_bf16_bits(const void* x, int x_dtype, const void* w16, 
   if ((mask && mask_bits) || (post_mask && post_mask_bits)) return UTV2_EARG;
   return conv2d_nhwc_fwd_bf16_impl(x, x_dtype, w16, y, y_dtype, scale, bias, residual, mask, post_mask, N, H, W, C, K, KH, KW, stride, pad,
                                    in_dil, OH, OW, relu, accumulate, rowinfo,
-                                   EpiBits{(unsigned char*)relu_bits, (const unsigned char*)mask_bits, (const unsigned char*)post_mask_bits},
+                                   EpiBits{(unsigned char*)relu_bits, (const unsigned char*)mask_bits, (const unsigned char*)post_mask_bits, nullptr, nullptr},
                                    stream);
 }
 
@@ -1573,21 +1578,20 @@ static int conv2d_nhwc_fwd_bf16_impl(const void* x, int x_dtype, const void* w16
 //   of y as stored - the statistics pass of the GroupNorm that follows (utv2_groupnorm_relu_seg_fwd_p32).
 //   rowinfo (optional): device int32[P][2], the per-output-row geometry table of utv2_conv2d_wgrad_bf16 for this conv (same pad and k):
 //   the tile prologues load it instead of decoding (level, image, row, column) and the tap bounds per staged row.
-int utv2_conv2d_ml_fwd_bf16_g(const void* x, int x_dtype, int x_pitch, const void* w16, void* y, int y_dtype, int y_pitch,
-                              const float* scale, const float* bias, const void* residual, int nlev, const int* H_host,
-                              const int* W_host, int N, int C, int K, int KH, int KW, int pad, int relu, int accumulate, int groups,
-                              float* gn_part, const int* rowinfo, hipStream_t stream) {
+static int ml_fwd_g(const void* x, int x_dtype, int x_pitch, const void* w16, void* y, int y_dtype, int y_pitch, const float* scale,
+                    const float* bias, const void* residual, int nlev, const int* H_host, const int* W_host, int N, int C, int K, int KH, int KW,
+                    int pad, int relu, int accumulate, int groups, float* gn_part, const int* rowinfo, EpiBits bits, hipStream_t stream) {
   if (gn_part && (y_dtype != UTV2_BF16 || (K & 7) || (y_pitch & 7) || x_dtype != UTV2_BF16 || (C % 32) || accumulate)) return UTV2_EARG;
   if (!x || !w16 || !y || nlev < 1 || nlev > CONV_MAX_LEVELS || (C % 8) || N <= 0 || bad_dtype(x_dtype) || bad_dtype(y_dtype) || groups < 1 ||
       K % groups || x_pitch < groups * C || y_pitch < K)
     return UTV2_EARG;
-  const bool plain = groups == 1 && x_pitch == C && y_pitch == K && !gn_part && !rowinfo;
+  const bool plain = groups == 1 && x_pitch == C && y_pitch == K && !gn_part && !rowinfo && !bits.mask_bits;
   if (!plain && (x_dtype != UTV2_BF16 || (C % 32) || (K & 3) || KH * KW > 16 || (x_pitch & 7) || (y_pitch & 7) ||
                  (groups > 1 && (K / groups) % 128)))
     return UTV2_EARG;
   ConvArgs16 a;
   a.ntiles = 0;
-  a.bits = EpiBits{nullptr, nullptr, nullptr};
+  a.bits = bits;
   a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
   if (!plain && ((int64_t)a.M * x_pitch >= (1ll << 31) || (int64_t)K * KH * KW * C >= (1ll << 31))) return UTV2_EARG;
   a.x = x; a.w = (const h16_t*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
@@ -1601,6 +1605,29 @@ int utv2_conv2d_ml_fwd_bf16_g(const void* x, int x_dtype, int x_pitch, const voi
   return utv2_launch_status();
 }
 
+int utv2_conv2d_ml_fwd_bf16_g(const void* x, int x_dtype, int x_pitch, const void* w16, void* y, int y_dtype, int y_pitch,
+                              const float* scale, const float* bias, const void* residual, int nlev, const int* H_host,
+                              const int* W_host, int N, int C, int K, int KH, int KW, int pad, int relu, int accumulate, int groups,
+                              float* gn_part, const int* rowinfo, hipStream_t stream) {
+  return ml_fwd_g(x, x_dtype, x_pitch, w16, y, y_dtype, y_pitch, scale, bias, residual, nlev, H_host, W_host, N, C, K, KH, KW, pad, relu,
+                  accumulate, groups, gn_part, rowinfo, EpiBits{nullptr, nullptr, nullptr, nullptr, nullptr}, stream);
+}
+
+// The dgrad that produces the gradient of a GroupNorm + ReLU output (FCOS towers, fcos/fcos.py:252-304 in backward): a 16-bit level-first
+// conv as utv2_conv2d_ml_fwd_bf16_g (dense y: pitch K) whose epilogue applies the ReLU mask - mask_bits: [P * K / 8] bytes, the plane
+// utv2_groupnorm_relu_seg_fwd_p32b wrote - and leaves GroupNorm backward's first reduction: gnb_part fp32 [ceil(P / 64)][K][2] =
+// {sum y, sum y * gnb_x} per 64-row block and channel over the rows as stored (gnb_x: [P][K], the GroupNorm's input, y's element type).
+// utv2_groupnorm_seg_bwd_p64 finishes the backward from them.  C % 64 == 0, KH * KW * C >= 1024, K % 128 == 0 per group.
+int utv2_conv2d_ml_fwd_bf16_gnb(const void* x, int x_pitch, const void* w16, void* y, int nlev, const int* H_host, const int* W_host, int N,
+                                int C, int K, int KH, int KW, int pad, int groups, const int* rowinfo, const void* mask_bits,
+                                const void* gnb_x, float* gnb_part, hipStream_t stream) {
+  if (!mask_bits || !gnb_x || !gnb_part || groups < 1 || K % groups || (C % 64) || KH * KW * C < 1024 || (K / groups) % 128 || (K & 7) ||
+      g_epi_general)
+    return UTV2_EARG;
+  return ml_fwd_g(x, UTV2_BF16, x_pitch, w16, y, UTV2_BF16, K, nullptr, nullptr, nullptr, nlev, H_host, W_host, N, C, K, KH, KW, pad, 0, 0,
+                  groups, nullptr, rowinfo, EpiBits{nullptr, (const unsigned char*)mask_bits, nullptr, gnb_x, gnb_part}, stream);
+}
+
 int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y, int y_dtype, const float* scale,
                             const float* bias, const void* residual, int nlev, const int* H_host, const int* W_host, int N,
                             int C, int K, int KH, int KW, int pad, int relu, int accumulate, hipStream_t stream) {
@@ -1608,7 +1635,7 @@ int utv2_conv2d_ml_fwd_bf16(const void* x, int x_dtype, const void* w16, void* y
     return UTV2_EARG;
   ConvArgs16 a;
   a.ntiles = 0;
-  a.bits = EpiBits{nullptr, nullptr, nullptr};
+  a.bits = EpiBits{nullptr, nullptr, nullptr, nullptr, nullptr};
   a.M = fill_levels16(a.lt, nlev, N, H_host, W_host);
   a.x = x; a.w = (const h16_t*)w16; a.y = y; a.scale = scale; a.bias = bias; a.residual = residual; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = 0; a.W = 0; a.C = C; a.OH = 0; a.OW = 0; a.K = K; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad; a.in_dil = 1;
@@ -1633,7 +1660,7 @@ int utv2_conv2d_stem_fwd_bf16(const void* xpad16, const void* w16s, void* y, int
     return UTV2_EARG;
   ConvArgs16 a;
   a.ntiles = 0;
-  a.bits = EpiBits{nullptr, nullptr, nullptr};
+  a.bits = EpiBits{nullptr, nullptr, nullptr, nullptr, nullptr};
   a.lt.n = 0;
   a.x = xpad16; a.w = (const h16_t*)w16s; a.y = y; a.scale = scale; a.bias = bias; a.residual = nullptr; a.mask = nullptr; a.post_mask = nullptr;
   a.N = N; a.H = H + 6; a.W = W + 8; a.C = 32; a.OH = OH; a.OW = OW; a.K = K; a.KH = 7; a.KW = 1; a.stride = 2; a.pad = 0;

@@ -626,7 +626,11 @@ __device__ __forceinline__ int gn_chunk_of_block(const GnSegs& sg) {
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_relu(GnSegs sg, const T* __restrict__ x, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                   const float* __restrict__ beta, T* __restrict__ y, int C, int G, int relu) {
+                                                   const float* __restrict__ beta, T* __restrict__ y, int C, int G, int relu,
+                                                   unsigned* __restrict__ bits = nullptr) {
+  // bits (optional; C % 32 == 0): the ReLU mask as a bit plane, bit (row * C + c) = y > 0 BEFORE the rounding to T (the reference's ReLU
+  // follows an fp32 GroupNorm under autocast; a positive value below T's range still passes its gradient) - the plane the conv epilogues
+  // read in place of a sign tensor (common.h EpiBits).  8 neighbouring lanes (32 channels of one row) assemble one 32-bit word.
   int seg, r0, r1;
   gn_locate(sg, gn_chunk_of_block(sg), seg, r0, r1);
   const int C4 = C >> 2, cpg = C / G;
@@ -642,6 +646,16 @@ __global__ __launch_bounds__(256) void gn_apply_relu(GnSegs sg, const T* __restr
       o[e] = relu ? fmaxf(t, 0.f) : t;
     }
     st4(y, i, o);
+    if (bits) {   // (wave-uniform; the 8 lanes of a word run the same rows)
+      unsigned b = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b |= (o[e] > 0.f ? 1u : 0u) << e;   // the fp32 value's sign: the mask gn_bwd_partial / gn_bwd_apply recompute from x
+      b <<= 4 * (threadIdx.x & 7);
+      b |= __shfl_xor(b, 1, 64);
+      b |= __shfl_xor(b, 2, 64);
+      b |= __shfl_xor(b, 4, 64);
+      if ((threadIdx.x & 7) == 0) bits[i >> 3] = b;
+    }
   };
   int row = r0 + rl;
   for (; row + 3 * RL < r1; row += 4 * RL) {  // four independent row loads in flight per thread
@@ -755,6 +769,75 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce(GnSegs sg, const float* __r
   if (ln == 0 && c < C) {
     const float sa = (ra[cl] + ra[cl + 64]) + (ra[cl + 128] + ra[cl + 192]);
     const float sb = (rb[cl] + rb[cl + 64]) + (rb[cl + 128] + rb[cl + 192]);
+    AB[((size_t)seg * C + c) * 2] = sa;
+    AB[((size_t)seg * C + c) * 2 + 1] = sb;
+    sh[cl][0] = sa * gamma[c];
+    sh[cl][1] = sb * gamma[c];
+  }
+  __syncthreads();
+  const int gpb = 64 / cpg;   // groups per block
+  if ((int)threadIdx.x < gpb && blockIdx.y * 64 + threadIdx.x * cpg < C) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < cpg; ++k) {
+      s1 += sh[threadIdx.x * cpg + k][0];
+      s2 += sh[threadIdx.x * cpg + k][1];
+    }
+    const int g = blockIdx.y * gpb + threadIdx.x;
+    s12[(seg * G + g) * 2] = s1;
+    s12[(seg * G + g) * 2 + 1] = s2;
+  }
+}
+
+// The same from the dgrad epilogue's partials (common.h EpiBits::gnb_part: fp32 [ceil(rows / 64)][C][2] = {sum g, sum g * x} per 64-row
+// block and channel, g = dy * mask as stored in `g`): A = sum g * xhat = rstd * (sum g x - mean * sum g), B = sum g.  The 64-row blocks
+// that lie inside the segment come from part64; the rows in front of the first and behind the last whole block - segments start at
+// arbitrary rows - are summed here from g and x.  Same grid and outputs as gn_bwd_reduce; double accumulation, fixed order.
+__global__ __launch_bounds__(256) void gn_bwd_reduce_p64(GnSegs sg, const float* __restrict__ part64, const h16_t* __restrict__ gy,
+                                                       const h16_t* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       float* __restrict__ AB, float* __restrict__ s12, int C, int G) {
+  __shared__ double r0s[256], r1s[256];
+  __shared__ float sh[64][2];
+  const int seg = blockIdx.x, cl = threadIdx.x & 63, ln = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl, cpg = C / G;
+  const int r0 = sg.row0[seg], r1 = sg.row0[seg + 1];
+  int b0 = (r0 + 63) >> 6, b1 = r1 >> 6;      // whole blocks [b0, b1)
+  if (b1 < b0) b1 = b0;                        // the segment lies inside one block
+  double t0 = 0.0, t1 = 0.0;
+  if (c < C) {
+    int k = b0 + ln;
+    for (; k + 12 < b1; k += 16) {   // four loads in flight per thread
+      float2 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = *(const float2*)(part64 + ((size_t)(k + 4 * q) * C + c) * 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { t0 += (double)v[q].x; t1 += (double)v[q].y; }
+    }
+    for (; k < b1; k += 4) {
+      const float2 v = *(const float2*)(part64 + ((size_t)k * C + c) * 2);
+      t0 += (double)v.x;
+      t1 += (double)v.y;
+    }
+    const int h1 = (b0 << 6) < r1 ? (b0 << 6) : r1;
+    const int e2 = (b1 << 6) > h1 ? (b1 << 6) : h1;
+    for (int pass = 0; pass < 2; ++pass) {
+      const int e0 = pass == 0 ? r0 : e2, e1 = pass == 0 ? h1 : r1;
+      for (int r = e0 + ln; r < e1; r += 4) {
+        const float gv = (float)gy[(size_t)r * C + c], xv = (float)x[(size_t)r * C + c];
+        t0 += (double)gv;
+        t1 += (double)(gv * xv);
+      }
+    }
+  }
+  r0s[threadIdx.x] = t0;
+  r1s[threadIdx.x] = t1;
+  __syncthreads();
+  if (ln == 0 && c < C) {
+    const double S0 = (r0s[cl] + r0s[cl + 64]) + (r0s[cl + 128] + r0s[cl + 192]);
+    const double S1 = (r1s[cl] + r1s[cl + 64]) + (r1s[cl + 128] + r1s[cl + 192]);
+    const int g = c / cpg;
+    const float sa = (float)((double)rstd[seg * G + g] * (S1 - (double)mean[seg * G + g] * S0));
+    const float sb = (float)S0;
     AB[((size_t)seg * C + c) * 2] = sa;
     AB[((size_t)seg * C + c) * 2 + 1] = sb;
     sh[cl][0] = sa * gamma[c];
@@ -1198,15 +1281,43 @@ int utv2_groupnorm_relu_seg_fwd(const void* x, const float* gamma, const float* 
 // bf16 x with 8 channels per group whose statistics partials the producing conv left in part32 (utv2_conv2d_ml_fwd_bf16_g gn_part:
 // fp32 [ceil(rows / 32)][G][2]): statistics from the partials (+ the segment-edge rows read from x), then the apply pass - one tensor
 // pass less than utv2_groupnorm_relu_seg_fwd.
-int utv2_groupnorm_relu_seg_fwd_p32(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                                    const float* part32, int nseg, const int* seg_rows_host, int C, int G, float eps, int relu,
-                                    hipStream_t stream) {
-  if (!x || !y || !mean || !rstd || !part32 || !gn_check(nseg, C, G) || C != 8 * G) return UTV2_EARG;
+// relu_bits (optional; C % 32 == 0): [rows * C / 8] bytes, bit (row * C + c) = y > 0 in fp32 (before the 16-bit rounding; the mask
+// utv2_groupnorm_relu_seg_bwd recomputes from x when it is given beta) - the plane utv2_conv2d_ml_fwd_bf16_gnb reads
+int utv2_groupnorm_relu_seg_fwd_p32b(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                     const float* part32, int nseg, const int* seg_rows_host, int C, int G, float eps, int relu,
+                                     void* relu_bits, hipStream_t stream) {
+  if (!x || !y || !mean || !rstd || !part32 || !gn_check(nseg, C, G) || C != 8 * G || (relu_bits && (C & 31))) return UTV2_EARG;
   GnSegs sg;
   const int chunks = gn_fill(sg, nseg, seg_rows_host);
   hipLaunchKernelGGL(gn_stats_final_p32, dim3(nseg, cdiv(G, 8)), dim3(256), 0, stream, sg, part32, (const h16_t*)x, mean, rstd, G, C, eps);
   hipLaunchKernelGGL(gn_apply_relu<h16_t>, dim3(chunks), dim3(256), 0, stream, sg, (const h16_t*)x, (const float*)mean, (const float*)rstd,
-                     gamma, beta, (h16_t*)y, C, G, relu);
+                     gamma, beta, (h16_t*)y, C, G, relu, (unsigned*)relu_bits);
+  return utv2_launch_status();
+}
+
+int utv2_groupnorm_relu_seg_fwd_p32(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                    const float* part32, int nseg, const int* seg_rows_host, int C, int G, float eps, int relu,
+                                    hipStream_t stream) {
+  return utv2_groupnorm_relu_seg_fwd_p32b(x, gamma, beta, y, mean, rstd, part32, nseg, seg_rows_host, C, G, eps, relu, nullptr, stream);
+}
+
+// GroupNorm (+ ReLU) backward whose first reduction the producing dgrad's epilogue already made (utv2_conv2d_ml_fwd_bf16_gnb): g = the
+// gradient with the ReLU mask applied (16-bit [rows][C]), part64 = that conv's gnb_part.  Two launches (segment sums; apply) instead of
+// three, and one pass over g and x instead of two.  Outputs as utv2_groupnorm_relu_seg_bwd_colsum; ws: utv2_groupnorm_seg_workspace_floats.
+int utv2_groupnorm_seg_bwd_p64(const void* g, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
+                               float* dgamma, float* dbeta, float* ws, int nseg, const int* seg_rows_host, int C, int G,
+                               const float* part64, float* colsum_part, hipStream_t stream) {
+  if (!g || !x || !dx || !ws || !part64 || !mean || !rstd || !gamma || !gn_check(nseg, C, G)) return UTV2_EARG;
+  GnSegs sg;
+  const int chunks = gn_fill(sg, nseg, seg_rows_host);
+  float* AB = ws;
+  float* s12 = AB + (size_t)nseg * C * 2;
+  hipLaunchKernelGGL(gn_bwd_reduce_p64, dim3(nseg, cdiv(C, 64)), dim3(256), 0, stream, sg, part64, (const h16_t*)g, (const h16_t*)x, mean,
+                     rstd, gamma, AB, s12, C, G);
+  const int pb = cdiv(C, 64);
+  hipLaunchKernelGGL(gn_bwd_apply<h16_t>, dim3(chunks > pb ? chunks : pb), dim3(256), 0, stream, sg, (const h16_t*)g, (const h16_t*)nullptr,
+                     (const h16_t*)x, mean, rstd, gamma, (const float*)nullptr, (const float*)s12, (h16_t*)dx, C, G, 0, (const float*)AB, dgamma,
+                     dbeta, pb, colsum_part);
   return utv2_launch_status();
 }
 

@@ -1095,10 +1095,25 @@ def _rows_ptr(t):
     return c_p(t.data_ptr()), int(t.stride(0))
 
 
+def gnb_eligible(x2d, w16, k, pad, groups):
+    """can conv2d_ml_fwd_bf16(..., gnb=...) take this dgrad?  (utv2_conv2d_ml_fwd_bf16_gnb's argument rules)"""
+    C = x2d.shape[1] // groups
+    K = w16.shape[0]
+    return (x2d.dtype == h16_dtype() and C % 64 == 0 and k * k * C >= 1024 and K % groups == 0 and (K // groups) % 128 == 0
+            and x2d.stride(1) == 1 and x2d.stride(0) % 8 == 0 and x2d.shape[0] * x2d.stride(0) < (1 << 31))
+
+
+def gnb_part_buffer(P, K, device):
+    """destination of the dgrad epilogue's GroupNorm-backward partials: fp32 [ceil(P / 64), K, 2]"""
+    return torch.empty(((P + 63) // 64, K, 2), dtype=torch.float32, device=device)
+
+
 def conv2d_ml_fwd_bf16(x2d, w16, level_hw, N, scale=None, bias=None, residual=None, k=3, pad=1, relu=False, out=None,
-                       out_dtype=None, groups=1, gn_part=None):
+                       out_dtype=None, groups=1, gn_part=None, gnb=None):
     """x2d [P, groups*C] (may be a column slice of a wider matrix); groups > 1: grouped conv, w16 [K, k*k*C] with K/groups output
-    channels per group; out (optional) may be a column slice too (then residual must be None)."""
+    channels per group; out (optional) may be a column slice too (then residual must be None).
+    gnb (optional) = (mask_bits, gn_x, part64): this conv is the dgrad that produces the gradient of a GroupNorm + ReLU output - the ReLU
+    bit plane of that output, the GroupNorm's input [P, K] and the partial-sum buffer (gnb_part_buffer); 16-bit dense output."""
     P = x2d.shape[0]
     C = x2d.shape[1] // groups
     K = w16.shape[0]
@@ -1108,6 +1123,15 @@ def conv2d_ml_fwd_bf16(x2d, w16, level_hw, N, scale=None, bias=None, residual=No
     H = _iarr([h for h, _ in level_hw]); W = _iarr([w_ for _, w_ in level_hw])
     xp, xpitch = _rows_ptr(x2d)
     yp, ypitch = _rows_ptr(out)
+    if gnb is not None:
+        bits, gx, part = gnb
+        assert (scale is None and bias is None and residual is None and not relu and gn_part is None and out.dtype == h16_dtype()
+                and ypitch == K and gx.dtype == h16_dtype() and gx.is_contiguous() and tuple(gx.shape) == (P, K)
+                and bits.numel() * bits.element_size() * 8 == P * K and tuple(part.shape) == ((P + 63) // 64, K, 2))
+        ri = rowinfo_ml(N, level_hw, pad, k, x2d.device) if (_CONV_ROWINFO and k > 1) else None
+        call("utv2_conv2d_ml_fwd_bf16_gnb", xp, xpitch, _p(w16), yp, len(level_hw), ctypes.cast(H, c_p), ctypes.cast(W, c_p), N, C, K, k, k,
+             pad, int(groups), _p(ri), _p(bits), _p(gx), _p(part), _stream())
+        return out
     # the geometry table the weight gradients read (cached per geometry): the conv's tile prologues load it instead of decoding it
     ri = None
     if (_CONV_ROWINFO and k > 1 and x2d.dtype == h16_dtype() and C % 32 == 0 and K % 4 == 0 and xpitch % 8 == 0 and ypitch % 8 == 0
@@ -1129,8 +1153,9 @@ def gn_part_buffer(P, K, device):
     return torch.empty(((P + 31) // 32, K // 8, 2), dtype=torch.float32, device=device)
 
 
-def groupnorm_relu_seg_fwd_p32(x2d, seg_rows, gamma, beta, part32, G, eps=1e-5, relu=True):
-    """groupnorm_relu_seg_fwd for bf16 x2d with 8 channels per group whose producer left the statistics partials in part32"""
+def groupnorm_relu_seg_fwd_p32(x2d, seg_rows, gamma, beta, part32, G, eps=1e-5, relu=True, relu_bits=None):
+    """groupnorm_relu_seg_fwd for bf16 x2d with 8 channels per group whose producer left the statistics partials in part32.
+    relu_bits (optional, uint8 [rows * C / 8], C % 32 == 0): also write the ReLU mask of y as a bit plane"""
     rows, C = x2d.shape
     assert sum(seg_rows) == rows and x2d.dtype == h16_dtype() and C == 8 * G
     y = torch.empty_like(x2d)
@@ -1138,8 +1163,13 @@ def groupnorm_relu_seg_fwd_p32(x2d, seg_rows, gamma, beta, part32, G, eps=1e-5, 
     mean = torch.empty((S, G), dtype=torch.float32, device=x2d.device)
     rstd = torch.empty((S, G), dtype=torch.float32, device=x2d.device)
     sr = _iarr(seg_rows)
-    call("utv2_groupnorm_relu_seg_fwd_p32", _p(x2d), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(part32), S, ctypes.cast(sr, c_p), C, G,
-         float(eps), int(relu), _stream())
+    if relu_bits is not None:
+        assert relu_bits.dtype == torch.uint8 and relu_bits.numel() * 8 == rows * C and C % 32 == 0
+        call("utv2_groupnorm_relu_seg_fwd_p32b", _p(x2d), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(part32), S, ctypes.cast(sr, c_p),
+             C, G, float(eps), int(relu), _p(relu_bits), _stream())
+    else:
+        call("utv2_groupnorm_relu_seg_fwd_p32", _p(x2d), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(part32), S, ctypes.cast(sr, c_p),
+             C, G, float(eps), int(relu), _stream())
     return y, mean, rstd
 
 
@@ -1281,6 +1311,24 @@ def groupnorm_relu_seg_bwd(dy, y, x2d, seg_rows, mean, rstd, gamma, dgamma, dbet
         part = torch.empty((load().utv2_groupnorm_seg_chunks(S, ctypes.cast(sr, c_p)), C), dtype=torch.float32, device=x2d.device)
     call("utv2_groupnorm_relu_seg_bwd_colsum", _p(dy), _p(y), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx), _p(dgamma), _p(dbeta),
          _p(ws), S, ctypes.cast(sr, c_p), C, G, int(relu), _same_dt(dy, y, x2d), _p(part), _stream())
+    return (dx, part) if want_colsum else dx
+
+
+def groupnorm_seg_bwd_p64(g, x2d, seg_rows, mean, rstd, gamma, dgamma, dbeta, G, part64, want_colsum=False):
+    """GroupNorm (+ ReLU) backward from the partial sums the producing dgrad left (conv2d_ml_fwd_bf16 gnb): g = the incoming gradient with
+    the ReLU mask applied.  -> dx, or (dx, colsum_part) as groupnorm_relu_seg_bwd"""
+    rows, C = x2d.shape
+    assert g.dtype == h16_dtype() and x2d.dtype == h16_dtype() and g.is_contiguous() and x2d.is_contiguous() and tuple(g.shape) == (rows, C)
+    assert tuple(part64.shape) == ((rows + 63) // 64, C, 2) and sum(seg_rows) == rows
+    S = len(seg_rows)
+    dx = torch.empty_like(x2d)
+    sr = _iarr(seg_rows)
+    ws = workspace(load().utv2_groupnorm_seg_workspace_floats(S, ctypes.cast(sr, c_p), C), x2d.device, "gn")
+    part = None
+    if want_colsum:
+        part = torch.empty((load().utv2_groupnorm_seg_chunks(S, ctypes.cast(sr, c_p)), C), dtype=torch.float32, device=x2d.device)
+    call("utv2_groupnorm_seg_bwd_p64", _p(g), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _p(ws), S,
+         ctypes.cast(sr, c_p), C, G, _p(part64), _p(part), _stream())
     return (dx, part) if want_colsum else dx
 
 

@@ -299,6 +299,8 @@ class FCOSHead:
                 be = store.new((2 * C,), "nodecay", lambda t: t.zero_())
                 be.export(gc + ".bias", lambda t: t[:C]).export(gb + ".bias", lambda t: t[C:])
                 layers.append(ops.pair_conv_gn(conv, ops.GroupNormReLU(ga, be, 64, 1e-5, True)))
+                if i > 0:
+                    ops.chain_gn_conv(layers[i - 1][1], conv)   # layer i - 1's GroupNorm output feeds this conv only
 
             def init_all(_t):
                 # the reference's module order (cls tower first, then the bbox tower): the random stream of the initialisation - and with
@@ -329,6 +331,8 @@ class FCOSHead:
                 ga = store.new((C,), "nodecay", lambda t: t.fill_(1.0)).export(pg + ".weight")
                 be = store.new((C,), "nodecay", lambda t: t.zero_()).export(pg + ".bias")
                 layers.append(ops.pair_conv_gn(conv, ops.GroupNormReLU(ga, be, 32, 1e-5, True)))
+                if i > 0:
+                    ops.chain_gn_conv(layers[i - 1][1], conv)
             self.towers[name] = layers
         nc = self.num_classes
         prior = fc.PRIOR_PROB

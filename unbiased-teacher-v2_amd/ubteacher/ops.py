@@ -373,6 +373,7 @@ class Conv:
         self.bias_by_gn = False     # set by pair_conv_gn(): the GroupNorm that consumes this conv's output produces its bias gradient
         self.gn_cpg = 0             # set by pair_conv_gn(): channels per group of that GroupNorm
         self._gn_part = None        # (data_ptr of the last output, its statistics partials): picked up by that GroupNorm
+        self.gnb_src = None         # set by chain_gn_conv(): the GroupNorm whose output is this conv's only input
         self.grad_premasked = False  # set by the model builder: every consumer of this conv's ReLU output has premask_input, i.e. applies
         #                              the mask (output > 0) in its own dgrad epilogue - no mask pass at the top of this conv's backward
         self._wt = None
@@ -506,6 +507,12 @@ class _ConvFn(torch.autograd.Function):
             GRAD_SYNC[0].on_forward(_sync_handles(layer, cs))
         ctx.save_for_backward(x, y if (layer.relu or cs is not None) else None)
         ctx.xshape = tuple(x.shape)
+        ctx.gnb = None      # (GroupNorm layer, its input, the ReLU bit plane of x): x is that GroupNorm's output (chain_gn_conv, gn_bwd_fuse_on)
+        src = layer.gnb_src
+        if src is not None and src._gnb_fwd is not None:
+            gf, src._gnb_fwd = src._gnb_fwd, None
+            if gf[0] == x.data_ptr() and x.is_contiguous() and tuple(gf[1].shape) == tuple(x.shape) and residual is None:
+                ctx.gnb = (src, gf[1], gf[2])
         ctx.fanin = out_holder[1] if len(out_holder) > 1 else None   # FanIn: another consumer's gradient of x, added in this dgrad's epilogue
         ctx.pair = out_holder[2] if len(out_holder) > 2 else None    # (ColPair, half): x is a column half of a paired tower's output
         return y
@@ -575,8 +582,17 @@ class _ConvFn(torch.autograd.Function):
                     # x a column half of a paired tower's output: the gradient is written straight into its half of ONE [P, 2C] buffer
                     # (row pitch 2C), which ColPair's backward hands on as the gradient of the whole matrix - no cat pass
                     dest = ctx.pair[0].grad_half(ctx.pair[1], x) if (ctx.pair is not None and other is None) else None
-                    dx = hip.conv2d_ml_fwd_bf16(gp, layer.wt16(wsc), meta.level_hw, meta.N, k=layer.k, pad=layer.k - 1 - layer.pad,
-                                                residual=other, out_dtype=x.dtype, out=dest, groups=G)
+                    wt = layer.wt16(wsc)
+                    if (ctx.gnb is not None and other is None and dest is None and x.dtype == hip.h16_dtype()
+                            and hip.gnb_eligible(gp, wt, layer.k, layer.k - 1 - layer.pad, G)):
+                        src, gx, bits = ctx.gnb
+                        part = hip.gnb_part_buffer(x.shape[0], x.shape[1], x.device)
+                        dx = hip.conv2d_ml_fwd_bf16(gp, wt, meta.level_hw, meta.N, k=layer.k, pad=layer.k - 1 - layer.pad, out_dtype=x.dtype,
+                                                    groups=G, gnb=(bits, gx, part))
+                        src._gnb_bwd = (dx.data_ptr(), part)
+                    else:
+                        dx = hip.conv2d_ml_fwd_bf16(gp, wt, meta.level_hw, meta.N, k=layer.k, pad=layer.k - 1 - layer.pad,
+                                                    residual=other, out_dtype=x.dtype, out=dest, groups=G)
                 elif G > 1:
                     dx = torch.cat([hip.conv2d_ml_dgrad(g[:, gi * Kg:(gi + 1) * Kg].contiguous(),
                                                         hip.weight_flip_transpose(layer.w.t[gi * Kg:(gi + 1) * Kg], Kg, layer.k, layer.k, layer.cin),
@@ -942,17 +958,35 @@ def pair_conv_gn(conv, gn):
     return conv, gn
 
 
+def gn_bwd_fuse_on():
+    """(UTV2_GN_BWD_FUSE=0 switches it off.)  Inside a conv -> GN -> ReLU -> conv chain (the FCOS towers) the SECOND conv's dgrad applies the ReLU
+    mask (a bit plane the GroupNorm's apply pass writes) and leaves GroupNorm backward's per-channel partial sums while its rows are in
+    registers (hip.conv2d_ml_fwd_bf16 gnb) - the backward's gn_bwd_partial pass (dy and x read again from HBM) disappears.  The sums
+    are the same quantities added in another order: gradients agree with the unfused path to fp32 rounding, not bit for bit."""
+    return os.environ.get("UTV2_GN_BWD_FUSE", "1") != "0"
+
+
+def chain_gn_conv(gn, conv):
+    """declare that `conv` (level-first, 3x3) consumes exactly the output of `gn` and nothing else does (tower layer i -> i + 1)"""
+    gn.next_conv = conv
+    conv.gnb_src = gn
+    return conv
+
+
 class GroupNormReLU:
     def __init__(self, gamma, beta, groups=32, eps=1e-5, relu=True):
         self.gamma, self.beta, self.groups, self.eps, self.relu = gamma, beta, groups, eps, relu
         self.bias_conv = None   # see pair_conv_gn
+        self.next_conv = None   # see chain_gn_conv
+        self._gnb_fwd = None    # (data_ptr of the last output, its input, its ReLU bit plane): picked up by next_conv's forward
+        self._gnb_bwd = None    # (data_ptr of the gradient next_conv's dgrad wrote, the partial sums it left): picked up by this layer's backward
 
     def __call__(self, x, meta=None):
         if torch.is_grad_enabled():
             return _GNFn.apply(x, hook(x.device), self, meta)
         return self._fwd(x, meta)[0]
 
-    def _fwd(self, x, meta):
+    def _fwd(self, x, meta, for_backward=False):
         if meta is None:  # one NHWC tensor: a segment per image
             N, H, W, C = x.shape
             y, mean, rstd = hip.groupnorm_relu_seg_fwd(x.view(-1, C), [H * W] * N, self.gamma.t, self.beta.t, self.groups, self.eps,
@@ -964,14 +998,24 @@ class GroupNormReLU:
         if gp is not None:
             conv._gn_part = None
             if gp[0] == x.data_ptr() and x.dtype == hip.h16_dtype():   # x is the output that conv just wrote: its epilogue left the statistics
-                return hip.groupnorm_relu_seg_fwd_p32(x, meta.seg_rows, self.gamma.t, self.beta.t, gp[1], self.groups, self.eps, self.relu)
+                bits = None
+                if (for_backward and self.next_conv is not None and self.relu and gn_bwd_fuse_on() and x.shape[1] % 32 == 0
+                        and x.is_contiguous()):
+                    bits = torch.empty((x.shape[0] * x.shape[1] // 8,), dtype=torch.uint8, device=x.device)
+                out = hip.groupnorm_relu_seg_fwd_p32(x, meta.seg_rows, self.gamma.t, self.beta.t, gp[1], self.groups, self.eps, self.relu,
+                                                     relu_bits=bits)
+                self._gnb_fwd = (out[0].data_ptr(), x, bits) if bits is not None else None
+                return out
         return hip.groupnorm_relu_seg_fwd(x, meta.seg_rows, self.gamma.t, self.beta.t, self.groups, self.eps, self.relu)
+
+
+GNB_STATS = {"fused": 0}     # GroupNorm backwards that ran from a dgrad epilogue's partial sums since import (tests)
 
 
 class _GNFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, hk, layer, meta):
-        y, mean, rstd = layer._fwd(x, meta)
+        y, mean, rstd = layer._fwd(x, meta, for_backward=ctx.needs_input_grad[0])
         ctx.layer = layer
         ctx.meta = meta
         if GRAD_SYNC[0] is not None:
@@ -991,8 +1035,15 @@ class _GNFn(torch.autograd.Function):
             dx = hip.groupnorm_relu_seg_bwd(dy.view(-1, C), y.view(-1, C), x.view(-1, C), [H * W] * N, mean, rstd, layer.gamma.t,
                                             layer.gamma.g, layer.beta.g, layer.groups, layer.relu, beta=layer.beta.t, want_colsum=cs)
         else:
-            dx = hip.groupnorm_relu_seg_bwd(dy, y, x, meta.seg_rows, mean, rstd, layer.gamma.t, layer.gamma.g, layer.beta.g,
-                                            layer.groups, layer.relu, beta=layer.beta.t, want_colsum=cs)
+            gb, layer._gnb_bwd = layer._gnb_bwd, None
+            if gb is not None and gb[0] == dy.data_ptr() and dy.dtype == hip.h16_dtype():
+                # dy came from next_conv's dgrad with the ReLU mask applied and the first reduction made (gn_bwd_fuse_on)
+                dx = hip.groupnorm_seg_bwd_p64(dy, x, meta.seg_rows, mean, rstd, layer.gamma.t, layer.gamma.g, layer.beta.g, layer.groups,
+                                               gb[1], want_colsum=cs)
+                GNB_STATS["fused"] += 1
+            else:
+                dx = hip.groupnorm_relu_seg_bwd(dy, y, x, meta.seg_rows, mean, rstd, layer.gamma.t, layer.gamma.g, layer.beta.g,
+                                                layer.groups, layer.relu, beta=layer.beta.t, want_colsum=cs)
         if cs:
             dx, part = dx
             # the few-hundred-row reduction of the per-chunk sums is nobody's dependency before the optimizer: weight-gradient stream
