@@ -174,6 +174,8 @@ class ConvTimer:
         t16 = "_Float16" if dtype == "f16" else "__bf16"    # element type of the kernel library's 16-bit build (csrc/common.h h16_t)
         big = "pp" if os.environ.get("UTV2_PP_RS", "1") == "0" else "rs"
         self.kernel = ("conv_igemm_bf16_%s<true,%s>+conv_igemm_bf16_v2<128,true,64,%s>" % (big, t16, t16)) if self.bf16 else "conv_igemm_f32<128,0,true>"
+        if self.bf16 and os.environ.get("UTV2_GN_BWD_FUSE", "1") != "0":
+            self.kernel += " (3 of the 4 tower dgrads per step: the same kernels' GroupNorm-backward instantiation - mask plane + partial sums in the epilogue)"
 
     def install(self):
         from ubteacher import hip
@@ -199,6 +201,8 @@ class ConvTimer:
             eb = 2 if timer.bf16 else 4
             # algorithmic HBM bytes: activations in and out (+ residual read) and the weights once
             bts = eb * P * C + eb * K * Kred + eb * P * K * (1 + (kw.get("residual") is not None))
+            if kw.get("gnb") is not None:   # the GroupNorm-backward form: + the GroupNorm input, the mask plane, the partial sums
+                bts += eb * P * K + P * K // 8 + 8 * K * -(-P // 64)
             timer.pairs.append((e0, e1, 2.0 * P * K * Kred, float(bts)))
             return y
 
