@@ -168,14 +168,14 @@ class ConvTimer:
 
     def __init__(self, dtype):
         self.pairs = []
+        self.pairs_gnb = []             # the tower dgrads in their GroupNorm-backward form (another instantiation, more epilogue work): timed apart
         self.enabled = False
         self.bf16 = dtype != "f32"      # a 16-bit MFMA mode (either type: the same kernels)
         self.entry = "conv2d_ml_fwd_bf16" if self.bf16 else "conv2d_ml_fwd"
         t16 = "_Float16" if dtype == "f16" else "__bf16"    # element type of the kernel library's 16-bit build (csrc/common.h h16_t)
         big = "pp" if os.environ.get("UTV2_PP_RS", "1") == "0" else "rs"
         self.kernel = ("conv_igemm_bf16_%s<true,%s>+conv_igemm_bf16_v2<128,true,64,%s>" % (big, t16, t16)) if self.bf16 else "conv_igemm_f32<128,0,true>"
-        if self.bf16 and os.environ.get("UTV2_GN_BWD_FUSE", "1") != "0":
-            self.kernel += " (3 of the 4 tower dgrads per step: the same kernels' GroupNorm-backward instantiation - mask plane + partial sums in the epilogue)"
+        self.kernel_gnb = "conv_igemm_bf16_rs<true,%s,true>+conv_igemm_bf16_v2<128,true,64,%s,false,true>" % (t16, t16)
 
     def install(self):
         from ubteacher import hip
@@ -203,18 +203,19 @@ class ConvTimer:
             bts = eb * P * C + eb * K * Kred + eb * P * K * (1 + (kw.get("residual") is not None))
             if kw.get("gnb") is not None:   # the GroupNorm-backward form: + the GroupNorm input, the mask plane, the partial sums
                 bts += eb * P * K + P * K // 8 + 8 * K * -(-P // 64)
-            timer.pairs.append((e0, e1, 2.0 * P * K * Kred, float(bts)))
+            (timer.pairs_gnb if kw.get("gnb") is not None else timer.pairs).append((e0, e1, 2.0 * P * K * Kred, float(bts)))
             return y
 
         setattr(hip, self.entry, wrapped)
 
-    def summary(self):
-        if not self.pairs:
+    def summary(self, gnb=False):
+        pairs = self.pairs_gnb if gnb else self.pairs
+        if not pairs:
             return None
-        ms = sum(p[0].elapsed_time(p[1]) for p in self.pairs)
-        fl = sum(p[2] for p in self.pairs)
-        by = sum(p[3] for p in self.pairs)
-        n = len(self.pairs)
+        ms = sum(p[0].elapsed_time(p[1]) for p in pairs)
+        fl = sum(p[2] for p in pairs)
+        by = sum(p[3] for p in pairs)
+        n = len(pairs)
         return dict(launches=n, total_ms=ms, avg_us=1e3 * ms / n, tflops=fl / ms / 1e9, alg_bytes=by / n,
                     alg_gbps=by / ms / 1e6)
 
@@ -698,7 +699,7 @@ def step_subrecord(kind, args, device_index, timer=None, steps=10, warmup=5, dty
             pseudo_cycle.append(counts())       # one entry per batch of the cycle (a device read each: warm-up only)
     torch.cuda.synchronize()
     if timer is not None:
-        timer.pairs = []
+        timer.pairs, timer.pairs_gnb = [], []
         timer.enabled = True
     from ubteacher.engine.step_gc import StepGC
     with StepGC() as step_gc:                    # the collector policy of the product's own train_loop (engine/step_gc.py)
@@ -1011,23 +1012,25 @@ def worker(args):
     amp_state = tr._amp_state.cpu().tolist() if getattr(tr, "_amp_state", None) is not None else None
     pseudo_count = pseudo_counts(tr)
     conv, wg = timer.summary(), wtimer.summary()
+    conv_gnb = timer.summary(gnb=True)
 
     # the same launches with the step's side streams off (teacher pass / weight gradients back on the main stream): the dominant kernels
     # alone on the GPU.  Not part of the timed region - reported beside the in-step figures as `exclusive`.
-    conv_x = wg_x = None
+    conv_x = wg_x = conv_gnb_x = None
     if rank == 0 and world == 1 and args.dtype != "f32" and not args.timed_only:
         saved = {k: os.environ.get(k) for k in ("UTV2_OVERLAP_TEACHER", "UTV2_WGRAD_STREAM")}
         os.environ["UTV2_OVERLAP_TEACHER"] = os.environ["UTV2_WGRAD_STREAM"] = "0"
         ot = getattr(tr, "overlap_teacher", None)
         if ot is not None:
             tr.overlap_teacher = False
-        timer.pairs, wtimer.pairs = [], []
+        timer.pairs, timer.pairs_gnb, wtimer.pairs = [], [], []
         timer.enabled = wtimer.enabled = True
         for _ in range(min(args.steps, 5)):
             tr.run_step_full_semisup(); tr.iter += 1
         torch.cuda.synchronize()
         timer.enabled = wtimer.enabled = False
         conv_x, wg_x = timer.summary(), wtimer.summary()
+        conv_gnb_x = timer.summary(gnb=True)
         if ot is not None:
             tr.overlap_teacher = ot
         for k, v in saved.items():
@@ -1276,7 +1279,8 @@ def worker(args):
             out["loss_scale_state"] = dict(zip(("scale", "found_inf", "clean_steps"), amp_state))
         if conv:
             out["roofline"] = {"bound": "mfma", "kernel": timer.kernel + (" (RPN head 3x3 conv over p2-p6, fwd+dgrad launches)" if rcnn else
-                                                                         " (FCOS tower 3x3 convs, all fwd+dgrad launches)"),
+                                                                         (" (FCOS tower 3x3 convs: the forward launches and the first layer's dgrad; the other three dgrads per step: `gn_backward_dgrads`)"
+                                                                          if conv_gnb else " (FCOS tower 3x3 convs, all fwd+dgrad launches)")),
                                "achieved": conv["tflops"], "peak": peak, "unit": "TFLOP/s",
                                "frac": conv["tflops"] / peak, "traffic": pmc_traffic(timer.kernel, args.model),
                                "algorithmic_bytes": conv["alg_bytes"], "algorithmic_GBps": conv["alg_gbps"],
@@ -1301,6 +1305,21 @@ def worker(args):
                                                 "launches": conv_x["launches"],
                                                 "note": "same launches, side streams off (UTV2_OVERLAP_TEACHER=0 UTV2_WGRAD_STREAM=0), outside the timed region: "
                                                         "in the timed region the teacher pass / weight gradients share the CUs with this kernel"}
+        if conv and conv_gnb:
+            # 3 of the 4 tower dgrads per step run the kernels' GroupNorm-backward instantiation: the same MFMA work + the
+            # ReLU mask plane, a second operand row and per-channel partial sums in the epilogue - another symbol in the kernel trace,
+            # so it is reported apart from `roofline` (whose launches are the forward convs and the first layer's dgrad)
+            out["roofline"]["gn_backward_dgrads"] = {
+                "kernel": timer.kernel_gnb, "achieved": conv_gnb["tflops"], "frac": conv_gnb["tflops"] / peak, "launches": conv_gnb["launches"],
+                "avg_us": conv_gnb["avg_us"], "algorithmic_bytes": conv_gnb["alg_bytes"], "time_share": conv_gnb["total_ms"] / (1e3 * dt),
+                "all_tower_launches": {"achieved": (conv["tflops"] * conv["total_ms"] + conv_gnb["tflops"] * conv_gnb["total_ms"]) / (conv["total_ms"] + conv_gnb["total_ms"]),
+                                       "frac": (conv["tflops"] * conv["total_ms"] + conv_gnb["tflops"] * conv_gnb["total_ms"]) / (conv["total_ms"] + conv_gnb["total_ms"]) / peak,
+                                       "launches": conv["launches"] + conv_gnb["launches"]},
+                "note": "the epilogue work replaces gn_bwd_partial (one pass over the gradient and the GroupNorm input per layer); UTV2_GN_BWD_FUSE=0 "
+                        "puts these launches back on the plain kernel"}
+            if conv_gnb_x:
+                out["roofline"]["gn_backward_dgrads"]["exclusive"] = {"achieved": conv_gnb_x["tflops"], "frac": conv_gnb_x["tflops"] / peak,
+                                                                      "avg_us": conv_gnb_x["avg_us"], "launches": conv_gnb_x["launches"]}
         if wg:
             out["roofline_wgrad"] = {"bound": "mfma", "kernel": wtimer.kernel, "achieved": wg["tflops"], "peak": peak, "unit": "TFLOP/s",
                                      "frac": wg["tflops"] / peak, "traffic": pmc_traffic("conv_wgrad_bf16_w8", args.model),

@@ -10,8 +10,11 @@ import sys
 
 # DF16b = __bf16 (libutv2_hip.so), DF16_ = _Float16 (libutv2_hip_f16.so: the same kernels on the fp16 build)
 # (round 5: the multi-level 3x3 launches run on the row-span form conv_igemm_bf16_rs; earlier traces / UTV2_PP_RS=0: conv_igemm_bf16_pp)
-TOWERS = [("_Z18conv_igemm_bf16_%sILb1EDF16%sEv10ConvArgs16" % (k, t), "_Z18conv_igemm_bf16_v2ILi128ELb1ELi64EDF16%sEv10ConvArgs16" % t)
-          for k in ("rs", "pp") for t in ("_", "b")]
+# (round 6: the row-span kernel has a third template argument - Lb0E: the plain instantiation, Lb1E: the GroupNorm-backward dgrad form)
+TOWERS = ([("_Z18conv_igemm_bf16_rsILb1EDF16%sLb0EEv10ConvArgs16" % t, "") for t in ("_", "b")] +
+          [("_Z18conv_igemm_bf16_%sILb1EDF16%sEv10ConvArgs16" % (k, t), "_Z18conv_igemm_bf16_v2ILi128ELb1ELi64EDF16%sEv10ConvArgs16" % t)
+           for k in ("rs", "pp") for t in ("_", "b")])
+TOWERS_GNB = ["_Z18conv_igemm_bf16_rsILb1EDF16%sLb1EEv10ConvArgs16" % t for t in ("_", "b")]
 WGRADS = ["_Z18conv_wgrad_bf16_pp11Wgrad16Args", "_Z18conv_wgrad_bf16_w811Wgrad16Args"]   # round 5: the ping-pong schedule; before / UTV2_WGRAD_PP=0: lock-step
 
 
@@ -48,6 +51,13 @@ if TOWER[0] in fetch:
         "fetch_size_kib_per_launch": round(fk, 2), "write_size_kib_per_launch": round(wk, 2),
         "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0, "launches_in_pmc_run": n,
         "covers": "the 256-tile kernel only (conv_igemm_bf16_rs<true> / _pp<true>: the whole rounds of 256x256 tiles of each launch)"}
+for g in TOWERS_GNB:
+    if g in fetch and g in write:
+        n = fetch[g][0]
+        res["tower_conv_gnb"] = {
+            "kernel": g, "fetch_size_kib_per_launch": round(fetch[g][1] / n, 2), "write_size_kib_per_launch": round(write[g][1] / n, 2),
+            "hbm_bytes_per_launch": (2.0 * fetch[g][1] / n + write[g][1] / n) * 1024.0, "launches_in_pmc_run": n,
+            "covers": "the tower dgrads that also apply the ReLU mask plane and leave GroupNorm backward's partial sums (DESIGN 10.7): + the GroupNorm input read"}
 kernels = {}
 for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch.get(k, (1, 0))[1] + write.get(k, (1, 0))[1])):
     nf, f = fetch.get(k, (0, 0.0))
