@@ -119,3 +119,27 @@ def test_unknown_amp_type_is_refused(monkeypatch):
                 ENABLED = True
     with pytest.raises(ValueError):
         T._TrainerBase._common_init(type("S", (T._TrainerBase,), {"__init__": lambda self: None})(), Cfg)
+
+
+@pytest.mark.parametrize("paired", ["1", "0"])
+def test_tower_layers_are_chained_for_the_fused_groupnorm_backward(paired, monkeypatch):
+    """ops.chain_gn_conv: inside a tower, layer i's GroupNorm output feeds layer i + 1's conv and nothing else - the link the
+    fused GroupNorm backward rides on.  The LAST GroupNorm of a tower has no link (its gradient comes from the prediction convs' dgrads),
+    the first conv has no source (it reads the FPN features); the switch defaults to on and UTV2_GN_BWD_FUSE=0 turns it off."""
+    from ubteacher import ops
+    from ubteacher.modeling import build_model
+    from ubteacher.presets import get_config
+    monkeypatch.setenv("UTV2_PAIR_TOWERS", paired)
+    m = build_model(get_config("fcos", 1, ["MODEL.DEVICE", "cpu"]))
+    head = m.proposal_generator.fcos_head
+    towers = [head.towers["pair"]] if paired == "1" else [head.towers["cls"], head.towers["bbox"]]
+    assert all(len(t) == 4 for t in towers)
+    for layers in towers:
+        assert layers[0][0].gnb_src is None and layers[-1][1].next_conv is None
+        for i in range(1, len(layers)):
+            assert layers[i][0].gnb_src is layers[i - 1][1] and layers[i - 1][1].next_conv is layers[i][0]
+    assert head.cls_logits.gnb_src is None and head.box_head.gnb_src is None
+    monkeypatch.delenv("UTV2_GN_BWD_FUSE", raising=False)
+    assert ops.gn_bwd_fuse_on()
+    monkeypatch.setenv("UTV2_GN_BWD_FUSE", "0")
+    assert not ops.gn_bwd_fuse_on()
