@@ -167,3 +167,45 @@ def test_trainer_test_runs_on_a_registered_coco_dataset(tiny, kind):
     res = T.test(cfg, tr.model_teacher, evaluators=ev)
     assert set(res["bbox"]) == {"AP", "AP50", "AP75", "APs", "APm", "APl"} and res["_speed"]["images"] >= 1
     assert len(seen) == 5 and all(a == b for a, b in seen.values())      # detections live in the ORIGINAL image frame
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["fcos", "rcnn"])
+def test_training_loop_evaluates_student_and_teacher_and_writes_metrics(tiny, kind, tmp_path):
+    """the loop's evaluation hooks and writers (reference engine/trainer.py:503-552) on the real trainers: TEST.EVAL_PERIOD 2 over 4
+    post-burn-in iterations with a registered COCO-format test set - student results under `bbox_student/*`, the teacher's under `bbox/*`
+    in OUTPUT_DIR/metrics.json next to the losses; the step after an evaluation runs (the Faster-RCNN teacher must come back in TRAINING
+    mode: its branch calls are training-mode forwards, rcnn.py:60-61; the FCOS teacher in eval mode, trainer.py:55)."""
+    import json
+    from tests.utv2_testutil import small_fcos_cfg
+    from ubteacher.data.synthetic import SyntheticTwoCropLoader
+    from ubteacher.engine import UBRCNNTeacherTrainer, UBTeacherTrainer
+    from ubteacher.presets import get_config
+    if kind == "fcos":
+        cfg, T = small_fcos_cfg(), UBTeacherTrainer
+    else:
+        cfg = get_config("rcnn", 1, ["SOLVER.IMG_PER_BATCH_LABEL", 2, "SOLVER.IMG_PER_BATCH_UNLABEL", 2, "MODEL.DEVICE", "cuda"])
+        T = UBRCNNTeacherTrainer
+    cfg.SEMISUPNET.BURN_UP_STEP = 1
+    cfg.DATASETS.TEST = (tiny[0],)
+    cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = 96, 160
+    cfg.TEST.EVAL_PERIOD = 2
+    cfg.SOLVER.BASE_LR = 1e-6
+    cfg.SOLVER.CHECKPOINT_PERIOD = 0
+    cfg.OUTPUT_DIR = str(tmp_path)
+    torch.manual_seed(0)
+    tr = T(cfg, data_loader=SyntheticTwoCropLoader(cfg, height=96, width=128))
+    tr.log_period = 2
+    tr.checkpointer.save = lambda *a, **k: None        # (a 400 MB file per save is not what this test is about)
+    teacher_mode = tr.model_teacher.training
+    tr.train_loop(0, 4)
+    assert tr.model.training and tr.model_teacher.training == teacher_mode and teacher_mode == (kind == "rcnn")
+    lines = [json.loads(l) for l in (tmp_path / "metrics.json").read_text().splitlines()]
+    by_it = {l["iteration"]: l for l in lines}
+    assert sorted(by_it) == [1, 3]
+    for it in (1, 3):
+        rec = by_it[it]
+        assert {"bbox/AP", "bbox/AP50", "bbox_student/AP", "bbox_student/APl", "total_loss", "lr", "time", "data_time"} <= set(rec), sorted(rec)
+        assert all(v == v for v in rec.values())
+    assert any(k.endswith("_pseudo") for k in by_it[3])            # the semi-supervised branch ran after the first evaluation
+    assert set(tr._last_eval_results_teacher["bbox"]) == {"AP", "AP50", "AP75", "APs", "APm", "APl"}

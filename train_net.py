@@ -23,7 +23,30 @@ def setup(args):
     if cfg.MODEL.DEVICE == "cuda":  # one process per GPU: this rank's device
         cfg.MODEL.DEVICE = "cuda:%d" % dist_info().get("device", 0)
     cfg.freeze()
+    setup_logger(cfg.OUTPUT_DIR, dist_info().get("rank", 0))
     return cfg
+
+
+def setup_logger(output_dir, rank):
+    """what the reference gets from Detectron2's default_setup (train_net.py:31): INFO lines of the main process on stdout and in
+    OUTPUT_DIR/log.txt (other ranks: OUTPUT_DIR/log.txt.rank<N>, warnings only on their consoles)"""
+    import logging
+    root = logging.getLogger()
+    if getattr(root, "_utv2_configured", False):
+        return
+    root._utv2_configured = True
+    root.setLevel(logging.INFO)
+    fmt = logging.Formatter("[%(asctime)s %(name)s]: %(message)s", datefmt="%m/%d %H:%M:%S")
+    ch = logging.StreamHandler(sys.stdout)
+    ch.setLevel(logging.INFO if rank == 0 else logging.WARNING)
+    ch.setFormatter(fmt)
+    root.addHandler(ch)
+    if output_dir:
+        os.makedirs(output_dir, exist_ok=True)
+        fh = logging.FileHandler(os.path.join(output_dir, "log.txt" if rank == 0 else "log.txt.rank%d" % rank))
+        fh.setLevel(logging.INFO)
+        fh.setFormatter(fmt)
+        root.addHandler(fh)
 
 
 def main(args):

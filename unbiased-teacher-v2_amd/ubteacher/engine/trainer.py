@@ -377,28 +377,86 @@ class _TrainerBase:
     def train(self):
         self.train_loop(self.start_iter, self.max_iter)
 
+    def build_writers(self):
+        """reference DefaultTrainer.build_writers (what `PeriodicWriter(self.build_writers(), period=20)`, engine/trainer.py:549-551, drives):
+        the console line and OUTPUT_DIR/metrics.json.  The step keeps its metrics on the device and reads them out every `log_period`
+        iterations (one host sync per 20 steps instead of ~30 per step), so a written value is the SAMPLED step's, not a 20-step median."""
+        from ..d2.events import CommonMetricPrinter, JSONWriter
+        ws = [CommonMetricPrinter(self.max_iter, window_size=1)]
+        if self.cfg.OUTPUT_DIR:
+            ws.append(JSONWriter(os.path.join(self.cfg.OUTPUT_DIR, "metrics.json"), window_size=1))
+        return ws
+
+    def _evaluate_student_and_teacher(self):
+        """the two EvalHooks of reference engine/trainer.py:533-546: the student's results under `<key>_student`, then the teacher's under
+        their own keys; every rank takes part (the evaluator gathers), the scalars go to the storage flattened `a/b` like EvalHook does"""
+        def flatten(d, prefix=""):
+            out = {}
+            for k, v in d.items():
+                if isinstance(v, dict):
+                    out.update(flatten(v, prefix + str(k) + "/"))
+                else:
+                    out[prefix + str(k)] = v
+            return out
+        # (inference_on_dataset restores each model's mode: the FCOS teacher lives in eval mode, the Faster-RCNN teacher in training mode -
+        # its branch calls are training-mode forwards, reference rcnn.py:60-61)
+        self._last_eval_results_student = self.test(self.cfg, self.model)
+        student = {k + "_student": v for k, v in (self._last_eval_results_student or {}).items()}
+        self._last_eval_results_teacher = self.test(self.cfg, self.model_teacher)
+        for res in (student, self._last_eval_results_teacher or {}):
+            res = {k: v for k, v in res.items() if not str(k).startswith("_")}       # "_speed": this package's timing record, not a metric
+            flat = {k: float(v) for k, v in flatten(res).items() if isinstance(v, (int, float)) and v == v}
+            if flat and comm.is_main_process() and self.storage is not None:
+                self.storage.put_scalars(smoothing_hint=False, **flat)
+        comm.synchronize()
+
     def train_loop(self, start_iter, max_iter):
         logger = logging.getLogger(__name__)
         logger.info("Starting training from iteration {}".format(start_iter))
         self.iter = self.start_iter = start_iter
         self.max_iter = max_iter
+        writers = self.build_writers() if comm.is_main_process() else []
+        eval_period = int(self.cfg.TEST.EVAL_PERIOD)
+        t_mark, t_acc, it_mark = time.perf_counter(), 0.0, start_iter
         with EventStorage(start_iter) as self.storage, StepGC() as step_gc:
             try:
                 for self.iter in range(start_iter, max_iter):
                     self.run_step_full_semisup()
+                    lr = float(self.optimizer.param_groups[0]["lr"])     # the rate this step ran at (hooks.LRScheduler logs it before stepping)
                     self.scheduler.step()
-                    self.storage.step()
                     step_gc.tick()
                     period = self.cfg.SOLVER.CHECKPOINT_PERIOD
                     if comm.is_main_process() and period > 0 and (self.iter + 1) % period == 0:
                         self.checkpointer.save("model_{:07d}".format(self.iter), iteration=self.iter)
                     if comm.is_main_process() and self.iter + 1 >= max_iter and self.cfg.OUTPUT_DIR:
                         self.checkpointer.save("model_final", iteration=self.iter)   # D2 PeriodicCheckpointer [D2-recall]
+                    last = self.iter + 1 >= max_iter
+                    log_due = (self.iter + 1) % self.log_period == 0 or last
+                    if log_due:
+                        if last:
+                            self.flush_metrics()
+                        # the metrics have just been read out (a device sync): wall time per iteration since the last read-out
+                        now = time.perf_counter()
+                        if self.iter + 1 > it_mark and comm.is_main_process():
+                            self.storage.put_scalar("time", (t_acc + now - t_mark) / (self.iter + 1 - it_mark), smoothing_hint=False)
+                        t_mark, t_acc, it_mark = now, 0.0, self.iter + 1
+                    # hooks.EvalHook: every TEST.EVAL_PERIOD iterations, and once after the last one
+                    if eval_period > 0 and ((self.iter + 1) % eval_period == 0 or last):
+                        t_acc += time.perf_counter() - t_mark
+                        self._evaluate_student_and_teacher()
+                        t_mark = time.perf_counter()      # evaluation time is not iteration time
+                    if writers and log_due:
+                        self.storage.put_scalar("lr", lr, smoothing_hint=False)
+                        for w in writers:
+                            w.write(self.storage)
+                    self.storage.step()
             except Exception:
                 logger.exception("Exception during training:")
                 raise
             finally:
                 self.flush_metrics()
+                for w in writers:
+                    w.close()
 
     # -- one step as a hipGraph (round 4) ----------------------------------------------------------------
     def run_step_graph(self):
