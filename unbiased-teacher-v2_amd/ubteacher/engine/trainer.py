@@ -644,6 +644,16 @@ class _TrainerBase:
             loader = cls.build_test_loader(cfg, name)
             evaluator = evaluators[idx] if evaluators is not None else cls.build_evaluator(cfg, name)
             results[name] = inference_on_dataset(model, loader, evaluator, cfg)
+            if comm.is_main_process():
+                # reference engine/trainer.py:596-603: the results of each set in Detectron2's print_csv_format shape [D2-recall]
+                logger = logging.getLogger(__name__)
+                logger.info("Evaluation results for {} in csv format:".format(name))
+                for task, res in results[name].items():
+                    if isinstance(res, dict) and not str(task).startswith("_"):
+                        keys = [k for k in res if "-" not in k]
+                        logger.info("copypaste: Task: {}".format(task))
+                        logger.info("copypaste: " + ",".join(keys))
+                        logger.info("copypaste: " + ",".join("{0:.4f}".format(float(res[k])) for k in keys))
         if len(results) == 1:
             results = list(results.values())[0]
         return results
