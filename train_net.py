@@ -24,7 +24,23 @@ def setup(args):
         cfg.MODEL.DEVICE = "cuda:%d" % dist_info().get("device", 0)
     cfg.freeze()
     setup_logger(cfg.OUTPUT_DIR, dist_info().get("rank", 0))
+    seed_all_rng(None if cfg.SEED < 0 else cfg.SEED + dist_info().get("rank", 0))
     return cfg
+
+
+def seed_all_rng(seed=None):
+    """Detectron2's default_setup seeds Python / NumPy / torch with cfg.SEED + rank (a fresh seed per process, logged, when SEED < 0) [D2-recall]"""
+    import logging
+    import random
+
+    import numpy as np
+    import torch
+    if seed is None:
+        seed = (os.getpid() + int.from_bytes(os.urandom(3), "big")) % (2 ** 31)
+        logging.getLogger(__name__).info("Using a generated random seed {}".format(seed))
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    random.seed(seed)
 
 
 def setup_logger(output_dir, rank):
