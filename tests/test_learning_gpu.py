@@ -28,7 +28,7 @@ def test_fcos_student_learns_to_detect_on_held_out_files(tmp_path, monkeypatch):
     from ubteacher.engine import UBTeacherTrainer
     from ubteacher.presets import get_config
     root = str(tmp_path / "ds")
-    monkeypatch.setattr(sys, "argv", ["make_tiny_coco.py", root, "64", "16"])
+    monkeypatch.setattr(sys, "argv", ["make_tiny_coco.py", root, "64", "16", "colour"])
     make_tiny_coco.main()
     weights = str(tmp_path / "backbone.pth")
     monkeypatch.setattr(sys, "argv", ["make_synthetic_backbone.py", "fcos", weights, "0"])

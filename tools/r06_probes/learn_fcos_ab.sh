@@ -1,7 +1,7 @@
 #!/bin/bash
 # FCOS on the tiny learnable dataset: where does the post-burn-in divergence come from?  (same run, one thing changed each time)
 mkdir -p gpurun_out; rm -f gpurun_out/learn_fcos_ab.txt
-python tools/make_tiny_coco.py /tmp/tiny_ds64 64 16 > /dev/null
+python tools/make_tiny_coco.py /tmp/tiny_ds64 64 16 colour > /dev/null
 python tools/make_synthetic_backbone.py fcos /tmp/synth_fcos.pth > /dev/null
 run() {
   local tag=$1; shift

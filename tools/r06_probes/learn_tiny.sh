@@ -2,7 +2,7 @@
 # does the whole thing LEARN?  64 train / 16 val images of coloured patches on noise (tools/make_tiny_coco.py), 50 % labeled, the launcher,
 # the recipe's learning rate, 1500 iterations (burn-in 500), box AP of student and teacher on the val files every 500 iterations
 mkdir -p gpurun_out; rm -f gpurun_out/learn_tiny.txt
-python tools/make_tiny_coco.py /tmp/tiny_ds64 64 16 > /dev/null
+python tools/make_tiny_coco.py /tmp/tiny_ds64 64 16 colour > /dev/null
 for kind in ${1:-fcos frcnn}; do
   python tools/make_synthetic_backbone.py $( [ $kind = frcnn ] && echo rcnn || echo fcos ) /tmp/synth_$kind.pth > /dev/null
   O=/tmp/learn_$kind; rm -rf $O
