@@ -25,3 +25,13 @@ def pytest_configure(config):
             torch.set_num_threads(cap)
     except Exception:  # noqa: BLE001
         pass
+
+
+@pytest.fixture(autouse=True)
+def _restore_precision_selection():
+    """A trainer selects the arithmetic mode (and with it the 16-bit kernel library) process-wide when it is built (ops.set_precision in
+    _common_init): a test that builds an AMP trainer must not decide which library the next test's raw kernel calls go to."""
+    yield
+    ops = sys.modules.get("ubteacher.ops")
+    if ops is not None and ops.PRECISION[0] != "fp32":
+        ops.set_precision("fp32")
