@@ -610,3 +610,37 @@ def test_fused_roi_inference_equals_the_aten_chain(monkeypatch):
     for k in ("boxes", "scores", "classes", "pred_boxes_std"):
         assert torch.equal(got[k][m], ref[k][m]), k
     assert torch.equal(rows[m], rows_ref[m])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_box_losses_ignore_what_the_reference_never_indexes(mode):
+    """box_reg_loss / box_reg_pseudo_loss (fast_rcnn.py:938-1090) index the FOREGROUND rows before any arithmetic: whatever a background or
+    empty row holds - a std logit of -200 (sigmoid = 0: nll = inf - inf), an infinite delta of a diverged model - never reaches the
+    sum.  The kernel walks every row: the loss value and the gradients with such rows must equal those with benign ones (found by a
+    launcher run from random weights: metric NaN, gradients fine)."""
+    from ubteacher import hip
+    g = torch.Generator().manual_seed(0)
+    R, K = 96, 80
+    cls = torch.randint(0, K + 1, (R,), generator=g)
+    cls[::7] = -1                                   # empty slots
+    cls[:8] = torch.arange(8)                       # some foreground for sure
+    prop = torch.rand(R, 4, generator=g) * 50
+    prop[:, 2:] += prop[:, :2] + 8
+    gtb = prop + torch.randn(R, 4, generator=g) * 2
+    pred = torch.randn(R, 8, generator=g) * 0.3
+    gstd = torch.randn(R, 4, generator=g)
+    fg = (cls >= 0) & (cls < K)
+    bad = pred.clone()
+    bad[~fg, 4:] = -200.0
+    bad[~fg, 0] = float("inf")
+    bad[~fg, 1] = float("-inf")
+    outs = []
+    for p in (pred, bad):
+        pc = p.cuda()
+        outs.append(hip.roi_box_loss(pc[:, :4], pc[:, 4:], cls.cuda(), prop.cuda(), gtb.cuda(), gstd.cuda() if mode == 2 else None, K, mode,
+                                     10.0, 5.0, 4.135, 0.1, 0.5))
+    (s0, gd0, gs0), (s1, gd1, gs1) = outs
+    assert torch.isfinite(s0).all() and float(s0) > 0
+    assert torch.equal(s0, s1) and torch.equal(gd0, gd1) and torch.equal(gs0, gs1)
+    assert float(gd1[~fg.cuda()].abs().max()) == 0 and float(gs1[~fg.cuda()].abs().max()) == 0

@@ -30,5 +30,9 @@ def ap(tag):
     rs = T.test(cfg, tr.model)["bbox"]; rt = T.test(cfg, tr.model_teacher)["bbox"]
     print(tag, "student AP %.1f AP50 %.1f | teacher AP %.1f AP50 %.1f" % (rs["AP"], rs["AP50"], rt["AP"], rt["AP50"]))
 tr.train_loop(0, 300); diff("after 300 burn-in iterations:"); ap("after 300:")
-tr.train_loop(300, 301); diff("after the boundary step:"); ap("after 301:")
-tr.train_loop(301, 340); diff("after 340:"); ap("after 340:")
+amp = lambda: [round(v, 1) for v in tr._amp_state.cpu().tolist()] if getattr(tr, "_amp_state", None) is not None else None
+print("loss-scale state {scale, found_inf, clean steps} before the boundary:", amp())
+tr.train_loop(300, 301); diff("after the boundary step:"); ap("after 301:"); print("loss-scale state after the boundary step:", amp())
+for a, b in ((301, 302), (302, 303), (303, 310), (310, 340)):
+    tr.train_loop(a, b); print("loss-scale state after iteration %d:" % (b - 1), amp())
+diff("after 340:"); ap("after 340:")

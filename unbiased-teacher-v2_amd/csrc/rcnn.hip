@@ -758,8 +758,10 @@ __global__ __launch_bounds__(256) void rpn_loss_fwd_kernel(RpnLossArgs p, float*
     float w = valid ? 1.f : 0.f;
     if (p.gt_scores) w = w * (hg ? p.gt_scores[(size_t)n * p.G + g] : 0.f);
     const float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
-    cls += bce * w;
-    gobj[slot] = (1.f / (1.f + expf(-x)) - t) * w;
+    // (selects, not products: a slot that carries no weight - an empty sampling slot, an image without boxes - contributes nothing even
+    // when the logit its index happens to name is not finite; the reference never indexes it)
+    if (w != 0.f) cls += bce * w;
+    gobj[slot] = w != 0.f ? (1.f / (1.f + expf(-x)) - t) * w : 0.f;
     if (pos) {
       const bool pv = valid && hg;
       float4 a = make_float4(0.f, 0.f, 1.f, 1.f), b = a;
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(256) void rpn_loss_fwd_kernel(RpnLossArgs p, float*
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float d = p.deltas[od + c] - tgt[c];
-        loc += fabsf(d) * m;
+        if (pv) loc += fabsf(d);
         gdl[((size_t)n * p.npos + j) * 4 + c] = (d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f) * m;
       }
     }
@@ -989,14 +991,14 @@ __global__ __launch_bounds__(256) void roi_box_loss_kernel(const float* __restri
         const float ct = 1.f - sigmoidf_(gstd ? gstd[(size_t)r * 4 + k] : 0.f), cs = 1.f - sigmoidf_(sl[k]);
         const float m = (ct > cs + ts_better && ct > t_cert && fg) ? 1.f : 0.f;
         const float df = d[k] - t[k];
-        acc += fabsf(df) * m;
+        if (m != 0.f) acc += fabsf(df);     // (selected rows only: a non-finite delta on an unselected row must not reach the sum as inf * 0)
         g_d[k] = (df > 0.f ? 1.f : df < 0.f ? -1.f : 0.f) * m;
       }
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float df = d[k] - t[k];
-        acc += fabsf(df) * fgf;
+        if (fg) acc += fabsf(df);
         g_d[k] = (df > 0.f ? 1.f : df < 0.f ? -1.f : 0.f) * fgf;
       }
       if (mode == 0) {
@@ -1025,7 +1027,9 @@ __global__ __launch_bounds__(256) void roi_box_loss_kernel(const float* __restri
           nll += df * df / (2.f * sq[k]) + 0.5f * logf(sq[k]);
         }
         nll += 2.f * 1.8378770664093453f;  // 2 log(2 pi)
-        acc += 0.05f * (nll * iou * fgf);
+        // (foreground rows only, as the reference indexes them: on a background row a std logit below -88 makes nll = inf - inf, and
+        // NaN * 0 would put a NaN into the loss VALUE - the gradients below were always guarded)
+        if (fg) acc += 0.05f * (nll * iou);
         if (fg) {
           // torch.max / torch.min send the gradient to the selected operand (half on a tie), clamp(min=0) passes it where its input >= 0
           const float cx = (rbx - ltx) >= 0.f ? 1.f : 0.f, cy = (rby - lty) >= 0.f ? 1.f : 0.f;
